@@ -1,0 +1,121 @@
+/*
+ * np2.h — C ABI of the MI355X-native NextPolish2 consensus hot path.
+ *
+ * The reference (Nextomics/NextPolish2 v0.2.2) has no FFI: the hot path is the block
+ * src/main.rs:1819-1836 (graph build -> best-path DP -> LQ candidates -> yak k-mer
+ * scoring -> phasing vote -> splice), run per contig inside the worker closure
+ * src/main.rs:1726-1837.  This header is the boundary a maintainer would bind from
+ * Rust (`extern "C"`): the cut is *after* AlignSeq construction
+ * (src/main.rs:1805-1817) and *before* output (src/main.rs:1837).
+ *
+ * All entry points return 0 on success and a negative NP2_E_* code otherwise; nothing
+ * panics or aborts across the ABI (the reference aborts: Cargo.toml:26-27 panic='abort').
+ * np2_last_error() returns a human-readable message for the last failure on a context.
+ */
+#ifndef NP2_H
+#define NP2_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NP2_OK 0
+#define NP2_E_ARG -1      /* bad argument / inconsistent packed read */
+#define NP2_E_DEVICE -2   /* HIP runtime failure */
+#define NP2_E_NOMEM -3
+#define NP2_E_UNSUPPORTED -4 /* e.g. k >= 32, pre != 10 */
+#define NP2_E_REFPANIC -5 /* input on which the reference itself would panic */
+
+/* One packed alignment == the reference's AlignSeq (src/main.rs:272-338).
+ * Nibble stream: 1 nibble per alignment column, high nibble first; low 3 bits = base
+ * code (A0 C1 G2 T3 '-'4 N5 M6, src/utils/kmer.rs:11-22), bit 3 = insertion column
+ * (target '-'); terminator nibble 0xF (src/main.rs:306-310).
+ * reads[0] must be the contig aligned to itself ("order 0", src/main.rs:1732-1739). */
+typedef struct np2_read {
+    uint32_t aln_t_s;  /* first reference position (src/main.rs:273) */
+    uint32_t aln_t_e;  /* INCLUSIVE last reference position (src/main.rs:274,295-297) */
+    uint64_t nib_off;  /* byte offset of this read's nibble stream; must be a multiple of 16 */
+    uint32_t n_cols;   /* number of alignment columns before the 0xF terminator */
+    uint32_t flags;    /* bit0: dropped (align_bases == [], src/main.rs:571): index retained */
+} np2_read_t;
+#define NP2_READ_DROPPED 1u
+
+/* One yak v2 table, file words verbatim (src/utils/kmer.rs:72-170):
+ * bucket b in [0, 1<<pre) holds words[bucket_off[b] .. bucket_off[b+1]);
+ * word = (hash >> 10) << 10 | count, hash & ((1<<pre)-1) == b.  Only pre == 10 is
+ * meaningful to the reference's lookup (kmer.rs:52-54,123-125). */
+typedef struct np2_yak {
+    uint32_t k;
+    uint32_t pre;
+    uint64_t n_words;
+    const uint64_t *words;
+    const uint64_t *bucket_off; /* (1<<pre)+1 entries */
+} np2_yak_t;
+
+/* Options that reach the hot path (src/utils/option.rs:267-292). */
+typedef struct np2_opts {
+    uint16_t min_kmer_count; /* -k, default 5; words with count < this are ignored (kmer.rs:160) */
+    int32_t max_indel_len;   /* -n, default 20 (main.rs:903) */
+    uint32_t iter_count;     /* -i, default 2 (main.rs:1819-1836); must be >= 1 */
+    uint8_t model_ref;       /* -m ref (1, default) | len (0) (main.rs:1547) */
+    uint8_t use_all_reads;   /* -r (main.rs:948-1010) */
+} np2_opts_t;
+
+typedef struct np2_ctx np2_ctx_t;
+typedef struct np2_contig np2_contig_t;
+
+/* Create a context on HIP device `device`; builds the HBM-resident open-addressed k-mer
+ * tables from `yaks` (ascending k, option.rs:238).  Replaces KmerInfo::new +
+ * retrieve_kmers file re-streaming (kmer.rs:72-170). */
+int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak);
+void np2_ctx_destroy(np2_ctx_t *ctx);
+const char *np2_last_error(np2_ctx_t *ctx);
+/* The HIP stream every kernel of this context is launched on (hipStream_t as void*). */
+void *np2_ctx_stream(np2_ctx_t *ctx);
+
+/* Upload one contig's packed pileup into HBM (borrowed host buffers, copied).
+ * Replaces the in-memory Vec<AlignSeq> + tseq (main.rs:1732-1817). */
+int np2_contig_upload(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads,
+                      uint32_t n_reads, const uint8_t *nibbles, uint64_t nib_bytes,
+                      np2_contig_t **out);
+void np2_contig_free(np2_ctx_t *ctx, np2_contig_t *c);
+
+/* The hot path on an HBM-resident contig: the loop main.rs:1819-1836.
+ * Outputs (callee-allocated, release with np2_free): consensus bases (ASCII) and their
+ * reference positions (ConsensusBase, main.rs:591-596). */
+int np2_polish_resident(np2_ctx_t *ctx, np2_contig_t *c, const np2_opts_t *opts,
+                        uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
+
+/* Convenience: upload + polish + free (PCIe-inclusive). */
+int np2_polish_contig(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads,
+                      uint32_t n_reads, const uint8_t *nibbles, uint64_t nib_bytes,
+                      const np2_opts_t *opts, uint8_t **out_bases, uint32_t **out_pos,
+                      uint64_t *out_len);
+void np2_free(void *p);
+
+/* Batched min-count k-mer scoring of byte strings against yak table `yak_idx`:
+ * scores[i] = min over k-mers of strs[off[i]..off[i+1]) of count (0 if none / absent /
+ * below min_kmer_count).  Mirrors the scoring closure main.rs:761-769 / 1300-1315
+ * (iter2kmer kmer.rs:255-287 + to_hash kmer.rs:102-110 + get kmer.rs:123-125). */
+int np2_score_strings(np2_ctx_t *ctx, int yak_idx, const uint8_t *strs, const uint64_t *off,
+                      uint64_t n, uint16_t min_kmer_count, uint16_t *scores);
+/* Point lookups of already-hashed k-mers (kmer.rs:123-125). */
+int np2_lookup_hashes(np2_ctx_t *ctx, int yak_idx, const uint64_t *hashes, uint64_t n,
+                      uint16_t min_kmer_count, uint16_t *counts);
+
+/* Stage-level exports for kernel parity tests and profiling.
+ * After np2_polish_resident with tracing enabled, np2_trace_get returns a pointer to a
+ * host copy of intermediate `name` of pass `pass` (valid until the next polish call). */
+void np2_ctx_set_trace(np2_ctx_t *ctx, int enable);
+int np2_trace_get(np2_ctx_t *ctx, int pass, const char *name, const void **data,
+                  uint64_t *nbytes);
+
+/* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
+ * names: NUL-separated list terminated by an empty string; ms[i] matches names[i]. */
+int np2_last_timings(np2_ctx_t *ctx, const char **names, const float **ms, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,166 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package nextpolish2_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from nextpolish2_amd._types import Opts, np2_opts_t, np2_read_t, np2_yak_t, yaks_array
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libnp2_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.np2o_ctx_create.restype = C.c_void_p
+        L.np2o_ctx_create.argtypes = [C.POINTER(np2_yak_t), C.c_int]
+        L.np2o_ctx_destroy.argtypes = [C.c_void_p]
+        L.np2o_last_error.restype = C.c_char_p
+        L.np2o_last_error.argtypes = [C.c_void_p]
+        L.np2o_set_trace.argtypes = [C.c_void_p, C.c_int]
+        L.np2o_polish_contig.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(np2_opts_t),
+            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+        ]
+        L.np2o_free.argtypes = [C.c_void_p]
+        L.np2o_trace_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.np2o_last_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.np2o_score_strings.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint16, C.c_void_p]
+        L.np2o_lookup_hashes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint16, C.c_void_p]
+        L.np2o_yak_hash64.restype = C.c_uint64
+        L.np2o_yak_hash64.argtypes = [C.c_uint64, C.c_uint32]
+        L.np2o_phase_communities.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+            C.c_void_p, C.POINTER(C.c_uint64),
+        ]
+        _LIB = L
+    return _LIB
+
+
+TRACE_DTYPES = {
+    "graph.off": np.uint32, "graph.bases": np.uint16, "graph.delta": np.uint16, "graph.count": np.uint32,
+    "lq.start": np.uint32, "lq.end": np.uint32, "invalid_ids": np.uint32,
+}
+for _t in ("cand", "seed", "hete", "rech0", "rech1", "rech2"):
+    TRACE_DTYPES.update({
+        f"{_t}.start": np.uint32, f"{_t}.end": np.uint32, f"{_t}.lable": np.uint8, f"{_t}.sudo_off": np.uint32,
+        f"{_t}.sudo": np.uint8, f"{_t}.cand_off": np.uint32, f"{_t}.order": np.uint32, f"{_t}.kscore": np.uint16,
+        f"{_t}.kmer": np.uint64, f"{_t}.seq_off": np.uint32, f"{_t}.seq": np.uint8,
+    })
+for _t in ("cns_raw", "cns_succ", "cns_rech0", "cns_rech1", "cns_rech2"):
+    TRACE_DTYPES.update({f"{_t}.pos": np.uint32, f"{_t}.base": np.uint8})
+
+
+class RefPanic(RuntimeError):
+    pass
+
+
+class Oracle:
+    """CPU restatement of the reference hot path (oracle/np2_oracle.cpp)."""
+
+    def __init__(self, yaks):
+        self._yaks = list(yaks)  # keep numpy buffers alive
+        arr = yaks_array(self._yaks)
+        self._h = lib().np2o_ctx_create(arr, len(self._yaks))
+        if not self._h:
+            raise ValueError("oracle: unsupported yak table (k must be < 32)")
+
+    def close(self):
+        if self._h:
+            lib().np2o_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_trace(self, on=True):
+        lib().np2o_set_trace(self._h, 1 if on else 0)
+
+    def polish(self, pileup, opts=None):
+        opts = opts or Opts()
+        o = opts.c()
+        ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        rc = lib().np2o_polish_contig(
+            self._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data, pileup.n_reads,
+            pileup.nibbles.ctypes.data, C.byref(o), C.byref(ob), C.byref(op), C.byref(on),
+        )
+        if rc != 0:
+            msg = lib().np2o_last_error(self._h).decode()
+            if rc == -5:
+                raise RefPanic(msg)
+            raise RuntimeError(f"oracle rc={rc}: {msg}")
+        n = on.value
+        bases = np.ctypeslib.as_array(C.cast(ob, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+        pos = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
+        lib().np2o_free(ob)
+        lib().np2o_free(op)
+        return bases, pos
+
+    def trace(self, pass_idx, name):
+        d, n = C.c_void_p(), C.c_uint64()
+        rc = lib().np2o_trace_get(self._h, pass_idx, name.encode(), C.byref(d), C.byref(n))
+        if rc != 0:
+            return None
+        dt = np.dtype(TRACE_DTYPES[name])
+        if n.value == 0:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_uint8 * n.value).from_address(d.value)
+        return np.frombuffer(bytes(buf), dtype=dt)
+
+    def stats(self):
+        out = np.zeros(5, dtype=np.uint64)
+        lib().np2o_last_stats(self._h, out.ctypes.data)
+        return dict(zip(["kmer_probes", "n_regions", "n_candidates", "n_nodes", "n_invalid"], out.tolist()))
+
+    def score_strings(self, yak_idx, strings, min_kmer_count=5):
+        off = np.zeros(len(strings) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in strings])
+        blob = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8)
+        out = np.zeros(len(strings), dtype=np.uint16)
+        rc = lib().np2o_score_strings(self._h, yak_idx, blob.ctypes.data, off.ctypes.data, len(strings), min_kmer_count, out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def lookup_hashes(self, yak_idx, hashes, min_kmer_count=5):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.zeros(h.shape[0], dtype=np.uint16)
+        rc = lib().np2o_lookup_hashes(self._h, yak_idx, h.ctypes.data, h.shape[0], min_kmer_count, out.ctypes.data)
+        assert rc == 0
+        return out
+
+
+def yak_hash64(kmer, k):
+    return int(lib().np2o_yak_hash64(int(kmer), int(k)))
+
+
+def phase_communities(edges, ref=None):
+    """edges: list of (a, b, w) applied in order with insert_data; ref: dict id->w or None."""
+    ea = np.array([e[0] for e in edges], dtype=np.uint32)
+    eb = np.array([e[1] for e in edges], dtype=np.uint32)
+    ew = np.array([e[2] for e in edges], dtype=np.float32)
+    ri = np.array(list(ref.keys()) if ref else [], dtype=np.uint32)
+    rw = np.array(list(ref.values()) if ref else [], dtype=np.float32)
+    out = np.zeros(max(1, len(edges) * 2 + 8), dtype=np.uint32)
+    n = C.c_uint64()
+    rc = lib().np2o_phase_communities(ea.ctypes.data, eb.ctypes.data, ew.ctypes.data, len(edges), ri.ctypes.data,
+                                      rw.ctypes.data, len(ri), 1 if ref is not None else 0, out.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise RefPanic("phase_communities")
+    return out[: n.value].tolist()
