@@ -1,0 +1,203 @@
+"""ctypes binding of libnp2_hip.so — the C-ABI of include/np2.h.
+
+There is no CPU fallback: importing is fine without a GPU (symbols can be inspected), but
+creating a Polisher requires the in-tree HIP library and a visible MI355X device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._types import Opts, Pileup, np2_opts_t, np2_read_t, np2_yak_t, yaks_array
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnp2_hip.so")
+_LIB = None
+
+# every symbol include/np2.h declares
+ABI_SYMBOLS = [
+    "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
+    "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings",
+]
+
+ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
+
+
+class Np2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libnp2_hip.so; raises loudly if the HIP extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with nextpolish2_amd/csrc/build.sh "
+                "(the np2 hot path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, u16 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint16
+        L.np2_ctx_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(np2_yak_t), C.c_int]
+        L.np2_ctx_destroy.argtypes = [vp]
+        L.np2_last_error.restype = C.c_char_p
+        L.np2_last_error.argtypes = [vp]
+        L.np2_ctx_stream.restype = vp
+        L.np2_ctx_stream.argtypes = [vp]
+        L.np2_contig_upload.argtypes = [vp, vp, u32, vp, u32, vp, u64, C.POINTER(vp)]
+        L.np2_contig_free.argtypes = [vp, vp]
+        L.np2_polish_resident.argtypes = [vp, vp, C.POINTER(np2_opts_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.np2_polish_contig.argtypes = [vp, vp, u32, vp, u32, vp, u64, C.POINTER(np2_opts_t), C.POINTER(vp),
+                                        C.POINTER(vp), C.POINTER(u64)]
+        L.np2_free.argtypes = [vp]
+        L.np2_score_strings.argtypes = [vp, C.c_int, vp, vp, u64, u16, vp]
+        L.np2_lookup_hashes.argtypes = [vp, C.c_int, vp, u64, u16, vp]
+        L.np2_ctx_set_trace.argtypes = [vp, C.c_int]
+        L.np2_trace_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
+        L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+TRACE_DTYPES = {
+    "graph.off": np.uint32, "graph.bases": np.uint16, "graph.delta": np.uint16, "graph.count": np.uint32,
+    "lq.start": np.uint32, "lq.end": np.uint32, "invalid_ids": np.uint32,
+}
+for _t in ("cand", "seed", "hete", "rech0", "rech1", "rech2"):
+    TRACE_DTYPES.update({
+        f"{_t}.start": np.uint32, f"{_t}.end": np.uint32, f"{_t}.lable": np.uint8, f"{_t}.sudo_off": np.uint32,
+        f"{_t}.sudo": np.uint8, f"{_t}.cand_off": np.uint32, f"{_t}.order": np.uint32, f"{_t}.kscore": np.uint16,
+        f"{_t}.kmer": np.uint64, f"{_t}.seq_off": np.uint32, f"{_t}.seq": np.uint8,
+    })
+for _t in ("cns_raw", "cns_succ", "cns_rech0", "cns_rech1", "cns_rech2"):
+    TRACE_DTYPES.update({f"{_t}.pos": np.uint32, f"{_t}.base": np.uint8})
+
+
+class ResidentContig:
+    """A contig's packed pileup resident in HBM (np2_contig_t)."""
+
+    def __init__(self, polisher, handle, pileup):
+        self._p = polisher
+        self._h = handle
+        self.L = pileup.L
+        self.n_reads = pileup.n_reads
+        self.n_columns = pileup.n_columns()
+        self.name = pileup.name
+
+    def free(self):
+        if self._h:
+            lib().np2_contig_free(self._p._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Polisher:
+    """One np2 context == one HIP device + HBM-resident yak tables.
+
+    Mirrors the reference's per-worker state (one Opt clone with its KmerInfo per worker thread,
+    src/main.rs:1724): contexts are independent, calls on one context are serialized."""
+
+    def __init__(self, yaks, device=0):
+        self._yaks = list(yaks)
+        arr = yaks_array(self._yaks)
+        h = C.c_void_p()
+        rc = lib().np2_ctx_create(C.byref(h), device, arr, len(self._yaks))
+        if rc != 0:
+            raise Np2Error(rc, "np2_ctx_create failed (see stderr)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().np2_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise Np2Error(rc, lib().np2_last_error(self._h).decode())
+
+    def set_trace(self, on=True):
+        lib().np2_ctx_set_trace(self._h, 1 if on else 0)
+
+    def upload(self, pileup: Pileup) -> ResidentContig:
+        h = C.c_void_p()
+        self._check(lib().np2_contig_upload(self._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
+                                            pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
+                                            C.byref(h)))
+        return ResidentContig(self, h, pileup)
+
+    def polish_resident(self, contig: ResidentContig, opts: Opts = None):
+        o = (opts or Opts()).c()
+        ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), C.byref(ob), C.byref(op), C.byref(on)))
+        n = on.value
+        bases = np.ctypeslib.as_array(C.cast(ob, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+        pos = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
+        lib().np2_free(ob)
+        lib().np2_free(op)
+        return bases, pos
+
+    def polish(self, pileup: Pileup, opts: Opts = None):
+        c = self.upload(pileup)
+        try:
+            return self.polish_resident(c, opts)
+        finally:
+            c.free()
+
+    def trace(self, pass_idx, name):
+        d, n = C.c_void_p(), C.c_uint64()
+        if lib().np2_trace_get(self._h, pass_idx, name.encode(), C.byref(d), C.byref(n)) != 0:
+            return None
+        dt = np.dtype(TRACE_DTYPES[name])
+        if n.value == 0:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_uint8 * n.value).from_address(d.value)
+        return np.frombuffer(bytes(buf), dtype=dt)
+
+    def timings(self):
+        names, ms, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        lib().np2_last_timings(self._h, C.byref(names), C.byref(ms), C.byref(n))
+        out = {}
+        if n.value:
+            raw = C.string_at(names.value, 4096)
+            parts = raw.split(b"\0")
+            vals = np.ctypeslib.as_array(C.cast(ms, C.POINTER(C.c_float)), shape=(n.value,))
+            for i in range(n.value):
+                out[parts[i].decode()] = float(vals[i])
+        return out
+
+    def score_strings(self, yak_idx, strings, min_kmer_count=5):
+        off = np.zeros(len(strings) + 1, dtype=np.uint64)
+        if strings:
+            off[1:] = np.cumsum([len(s) for s in strings])
+        blob = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8)
+        out = np.zeros(len(strings), dtype=np.uint16)
+        self._check(lib().np2_score_strings(self._h, yak_idx, blob.ctypes.data, off.ctypes.data, len(strings),
+                                            min_kmer_count, out.ctypes.data))
+        return out
+
+    def lookup_hashes(self, yak_idx, hashes, min_kmer_count=5):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.zeros(h.shape[0], dtype=np.uint16)
+        self._check(lib().np2_lookup_hashes(self._h, yak_idx, h.ctypes.data, h.shape[0], min_kmer_count,
+                                            out.ctypes.data))
+        return out
+
+
+def fasta_record(name, bases, pos):
+    """display_consensusbase_vec (src/main.rs:607-645): '>{name} start:{first} end:{last}\\n{seq}\\n'."""
+    return b">%s start:%d end:%d\n%s\n" % (name.encode() if isinstance(name, str) else name, int(pos[0]), int(pos[-1]),
+                                           bytes(bases))

@@ -1,0 +1,1253 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) for the NextPolish2 consensus hot path.
+//
+// Design: "ref-diff sparse graph" (DESIGN.md).  The reference builds, per contig position, a
+// multiset of 3-column-mers from every read column (update_msas, src/main.rs:576-589).
+// At HiFi error rates >99 % of those insertions reproduce the node the contig itself
+// contributes (read 0).  k_diff_reads streams the packed pileup once (HBM-bound, 0.5 B per
+// column), compares it against the nibble-packed contig and emits only *exception* nodes;
+// the implicit node N0(p) of the contig has count = coverage(p) - #exceptions(delta3 == 0).
+// Everything downstream (DP, backtrack, LQ detection, candidates) runs on that sparse graph
+// and is exact: positions without exceptions hold a single node every path passes through,
+// so the whole-contig DP (main.rs:1645-1687) decomposes into independent "dirty runs".
+#include "np2_common.hpp"
+#include "np2_kernels.hpp"
+#include "../../include/np2.h"
+
+namespace np2 {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t swap_nib(uint32_t w) {
+    return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu);
+}
+// gather bit 0 of each of the 16 nibbles of x into 16 contiguous bits
+__device__ __forceinline__ uint32_t gather16(uint64_t x) {
+    x &= 0x1111111111111111ULL;
+    x = (x | (x >> 3)) & 0x0303030303030303ULL;
+    x = (x | (x >> 6)) & 0x000F000F000F000FULL;
+    x = (x | (x >> 12)) & 0x000000FF000000FFULL;
+    x = (x | (x >> 24)) & 0xFFFFULL;
+    return (uint32_t)x;
+}
+// nonzero-nibble mask (bit 0 of each nibble)
+__device__ __forceinline__ uint64_t nz_nib(uint64_t x) {
+    x |= x >> 1;
+    x |= x >> 2;
+    return x & 0x1111111111111111ULL;
+}
+// nibble-packed contig: code of position p at bits 4*(p&15) of 64-bit word p>>4
+__device__ __forceinline__ void load_ref128(const uint64_t *__restrict__ refw, uint32_t t, uint64_t &lo,
+                                            uint64_t &hi) {
+    uint32_t wi = t >> 4, sh = (t & 15) * 4;
+    uint64_t w0 = refw[wi], w1 = refw[wi + 1], w2 = refw[wi + 2];
+    if (sh) {
+        lo = (w0 >> sh) | (w1 << (64 - sh));
+        hi = (w1 >> sh) | (w2 << (64 - sh));
+    } else {
+        lo = w0;
+        hi = w1;
+    }
+}
+__device__ __forceinline__ uint8_t ref_code(const uint8_t *__restrict__ refnib, uint32_t p) {
+    return (refnib[p >> 1] >> (4 * (p & 1))) & 7;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: contig codes from read 0 (the contig aligned to itself, main.rs:1732-1739)
+// ------------------------------------------------------------------------------------------
+__global__ void k_encode_ref(const uint8_t *__restrict__ read0, uint32_t L, uint8_t *__restrict__ refnib,
+                             uint32_t nbytes_total, uint32_t *__restrict__ err) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbytes_total) return;
+    uint32_t c0 = 2 * i, c1 = 2 * i + 1;
+    uint8_t b = c0 < L ? read0[i] : 0;
+    uint8_t hi = c0 < L ? (b >> 4) : 0, lo = c1 < L ? (b & 15) : 0;
+    if ((c0 < L && c0 != 0 && (hi & 8)) || (c1 < L && (lo & 8))) atomicOr(err, 1u); // read 0 has an insertion column
+    if (c0 < L && (hi & 7) == 7) atomicOr(err, 1u);
+    if (c1 < L && (lo & 7) == 7) atomicOr(err, 1u);
+    refnib[i] = (uint8_t)((hi & 7) | ((lo & 7) << 4));
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: dense pass — compare every read column with the contig, emit exception nodes and
+//     per-read checkpoints.  One wavefront per read; each lane owns 32 columns (16 B) per
+//     iteration, i.e. a coalesced 1 KiB per wave-instruction.
+// ------------------------------------------------------------------------------------------
+struct EmitCtx {
+    const uint8_t *base; // nibble stream of this read
+    uint32_t ts;         // aln_t_s
+    uint32_t read;
+};
+
+__device__ __forceinline__ AlignBase make_col(const EmitCtx &cx, int64_t gc, uint32_t n_upto) {
+    // AlignBase of global column gc (gc == -2 / -1: the two head sentinels, main.rs:579-580);
+    // n_upto = number of non-insertion columns in [0..gc]
+    if (gc == -2) return ab_head(cx.ts - 1, 0);
+    if (gc == -1) return ab_head(cx.ts - 1, 1);
+    uint8_t nb = nib_at(cx.base, (uint32_t)gc);
+    AlignBase a;
+    a.q = nb & 7;
+    a.t_pos = cx.ts + n_upto - 1;
+    a.delta = 0;
+    if (gc > 0 && (nb & 8)) {
+        uint16_t d = 1;
+        int64_t c = gc - 1;
+        while (c > 0 && (nib_at(cx.base, (uint32_t)c) & 8)) {
+            d = (uint16_t)(d + 1);
+            --c;
+        }
+        a.delta = d;
+    }
+    return a;
+}
+
+__device__ void emit_lane(const EmitCtx &cx, uint32_t lc0, uint32_t Nb, uint32_t im, uint32_t E,
+                          uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint64_t out_base,
+                          uint64_t out_limit) {
+    const uint32_t first = __builtin_ctz(E), last = 31 - __builtin_clz(E);
+    const uint32_t j0 = first >= 2 ? first - 2 : 0;
+    // N(lc0 + j0 - 1): non-insertion columns before lane column j0
+    uint32_t n = Nb + __builtin_popcount(~im & ((1u << j0) - 1u));
+    const int64_t g = (int64_t)lc0 + j0;
+    AlignBase b2 = make_col(cx, g - 1, n);
+    bool prev_nonins = (g - 1 >= 0) && ((g - 1 == 0) || !(nib_at(cx.base, (uint32_t)(g - 1)) & 8));
+    AlignBase b1 = make_col(cx, g - 2, n - (prev_nonins ? 1u : 0u));
+    uint64_t o = out_base;
+    for (uint32_t j = j0; j <= last; ++j) {
+        const uint32_t gc = lc0 + j;
+        const uint8_t nb = nib_at(cx.base, gc);
+        AlignBase b3;
+        b3.q = nb & 7;
+        if (gc == 0) { // get_align_tag, p == 0 (main.rs:332-335)
+            b3.t_pos = cx.ts;
+            b3.delta = 0;
+        } else if (nb & 8) {
+            b3.t_pos = b2.t_pos;
+            b3.delta = (uint16_t)(b2.delta + 1);
+        } else {
+            b3.t_pos = b2.t_pos + 1;
+            b3.delta = 0;
+        }
+        if ((E >> j) & 1u) {
+            if (o < out_limit) {
+                out_keys[o] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
+                out_vals[o] = cx.read;
+            }
+            ++o;
+        }
+        b1 = b2;
+        b2 = b3;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_diff_reads(
+    const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ nib,
+    const uint64_t *__restrict__ refw, const uint8_t *__restrict__ refnib, uint32_t L,
+    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ shard_cnt,
+    uint32_t shard_cap, const uint64_t *__restrict__ ck_off, uint32_t *__restrict__ ckpt,
+    uint32_t *__restrict__ err) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t r = gwave;
+    if (r >= R || r == 0) return;
+    const np2_read_t rd = reads[r];
+    if (rd.flags & NP2_READ_DROPPED) return;
+    const uint8_t *base = nib + rd.nib_off;
+    const uint32_t ncols = rd.n_cols, ts = rd.aln_t_s;
+    const uint32_t shard = gwave & (NSHARD - 1);
+    const uint64_t ckbase = ck_off[r];
+    const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
+    const uint32_t nck = (uint32_t)(ck_off[r + 1] - ckbase);
+    EmitCtx cx{base, ts, r};
+    uint32_t carryN = 0, prev_last_bad = 0;
+
+    for (uint32_t c0 = 0; c0 < ncols; c0 += 2048) {
+        const uint32_t lc0 = c0 + lane * 32;
+        const uint32_t nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
+        uint64_t lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
+        uint64_t hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
+        uint64_t mlo = ~0ULL, mhi = ~0ULL; // valid-nibble masks
+        if (nv < 32) {
+            if (nv <= 16) {
+                mhi = 0;
+                mlo = nv == 16 ? ~0ULL : ((1ULL << (4 * nv)) - 1);
+            } else {
+                mhi = (1ULL << (4 * (nv - 16))) - 1;
+            }
+        }
+        lo &= mlo;
+        hi &= mhi;
+        uint64_t ilo = lo & 0x8888888888888888ULL, ihi = hi & 0x8888888888888888ULL;
+        if (lc0 == 0) ilo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
+        lo &= 0x7777777777777777ULL;
+        hi &= 0x7777777777777777ULL;
+        const uint32_t n_ins = __builtin_popcountll(ilo) + __builtin_popcountll(ihi);
+        const uint32_t nonins = nv - n_ins;
+        const uint32_t incl = wave_incl_scan(nonins);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t Nb = carryN + (incl - nonins); // non-insertion columns before this lane
+        const uint32_t t0 = ts + Nb;                  // t_pos of the lane's first non-insertion column
+        uint32_t bad = 0, im = 0;
+        if (nv) {
+            if (n_ins == 0) {
+                uint64_t rlo, rhi;
+                load_ref128(refw, t0, rlo, rhi);
+                uint64_t x = (lo ^ rlo) & mlo, y = (hi ^ rhi) & mhi;
+                if (x | y) bad = gather16(nz_nib(x)) | (gather16(nz_nib(y)) << 16);
+            } else {
+                im = gather16(ilo >> 3) | (gather16(ihi >> 3) << 16);
+                const uint32_t runs = __builtin_popcount(im & ~(im << 1));
+                const uint32_t i1 = __builtin_ctz(im);
+                const uint32_t vmask = nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+                if (runs == 1 && t0 >= n_ins) {
+                    // one insertion run [i1, i1+m): columns before it sit at t0+j, after it at t0+j-m
+                    uint64_t rlo, rhi;
+                    load_ref128(refw, t0, rlo, rhi);
+                    uint32_t badA = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
+                    load_ref128(refw, t0 - n_ins, rlo, rhi);
+                    uint32_t badB = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
+                    const uint32_t below = (1u << i1) - 1u;
+                    const uint32_t e2 = i1 + n_ins;
+                    const uint32_t above = e2 >= 32 ? 0u : ~((1u << e2) - 1u);
+                    bad = ((badA & below) | (badB & above) | im) & vmask;
+                } else {
+                    uint32_t tcur = t0 - 1;
+                    for (uint32_t j = 0; j < nv; ++j) {
+                        if ((im >> j) & 1u) {
+                            bad |= 1u << j;
+                        } else {
+                            ++tcur;
+                            uint8_t q = (uint8_t)(((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16)))) & 7);
+                            if (tcur >= L || q != ref_code(refnib, tcur)) bad |= 1u << j;
+                        }
+                    }
+                }
+            }
+            // checkpoint: column of the reference column at the next multiple of CKPT
+            if (nonins) {
+                const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
+                uint32_t nth = tstar - t0;
+                if (nth < nonins) {
+                    uint32_t j = nth;
+                    if (n_ins) {
+                        j = 0;
+                        for (;; ++j) {
+                            if (!((im >> j) & 1u)) {
+                                if (nth == 0) break;
+                                --nth;
+                            }
+                        }
+                    }
+                    const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
+                    if (idx < nck) ckpt[ckbase + idx] = lc0 + j;
+                }
+            }
+        }
+        uint32_t pb = __shfl_up(bad, 1);
+        if (lane == 0) pb = prev_last_bad;
+        uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
+        if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
+        E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+        prev_last_bad = __shfl(bad, 63);
+        if (__ballot(E != 0)) {
+            const uint32_t cnt = __builtin_popcount(E);
+            const uint32_t inc2 = wave_incl_scan(cnt);
+            const uint32_t tot = __shfl(inc2, 63);
+            uint32_t basepos = 0;
+            if (lane == 0) basepos = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
+            basepos = __shfl(basepos, 0);
+            if (E) {
+                const uint64_t sb = (uint64_t)shard * shard_cap;
+                emit_lane(cx, lc0, Nb, im, E, out_keys, out_vals, sb + basepos + (inc2 - cnt), sb + shard_cap);
+            }
+        }
+        carryN += total;
+    }
+    if (lane == 0) {
+        // the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
+        if (ncols == 0 || ts + carryN - 1 != rd.aln_t_e || rd.aln_t_e >= L) atomicOr(err, 2u);
+        if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
+    }
+}
+
+__global__ void k_compact_shards(const uint64_t *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
+                                 uint32_t shard_cap, const uint32_t *__restrict__ shard_cnt,
+                                 const uint64_t *__restrict__ shard_off, uint64_t *__restrict__ out_keys,
+                                 uint32_t *__restrict__ out_vals) {
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = shard_cnt[s * SHARD_STRIDE];
+    const uint64_t src = (uint64_t)s * shard_cap, dst = shard_off[s];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out_keys[dst + i] = in_keys[src + i];
+        out_vals[dst + i] = in_vals[src + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: per pass — group identical exception nodes of live reads (Msa::push, main.rs:193-207)
+// ------------------------------------------------------------------------------------------
+__global__ void k_group_nodes(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t T,
+                              const uint8_t *__restrict__ alive, uint32_t *__restrict__ gcount,
+                              uint32_t *__restrict__ gmin) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const uint64_t k = keys[i];
+    if (i > 0 && keys[i - 1] == k) {
+        gcount[i] = 0;
+        return;
+    }
+    uint32_t cnt = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t j = i; j < T && keys[j] == k; ++j) {
+        const uint32_t r = vals[j];
+        if (alive[r]) {
+            ++cnt;
+            mn = min(mn, r);
+        }
+    }
+    gcount[i] = cnt;
+    gmin[i] = mn;
+}
+
+__global__ void k_flag_nonzero(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ flag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = in[i] != 0;
+}
+
+__global__ void k_scatter_nodes(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ gcount,
+                                const uint32_t *__restrict__ gmin, const uint32_t *__restrict__ idx, uint32_t T,
+                                NodeArrays nd, uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ n_nodes) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const uint32_t c = gcount[i];
+    if (c) {
+        const uint32_t o = idx[i];
+        const uint64_t k = keys[i];
+        nd.pos[o] = (uint32_t)(k >> 32);
+        nd.bases[o] = (uint16_t)(k >> 16);
+        nd.delta[o] = (uint16_t)k;
+        nd.count[o] = c;
+        nd.minr[o] = gmin[i];
+        atomicAdd(&node_cnt[(uint32_t)(k >> 32)], 1u);
+    }
+    if (i == T - 1) *n_nodes = idx[i] + (c ? 1u : 0u);
+}
+
+// order the nodes of one position like Msa::sort over first-seen order: (delta3, first read)
+__global__ void k_order_nodes(const uint32_t *__restrict__ node_off, uint32_t L, NodeArrays nd) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    const uint32_t o0 = node_off[p], o1 = node_off[p + 1];
+    if (o1 - o0 < 2) return;
+    for (uint32_t i = o0 + 1; i < o1; ++i) {
+        const uint16_t b = nd.bases[i], d = nd.delta[i];
+        const uint32_t c = nd.count[i], m = nd.minr[i];
+        const uint32_t kd = node_delta3(b, d);
+        uint32_t j = i;
+        while (j > o0) {
+            const uint32_t pd = node_delta3(nd.bases[j - 1], nd.delta[j - 1]);
+            if (pd < kd || (pd == kd && nd.minr[j - 1] < m)) break;
+            nd.bases[j] = nd.bases[j - 1];
+            nd.delta[j] = nd.delta[j - 1];
+            nd.count[j] = nd.count[j - 1];
+            nd.minr[j] = nd.minr[j - 1];
+            --j;
+        }
+        nd.bases[j] = b;
+        nd.delta[j] = d;
+        nd.count[j] = c;
+        nd.minr[j] = m;
+    }
+}
+
+// coverage(p) = number of live reads spanning p (Msa::coverage, main.rs:232-241)
+__global__ void k_cov_delta(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
+                            int32_t *__restrict__ covd) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R || !alive[r]) return;
+    atomicAdd(&covd[reads[r].aln_t_s], 1);
+    atomicAdd(&covd[reads[r].aln_t_e + 1], -1);
+}
+
+__global__ void k_init_alive(const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
+}
+__global__ void k_kill_reads(const uint32_t *__restrict__ ids, uint32_t n, uint8_t *__restrict__ alive) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) alive[ids[i]] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse-graph accessors.  Node index 0 at a position is the contig's implicit node N0(p);
+// index 1+k is exception node node_off[p]+k.
+// ------------------------------------------------------------------------------------------
+struct Graph {
+    const uint8_t *refnib;
+    const uint32_t *node_off;
+    NodeArrays nd;
+    const int32_t *cov;
+    uint32_t L;
+};
+__device__ __forceinline__ void n0_key(const Graph &g, uint32_t p, uint16_t &bases, uint16_t &delta) {
+    const uint8_t c = ref_code(g.refnib, p);
+    if (p >= 2) {
+        bases = (uint16_t)((ref_code(g.refnib, p - 2) << 8) | (ref_code(g.refnib, p - 1) << 4) | c);
+        delta = 0;
+    } else if (p == 1) { // (head(-1,1), c0, c1)
+        bases = (uint16_t)(0x0F00 | (ref_code(g.refnib, 0) << 4) | c);
+        delta = 1;
+    } else { // (head(-1,0), head(-1,1), c0)
+        bases = (uint16_t)(0x4FF0 | c);
+        delta = 0;
+    }
+}
+__device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
+    uint32_t e0 = 0;
+    for (uint32_t i = g.node_off[p]; i < g.node_off[p + 1]; ++i)
+        if (node_delta3(g.nd.bases[i], g.nd.delta[i]) == 0) e0 += g.nd.count[i];
+    return (uint32_t)g.cov[p] - e0;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5/K6: dirty runs and the per-run DP (get_cns_from_align_tags, main.rs:1645-1687)
+// ------------------------------------------------------------------------------------------
+__global__ void k_mark_runs(const uint32_t *__restrict__ node_off, uint32_t L, uint32_t *__restrict__ flag) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    const bool d = node_off[p + 1] > node_off[p];
+    const bool dp = p > 0 && node_off[p] > node_off[p - 1];
+    flag[p] = d && !dp;
+}
+__global__ void k_scatter_idx(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n,
+                              uint32_t *__restrict__ out, uint32_t *__restrict__ n_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) out[idx[i]] = i;
+    if (i == n - 1) *n_out = idx[i] + (flag[i] ? 1u : 0u);
+}
+
+// score one node K at position p given the already-scored candidates of its predecessor
+// position q (q == p: nodes before K in the same position; q == p-1: previous position).
+struct PosView {
+    uint32_t p;      // position
+    uint32_t o0, o1; // exception node range
+    uint16_t b0, d0; // N0 key
+    int64_t s0;      // N0 score
+    bool has_n0_score;
+};
+
+__device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q, const AlignBase &kb1,
+                                           const AlignBase &kb2, AlignBase &pb1) {
+    // Msa::get(base2 = K.b1, base3 = K.b2) (main.rs:209-225)
+    const uint8_t base23 = (uint8_t)((kb1.q << 4) | kb2.q);
+    const uint16_t delta23 = kb1.t_pos == kb2.t_pos ? 1 : 0;
+    if ((uint8_t)vb != base23 || ((vb >> 12) & 1) != delta23) return false;
+    AlignBase pb2, pb3;
+    node_decode(vb, vd, q, pb1, pb2, pb3);
+    return pb2.eq(kb1) && pb3.eq(kb2);
+}
+
+__global__ void k_dp_runs(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ n_runs, Graph g,
+                          int64_t *__restrict__ nscore, uint32_t *__restrict__ nbesti,
+                          uint32_t *__restrict__ n0_besti, uint32_t *__restrict__ run_end,
+                          int64_t *__restrict__ last_n0_score, unsigned long long *__restrict__ total_gain) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_runs) return;
+    const uint32_t a = run_start[r], L = g.L;
+    // previous position view (starts as the clean position a-1, score 0 by convention)
+    uint32_t pv_o0 = 0, pv_o1 = 0;
+    uint16_t pv_b0 = 0, pv_d0 = 0;
+    int64_t pv_s0 = 0;
+    bool pv_valid = a > 0;
+    if (pv_valid) n0_key(g, a - 1, pv_b0, pv_d0);
+    uint32_t p = a;
+    for (;; ++p) {
+        const bool in_run = p < L && g.node_off[p + 1] > g.node_off[p];
+        if (p >= L) break;
+        const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
+        uint16_t b0, d0;
+        n0_key(g, p, b0, d0);
+        const int64_t cov = g.cov[p];
+        uint32_t e0 = 0;
+        for (uint32_t i = o0; i < o1; ++i)
+            if (node_delta3(g.nd.bases[i], g.nd.delta[i]) == 0) e0 += g.nd.count[i];
+        const int64_t c0 = cov - (int64_t)e0;
+        int64_t s0_cur = 0;
+        const uint32_t nn = 1 + (o1 - o0);
+        for (uint32_t idx = 0; idx < nn; ++idx) {
+            const uint16_t kb = idx ? g.nd.bases[o0 + idx - 1] : b0;
+            const uint16_t kd = idx ? g.nd.delta[o0 + idx - 1] : d0;
+            const int64_t cnt = idx ? (int64_t)g.nd.count[o0 + idx - 1] : c0;
+            AlignBase k1, k2, k3;
+            node_decode(kb, kd, p, k1, k2, k3);
+            int64_t score;
+            uint32_t besti = 0;
+            if (k2.is_head()) {
+                score = 10 * cnt - 4 * cov;
+            } else {
+                score = SCORE_NEG;
+                const uint32_t q = k2.t_pos;
+                uint32_t qo0, qn;
+                uint16_t qb0, qd0;
+                int64_t qs0;
+                bool ok = false;
+                if (q == p) { // same position: only nodes before K can match (their b3.delta = K.b2.delta)
+                    qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
+                } else if (q + 1 == p && pv_valid) {
+                    qo0 = pv_o0, qn = 1 + (pv_o1 - pv_o0), qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
+                }
+                if (ok) {
+                    for (uint32_t pi = 0; pi < qn; ++pi) {
+                        const uint16_t vb = pi ? g.nd.bases[qo0 + pi - 1] : qb0;
+                        const uint16_t vd = pi ? g.nd.delta[qo0 + pi - 1] : qd0;
+                        AlignBase pb1;
+                        if (!pred_match(vb, vd, q, k1, k2, pb1)) continue;
+                        if (q >= 3 && pb1.is_head()) continue; // main.rs:1666-1668
+                        const int64_t ps = pi ? nscore[qo0 + pi - 1] : qs0;
+                        const int64_t s = ps + 10 * cnt - 4 * cov;
+                        if (s > score || (s == score && pb1.q != 4)) { // main.rs:1670
+                            score = s;
+                            besti = pi;
+                        }
+                    }
+                }
+            }
+            if (idx) {
+                nscore[o0 + idx - 1] = score;
+                nbesti[o0 + idx - 1] = besti;
+            } else {
+                s0_cur = score;
+                n0_besti[p] = besti;
+            }
+        }
+        if (!in_run) { // p == b+1: the clean position closing the run; its N0 is scored above
+            run_end[r] = p - 1;
+            atomicAdd(total_gain, (unsigned long long)s0_cur);
+            return;
+        }
+        pv_o0 = o0, pv_o1 = o1, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
+    }
+    // the run reaches the contig end
+    run_end[r] = L - 1;
+    *last_n0_score = pv_s0;
+}
+
+// sum of the gains of clean positions whose predecessor is clean (or p == 0): 10*c0 - 4*cov = 6*cov
+__global__ void k_clean_gain(const uint32_t *__restrict__ node_off, const int32_t *__restrict__ cov, uint32_t L,
+                             unsigned long long *__restrict__ total_gain) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    long long v = 0;
+    if (p < L) {
+        const bool d = node_off[p + 1] > node_off[p];
+        const bool dp = p > 0 && node_off[p] > node_off[p - 1];
+        if (!d && !dp) v = 6LL * cov[p];
+    }
+    // block reduction
+    __shared__ long long sm[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) s += sm[w];
+        if (s) atomicAdd(total_gain, (unsigned long long)s);
+    }
+}
+
+// global best node at L-1 (main.rs:1651,1680): later node wins ties, must reach score >= 0
+__global__ void k_pick_best(Graph g, const int64_t *__restrict__ nscore, const int64_t *__restrict__ last_n0_score,
+                            const unsigned long long *__restrict__ total_gain, uint32_t *__restrict__ best_idx) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t p = g.L - 1;
+    const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
+    const int64_t total = (int64_t)*total_gain;
+    if (o1 == o0) {
+        *best_idx = total >= 0 ? 0u : 0xFFFFFFFFu;
+        return;
+    }
+    int64_t best = 0;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t idx = 0; idx < 1 + (o1 - o0); ++idx) {
+        const int64_t rel = idx ? nscore[o0 + idx - 1] : *last_n0_score;
+        const int64_t s = rel <= (SCORE_NEG / 2) ? rel : total + rel;
+        if (s >= best) {
+            best = s;
+            bi = idx;
+        }
+    }
+    *best_idx = bi;
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: backtrack + consensus emission (generate_cns_from_best_score_lq, main.rs:1555-1637)
+// ------------------------------------------------------------------------------------------
+template <bool WRITE>
+__device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t entry_idx,
+                            const uint32_t *__restrict__ nbesti, const uint32_t *__restrict__ n0_besti,
+                            uint32_t *__restrict__ path_begin, uint32_t out_end, uint32_t *__restrict__ cns_pos,
+                            uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls) {
+    // walks right -> left from node (b, entry_idx) until it leaves [a, b]; returns #emitted bases;
+    // with WRITE, bases are stored at out_end-1, out_end-2, ...
+    uint32_t pos = b, idx = entry_idx, n = 0;
+    for (;;) {
+        uint16_t kb, kd;
+        uint32_t cnt, bi;
+        const uint32_t o0 = g.node_off[pos];
+        if (idx == 0) {
+            n0_key(g, pos, kb, kd);
+            cnt = n0_count(g, pos);
+            bi = n0_besti[pos];
+        } else {
+            kb = g.nd.bases[o0 + idx - 1];
+            kd = g.nd.delta[o0 + idx - 1];
+            cnt = g.nd.count[o0 + idx - 1];
+            bi = nbesti[o0 + idx - 1];
+        }
+        AlignBase k1, k2, k3;
+        node_decode(kb, kd, pos, k1, k2, k3);
+        if (k3.q != 4) {
+            if (WRITE) {
+                const int64_t cov = g.cov[k3.t_pos];
+                const int64_t qv = cov > 0 ? (int64_t)cnt * 100 / cov : 0;
+                const uint32_t o = out_end - 1 - n;
+                cns_pos[o] = k3.t_pos;
+                cns_base[o] = code_to_ascii(k3.q);
+                cns_cls[o] = cov < 2 ? CLS_RESET : (qv < 95 ? CLS_LQ : CLS_HQ);
+            }
+            ++n;
+        }
+        if (k2.is_head()) {
+            if (!WRITE && k3.t_pos > 0) atomicMax(path_begin, k3.t_pos);
+            break;
+        }
+        const uint32_t np_ = k2.t_pos;
+        if (np_ < a || np_ > pos) break; // left the run (np_ == a-1 -> N0(a-1)); np_ > pos: wrapped
+        pos = np_;
+        idx = bi;
+    }
+    return n;
+}
+
+__global__ void k_emit_init(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib, uint32_t L,
+                            uint32_t *__restrict__ emit) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    const bool d = node_off[p + 1] > node_off[p];
+    emit[p] = d ? 0u : (ref_code(refnib, p) != 4 ? 1u : 0u);
+}
+
+__global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
+                           const uint32_t *__restrict__ n_runs, Graph g, const uint32_t *__restrict__ nbesti,
+                           const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
+                           uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_runs) return;
+    const uint32_t a = run_start[r], b = run_end[r];
+    const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
+    emit[a] = bt_walk<false>(g, a, b, entry, nbesti, n0_besti, path_begin, 0, nullptr, nullptr, nullptr);
+}
+
+// positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
+// main.rs:1666-1668, so at most positions 0..1 are affected)
+__global__ void k_emit_fix(uint32_t *__restrict__ emit, const uint32_t *__restrict__ path_begin,
+                           const uint32_t *__restrict__ node_off, uint32_t L) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t pb = *path_begin;
+    uint32_t p = 0;
+    while (p < pb && p < L) {
+        if (!(node_off[p + 1] > node_off[p])) {
+            emit[p] = 0; // clean position before the path start
+            ++p;
+        } else {
+            uint32_t e = p;
+            while (e + 1 < L && node_off[e + 2] > node_off[e + 1]) ++e;
+            if (e < pb) emit[p] = 0; // whole dirty run lies before the path start
+            p = e + 1;
+        }
+    }
+}
+
+__global__ void k_clean_write(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
+                              const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
+                              const uint32_t *__restrict__ eoff, uint32_t L, uint32_t *__restrict__ cns_pos,
+                              uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    if (node_off[p + 1] > node_off[p] || emit[p] == 0) return;
+    const uint32_t o = eoff[p];
+    cns_pos[o] = p;
+    cns_base[o] = code_to_ascii(ref_code(refnib, p));
+    cns_cls[o] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
+}
+
+__global__ void k_bt_write(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
+                           const uint32_t *__restrict__ n_runs, Graph g, const uint32_t *__restrict__ nbesti,
+                           const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
+                           const uint32_t *__restrict__ emit, const uint32_t *__restrict__ eoff,
+                           uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
+                           uint8_t *__restrict__ cns_cls) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_runs) return;
+    const uint32_t a = run_start[r], b = run_end[r];
+    if (emit[a] == 0) return;
+    const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
+    bt_walk<true>(g, a, b, entry, nbesti, n0_besti, nullptr, eoff[a] + emit[a], cns_pos, cns_base, cns_cls);
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: LQ-region detection — the right-to-left state machine of main.rs:1586-1625, evaluated in
+// parallel.  Indices `p` below are the reference's emission indices (p = M-1-i).
+// ------------------------------------------------------------------------------------------
+enum : uint8_t { LQK_LINK = 0, LQK_CLOSE = 1, LQK_RESET = 2, LQK_OPEN = 3 };
+
+__global__ void k_lq_scan(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
+                          const uint8_t *__restrict__ cns_cls, uint32_t M, uint8_t *__restrict__ lq_kind,
+                          uint32_t *__restrict__ lq_next, uint8_t *__restrict__ lq_nothead) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M || cns_cls[i] != CLS_LQ) return;
+    const uint32_t p = M - 1 - i;
+    uint8_t kind = LQK_OPEN;
+    uint32_t pp = p + 1;
+    for (; pp < M; ++pp) {
+        const uint32_t ii = M - 1 - pp;
+        const uint8_t cl = cns_cls[ii];
+        if (cl == CLS_RESET) {
+            kind = LQK_RESET;
+            break;
+        }
+        if (cl == CLS_LQ) {
+            kind = LQK_LINK;
+            break;
+        }
+        if (pp - p > 4) { // p - lq_e > 2*lq_min_length, c(pp-1) vs c(pp-2) (main.rs:1596-1598)
+            const uint32_t i1 = ii + 1, i2 = ii + 2;
+            if (cns_pos[i1] != cns_pos[i2] && cns_base[i1] != cns_base[i2]) {
+                kind = LQK_CLOSE;
+                break;
+            }
+        }
+    }
+    lq_kind[p] = kind;
+    lq_next[p] = pp;
+    if (kind == LQK_LINK) lq_nothead[pp] = 1;
+}
+
+__global__ void k_lq_region(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
+                            const uint8_t *__restrict__ cns_cls, uint32_t M, const uint8_t *__restrict__ lq_kind,
+                            const uint32_t *__restrict__ lq_next, const uint8_t *__restrict__ lq_nothead,
+                            uint32_t *__restrict__ rflag, uint32_t *__restrict__ rstart,
+                            uint32_t *__restrict__ rend) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    rflag[p] = 0;
+    if (cns_cls[M - 1 - p] != CLS_LQ || lq_nothead[p]) return;
+    uint32_t q = p;
+    while (lq_kind[q] == LQK_LINK) q = lq_next[q];
+    if (lq_kind[q] != LQK_CLOSE) return;
+    const uint32_t pe = lq_next[q];
+    const uint32_t lq_e = pe - 2;
+    uint32_t lq_s = p > 2 ? p - 2 : 1;
+#define CP(x) cns_pos[M - 1 - (x)]
+#define CB(x) cns_base[M - 1 - (x)]
+    while (lq_s > 1 && (CP(lq_s - 1) == CP(lq_s) || CB(lq_s - 1) == CB(lq_s))) --lq_s;
+    rflag[p] = 1;
+    rend[p] = CP(lq_s);
+    rstart[p] = CP(lq_e);
+#undef CP
+#undef CB
+}
+
+__global__ void k_scatter_regions(const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ ridx,
+                                  const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ rend, uint32_t M,
+                                  uint32_t *__restrict__ raw_start, uint32_t *__restrict__ raw_end,
+                                  uint32_t *__restrict__ n_raw) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    if (rflag[p]) {
+        raw_start[ridx[p]] = rstart[p];
+        raw_end[ridx[p]] = rend[p];
+    }
+    if (p == M - 1) *n_raw = ridx[p] + rflag[p];
+}
+
+// merge rule main.rs:1613-1615: region j merges into j-1 iff end_j >= start_{j-1}
+__global__ void k_lq_merge_flag(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
+                                const uint32_t *__restrict__ n_raw, uint32_t *__restrict__ headflag) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *n_raw) return;
+    headflag[j] = !(j >= 1 && raw_end[j] >= raw_start[j - 1]);
+}
+__global__ void k_lq_merge_write(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
+                                 const uint32_t *__restrict__ n_raw, const uint32_t *__restrict__ headflag,
+                                 const uint32_t *__restrict__ hidx, uint32_t *__restrict__ lq_start,
+                                 uint32_t *__restrict__ lq_end, uint32_t *__restrict__ n_reg) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *n_raw;
+    if (j >= n) return;
+    if (headflag[j]) {
+        uint32_t l = j;
+        while (l + 1 < n && !headflag[l + 1]) ++l;
+        lq_end[hidx[j]] = raw_end[j];
+        lq_start[hidx[j]] = raw_start[l];
+    }
+    if (j == n - 1) *n_reg = hidx[j] + headflag[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// K9: candidate extraction (generate_lqseqs_from_tags_kmer part 1, main.rs:1439-1523)
+// regions are indexed right -> left (index 0 = rightmost), starts/ends strictly decreasing.
+// ------------------------------------------------------------------------------------------
+// number of entries of a descending array that are >= v  /  > v
+__device__ __forceinline__ uint32_t count_ge_desc(const uint32_t *a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] >= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t count_gt_desc(const uint32_t *a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] > v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// the cursor `s` of main.rs:1446-1448 is a running minimum over live reads of
+// m(r) = max(0, #regions with start >= aln_t_s - 1)
+__global__ void k_read_m(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
+                         const uint32_t *__restrict__ lq_start, uint32_t n_reg, int32_t *__restrict__ mval) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    if (!alive[r]) {
+        mval[r] = 0x7FFFFFFF;
+        return;
+    }
+    const uint32_t c = count_ge_desc(lq_start, n_reg, reads[r].aln_t_s);
+    mval[r] = c ? (int32_t)(c - 1) : 0;
+}
+
+__global__ void k_pair_count(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
+                             const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end,
+                             uint32_t n_reg, const int32_t *__restrict__ smin, uint32_t *__restrict__ pj,
+                             uint32_t *__restrict__ pcount) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    uint32_t cnt = 0, j = 0;
+    if (alive[r]) {
+        const uint32_t s = min((uint32_t)smin[r], n_reg - 1);
+        const uint32_t ts = reads[r].aln_t_s, te = reads[r].aln_t_e;
+        if (!(lq_start[s] < ts || lq_end[s] > te)) {
+            j = count_gt_desc(lq_end, n_reg, te); // main.rs:1454-1460
+            cnt = s - j + 1;
+        }
+    }
+    pj[r] = j;
+    pcount[r] = cnt;
+}
+
+__global__ void k_pair_fill(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ pcount,
+                            const uint32_t *__restrict__ poff, uint32_t *__restrict__ pair_region,
+                            uint32_t *__restrict__ pair_read, uint32_t *__restrict__ reg_npairs) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const uint32_t n = pcount[r], o = poff[r], j = pj[r];
+    for (uint32_t i = 0; i < n; ++i) {
+        pair_region[o + i] = j + i;
+        pair_read[o + i] = r;
+        atomicAdd(&reg_npairs[j + i], 1u);
+    }
+}
+
+struct CandCtx {
+    const np2_read_t *reads;
+    const uint8_t *nib;
+    const uint64_t *ck_off;
+    const uint32_t *ckpt;
+    const uint32_t *lq_start;
+    const uint32_t *lq_end;
+    const uint32_t *pj;
+    uint32_t ksize;
+};
+
+// Decode the candidate of (read r, region g): returns seq length; optionally writes the
+// sequence and the hashed first k-mer (main.rs:1478-1521).
+template <bool WRITE>
+__device__ uint32_t cand_decode(const CandCtx &cx, uint32_t r, uint32_t g, uint8_t *__restrict__ seq_out,
+                                uint64_t *kmer_out) {
+    const np2_read_t rd = cx.reads[r];
+    const uint8_t *base = cx.nib + rd.nib_off;
+    const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
+    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
+    // locate the reference column of t_pos == start from the nearest checkpoint at or before it
+    uint32_t col = 0, t = rd.aln_t_s;
+    const uint32_t ck_first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT;
+    const uint32_t cki = start >> CKPT_SHIFT;
+    if (cki >= ck_first) {
+        col = cx.ckpt[cx.ck_off[r] + (cki - ck_first)];
+        t = cki << CKPT_SHIFT;
+    }
+    while (t < start) {
+        ++col;
+        if (!(nib_at(base, col) & 8)) ++t;
+    }
+    const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
+    uint64_t fw = 0, rv = 0, l = 0;
+    uint32_t len = 0;
+    for (uint32_t c = col; c < rd.n_cols; ++c) {
+        const uint8_t nb = nib_at(base, c);
+        if (c != col && !(nb & 8)) ++t;
+        const uint8_t q = nb & 7;
+        if (q != 4) {
+            if (t <= end) {
+                if (WRITE) seq_out[len] = code_to_ascii(q);
+                ++len;
+            }
+            if (l < ksize) { // N/M codes are not filtered here (main.rs:1488-1492)
+                fw = ((fw << 2) | (uint64_t)q) & mask;
+                rv = (rv >> 2) | ((3ULL ^ (uint64_t)q) << shift);
+                ++l;
+            }
+            if (t > end && l >= ksize) break;
+        }
+        if (t > limit) break; // this column was the last one decoded
+    }
+    if (WRITE) {
+        uint64_t km = INVALID_KMER;
+        if (l >= ksize) km = yak_hash64(fw < rv ? fw : rv, mask);
+        *kmer_out = km;
+    }
+    return len;
+}
+
+__global__ void k_cand_measure(CandCtx cx, const uint32_t *__restrict__ pair_region,
+                               const uint32_t *__restrict__ pair_read, uint32_t n_pairs,
+                               uint32_t *__restrict__ pair_len) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    pair_len[i] = cand_decode<false>(cx, pair_read[i], pair_region[i], nullptr, nullptr);
+}
+
+// per region: keep the first 60 non-empty candidates in read order (main.rs:1474,1509)
+__global__ void k_region_rank(const uint32_t *__restrict__ reg_poff, uint32_t n_reg,
+                              const uint32_t *__restrict__ pair_len, uint32_t *__restrict__ pair_keep,
+                              uint32_t *__restrict__ reg_ncand) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_reg) return;
+    uint32_t c = 0;
+    for (uint32_t i = reg_poff[g]; i < reg_poff[g + 1]; ++i) {
+        const bool keep = pair_len[i] > 0 && c < LQSEQ_MAX_CAN_COUNT;
+        pair_keep[i] = keep ? pair_len[i] : 0; // kept length (0 = dropped)
+        c += keep;
+    }
+    reg_ncand[g] = c;
+}
+
+__global__ void k_cand_write(CandCtx cx, const uint32_t *__restrict__ pair_region,
+                             const uint32_t *__restrict__ pair_read, const uint32_t *__restrict__ pair_keep,
+                             const uint32_t *__restrict__ cand_idx, const uint32_t *__restrict__ seq_off,
+                             uint32_t n_pairs, uint32_t *__restrict__ cand_order, uint64_t *__restrict__ cand_kmer,
+                             uint32_t *__restrict__ cand_seq_off, uint8_t *__restrict__ cand_seq) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs || pair_keep[i] == 0) return;
+    const uint32_t ci = cand_idx[i];
+    const uint32_t so = seq_off[i];
+    cand_order[ci] = pair_read[i];
+    cand_seq_off[ci] = so;
+    cand_decode<true>(cx, pair_read[i], pair_region[i], cand_seq + so, &cand_kmer[ci]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K10/K11: HBM-resident yak table.  1024 sub-tables (one per file bucket, x & 1023), each
+// open-addressed with linear probing on (x >> 10); the slot holds the file word verbatim
+// ((x >> 10) << 10 | count, kmer.rs:52-58).  EMPTY = ~0 (a file word never has its top bits set).
+// ------------------------------------------------------------------------------------------
+static constexpr uint64_t YAK_EMPTY = ~0ULL;
+
+__global__ void k_yak_insert(const uint64_t *__restrict__ words, const uint64_t *__restrict__ bucket_off,
+                             uint32_t n_buckets, uint64_t *__restrict__ table, uint32_t cap_log2,
+                             uint32_t *__restrict__ dup_flag) {
+    const uint32_t b = blockIdx.y;
+    if (b >= n_buckets) return;
+    const uint64_t n = bucket_off[b + 1] - bucket_off[b];
+    const uint64_t capm = (1ULL << cap_log2) - 1;
+    uint64_t *tb = table + ((uint64_t)b << cap_log2);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = words[bucket_off[b] + i];
+        const uint64_t key = w >> 10;
+        uint64_t s = key & capm;
+        for (;;) {
+            const unsigned long long old = atomicCAS((unsigned long long *)&tb[s], (unsigned long long)YAK_EMPTY,
+                                                     (unsigned long long)w);
+            if (old == YAK_EMPTY) break;
+            if ((old >> 10) == key) {
+                atomicOr(dup_flag, 1u);
+                break;
+            }
+            s = (s + 1) & capm;
+        }
+    }
+}
+
+__device__ __forceinline__ uint16_t yak_get(const YakDev &y, uint64_t x, uint16_t min_count) {
+    // KmerInfo::get after retrieve_kmers(min_count) (kmer.rs:123-125,160-166), unwrap_or(0)
+    const uint64_t capm = (1ULL << y.cap_log2) - 1;
+    const uint64_t *tb = y.table + ((x & 1023) << y.cap_log2);
+    const uint64_t key = x >> 10;
+    uint64_t s = key & capm;
+    for (;;) {
+        const uint64_t w = tb[s];
+        if (w == YAK_EMPTY) return 0;
+        if ((w >> 10) == key) {
+            const uint16_t c = (uint16_t)(w & 1023);
+            return c >= min_count ? c : 0;
+        }
+        s = (s + 1) & capm;
+    }
+}
+
+__global__ void k_lookup(YakDev y, const uint64_t *__restrict__ hashes, uint64_t n, uint16_t min_count,
+                         uint16_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = yak_get(y, hashes[i], min_count);
+}
+
+// one wavefront per string: lanes own k-mer start offsets; min-count over all valid k-mers
+// (iter2kmer kmer.rs:255-287: a k-mer exists where the last k characters are all ACGT)
+__device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uint8_t *__restrict__ s, uint32_t len,
+                                                      uint16_t min_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = y.k;
+    const uint64_t mask = (1ULL << (2 * (uint64_t)k)) - 1, shift = 2 * ((uint64_t)k - 1);
+    uint32_t mn = 0xFFFFFFFFu;
+    if (len >= k) {
+        for (uint32_t st = lane; st + k <= len; st += 64) {
+            uint64_t fw = 0, rv = 0;
+            bool ok = true;
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t c = ascii_to_code(s[st + j]);
+                if (c >= 4) {
+                    ok = false;
+                    break;
+                }
+                fw = ((fw << 2) | c) & mask;
+                rv = (rv >> 2) | ((3ULL ^ c) << shift);
+            }
+            if (ok) mn = min(mn, (uint32_t)yak_get(y, yak_hash64(fw < rv ? fw : rv, mask), min_count));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+    return mn == 0xFFFFFFFFu ? (uint16_t)0 : (uint16_t)mn;
+}
+
+__global__ void k_score_strings(YakDev y, const uint8_t *__restrict__ strs, const uint64_t *__restrict__ off,
+                                uint64_t n, uint16_t min_count, uint16_t *__restrict__ out) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n) return;
+    const uint16_t sc = wave_score_string(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count);
+    if ((threadIdx.x & 63) == 0) out[w] = sc;
+}
+
+// retrieve_kmer_count (main.rs:740-778): len > k -> min over the candidate's own k-mers,
+// else the pre-hashed first k-mer, else 0
+__global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint8_t *__restrict__ cand_seq,
+                             const uint64_t *__restrict__ cand_kmer, uint32_t n_cand, uint16_t min_count,
+                             uint16_t *__restrict__ kscore) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_cand) return;
+    const uint32_t len = cand_seq_off[w + 1] - cand_seq_off[w];
+    uint16_t sc = 0;
+    if (len > y.k) {
+        sc = wave_score_string(y, cand_seq + cand_seq_off[w], len, min_count);
+    } else if ((threadIdx.x & 63) == 0) {
+        const uint64_t km = cand_kmer[w];
+        if (km != INVALID_KMER) sc = yak_get(y, km, min_count);
+    }
+    if ((threadIdx.x & 63) == 0) kscore[w] = sc;
+}
+
+} // namespace np2
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+namespace np2 {
+static inline dim3 grid1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes,
+                       uint32_t *err) {
+    hipLaunchKernelGGL(k_encode_ref, grid1(nbytes), dim3(256), 0, s, read0, L, refnib, nbytes, err);
+}
+void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
+                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
+                       uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err) {
+    hipLaunchKernelGGL(k_diff_reads, dim3((R + 3) / 4), dim3(256), 0, s, reads, R, nib, refw, refnib, L, keys, vals,
+                       shard_cnt, shard_cap, ck_off, ckpt, err);
+}
+void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
+                           const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
+                           uint32_t *out_vals) {
+    hipLaunchKernelGGL(k_compact_shards, dim3(NSHARD), dim3(256), 0, s, in_keys, in_vals, shard_cap, shard_cnt,
+                       shard_off, out_keys, out_vals);
+}
+void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
+    hipLaunchKernelGGL(k_init_alive, grid1(R), dim3(256), 0, s, reads, R, alive);
+}
+void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
+    if (n) hipLaunchKernelGGL(k_kill_reads, grid1(n), dim3(256), 0, s, ids, n, alive);
+}
+void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,
+                        uint32_t *gcount, uint32_t *gmin, uint32_t *flag) {
+    hipLaunchKernelGGL(k_group_nodes, grid1(T), dim3(256), 0, s, keys, vals, T, alive, gcount, gmin);
+    hipLaunchKernelGGL(k_flag_nonzero, grid1(T), dim3(256), 0, s, gcount, T, flag);
+}
+void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag) {
+    if (n) hipLaunchKernelGGL(k_flag_nonzero, grid1(n), dim3(256), 0, s, in, n, flag);
+}
+void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *gcount, const uint32_t *gmin,
+                          const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes) {
+    hipLaunchKernelGGL(k_scatter_nodes, grid1(T), dim3(256), 0, s, keys, gcount, gmin, idx, T, nd, node_cnt, n_nodes);
+}
+void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd) {
+    hipLaunchKernelGGL(k_order_nodes, grid1(L), dim3(256), 0, s, node_off, L, nd);
+}
+void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd) {
+    hipLaunchKernelGGL(k_cov_delta, grid1(R), dim3(256), 0, s, reads, R, alive, covd);
+}
+void launch_mark_runs(hipStream_t s, const uint32_t *node_off, uint32_t L, uint32_t *flag) {
+    hipLaunchKernelGGL(k_mark_runs, grid1(L), dim3(256), 0, s, node_off, L, flag);
+}
+void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx, uint32_t n, uint32_t *out,
+                        uint32_t *n_out) {
+    hipLaunchKernelGGL(k_scatter_idx, grid1(n), dim3(256), 0, s, flag, idx, n, out, n_out);
+}
+static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L}; }
+
+void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+               uint32_t max_runs, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,
+               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx) {
+    Graph g = mk_graph(gp);
+    if (max_runs)
+        hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, 64), dim3(64), 0, s, run_start, n_runs, g, nscore, nbesti,
+                           n0_besti, run_end, last_n0_score, total_gain);
+    hipLaunchKernelGGL(k_clean_gain, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.cov, gp.L, total_gain);
+    hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
+}
+void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
+                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
+                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin) {
+    Graph g = mk_graph(gp);
+    hipLaunchKernelGGL(k_emit_init, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.L, emit);
+    if (max_runs)
+        hipLaunchKernelGGL(k_bt_count, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
+                           n0_besti, best_idx, emit, path_begin);
+    hipLaunchKernelGGL(k_emit_fix, dim3(1), dim3(64), 0, s, emit, path_begin, gp.node_off, gp.L);
+}
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
+                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
+                     const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
+                     uint8_t *cns_base, uint8_t *cns_cls) {
+    Graph g = mk_graph(gp);
+    hipLaunchKernelGGL(k_clean_write, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, gp.L,
+                       cns_pos, cns_base, cns_cls);
+    if (max_runs)
+        hipLaunchKernelGGL(k_bt_write, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
+                           n0_besti, best_idx, emit, eoff, cns_pos, cns_base, cns_cls);
+}
+void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
+                    uint32_t M, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag,
+                    uint32_t *rstart, uint32_t *rend) {
+    hipLaunchKernelGGL(k_lq_scan, grid1(M), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M, lq_kind, lq_next,
+                       lq_nothead);
+    hipLaunchKernelGGL(k_lq_region, grid1(M), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M, lq_kind, lq_next,
+                       lq_nothead, rflag, rstart, rend);
+}
+void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
+                            const uint32_t *rend, uint32_t M, uint32_t *raw_start, uint32_t *raw_end,
+                            uint32_t *n_raw) {
+    hipLaunchKernelGGL(k_scatter_regions, grid1(M), dim3(256), 0, s, rflag, ridx, rstart, rend, M, raw_start, raw_end,
+                       n_raw);
+}
+void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                          uint32_t max_raw, uint32_t *headflag) {
+    hipLaunchKernelGGL(k_lq_merge_flag, grid1(max_raw), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag);
+}
+void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                           uint32_t max_raw, const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start,
+                           uint32_t *lq_end, uint32_t *n_reg) {
+    hipLaunchKernelGGL(k_lq_merge_write, grid1(max_raw), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag, hidx,
+                       lq_start, lq_end, n_reg);
+}
+void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
+                   uint32_t n_reg, int32_t *mval) {
+    hipLaunchKernelGGL(k_read_m, grid1(R), dim3(256), 0, s, reads, R, alive, lq_start, n_reg, mval);
+}
+void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive,
+                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin,
+                       uint32_t *pj, uint32_t *pcount) {
+    hipLaunchKernelGGL(k_pair_count, grid1(R), dim3(256), 0, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj,
+                       pcount);
+}
+void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
+                      uint32_t *pair_region, uint32_t *pair_read, uint32_t *reg_npairs) {
+    hipLaunchKernelGGL(k_pair_fill, grid1(R), dim3(256), 0, s, R, pj, pcount, poff, pair_region, pair_read,
+                       reg_npairs);
+}
+static CandCtx mk_cand(const CandPtrs &c) {
+    return CandCtx{c.reads, c.nib, c.ck_off, c.ckpt, c.lq_start, c.lq_end, c.pj, c.ksize};
+}
+void launch_cand_measure(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
+                         uint32_t n_pairs, uint32_t *pair_len) {
+    if (n_pairs)
+        hipLaunchKernelGGL(k_cand_measure, grid1(n_pairs, 64), dim3(64), 0, s, mk_cand(c), pair_region, pair_read,
+                           n_pairs, pair_len);
+}
+void launch_region_rank(hipStream_t s, const uint32_t *reg_poff, uint32_t n_reg, const uint32_t *pair_len,
+                        uint32_t *pair_keep, uint32_t *reg_ncand) {
+    hipLaunchKernelGGL(k_region_rank, grid1(n_reg, 64), dim3(64), 0, s, reg_poff, n_reg, pair_len, pair_keep,
+                       reg_ncand);
+}
+void launch_cand_write(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
+                       const uint32_t *pair_keep, const uint32_t *cand_idx, const uint32_t *seq_off, uint32_t n_pairs,
+                       uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq) {
+    if (n_pairs)
+        hipLaunchKernelGGL(k_cand_write, grid1(n_pairs, 64), dim3(64), 0, s, mk_cand(c), pair_region, pair_read,
+                           pair_keep, cand_idx, seq_off, n_pairs, cand_order, cand_kmer, cand_seq_off, cand_seq);
+}
+void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
+                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag) {
+    uint32_t gx = (uint32_t)((max_bucket + 255) / 256);
+    if (gx == 0) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_yak_insert, dim3(gx, n_buckets), dim3(256), 0, s, words, bucket_off, n_buckets, table,
+                       cap_log2, dup_flag);
+}
+void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count,
+                   uint16_t *out) {
+    if (n) hipLaunchKernelGGL(k_lookup, grid1(n), dim3(256), 0, s, y, hashes, n, min_count, out);
+}
+void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
+                          uint16_t min_count, uint16_t *out) {
+    if (n) hipLaunchKernelGGL(k_score_strings, grid1(n * 64), dim3(256), 0, s, y, strs, off, n, min_count, out);
+}
+void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
+                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore) {
+    if (n_cand)
+        hipLaunchKernelGGL(k_cand_score, grid1((uint64_t)n_cand * 64), dim3(256), 0, s, y, cand_seq_off, cand_seq,
+                           cand_kmer, n_cand, min_count, kscore);
+}
+} // namespace np2

@@ -1,0 +1,112 @@
+// Launcher declarations for np2_kernels.hip / np2_prims.hip (host-callable, all asynchronous on `s`).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime.h>
+#include "../../include/np2.h"
+
+namespace np2 {
+
+static constexpr int NSHARD = 256;          // exception-tuple output shards (atomic counters 128 B apart)
+static constexpr int SHARD_STRIDE = 32;     // in uint32_t
+
+struct NodeArrays { // exception nodes, grouped by position, ordered like Msa::sort (main.rs:227-229)
+    uint32_t *pos;
+    uint16_t *bases;
+    uint16_t *delta;
+    uint32_t *count;
+    uint32_t *minr;
+};
+struct GraphPtrs {
+    const uint8_t *refnib;
+    const uint32_t *node_off;
+    NodeArrays nd;
+    const int32_t *cov;
+    uint32_t L;
+};
+struct CandPtrs {
+    const np2_read_t *reads;
+    const uint8_t *nib;
+    const uint64_t *ck_off;
+    const uint32_t *ckpt;
+    const uint32_t *lq_start;
+    const uint32_t *lq_end;
+    const uint32_t *pj;
+    uint32_t ksize;
+};
+struct YakDev {
+    const uint64_t *table; // 1024 sub-tables of (1 << cap_log2) slots
+    uint32_t cap_log2;
+    uint32_t k;
+};
+
+void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t *err);
+void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
+                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
+                       uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err);
+void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
+                           const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys, uint32_t *out_vals);
+void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
+void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
+void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,
+                        uint32_t *gcount, uint32_t *gmin, uint32_t *flag);
+void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag);
+void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *gcount, const uint32_t *gmin,
+                          const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes);
+void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd);
+void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd);
+void launch_mark_runs(hipStream_t s, const uint32_t *node_off, uint32_t L, uint32_t *flag);
+void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx, uint32_t n, uint32_t *out, uint32_t *n_out);
+void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
+               int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
+               unsigned long long *total_gain, uint32_t *best_idx);
+void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
+                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
+                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin);
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
+                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
+                     const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
+                     uint8_t *cns_base, uint8_t *cns_cls);
+void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls, uint32_t M,
+                    uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag, uint32_t *rstart,
+                    uint32_t *rend);
+void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
+                            const uint32_t *rend, uint32_t M, uint32_t *raw_start, uint32_t *raw_end, uint32_t *n_raw);
+void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                          uint32_t max_raw, uint32_t *headflag);
+void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                           uint32_t max_raw, const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start,
+                           uint32_t *lq_end, uint32_t *n_reg);
+void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
+                   uint32_t n_reg, int32_t *mval);
+void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
+                       const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
+void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
+                      uint32_t *pair_region, uint32_t *pair_read, uint32_t *reg_npairs);
+void launch_cand_measure(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
+                         uint32_t n_pairs, uint32_t *pair_len);
+void launch_region_rank(hipStream_t s, const uint32_t *reg_poff, uint32_t n_reg, const uint32_t *pair_len,
+                        uint32_t *pair_keep, uint32_t *reg_ncand);
+void launch_cand_write(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
+                       const uint32_t *pair_keep, const uint32_t *cand_idx, const uint32_t *seq_off, uint32_t n_pairs,
+                       uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq);
+void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
+                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag);
+void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count, uint16_t *out);
+void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
+                          uint16_t min_count, uint16_t *out);
+void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
+                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore);
+
+// ---- np2_prims.hip: device-wide sort / scan plumbing (rocPRIM) -------------------------------
+// All take a caller-provided temp buffer; *_temp_bytes report the requirement for n elements.
+size_t prim_temp_bytes(size_t n);
+int prim_sort_pairs_u64_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                            const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+int prim_sort_pairs_u32_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout,
+                            const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+int prim_exclusive_sum_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
+int prim_inclusive_sum_i32(hipStream_t s, void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, size_t n);
+int prim_inclusive_min_i32(hipStream_t s, void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, size_t n);
+
+} // namespace np2
