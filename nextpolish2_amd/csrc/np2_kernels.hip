@@ -897,7 +897,10 @@ __device__ uint32_t cand_decode(const CandCtx &cx, uint32_t r, uint32_t g, uint8
     uint32_t col = 0, t = rd.aln_t_s;
     const uint32_t ck_first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT;
     const uint32_t cki = start >> CKPT_SHIFT;
-    if (cki >= ck_first) {
+    if (r == 0) { // the contig aligned to itself: column index == position (k_diff_reads skips read 0)
+        col = start;
+        t = start;
+    } else if (cki >= ck_first) {
         col = cx.ckpt[cx.ck_off[r] + (cki - ck_first)];
         t = cki << CKPT_SHIFT;
     }
