@@ -1,0 +1,138 @@
+"""bench.py — polished reference Mbp/s of the NextPolish2 hot path on MI355X.
+
+A "step" = one pass of the whole hot path (np2_polish_resident: dense diff -> sparse graph -> DP ->
+LQ regions -> candidates -> yak scoring -> phasing vote -> second pass -> seed/recheck/splice) over one
+HBM-resident synthetic contig.  Workload = BASELINE.json configs[1]: E. coli-sized 4.6 Mb contig,
+30x simulated HiFi, k21 yak only.  With --gpus N every rank polishes its own contig (weak scaling, no
+data-path collective) and the polished sequences are all-gathered over RCCL inside the timed step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--length", type=int, default=4_600_000, help="contig length (bp); default = E. coli")
+    ap.add_argument("--depth", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="bp of the same workload timed on the CPU oracle")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nextpolish2_amd import Opts, Polisher
+    from nextpolish2_amd.dist import all_gather_sequences
+    from nextpolish2_amd.synth import Synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # synthetic inputs (SURVEY.md §8d recipe), one contig per rank
+    syn = Synth(a.length, depth=a.depth, seed=1 + rank)
+    yaks = [syn.yak(21)]
+    pol = Polisher(yaks, device=local_rank)
+    contig = pol.upload(syn.pileup)  # pileup resident in HBM before the timed region
+    opts = Opts()
+
+    def step():
+        bases, pos = pol.polish_resident(contig, opts)
+        if world > 1:
+            all_gather_sequences([(rank, bases.tobytes())], device=dev)
+        return bases, pos
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    diff_ms = []
+    stage_ms = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        bases, pos = step()
+        tm = pol.timings()  # HIP events recorded on the context's own stream
+        diff_ms.append(tm.get("diff_reads", 0.0))
+        for k, v in tm.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v / a.steps
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    L = syn.pileup.L
+    value = world * L * a.steps / dt / 1e6
+    # roofline of the dominant kernel k_diff_reads: algorithmic bytes per launch =
+    # 0.5 B per pileup column (packed nibbles, read once) + 0.5 B per contig base (nibble-packed contig)
+    n_cols = syn.pileup.n_columns() - L  # read 0 (the contig itself) is not streamed
+    alg_bytes = 0.5 * n_cols + 0.5 * L
+    avg_ms = float(np.mean(diff_ms)) if diff_ms else 0.0
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    out = {
+        "metric": "polished reference Mbp/s (whole node) at 30x HiFi + k21 yak; FASTA identical to oracle",
+        "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "E. coli-sized contig, 30x simulated HiFi, k21 yak only, 1 contig per MI355X",
+                   "contig_bp": L, "depth": a.depth, "reads": syn.pileup.n_reads, "pileup_columns": int(n_cols),
+                   "yak_k": [21], "iter_count": 2, "parallelism": f"contig-sharded x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "k_diff_reads", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4)},
+        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+    }
+
+    if rank == 0 and not a.no_cpu_baseline:
+        # CPU baseline: the oracle (a port of the reference algorithm; the Rust reference cannot be
+        # built here) on a bounded sample of the same workload, one thread like one reference worker.
+        from oracle.np2_oracle import Oracle
+        sl = min(a.cpu_sample, a.length)
+        s2 = syn if sl == a.length else Synth(sl, depth=a.depth, seed=1)
+        y2 = yaks if s2 is syn else [s2.yak(21)]
+        o = Oracle(y2)
+        t1 = time.perf_counter()
+        ob, op = o.polish(s2.pileup, opts)
+        cpu_dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(s2.pileup.L / cpu_dt / 1e6, 4), "unit": "Mbp/s", "cores": 1,
+                               "kind": "port", "sample": f"{s2.pileup.L} bp contig of the same workload, 1 thread "
+                               f"(one reference worker = one contig per thread), in-memory yak table",
+                               "host_cores": os.cpu_count()}
+        if s2 is syn:
+            out["fasta_identical_to_oracle"] = bool(np.array_equal(ob, bases) and np.array_equal(op, pos))
+        else:
+            gb, gp = Polisher(y2, device=local_rank).polish(s2.pileup, opts)
+            out["fasta_identical_to_oracle"] = bool(np.array_equal(ob, gb) and np.array_equal(op, gp))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, contigs sharded across ranks.
+
+Contigs are fully independent in the reference (one contig per worker thread, src/main.rs:1726-1837),
+so the data path needs no collective; the only exchange is the final all-gather of the polished
+per-contig sequences (RCCL over xGMI when the backend is "nccl"; gloo on CPU for tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def assign_contigs(lengths, world_size):
+    """Longest-first greedy assignment of contigs to ranks -> list of contig-index lists per rank.
+
+    Deterministic: ties broken by contig index, least-loaded rank with the smallest rank id wins."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(lengths[i])
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def all_gather_sequences(local, device=None, group=None):
+    """All-gather variable-length byte sequences.
+
+    `local` is a list of (contig_index, bytes-like); every rank returns the same dict
+    {contig_index: bytes}.  Payload = one padded uint8 all_gather + one int64 header all_gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return {int(i): bytes(s) for i, s in local}
+    device = device or torch.device("cpu")
+    n_local = len(local)
+    hdr = torch.zeros(1, dtype=torch.int64, device=device)
+    hdr[0] = n_local
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, hdr, group=group)
+    max_n = max(int(c.item()) for c in counts)
+    meta = torch.full((max(max_n, 1), 2), -1, dtype=torch.int64, device=device)
+    for k, (i, s) in enumerate(local):
+        meta[k, 0] = int(i)
+        meta[k, 1] = len(s)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    total_local = sum(len(s) for _, s in local)
+    tot = torch.tensor([total_local], dtype=torch.int64, device=device)
+    tots = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(tots, tot, group=group)
+    max_bytes = max(1, max(int(t.item()) for t in tots))
+    buf = torch.zeros(max_bytes, dtype=torch.uint8, device=device)
+    if total_local:
+        cat = np.concatenate([np.frombuffer(bytes(s), dtype=np.uint8) for _, s in local if len(s)])
+        buf[:total_local] = torch.from_numpy(cat.copy()).to(device)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = {}
+    for r in range(world):
+        off = 0
+        m = metas[r].cpu().numpy()
+        b = bufs[r].cpu().numpy()
+        for k in range(int(counts[r].item())):
+            idx, ln = int(m[k, 0]), int(m[k, 1])
+            out[idx] = b[off:off + ln].tobytes()
+            off += ln
+    return out

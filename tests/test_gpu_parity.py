@@ -1,0 +1,162 @@
+"""GPU parity tests: the HIP path (through the C-ABI, include/np2.h) vs the CPU oracle.
+
+Integer/byte work: the bar is bit-exact, at every stage and on the final consensus."""
+import numpy as np
+import pytest
+
+from golden_util import golden_cases, load_golden
+from nextpolish2_amd import Opts, Polisher
+from nextpolish2_amd._types import Pileup, Yak
+from nextpolish2_amd.api import Np2Error
+from nextpolish2_amd.synth import Synth, pileup_from_alignments
+from oracle import np2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ["graph.off", "graph.bases", "graph.delta", "graph.count", "cns_raw.pos", "cns_raw.base", "lq.start", "lq.end",
+          "cand.cand_off", "cand.order", "cand.seq_off", "cand.seq", "cand.kmer", "cand.kscore", "hete.lable",
+          "hete.kscore", "invalid_ids", "seed.lable", "seed.sudo", "seed.cand_off", "seed.order", "cns_succ.pos",
+          "cns_succ.base", "rech0.kscore", "rech0.lable", "rech0.sudo", "cns_rech0.pos", "cns_rech0.base",
+          "rech1.kscore", "rech1.lable", "rech1.sudo", "cns_rech1.pos", "cns_rech1.base"]
+
+
+def check_all_stages(pu, yaks, opts):
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    ob, op = o.polish(pu, opts)
+    g = Polisher(yaks)
+    g.set_trace(True)
+    gb, gp = g.polish(pu, opts)
+    for ps in range(opts.iter_count):
+        for st in STAGES:
+            a, b = o.trace(ps, st), g.trace(ps, st)
+            assert (a is None) == (b is None), (ps, st)
+            if a is not None:
+                assert a.shape == b.shape and np.array_equal(a, b), f"pass {ps} stage {st} differs"
+    assert np.array_equal(ob, gb) and np.array_equal(op, gp)
+    return gb, gp
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixtures(name):
+    pu, yaks, opts, exp_b, exp_p, _ = load_golden(name)
+    gb, gp = Polisher(yaks).polish(pu, opts)
+    assert np.array_equal(gb, exp_b) and np.array_equal(gp, exp_p)
+
+
+@pytest.mark.parametrize("seed,diploid,ks", [(31, False, [21]), (32, True, [21, 31]), (33, True, [21]), (34, False, [17, 21, 31])])
+def test_stage_parity_synthetic(seed, diploid, ks):
+    s = Synth(50000, depth=30, seed=seed, diploid=diploid, read_len_mean=8000.0, read_len_sd=1500.0)
+    check_all_stages(s.pileup, [s.yak(k) for k in ks], Opts())
+
+
+@pytest.mark.parametrize("opts", [Opts(iter_count=1), Opts(iter_count=3), Opts(model="len"), Opts(use_all_reads=True),
+                                  Opts(min_kmer_count=60), Opts(max_indel_len=0)])
+def test_stage_parity_options(opts, small_diploid):
+    s, yaks = small_diploid
+    check_all_stages(s.pileup, yaks, opts)
+
+
+def test_high_error_reads_and_low_depth():
+    s = Synth(30000, depth=8, seed=41, diploid=True, read_err_rate=0.02, read_len_mean=4000.0, read_len_sd=800.0)
+    check_all_stages(s.pileup, [s.yak(21)], Opts())
+
+
+def test_deep_pileup_hits_the_60_candidate_cap():
+    s = Synth(20000, depth=120, seed=42, read_len_mean=5000.0, read_len_sd=800.0)
+    gb, _ = check_all_stages(s.pileup, [s.yak(21)], Opts())
+    assert gb.tobytes() == s.hap1
+
+
+def test_dropped_reads_and_position_zero_starts():
+    s = Synth(30000, depth=20, seed=43, read_len_mean=5000.0, read_len_sd=800.0)
+    pu = s.pileup
+    reads = pu.reads.copy()
+    reads["flags"][5::7] = 1  # align_bases == [] but index retained (main.rs:571)
+    check_all_stages(Pileup(pu.ref, reads, pu.nibbles), [s.yak(21)], Opts())
+
+
+def test_hand_made_edge_cases():
+    rng = np.random.default_rng(7)
+    truth = "".join("ACGT"[i] for i in rng.integers(0, 4, 400))
+    ref = truth[:150] + "T" + truth[150:]  # contig carries an extra base
+    t_ins = ref
+    q_del = truth[:150] + "-" + truth[150:]
+    alns = [(0, t_ins, q_del)] * 6 + [(0, ref, ref)] * 2
+    # a read with a long insertion and lower-case / N letters
+    t2 = ref[:60] + "-----" + ref[60:300]
+    q2 = ref[:60] + "acgNn" + ref[60:300]
+    alns += [(0, t2, q2), (3, ref[3:], ref[3:]), (1, ref[1:390], ref[1:390])]
+    pu = pileup_from_alignments(ref, alns)
+    k = 21
+    from test_oracle import yak_from_seqs
+    check_all_stages(pu, [yak_from_seqs([truth], k)], Opts())
+
+
+def test_non_acgt_reference_letters():
+    rng = np.random.default_rng(9)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 300))
+    ref = base[:100] + "R" + base[101:200] + "n" + base[201:]
+    alns = [(0, ref, base)] * 5 + [(0, ref, ref)] * 2
+    from test_oracle import empty_yak
+    check_all_stages(pileup_from_alignments(ref, alns), [empty_yak()], Opts())
+
+
+def test_score_strings_and_lookup_match_oracle(small_diploid):
+    s, yaks = small_diploid
+    rng = np.random.default_rng(3)
+    h = s.hap1
+    strs = []
+    for _ in range(500):
+        a = int(rng.integers(0, len(h) - 200))
+        ln = int(rng.integers(0, 120))
+        b = bytearray(h[a:a + ln])
+        if ln and rng.random() < 0.3:
+            b[int(rng.integers(0, ln))] = ord("N")
+        if ln and rng.random() < 0.3:
+            b[int(rng.integers(0, ln))] = ord("acgt"[int(rng.integers(0, 4))])
+        strs.append(bytes(b))
+    g, o = Polisher(yaks), orc.Oracle(yaks)
+    for yi in range(len(yaks)):
+        for mk in (1, 5, 40):
+            assert np.array_equal(g.score_strings(yi, strs, mk), o.score_strings(yi, strs, mk))
+        hashes = np.concatenate([yaks[yi].words[:2000] >> np.uint64(10) << np.uint64(10), rng.integers(0, 1 << 40, 500, dtype=np.uint64)])
+        # reconstruct full hashes for stored words: bucket index is implied by the file position
+        offs = yaks[yi].bucket_off
+        bucket = np.searchsorted(offs, np.arange(2000), side="right") - 1
+        hashes[:2000] |= bucket.astype(np.uint64)
+        assert np.array_equal(g.lookup_hashes(yi, hashes, 5), o.lookup_hashes(yi, hashes, 5))
+
+
+def test_bad_inputs_are_rejected_with_error_codes(small_haploid):
+    s, yaks = small_haploid
+    g = Polisher(yaks)
+    pu = s.pileup
+    reads = pu.reads.copy()
+    reads["n_cols"][3] += 2  # descriptor disagrees with the stream
+    with pytest.raises(Np2Error) as e:
+        g.polish(Pileup(pu.ref, reads, pu.nibbles), Opts())
+    assert e.value.code == -1
+    reads = pu.reads.copy()
+    reads["aln_t_s"][0] = 1  # reads[0] must be the contig itself
+    with pytest.raises(Np2Error):
+        g.polish(Pileup(pu.ref, reads, pu.nibbles), Opts())
+    with pytest.raises(Np2Error):
+        Polisher([Yak(33, np.zeros(0, np.uint64), np.zeros(1025, np.uint64))])
+    # the context is still usable afterwards
+    gb, _ = g.polish(pu, Opts())
+    assert gb.tobytes() == s.hap1
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] scale (4.6 Mb, 30x, k21): size-independent properties — the polished
+    sequence equals the simulated truth, positions are non-decreasing, and a second call is identical."""
+    s = Synth(4_600_000, depth=30, seed=1)
+    g = Polisher([s.yak(21)])
+    c = g.upload(s.pileup)
+    b1, p1 = g.polish_resident(c, Opts())
+    b2, p2 = g.polish_resident(c, Opts())
+    assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+    assert np.all(np.diff(p1.astype(np.int64)) >= 0)
+    assert b1.tobytes() == s.hap1
+    assert s.pileup.ref.tobytes() != s.hap1

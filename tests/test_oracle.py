@@ -1,0 +1,265 @@
+"""CPU tests of the oracle (oracle/np2_oracle.cpp) against hand-derived known answers.
+
+The reference ships no tests or golden vectors for this path: every expectation
+below is derived by hand from the Rust source (cited per test)."""
+import numpy as np
+import pytest
+
+from nextpolish2_amd import Opts
+from nextpolish2_amd._types import Yak
+from nextpolish2_amd.synth import Synth, pack_alignment, pileup_from_alignments
+from oracle import np2_oracle as orc
+
+
+def empty_yak(k=21):
+    return Yak(k, np.zeros(0, np.uint64), np.zeros(1025, np.uint64))
+
+
+def yak_from_seqs(seqs, k, count=50):
+    """yak table holding every canonical k-mer of `seqs` with a fixed count (kmer.rs:72-170 layout)."""
+    words = {}
+    mask = (1 << (2 * k)) - 1
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for s in seqs:
+        fw = rv = 0
+        l = 0
+        for ch in s:
+            if ch not in code:
+                l = 0
+                continue
+            c = code[ch]
+            fw = ((fw << 2) | c) & mask
+            rv = (rv >> 2) | ((3 ^ c) << (2 * (k - 1)))
+            l += 1
+            if l >= k:
+                h = orc.yak_hash64(min(fw, rv), k)
+                words[h] = count
+    buckets = [[] for _ in range(1024)]
+    for h, c in words.items():
+        buckets[h & 1023].append(((h >> 10) << 10) | c)
+    off = np.zeros(1025, np.uint64)
+    flat = []
+    for b in range(1024):
+        flat.extend(buckets[b])
+        off[b + 1] = len(flat)
+    return Yak(k, np.array(flat, dtype=np.uint64), off)
+
+
+def test_pack_alignment_matches_survey_example():
+    # SURVEY.md A.1 / main.rs:279-312: ref ACGT at pos 10, read AC-T with TT inserted after C
+    b, te, n = pack_alignment("AC--GT", "ACtt-T", 10)
+    assert n == 6 and te == 13
+    assert b.tolist() == [0x01, 0xBB, 0x43, 0xFF]
+    # odd number of columns: terminator in the low nibble, one spare zero byte (vec![0; len+1])
+    b, te, n = pack_alignment("ACG", "ACG", 0)
+    assert b.tolist() == [0x01, 0x2F, 0x00] and te == 2
+
+
+def test_seq_num_codes_via_packing():
+    # kmer.rs:11-22: A/a 0, C/c 1, G/g 2, T/t/U/u 3, N/n 5, M/m 6, everything else 4 ('-')
+    b, _, _ = pack_alignment("AAAAAAAAAAAAAA", "AaCcGgTtUuNnMm", 0)
+    nib = [(x >> 4, x & 15) for x in b[:7]]
+    assert [v for p in nib for v in p] == [0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 5, 5, 6, 6]
+    b, _, _ = pack_alignment("AAAA", "RY-*", 0)
+    assert [(x >> 4, x & 15) for x in b[:2]] == [(4, 4), (4, 4)]
+
+
+def test_yak_hash64_is_a_bijection_on_small_k():
+    # kmer.rs:223-233: invertible hash masked to 2k bits
+    k = 5
+    hs = {orc.yak_hash64(x, k) for x in range(1 << (2 * k))}
+    assert len(hs) == 1 << (2 * k) and max(hs) < 1 << (2 * k)
+
+
+def test_fxhash_constants():
+    # FxHash of u32 k = k * 0x517cc1b727220a95 mod 2^64; h2 = h >> 57
+    m = (1 << 64) - 1
+    assert (1 * 0x517CC1B727220A95) & m == 0x517CC1B727220A95
+    assert ((1 * 0x517CC1B727220A95) & m) >> 57 == 40
+    assert (2 * 0x517CC1B727220A95) & m == 0xA2F9836E4E44152A
+    assert (3 * 0x517CC1B727220A95) & m == 0xF476452575661FBF
+
+
+def test_all_reads_agree_is_identity():
+    # no LQ region -> consensus == contig, pos = 0..L-1 (main.rs:1638-1639)
+    ref = "ACGTTGCAAGCTTAGGCTAACGTAGCTAGGATCCGATTACGCTAGCTAGGCTTAAGCG" * 3
+    alns = [(0, ref, ref)] * 5 + [(0, ref[:-5], ref[:-5])] * 3
+    pu = pileup_from_alignments(ref, alns)
+    o = orc.Oracle([empty_yak()])
+    o.set_trace(True)
+    b, p = o.polish(pu, Opts())
+    assert b.tobytes().decode() == ref
+    assert p.tolist() == list(range(len(ref)))
+    assert len(o.trace(1, "lq.start")) == 0
+
+
+def test_read_starts_lower_qv_and_open_lq_regions():
+    # a read's first two nodes carry head sentinels (main.rs:579-580), so at its start position it does
+    # not support the contig's node: 3 of 9 reads starting at position 40 -> qv = 66 < 95 -> LQ region
+    ref = "ACGTTGCAAGCTTAGGCTAACGTAGCTAGGATCCGATTACGCTAGCTAGGCTTAAGCG" * 3
+    alns = [(0, ref, ref)] * 5 + [(40, ref[40:], ref[40:])] * 3
+    o = orc.Oracle([empty_yak()])
+    o.set_trace(True)
+    b, p = o.polish(pileup_from_alignments(ref, alns), Opts())
+    st, en = o.trace(1, "lq.start"), o.trace(1, "lq.end")
+    assert len(st) == 1 and st[0] < 40 < en[0]
+    assert b.tobytes().decode() == ref  # all candidates equal the contig -> sequence unchanged
+
+
+def make_snv_case(n_alt=8, n_ref=0, k=21):
+    """contig has a wrong base; n_alt reads carry the true base, n_ref reads agree with the contig."""
+    rng = np.random.default_rng(5)
+    truth = "".join("ACGT"[i] for i in rng.integers(0, 4, 200))
+    pos = 100
+    wrong = "ACGT"[("ACGT".index(truth[pos]) + 1) % 4]
+    ref = truth[:pos] + wrong + truth[pos + 1:]
+    alns = [(0, ref, truth)] * n_alt + [(0, ref, ref)] * n_ref
+    return truth, ref, pileup_from_alignments(ref, alns), pos
+
+
+def test_snv_is_fixed_when_kmers_support_the_read_allele():
+    # final pass: ref candidate has kscore 0 (its k-mer is absent), read candidate > 0
+    # -> fill_seed_lqseqs picks the read allele (main.rs:862-914), splice (main.rs:1027-1058)
+    truth, ref, pu, pos = make_snv_case()
+    o = orc.Oracle([yak_from_seqs([truth], 21)])
+    o.set_trace(True)
+    b, p = o.polish(pu, Opts())
+    assert b.tobytes().decode() == truth
+    # one LQ region around the SNV; candidates: contig (order 0) + 8 reads
+    st, en = o.trace(1, "lq.start"), o.trace(1, "lq.end")
+    assert len(st) == 1 and st[0] <= pos <= en[0]
+    assert o.trace(1, "cand.order").tolist() == list(range(9))
+    ks = o.trace(1, "cand.kscore").tolist()
+    assert ks[0] == 0 and all(x == 50 for x in ks[1:])
+    # spliced bases all carry pos == region start (main.rs:1039-1045)
+    assert (p == st[0]).sum() == len(o.trace(1, "seed.sudo"))
+
+
+def test_snv_kept_when_no_kmer_supports_any_candidate():
+    # every kscore is 0 -> max1_c = 0 < min_c -> order_stat[0] = min_c -> contig sequence kept (main.rs:897-899)
+    truth, ref, pu, pos = make_snv_case()
+    o = orc.Oracle([empty_yak()])
+    b, _ = o.polish(pu, Opts())
+    assert b.tobytes().decode() == ref
+
+
+def test_min_kmer_count_filter_is_strictly_less_than():
+    # kmer.rs:160-162: words with count < min_kmer_count are ignored (help text says <=, code is <)
+    truth, ref, pu, pos = make_snv_case()
+    y = yak_from_seqs([truth], 21, count=5)
+    assert orc.Oracle([y]).polish(pu, Opts(min_kmer_count=5))[0].tobytes().decode() == truth
+    assert orc.Oracle([y]).polish(pu, Opts(min_kmer_count=6))[0].tobytes().decode() == ref
+
+
+def test_dp_scores_and_graph_nodes_by_hand():
+    # 3 reads + contig over "ACGTACGTAC": graph at p>=2 has one node AAA with count 4 (main.rs:84-102)
+    ref = "ACGTACGTACGTAGCTAGCATCGATCGAT"
+    pu = pileup_from_alignments(ref, [(0, ref, ref)] * 3)
+    o = orc.Oracle([empty_yak()])
+    o.set_trace(True)
+    o.polish(pu, Opts())
+    off, bases, delta, count = (o.trace(0, "graph." + n) for n in ("off", "bases", "delta", "count"))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    # p = 0: (head, head, A): f14 set -> 0x4FF0 | code ; delta 0
+    assert off[1] - off[0] == 1 and bases[0] == (0x4FF0 | code[ref[0]]) and delta[0] == 0 and count[0] == 4
+    # p = 1: (head(-1,1), c0, c1): no flags, delta(b1) = 1
+    assert bases[1] == (0x0F00 | code[ref[0]] << 4 | code[ref[1]]) and delta[1] == 1
+    for p in range(2, len(ref)):
+        assert off[p + 1] - off[p] == 1
+        assert bases[off[p]] == (code[ref[p - 2]] << 8 | code[ref[p - 1]] << 4 | code[ref[p]])
+        assert count[off[p]] == 4
+
+
+def test_insertion_nodes_flags_and_order():
+    # one read with a 2-base insertion after position 10: nodes at p=10 with delta3 = 1, 2 follow
+    # the delta3 = 0 nodes (Msa::sort, main.rs:227-229); flags per Kmer::new (main.rs:84-92)
+    ref = "ACGTTGCAAGCTTAGGCTAACGTAGCTAGG"
+    t = ref[:11] + "--" + ref[11:]
+    q = ref[:11] + "GG" + ref[11:]
+    pu = pileup_from_alignments(ref, [(0, t, q), (0, ref, ref)])
+    o = orc.Oracle([empty_yak()])
+    o.set_trace(True)
+    o.polish(pu, Opts())
+    off, bases, delta = (o.trace(0, "graph." + n) for n in ("off", "bases", "delta"))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    nodes10 = [(int(bases[i]), int(delta[i])) for i in range(off[10], off[11])]
+    r = [code[c] for c in ref]
+    aaa = r[8] << 8 | r[9] << 4 | r[10]
+    aa_ = 0x1000 | r[9] << 8 | r[10] << 4 | 2          # (9,0) (10,0) (10,1): f12
+    a__ = 0x5000 | r[10] << 8 | 2 << 4 | 2             # (10,0) (10,1) (10,2): f14|f12
+    assert nodes10 == [(aaa, 0), (aa_, 0), (a__, 0)]
+    nodes11 = [(int(bases[i]), int(delta[i])) for i in range(off[11], off[12])]
+    # contig/read-2 node first (first seen by read 0), then the inserting read's A-A node (delta(b1)=1)
+    assert nodes11 == [(r[9] << 8 | r[10] << 4 | r[11], 0), (0x4000 | 2 << 8 | 2 << 4 | r[11], 1)]
+
+
+def test_non_acgtnm_reference_letters_vanish():
+    # SEQ_NUM maps IUPAC letters to '-' (code 4); b3 == '-' emits nothing (main.rs:1574)
+    ref = "ACGTTGCAAGCTTAGGCTAACGTRGCTAGGATCCGATTACG"
+    clean = ref.replace("R", "A")
+    pu = pileup_from_alignments(ref, [(0, ref, clean)] * 4)
+    o = orc.Oracle([empty_yak()])
+    b, p = o.polish(pu, Opts())
+    # coverage counts '-' columns too, so the reads' A wins the DP at that column
+    assert len(b) in (len(ref), len(ref) - 1)
+    assert "R" not in b.tobytes().decode()
+
+
+def test_iter_count_one_skips_phasing(small_diploid):
+    s, yaks = small_diploid
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    o.polish(s.pileup, Opts(iter_count=1))
+    assert o.trace(0, "invalid_ids") is None and o.trace(0, "cns_succ.pos") is not None
+
+
+def test_haploid_polish_recovers_truth(small_haploid):
+    s, yaks = small_haploid
+    b, _ = orc.Oracle(yaks).polish(s.pileup, Opts())
+    assert s.pileup.ref.tobytes() != s.hap1
+    assert b.tobytes() == s.hap1
+
+
+def test_diploid_phasing_drops_reads_and_keeps_reference_haplotype(small_diploid):
+    s, yaks = small_diploid
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    b, _ = o.polish(s.pileup, Opts())
+    inv = o.trace(0, "invalid_ids")
+    assert 0.25 * s.pileup.n_reads < len(inv) < 0.75 * s.pileup.n_reads
+    assert b.tobytes() == s.hap1
+    # -r keeps reads that disagree with the contig haplotype (main.rs:976-978)
+    o2 = orc.Oracle(yaks)
+    o2.polish(s.pileup, Opts(use_all_reads=True))
+    assert o2.stats()["n_invalid"] <= len(inv)
+
+
+def test_louvain_two_cliques_loser_is_the_smaller_conflicting_community():
+    # louvain.rs: +1 inside cliques {1,2,3} and {4,5}, -1 across -> two communities in conflict;
+    # -m len: sorted by weight desc, the lighter one loses (louvain.rs:319,324-339)
+    e = []
+    def add(a, b, w):
+        e.append((a, b, w)); e.append((b, a, w))
+    for a, b in [(1, 2), (1, 3), (2, 3)]:
+        add(a, b, 1.0)
+    add(4, 5, 1.0)
+    for a in (1, 2, 3):
+        for b in (4, 5):
+            add(a, b, -1.0)
+    assert orc.phase_communities(e, None) == [4, 5]
+    # -m ref: communities ranked by agreement with the contig haplotype (louvain.rs:294-316)
+    assert orc.phase_communities(e, {4: 1.0, 5: 1.0, 1: -1.0}) == [1, 2, 3]
+
+
+def test_louvain_no_conflict_no_losers():
+    e = [(1, 2, 1.0), (2, 1, 1.0), (3, 4, 1.0), (4, 3, 1.0)]
+    assert orc.phase_communities(e, None) == []
+
+
+def test_refpanic_is_reported_not_crashed():
+    # contig with only '-'-coded letters in an LQ region cannot happen easily; instead check the
+    # iter_count validation path and that errors come back as exceptions
+    ref = "ACGT" * 10
+    pu = pileup_from_alignments(ref, [(0, ref, ref)])
+    with pytest.raises(RuntimeError):
+        orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=0))
