@@ -109,6 +109,14 @@ struct np2_ctx {
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;
     DevBuf<uint32_t> scal; // device scalars: see enum below
+    // region logic
+    DevBuf<uint8_t> reg_lable, grp, ref_seen, bad, cns_base2, rech_groups;
+    DevBuf<uint32_t> ecount, first_reg, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
+        sp_idx_e, sp_flag, sp_slot, ap_g, ap_s, ap_e, rech, rech_head, rech_gslot, rech_njobs, rech_joboff, job_len,
+        job_off32;
+    DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
+    DevBuf<uint64_t> ekey, ekey_s;
+    DevBuf<uint16_t> keep_ks;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
     DevBuf<uint16_t> sscore;
@@ -117,7 +125,7 @@ struct np2_ctx {
 namespace {
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_COUNT = 16 };
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_COUNT = 24 };
 
 struct EventTimer {
     np2_ctx *cx;
@@ -181,135 +189,178 @@ void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
 }
 
 // ------------------------------------------------------------------------------------------
-// host-side region logic (operates on the GPU-built candidate tables)
+// region state (device-resident; host keeps only counters)
 // ------------------------------------------------------------------------------------------
 static const uint8_t LB_TEMP = 0x01, LB_SUCC = 0x80, LB_HETE = 0x40, LB_RECH = 0x20; // main.rs:655-658
 
-struct Cand {
-    uint32_t order;
-    uint16_t kscore;
-    uint32_t so, len; // sequence = pool[so, so+len)
-};
-struct Region {
-    uint32_t start, end;
-    uint8_t lable = 0;
-    std::string sudoseed;
-    std::vector<Cand> seqs;
-};
 struct Cns {
     std::vector<uint32_t> pos;
     std::vector<uint8_t> base;
     size_t size() const { return pos.size(); }
 };
-struct RegionSet {
-    std::vector<Region> regs;
-    std::vector<uint8_t> pool;
-    bool same(const Cand &a, const Cand &b) const {
-        return a.len == b.len && memcmp(pool.data() + a.so, pool.data() + b.so, a.len) == 0;
-    }
-    std::string str(const Cand &c) const { return std::string((const char *)pool.data() + c.so, c.len); }
-};
-
-struct GroupStat { // fill_order_stat, main.rs:813-849
-    size_t stats[LQSEQ_MAX_CAN_COUNT];
-    std::vector<std::pair<uint32_t, size_t>> by_order; // HashMap<u32, usize>: order -> count
-    size_t max1_c = 0, max1_p = 0, max2_c = 0, max2_p = 0;
-    size_t *find(uint32_t order) {
-        for (auto &e : by_order)
-            if (e.first == order) return &e.second;
-        return nullptr;
-    }
-    size_t get_or0(uint32_t order) {
-        size_t *p = find(order);
-        return p ? *p : 0;
-    }
-    void set(uint32_t order, size_t v) {
-        size_t *p = find(order);
-        if (p)
-            *p = v;
-        else
-            by_order.emplace_back(order, v);
-    }
-};
-
-void group_stats(const RegionSet &rs, const Region &rg, GroupStat &g) {
-    g.max1_c = g.max1_p = g.max2_c = g.max2_p = 0;
-    std::fill(g.stats, g.stats + LQSEQ_MAX_CAN_COUNT, 0);
-    g.by_order.clear();
-    const size_t n = rg.seqs.size();
-    for (size_t a = 0; a < n; ++a) {
-        if (rg.seqs[a].kscore == 0 || g.stats[a] > 0) continue;
-        size_t c = 0;
-        for (size_t b = a; b < n; ++b) c += rs.same(rg.seqs[b], rg.seqs[a]);
-        g.set(rg.seqs[a].order, c);
-        for (size_t b = a; b < n; ++b)
-            if (rs.same(rg.seqs[b], rg.seqs[a])) g.stats[b] = c;
-        if (c > g.max1_c || (c == g.max1_c && rg.seqs[a].order == 0)) {
-            g.max2_c = g.max1_c, g.max2_p = g.max1_p;
-            g.max1_c = c, g.max1_p = a;
-        } else if (g.max1_p == g.max2_p || c > g.max2_c) {
-            g.max2_c = c, g.max2_p = a;
-        }
-    }
-}
-inline size_t min_support(size_t n) { return n >= 9 ? 3 : (n >= 6 ? 2 : 1); } // get_min_count, main.rs:803-811
-
-bool differs_after_hp_compression(const uint8_t *a, size_t na, const uint8_t *b, size_t nb) { // is_valid_snp
-    size_t i = 0, j = 0;
-    while (i < na && j < nb) {
-        if (a[i] != b[j]) return true;
-        while (i + 1 < na && a[i] == a[i + 1]) ++i;
-        while (j + 1 < nb && b[j] == b[j + 1]) ++j;
-        ++i, ++j;
-    }
-    return false;
+void trace_cns(np2_ctx *cx, int pass, const std::string &tag, const Cns &c) {
+    trace_put(cx, pass, tag + ".pos", c.pos);
+    trace_put(cx, pass, tag + ".base", c.base);
 }
 
-// phasing pass: mark_hete_lqseqs (main.rs:916-946) + phase_reads_by_lqseqs (948-1015)
-std::vector<uint32_t> phasing_vote(RegionSet &rs, bool asref, bool use_all_reads) {
-    GroupStat g;
-    for (Region &rg : rs.regs) {
-        group_stats(rs, rg, g);
-        const size_t min_c = min_support(rg.seqs.size());
-        if (g.max2_c < min_c) continue;
-        const Cand &c1 = rg.seqs[g.max1_p], &c2 = rg.seqs[g.max2_p];
-        if (!(c1.len == c2.len || (rg.seqs.size() >= 6 && g.max2_c >= g.max1_c / 2))) continue;
-        if (!differs_after_hp_compression(rs.pool.data() + c1.so, c1.len, rs.pool.data() + c2.so, c2.len)) continue;
-        rg.lable |= LB_HETE;
-        for (size_t p = 0; p < rg.seqs.size(); ++p)
-            if (rg.seqs[p].kscore > 0 && g.stats[p] < min_c) rg.seqs[p].kscore = 0;
+struct PassCounts {
+    uint32_t n_reg = 0, NC = 0, SB = 0, M = 0;
+};
+
+RegionTables region_tables(np2_ctx *cx, uint32_t n_reg) {
+    return RegionTables{cx->cand_off.p, cx->cand_order.p, cx->kscore.p, cx->cand_seq_off.p, cx->cand_seq.p, n_reg};
+}
+
+// candidate tables as the oracle traces them ("cand" / "hete": every candidate; "seed" / "rechN": kept lists)
+void trace_region_tables(np2_ctx *cx, int pass, const std::string &tag, const PassCounts &pc, bool kept_view) {
+    if (!cx->trace) return;
+    const uint32_t n_reg = pc.n_reg;
+    auto start = d2h(cx, cx->lq_start.p, n_reg), end = d2h(cx, cx->lq_end.p, n_reg);
+    auto coff = d2h(cx, cx->cand_off.p, (size_t)n_reg + 1);
+    auto order = d2h(cx, cx->cand_order.p, pc.NC);
+    auto ks = d2h(cx, cx->kscore.p, pc.NC);
+    auto soff = d2h(cx, cx->cand_seq_off.p, (size_t)pc.NC + 1);
+    auto pool = d2h(cx, cx->cand_seq.p, pc.SB);
+    std::vector<uint8_t> lable(n_reg, 0);
+    std::vector<uint32_t> seedc, keepn, keepl;
+    std::vector<uint16_t> keepks;
+    if (tag != "cand") lable = d2h(cx, cx->reg_lable.p, n_reg);
+    if (kept_view) {
+        seedc = d2h(cx, cx->seed_cand.p, n_reg);
+        keepn = d2h(cx, cx->keep_n.p, n_reg);
+        keepl = d2h(cx, cx->keep_list.p, pc.NC);
+        keepks = d2h(cx, cx->keep_ks.p, pc.NC);
     }
-    phase::Weights data, dif, ref_data;
-    std::unordered_set<uint32_t> bad;
-    for (const Region &rg : rs.regs) {
-        if (!(rg.lable & LB_HETE)) continue;
-        for (size_t i = 0; i < rg.seqs.size(); ++i) {
-            const Cand &a = rg.seqs[i];
-            if (a.kscore == 0) continue;
-            for (size_t j = i + 1; j < rg.seqs.size(); ++j) {
-                const Cand &b = rg.seqs[j];
-                if (b.kscore == 0) continue;
-                const float w = rs.same(a, b) ? 1.f : -1.f;
-                if (a.order == 0) {
-                    if (asref) phase::add_weight(ref_data, a.order, b.order, w);
-                    if (w < 0.f && !use_all_reads) bad.insert(b.order);
-                    continue;
-                }
-                REFPANIC_IF(b.order == 0, "seq2 order is equal to 0");
-                if (w == -1.f) {
-                    phase::add_weight(dif, a.order, b.order, -1.f);
-                    phase::add_weight(dif, b.order, a.order, -1.f);
-                }
-                phase::add_weight(data, a.order, b.order, w);
-                phase::add_weight(data, b.order, a.order, w);
+    std::vector<uint32_t> o_coff(1, 0), o_order, o_soff(1, 0), sudo_off(1, 0);
+    std::vector<uint16_t> o_ks;
+    std::vector<uint8_t> o_seq, sudo;
+    for (uint32_t g = 0; g < n_reg; ++g) {
+        if (kept_view) {
+            const uint32_t c = seedc[g];
+            if (c != 0xFFFFFFFFu) sudo.insert(sudo.end(), pool.begin() + soff[c], pool.begin() + soff[c + 1]);
+            for (uint32_t t = 0; t < keepn[g]; ++t) {
+                const uint32_t ci = keepl[coff[g] + t];
+                o_order.push_back(order[ci]);
+                o_ks.push_back(keepks[coff[g] + t]);
+                o_seq.insert(o_seq.end(), pool.begin() + soff[ci], pool.begin() + soff[ci + 1]);
+                o_soff.push_back((uint32_t)o_seq.size());
+            }
+        } else {
+            for (uint32_t ci = coff[g]; ci < coff[g + 1]; ++ci) {
+                o_order.push_back(order[ci]);
+                o_ks.push_back(ks[ci]);
+                o_seq.insert(o_seq.end(), pool.begin() + soff[ci], pool.begin() + soff[ci + 1]);
+                o_soff.push_back((uint32_t)o_seq.size());
             }
         }
+        sudo_off.push_back((uint32_t)sudo.size());
+        o_coff.push_back((uint32_t)o_order.size());
     }
-    dif.each([&](uint32_t n1, const phase::Row &row) {
-        for (const auto &e : row)
-            if (e.second <= -3.f) phase::set_weight(data, n1, e.first, e.second);
-    });
-    if (!use_all_reads) {
+    trace_put(cx, pass, tag + ".start", start);
+    trace_put(cx, pass, tag + ".end", end);
+    trace_put(cx, pass, tag + ".lable", lable);
+    trace_put(cx, pass, tag + ".sudo_off", sudo_off);
+    trace_put(cx, pass, tag + ".sudo", sudo);
+    trace_put(cx, pass, tag + ".cand_off", o_coff);
+    trace_put(cx, pass, tag + ".order", o_order);
+    trace_put(cx, pass, tag + ".kscore", o_ks);
+    trace_put(cx, pass, tag + ".seq_off", o_soff);
+    trace_put(cx, pass, tag + ".seq", o_seq);
+    if (tag == "cand") trace_put(cx, pass, "cand.kmer", d2h(cx, cx->cand_kmer.p, pc.NC));
+}
+
+void check_region_err(np2_ctx *cx) {
+    const uint32_t e = d2h(cx, cx->scal.p + S_ERR, 1)[0];
+    if (e & 4u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: seq2 order is equal to 0");
+    if (e & 8u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: index out of bounds: lqseq.seqs[max1_p]");
+    if (e & 16u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: the first lqseq is not ref.");
+    if (e & 32u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: lqseq.seqs[0] after retain_sort_seqs");
+    if (e & 64u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: consensus index out of bounds in reupdate");
+    if (e & 128u) throw Np2Error(NP2_E_NOMEM, "cartesian product of chained LQ regions is too large");
+}
+
+// phasing pass on the GPU tables: mark_hete (main.rs:916-946), pair edges (948-1002); Louvain on the host
+std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCounts &pc, bool asref, bool use_all,
+                                       int pass) {
+    hipStream_t s = cx->stream;
+    const uint32_t R = c->R, n_reg = pc.n_reg;
+    RegionTables rt = region_tables(cx, n_reg);
+    uint32_t NE = 0, NU = 0;
+    {
+        EventTimer t(cx, "vote_phase");
+        cx->reg_lable.ensure(n_reg + 2);
+        cx->grp.ensure(pc.NC + 2);
+        cx->ecount.ensure(n_reg + 2);
+        cx->eoff.ensure(std::max<size_t>(n_reg + 2, (size_t)c->L + 2));
+        cx->ref_w.ensure(R + 2);
+        cx->ref_seen.ensure(R + 2);
+        cx->bad.ensure(R + 2);
+        cx->first_reg.ensure(R + 2);
+        zero32(cx, cx->ref_w.p, R + 2);
+        zero32(cx, cx->ref_seen.p, R + 2, 1);
+        zero32(cx, cx->bad.p, R + 2, 1);
+        HIPCHK(hipMemsetAsync(cx->first_reg.p, 0xFF, (size_t)(R + 2) * 4, s));
+        zero32(cx, cx->scal.p + S_ERR, 1);
+        launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, cx->ref_w.p, cx->ref_seen.p,
+                          cx->bad.p, cx->first_reg.p, cx->scal.p + S_ERR);
+        zero32(cx, cx->ecount.p + n_reg, 1);
+        exclusive_total(cx, cx->ecount.p, cx->eoff.p, (size_t)n_reg + 1);
+        NE = d2h(cx, cx->eoff.p + n_reg, 1)[0];
+    }
+    check_region_err(cx);
+    std::vector<uint64_t> ukey;
+    std::vector<int32_t> uw;
+    if (NE) {
+        EventTimer t(cx, "vote_phase");
+        cx->ekey.ensure(NE + 2);
+        cx->ekey_s.ensure(NE + 2);
+        cx->eval.ensure(NE + 2);
+        cx->eval_s.ensure(NE + 2);
+        cx->eflag.ensure(NE + 2);
+        cx->eidx.ensure(NE + 2);
+        cx->ew.ensure(NE + 2);
+        cx->tmp.ensure(prim_temp_bytes((size_t)NE + 2));
+        launch_edges_write(s, rt, cx->reg_lable.p, cx->grp.p, cx->ecount.p, cx->eoff.p, cx->ekey.p, cx->eval.p);
+        if (prim_sort_pairs_u64_u32(s, cx->tmp.p, cx->tmp.cap, cx->ekey.p, cx->ekey_s.p, cx->eval.p, cx->eval_s.p, NE, 64))
+            throw Np2Error(NP2_E_DEVICE, "rocprim edge sort failed");
+        launch_edge_reduce(s, cx->ekey_s.p, cx->eval_s.p, NE, cx->eflag.p, cx->ew.p);
+        exclusive_total(cx, cx->eflag.p, cx->eidx.p, NE);
+        // compact into ekey / eval (reused as int32 weights)
+        launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, cx->ew.p, NE, cx->ekey.p, (int32_t *)cx->eval.p,
+                            cx->scal.p + S_NRAW);
+        NU = d2h(cx, cx->scal.p + S_NRAW, 1)[0];
+        ukey = d2h(cx, cx->ekey.p, NU);
+        uw = d2h(cx, (const int32_t *)cx->eval.p, NU);
+    }
+    auto first_reg = d2h(cx, cx->first_reg.p, R);
+    auto ref_w = d2h(cx, cx->ref_w.p, R);
+    auto ref_seen = d2h(cx, cx->ref_seen.p, R);
+    auto badv = d2h(cx, cx->bad.p, R);
+    if (cx->trace) {
+        trace_put(cx, pass, "hete.lable", d2h(cx, cx->reg_lable.p, n_reg));
+        trace_put(cx, pass, "hete.kscore", d2h(cx, cx->kscore.p, pc.NC));
+    }
+    // ---- host: rebuild the weight maps in the reference's key-creation order, then Louvain --------
+    // outer keys of `data` are created region by region (index order), valid non-ref candidates in
+    // position (= read index) order, first occurrence wins
+    std::vector<std::pair<uint32_t, uint32_t>> keys;
+    for (uint32_t r = 0; r < R; ++r)
+        if (first_reg[r] != 0xFFFFFFFFu) keys.emplace_back(first_reg[r], r);
+    std::sort(keys.begin(), keys.end());
+    phase::Weights data;
+    for (auto &k : keys) data.put_vacant(k.second, phase::Row());
+    for (uint32_t i = 0; i < NU; ++i) {
+        const uint32_t a = (uint32_t)(ukey[i] >> 32), b = (uint32_t)ukey[i];
+        const float w = (float)uw[i];
+        phase::Row *ra = data.get(a), *rb = data.get(b);
+        if (!ra || !rb) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
+        (*ra)[b] = w;
+        (*rb)[a] = w;
+    }
+    std::unordered_set<uint32_t> bad;
+    for (uint32_t r = 0; r < R; ++r)
+        if (badv[r]) bad.insert(r);
+    if (!use_all) {
         data.keep_if([&](uint32_t k, phase::Row &) { return bad.count(k) == 0; });
         data.each_mut([&](uint32_t, phase::Row &row) {
             for (auto it = row.begin(); it != row.end();) it = bad.count(it->first) ? row.erase(it) : std::next(it);
@@ -317,9 +368,11 @@ std::vector<uint32_t> phasing_vote(RegionSet &rs, bool asref, bool use_all_reads
     }
     phase::Row ref_row;
     bool have_ref = false;
-    ref_data.each([&](uint32_t, const phase::Row &row) {
-        if (!have_ref) ref_row = row, have_ref = true;
-    });
+    for (uint32_t r = 0; r < R; ++r)
+        if (ref_seen[r]) {
+            ref_row[r] = (float)ref_w[r];
+            have_ref = true;
+        }
     std::vector<uint32_t> losers;
     if (!phase::losing_reads(std::move(data), have_ref ? &ref_row : nullptr, losers))
         throw Np2Error(NP2_E_REFPANIC,
@@ -330,123 +383,120 @@ std::vector<uint32_t> phasing_vote(RegionSet &rs, bool asref, bool use_all_reads
     return losers;
 }
 
-// final pass part 1: fill_seed_lqseqs (main.rs:862-914) with retain_sort_seqs (714-726)
-void choose_seeds(RegionSet &rs, long max_indel_len) {
-    GroupStat g;
-    for (Region &rg : rs.regs) {
-        group_stats(rs, rg, g);
-        REFPANIC_IF(rg.seqs.empty(), "index out of bounds: lqseq.seqs[max1_p]");
-        rg.sudoseed = rs.str(rg.seqs[g.max1_p]);
-        rg.lable |= LB_SUCC | LB_RECH;
-        const size_t min_c = min_support(rg.seqs.size());
-        REFPANIC_IF(rg.seqs[0].order != 0, "the first lqseq is not ref.");
-        if (size_t *v = g.find(0)) {
-            if (*v > 1 && *v < min_c) *v = min_c;
-        } else {
-            size_t c = 0;
-            for (const Cand &x : rg.seqs) c += rs.same(x, rg.seqs[0]);
-            if (c > 1) g.set(0, min_c);
-        }
-        bool nodup = true; // no_dupseq_lqseq (main.rs:851-860): evaluated lazily below
-        auto no_dup = [&]() {
-            for (size_t a = 1; a < rg.seqs.size(); ++a)
-                for (size_t b = a + 1; b < rg.seqs.size(); ++b)
-                    if (rs.same(rg.seqs[a], rg.seqs[b])) return false;
-            return true;
-        };
-        (void)nodup;
-        if (g.max1_p != 0 && g.max1_c < min_c && (g.max1_c > 1 || no_dup())) {
-            size_t *v = g.find(rg.seqs[g.max1_p].order);
-            REFPANIC_IF(!v, "unwrap on None: order_stat.get_mut");
-            *v = min_c;
-            g.set(0, min_c);
-        } else if (g.max1_c < min_c) {
-            g.set(0, min_c);
-        }
-        // retain_sort_seqs: stable sort by group count descending, cut below min_c
-        std::stable_sort(rg.seqs.begin(), rg.seqs.end(),
-                         [&](const Cand &a, const Cand &b) { return g.get_or0(a.order) > g.get_or0(b.order); });
-        size_t keep = 0;
-        while (keep < rg.seqs.size() && g.get_or0(rg.seqs[keep].order) >= min_c) ++keep;
-        rg.seqs.resize(keep);
-        REFPANIC_IF(rg.seqs.empty(), "index out of bounds: lqseq.seqs[0] after retain_sort_seqs");
-        long d = (long)rg.sudoseed.size() - (long)rg.seqs[0].len;
-        const bool too_long = (d < 0 ? -d : d) > max_indel_len;
-        if (rg.seqs.size() <= 1 || too_long) {
-            rg.sudoseed = rs.str(rg.seqs[0]);
-            rg.lable ^= LB_RECH;
-            rg.seqs.clear();
-        }
+// consensus double buffer: cns_pos/cns_base (A) <-> cns_pos2/cns_base2 (B)
+struct CnsDev {
+    uint32_t *pos;
+    uint8_t *base;
+    uint32_t M;
+};
+
+// update_consensus_with_lqseqs on the device; returns the new consensus (in the other buffer)
+CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, uint32_t grow_bound, bool to_b) {
+    hipStream_t s = cx->stream;
+    EventTimer t(cx, "splice");
+    cx->sp_idx_s.ensure(n_reg + 2);
+    cx->sp_idx_e.ensure(n_reg + 2);
+    cx->sp_flag.ensure(n_reg + 2);
+    cx->sp_slot.ensure(n_reg + 2);
+    cx->ap_g.ensure(n_reg + 2);
+    cx->ap_s.ensure(n_reg + 2);
+    cx->ap_e.ensure(n_reg + 2);
+    cx->ap_delta.ensure(n_reg + 2);
+    cx->ap_shift.ensure(n_reg + 2);
+    const size_t cap = (size_t)in.M + grow_bound + 64;
+    uint32_t *opos = to_b ? cx->cns_pos2.ensure(cap) : cx->cns_pos.ensure(cap);
+    uint8_t *obase = to_b ? cx->cns_base2.ensure(cap) : cx->cns_base.ensure(cap);
+    zero32(cx, cx->scal.p + S_STUCK, 2); // stuck, n_ap
+    launch_splice_find(s, in.pos, in.M, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
+                       cx->sp_idx_e.p, cx->scal.p + S_STUCK, cx->sp_flag.p);
+    exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
+    launch_splice_slots(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p,
+                        cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->scal.p + S_NAP);
+    const uint32_t n_ap = d2h(cx, cx->scal.p + S_NAP, 1)[0];
+    int32_t total_shift = 0;
+    if (n_ap) {
+        if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->ap_delta.p, cx->ap_shift.p, n_ap))
+            throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+        total_shift = d2h(cx, cx->ap_shift.p + (n_ap - 1), 1)[0];
     }
+    launch_splice_write(s, in.pos, in.base, in.M, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p,
+                        cx->scal.p + S_NAP, n_ap, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->cand_seq.p,
+                        opos, obase);
+    return CnsDev{opos, obase, (uint32_t)((int64_t)in.M + total_shift)};
 }
 
-// update_consensus_with_lqseqs (main.rs:1027-1058) incl. the wrapping cursor of 1017-1025
-Cns splice(const std::vector<Region> &regs, const Cns &in, uint8_t lable) {
-    Cns out;
-    out.pos.reserve(in.size());
-    out.base.reserve(in.size());
-    auto next_with = [&](size_t i) {
-        i -= 1;
-        while (i < regs.size() && !(regs[i].lable & lable)) i -= 1;
-        return i;
-    };
-    size_t i = 0, li = next_with(regs.size());
-    while (i < in.size()) {
-        const uint32_t p = in.pos[i];
-        if (li < regs.size() && p == regs[li].start) {
-            for (char b : regs[li].sudoseed) {
-                out.pos.push_back(p);
-                out.base.push_back((uint8_t)b);
-            }
-            while (i < in.size() && in.pos[i] <= regs[li].end) ++i;
-            li = next_with(li);
-        } else {
-            out.pos.push_back(p);
-            out.base.push_back(in.base[i]);
-            ++i;
-        }
+Cns fetch_cns_dev(np2_ctx *cx, const CnsDev &c) {
+    Cns r;
+    r.pos = d2h(cx, c.pos, c.M);
+    r.base = d2h(cx, c.base, c.M);
+    return r;
+}
+
+// reupdate_consensus_with_lqseqs for one yak table, on the device
+CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_idx, uint16_t min_kmer_count,
+                   bool first_yak, bool to_b) {
+    hipStream_t s = cx->stream;
+    const uint32_t n_reg = pc.n_reg, ksize = cx->yaks[yak_idx].k;
+    uint32_t n_rech = 0, n_groups = 0, n_jobs = 0;
+    {
+        EventTimer t(cx, "recheck");
+        cx->sp_flag.ensure(n_reg + 2);
+        cx->sp_slot.ensure(n_reg + 2);
+        cx->rech.ensure(n_reg + 2);
+        zero32(cx, cx->scal.p + S_ERR, 1);
+        zero32(cx, cx->scal.p + S_NRECH, 2);
+        launch_rech_list(s, cx->reg_lable.p, n_reg, cx->sp_flag.p);
+        exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
+        launch_rech_list2(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH);
+        n_rech = d2h(cx, cx->scal.p + S_NRECH, 1)[0];
     }
+    if (n_rech) {
+        {
+            EventTimer t(cx, "recheck");
+            cx->rech_head.ensure(n_rech + 2);
+            cx->rech_gslot.ensure(n_rech + 2);
+            cx->rech_groups.ensure((size_t)(n_rech + 2) * rech_group_bytes());
+            cx->rech_njobs.ensure(n_rech + 2);
+            cx->rech_joboff.ensure(n_rech + 2);
+            launch_rech_heads(s, cx->rech.p, cx->scal.p + S_NRECH, n_rech, cx->lq_start.p, cx->lq_end.p, ksize,
+                              cx->rech_head.p);
+            exclusive_total(cx, cx->rech_head.p, cx->rech_gslot.p, n_rech);
+            zero32(cx, cx->rech_njobs.p, n_rech + 2);
+            launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_rech, in.pos,
+                               in.M, cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p,
+                               cx->rech_njobs.p, cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
+            n_groups = d2h(cx, cx->scal.p + S_NGROUPS, 1)[0];
+            exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_groups + 1);
+            n_jobs = d2h(cx, cx->rech_joboff.p + n_groups, 1)[0];
+        }
+        check_region_err(cx);
+        RechPtrs rp{cx->rech_groups.p, cx->rech_joboff.p, cx->rech.p, cx->cand_off.p, cx->keep_list.p,
+                    cx->cand_seq_off.p, cx->cand_seq.p, in.base, n_groups};
+        if (n_jobs) {
+            EventTimer t(cx, "recheck");
+            cx->job_len.ensure(n_jobs + 2);
+            cx->job_off32.ensure(n_jobs + 2);
+            cx->soff.ensure(n_jobs + 2);
+            cx->sscore.ensure(n_jobs + 2);
+            cx->tmp.ensure(prim_temp_bytes((size_t)n_jobs + 2));
+            launch_rech_job_len(s, rp, n_jobs, cx->job_len.p);
+            zero32(cx, cx->job_len.p + n_jobs, 1);
+            exclusive_total(cx, cx->job_len.p, cx->job_off32.p, (size_t)n_jobs + 1);
+            const uint32_t blob_bytes = d2h(cx, cx->job_off32.p + n_jobs, 1)[0];
+            cx->sstr.ensure((size_t)blob_bytes + 64);
+            launch_rech_job_build(s, rp, n_jobs, cx->job_off32.p, cx->soff.p, cx->sstr.p);
+            launch_score_strings(s, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n_jobs, min_kmer_count,
+                                 cx->sscore.p);
+            launch_rech_apply(s, rp, cx->sscore.p, cx->keep_ks.p);
+        }
+        EventTimer t(cx, "recheck");
+        launch_rech_select(s, cx->rech.p, cx->scal.p + S_NRECH, n_rech, cx->cand_off.p, cx->keep_n.p, cx->keep_list.p,
+                           cx->keep_ks.p, cx->cand_order.p, first_yak, cx->reg_lable.p, cx->seed_cand.p);
+    }
+    CnsDev out = splice_gpu(cx, in, n_reg, LB_RECH, pc.SB, to_b);
+    launch_rech_relabel(s, cx->reg_lable.p, n_reg);
     return out;
 }
-
-// cursor helpers of reupdate_consensus_with_lqseqs (main.rs:1068-1139); out-of-range indexing
-// is a panic in the reference
-struct CnsCursor {
-    const Cns &c;
-    size_t idx = 0;
-    explicit CnsCursor(const Cns &cns) : c(cns) {}
-    uint32_t pos(size_t i) const {
-        REFPANIC_IF(i >= c.size(), "index out of bounds: consensus[i] in reupdate");
-        return c.pos[i];
-    }
-    void left_flank(uint32_t p, size_t l, size_t &si, size_t &ei) {
-        size_t i = idx;
-        while (pos(i) >= p) i -= 1;
-        while (pos(i) < p) i += 1;
-        REFPANIC_IF(!(pos(i) >= p && pos(i - 1) < p), "assert iter_consensus_extend (left)");
-        idx = i, ei = i, si = i > l ? i - l : 0;
-    }
-    void right_flank(uint32_t p, size_t l, size_t &si, size_t &ei) {
-        size_t i = idx;
-        while (pos(i) <= p) i += 1;
-        while (pos(i) > p) i -= 1;
-        REFPANIC_IF(!(pos(i) <= p && pos(i + 1) > p), "assert iter_consensus_extend (right)");
-        idx = i, si = i + 1, ei = (i + l < c.size()) ? i + l + 1 : c.size();
-    }
-    void between(uint32_t s, uint32_t e, size_t &si, size_t &ei) {
-        size_t i = idx;
-        while (pos(i) <= s) i += 1;
-        while (pos(i) > s) i -= 1;
-        i += 1;
-        REFPANIC_IF(!(pos(i) > s && pos(i - 1) <= s), "assert iter_consensus_region (1)");
-        si = i;
-        while (pos(i) >= e) i -= 1;
-        while (pos(i) < e) i += 1;
-        i -= 1;
-        REFPANIC_IF(!(pos(i) < e && pos(i + 1) >= e), "assert iter_consensus_region (2)");
-        idx = i, ei = i + 1;
-    }
-};
 
 void gpu_score_strings(np2_ctx *cx, int yak_idx, const std::vector<uint8_t> &blob, const std::vector<uint64_t> &off,
                        uint16_t min_kmer_count, std::vector<uint16_t> &scores) {
@@ -465,175 +515,6 @@ void gpu_score_strings(np2_ctx *cx, int yak_idx, const std::vector<uint8_t> &blo
     }
     HIPCHK(hipMemcpyAsync(scores.data(), cx->sscore.p, n * 2, hipMemcpyDeviceToHost, cx->stream));
     HIPCHK(hipStreamSynchronize(cx->stream));
-}
-
-// reupdate_consensus_with_lqseqs (main.rs:1060-1420): strings are assembled on the host, scored
-// in one batch by the k-mer kernel, then the selection rules are applied.
-Cns recheck(np2_ctx *cx, RegionSet &rs, const Cns &cns, int yak_idx, uint16_t min_kmer_count, size_t iter_count) {
-    const uint32_t ksize = cx->yaks[yak_idx].k;
-    std::vector<size_t> rech;
-    for (size_t i = rs.regs.size(); i-- > 0;)
-        if (rs.regs[i].lable & LB_RECH) rech.push_back(i);
-
-    struct Group {
-        size_t sj, ej;
-        size_t first_job;
-        std::vector<uint32_t> lens; // product radix (chains only)
-    };
-    std::vector<Group> groups;
-    std::vector<uint8_t> blob;
-    std::vector<uint64_t> off(1, 0);
-    CnsCursor cur(cns);
-    auto add_cns = [&](size_t si, size_t ei) {
-        REFPANIC_IF(si > ei || ei > cns.size(), "slice index out of range in reupdate");
-        blob.insert(blob.end(), cns.base.begin() + (long)si, cns.base.begin() + (long)ei);
-    };
-    auto add_seq = [&](const Cand &c) { blob.insert(blob.end(), rs.pool.begin() + c.so, rs.pool.begin() + c.so + c.len); };
-    size_t sj = 0;
-    while (sj < rech.size()) {
-        size_t ej = sj + 1;
-        while (ej < rech.size() && rs.regs[rech[ej]].start < rs.regs[rech[ej - 1]].end + ksize) {
-            ej += 1;
-            if (ej > sj + 5) break; // at most 6 chained regions (main.rs:1202-1205)
-        }
-        size_t sl, el, sr, er;
-        cur.left_flank(rs.regs[rech[sj]].start, ksize - 1, sl, el);
-        cur.right_flank(rs.regs[rech[ej - 1]].end, ksize - 1, sr, er);
-        Group g{sj, ej, off.size() - 1, {}};
-        if (ej == sj + 1) {
-            for (const Cand &c : rs.regs[rech[sj]].seqs) {
-                add_cns(sl, el);
-                add_seq(c);
-                add_cns(sr, er);
-                off.push_back(blob.size());
-            }
-        } else {
-            const size_t n = ej - sj;
-            std::vector<size_t> pick(n, 0);
-            bool done = false;
-            for (size_t x = 0; x < n; ++x) {
-                g.lens.push_back((uint32_t)rs.regs[rech[sj + x]].seqs.size());
-                done |= g.lens.back() == 0;
-            }
-            while (!done) { // multi_cartesian_product: last iterator fastest
-                add_cns(sl, el);
-                for (size_t x = 0; x < n; ++x) {
-                    add_seq(rs.regs[rech[sj + x]].seqs[pick[x]]);
-                    if (x + 1 < n) {
-                        const uint32_t s = rs.regs[rech[sj + x]].end, e = rs.regs[rech[sj + x + 1]].start;
-                        if (s + 1 != e) {
-                            size_t si, ei;
-                            cur.between(s, e, si, ei);
-                            add_cns(si, ei);
-                        }
-                    } else {
-                        add_cns(sr, er);
-                    }
-                }
-                off.push_back(blob.size());
-                size_t d = n;
-                while (d-- > 0) {
-                    if (++pick[d] < g.lens[d]) break;
-                    pick[d] = 0;
-                    if (d == 0) done = true;
-                }
-            }
-        }
-        groups.push_back(std::move(g));
-        sj = ej;
-    }
-
-    std::vector<uint16_t> scores;
-    blob.resize(blob.size() + 8, 0);
-    gpu_score_strings(cx, yak_idx, blob, off, min_kmer_count, scores);
-
-    for (const Group &g : groups) {
-        size_t job = g.first_job;
-        if (g.ej == g.sj + 1) {
-            for (Cand &c : rs.regs[rech[g.sj]].seqs) c.kscore = scores[job++];
-        } else {
-            const size_t n = g.ej - g.sj;
-            for (size_t x = 0; x < n; ++x)
-                for (Cand &c : rs.regs[rech[g.sj + x]].seqs) c.kscore = 0;
-            size_t total = 1;
-            for (uint32_t l : g.lens) total *= l;
-            std::vector<size_t> pick(n, 0);
-            for (size_t t = 0; t < total; ++t) { // later products overwrite earlier ones (main.rs:1364-1366)
-                const uint16_t ks = scores[job++];
-                if (ks > 0)
-                    for (size_t x = 0; x < n; ++x) rs.regs[rech[g.sj + x]].seqs[pick[x]].kscore = ks;
-                size_t d = n;
-                while (d-- > 0) {
-                    if (++pick[d] < g.lens[d]) break;
-                    pick[d] = 0;
-                }
-            }
-        }
-    }
-
-    for (Region &rg : rs.regs) {
-        if (!(rg.lable & LB_RECH)) continue;
-        size_t c = 0, valid = 0;
-        for (size_t p = 0; p < rg.seqs.size(); ++p)
-            if (rg.seqs[p].kscore != 0) {
-                if (c == 0 || rg.seqs[p].order == 0) c = p + 1;
-                ++valid;
-            }
-        if (valid > 1) rg.lable |= LB_TEMP;
-        if (c != 0) {
-            rg.sudoseed = rs.str(rg.seqs[c - 1]);
-        } else if (iter_count == 1) {
-            size_t i = 0;
-            for (size_t p = 0; p < rg.seqs.size(); ++p)
-                if (rg.seqs[p].order == 0) {
-                    i = p;
-                    break;
-                }
-            REFPANIC_IF(rg.seqs.empty(), "index out of bounds: lqseq.seqs[i] in reupdate");
-            rg.sudoseed = rs.str(rg.seqs[i]);
-        }
-    }
-    Cns out = splice(rs.regs, cns, LB_RECH);
-    for (Region &rg : rs.regs) {
-        if (!(rg.lable & LB_RECH)) continue;
-        rg.lable ^= (rg.lable & LB_TEMP) ? LB_TEMP : LB_RECH;
-    }
-    return out;
-}
-
-void trace_regions(np2_ctx *cx, int pass, const std::string &tag, const RegionSet &rs) {
-    if (!cx->trace) return;
-    std::vector<uint32_t> start, end, cand_off(1, 0), order, seq_off(1, 0), sudo_off(1, 0);
-    std::vector<uint16_t> kscore;
-    std::vector<uint8_t> lable, seqs, sudo;
-    for (const Region &rg : rs.regs) {
-        start.push_back(rg.start);
-        end.push_back(rg.end);
-        lable.push_back(rg.lable);
-        sudo.insert(sudo.end(), rg.sudoseed.begin(), rg.sudoseed.end());
-        sudo_off.push_back((uint32_t)sudo.size());
-        for (const Cand &c : rg.seqs) {
-            order.push_back(c.order);
-            kscore.push_back(c.kscore);
-            seqs.insert(seqs.end(), rs.pool.begin() + c.so, rs.pool.begin() + c.so + c.len);
-            seq_off.push_back((uint32_t)seqs.size());
-        }
-        cand_off.push_back((uint32_t)order.size());
-    }
-    trace_put(cx, pass, tag + ".start", start);
-    trace_put(cx, pass, tag + ".end", end);
-    trace_put(cx, pass, tag + ".lable", lable);
-    trace_put(cx, pass, tag + ".sudo_off", sudo_off);
-    trace_put(cx, pass, tag + ".sudo", sudo);
-    trace_put(cx, pass, tag + ".cand_off", cand_off);
-    trace_put(cx, pass, tag + ".order", order);
-    trace_put(cx, pass, tag + ".kscore", kscore);
-    trace_put(cx, pass, tag + ".seq_off", seq_off);
-    trace_put(cx, pass, tag + ".seq", seqs);
-}
-void trace_cns(np2_ctx *cx, int pass, const std::string &tag, const Cns &c) {
-    trace_put(cx, pass, tag + ".pos", c.pos);
-    trace_put(cx, pass, tag + ".base", c.base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -864,7 +745,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
 
 // candidate extraction + first-yak scoring; fills the host RegionSet
 void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min_kmer_count, int pass,
-                        RegionSet &rs) {
+                        PassCounts &pc) {
     hipStream_t s = cx->stream;
     const uint32_t R = c->R;
     REFPANIC_IF(cx->yaks.empty(), "index out of bounds: opt.yak[0]");
@@ -950,25 +831,10 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
                           min_kmer_count, cx->kscore.p);
     }
     HIPCHK(hipStreamSynchronize(s));
-    // D2H of the candidate tables
-    auto start = d2h(cx, cx->lq_start.p, n_reg), end = d2h(cx, cx->lq_end.p, n_reg);
-    auto coff = d2h(cx, cx->cand_off.p, (size_t)n_reg + 1);
-    auto order = d2h(cx, cx->cand_order.p, NC);
-    auto ks = d2h(cx, cx->kscore.p, NC);
-    auto soff = d2h(cx, cx->cand_seq_off.p, (size_t)NC + 1);
-    rs.pool = d2h(cx, cx->cand_seq.p, SB);
-    rs.regs.assign(n_reg, Region());
-    for (uint32_t g = 0; g < n_reg; ++g) {
-        Region &rg = rs.regs[g];
-        rg.start = start[g];
-        rg.end = end[g];
-        rg.seqs.reserve(coff[g + 1] - coff[g]);
-        for (uint32_t i = coff[g]; i < coff[g + 1]; ++i) rg.seqs.push_back(Cand{order[i], ks[i], soff[i], soff[i + 1] - soff[i]});
-    }
-    if (cx->trace) {
-        trace_regions(cx, pass, "cand", rs);
-        trace_put(cx, pass, "cand.kmer", d2h(cx, cx->cand_kmer.p, NC));
-    }
+    pc.n_reg = n_reg;
+    pc.NC = NC;
+    pc.SB = SB;
+    trace_region_tables(cx, pass, "cand", pc, false);
 }
 
 Cns fetch_cns(np2_ctx *cx, uint32_t M) {
@@ -1006,11 +872,11 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
             }
             continue;
         }
-        RegionSet rs;
-        extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, rs);
+        PassCounts pc;
+        pc.M = M;
+        extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
         if (!out_cns) {
-            std::vector<uint32_t> losers = phasing_vote(rs, o->model_ref != 0, o->use_all_reads != 0);
-            trace_regions(cx, (int)pass, "hete", rs);
+            std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
             trace_put(cx, (int)pass, "invalid_ids", losers);
             for (uint32_t id : losers) REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
             if (!losers.empty()) {
@@ -1020,17 +886,32 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
                 HIPCHK(hipStreamSynchronize(s));
             }
         } else {
-            Cns cns = fetch_cns(cx, M);
-            choose_seeds(rs, o->max_indel_len);
-            trace_regions(cx, (int)pass, "seed", rs);
-            cns = splice(rs.regs, cns, LB_SUCC);
-            trace_cns(cx, (int)pass, "cns_succ", cns);
-            for (size_t y = 0; y < cx->yaks.size(); ++y) {
-                cns = recheck(cx, rs, cns, (int)y, o->min_kmer_count, y + 1);
-                trace_regions(cx, (int)pass, "rech" + std::to_string(y), rs);
-                trace_cns(cx, (int)pass, "cns_rech" + std::to_string(y), cns);
+            RegionTables rt = region_tables(cx, n_reg);
+            cx->reg_lable.ensure(n_reg + 2);
+            cx->seed_cand.ensure(n_reg + 2);
+            cx->keep_n.ensure(n_reg + 2);
+            cx->keep_list.ensure(pc.NC + 2);
+            cx->keep_ks.ensure(pc.NC + 2);
+            {
+                EventTimer t(cx, "seed");
+                zero32(cx, cx->scal.p + S_ERR, 1);
+                launch_seed(s, rt, o->max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
+                            cx->keep_ks.p, cx->scal.p + S_ERR);
             }
-            result = std::move(cns);
+            check_region_err(cx);
+            trace_region_tables(cx, (int)pass, "seed", pc, true);
+            CnsDev cur{cx->cns_pos.p, cx->cns_base.p, M};
+            bool to_b = true;
+            cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.SB, to_b);
+            to_b = !to_b;
+            if (cx->trace) trace_cns(cx, (int)pass, "cns_succ", fetch_cns_dev(cx, cur));
+            for (size_t y = 0; y < cx->yaks.size(); ++y) {
+                cur = recheck_gpu(cx, cur, pc, (int)y, o->min_kmer_count, y == 0, to_b);
+                to_b = !to_b;
+                trace_region_tables(cx, (int)pass, "rech" + std::to_string(y), pc, true);
+                if (cx->trace) trace_cns(cx, (int)pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
+            }
+            result = fetch_cns_dev(cx, cur);
             return;
         }
     }

@@ -98,6 +98,66 @@ void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, c
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
                        const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore);
 
+
+// ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
+struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)
+    const uint32_t *cand_off; // [n_reg + 1]
+    const uint32_t *order;    // read index of each candidate
+    uint16_t *kscore;
+    const uint32_t *seq_off;  // [n_cand + 1]
+    const uint8_t *seq;
+    uint32_t n_reg;
+};
+struct RechPtrs {
+    const void *groups;
+    const uint32_t *job_off;
+    const uint32_t *rech;
+    const uint32_t *cand_off;
+    const uint32_t *keep_list;
+    const uint32_t *seq_off;
+    const uint8_t *seq;
+    const uint8_t *cns_base;
+    uint32_t n_groups;
+};
+void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, uint8_t *reg_lable, uint8_t *grp,
+                       uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
+                       uint32_t *err);
+void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
+                        const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval);
+void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, int32_t *wout);
+void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx, const int32_t *wout,
+                         uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out);
+void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
+                 uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err);
+void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, uint32_t M, const uint32_t *lq_start, const uint32_t *lq_end,
+                        const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg, uint32_t *idx_s, uint32_t *idx_e,
+                        uint32_t *stuck, uint32_t *flag);
+void launch_splice_slots(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, const uint32_t *idx_s,
+                         const uint32_t *idx_e, const uint32_t *seed_cand, const uint32_t *seq_off, uint32_t *ap_g,
+                         uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta, uint32_t *n_ap);
+void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, uint32_t M, const uint32_t *ap_g,
+                         const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta, const int32_t *ap_shift_incl,
+                         const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start, const uint32_t *seed_cand,
+                         const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos, uint8_t *out_base);
+void launch_rech_list(hipStream_t s, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *flag);
+void launch_rech_list2(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, uint32_t *rech,
+                       uint32_t *n_rech);
+void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t ksize, uint32_t *headflag);
+void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
+                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, uint32_t M,
+                        const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize, void *groups,
+                        uint32_t *njobs, uint32_t *n_groups, uint32_t *err);
+size_t rech_group_bytes();
+void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len);
+void launch_rech_job_build(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, const uint32_t *soff32, uint64_t *soff64,
+                           uint8_t *blob);
+void launch_rech_apply(hipStream_t s, const RechPtrs &p, const uint16_t *score, uint16_t *keep_ks);
+void launch_rech_select(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                        const uint32_t *cand_off, const uint32_t *keep_n, const uint32_t *keep_list, const uint16_t *keep_ks,
+                        const uint32_t *order, bool first_yak, uint8_t *reg_lable, uint32_t *seed_cand);
+void launch_rech_relabel(hipStream_t s, uint8_t *reg_lable, uint32_t n_reg);
+
 // ---- np2_prims.hip: device-wide sort / scan plumbing (rocPRIM) -------------------------------
 // All take a caller-provided temp buffer; *_temp_bytes report the requirement for n elements.
 size_t prim_temp_bytes(size_t n);

@@ -1,0 +1,716 @@
+// Region-logic kernels (gfx950, wave64): one wavefront per LQ region, one lane per candidate
+// (<= 60 candidates per region, main.rs:30).  Reproduces, on the GPU-resident candidate tables:
+//   fill_order_stat (main.rs:813-849), mark_hete_lqseqs (916-946), the +-1 read-pair edges of
+//   phase_reads_by_lqseqs (948-1002), fill_seed_lqseqs + retain_sort_seqs (862-914, 714-726),
+//   update_consensus_with_lqseqs (1027-1058) and reupdate_consensus_with_lqseqs (1060-1420).
+#include "np2_common.hpp"
+#include "np2_kernels.hpp"
+
+namespace np2 {
+
+static constexpr uint8_t LB_TEMP = 0x01, LB_SUCC = 0x80, LB_HETE = 0x40, LB_RECH = 0x20; // main.rs:655-658
+
+__device__ __forceinline__ uint32_t min_support(uint32_t n) { return n >= 9 ? 3u : (n >= 6 ? 2u : 1u); }
+
+// ---- per-region wave statistics ------------------------------------------------------------
+struct WaveStats {
+    uint64_t eqmask;  // per lane: candidates with an identical sequence (bit j)
+    uint32_t stat;    // per lane: stats[p] of fill_order_stat (0 = not grouped)
+    uint32_t c;       // per lane: group size if this lane is a group head
+    bool head;        // per lane: first kscore>0 member of its class
+    uint32_t max1_c, max1_p, max2_c, max2_p; // wave-uniform
+};
+
+__device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
+                                                      const uint8_t *__restrict__ seq, bool kpos, uint32_t order) {
+    WaveStats w;
+    w.eqmask = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t sj = __shfl(so, j), lj = __shfl(len, j);
+        bool eq = lane < n && lj == len;
+        if (eq)
+            for (uint32_t t = 0; t < len; ++t)
+                if (seq[so + t] != seq[sj + t]) {
+                    eq = false;
+                    break;
+                }
+        if (eq) w.eqmask |= 1ull << j;
+    }
+    const uint64_t kmask = __ballot(lane < n && kpos);
+    const uint64_t valid = w.eqmask & kmask;
+    uint32_t p1 = 64;
+    w.c = 0;
+    if (lane < n && valid) {
+        p1 = __builtin_ctzll(valid);
+        w.c = __builtin_popcountll(w.eqmask >> p1);
+    }
+    w.stat = (p1 < 64 && lane >= p1) ? w.c : 0;
+    w.head = lane < n && p1 == lane;
+    w.max1_c = w.max1_p = w.max2_c = w.max2_p = 0;
+    uint64_t hm = __ballot(w.head);
+    while (hm) {
+        const uint32_t h = __builtin_ctzll(hm);
+        hm &= hm - 1;
+        const uint32_t ch = __shfl(w.c, h), oh = __shfl(order, h);
+        if (ch > w.max1_c || (ch == w.max1_c && oh == 0)) {
+            w.max2_c = w.max1_c, w.max2_p = w.max1_p;
+            w.max1_c = ch, w.max1_p = h;
+        } else if (w.max1_p == w.max2_p || ch > w.max2_c) {
+            w.max2_c = ch, w.max2_p = h;
+        }
+    }
+    return w;
+}
+
+// is_valid_snp (main.rs:780-801): differ after homopolymer compression
+__device__ bool hp_differs(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb) {
+    uint32_t i = 0, j = 0;
+    while (i < na && j < nb) {
+        if (a[i] != b[j]) return true;
+        while (i + 1 < na && a[i] == a[i + 1]) ++i;
+        while (j + 1 < nb && b[j] == b[j + 1]) ++j;
+        ++i, ++j;
+    }
+    return false;
+}
+
+// ---- phasing pass -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vote_phase(RegionTables rt, uint32_t asref, uint32_t use_all,
+                                                    uint8_t *__restrict__ reg_lable, uint8_t *__restrict__ grp,
+                                                    uint32_t *__restrict__ ecount, int32_t *__restrict__ ref_w,
+                                                    uint8_t *__restrict__ ref_seen, uint8_t *__restrict__ bad,
+                                                    uint32_t *__restrict__ first_reg, uint32_t *__restrict__ err) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= rt.n_reg) return;
+    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+    uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
+    uint16_t ks = 0;
+    if (lane < n) {
+        so = rt.seq_off[c0 + lane];
+        len = rt.seq_off[c0 + lane + 1] - so;
+        order = rt.order[c0 + lane];
+        ks = rt.kscore[c0 + lane];
+    }
+    WaveStats w = wave_group_stats(lane, n, so, len, rt.seq, ks > 0, order);
+    const uint32_t min_c = min_support(n);
+    uint8_t lable = 0;
+    uint32_t ne = 0;
+    if (lane < n) grp[c0 + lane] = (uint8_t)__builtin_ctzll(w.eqmask);
+    if (w.max2_c >= min_c && n > 0) {
+        const uint32_t l1 = __shfl(len, w.max1_p), l2 = __shfl(len, w.max2_p);
+        const uint32_t s1 = __shfl(so, w.max1_p), s2 = __shfl(so, w.max2_p);
+        bool het = (l1 == l2) || (n >= 6 && w.max2_c >= w.max1_c / 2);
+        if (het) {
+            uint32_t d = 0;
+            if (lane == 0) d = hp_differs(rt.seq + s1, l1, rt.seq + s2, l2) ? 1u : 0u;
+            het = __shfl(d, 0) != 0;
+        }
+        if (het) {
+            lable = LB_HETE;
+            if (lane < n && ks > 0 && w.stat < min_c) { // main.rs:934-943
+                ks = 0;
+                rt.kscore[c0 + lane] = 0;
+            }
+            const uint64_t valid = __ballot(lane < n && ks > 0);
+            const bool ref_valid = (valid & 1ull) && __shfl(order, 0) == 0;
+            if (lane < n && ks > 0 && order == 0 && lane != 0) atomicOr(err, 4u); // seq2 order == 0 assertion
+            if (ref_valid && lane >= 1 && lane < n && ks > 0) { // pairs (ref, j): main.rs:972-980
+                const int wgt = ((w.eqmask & 1ull) != 0) ? 1 : -1;
+                if (asref) {
+                    atomicAdd(&ref_w[order], wgt);
+                    ref_seen[order] = 1;
+                }
+                if (wgt < 0 && !use_all) bad[order] = 1;
+            }
+            const uint64_t V = ref_valid ? (valid & ~1ull) : valid;
+            const uint32_t m = __builtin_popcountll(V);
+            if (m >= 2) {
+                ne = m * (m - 1) / 2;
+                if ((V >> lane) & 1ull) atomicMin(&first_reg[order], g);
+            }
+        }
+    }
+    if (lane == 0) {
+        reg_lable[g] = lable;
+        ecount[g] = ne;
+    }
+}
+
+// edges among the valid non-ref candidates of HETE regions: key = order_i << 32 | order_j (i < j), val = +1 / -1
+__global__ __launch_bounds__(256) void k_edges_write(RegionTables rt, const uint8_t *__restrict__ reg_lable,
+                                                     const uint8_t *__restrict__ grp,
+                                                     const uint32_t *__restrict__ ecount,
+                                                     const uint32_t *__restrict__ eoff, uint64_t *__restrict__ ekey,
+                                                     uint32_t *__restrict__ eval) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= rt.n_reg || ecount[g] == 0) return;
+    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+    uint32_t order = 0xFFFFFFFFu, gi = 0;
+    bool v = false;
+    if (lane < n) {
+        order = rt.order[c0 + lane];
+        gi = grp[c0 + lane];
+        v = rt.kscore[c0 + lane] > 0;
+    }
+    uint64_t V = __ballot(v);
+    if ((V & 1ull) && __shfl(order, 0) == 0) V &= ~1ull;
+    const bool mine = (V >> lane) & 1ull;
+    const uint32_t cnt = mine ? __builtin_popcountll(lane == 63 ? 0ull : (V >> (lane + 1))) : 0u;
+    uint32_t inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    uint32_t o = eoff[g] + inc - cnt;
+    // shuffles must be wave-uniform: iterate j uniformly
+    for (uint32_t j = 1; j < n; ++j) {
+        const uint32_t oj = __shfl(order, j), gj = __shfl(gi, j);
+        if (mine && j > lane && ((V >> j) & 1ull)) {
+            ekey[o] = ((uint64_t)order << 32) | oj;
+            eval[o] = (gj == gi) ? 1u : 0xFFFFFFFFu;
+            ++o;
+        }
+    }
+}
+
+// reduce sorted edges: data weight = sum(w), unless #(-1) >= 3 then -(#-1) (main.rs:996-1002)
+__global__ void k_edge_reduce(const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ eval, uint32_t n,
+                              uint32_t *__restrict__ flag, int32_t *__restrict__ wout) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = ekey[i];
+    if (i > 0 && ekey[i - 1] == k) {
+        flag[i] = 0;
+        return;
+    }
+    int32_t sum = 0, neg = 0;
+    for (uint32_t j = i; j < n && ekey[j] == k; ++j) {
+        const int32_t w = (int32_t)eval[j];
+        sum += w;
+        neg += w < 0;
+    }
+    flag[i] = 1;
+    wout[i] = neg >= 3 ? -neg : sum;
+}
+__global__ void k_edge_compact(const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ flag,
+                               const uint32_t *__restrict__ idx, const int32_t *__restrict__ wout, uint32_t n,
+                               uint64_t *__restrict__ ukey, int32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        ukey[idx[i]] = ekey[i];
+        uw[idx[i]] = wout[i];
+    }
+    if (i == n - 1) *n_out = idx[i] + flag[i];
+}
+
+// ---- final pass: seeds -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seed(RegionTables rt, int32_t max_indel_len,
+                                              uint8_t *__restrict__ reg_lable, uint32_t *__restrict__ seed_cand,
+                                              uint32_t *__restrict__ keep_n, uint32_t *__restrict__ keep_list,
+                                              uint16_t *__restrict__ keep_ks, uint32_t *__restrict__ err) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= rt.n_reg) return;
+    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+    if (n == 0) { // lqseq.seqs[max1_p] would be out of bounds
+        if (lane == 0) {
+            atomicOr(err, 8u);
+            reg_lable[g] = 0;
+            keep_n[g] = 0;
+            seed_cand[g] = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
+    uint16_t ks = 0;
+    if (lane < n) {
+        so = rt.seq_off[c0 + lane];
+        len = rt.seq_off[c0 + lane + 1] - so;
+        order = rt.order[c0 + lane];
+        ks = rt.kscore[c0 + lane];
+    }
+    WaveStats w = wave_group_stats(lane, n, so, len, rt.seq, ks > 0, order);
+    const uint32_t min_c = min_support(n);
+    if (__shfl(order, 0) != 0) { // "the first lqseq is not ref."
+        if (lane == 0) atomicOr(err, 16u);
+    }
+    // order_stat as a per-lane key (each candidate has its own read index)
+    uint32_t key = w.head ? w.c : 0;
+    {
+        const bool has0 = __shfl((uint32_t)w.head, 0) != 0;
+        uint32_t k0 = __shfl(key, 0);
+        if (has0) {
+            if (k0 > 1 && k0 < min_c) k0 = min_c;
+        } else {
+            const uint32_t cnt0 = __builtin_popcountll(__shfl((uint32_t)(w.eqmask & 0xFFFFFFFFu), 0)) +
+                                  __builtin_popcountll(__shfl((uint32_t)(w.eqmask >> 32), 0));
+            if (cnt0 > 1) k0 = min_c;
+        }
+        // no_dupseq_lqseq (main.rs:851-860): no two equal sequences among candidates 1..
+        const bool dup = lane >= 1 && lane < n && lane < 63 && ((w.eqmask >> (lane + 1)) != 0);
+        const bool nodup = __ballot(dup) == 0;
+        if (w.max1_p != 0 && w.max1_c < min_c && (w.max1_c > 1 || nodup)) {
+            if (lane == w.max1_p) key = min_c;
+            k0 = min_c;
+        } else if (w.max1_c < min_c) {
+            k0 = min_c;
+        }
+        if (lane == 0) key = k0;
+    }
+    // retain_sort_seqs: stable sort by key descending, keep key >= min_c
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t kj = __shfl(key, j);
+        if (lane < n && (kj > key || (kj == key && j < lane))) ++rank;
+    }
+    const bool kept = lane < n && key >= min_c;
+    uint32_t kn = __builtin_popcountll(__ballot(kept));
+    if (kn == 0) {
+        if (lane == 0) atomicOr(err, 32u); // lqseq.seqs[0] out of bounds after retain_sort_seqs
+        kn = 0;
+    }
+    // candidate of rank 0
+    const uint64_t r0mask = __ballot(kept && rank == 0);
+    const uint32_t first = r0mask ? __builtin_ctzll(r0mask) : 0;
+    uint32_t seed = w.max1_p;
+    const int32_t d = (int32_t)__shfl(len, w.max1_p) - (int32_t)__shfl(len, first);
+    const bool too_long = (d < 0 ? -d : d) > max_indel_len;
+    uint8_t lable = LB_SUCC | LB_RECH;
+    if (kn <= 1 || too_long) {
+        seed = first;
+        lable = LB_SUCC;
+        kn = 0;
+    }
+    if (kept && kn) {
+        keep_list[c0 + rank] = c0 + lane;
+        keep_ks[c0 + rank] = ks;
+    }
+    if (lane == 0) {
+        reg_lable[g] = lable;
+        seed_cand[g] = c0 + seed;
+        keep_n[g] = kn;
+    }
+}
+
+// ---- splice (update_consensus_with_lqseqs, main.rs:1027-1058) -----------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// per labelled region: [idx_s, idx_e) to delete; the cursor gets stuck at the leftmost (highest index)
+// labelled region whose start position no longer exists in the consensus
+__global__ void k_splice_find(const uint32_t *__restrict__ cns_pos, uint32_t M, const uint32_t *__restrict__ lq_start,
+                              const uint32_t *__restrict__ lq_end, const uint8_t *__restrict__ reg_lable,
+                              uint8_t lable, uint32_t n_reg, uint32_t *__restrict__ idx_s, uint32_t *__restrict__ idx_e,
+                              uint32_t *__restrict__ stuck) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_reg || !(reg_lable[g] & lable)) return;
+    const uint32_t s = lower_bound_u32(cns_pos, M, lq_start[g]);
+    const bool found = s < M && cns_pos[s] == lq_start[g];
+    idx_s[g] = s;
+    idx_e[g] = found ? max(s, upper_bound_u32(cns_pos, M, lq_end[g])) : s;
+    if (!found) atomicMax(stuck, g + 1);
+}
+// applied regions in left -> right order (reverse region index): flag + per-slot payload
+__global__ void k_splice_flag(const uint8_t *__restrict__ reg_lable, uint8_t lable, uint32_t n_reg,
+                              const uint32_t *__restrict__ stuck, uint32_t *__restrict__ flag) {
+    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr >= n_reg) return;
+    const uint32_t g = n_reg - 1 - rr;
+    flag[rr] = ((reg_lable[g] & lable) && g + 1 > *stuck) ? 1u : 0u;
+}
+__global__ void k_splice_slots(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot, uint32_t n_reg,
+                               const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ idx_e,
+                               const uint32_t *__restrict__ seed_cand, const uint32_t *__restrict__ seq_off,
+                               uint32_t *__restrict__ ap_g, uint32_t *__restrict__ ap_s, uint32_t *__restrict__ ap_e,
+                               int32_t *__restrict__ ap_delta, uint32_t *__restrict__ n_ap) {
+    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr >= n_reg) return;
+    if (flag[rr]) {
+        const uint32_t g = n_reg - 1 - rr, o = slot[rr];
+        const uint32_t c = seed_cand[g];
+        const uint32_t len = seq_off[c + 1] - seq_off[c];
+        ap_g[o] = g;
+        ap_s[o] = idx_s[g];
+        ap_e[o] = idx_e[g];
+        ap_delta[o] = (int32_t)len - (int32_t)(idx_e[g] - idx_s[g]);
+    }
+    if (rr == n_reg - 1) *n_ap = slot[rr] + flag[rr];
+}
+__global__ void k_splice_bases(const uint32_t *__restrict__ in_pos, const uint8_t *__restrict__ in_base, uint32_t M,
+                               const uint32_t *__restrict__ ap_s, const uint32_t *__restrict__ ap_e,
+                               const int32_t *__restrict__ ap_shift_incl, const uint32_t *__restrict__ n_ap_p,
+                               uint32_t *__restrict__ out_pos, uint8_t *__restrict__ out_base) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t n_ap = *n_ap_p;
+    // last slot with ap_s <= i
+    uint32_t lo = 0, hi = n_ap;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    int64_t o = i;
+    if (lo > 0) {
+        const uint32_t sl = lo - 1;
+        if (i < ap_e[sl]) return; // replaced by the region's seed
+        o += ap_shift_incl[sl];
+    }
+    out_pos[o] = in_pos[i];
+    out_base[o] = in_base[i];
+}
+__global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t *__restrict__ ap_s,
+                               const int32_t *__restrict__ ap_delta, const int32_t *__restrict__ ap_shift_incl,
+                               const uint32_t *__restrict__ n_ap_p, const uint32_t *__restrict__ lq_start,
+                               const uint32_t *__restrict__ seed_cand, const uint32_t *__restrict__ seq_off,
+                               const uint8_t *__restrict__ seq, uint32_t *__restrict__ out_pos,
+                               uint8_t *__restrict__ out_base) {
+    uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= *n_ap_p) return;
+    const uint32_t g = ap_g[sl], c = seed_cand[g];
+    const uint32_t so = seq_off[c], len = seq_off[c + 1] - so;
+    const int64_t o = (int64_t)ap_s[sl] + (ap_shift_incl[sl] - ap_delta[sl]);
+    const uint32_t p = lq_start[g];
+    for (uint32_t t = 0; t < len; ++t) { // spliced bases all carry pos == start (main.rs:1039-1045)
+        out_pos[o + t] = p;
+        out_base[o + t] = seq[so + t];
+    }
+}
+
+// ---- recheck (reupdate_consensus_with_lqseqs, main.rs:1060-1420) ------------------------------------
+__global__ void k_rech_flag(const uint8_t *__restrict__ reg_lable, uint32_t n_reg, uint32_t *__restrict__ flag) {
+    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr < n_reg) flag[rr] = (reg_lable[n_reg - 1 - rr] & LB_RECH) ? 1u : 0u;
+}
+__global__ void k_rech_list(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot, uint32_t n_reg,
+                            uint32_t *__restrict__ rech, uint32_t *__restrict__ n_rech) {
+    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rr >= n_reg) return;
+    if (flag[rr]) rech[slot[rr]] = n_reg - 1 - rr;
+    if (rr == n_reg - 1) *n_rech = slot[rr] + flag[rr];
+}
+// chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions
+__global__ void k_rech_heads(const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
+                             const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end, uint32_t ksize,
+                             uint32_t *__restrict__ headflag) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *n_rech_p) return;
+    uint32_t back = 0, x = e;
+    while (x > 0 && lq_start[rech[x]] < lq_end[rech[x - 1]] + ksize) {
+        --x;
+        ++back;
+    }
+    headflag[e] = (back % 6 == 0) ? 1u : 0u;
+}
+
+struct RechGroup { // one recheck group = 1..6 chained RECH regions
+    uint32_t first, n;       // range in rech[]
+    uint32_t sl, el, sr, er; // flank index ranges in the consensus
+    uint32_t bs[5], be[5];   // consensus ranges between consecutive regions
+    uint32_t lens[6];        // kept-candidate counts (product radix)
+    uint32_t njobs;
+};
+
+__global__ void k_rech_groups(const uint32_t *__restrict__ headflag, const uint32_t *__restrict__ gslot,
+                              const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
+                              const uint32_t *__restrict__ cns_pos, uint32_t M, const uint32_t *__restrict__ lq_start,
+                              const uint32_t *__restrict__ lq_end, const uint32_t *__restrict__ keep_n, uint32_t ksize,
+                              RechGroup *__restrict__ groups, uint32_t *__restrict__ njobs,
+                              uint32_t *__restrict__ n_groups, uint32_t *__restrict__ err) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_rech = *n_rech_p;
+    if (e >= n_rech) return;
+    if (e == n_rech - 1) *n_groups = gslot[e] + headflag[e];
+    if (!headflag[e]) return;
+    RechGroup G;
+    G.first = e;
+    uint32_t n = 1;
+    while (e + n < n_rech && !headflag[e + n]) ++n;
+    G.n = n;
+    const uint32_t l = ksize - 1;
+    // iter_consensus_extend(toleft): first index with pos >= start; the reference indexes [i-1]
+    const uint32_t p0 = lq_start[rech[e]];
+    const uint32_t i0 = lower_bound_u32(cns_pos, M, p0);
+    if (i0 == 0 || i0 >= M) atomicOr(err, 64u);
+    G.el = i0;
+    G.sl = i0 > l ? i0 - l : 0;
+    // iter_consensus_extend(right): last index with pos <= end; the reference indexes [i+1]
+    const uint32_t p1 = lq_end[rech[e + n - 1]];
+    const uint32_t i1u = upper_bound_u32(cns_pos, M, p1);
+    if (i1u == 0 || i1u >= M) atomicOr(err, 64u);
+    const uint32_t i1 = i1u ? i1u - 1 : 0;
+    G.sr = i1 + 1;
+    G.er = (i1 + l < M) ? i1 + l + 1 : M;
+    uint64_t jobs = 1;
+    for (uint32_t x = 0; x < n; ++x) {
+        G.lens[x] = keep_n[rech[e + x]];
+        jobs *= G.lens[x];
+        if (jobs > 0x7FFFFFFFull) {
+            atomicOr(err, 128u);
+            jobs = 0;
+        }
+        if (x + 1 < n) { // iter_consensus_region(s, e): indices with s < pos < e
+            const uint32_t s = lq_end[rech[e + x]], en = lq_start[rech[e + x + 1]];
+            if (s + 1 == en) {
+                G.bs[x] = G.be[x] = 0;
+            } else {
+                G.bs[x] = upper_bound_u32(cns_pos, M, s);
+                G.be[x] = lower_bound_u32(cns_pos, M, en);
+                if (G.be[x] < G.bs[x]) G.be[x] = G.bs[x];
+            }
+        }
+    }
+    G.njobs = (uint32_t)jobs;
+    groups[gslot[e]] = G;
+    njobs[gslot[e]] = (uint32_t)jobs;
+}
+
+struct RechCtx {
+    const RechGroup *groups;
+    const uint32_t *job_off; // per group
+    const uint32_t *rech;
+    const uint32_t *cand_off;
+    const uint32_t *keep_list;
+    const uint32_t *seq_off;
+    const uint8_t *seq;
+    const uint8_t *cns_base;
+    uint32_t n_groups;
+};
+__device__ __forceinline__ uint32_t job_group(const RechCtx &cx, uint32_t job) {
+    uint32_t lo = 0, hi = cx.n_groups; // last group with job_off <= job
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cx.job_off[mid] <= job) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+// length (WRITE = false) or bytes (WRITE = true) of one recheck string:
+// left flank + seq_0 [+ between_0 + seq_1 ...] + right flank  (main.rs:1141-1176, 1224-1230)
+template <bool WRITE> __device__ uint32_t rech_string(const RechCtx &cx, uint32_t job, uint8_t *__restrict__ out) {
+    const uint32_t gi = job_group(cx, job);
+    const RechGroup &G = cx.groups[gi];
+    uint32_t rem = job - cx.job_off[gi];
+    uint32_t pick[6];
+    for (uint32_t x = G.n; x-- > 0;) { // last iterator fastest
+        pick[x] = rem % G.lens[x];
+        rem /= G.lens[x];
+    }
+    uint32_t o = 0;
+    for (uint32_t i = G.sl; i < G.el; ++i, ++o)
+        if (WRITE) out[o] = cx.cns_base[i];
+    for (uint32_t x = 0; x < G.n; ++x) {
+        const uint32_t g = cx.rech[G.first + x];
+        const uint32_t c = cx.keep_list[cx.cand_off[g] + pick[x]];
+        const uint32_t so = cx.seq_off[c], len = cx.seq_off[c + 1] - so;
+        for (uint32_t t = 0; t < len; ++t, ++o)
+            if (WRITE) out[o] = cx.seq[so + t];
+        if (x + 1 < G.n)
+            for (uint32_t i = G.bs[x]; i < G.be[x]; ++i, ++o)
+                if (WRITE) out[o] = cx.cns_base[i];
+    }
+    for (uint32_t i = G.sr; i < G.er; ++i, ++o)
+        if (WRITE) out[o] = cx.cns_base[i];
+    return o;
+}
+__global__ void k_rech_job_len(RechCtx cx, uint32_t n_jobs, uint32_t *__restrict__ len) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_jobs) len[j] = rech_string<false>(cx, j, nullptr);
+}
+__global__ void k_rech_job_build(RechCtx cx, uint32_t n_jobs, const uint64_t *__restrict__ soff,
+                                 uint8_t *__restrict__ blob) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_jobs) rech_string<true>(cx, j, blob + soff[j]);
+}
+__global__ void k_u32_to_u64_off(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// apply the scores: single regions take their job's score; chains zero everything, then every product with
+// score > 0 stamps its members, later products overwriting earlier ones (main.rs:1358-1366)
+__global__ void k_rech_apply(RechCtx cx, const uint16_t *__restrict__ score, uint16_t *__restrict__ keep_ks) {
+    uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= cx.n_groups) return;
+    const RechGroup &G = cx.groups[gi];
+    const uint32_t j0 = cx.job_off[gi];
+    if (G.n == 1) {
+        const uint32_t g = cx.rech[G.first];
+        for (uint32_t t = 0; t < G.lens[0]; ++t) keep_ks[cx.cand_off[g] + t] = score[j0 + t];
+        return;
+    }
+    for (uint32_t x = 0; x < G.n; ++x) {
+        const uint32_t g = cx.rech[G.first + x];
+        for (uint32_t t = 0; t < G.lens[x]; ++t) keep_ks[cx.cand_off[g] + t] = 0;
+    }
+    for (uint32_t j = 0; j < G.njobs; ++j) {
+        const uint16_t ks = score[j0 + j];
+        if (!ks) continue;
+        uint32_t rem = j;
+        for (uint32_t x = G.n; x-- > 0;) {
+            const uint32_t p = rem % G.lens[x];
+            rem /= G.lens[x];
+            keep_ks[cx.cand_off[cx.rech[G.first + x]] + p] = ks;
+        }
+    }
+}
+
+// selection per RECH region (main.rs:1371-1406)
+__global__ void k_rech_select(const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
+                              const uint32_t *__restrict__ cand_off, const uint32_t *__restrict__ keep_n,
+                              const uint32_t *__restrict__ keep_list, const uint16_t *__restrict__ keep_ks,
+                              const uint32_t *__restrict__ order, uint32_t first_yak, uint8_t *__restrict__ reg_lable,
+                              uint32_t *__restrict__ seed_cand) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *n_rech_p) return;
+    const uint32_t g = rech[e], c0 = cand_off[g], n = keep_n[g];
+    uint32_t c = 0, valid = 0;
+    for (uint32_t p = 0; p < n; ++p)
+        if (keep_ks[c0 + p] != 0) {
+            if (c == 0 || order[keep_list[c0 + p]] == 0) c = p + 1;
+            ++valid;
+        }
+    if (valid > 1) reg_lable[g] |= LB_TEMP;
+    if (c != 0) {
+        seed_cand[g] = keep_list[c0 + c - 1];
+    } else if (first_yak) { // keep the contig's own sequence if every candidate is invalid
+        uint32_t i = 0;
+        for (uint32_t p = 0; p < n; ++p)
+            if (order[keep_list[c0 + p]] == 0) {
+                i = p;
+                break;
+            }
+        seed_cand[g] = keep_list[c0 + i];
+    }
+}
+__global__ void k_rech_relabel(uint8_t *__restrict__ reg_lable, uint32_t n_reg) { // main.rs:1411-1417
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_reg) return;
+    const uint8_t l = reg_lable[g];
+    if (!(l & LB_RECH)) return;
+    reg_lable[g] = (l & LB_TEMP) ? (uint8_t)(l ^ LB_TEMP) : (uint8_t)(l ^ LB_RECH);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline dim3 g1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, uint8_t *reg_lable, uint8_t *grp,
+                       uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
+                       uint32_t *err) {
+    if (rt.n_reg)
+        hipLaunchKernelGGL(k_vote_phase, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, asref ? 1u : 0u,
+                           use_all ? 1u : 0u, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
+}
+void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
+                        const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval) {
+    if (rt.n_reg)
+        hipLaunchKernelGGL(k_edges_write, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, reg_lable, grp, ecount, eoff,
+                           ekey, eval);
+}
+void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag,
+                        int32_t *wout) {
+    if (n) hipLaunchKernelGGL(k_edge_reduce, g1(n), dim3(256), 0, s, ekey, eval, n, flag, wout);
+}
+void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx,
+                         const int32_t *wout, uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out) {
+    if (n) hipLaunchKernelGGL(k_edge_compact, g1(n), dim3(256), 0, s, ekey, flag, idx, wout, n, ukey, uw, n_out);
+}
+void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
+                 uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err) {
+    if (rt.n_reg)
+        hipLaunchKernelGGL(k_seed, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, max_indel_len, reg_lable, seed_cand,
+                           keep_n, keep_list, keep_ks, err);
+}
+void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, uint32_t M, const uint32_t *lq_start,
+                        const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
+                        uint32_t *idx_s, uint32_t *idx_e, uint32_t *stuck, uint32_t *flag) {
+    hipLaunchKernelGGL(k_splice_find, g1(n_reg), dim3(256), 0, s, cns_pos, M, lq_start, lq_end, reg_lable, lable, n_reg,
+                       idx_s, idx_e, stuck);
+    hipLaunchKernelGGL(k_splice_flag, g1(n_reg), dim3(256), 0, s, reg_lable, lable, n_reg, stuck, flag);
+}
+void launch_splice_slots(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg,
+                         const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
+                         const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
+                         uint32_t *n_ap) {
+    hipLaunchKernelGGL(k_splice_slots, g1(n_reg), dim3(256), 0, s, flag, slot, n_reg, idx_s, idx_e, seed_cand, seq_off,
+                       ap_g, ap_s, ap_e, ap_delta, n_ap);
+}
+void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, uint32_t M,
+                         const uint32_t *ap_g, const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta,
+                         const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
+                         const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
+                         uint8_t *out_base) {
+    hipLaunchKernelGGL(k_splice_bases, g1(M), dim3(256), 0, s, in_pos, in_base, M, ap_s, ap_e, ap_shift_incl, n_ap,
+                       out_pos, out_base);
+    if (max_ap)
+        hipLaunchKernelGGL(k_splice_seeds, g1(max_ap, 64), dim3(64), 0, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap,
+                           lq_start, seed_cand, seq_off, seq, out_pos, out_base);
+}
+void launch_rech_list(hipStream_t s, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *flag) {
+    hipLaunchKernelGGL(k_rech_flag, g1(n_reg), dim3(256), 0, s, reg_lable, n_reg, flag);
+}
+void launch_rech_list2(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, uint32_t *rech,
+                       uint32_t *n_rech) {
+    hipLaunchKernelGGL(k_rech_list, g1(n_reg), dim3(256), 0, s, flag, slot, n_reg, rech, n_rech);
+}
+void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t ksize, uint32_t *headflag) {
+    if (max_rech)
+        hipLaunchKernelGGL(k_rech_heads, g1(max_rech), dim3(256), 0, s, rech, n_rech_p, lq_start, lq_end, ksize,
+                           headflag);
+}
+void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
+                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, uint32_t M,
+                        const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize,
+                        void *groups, uint32_t *njobs, uint32_t *n_groups, uint32_t *err) {
+    if (max_rech)
+        hipLaunchKernelGGL(k_rech_groups, g1(max_rech, 64), dim3(64), 0, s, headflag, gslot, rech, n_rech_p, cns_pos, M,
+                           lq_start, lq_end, keep_n, ksize, (RechGroup *)groups, njobs, n_groups, err);
+}
+size_t rech_group_bytes() { return sizeof(RechGroup); }
+static RechCtx mk_rech(const RechPtrs &p) {
+    return RechCtx{(const RechGroup *)p.groups, p.job_off, p.rech, p.cand_off, p.keep_list, p.seq_off, p.seq,
+                   p.cns_base, p.n_groups};
+}
+void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len) {
+    if (n_jobs) hipLaunchKernelGGL(k_rech_job_len, g1(n_jobs, 64), dim3(64), 0, s, mk_rech(p), n_jobs, len);
+}
+void launch_rech_job_build(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, const uint32_t *soff32, uint64_t *soff64,
+                           uint8_t *blob) {
+    if (!n_jobs) return;
+    hipLaunchKernelGGL(k_u32_to_u64_off, g1(n_jobs + 1), dim3(256), 0, s, soff32, n_jobs + 1, soff64);
+    hipLaunchKernelGGL(k_rech_job_build, g1(n_jobs, 64), dim3(64), 0, s, mk_rech(p), n_jobs, soff64, blob);
+}
+void launch_rech_apply(hipStream_t s, const RechPtrs &p, const uint16_t *score, uint16_t *keep_ks) {
+    if (p.n_groups) hipLaunchKernelGGL(k_rech_apply, g1(p.n_groups, 64), dim3(64), 0, s, mk_rech(p), score, keep_ks);
+}
+void launch_rech_select(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                        const uint32_t *cand_off, const uint32_t *keep_n, const uint32_t *keep_list,
+                        const uint16_t *keep_ks, const uint32_t *order, bool first_yak, uint8_t *reg_lable,
+                        uint32_t *seed_cand) {
+    if (max_rech)
+        hipLaunchKernelGGL(k_rech_select, g1(max_rech, 64), dim3(64), 0, s, rech, n_rech_p, cand_off, keep_n, keep_list,
+                           keep_ks, order, first_yak ? 1u : 0u, reg_lable, seed_cand);
+}
+void launch_rech_relabel(hipStream_t s, uint8_t *reg_lable, uint32_t n_reg) {
+    hipLaunchKernelGGL(k_rech_relabel, g1(n_reg), dim3(256), 0, s, reg_lable, n_reg);
+}
+
+} // namespace np2
