@@ -5,6 +5,7 @@ creating a Polisher requires the in-tree HIP library and a visible MI355X device
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -73,6 +74,13 @@ for _t in ("cand", "seed", "hete", "rech0", "rech1", "rech2"):
     })
 for _t in ("cns_raw", "cns_succ", "cns_rech0", "cns_rech1", "cns_rech2"):
     TRACE_DTYPES.update({f"{_t}.pos": np.uint32, f"{_t}.base": np.uint8})
+
+
+def _owned(ptr, n, ctype):
+    """Zero-copy numpy view of a callee-allocated result buffer; np2_free runs when the array is collected."""
+    base = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(max(n, 1),))
+    weakref.finalize(base, lib().np2_free, C.c_void_p(ptr.value))
+    return base[:n]
 
 
 class ResidentContig:
@@ -144,11 +152,7 @@ class Polisher:
         ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), C.byref(ob), C.byref(op), C.byref(on)))
         n = on.value
-        bases = np.ctypeslib.as_array(C.cast(ob, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
-        pos = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
-        lib().np2_free(ob)
-        lib().np2_free(op)
-        return bases, pos
+        return _owned(ob, n, C.c_uint8), _owned(op, n, C.c_uint32)
 
     def polish(self, pileup: Pileup, opts: Opts = None):
         c = self.upload(pileup)

@@ -8,10 +8,12 @@
 #include "np2_phase_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -57,6 +59,68 @@ template <class T> struct DevBuf {
     }
 };
 
+// Pinned host memory pool for result buffers: np2_free() returns blocks here (no ctx needed).
+// Pageable D2H makes the ROCm runtime pin/unpin user pages lazily (multi-ms stalls on the next copy).
+struct PinnedPool {
+    std::mutex mu;
+    std::map<void *, size_t> live;                 // handed out
+    std::vector<std::pair<size_t, void *>> free_;  // (capacity, ptr)
+    void *get(size_t bytes) {
+        std::lock_guard<std::mutex> l(mu);
+        size_t best = free_.size();
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].first >= bytes && (best == free_.size() || free_[i].first < free_[best].first)) best = i;
+        void *p = nullptr;
+        size_t cap = 0;
+        if (best != free_.size()) {
+            p = free_[best].second;
+            cap = free_[best].first;
+            free_.erase(free_.begin() + (long)best);
+        } else {
+            cap = bytes + bytes / 8 + 4096;
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        live[p] = cap;
+        return p;
+    }
+    bool put(void *p) {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        free_.emplace_back(it->second, p);
+        live.erase(it);
+        while (free_.size() > 8) { // keep the pool small
+            (void)hipHostFree(free_.front().second);
+            free_.erase(free_.begin());
+        }
+        return true;
+    }
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool(); // leaked on purpose: outlives every context
+    return *p;
+}
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void *ensure(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            size_t want = n + n / 4 + 65536;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
+                throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            cap = want;
+        }
+        return p;
+    }
+};
+
 struct YakTable {
     uint32_t k = 0, cap_log2 = 0;
     DevBuf<uint64_t> table;
@@ -67,7 +131,11 @@ struct Timing {
     std::vector<std::string> names;
     std::vector<float> ms;
     std::string joined;
+    std::vector<std::pair<std::string, float>> host; // host wall-clock sections (ms)
 };
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 } // namespace
 
@@ -91,6 +159,7 @@ struct np2_ctx {
     Timing timing;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 
+    PinnedBuf pin_d2h, pin_h2d;
     // scratch (reused across contigs)
     DevBuf<uint8_t> tmp;
     DevBuf<uint64_t> keys_raw, keys;
@@ -117,6 +186,7 @@ struct np2_ctx {
     DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
+    DevBuf<uint32_t> long_list;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
     DevBuf<uint16_t> sscore;
@@ -125,7 +195,15 @@ struct np2_ctx {
 namespace {
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_COUNT = 24 };
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_COUNT = 24 };
+
+struct WallTimer {
+    np2_ctx *cx;
+    const char *name;
+    double t0;
+    WallTimer(np2_ctx *c, const char *n);
+    ~WallTimer();
+};
 
 struct EventTimer {
     np2_ctx *cx;
@@ -138,6 +216,9 @@ struct EventTimer {
     }
     ~EventTimer() { (void)hipEventRecord(b, cx->stream); }
 };
+
+WallTimer::WallTimer(np2_ctx *c, const char *n) : cx(c), name(n), t0(now_ms()) {}
+WallTimer::~WallTimer() { cx->timing.host.push_back({name, (float)(now_ms() - t0)}); }
 
 void flush_timings(np2_ctx *cx) {
     std::map<std::string, float> acc;
@@ -152,6 +233,11 @@ void flush_timings(np2_ctx *cx) {
         (void)hipEventDestroy(e.second.second);
     }
     cx->pending_events.clear();
+    for (auto &h : cx->timing.host) {
+        if (!acc.count(h.first)) order.push_back(h.first);
+        acc[h.first] += h.second;
+    }
+    cx->timing.host.clear();
     cx->timing.names = order;
     cx->timing.ms.clear();
     cx->timing.joined.clear();
@@ -166,10 +252,20 @@ void flush_timings(np2_ctx *cx) {
 template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
     std::vector<T> v(n);
     if (n) {
-        HIPCHK(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, cx->stream));
+        void *pin = cx->pin_d2h.ensure(n * sizeof(T));
+        HIPCHK(hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, cx->stream));
         HIPCHK(hipStreamSynchronize(cx->stream));
+        memcpy(v.data(), pin, n * sizeof(T));
     }
     return v;
+}
+// host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
+void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    HIPCHK(hipStreamSynchronize(cx->stream)); // the staging buffer may still be in flight
+    void *pin = cx->pin_h2d.ensure(bytes);
+    memcpy(pin, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, cx->stream));
 }
 template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name, const std::vector<T> &v) {
     if (!cx->trace) return;
@@ -506,15 +602,21 @@ void gpu_score_strings(np2_ctx *cx, int yak_idx, const std::vector<uint8_t> &blo
     cx->sstr.ensure(blob.size() + 16);
     cx->soff.ensure(off.size());
     cx->sscore.ensure(n);
-    HIPCHK(hipMemcpyAsync(cx->sstr.p, blob.data(), blob.size(), hipMemcpyHostToDevice, cx->stream));
-    HIPCHK(hipMemcpyAsync(cx->soff.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, cx->stream));
+    {
+        HIPCHK(hipStreamSynchronize(cx->stream));
+        uint8_t *pin = (uint8_t *)cx->pin_h2d.ensure(blob.size() + off.size() * 8 + 16);
+        const size_t o2 = (blob.size() + 7) & ~(size_t)7;
+        memcpy(pin, blob.data(), blob.size());
+        memcpy(pin + o2, off.data(), off.size() * 8);
+        HIPCHK(hipMemcpyAsync(cx->sstr.p, pin, blob.size(), hipMemcpyHostToDevice, cx->stream));
+        HIPCHK(hipMemcpyAsync(cx->soff.p, pin + o2, off.size() * 8, hipMemcpyHostToDevice, cx->stream));
+    }
     {
         EventTimer t(cx, "score_strings");
         launch_score_strings(cx->stream, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n, min_kmer_count,
                              cx->sscore.p);
     }
-    HIPCHK(hipMemcpyAsync(scores.data(), cx->sscore.p, n * 2, hipMemcpyDeviceToHost, cx->stream));
-    HIPCHK(hipStreamSynchronize(cx->stream));
+    scores = d2h(cx, cx->sscore.p, n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -530,6 +632,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     const uint32_t L = c->L, R = c->R;
     uint64_t cap_total = std::max<uint64_t>(c->n_cols / 24 + (uint64_t)R * 8 + 65536, 1u << 20);
     for (int attempt = 0; attempt < 3; ++attempt) {
+        const double tA = now_ms();
         uint32_t shard_cap = (uint32_t)((cap_total + NSHARD - 1) / NSHARD);
         uint64_t cap = (uint64_t)shard_cap * NSHARD;
         cx->keys_raw.ensure(cap);
@@ -543,10 +646,12 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
                               cx->keys_raw.p, cx->vals_raw.p, cx->shard_cnt.p, shard_cap, c->ck_off.p, c->ckpt.p,
                               cx->scal.p + S_ERR);
         }
+        const double tB = now_ms();
         std::vector<uint32_t> cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
         std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
+        const double tC = now_ms();
         uint32_t mx = 0;
         uint64_t total = 0;
         std::vector<uint64_t> off(NSHARD + 1, 0);
@@ -565,8 +670,10 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         cx->vals.ensure(T + 1);
         cx->keys_raw.ensure(std::max<uint64_t>(cap, T + 1));
         cx->shard_off.ensure(NSHARD + 1);
-        HIPCHK(hipMemcpyAsync(cx->shard_off.p, off.data(), (NSHARD + 1) * 8, hipMemcpyHostToDevice, s));
+        h2d_staged(cx, cx->shard_off.p, off.data(), (NSHARD + 1) * 8);
+        const double tD = now_ms();
         cx->tmp.ensure(prim_temp_bytes(std::max<size_t>({(size_t)T + 1, (size_t)L + 2, (size_t)R + 1})));
+        const double tE = now_ms();
         {
             EventTimer t(cx, "sort_exceptions");
             // compact into keys/vals, sort back into keys_raw/vals_raw, then swap roles
@@ -578,7 +685,15 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
                                              cx->vals_raw.p, T, 32 + pos_bits);
             if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
         }
+        const double tF = now_ms();
         HIPCHK(hipStreamSynchronize(s)); // shard_off host vector goes out of scope
+        const double tG = now_ms();
+        cx->timing.host.push_back({"w_diff_launch", (float)(tB - tA)});
+        cx->timing.host.push_back({"w_diff_d2h", (float)(tC - tB)});
+        cx->timing.host.push_back({"w_diff_host", (float)(tD - tC)});
+        cx->timing.host.push_back({"w_diff_tmpbytes", (float)(tE - tD)});
+        cx->timing.host.push_back({"w_diff_sortlaunch", (float)(tF - tE)});
+        cx->timing.host.push_back({"w_diff_sync", (float)(tG - tF)});
         return;
     }
     throw Np2Error(NP2_E_NOMEM, "exception buffer kept overflowing");
@@ -783,15 +898,21 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     CandPtrs cp{c->reads.p, c->nib.p, c->ck_off.p, c->ckpt.p, cx->lq_start.p, cx->lq_end.p, cx->pj.p, cx->yaks[0].k};
     {
         EventTimer t(cx, "candidates");
+        // pairs per region via a difference array over each read's region interval [j, s]
         zero32(cx, cx->reg_npairs.p, n_reg + 2);
-        launch_pair_fill(s, R, cx->pj.p, cx->pcount.p, cx->poff.p, cx->pair_region.p, cx->pair_read.p,
-                         cx->reg_npairs.p);
+        launch_pair_fill(s, R, cx->pj.p, cx->pcount.p, cx->poff.p, NP, cx->pair_region.p, cx->pair_read.p,
+                         (int32_t *)cx->reg_npairs.p);
+        if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, (const int32_t *)cx->reg_npairs.p,
+                                   (int32_t *)cx->reg_ncand.p, (size_t)n_reg + 1))
+            throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+        // reg_ncand temporarily holds pairs-per-region; its exclusive scan gives the sorted segment offsets
         unsigned bits = 1;
         while ((1ull << bits) < (uint64_t)n_reg + 1) ++bits;
         if (prim_sort_pairs_u32_u32(s, cx->tmp.p, cx->tmp.cap, cx->pair_region.p, cx->pair_region_s.p,
                                     cx->pair_read.p, cx->pair_read_s.p, NP, bits))
             throw Np2Error(NP2_E_DEVICE, "rocprim pair sort failed");
-        exclusive_total(cx, cx->reg_npairs.p, cx->reg_poff.p, (size_t)n_reg + 1);
+        zero32(cx, cx->reg_ncand.p + n_reg, 1);
+        exclusive_total(cx, cx->reg_ncand.p, cx->reg_poff.p, (size_t)n_reg + 1);
         launch_cand_measure(s, cp, cx->pair_region_s.p, cx->pair_read_s.p, NP, cx->pair_len.p);
         launch_region_rank(s, cx->reg_poff.p, n_reg, cx->pair_len.p, cx->pair_keep.p, cx->reg_ncand.p);
         zero32(cx, cx->reg_ncand.p + n_reg, 1);
@@ -823,12 +944,14 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
         EventTimer t(cx, "candidates");
         launch_cand_write(s, cp, cx->pair_region_s.p, cx->pair_read_s.p, cx->pair_keep.p, cx->cand_idx.p,
                           cx->seq_off.p, NP, cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
-        HIPCHK(hipMemcpyAsync(cx->cand_seq_off.p + NC, &SB, 4, hipMemcpyHostToDevice, s));
+        h2d_staged(cx, cx->cand_seq_off.p + NC, &SB, 4);
     }
     {
         EventTimer t(cx, "kmer_score");
+        cx->long_list.ensure(NC + 2);
+        zero32(cx, cx->scal.p + S_NLONG, 1);
         launch_cand_score(s, cx->yaks[0].dev(), cx->cand_seq_off.p, cx->cand_seq.p, cx->cand_kmer.p, NC,
-                          min_kmer_count, cx->kscore.p);
+                          min_kmer_count, cx->kscore.p, cx->long_list.p, cx->scal.p + S_NLONG);
     }
     HIPCHK(hipStreamSynchronize(s));
     pc.n_reg = n_reg;
@@ -844,7 +967,24 @@ Cns fetch_cns(np2_ctx *cx, uint32_t M) {
     return c;
 }
 
-void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
+struct ResultOut {
+    uint8_t *bases = nullptr;
+    uint32_t *pos = nullptr;
+    uint64_t len = 0;
+};
+void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, uint32_t M, ResultOut &r) {
+    const double t0 = now_ms();
+    r.len = M;
+    r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
+    r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
+    if (!r.bases || !r.pos) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+    HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
+    HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
+    HIPCHK(hipStreamSynchronize(cx->stream));
+    cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
+}
+
+void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
     if (o->iter_count < 1) throw Np2Error(NP2_E_ARG, "iter_count must be >= 1");
     hipStream_t s = cx->stream;
     HIPCHK(hipSetDevice(cx->device));
@@ -852,14 +992,23 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
     cx->scal.ensure(S_COUNT);
     cx->alive.ensure(c->R + 2);
     uint32_t T = 0;
-    run_diff(cx, c, T);
+    {
+        WallTimer w(cx, "wall_diff");
+        run_diff(cx, c, T);
+    }
     launch_init_alive(s, c->reads.p, c->R, cx->alive.p);
     for (uint32_t pass = 0; pass < o->iter_count; ++pass) {
         const bool out_cns = pass + 1 == o->iter_count;
         uint32_t n_nodes = 0, n_runs = 0, M = 0, n_reg = 0;
-        build_graph(cx, c, T, n_nodes, n_runs);
+        {
+            WallTimer w(cx, "wall_graph");
+            build_graph(cx, c, T, n_nodes, n_runs);
+        }
         trace_graph(cx, c, (int)pass, n_nodes);
-        consensus_and_regions(cx, c, n_runs, M, n_reg);
+        {
+            WallTimer w(cx, "wall_cns_lq");
+            consensus_and_regions(cx, c, n_runs, M, n_reg);
+        }
         if (cx->trace) {
             trace_cns(cx, (int)pass, "cns_raw", fetch_cns(cx, M));
             trace_put(cx, (int)pass, "lq.start", d2h(cx, cx->lq_start.p, n_reg));
@@ -867,25 +1016,30 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
         }
         if (n_reg == 0) {
             if (out_cns) {
-                result = fetch_cns(cx, M);
+                fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, M, result);
                 return;
             }
             continue;
         }
         PassCounts pc;
         pc.M = M;
-        extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
+        {
+            WallTimer w(cx, "wall_extract");
+            extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
+        }
         if (!out_cns) {
+            WallTimer w(cx, "wall_vote");
             std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
             trace_put(cx, (int)pass, "invalid_ids", losers);
             for (uint32_t id : losers) REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
             if (!losers.empty()) {
                 cx->kill_ids.ensure(losers.size());
-                HIPCHK(hipMemcpyAsync(cx->kill_ids.p, losers.data(), losers.size() * 4, hipMemcpyHostToDevice, s));
+                h2d_staged(cx, cx->kill_ids.p, losers.data(), losers.size() * 4);
                 launch_kill_reads(s, cx->kill_ids.p, (uint32_t)losers.size(), cx->alive.p);
                 HIPCHK(hipStreamSynchronize(s));
             }
         } else {
+            WallTimer w(cx, "wall_final");
             RegionTables rt = region_tables(cx, n_reg);
             cx->reg_lable.ensure(n_reg + 2);
             cx->seed_cand.ensure(n_reg + 2);
@@ -911,7 +1065,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, Cns &result) {
                 trace_region_tables(cx, (int)pass, "rech" + std::to_string(y), pc, true);
                 if (cx->trace) trace_cns(cx, (int)pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
             }
-            result = fetch_cns_dev(cx, cur);
+            fetch_result(cx, cur.pos, cur.base, cur.M, result);
             return;
         }
     }
@@ -1055,21 +1209,22 @@ void np2_contig_free(np2_ctx_t *cx, np2_contig_t *c) {
 int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, uint8_t **out_bases,
                         uint32_t **out_pos, uint64_t *out_len) {
     if (!cx || !c || !opts || !out_bases || !out_pos || !out_len) return NP2_E_ARG;
-    Cns r;
+    ResultOut r;
+    const double t_wall0 = now_ms();
     try {
         polish_impl(cx, c, opts, r);
+        cx->timing.host.push_back({"wall_polish", (float)(now_ms() - t_wall0)});
         flush_timings(cx);
     } catch (const Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);
         flush_timings(cx);
+        if (r.bases) pinned_pool().put(r.bases);
+        if (r.pos) pinned_pool().put(r.pos);
         return fail(cx, e);
     }
-    *out_len = r.size();
-    *out_bases = (uint8_t *)malloc(r.size() + 1);
-    *out_pos = (uint32_t *)malloc((r.size() + 1) * sizeof(uint32_t));
-    if (!*out_bases || !*out_pos) return NP2_E_NOMEM;
-    memcpy(*out_bases, r.base.data(), r.size());
-    memcpy(*out_pos, r.pos.data(), r.size() * sizeof(uint32_t));
+    *out_len = r.len;
+    *out_bases = r.bases;
+    *out_pos = r.pos;
     return NP2_OK;
 }
 
@@ -1083,7 +1238,10 @@ int np2_polish_contig(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
     np2_contig_free(cx, c);
     return rc;
 }
-void np2_free(void *p) { free(p); }
+void np2_free(void *p) {
+    if (!p) return;
+    if (!pinned_pool().put(p)) free(p);
+}
 
 int np2_score_strings(np2_ctx_t *cx, int yak_idx, const uint8_t *strs, const uint64_t *off, uint64_t n,
                       uint16_t min_kmer_count, uint16_t *scores) {

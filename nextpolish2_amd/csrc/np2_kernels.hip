@@ -547,14 +547,12 @@ __global__ void k_dp_runs(const uint32_t *__restrict__ run_start, const uint32_t
 // sum of the gains of clean positions whose predecessor is clean (or p == 0): 10*c0 - 4*cov = 6*cov
 __global__ void k_clean_gain(const uint32_t *__restrict__ node_off, const int32_t *__restrict__ cov, uint32_t L,
                              unsigned long long *__restrict__ total_gain) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     long long v = 0;
-    if (p < L) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < L; p += gridDim.x * blockDim.x) {
         const bool d = node_off[p + 1] > node_off[p];
         const bool dp = p > 0 && node_off[p] > node_off[p - 1];
-        if (!d && !dp) v = 6LL * cov[p];
+        if (!d && !dp) v += 6LL * cov[p];
     }
-    // block reduction
     __shared__ long long sm[4];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -860,17 +858,27 @@ __global__ void k_pair_count(const np2_read_t *__restrict__ reads, uint32_t R, c
     pcount[r] = cnt;
 }
 
-__global__ void k_pair_fill(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ pcount,
-                            const uint32_t *__restrict__ poff, uint32_t *__restrict__ pair_region,
-                            uint32_t *__restrict__ pair_read, uint32_t *__restrict__ reg_npairs) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const uint32_t n = pcount[r], o = poff[r], j = pj[r];
-    for (uint32_t i = 0; i < n; ++i) {
-        pair_region[o + i] = j + i;
-        pair_read[o + i] = r;
-        atomicAdd(&reg_npairs[j + i], 1u);
+// one thread per (read, region) pair: the read is found by binary search in the pair offsets
+__global__ void k_pair_fill(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ poff,
+                            uint32_t n_pairs, uint32_t *__restrict__ pair_region, uint32_t *__restrict__ pair_read) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    uint32_t lo = 0, hi = R; // last read with poff[r] <= i
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (poff[mid] <= i) lo = mid + 1; else hi = mid;
     }
+    const uint32_t r = lo - 1;
+    pair_region[i] = pj[r] + (i - poff[r]);
+    pair_read[i] = r;
+}
+// pairs per region = number of reads whose region interval [j, s] covers it: difference array
+__global__ void k_pair_region_diff(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ pcount,
+                                   int32_t *__restrict__ reg_diff) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R || pcount[r] == 0) return;
+    atomicAdd(&reg_diff[pj[r]], 1);
+    atomicAdd(&reg_diff[pj[r] + pcount[r]], -1);
 }
 
 struct CandCtx {
@@ -1065,22 +1073,34 @@ __global__ void k_score_strings(YakDev y, const uint8_t *__restrict__ strs, cons
     if ((threadIdx.x & 63) == 0) out[w] = sc;
 }
 
-// retrieve_kmer_count (main.rs:740-778): len > k -> min over the candidate's own k-mers,
-// else the pre-hashed first k-mer, else 0
-__global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint8_t *__restrict__ cand_seq,
-                             const uint64_t *__restrict__ cand_kmer, uint32_t n_cand, uint16_t min_count,
-                             uint16_t *__restrict__ kscore) {
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w >= n_cand) return;
-    const uint32_t len = cand_seq_off[w + 1] - cand_seq_off[w];
+// retrieve_kmer_count (main.rs:740-778): len > k -> min over the candidate's own k-mers (rare: one wave
+// each, second kernel), else the pre-hashed first k-mer (one lookup, thread per candidate), else 0
+__global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint64_t *__restrict__ cand_kmer,
+                             uint32_t n_cand, uint16_t min_count, uint16_t *__restrict__ kscore,
+                             uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const uint32_t len = cand_seq_off[c + 1] - cand_seq_off[c];
     uint16_t sc = 0;
     if (len > y.k) {
-        sc = wave_score_string(y, cand_seq + cand_seq_off[w], len, min_count);
-    } else if ((threadIdx.x & 63) == 0) {
-        const uint64_t km = cand_kmer[w];
+        long_list[atomicAdd(n_long, 1u)] = c;
+    } else {
+        const uint64_t km = cand_kmer[c];
         if (km != INVALID_KMER) sc = yak_get(y, km, min_count);
     }
-    if ((threadIdx.x & 63) == 0) kscore[w] = sc;
+    kscore[c] = sc;
+}
+__global__ void k_cand_score_long(YakDev y, const uint32_t *__restrict__ cand_seq_off,
+                                  const uint8_t *__restrict__ cand_seq, const uint32_t *__restrict__ long_list,
+                                  const uint32_t *__restrict__ n_long, uint16_t min_count,
+                                  uint16_t *__restrict__ kscore) {
+    const uint32_t nl = *n_long;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nl; w += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t c = long_list[w];
+        const uint16_t sc = wave_score_string(y, cand_seq + cand_seq_off[c], cand_seq_off[c + 1] - cand_seq_off[c],
+                                              min_count);
+        if ((threadIdx.x & 63) == 0) kscore[c] = sc;
+    }
 }
 
 } // namespace np2
@@ -1147,7 +1167,7 @@ void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, co
     if (max_runs)
         hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, 64), dim3(64), 0, s, run_start, n_runs, g, nscore, nbesti,
                            n0_besti, run_end, last_n0_score, total_gain);
-    hipLaunchKernelGGL(k_clean_gain, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.cov, gp.L, total_gain);
+    hipLaunchKernelGGL(k_clean_gain, dim3(min(1024u, (gp.L + 255) / 256)), dim3(256), 0, s, gp.node_off, gp.cov, gp.L, total_gain);
     hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
 }
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
@@ -1206,9 +1226,10 @@ void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const
                        pcount);
 }
 void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
-                      uint32_t *pair_region, uint32_t *pair_read, uint32_t *reg_npairs) {
-    hipLaunchKernelGGL(k_pair_fill, grid1(R), dim3(256), 0, s, R, pj, pcount, poff, pair_region, pair_read,
-                       reg_npairs);
+                      uint32_t n_pairs, uint32_t *pair_region, uint32_t *pair_read, int32_t *reg_diff) {
+    hipLaunchKernelGGL(k_pair_region_diff, grid1(R), dim3(256), 0, s, R, pj, pcount, reg_diff);
+    if (n_pairs)
+        hipLaunchKernelGGL(k_pair_fill, grid1(n_pairs), dim3(256), 0, s, R, pj, poff, n_pairs, pair_region, pair_read);
 }
 static CandCtx mk_cand(const CandPtrs &c) {
     return CandCtx{c.reads, c.nib, c.ck_off, c.ckpt, c.lq_start, c.lq_end, c.pj, c.ksize};
@@ -1248,9 +1269,12 @@ void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, c
     if (n) hipLaunchKernelGGL(k_score_strings, grid1(n * 64), dim3(256), 0, s, y, strs, off, n, min_count, out);
 }
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
-                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore) {
-    if (n_cand)
-        hipLaunchKernelGGL(k_cand_score, grid1((uint64_t)n_cand * 64), dim3(256), 0, s, y, cand_seq_off, cand_seq,
-                           cand_kmer, n_cand, min_count, kscore);
+                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
+                       uint32_t *long_list, uint32_t *n_long) {
+    if (!n_cand) return;
+    hipLaunchKernelGGL(k_cand_score, grid1(n_cand), dim3(256), 0, s, y, cand_seq_off, cand_kmer, n_cand, min_count,
+                       kscore, long_list, n_long);
+    hipLaunchKernelGGL(k_cand_score_long, dim3(1024), dim3(256), 0, s, y, cand_seq_off, cand_seq, long_list, n_long,
+                       min_count, kscore);
 }
 } // namespace np2

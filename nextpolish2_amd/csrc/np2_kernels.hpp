@@ -82,7 +82,7 @@ void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uin
 void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                        const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
 void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
-                      uint32_t *pair_region, uint32_t *pair_read, uint32_t *reg_npairs);
+                      uint32_t n_pairs, uint32_t *pair_region, uint32_t *pair_read, int32_t *reg_diff);
 void launch_cand_measure(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
                          uint32_t n_pairs, uint32_t *pair_len);
 void launch_region_rank(hipStream_t s, const uint32_t *reg_poff, uint32_t n_reg, const uint32_t *pair_len,
@@ -96,7 +96,8 @@ void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint6
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
                           uint16_t min_count, uint16_t *out);
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
-                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore);
+                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
+                       uint32_t *long_list, uint32_t *n_long);
 
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
