@@ -87,6 +87,11 @@ void np2_contig_free(np2_ctx_t *ctx, np2_contig_t *c);
 int np2_polish_resident(np2_ctx_t *ctx, np2_contig_t *c, const np2_opts_t *opts,
                         uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
 
+/* FASTA header span of the last successful polish on this context: pos of the first / last consensus
+ * base (display_consensusbase_vec, main.rs:627-632).  `out_pos` of np2_polish_resident may be NULL when
+ * only the sequence and this span are needed (FASTA output), which skips a 4 B/bp device-to-host copy. */
+int np2_last_span(np2_ctx_t *ctx, uint32_t *first_pos, uint32_t *last_pos);
+
 /* Convenience: upload + polish + free (PCIe-inclusive). */
 int np2_polish_contig(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads,
                       uint32_t n_reads, const uint8_t *nibbles, uint64_t nib_bytes,

@@ -19,7 +19,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
-    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings", "np2_last_span",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -58,6 +58,7 @@ def lib():
         L.np2_ctx_set_trace.argtypes = [vp, C.c_int]
         L.np2_trace_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
         L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
+        L.np2_last_span.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         _LIB = L
     return _LIB
 
@@ -147,12 +148,21 @@ class Polisher:
                                             C.byref(h)))
         return ResidentContig(self, h, pileup)
 
-    def polish_resident(self, contig: ResidentContig, opts: Opts = None):
+    def polish_resident(self, contig: ResidentContig, opts: Opts = None, want_pos=True):
+        """np2_polish_resident.  want_pos=False returns (bases, (first_pos, last_pos)) — all a FASTA record needs."""
         o = (opts or Opts()).c()
         ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
-        self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), C.byref(ob), C.byref(op), C.byref(on)))
+        self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), C.byref(ob),
+                                              C.byref(op) if want_pos else None, C.byref(on)))
         n = on.value
-        return _owned(ob, n, C.c_uint8), _owned(op, n, C.c_uint32)
+        if want_pos:
+            return _owned(ob, n, C.c_uint8), _owned(op, n, C.c_uint32)
+        return _owned(ob, n, C.c_uint8), self.last_span()
+
+    def last_span(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(lib().np2_last_span(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def polish(self, pileup: Pileup, opts: Opts = None):
         c = self.upload(pileup)

@@ -160,6 +160,8 @@ struct np2_ctx {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 
     PinnedBuf pin_d2h, pin_h2d;
+    uint32_t last_first_pos = 0, last_last_pos = 0;
+    bool reuse_identical_pass = true;
     // scratch (reused across contigs)
     DevBuf<uint8_t> tmp;
     DevBuf<uint64_t> keys_raw, keys;
@@ -187,6 +189,7 @@ struct np2_ctx {
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list;
+    DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
     DevBuf<uint16_t> sscore;
@@ -971,16 +974,22 @@ struct ResultOut {
     uint8_t *bases = nullptr;
     uint32_t *pos = nullptr;
     uint64_t len = 0;
+    bool want_pos = true;
 };
 void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, uint32_t M, ResultOut &r) {
     const double t0 = now_ms();
     r.len = M;
     r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
-    r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
-    if (!r.bases || !r.pos) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+    if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
+    if (!r.bases || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
     HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
-    HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
+    if (r.want_pos) HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
+    uint32_t *span = (uint32_t *)cx->pin_d2h.ensure(16);
+    HIPCHK(hipMemcpyAsync(span, dpos, 4, hipMemcpyDeviceToHost, cx->stream));
+    HIPCHK(hipMemcpyAsync(span + 1, dpos + (M - 1), 4, hipMemcpyDeviceToHost, cx->stream));
     HIPCHK(hipStreamSynchronize(cx->stream));
+    cx->last_first_pos = span[0];
+    cx->last_last_pos = span[1];
     cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
 }
 
@@ -997,38 +1006,55 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
         run_diff(cx, c, T);
     }
     launch_init_alive(s, c->reads.p, c->R, cx->alive.p);
+    // If a phasing pass votes out no read, the next pass would rebuild a byte-identical graph, consensus,
+    // region list and candidate table (they are pure functions of the pileup and the live-read set): reuse
+    // them.  The reference recomputes (main.rs:1819-1836); the result is identical by construction.
+    bool reuse = false;
+    uint32_t M = 0, n_reg = 0;
+    PassCounts pc;
     for (uint32_t pass = 0; pass < o->iter_count; ++pass) {
         const bool out_cns = pass + 1 == o->iter_count;
-        uint32_t n_nodes = 0, n_runs = 0, M = 0, n_reg = 0;
-        {
-            WallTimer w(cx, "wall_graph");
-            build_graph(cx, c, T, n_nodes, n_runs);
-        }
-        trace_graph(cx, c, (int)pass, n_nodes);
-        {
-            WallTimer w(cx, "wall_cns_lq");
-            consensus_and_regions(cx, c, n_runs, M, n_reg);
-        }
-        if (cx->trace) {
-            trace_cns(cx, (int)pass, "cns_raw", fetch_cns(cx, M));
-            trace_put(cx, (int)pass, "lq.start", d2h(cx, cx->lq_start.p, n_reg));
-            trace_put(cx, (int)pass, "lq.end", d2h(cx, cx->lq_end.p, n_reg));
+        if (!reuse) {
+            uint32_t n_nodes = 0, n_runs = 0;
+            {
+                WallTimer w(cx, "wall_graph");
+                build_graph(cx, c, T, n_nodes, n_runs);
+            }
+            trace_graph(cx, c, (int)pass, n_nodes);
+            {
+                WallTimer w(cx, "wall_cns_lq");
+                consensus_and_regions(cx, c, n_runs, M, n_reg);
+            }
+            if (cx->trace) {
+                trace_cns(cx, (int)pass, "cns_raw", fetch_cns(cx, M));
+                trace_put(cx, (int)pass, "lq.start", d2h(cx, cx->lq_start.p, n_reg));
+                trace_put(cx, (int)pass, "lq.end", d2h(cx, cx->lq_end.p, n_reg));
+            }
         }
         if (n_reg == 0) {
             if (out_cns) {
                 fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, M, result);
                 return;
             }
+            reuse = cx->reuse_identical_pass && !cx->trace; // no region -> no read is voted out
             continue;
         }
-        PassCounts pc;
-        pc.M = M;
-        {
+        if (!reuse) {
+            pc = PassCounts();
+            pc.M = M;
             WallTimer w(cx, "wall_extract");
             extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
+        } else if (pc.NC) { // undo mark_hete's kscore edits of the previous (identical) pass
+            HIPCHK(hipMemcpyAsync(cx->kscore.p, cx->kscore_saved.p, (size_t)pc.NC * 2, hipMemcpyDeviceToDevice, s));
         }
+        reuse = false;
         if (!out_cns) {
             WallTimer w(cx, "wall_vote");
+            const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
+            if (may_reuse && pc.NC) {
+                cx->kscore_saved.ensure(pc.NC + 2);
+                HIPCHK(hipMemcpyAsync(cx->kscore_saved.p, cx->kscore.p, (size_t)pc.NC * 2, hipMemcpyDeviceToDevice, s));
+            }
             std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
             trace_put(cx, (int)pass, "invalid_ids", losers);
             for (uint32_t id : losers) REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
@@ -1037,6 +1063,8 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
                 h2d_staged(cx, cx->kill_ids.p, losers.data(), losers.size() * 4);
                 launch_kill_reads(s, cx->kill_ids.p, (uint32_t)losers.size(), cx->alive.p);
                 HIPCHK(hipStreamSynchronize(s));
+            } else if (may_reuse) {
+                reuse = true;
             }
         } else {
             WallTimer w(cx, "wall_final");
@@ -1208,8 +1236,9 @@ void np2_contig_free(np2_ctx_t *cx, np2_contig_t *c) {
 
 int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, uint8_t **out_bases,
                         uint32_t **out_pos, uint64_t *out_len) {
-    if (!cx || !c || !opts || !out_bases || !out_pos || !out_len) return NP2_E_ARG;
+    if (!cx || !c || !opts || !out_bases || !out_len) return NP2_E_ARG;
     ResultOut r;
+    r.want_pos = out_pos != nullptr;
     const double t_wall0 = now_ms();
     try {
         polish_impl(cx, c, opts, r);
@@ -1224,7 +1253,7 @@ int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, 
     }
     *out_len = r.len;
     *out_bases = r.bases;
-    *out_pos = r.pos;
+    if (out_pos) *out_pos = r.pos;
     return NP2_OK;
 }
 
@@ -1275,6 +1304,13 @@ int np2_lookup_hashes(np2_ctx_t *cx, int yak_idx, const uint64_t *hashes, uint64
     } catch (const Np2Error &e) {
         return fail(cx, e);
     }
+    return NP2_OK;
+}
+
+int np2_last_span(np2_ctx_t *cx, uint32_t *first_pos, uint32_t *last_pos) {
+    if (!cx || !first_pos || !last_pos) return NP2_E_ARG;
+    *first_pos = cx->last_first_pos;
+    *last_pos = cx->last_last_pos;
     return NP2_OK;
 }
 

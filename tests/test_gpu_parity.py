@@ -148,6 +148,23 @@ def test_bad_inputs_are_rejected_with_error_codes(small_haploid):
     assert gb.tobytes() == s.hap1
 
 
+def test_identical_pass_reuse_and_bases_only_output(small_haploid, small_diploid):
+    # trace mode recomputes every pass; the default mode reuses a byte-identical pass (no read voted out)
+    for s, yaks in (small_haploid, small_diploid):
+        g = Polisher(yaks)
+        c = g.upload(s.pileup)
+        b1, p1 = g.polish_resident(c, Opts())
+        g.set_trace(True)
+        b2, p2 = g.polish_resident(c, Opts())
+        g.set_trace(False)
+        assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+        b3, span = g.polish_resident(c, Opts(), want_pos=False)
+        assert np.array_equal(b1, b3) and span == (int(p1[0]), int(p1[-1]))
+        b4, _ = g.polish_resident(c, Opts(iter_count=4))
+        ob, _ = orc.Oracle(yaks).polish(s.pileup, Opts(iter_count=4))
+        assert np.array_equal(b4, ob)
+
+
 def test_full_size_properties():
     """BASELINE.json configs[1] scale (4.6 Mb, 30x, k21): size-independent properties — the polished
     sequence equals the simulated truth, positions are non-decreasing, and a second call is identical."""
