@@ -147,6 +147,9 @@ struct np2_contig {
     DevBuf<uint8_t> refnib; // nibble-packed contig codes (+ padding), also viewed as uint64_t words
     DevBuf<uint64_t> ck_off;
     DevBuf<uint32_t> ckpt;
+    // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
+    uint32_t n_chunks = 0;
+    DevBuf<uint32_t> chunk_read, chunk_base;
 };
 
 struct np2_ctx {
@@ -188,7 +191,7 @@ struct np2_ctx {
     DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
-    DevBuf<uint32_t> long_list;
+    DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
@@ -643,11 +646,20 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         cx->shard_cnt.ensure(NSHARD * SHARD_STRIDE);
         zero32(cx, cx->shard_cnt.p, NSHARD * SHARD_STRIDE);
         zero32(cx, cx->scal.p, S_COUNT);
+        cx->chunk_n.ensure(c->n_chunks + 2);
+        cx->chunk_pre.ensure(c->n_chunks + 2);
+        cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)c->n_chunks + 2, (size_t)L + 2)));
+        {
+            EventTimer t(cx, "chunk_prefix");
+            launch_chunk_count(s, c->reads.p, c->nib.p, c->chunk_read.p, c->chunk_base.p, c->n_chunks, cx->chunk_n.p);
+            zero32(cx, cx->chunk_n.p + c->n_chunks, 1);
+            exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)c->n_chunks + 1);
+        }
         {
             EventTimer t(cx, "diff_reads");
             launch_diff_reads(s, c->reads.p, R, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
-                              cx->keys_raw.p, cx->vals_raw.p, cx->shard_cnt.p, shard_cap, c->ck_off.p, c->ckpt.p,
-                              cx->scal.p + S_ERR);
+                              c->chunk_read.p, c->chunk_base.p, cx->chunk_pre.p, c->n_chunks, cx->keys_raw.p,
+                              cx->vals_raw.p, cx->shard_cnt.p, shard_cap, c->ck_off.p, c->ckpt.p, cx->scal.p + S_ERR);
         }
         const double tB = now_ms();
         std::vector<uint32_t> cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
@@ -1202,6 +1214,20 @@ int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
             ck[r + 1] = ck[r] + (last >= first ? last - first + 1 : 0);
             cols += rd.n_cols;
         }
+        std::vector<uint32_t> chunk_base(n_reads + 1, 0), chunk_read;
+        for (uint32_t r = 0; r < n_reads; ++r) {
+            uint32_t nch = 0;
+            if (r != 0 && !(reads[r].flags & NP2_READ_DROPPED)) nch = (reads[r].n_cols + 2047) / 2048;
+            chunk_base[r + 1] = chunk_base[r] + nch;
+            for (uint32_t k = 0; k < nch; ++k) chunk_read.push_back(r);
+        }
+        c->n_chunks = chunk_base[n_reads];
+        c->chunk_base.ensure(n_reads + 1);
+        c->chunk_read.ensure(c->n_chunks + 1);
+        HIPCHK(hipMemcpyAsync(c->chunk_base.p, chunk_base.data(), (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, cx->stream));
+        if (c->n_chunks)
+            HIPCHK(hipMemcpyAsync(c->chunk_read.p, chunk_read.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream)); // host vectors go out of scope
         c->L = L;
         c->R = n_reads;
         c->nib_bytes = nib_bytes;

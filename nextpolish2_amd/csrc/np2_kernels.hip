@@ -150,134 +150,277 @@ __device__ void emit_lane(const EmitCtx &cx, uint32_t lc0, uint32_t Nb, uint32_t
     }
 }
 
+// register-resident emission: the lane's 32 columns live in (lo, hi, im); the two columns before
+// the lane come from the previous lane (or the previous chunk) as (code, insertion flag, delta)
+struct PrevCols {
+    uint8_t q31, q30;   // codes of the previous lane's columns 31 / 30
+    uint8_t i31, i30;   // insertion flags
+    uint16_t d31, d30;  // their deltas
+};
+__device__ __forceinline__ uint8_t reg_nib(uint64_t lo, uint64_t hi, uint32_t j) {
+    return (uint8_t)(((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16)))) & 7);
+}
+__device__ void emit_lane_regs(uint64_t lo, uint64_t hi, uint32_t im, uint32_t E, uint32_t ts, uint32_t lc0,
+                               uint32_t Nb, const PrevCols &pv, uint32_t read, uint64_t *__restrict__ out_keys,
+                               uint32_t *__restrict__ out_vals, uint64_t out_base, uint64_t out_limit) {
+    const uint32_t first = __builtin_ctz(E), last = 31 - __builtin_clz(E);
+    // AlignBase of lane column j in [-2, 31]
+    auto col = [&](int j) -> AlignBase {
+        const int64_t gc = (int64_t)lc0 + j;
+        if (gc == -2) return ab_head(ts - 1, 0);
+        if (gc == -1) return ab_head(ts - 1, 1);
+        AlignBase a;
+        if (j == -1) {
+            a.q = pv.q31;
+            a.t_pos = ts + Nb - 1;
+            a.delta = pv.i31 ? pv.d31 : 0;
+        } else if (j == -2) {
+            a.q = pv.q30;
+            a.t_pos = ts + Nb - 1 - (pv.i31 ? 0u : 1u);
+            a.delta = pv.i30 ? pv.d30 : 0;
+        } else {
+            a.q = reg_nib(lo, hi, (uint32_t)j);
+            const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
+            a.t_pos = ts + Nb + __builtin_popcount(~im & low) - 1;
+            a.delta = 0;
+            if ((im >> j) & 1u) {
+                // consecutive insertion columns ending at j (within the lane)
+                const uint32_t inv = ~(im << (31 - j));
+                const uint32_t run = inv ? (uint32_t)__builtin_clz(inv) : 32u;
+                uint32_t d = run > (uint32_t)j + 1 ? (uint32_t)j + 1 : run;
+                if (d == (uint32_t)j + 1 && pv.i31) d += pv.d31; // the run continues into the previous lane
+                a.delta = (uint16_t)d;
+            }
+        }
+        return a;
+    };
+    AlignBase b1 = col((int)first - 2), b2 = col((int)first - 1);
+    uint64_t o = out_base;
+    for (uint32_t j = first; j <= last; ++j) {
+        const uint32_t gc = lc0 + j;
+        AlignBase b3;
+        b3.q = reg_nib(lo, hi, j);
+        if (gc == 0) {
+            b3.t_pos = ts;
+            b3.delta = 0;
+        } else if ((im >> j) & 1u) {
+            b3.t_pos = b2.t_pos;
+            b3.delta = (uint16_t)(b2.delta + 1);
+        } else {
+            b3.t_pos = b2.t_pos + 1;
+            b3.delta = 0;
+        }
+        if ((E >> j) & 1u) {
+            if (o < out_limit) {
+                out_keys[o] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
+                out_vals[o] = read;
+            }
+            ++o;
+        }
+        b1 = b2;
+        b2 = b3;
+    }
+}
+
+// decode the lane's 16 bytes into codes (lo, hi), the compact insertion mask and the valid count
+struct LaneCols {
+    uint64_t lo, hi, mlo, mhi;
+    uint64_t ilo, ihi;
+    uint32_t nv, n_ins;
+};
+__device__ __forceinline__ LaneCols load_lane(const uint8_t *__restrict__ base, uint32_t lc0, uint32_t ncols) {
+    LaneCols c;
+    c.nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c.nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
+    c.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
+    c.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
+    c.mlo = ~0ULL, c.mhi = ~0ULL;
+    if (c.nv < 32) {
+        if (c.nv <= 16) {
+            c.mhi = 0;
+            c.mlo = c.nv == 16 ? ~0ULL : ((1ULL << (4 * c.nv)) - 1);
+        } else {
+            c.mhi = (1ULL << (4 * (c.nv - 16))) - 1;
+        }
+    }
+    c.lo &= c.mlo;
+    c.hi &= c.mhi;
+    c.ilo = c.lo & 0x8888888888888888ULL, c.ihi = c.hi & 0x8888888888888888ULL;
+    if (lc0 == 0) c.ilo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
+    c.lo &= 0x7777777777777777ULL;
+    c.hi &= 0x7777777777777777ULL;
+    c.n_ins = __builtin_popcountll(c.ilo) + __builtin_popcountll(c.ihi);
+    return c;
+}
+
+// pre-pass: non-insertion columns per 2048-column chunk (one wavefront per chunk)
+__global__ __launch_bounds__(256) void k_chunk_count(const np2_read_t *__restrict__ reads,
+                                                     const uint8_t *__restrict__ nib,
+                                                     const uint32_t *__restrict__ chunk_read,
+                                                     const uint32_t *__restrict__ chunk_base, uint32_t n_chunks,
+                                                     uint32_t *__restrict__ chunk_n) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    const uint32_t r = chunk_read[ch];
+    const np2_read_t rd = reads[r];
+    const uint32_t lc0 = (ch - chunk_base[r]) * 2048 + lane * 32;
+    const LaneCols c = load_lane(nib + rd.nib_off, lc0, rd.n_cols);
+    uint32_t v = c.nv - c.n_ins;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) chunk_n[ch] = v;
+}
+
 __global__ __launch_bounds__(256) void k_diff_reads(
     const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ nib,
     const uint64_t *__restrict__ refw, const uint8_t *__restrict__ refnib, uint32_t L,
-    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ shard_cnt,
-    uint32_t shard_cap, const uint64_t *__restrict__ ck_off, uint32_t *__restrict__ ckpt,
-    uint32_t *__restrict__ err) {
+    const uint32_t *__restrict__ chunk_read, const uint32_t *__restrict__ chunk_base,
+    const uint32_t *__restrict__ chunk_pre, uint32_t n_chunks, uint64_t *__restrict__ out_keys,
+    uint32_t *__restrict__ out_vals, uint32_t *__restrict__ shard_cnt, uint32_t shard_cap,
+    const uint64_t *__restrict__ ck_off, uint32_t *__restrict__ ckpt, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t r = gwave;
-    if (r >= R || r == 0) return;
+    const uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    const uint32_t r = chunk_read[ch];
     const np2_read_t rd = reads[r];
-    if (rd.flags & NP2_READ_DROPPED) return;
     const uint8_t *base = nib + rd.nib_off;
     const uint32_t ncols = rd.n_cols, ts = rd.aln_t_s;
-    const uint32_t shard = gwave & (NSHARD - 1);
+    const uint32_t cb = chunk_base[r];
+    const uint32_t c0 = (ch - cb) * 2048;
+    const uint32_t carryN = chunk_pre[ch] - chunk_pre[cb]; // non-insertion columns before this chunk
+    const uint32_t shard = ch & (NSHARD - 1);
     const uint64_t ckbase = ck_off[r];
     const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
     const uint32_t nck = (uint32_t)(ck_off[r + 1] - ckbase);
-    EmitCtx cx{base, ts, r};
-    uint32_t carryN = 0, prev_last_bad = 0;
+    const uint32_t lc0 = c0 + lane * 32;
 
-    for (uint32_t c0 = 0; c0 < ncols; c0 += 2048) {
-        const uint32_t lc0 = c0 + lane * 32;
-        const uint32_t nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
-        uint64_t lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
-        uint64_t hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
-        uint64_t mlo = ~0ULL, mhi = ~0ULL; // valid-nibble masks
-        if (nv < 32) {
-            if (nv <= 16) {
-                mhi = 0;
-                mlo = nv == 16 ? ~0ULL : ((1ULL << (4 * nv)) - 1);
-            } else {
-                mhi = (1ULL << (4 * (nv - 16))) - 1;
-            }
-        }
-        lo &= mlo;
-        hi &= mhi;
-        uint64_t ilo = lo & 0x8888888888888888ULL, ihi = hi & 0x8888888888888888ULL;
-        if (lc0 == 0) ilo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-        lo &= 0x7777777777777777ULL;
-        hi &= 0x7777777777777777ULL;
-        const uint32_t n_ins = __builtin_popcountll(ilo) + __builtin_popcountll(ihi);
-        const uint32_t nonins = nv - n_ins;
-        const uint32_t incl = wave_incl_scan(nonins);
-        const uint32_t total = __shfl(incl, 63);
-        const uint32_t Nb = carryN + (incl - nonins); // non-insertion columns before this lane
-        const uint32_t t0 = ts + Nb;                  // t_pos of the lane's first non-insertion column
-        uint32_t bad = 0, im = 0;
-        if (nv) {
-            if (n_ins == 0) {
+    // lane 0 of a non-first chunk: the two columns before the chunk (issued early, off the critical path)
+    uint32_t pbad = 0; // bad bits of previous columns: bit 31 = column c0-1, bit 30 = column c0-2
+    PrevCols pv{0, 0, 0, 0, 0, 0};
+    bool prev_slow = false;
+    if (lane == 0 && c0 > 0) {
+        const uint8_t byte = base[(c0 - 2) >> 1];
+        const uint8_t n2 = byte >> 4, n1 = byte & 15; // columns c0-2, c0-1
+        const uint32_t t1 = ts + carryN - 1;
+        const uint32_t t2 = t1 - ((n1 & 8) ? 0u : 1u);
+        const bool b1 = (n1 & 8) || t1 >= L || (n1 & 7) != ref_code(refnib, t1);
+        const bool b2 = (n2 & 8) || t2 >= L || (n2 & 7) != ref_code(refnib, t2);
+        pbad = (b1 ? 0x80000000u : 0u) | (b2 ? 0x40000000u : 0u);
+        pv.q31 = n1 & 7, pv.q30 = n2 & 7;
+        pv.i31 = (n1 & 8) ? 1 : 0, pv.i30 = (n2 & 8) ? 1 : 0;
+        prev_slow = pv.i31 || pv.i30; // their deltas need a walk back through memory
+    }
+
+    const LaneCols c = load_lane(base, lc0, ncols);
+    const uint64_t lo = c.lo, hi = c.hi;
+    const uint32_t nv = c.nv, n_ins = c.n_ins;
+    const uint32_t nonins = nv - n_ins;
+    const uint32_t incl = wave_incl_scan(nonins);
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t Nb = carryN + (incl - nonins); // non-insertion columns before this lane
+    const uint32_t t0 = ts + Nb;                  // t_pos of the lane's first non-insertion column
+    uint32_t bad = 0, im = 0;
+    if (nv) {
+        if (n_ins == 0) {
+            uint64_t rlo, rhi;
+            load_ref128(refw, t0, rlo, rhi);
+            const uint64_t x = (lo ^ rlo) & c.mlo, y = (hi ^ rhi) & c.mhi;
+            if (x | y) bad = gather16(nz_nib(x)) | (gather16(nz_nib(y)) << 16);
+        } else {
+            im = gather16(c.ilo >> 3) | (gather16(c.ihi >> 3) << 16);
+            const uint32_t runs = __builtin_popcount(im & ~(im << 1));
+            const uint32_t i1 = __builtin_ctz(im);
+            const uint32_t vmask = nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+            if (runs == 1 && t0 >= n_ins) {
+                // one insertion run [i1, i1+m): columns before it sit at t0+j, after it at t0+j-m
                 uint64_t rlo, rhi;
                 load_ref128(refw, t0, rlo, rhi);
-                uint64_t x = (lo ^ rlo) & mlo, y = (hi ^ rhi) & mhi;
-                if (x | y) bad = gather16(nz_nib(x)) | (gather16(nz_nib(y)) << 16);
+                const uint32_t badA = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
+                load_ref128(refw, t0 - n_ins, rlo, rhi);
+                const uint32_t badB = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
+                const uint32_t below = (1u << i1) - 1u;
+                const uint32_t e2 = i1 + n_ins;
+                const uint32_t above = e2 >= 32 ? 0u : ~((1u << e2) - 1u);
+                bad = ((badA & below) | (badB & above) | im) & vmask;
             } else {
-                im = gather16(ilo >> 3) | (gather16(ihi >> 3) << 16);
-                const uint32_t runs = __builtin_popcount(im & ~(im << 1));
-                const uint32_t i1 = __builtin_ctz(im);
-                const uint32_t vmask = nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-                if (runs == 1 && t0 >= n_ins) {
-                    // one insertion run [i1, i1+m): columns before it sit at t0+j, after it at t0+j-m
-                    uint64_t rlo, rhi;
-                    load_ref128(refw, t0, rlo, rhi);
-                    uint32_t badA = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
-                    load_ref128(refw, t0 - n_ins, rlo, rhi);
-                    uint32_t badB = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
-                    const uint32_t below = (1u << i1) - 1u;
-                    const uint32_t e2 = i1 + n_ins;
-                    const uint32_t above = e2 >= 32 ? 0u : ~((1u << e2) - 1u);
-                    bad = ((badA & below) | (badB & above) | im) & vmask;
-                } else {
-                    uint32_t tcur = t0 - 1;
-                    for (uint32_t j = 0; j < nv; ++j) {
-                        if ((im >> j) & 1u) {
-                            bad |= 1u << j;
-                        } else {
-                            ++tcur;
-                            uint8_t q = (uint8_t)(((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16)))) & 7);
-                            if (tcur >= L || q != ref_code(refnib, tcur)) bad |= 1u << j;
-                        }
+                uint32_t tcur = t0 - 1;
+                for (uint32_t j = 0; j < nv; ++j) {
+                    if ((im >> j) & 1u) {
+                        bad |= 1u << j;
+                    } else {
+                        ++tcur;
+                        if (tcur >= L || reg_nib(lo, hi, j) != ref_code(refnib, tcur)) bad |= 1u << j;
                     }
                 }
             }
-            // checkpoint: column of the reference column at the next multiple of CKPT
-            if (nonins) {
-                const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
-                uint32_t nth = tstar - t0;
-                if (nth < nonins) {
-                    uint32_t j = nth;
-                    if (n_ins) {
-                        j = 0;
-                        for (;; ++j) {
-                            if (!((im >> j) & 1u)) {
-                                if (nth == 0) break;
-                                --nth;
-                            }
+        }
+        // checkpoint: column of the reference column at the next multiple of CKPT
+        if (nonins) {
+            const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
+            uint32_t nth = tstar - t0;
+            if (nth < nonins) {
+                uint32_t j = nth;
+                if (n_ins) {
+                    j = 0;
+                    for (;; ++j) {
+                        if (!((im >> j) & 1u)) {
+                            if (nth == 0) break;
+                            --nth;
                         }
                     }
-                    const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                    if (idx < nck) ckpt[ckbase + idx] = lc0 + j;
                 }
+                const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
+                if (idx < nck) ckpt[ckbase + idx] = lc0 + j;
             }
         }
-        uint32_t pb = __shfl_up(bad, 1);
-        if (lane == 0) pb = prev_last_bad;
-        uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
-        if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
-        E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-        prev_last_bad = __shfl(bad, 63);
-        if (__ballot(E != 0)) {
-            const uint32_t cnt = __builtin_popcount(E);
-            const uint32_t inc2 = wave_incl_scan(cnt);
-            const uint32_t tot = __shfl(inc2, 63);
-            uint32_t basepos = 0;
-            if (lane == 0) basepos = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
-            basepos = __shfl(basepos, 0);
-            if (E) {
-                const uint64_t sb = (uint64_t)shard * shard_cap;
-                emit_lane(cx, lc0, Nb, im, E, out_keys, out_vals, sb + basepos + (inc2 - cnt), sb + shard_cap);
-            }
-        }
-        carryN += total;
     }
-    if (lane == 0) {
-        // the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
-        if (ncols == 0 || ts + carryN - 1 != rd.aln_t_e || rd.aln_t_e >= L) atomicOr(err, 2u);
+    // previous-lane context (wave-uniform shuffles)
+    uint32_t pb = __shfl_up(bad, 1);
+    {
+        // deltas of this lane's columns 31 / 30 (insertion runs ending there), for the next lane
+        const uint32_t r31 = ((im >> 31) & 1u) ? (~im ? (uint32_t)__builtin_clz(~im) : 32u) : 0u;
+        const uint32_t r30 = ((im >> 30) & 1u) ? (uint32_t)__builtin_clz(~(im << 1)) : 0u;
+        const uint32_t packed = (uint32_t)reg_nib(lo, hi, 31) | ((uint32_t)reg_nib(lo, hi, 30) << 4) |
+                                (((im >> 31) & 1u) << 8) | (((im >> 30) & 1u) << 9) | (min(r31, 63u) << 10) |
+                                (min(r30, 63u) << 16);
+        const uint32_t pp = __shfl_up(packed, 1);
+        if (lane != 0) {
+            pv.q31 = pp & 7, pv.q30 = (pp >> 4) & 7;
+            pv.i31 = (pp >> 8) & 1, pv.i30 = (pp >> 9) & 1;
+            pv.d31 = (pp >> 10) & 63, pv.d30 = (pp >> 16) & 63;
+        } else {
+            pb = pbad;
+        }
+    }
+    uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
+    if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
+    E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+    // an insertion run that reaches a lane's first column from column 30/31 needs the memory walk
+    const bool longrun = (im == 0xFFFFFFFFu) || ((im >> 30) == 3u && (im | 0xC0000000u) == 0xFFFFFFFFu) ||
+                         ((im & 0x7FFFFFFFu) == 0x7FFFFFFFu);
+    const bool any_long = __ballot(longrun) != 0;
+    if (__ballot(E != 0)) {
+        const uint32_t cnt = __builtin_popcount(E);
+        const uint32_t inc2 = wave_incl_scan(cnt);
+        const uint32_t tot = __shfl(inc2, 63);
+        uint32_t basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
+        basepos = __shfl(basepos, 0);
+        if (E) {
+            const uint64_t sb = (uint64_t)shard * shard_cap;
+            if (any_long || prev_slow) {
+                EmitCtx cx{base, ts, r};
+                emit_lane(cx, lc0, Nb, im, E, out_keys, out_vals, sb + basepos + (inc2 - cnt), sb + shard_cap);
+            } else {
+                emit_lane_regs(lo, hi, im, E, ts, lc0, Nb, pv, r, out_keys, out_vals, sb + basepos + (inc2 - cnt),
+                               sb + shard_cap);
+            }
+        }
+    }
+    if (lane == 0 && c0 + 2048 >= ncols) {
+        // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
+        if (ncols == 0 || ts + carryN + total - 1 != rd.aln_t_e || rd.aln_t_e >= L) atomicOr(err, 2u);
         if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
     }
 }
@@ -1116,10 +1259,19 @@ void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t 
     hipLaunchKernelGGL(k_encode_ref, grid1(nbytes), dim3(256), 0, s, read0, L, refnib, nbytes, err);
 }
 void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
-                       uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err) {
-    hipLaunchKernelGGL(k_diff_reads, dim3((R + 3) / 4), dim3(256), 0, s, reads, R, nib, refw, refnib, L, keys, vals,
-                       shard_cnt, shard_cap, ck_off, ckpt, err);
+                       const uint8_t *refnib, uint32_t L, const uint32_t *chunk_read, const uint32_t *chunk_base,
+                       const uint32_t *chunk_pre, uint32_t n_chunks, uint64_t *keys, uint32_t *vals,
+                       uint32_t *shard_cnt, uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err) {
+    if (n_chunks)
+        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 3) / 4), dim3(256), 0, s, reads, R, nib, refw, refnib, L,
+                           chunk_read, chunk_base, chunk_pre, n_chunks, keys, vals, shard_cnt, shard_cap, ck_off, ckpt,
+                           err);
+}
+void launch_chunk_count(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *chunk_read,
+                        const uint32_t *chunk_base, uint32_t n_chunks, uint32_t *chunk_n) {
+    if (n_chunks)
+        hipLaunchKernelGGL(k_chunk_count, dim3((n_chunks + 3) / 4), dim3(256), 0, s, reads, nib, chunk_read, chunk_base,
+                           n_chunks, chunk_n);
 }
 void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
                            const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,

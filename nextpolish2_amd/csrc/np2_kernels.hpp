@@ -42,8 +42,11 @@ struct YakDev {
 
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t *err);
 void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
+                       const uint8_t *refnib, uint32_t L, const uint32_t *chunk_read, const uint32_t *chunk_base,
+                       const uint32_t *chunk_pre, uint32_t n_chunks, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
                        uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err);
+void launch_chunk_count(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *chunk_read,
+                        const uint32_t *chunk_base, uint32_t n_chunks, uint32_t *chunk_n);
 void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
                            const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys, uint32_t *out_vals);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
