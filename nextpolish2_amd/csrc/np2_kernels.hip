@@ -1035,13 +1035,31 @@ struct CandCtx {
     uint32_t ksize;
 };
 
+// sequential nibble reader with a 16-column (8-byte) register window; `base` is 16-byte aligned
+struct NibReader {
+    const uint8_t *base;
+    uint64_t w;     // current window, nibble of column c at bits 4*(c & 15)
+    uint32_t wbase; // first column of the window (multiple of 16), 0xFFFFFFFF = empty
+    __device__ __forceinline__ uint8_t get(uint32_t c) {
+        const uint32_t b = c & ~15u;
+        if (b != wbase) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(base + (b >> 1));
+            const uint32_t x = ((v.x & 0x0F0F0F0Fu) << 4) | ((v.x >> 4) & 0x0F0F0F0Fu);
+            const uint32_t y = ((v.y & 0x0F0F0F0Fu) << 4) | ((v.y >> 4) & 0x0F0F0F0Fu);
+            w = (uint64_t)x | ((uint64_t)y << 32);
+            wbase = b;
+        }
+        return (uint8_t)((w >> (4 * (c & 15))) & 15);
+    }
+};
+
 // Decode the candidate of (read r, region g): returns seq length; optionally writes the
 // sequence and the hashed first k-mer (main.rs:1478-1521).
 template <bool WRITE>
 __device__ uint32_t cand_decode(const CandCtx &cx, uint32_t r, uint32_t g, uint8_t *__restrict__ seq_out,
                                 uint64_t *kmer_out) {
     const np2_read_t rd = cx.reads[r];
-    const uint8_t *base = cx.nib + rd.nib_off;
+    NibReader nr{cx.nib + rd.nib_off, 0, 0xFFFFFFFFu};
     const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
     const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
     // locate the reference column of t_pos == start from the nearest checkpoint at or before it
@@ -1057,13 +1075,13 @@ __device__ uint32_t cand_decode(const CandCtx &cx, uint32_t r, uint32_t g, uint8
     }
     while (t < start) {
         ++col;
-        if (!(nib_at(base, col) & 8)) ++t;
+        if (!(nr.get(col) & 8)) ++t;
     }
     const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
     uint64_t fw = 0, rv = 0, l = 0;
     uint32_t len = 0;
     for (uint32_t c = col; c < rd.n_cols; ++c) {
-        const uint8_t nb = nib_at(base, c);
+        const uint8_t nb = nr.get(c);
         if (c != col && !(nb & 8)) ++t;
         const uint8_t q = nb & 7;
         if (q != 4) {

@@ -21,10 +21,10 @@ struct WaveStats {
     uint32_t max1_c, max1_p, max2_c, max2_p; // wave-uniform
 };
 
-__device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
-                                                      const uint8_t *__restrict__ seq, bool kpos, uint32_t order) {
-    WaveStats w;
-    w.eqmask = 0;
+// exact byte-wise class computation (fallback; also the definition the fast path must reproduce)
+__device__ __forceinline__ uint64_t eqmask_exact(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
+                                                  const uint8_t *__restrict__ seq) {
+    uint64_t m = 0;
     for (uint32_t j = 0; j < n; ++j) {
         const uint32_t sj = __shfl(so, j), lj = __shfl(len, j);
         bool eq = lane < n && lj == len;
@@ -34,8 +34,45 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
                     eq = false;
                     break;
                 }
-        if (eq) w.eqmask |= 1ull << j;
+        if (eq) m |= 1ull << j;
     }
+    return m;
+}
+
+__device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
+                                                      const uint8_t *__restrict__ seq, bool kpos, uint32_t order) {
+    WaveStats w;
+    // classes by (length, 64-bit hash); every lane then verifies byte-wise against its class head.  A hash
+    // collision (never observed) falls back to the exact O(n^2) comparison, so the result is always exact.
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+    if (lane < n)
+        for (uint32_t t = 0; t < len; ++t) {
+            h ^= seq[so + t];
+            h *= 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+    const uint32_t hlo = (uint32_t)h, hhi = (uint32_t)(h >> 32);
+    w.eqmask = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t jl = __shfl(hlo, j), jh = __shfl(hhi, j);
+        if (lane < n && jl == hlo && jh == hhi) w.eqmask |= 1ull << j;
+    }
+    bool ok = true;
+    if (lane < n) {
+        const uint32_t head = __builtin_ctzll(w.eqmask);
+        const uint32_t sh = __shfl(so, head), lh = __shfl(len, head);
+        ok = lh == len;
+        if (ok && head != lane)
+            for (uint32_t t = 0; t < len; ++t)
+                if (seq[so + t] != seq[sh + t]) {
+                    ok = false;
+                    break;
+                }
+    } else {
+        (void)__shfl(so, 0);
+        (void)__shfl(len, 0);
+    }
+    if (__ballot(!ok)) w.eqmask = eqmask_exact(lane, n, so, len, seq);
     const uint64_t kmask = __ballot(lane < n && kpos);
     const uint64_t valid = w.eqmask & kmask;
     uint32_t p1 = 64;
@@ -49,14 +86,14 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
     w.max1_c = w.max1_p = w.max2_c = w.max2_p = 0;
     uint64_t hm = __ballot(w.head);
     while (hm) {
-        const uint32_t h = __builtin_ctzll(hm);
+        const uint32_t hd = __builtin_ctzll(hm);
         hm &= hm - 1;
-        const uint32_t ch = __shfl(w.c, h), oh = __shfl(order, h);
+        const uint32_t ch = __shfl(w.c, hd), oh = __shfl(order, hd);
         if (ch > w.max1_c || (ch == w.max1_c && oh == 0)) {
             w.max2_c = w.max1_c, w.max2_p = w.max1_p;
-            w.max1_c = ch, w.max1_p = h;
+            w.max1_c = ch, w.max1_p = hd;
         } else if (w.max1_p == w.max2_p || ch > w.max2_c) {
-            w.max2_c = ch, w.max2_p = h;
+            w.max2_c = ch, w.max2_p = hd;
         }
     }
     return w;
