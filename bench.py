@@ -34,7 +34,7 @@ def main():
     import torch
     import torch.distributed as dist
     from nextpolish2_amd import Opts, Polisher
-    from nextpolish2_amd.dist import all_gather_sequences
+    from nextpolish2_amd.dist import SequenceGatherer
     from nextpolish2_amd.synth import Synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -54,12 +54,13 @@ def main():
     pol = Polisher(yaks, device=local_rank)
     contig = pol.upload(syn.pileup)  # pileup resident in HBM before the timed region
     opts = Opts()
+    gatherer = SequenceGatherer(a.length + a.length // 16 + 4096, dev) if world > 1 else None
 
     def step():
         # FASTA output needs the sequence and the first/last position only (main.rs:627-632)
         bases, pos = pol.polish_resident(contig, opts, want_pos=False)
         if world > 1:
-            all_gather_sequences([(rank, bases.tobytes())], device=dev)
+            gatherer.gather(bases)  # RCCL all-gather of the polished contigs, stays on the GPUs
         return bases, pos
 
     def sync():

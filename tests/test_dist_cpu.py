@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nextpolish2_amd.dist import all_gather_sequences, assign_contigs
+from nextpolish2_amd.dist import SequenceGatherer, all_gather_sequences, assign_contigs
 
 
 def test_assign_contigs_is_balanced_and_deterministic():
@@ -32,6 +32,12 @@ def _worker(rank, world, port, q):
         # a rank with no contig still participates
         got2 = all_gather_sequences([(0, b"ACGT")] if rank == 0 else [], device=torch.device("cpu"))
         ok = ok and got2 == {0: b"ACGT"}
+        import numpy as np
+        g = SequenceGatherer(64, torch.device("cpu"))
+        for step in range(2):
+            mine_b = np.frombuffer((b"AC" if rank == 0 else b"GGTTA") * (step + 1), dtype=np.uint8)
+            g.gather(mine_b)
+            ok = ok and g.to_host() == {0: b"AC" * (step + 1), 1: b"GGTTA" * (step + 1)}
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
