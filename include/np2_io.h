@@ -1,0 +1,78 @@
+/*
+ * np2_io.h — input side of the NextPolish2 hot path.
+ *
+ * Replaces the reference's rust-htslib / kseq / KmerInfo::new call sites:
+ *   FASTA[.gz] records            src/main.rs:1705-1714   (kseq: name = header up to first whitespace)
+ *   indexed BAM fetch per contig  src/main.rs:1745-1758   (IndexedReader::from_path + fetch(tid, 0, len))
+ *   record admission + packing    src/main.rs:1758-1817   (filters, fill_with_cigar, is_clip, trim(8),
+ *                                                          AlignSeq::new, filter_alignseqs_by_clip)
+ *   yak v2 dump header + buckets  src/utils/kmer.rs:72-170
+ * BGZF inflate and BAM parsing run on the host (zlib); the CIGAR walk / trim(8) / nibble packing
+ * is a HIP kernel that writes the packed pileup straight into HBM (np2_contig_t).
+ */
+#ifndef NP2_IO_H
+#define NP2_IO_H
+#include "np2.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* read-admission options (src/utils/option.rs:267-292) */
+typedef struct np2_front_opts {
+    uint32_t min_read_len;     /* -l 1000 */
+    uint32_t min_map_len;      /* -a integer part, 500 */
+    float min_map_fra;         /* -a fractional part, 0.5 */
+    int16_t min_map_qual;      /* -q 1 */
+    uint32_t max_clip_len;     /* -c 100 */
+    uint8_t use_supplementary; /* -s */
+    uint8_t use_secondary;     /* -S (needs SEQ recovery, secondary.rs: not supported -> NP2_E_UNSUPPORTED) */
+} np2_front_opts_t;
+
+/* one alignment record, fields as in the BAM record (what rust-htslib's Record exposes, main.rs:1751-1797) */
+typedef struct np2_bamrec {
+    int32_t pos;        /* 0-based leftmost position */
+    uint16_t flag;
+    uint8_t mapq;
+    uint8_t pad;
+    uint32_t n_cigar;
+    uint64_t cigar_off; /* index into cigar[] (u32 each: len << 4 | op, BAM encoding) */
+    uint32_t l_seq;
+    uint64_t seq_off;   /* byte offset into seq4[] (4-bit packed, BAM encoding, high nibble first) */
+} np2_bamrec_t;
+
+/* ---- FASTA[.gz] ---- */
+typedef struct np2_fasta np2_fasta_t;
+int np2_fasta_open(const char *path, np2_fasta_t **out);
+/* returns 1 and borrows name/seq until the next call, 0 at end of file, <0 on error */
+int np2_fasta_next(np2_fasta_t *f, const char **name, const uint8_t **seq, uint64_t *len);
+void np2_fasta_close(np2_fasta_t *f);
+
+/* ---- yak v2 dump ---- */
+/* fills *out with malloc'ed arrays (release with np2_yak_free) */
+int np2_yak_load(const char *path, np2_yak_t *out);
+void np2_yak_free(np2_yak_t *y);
+
+/* ---- indexed BAM ---- */
+typedef struct np2_bam np2_bam_t;
+int np2_bam_open(const char *path, np2_bam_t **out); /* needs <path>.bai (or <stem>.bai) */
+void np2_bam_close(np2_bam_t *b);
+int np2_bam_n_refs(np2_bam_t *b);
+const char *np2_bam_ref_name(np2_bam_t *b, int tid, uint32_t *len);
+const char *np2_io_last_error(void);
+
+/* Packed pileup of one contig, resident in HBM, built from its alignment records.
+ * ref = contig bytes exactly as in the FASTA (case matters for trim, main.rs:447-513). */
+int np2_contig_from_records(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs,
+                            uint32_t n_recs, const uint32_t *cigar, const uint8_t *seq4,
+                            const np2_front_opts_t *opts, np2_contig_t **out);
+/* same, reading the records of contig `name` from an indexed BAM (must be coordinate sorted) */
+int np2_contig_from_bam(np2_ctx_t *ctx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L,
+                        const np2_front_opts_t *opts, np2_contig_t **out);
+/* copy a resident packed pileup back to the host (parity tests / debugging); free both with np2_free */
+int np2_contig_export(np2_ctx_t *ctx, np2_contig_t *c, np2_read_t **reads, uint32_t *n_reads,
+                      uint8_t **nibbles, uint64_t *nib_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

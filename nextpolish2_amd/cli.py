@@ -1,0 +1,120 @@
+"""nextPolish2 command line mirror (src/utils/option.rs:45-292, src/main.rs:1689-1856).
+
+Usage: nextPolish2 [OPTIONS] <HiFi.map.bam> <genome.fa[.gz]> <short.read.yak>...
+Same positionals, flags, defaults and output format as the reference; contigs are polished on the GPU
+(one np2 context per process) and written in input order."""
+import argparse
+import os
+import resource
+import sys
+import time
+
+from . import io as np2io
+from ._types import Opts
+from .api import Polisher, fasta_record
+
+VERSION = "np2-mi355x 0.1 (reference semantics: NextPolish2 v0.2.2)"
+
+
+def _existing(path):
+    p = os.path.abspath(path)
+    if not os.path.exists(p):
+        raise argparse.ArgumentTypeError(f"{p!r} does not exist!")
+    return p
+
+
+def _map_len(v):
+    f = float(v)  # -a INT.FLOAT: integer part = min length, fractional part = min fraction (option.rs:232,258-259)
+    return f
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="nextPolish2", description="Repeat-aware polishing genomes assembled using HiFi long reads")
+    p.add_argument("bam", type=_existing, metavar="HiFi.map.bam", help="HiFi-to-ref mapping file in sorted BAM format")
+    p.add_argument("fa", type=_existing, metavar="genome.fa[.gz]", help="genome assembly file in [GZIP] FASTA format")
+    p.add_argument("yak", type=_existing, nargs="+", metavar="short.read.yak", help="one or more k-mer dataset in yak format")
+    p.add_argument("-o", "--out", default=None, metavar="FILE", help="output file [stdout]")
+    p.add_argument("-u", "--uppercase", action="store_true", help="output in uppercase sequences")
+    p.add_argument("--out_pos", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("-k", "--min_kmer_count", type=int, default=5)
+    p.add_argument("-t", "--thread", type=int, default=1, help="accepted for compatibility (contigs run on the GPU)")
+    p.add_argument("-i", "--iter_count", type=int, default=2)
+    p.add_argument("-m", "--model", default="ref", type=str, help="ref|len (case-insensitive)")
+    p.add_argument("-l", "--min_read_len", type=int, default=1000)
+    p.add_argument("-L", "--min_ctg_len", type=int, default=1000000)
+    p.add_argument("-n", "--max_indel_len", type=int, default=20)
+    p.add_argument("-s", "--use_supplementary", action="store_true")
+    p.add_argument("-S", "--use_secondary", action="store_true")
+    p.add_argument("-a", "--min_map_len", type=_map_len, default=500.5, metavar="INT.FLOAT")
+    p.add_argument("-q", "--min_map_qual", type=int, default=1)
+    p.add_argument("-c", "--max_clip_len", type=int, default=100)
+    p.add_argument("-r", "--use_all_reads", action="store_true")
+    p.add_argument("--min_base_cov", type=int, default=1, help=argparse.SUPPRESS)
+    p.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device index")
+    p.add_argument("-V", "--version", action="version", version=VERSION)
+    return p
+
+
+def resource_str(t0, argv):
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return (f"[INFO] Version: {VERSION}\n[INFO] CMD: {' '.join(argv)}\n[INFO] Real time: {time.time() - t0:.3f} sec; "
+            f"CPU: {ru.ru_utime + ru.ru_stime:.3f} sec; Peak RSS: {ru.ru_maxrss / 1048576:.3f} GB")
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    t0 = time.time()
+    a = build_parser().parse_args(argv)
+    if a.model.lower() not in ("ref", "len"):
+        raise SystemExit("error: invalid value for --model (ref|len)")
+    out = sys.stdout.buffer
+    if a.out is not None:
+        path = os.path.abspath(a.out)
+        if os.path.exists(path):  # option.rs:312-316: refuse to overwrite
+            raise SystemExit(f"Error: {path!r} already exists!")
+        out = open(path, "wb")
+    yaks = sorted((np2io.load_yak(y) for y in a.yak), key=lambda y: y.k)  # option.rs:238
+    # main.rs:1547 compares the raw option with "ref" (case-sensitive)
+    opts = Opts(min_kmer_count=a.min_kmer_count, max_indel_len=a.max_indel_len, iter_count=a.iter_count,
+                model=a.model, use_all_reads=a.use_all_reads)
+    fopts = np2io.FrontOpts(min_read_len=a.min_read_len, min_map_len=int(a.min_map_len),
+                            min_map_fra=a.min_map_len - int(a.min_map_len), min_map_qual=a.min_map_qual,
+                            max_clip_len=a.max_clip_len, use_supplementary=a.use_supplementary,
+                            use_secondary=a.use_secondary)
+    pol = bam = None
+    try:
+        for name, seq in np2io.read_fasta(a.fa):
+            if len(seq) >= 0xFFFFFFFF:
+                raise SystemExit(f"{name} is too long!")
+            if len(seq) < a.min_ctg_len:  # pass-through (main.rs:1727-1730)
+                s = seq.upper() if a.uppercase else seq
+                if a.out_pos:
+                    out.write(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
+                else:
+                    out.write(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
+                continue
+            if pol is None:
+                pol = Polisher(yaks, device=a.device)
+                bam = np2io.Bam(a.bam)
+            contig = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+            try:
+                bases, pos = pol.polish_resident(contig, opts, want_pos=a.out_pos)
+            finally:
+                contig.free()
+            b = bases.tobytes()
+            if a.uppercase:
+                b = b.upper()
+            if a.out_pos:
+                out.write(b"".join(b"%s\t%c\t%d\n" % (name.encode(), b[i:i + 1], int(pos[i])) for i in range(len(b))))
+            else:
+                out.write(b">%s start:%d end:%d\n%s\n" % (name.encode(), pos[0], pos[1], b))
+        out.flush()
+    finally:
+        if a.out is not None:
+            out.close()
+    print(resource_str(t0, ["nextPolish2"] + argv), file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

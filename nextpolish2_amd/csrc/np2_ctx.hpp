@@ -1,0 +1,299 @@
+// Internal shared definitions of the np2 host driver (context, device buffers, transfer helpers).
+#pragma once
+#include "../../include/np2.h"
+#include "np2_common.hpp"
+#include "np2_kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace np2h {
+using namespace np2;
+
+
+struct Np2Error : std::runtime_error {
+    int code;
+    Np2Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+            throw Np2Error(NP2_E_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+#define REFPANIC_IF(c, m)                                                                          \
+    do {                                                                                           \
+        if (c) throw Np2Error(NP2_E_REFPANIC, std::string("reference would panic: ") + (m));        \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    T *ensure(size_t n) {
+        if (n > cap) {
+            release();
+            size_t want = n + n / 8 + 64;
+            HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+            cap = want;
+        }
+        return p;
+    }
+};
+
+// Pinned host memory pool for result buffers: np2_free() returns blocks here (no ctx needed).
+// Pageable D2H makes the ROCm runtime pin/unpin user pages lazily (multi-ms stalls on the next copy).
+struct PinnedPool {
+    std::mutex mu;
+    std::map<void *, size_t> live;                 // handed out
+    std::vector<std::pair<size_t, void *>> free_;  // (capacity, ptr)
+    void *get(size_t bytes) {
+        std::lock_guard<std::mutex> l(mu);
+        size_t best = free_.size();
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].first >= bytes && (best == free_.size() || free_[i].first < free_[best].first)) best = i;
+        void *p = nullptr;
+        size_t cap = 0;
+        if (best != free_.size()) {
+            p = free_[best].second;
+            cap = free_[best].first;
+            free_.erase(free_.begin() + (long)best);
+        } else {
+            cap = bytes + bytes / 8 + 4096;
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        live[p] = cap;
+        return p;
+    }
+    bool put(void *p) {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        free_.emplace_back(it->second, p);
+        live.erase(it);
+        while (free_.size() > 8) { // keep the pool small
+            (void)hipHostFree(free_.front().second);
+            free_.erase(free_.begin());
+        }
+        return true;
+    }
+};
+inline PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool(); // leaked on purpose: outlives every context
+    return *p;
+}
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void *ensure(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            size_t want = n + n / 4 + 65536;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
+                throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            cap = want;
+        }
+        return p;
+    }
+};
+
+struct YakTable {
+    uint32_t k = 0, cap_log2 = 0;
+    DevBuf<uint64_t> table;
+    YakDev dev() const { return YakDev{table.p, cap_log2, k}; }
+};
+
+struct Timing {
+    std::vector<std::string> names;
+    std::vector<float> ms;
+    std::string joined;
+    std::vector<std::pair<std::string, float>> host; // host wall-clock sections (ms)
+};
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+
+} // namespace np2h
+
+using namespace np2h;
+
+struct np2_contig {
+    uint32_t L = 0, R = 0;
+    uint64_t nib_bytes = 0, n_cols = 0, n_ckpt = 0;
+    DevBuf<np2_read_t> reads;
+    DevBuf<uint8_t> nib;
+    DevBuf<uint8_t> refnib; // nibble-packed contig codes (+ padding), also viewed as uint64_t words
+    DevBuf<uint64_t> ck_off;
+    DevBuf<uint32_t> ckpt;
+    // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
+    uint32_t n_chunks = 0;
+    DevBuf<uint32_t> chunk_read, chunk_base;
+};
+
+struct np2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<YakTable> yaks;
+    std::string err;
+    bool trace = false;
+    std::map<std::string, std::vector<uint8_t>> trace_items;
+    Timing timing;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+
+    PinnedBuf pin_d2h, pin_h2d;
+    uint32_t last_first_pos = 0, last_last_pos = 0;
+    bool reuse_identical_pass = true;
+    // scratch (reused across contigs)
+    DevBuf<uint8_t> tmp;
+    DevBuf<uint64_t> keys_raw, keys;
+    DevBuf<uint32_t> vals_raw, vals, shard_cnt, gcount, gmin, flag, idx;
+    DevBuf<uint64_t> shard_off;
+    DevBuf<uint32_t> npos, ncount, nminr, nbesti, node_cnt, node_off, run_start, run_end, n0_besti, emit, eoff;
+    DevBuf<uint16_t> nbases, ndelta;
+    DevBuf<int64_t> nscore;
+    DevBuf<int32_t> covd, cov, mval, smin;
+    DevBuf<uint8_t> alive, cns_base, cns_cls, lq_kind, lq_nothead;
+    DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
+        lq_end;
+    DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
+        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, cand_off, cand_order, cand_seq_off, kill_ids;
+    DevBuf<uint64_t> cand_kmer;
+    DevBuf<uint8_t> cand_seq;
+    DevBuf<uint16_t> kscore;
+    DevBuf<uint32_t> scal; // device scalars: see enum below
+    // region logic
+    DevBuf<uint8_t> reg_lable, grp, ref_seen, bad, cns_base2, rech_groups;
+    DevBuf<uint32_t> ecount, first_reg, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
+        sp_idx_e, sp_flag, sp_slot, ap_g, ap_s, ap_e, rech, rech_head, rech_gslot, rech_njobs, rech_joboff, job_len,
+        job_off32;
+    DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
+    DevBuf<uint64_t> ekey, ekey_s;
+    DevBuf<uint16_t> keep_ks;
+    DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
+    DevBuf<uint16_t> kscore_saved;
+    DevBuf<uint8_t> sstr;
+    DevBuf<uint64_t> soff;
+    DevBuf<uint16_t> sscore;
+};
+
+
+namespace np2h {
+
+
+enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_COUNT = 24 };
+
+struct WallTimer {
+    np2_ctx *cx;
+    const char *name;
+    double t0;
+    WallTimer(np2_ctx *c, const char *n);
+    ~WallTimer();
+};
+
+struct EventTimer {
+    np2_ctx *cx;
+    hipEvent_t a, b;
+    EventTimer(np2_ctx *c, const char *name) : cx(c) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, cx->stream);
+        cx->pending_events.push_back({name, {a, b}});
+    }
+    ~EventTimer() { (void)hipEventRecord(b, cx->stream); }
+};
+
+inline WallTimer::WallTimer(np2_ctx *c, const char *n) : cx(c), name(n), t0(now_ms()) {}
+inline WallTimer::~WallTimer() { cx->timing.host.push_back({name, (float)(now_ms() - t0)}); }
+
+inline void flush_timings(np2_ctx *cx) {
+    std::map<std::string, float> acc;
+    std::vector<std::string> order;
+    for (auto &e : cx->pending_events) {
+        float ms = 0;
+        (void)hipEventSynchronize(e.second.second);
+        (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
+        if (!acc.count(e.first)) order.push_back(e.first);
+        acc[e.first] += ms;
+        (void)hipEventDestroy(e.second.first);
+        (void)hipEventDestroy(e.second.second);
+    }
+    cx->pending_events.clear();
+    for (auto &h : cx->timing.host) {
+        if (!acc.count(h.first)) order.push_back(h.first);
+        acc[h.first] += h.second;
+    }
+    cx->timing.host.clear();
+    cx->timing.names = order;
+    cx->timing.ms.clear();
+    cx->timing.joined.clear();
+    for (auto &n : order) {
+        cx->timing.ms.push_back(acc[n]);
+        cx->timing.joined += n;
+        cx->timing.joined.push_back('\0');
+    }
+    cx->timing.joined.push_back('\0');
+}
+
+template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
+    std::vector<T> v(n);
+    if (n) {
+        void *pin = cx->pin_d2h.ensure(n * sizeof(T));
+        HIPCHK(hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream));
+        memcpy(v.data(), pin, n * sizeof(T));
+    }
+    return v;
+}
+// host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
+inline void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    HIPCHK(hipStreamSynchronize(cx->stream)); // the staging buffer may still be in flight
+    void *pin = cx->pin_h2d.ensure(bytes);
+    memcpy(pin, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, cx->stream));
+}
+template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name, const std::vector<T> &v) {
+    if (!cx->trace) return;
+    auto &dst = cx->trace_items[std::to_string(pass) + ":" + name];
+    dst.resize(v.size() * sizeof(T));
+    if (!v.empty()) memcpy(dst.data(), v.data(), dst.size());
+}
+
+inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
+    // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
+    int rc = prim_exclusive_sum_u32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n_plus1);
+    if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim exclusive_scan failed");
+    return 0;
+}
+inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
+    if (n_elems) HIPCHK(hipMemsetAsync(p, 0, n_elems * elem, cx->stream));
+}
+
+// validate the read descriptors, build checkpoint offsets / chunk tables / contig codes for a contig whose
+// reads (host copy given) and nibble buffer are already resident
+void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t n_reads, uint32_t L,
+                   uint64_t nib_bytes);
+int fail(np2_ctx *cx, const Np2Error &e);
+
+} // namespace np2h

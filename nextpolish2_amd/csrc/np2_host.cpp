@@ -5,6 +5,7 @@
 #include "../../include/np2.h"
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_ctx.hpp"
 #include "np2_phase_host.hpp"
 
 #include <algorithm>
@@ -22,273 +23,8 @@
 
 using namespace np2;
 
-namespace {
-
-struct Np2Error : std::runtime_error {
-    int code;
-    Np2Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
-};
-#define HIPCHK(x)                                                                                  \
-    do {                                                                                           \
-        hipError_t e_ = (x);                                                                       \
-        if (e_ != hipSuccess)                                                                      \
-            throw Np2Error(NP2_E_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_));          \
-    } while (0)
-#define REFPANIC_IF(c, m)                                                                          \
-    do {                                                                                           \
-        if (c) throw Np2Error(NP2_E_REFPANIC, std::string("reference would panic: ") + (m));        \
-    } while (0)
-
-template <class T> struct DevBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    T *ensure(size_t n) {
-        if (n > cap) {
-            release();
-            size_t want = n + n / 8 + 64;
-            HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-            cap = want;
-        }
-        return p;
-    }
-};
-
-// Pinned host memory pool for result buffers: np2_free() returns blocks here (no ctx needed).
-// Pageable D2H makes the ROCm runtime pin/unpin user pages lazily (multi-ms stalls on the next copy).
-struct PinnedPool {
-    std::mutex mu;
-    std::map<void *, size_t> live;                 // handed out
-    std::vector<std::pair<size_t, void *>> free_;  // (capacity, ptr)
-    void *get(size_t bytes) {
-        std::lock_guard<std::mutex> l(mu);
-        size_t best = free_.size();
-        for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].first >= bytes && (best == free_.size() || free_[i].first < free_[best].first)) best = i;
-        void *p = nullptr;
-        size_t cap = 0;
-        if (best != free_.size()) {
-            p = free_[best].second;
-            cap = free_[best].first;
-            free_.erase(free_.begin() + (long)best);
-        } else {
-            cap = bytes + bytes / 8 + 4096;
-            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
-        }
-        live[p] = cap;
-        return p;
-    }
-    bool put(void *p) {
-        std::lock_guard<std::mutex> l(mu);
-        auto it = live.find(p);
-        if (it == live.end()) return false;
-        free_.emplace_back(it->second, p);
-        live.erase(it);
-        while (free_.size() > 8) { // keep the pool small
-            (void)hipHostFree(free_.front().second);
-            free_.erase(free_.begin());
-        }
-        return true;
-    }
-};
-PinnedPool &pinned_pool() {
-    static PinnedPool *p = new PinnedPool(); // leaked on purpose: outlives every context
-    return *p;
-}
-
-struct PinnedBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    ~PinnedBuf() {
-        if (p) (void)hipHostFree(p);
-    }
-    void *ensure(size_t n) {
-        if (n > cap) {
-            if (p) (void)hipHostFree(p);
-            p = nullptr;
-            cap = 0;
-            size_t want = n + n / 4 + 65536;
-            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
-                throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
-            cap = want;
-        }
-        return p;
-    }
-};
-
-struct YakTable {
-    uint32_t k = 0, cap_log2 = 0;
-    DevBuf<uint64_t> table;
-    YakDev dev() const { return YakDev{table.p, cap_log2, k}; }
-};
-
-struct Timing {
-    std::vector<std::string> names;
-    std::vector<float> ms;
-    std::string joined;
-    std::vector<std::pair<std::string, float>> host; // host wall-clock sections (ms)
-};
-static inline double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-} // namespace
-
-struct np2_contig {
-    uint32_t L = 0, R = 0;
-    uint64_t nib_bytes = 0, n_cols = 0, n_ckpt = 0;
-    DevBuf<np2_read_t> reads;
-    DevBuf<uint8_t> nib;
-    DevBuf<uint8_t> refnib; // nibble-packed contig codes (+ padding), also viewed as uint64_t words
-    DevBuf<uint64_t> ck_off;
-    DevBuf<uint32_t> ckpt;
-    // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
-    uint32_t n_chunks = 0;
-    DevBuf<uint32_t> chunk_read, chunk_base;
-};
-
-struct np2_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::vector<YakTable> yaks;
-    std::string err;
-    bool trace = false;
-    std::map<std::string, std::vector<uint8_t>> trace_items;
-    Timing timing;
-    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
-
-    PinnedBuf pin_d2h, pin_h2d;
-    uint32_t last_first_pos = 0, last_last_pos = 0;
-    bool reuse_identical_pass = true;
-    // scratch (reused across contigs)
-    DevBuf<uint8_t> tmp;
-    DevBuf<uint64_t> keys_raw, keys;
-    DevBuf<uint32_t> vals_raw, vals, shard_cnt, gcount, gmin, flag, idx;
-    DevBuf<uint64_t> shard_off;
-    DevBuf<uint32_t> npos, ncount, nminr, nbesti, node_cnt, node_off, run_start, run_end, n0_besti, emit, eoff;
-    DevBuf<uint16_t> nbases, ndelta;
-    DevBuf<int64_t> nscore;
-    DevBuf<int32_t> covd, cov, mval, smin;
-    DevBuf<uint8_t> alive, cns_base, cns_cls, lq_kind, lq_nothead;
-    DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
-        lq_end;
-    DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
-        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, cand_off, cand_order, cand_seq_off, kill_ids;
-    DevBuf<uint64_t> cand_kmer;
-    DevBuf<uint8_t> cand_seq;
-    DevBuf<uint16_t> kscore;
-    DevBuf<uint32_t> scal; // device scalars: see enum below
-    // region logic
-    DevBuf<uint8_t> reg_lable, grp, ref_seen, bad, cns_base2, rech_groups;
-    DevBuf<uint32_t> ecount, first_reg, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
-        sp_idx_e, sp_flag, sp_slot, ap_g, ap_s, ap_e, rech, rech_head, rech_gslot, rech_njobs, rech_joboff, job_len,
-        job_off32;
-    DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
-    DevBuf<uint64_t> ekey, ekey_s;
-    DevBuf<uint16_t> keep_ks;
-    DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
-    DevBuf<uint16_t> kscore_saved;
-    DevBuf<uint8_t> sstr;
-    DevBuf<uint64_t> soff;
-    DevBuf<uint16_t> sscore;
-};
 
 namespace {
-
-enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_COUNT = 24 };
-
-struct WallTimer {
-    np2_ctx *cx;
-    const char *name;
-    double t0;
-    WallTimer(np2_ctx *c, const char *n);
-    ~WallTimer();
-};
-
-struct EventTimer {
-    np2_ctx *cx;
-    hipEvent_t a, b;
-    EventTimer(np2_ctx *c, const char *name) : cx(c) {
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, cx->stream);
-        cx->pending_events.push_back({name, {a, b}});
-    }
-    ~EventTimer() { (void)hipEventRecord(b, cx->stream); }
-};
-
-WallTimer::WallTimer(np2_ctx *c, const char *n) : cx(c), name(n), t0(now_ms()) {}
-WallTimer::~WallTimer() { cx->timing.host.push_back({name, (float)(now_ms() - t0)}); }
-
-void flush_timings(np2_ctx *cx) {
-    std::map<std::string, float> acc;
-    std::vector<std::string> order;
-    for (auto &e : cx->pending_events) {
-        float ms = 0;
-        (void)hipEventSynchronize(e.second.second);
-        (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
-        if (!acc.count(e.first)) order.push_back(e.first);
-        acc[e.first] += ms;
-        (void)hipEventDestroy(e.second.first);
-        (void)hipEventDestroy(e.second.second);
-    }
-    cx->pending_events.clear();
-    for (auto &h : cx->timing.host) {
-        if (!acc.count(h.first)) order.push_back(h.first);
-        acc[h.first] += h.second;
-    }
-    cx->timing.host.clear();
-    cx->timing.names = order;
-    cx->timing.ms.clear();
-    cx->timing.joined.clear();
-    for (auto &n : order) {
-        cx->timing.ms.push_back(acc[n]);
-        cx->timing.joined += n;
-        cx->timing.joined.push_back('\0');
-    }
-    cx->timing.joined.push_back('\0');
-}
-
-template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
-    std::vector<T> v(n);
-    if (n) {
-        void *pin = cx->pin_d2h.ensure(n * sizeof(T));
-        HIPCHK(hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, cx->stream));
-        HIPCHK(hipStreamSynchronize(cx->stream));
-        memcpy(v.data(), pin, n * sizeof(T));
-    }
-    return v;
-}
-// host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
-void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
-    if (!bytes) return;
-    HIPCHK(hipStreamSynchronize(cx->stream)); // the staging buffer may still be in flight
-    void *pin = cx->pin_h2d.ensure(bytes);
-    memcpy(pin, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, cx->stream));
-}
-template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name, const std::vector<T> &v) {
-    if (!cx->trace) return;
-    auto &dst = cx->trace_items[std::to_string(pass) + ":" + name];
-    dst.resize(v.size() * sizeof(T));
-    if (!v.empty()) memcpy(dst.data(), v.data(), dst.size());
-}
-
-uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
-    // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
-    int rc = prim_exclusive_sum_u32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n_plus1);
-    if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim exclusive_scan failed");
-    return 0;
-}
-void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
-    if (n_elems) HIPCHK(hipMemsetAsync(p, 0, n_elems * elem, cx->stream));
-}
 
 // ------------------------------------------------------------------------------------------
 // region state (device-resident; host keeps only counters)
@@ -1112,13 +848,69 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     throw Np2Error(NP2_E_ARG, "unreachable: no final pass");
 }
 
+} // namespace
+
+
+
+namespace np2h {
 int fail(np2_ctx *cx, const Np2Error &e) {
     if (cx) cx->err = e.what();
     return e.code;
 }
 
-} // namespace
-
+void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t n_reads, uint32_t L,
+                   uint64_t nib_bytes) {
+    if (reads[0].aln_t_s != 0 || reads[0].n_cols != L || reads[0].aln_t_e != L - 1 ||
+        (reads[0].flags & NP2_READ_DROPPED))
+        throw Np2Error(NP2_E_ARG, "reads[0] must be the contig aligned to itself (main.rs:1732-1739)");
+    std::vector<uint64_t> ck(n_reads + 1, 0);
+    std::vector<uint32_t> chunk_base(n_reads + 1, 0), chunk_read;
+    uint64_t cols = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const np2_read_t &rd = reads[r];
+        const bool dropped = rd.flags & NP2_READ_DROPPED;
+        if (rd.nib_off & 15) throw Np2Error(NP2_E_ARG, "nib_off must be a multiple of 16");
+        if (!dropped && (rd.aln_t_e >= L || rd.aln_t_s > rd.aln_t_e))
+            throw Np2Error(NP2_E_ARG, "read span outside the contig");
+        if (rd.nib_off + ((uint64_t)(rd.n_cols + 1) >> 1) + 1 + 16 > nib_bytes)
+            throw Np2Error(NP2_E_ARG, "nibble stream (plus 16 B tail padding) exceeds the buffer");
+        uint32_t nck = 0, nch = 0;
+        if (!dropped) {
+            const uint32_t first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT, last = rd.aln_t_e >> CKPT_SHIFT;
+            nck = last >= first ? last - first + 1 : 0;
+            if (r != 0) nch = (rd.n_cols + 2047) / 2048;
+            cols += rd.n_cols;
+        }
+        ck[r + 1] = ck[r] + nck;
+        chunk_base[r + 1] = chunk_base[r] + nch;
+        for (uint32_t k = 0; k < nch; ++k) chunk_read.push_back(r);
+    }
+    hipStream_t s = cx->stream;
+    c->L = L;
+    c->R = n_reads;
+    c->nib_bytes = nib_bytes;
+    c->n_cols = cols;
+    c->n_ckpt = ck[n_reads];
+    c->n_chunks = chunk_base[n_reads];
+    c->reads.ensure(n_reads);
+    const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds
+    c->refnib.ensure(((size_t)refbytes + 7) & ~(size_t)7);
+    c->ck_off.ensure(n_reads + 1);
+    c->ckpt.ensure(c->n_ckpt + 1);
+    c->chunk_base.ensure(n_reads + 1);
+    c->chunk_read.ensure(c->n_chunks + 1);
+    HIPCHK(hipMemcpyAsync(c->reads.p, reads, (size_t)n_reads * sizeof(np2_read_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ck_off.p, ck.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->chunk_base.p, chunk_base.data(), (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, s));
+    if (c->n_chunks)
+        HIPCHK(hipMemcpyAsync(c->chunk_read.p, chunk_read.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, s));
+    cx->scal.ensure(64);
+    zero32(cx, cx->scal.p, 24);
+    launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p);
+    auto sc = d2h(cx, cx->scal.p, 1); // also syncs: the host staging vectors above go out of scope
+    if (sc[0]) throw Np2Error(NP2_E_ARG, "reads[0] is not a plain self-alignment of the contig");
+}
+} // namespace np2h
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -1199,55 +991,9 @@ int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
         (void)ref;
         HIPCHK(hipSetDevice(cx->device));
         if (L < 3 || n_reads < 1 || !reads || !nibbles) throw Np2Error(NP2_E_ARG, "bad contig arguments");
-        if (reads[0].aln_t_s != 0 || reads[0].n_cols != L || reads[0].aln_t_e != L - 1 ||
-            (reads[0].flags & NP2_READ_DROPPED))
-            throw Np2Error(NP2_E_ARG, "reads[0] must be the contig aligned to itself (main.rs:1732-1739)");
-        std::vector<uint64_t> ck(n_reads + 1, 0);
-        uint64_t cols = 0;
-        for (uint32_t r = 0; r < n_reads; ++r) {
-            const np2_read_t &rd = reads[r];
-            if (rd.nib_off & 15) throw Np2Error(NP2_E_ARG, "nib_off must be a multiple of 16");
-            if (rd.aln_t_e >= L || rd.aln_t_s > rd.aln_t_e) throw Np2Error(NP2_E_ARG, "read span outside the contig");
-            if (rd.nib_off + ((uint64_t)(rd.n_cols + 1) >> 1) + 1 + 16 > nib_bytes)
-                throw Np2Error(NP2_E_ARG, "nibble stream (plus 16 B tail padding) exceeds the buffer");
-            const uint32_t first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT, last = rd.aln_t_e >> CKPT_SHIFT;
-            ck[r + 1] = ck[r] + (last >= first ? last - first + 1 : 0);
-            cols += rd.n_cols;
-        }
-        std::vector<uint32_t> chunk_base(n_reads + 1, 0), chunk_read;
-        for (uint32_t r = 0; r < n_reads; ++r) {
-            uint32_t nch = 0;
-            if (r != 0 && !(reads[r].flags & NP2_READ_DROPPED)) nch = (reads[r].n_cols + 2047) / 2048;
-            chunk_base[r + 1] = chunk_base[r] + nch;
-            for (uint32_t k = 0; k < nch; ++k) chunk_read.push_back(r);
-        }
-        c->n_chunks = chunk_base[n_reads];
-        c->chunk_base.ensure(n_reads + 1);
-        c->chunk_read.ensure(c->n_chunks + 1);
-        HIPCHK(hipMemcpyAsync(c->chunk_base.p, chunk_base.data(), (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, cx->stream));
-        if (c->n_chunks)
-            HIPCHK(hipMemcpyAsync(c->chunk_read.p, chunk_read.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, cx->stream));
-        HIPCHK(hipStreamSynchronize(cx->stream)); // host vectors go out of scope
-        c->L = L;
-        c->R = n_reads;
-        c->nib_bytes = nib_bytes;
-        c->n_cols = cols;
-        c->n_ckpt = ck[n_reads];
-        c->reads.ensure(n_reads);
         c->nib.ensure(nib_bytes + 64);
-        const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds
-        c->refnib.ensure(((size_t)refbytes + 7) & ~(size_t)7);
-        c->ck_off.ensure(n_reads + 1);
-        c->ckpt.ensure(c->n_ckpt + 1);
-        hipStream_t s = cx->stream;
-        HIPCHK(hipMemcpyAsync(c->reads.p, reads, (size_t)n_reads * sizeof(np2_read_t), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->nib.p, nibbles, nib_bytes, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->ck_off.p, ck.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-        cx->scal.ensure(S_COUNT);
-        zero32(cx, cx->scal.p, S_COUNT);
-        launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p + S_ERR);
-        auto sc = d2h(cx, cx->scal.p, S_COUNT);
-        if (sc[S_ERR]) throw Np2Error(NP2_E_ARG, "reads[0] is not a plain self-alignment of the contig");
+        HIPCHK(hipMemcpyAsync(c->nib.p, nibbles, nib_bytes, hipMemcpyHostToDevice, cx->stream));
+        finish_contig(cx, c, reads, n_reads, L, nib_bytes);
     } catch (const Np2Error &e) {
         delete c;
         return fail(cx, e);

@@ -1,0 +1,598 @@
+// Input side of the hot path (include/np2_io.h): FASTA[.gz], yak v2 dumps, indexed BAM (BGZF + BAI on zlib),
+// record admission (src/main.rs:1758-1817) and the GPU columnariser orchestration.
+#include "../../include/np2_io.h"
+#include "np2_ctx.hpp"
+
+#include <zlib.h>
+
+namespace {
+
+thread_local std::string g_io_err;
+int io_fail(int code, const std::string &m) {
+    g_io_err = m;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTA[.gz] (kseq semantics: name = header up to the first whitespace, sequence lines concatenated)
+// ---------------------------------------------------------------------------------------------
+struct Fasta {
+    gzFile f = nullptr;
+    std::string name, seq, pending; // pending = next header line
+    bool eof = false;
+    std::vector<char> buf;
+    bool getline(std::string &out) {
+        out.clear();
+        for (;;) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
+            size_t n = strlen(buf.data());
+            out.append(buf.data(), n);
+            if (n && buf[n - 1] == '\n') break;
+        }
+        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BGZF stream
+// ---------------------------------------------------------------------------------------------
+struct Bgzf {
+    FILE *f = nullptr;
+    std::vector<uint8_t> block, cdata;
+    size_t bpos = 0;
+    uint64_t block_coffset = 0;
+    bool read_block() { // returns false at EOF
+        block.clear();
+        bpos = 0;
+        block_coffset = (uint64_t)ftello(f);
+        uint8_t hd[18];
+        size_t n = fread(hd, 1, 18, f);
+        if (n == 0) return false;
+        if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
+            throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+        const uint32_t xlen = hd[10] | (hd[11] << 8);
+        // the BC subfield is normally the first (and only) extra field
+        std::vector<uint8_t> extra(xlen);
+        memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6)
+            throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF header");
+        uint32_t bsize = 0;
+        for (size_t p = 0; p + 4 <= xlen;) {
+            const uint32_t slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
+            p += 4 + slen;
+        }
+        if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+        const size_t clen = bsize - 12 - xlen - 8;
+        cdata.resize(clen + 8);
+        if (fread(cdata.data(), 1, clen + 8, f) != clen + 8) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+        const uint32_t isize = cdata[clen + 4] | (cdata[clen + 5] << 8) | (cdata[clen + 6] << 16) | ((uint32_t)cdata[clen + 7] << 24);
+        block.resize(isize);
+        if (isize) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw np2h::Np2Error(NP2_E_NOMEM, "inflateInit2 failed");
+            zs.next_in = cdata.data();
+            zs.avail_in = (uInt)clen;
+            zs.next_out = block.data();
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
+        }
+        return true;
+    }
+    void seek(uint64_t voffset) {
+        fseeko(f, (off_t)(voffset >> 16), SEEK_SET);
+        if (!read_block()) {
+            block.clear();
+            bpos = 0;
+            return;
+        }
+        bpos = voffset & 0xFFFF;
+    }
+    // read exactly n bytes; returns false on clean EOF before the first byte
+    bool read(void *dst, size_t n) {
+        uint8_t *d = (uint8_t *)dst;
+        size_t got = 0;
+        while (got < n) {
+            if (bpos >= block.size()) {
+                if (!read_block()) {
+                    if (got == 0) return false;
+                    throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+                }
+                continue;
+            }
+            const size_t k = std::min(n - got, block.size() - bpos);
+            memcpy(d + got, block.data() + bpos, k);
+            got += k;
+            bpos += k;
+        }
+        return true;
+    }
+};
+
+uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+} // namespace
+
+struct np2_fasta {
+    Fasta f;
+};
+struct np2_bam {
+    Bgzf z;
+    std::vector<std::string> ref_names;
+    std::vector<uint32_t> ref_lens;
+    std::vector<uint64_t> ref_start; // virtual offset of the first record of each reference (~0 = none)
+    uint64_t first_record_voffset = 0;
+};
+
+namespace {
+
+// ---- record admission + GPU columnarisation (main.rs:1758-1817) -----------------------------------
+struct Admitted {
+    uint32_t rec;     // input record index
+    bool is_clip;
+    uint32_t n_cols;  // untrimmed columns
+};
+
+void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs, uint32_t n_recs,
+                         const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes,
+                         const np2_front_opts_t *o, np2_contig **out) {
+    HIPCHK(hipSetDevice(cx->device));
+    hipStream_t s = cx->stream;
+    if (L < 3) throw np2h::Np2Error(NP2_E_ARG, "contig too short");
+    std::vector<FrontRec> frec;
+    std::vector<FrontOp> fops;
+    std::vector<Admitted> adm;
+    uint64_t out_off = ((((uint64_t)L + 1) >> 1) + 1 + 15) & ~15ull; // slot 0 = the contig itself
+    int32_t pre_pos = 0;
+    for (uint32_t i = 0; i < n_recs; ++i) {
+        const np2_bamrec_t &r = recs[i];
+        if (r.pos < pre_pos) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: Unsorted input file!");
+        const uint32_t *cg = cigar + r.cigar_off;
+        uint64_t rlen = 0;
+        int64_t span = 0;
+        for (uint32_t k = 0; k < r.n_cigar; ++k) { // seq_len_from_cigar(true) / reference_end - reference_start
+            const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8 || op == 5) rlen += l;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += l;
+        }
+        const bool secondary = r.flag & 0x100, supplementary = r.flag & 0x800;
+        const int64_t need = std::max<int64_t>((int64_t)o->min_map_len, (int64_t)((float)rlen * o->min_map_fra));
+        if ((r.flag & 0x404) != 0 || (int16_t)r.mapq <= o->min_map_qual || rlen <= o->min_read_len ||
+            (secondary && !o->use_secondary) || (supplementary && !o->use_supplementary) || span < need)
+            continue;
+        if (secondary) throw np2h::Np2Error(NP2_E_UNSUPPORTED, "-S (secondary alignments) needs SEQ recovery (secondary.rs)");
+        if (r.pos < 0 || (uint32_t)r.pos > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: record start outside the contig");
+        // fill_with_cigar bookkeeping (main.rs:390-439): query clipping, op prefix sums
+        uint32_t qs = 0, ts = 0, col = 0, aln_q_s = 0, aln_q_e = 0;
+        bool is_first = true;
+        FrontRec fr;
+        fr.pos = (uint32_t)r.pos;
+        fr.op_off = fops.size();
+        fr.seq_off = r.seq_off;
+        for (uint32_t k = 0; k < r.n_cigar; ++k) {
+            const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
+            switch (op) {
+            case 4:
+                qs += l;
+                if (is_first) aln_q_s = qs; else aln_q_e = qs - l;
+                break;
+            case 0: case 7: case 8:
+                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | op});
+                col += l, qs += l, ts += l;
+                break;
+            case 1:
+                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | 1u});
+                col += l, qs += l;
+                break;
+            case 2:
+                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | 2u});
+                col += l, ts += l;
+                break;
+            case 5:
+                break;
+            default:
+                throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: Unknown cigar");
+            }
+            is_first = false;
+        }
+        if (aln_q_e == 0) aln_q_e = qs;
+        if (qs > r.l_seq) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: SEQ shorter than CIGAR");
+        if ((uint64_t)r.pos + ts > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end");
+        if (r.seq_off + ((uint64_t)r.l_seq + 1) / 2 > seq4_bytes) throw np2h::Np2Error(NP2_E_ARG, "SEQ outside the buffer");
+        fr.n_ops = (uint32_t)(fops.size() - fr.op_off);
+        fr.n_cols = col;
+        fr.pad = 0;
+        fr.out_off = out_off;
+        out_off += ((((uint64_t)col + 1) >> 1) + 1 + 15) & ~15ull;
+        const bool is_clip = aln_q_e - aln_q_s + o->max_clip_len < (uint32_t)rlen; // main.rs:1796-1797
+        adm.push_back(Admitted{i, is_clip, col});
+        frec.push_back(fr);
+        pre_pos = r.pos;
+    }
+    const uint32_t n = (uint32_t)frec.size();
+    const uint64_t nib_bytes = out_off + 64;
+
+    np2_contig *c = new np2_contig();
+    try {
+        c->nib.ensure(nib_bytes + 64);
+        HIPCHK(hipMemsetAsync(c->nib.p, 0, nib_bytes + 64, s));
+        np2h::DevBuf<uint8_t> d_ref, d_seq;
+        np2h::DevBuf<FrontRec> d_rec;
+        np2h::DevBuf<FrontOp> d_ops;
+        np2h::DevBuf<FrontOut> d_out;
+        d_ref.ensure(L + 16);
+        HIPCHK(hipMemcpyAsync(d_ref.p, ref, L, hipMemcpyHostToDevice, s));
+        launch_pack_ref(s, d_ref.p, L, c->nib.p);
+        std::vector<FrontOut> fout(n);
+        if (n) {
+            d_seq.ensure(seq4_bytes + 16);
+            d_rec.ensure(n);
+            d_ops.ensure(fops.size() + 1);
+            d_out.ensure(n);
+            HIPCHK(hipMemcpyAsync(d_seq.p, seq4, seq4_bytes, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(d_rec.p, frec.data(), (size_t)n * sizeof(FrontRec), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(d_ops.p, fops.data(), fops.size() * sizeof(FrontOp), hipMemcpyHostToDevice, s));
+            {
+                np2h::EventTimer t(cx, "columnarise");
+                launch_columnarise(s, d_rec.p, n, d_ops.p, d_ref.p, d_seq.p, c->nib.p, d_out.p);
+            }
+            fout = np2h::d2h(cx, d_out.p, n);
+        } else {
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        // keep / drop / label (main.rs:1798-1813), then filter_alignseqs_by_clip (531-574)
+        std::vector<np2_read_t> reads;
+        std::vector<uint8_t> lable;
+        np2_read_t r0;
+        memset(&r0, 0, sizeof r0);
+        r0.aln_t_s = 0, r0.aln_t_e = L - 1, r0.nib_off = 0, r0.n_cols = L;
+        reads.push_back(r0);
+        lable.push_back(0);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (fout[i].n_cols <= o->min_map_len) continue; // aln_len() <= min_map_len
+            if (adm[i].is_clip && L < 500000) continue;
+            np2_read_t rd;
+            memset(&rd, 0, sizeof rd);
+            rd.aln_t_s = fout[i].aln_t_s;
+            rd.aln_t_e = fout[i].aln_t_e;
+            rd.n_cols = fout[i].n_cols;
+            rd.nib_off = frec[i].out_off;
+            reads.push_back(rd);
+            lable.push_back(adm[i].is_clip ? 1 : 0);
+        }
+        {
+            const uint32_t offset = 50;
+            std::vector<std::pair<uint32_t, uint32_t>> ranges;
+            uint32_t rs = 0, re = 0;
+            for (size_t i = 0; i < reads.size(); ++i) {
+                if (lable[i]) continue;
+                const uint32_t ts = reads[i].aln_t_s + offset, te = reads[i].aln_t_e - offset;
+                if (rs == re) {
+                    rs = ts, re = te;
+                } else if (ts > re) {
+                    ranges.emplace_back(rs, re);
+                    rs = ts, re = te;
+                } else if (re < te) {
+                    re = te;
+                }
+            }
+            if (rs != re) ranges.emplace_back(rs, re);
+            for (size_t i = 0; i < reads.size(); ++i) {
+                if (!lable[i]) continue;
+                for (auto &rg : ranges) {
+                    if (rg.first <= reads[i].aln_t_s && reads[i].aln_t_e <= rg.second) {
+                        reads[i].flags |= NP2_READ_DROPPED; // align_bases = Vec::new(), index retained
+                        reads[i].n_cols = 0;
+                        break;
+                    } else if (reads[i].aln_t_e < rg.first) {
+                        break;
+                    }
+                }
+            }
+            // a dropped slot still needs a terminator in its (unused) stream
+            for (size_t i = 0; i < reads.size(); ++i)
+                if (reads[i].flags & NP2_READ_DROPPED) {
+                    const uint8_t ff = 0xFF;
+                    np2h::h2d_staged(cx, c->nib.p + reads[i].nib_off, &ff, 1);
+                }
+        }
+        np2h::finish_contig(cx, c, reads.data(), (uint32_t)reads.size(), L, nib_bytes);
+    } catch (...) {
+        delete c;
+        throw;
+    }
+    *out = c;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *np2_io_last_error(void) { return g_io_err.c_str(); }
+
+// ---- FASTA ---------------------------------------------------------------------------------------
+int np2_fasta_open(const char *path, np2_fasta_t **out) {
+    np2_fasta *h = new np2_fasta();
+    h->f.f = gzopen(path, "rb");
+    if (!h->f.f) {
+        delete h;
+        return io_fail(NP2_E_ARG, std::string("cannot open ") + path);
+    }
+    gzbuffer(h->f.f, 1 << 20);
+    h->f.buf.resize(1 << 16);
+    std::string line;
+    while (h->f.getline(line)) // skip to the first header
+        if (!line.empty() && line[0] == '>') {
+            h->f.pending = line;
+            break;
+        }
+    *out = h;
+    return NP2_OK;
+}
+int np2_fasta_next(np2_fasta_t *h, const char **name, const uint8_t **seq, uint64_t *len) {
+    Fasta &f = h->f;
+    if (f.pending.empty()) return 0;
+    size_t e = 1;
+    while (e < f.pending.size() && !isspace((unsigned char)f.pending[e])) ++e;
+    f.name = f.pending.substr(1, e - 1);
+    f.pending.clear();
+    f.seq.clear();
+    std::string line;
+    while (f.getline(line)) {
+        if (!line.empty() && line[0] == '>') {
+            f.pending = line;
+            break;
+        }
+        f.seq += line;
+    }
+    *name = f.name.c_str();
+    *seq = (const uint8_t *)f.seq.data();
+    *len = f.seq.size();
+    return 1;
+}
+void np2_fasta_close(np2_fasta_t *h) {
+    if (!h) return;
+    if (h->f.f) gzclose(h->f.f);
+    delete h;
+}
+
+// ---- yak v2 (kmer.rs:72-170) -----------------------------------------------------------------------
+int np2_yak_load(const char *path, np2_yak_t *out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return io_fail(NP2_E_ARG, std::string("cannot open ") + path);
+    uint8_t hd[16];
+    if (fread(hd, 1, 16, f) != 16 || memcmp(hd, "YAK\2", 4) != 0) {
+        fclose(f);
+        return io_fail(NP2_E_ARG, "The input binary k-mer dump file is incompatible.");
+    }
+    const uint32_t k = le32(hd + 4), pre = le32(hd + 8), cbits = le32(hd + 12);
+    if (cbits != 10) {
+        fclose(f);
+        return io_fail(NP2_E_ARG, "different YAK_COUNTER_BITS");
+    }
+    if (pre > 20) {
+        fclose(f);
+        return io_fail(NP2_E_UNSUPPORTED, "yak prefix bits too large");
+    }
+    const size_t nb = (size_t)1 << pre;
+    std::vector<uint64_t> words;
+    uint64_t *off = (uint64_t *)malloc((nb + 1) * 8);
+    off[0] = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        uint8_t h8[8];
+        if (fread(h8, 1, 8, f) != 8) {
+            fclose(f);
+            free(off);
+            return io_fail(NP2_E_ARG, "Failed to parse the dump file");
+        }
+        const uint32_t n = le32(h8 + 4); // first u32 (capacity bits) is ignored like the reference (kmer.rs:143-147)
+        const size_t base = words.size();
+        words.resize(base + n);
+        const size_t got = fread(words.data() + base, 8, n, f);
+        words.resize(base + got); // UnexpectedEof ends the bucket (kmer.rs:151-155)
+        off[b + 1] = words.size();
+    }
+    fclose(f);
+    uint64_t *w = (uint64_t *)malloc((words.size() + 1) * 8);
+    memcpy(w, words.data(), words.size() * 8);
+    out->k = k;
+    out->pre = pre;
+    out->n_words = words.size();
+    out->words = w;
+    out->bucket_off = off;
+    return NP2_OK;
+}
+void np2_yak_free(np2_yak_t *y) {
+    if (!y) return;
+    free((void *)y->words);
+    free((void *)y->bucket_off);
+    y->words = nullptr;
+    y->bucket_off = nullptr;
+}
+
+// ---- BAM ---------------------------------------------------------------------------------------------
+int np2_bam_open(const char *path, np2_bam_t **out) {
+    np2_bam *b = new np2_bam();
+    b->z.f = fopen(path, "rb");
+    try {
+        if (!b->z.f) throw np2h::Np2Error(NP2_E_ARG, std::string("cannot open ") + path);
+        fseeko(b->z.f, 0, SEEK_SET);
+        b->z.block.clear();
+        b->z.bpos = 0;
+        uint8_t h8[8];
+        if (!b->z.read(h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw np2h::Np2Error(NP2_E_ARG, "not a BAM file");
+        const uint32_t l_text = le32(h8 + 4);
+        std::vector<uint8_t> text(l_text + 1);
+        if (l_text) b->z.read(text.data(), l_text);
+        uint8_t h4[4];
+        b->z.read(h4, 4);
+        const uint32_t n_ref = le32(h4);
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            b->z.read(h4, 4);
+            const uint32_t l_name = le32(h4);
+            std::vector<char> nm(l_name + 1, 0);
+            b->z.read(nm.data(), l_name);
+            b->z.read(h4, 4);
+            b->ref_names.emplace_back(nm.data());
+            b->ref_lens.push_back(le32(h4));
+        }
+        b->ref_start.assign(n_ref, ~0ull);
+        // index: <path>.bai or <stem>.bai
+        std::string p1 = std::string(path) + ".bai", p2 = path;
+        if (p2.size() > 4 && p2.substr(p2.size() - 4) == ".bam") p2 = p2.substr(0, p2.size() - 4) + ".bai";
+        FILE *fi = fopen(p1.c_str(), "rb");
+        if (!fi) fi = fopen(p2.c_str(), "rb");
+        if (!fi) throw np2h::Np2Error(NP2_E_ARG, "Faield random access BAM/SAM! (no .bai index)");
+        std::vector<uint8_t> idx;
+        {
+            fseeko(fi, 0, SEEK_END);
+            const size_t sz = (size_t)ftello(fi);
+            fseeko(fi, 0, SEEK_SET);
+            idx.resize(sz);
+            if (fread(idx.data(), 1, sz, fi) != sz) {
+                fclose(fi);
+                throw np2h::Np2Error(NP2_E_ARG, "cannot read the .bai index");
+            }
+            fclose(fi);
+        }
+        if (idx.size() < 8 || memcmp(idx.data(), "BAI\1", 4) != 0) throw np2h::Np2Error(NP2_E_ARG, "bad .bai magic");
+        size_t p = 4;
+        const uint32_t n_ref_i = le32(idx.data() + p);
+        p += 4;
+        for (uint32_t r = 0; r < n_ref_i && r < n_ref; ++r) {
+            if (p + 4 > idx.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated .bai");
+            const uint32_t n_bin = le32(idx.data() + p);
+            p += 4;
+            uint64_t best = ~0ull;
+            for (uint32_t bi = 0; bi < n_bin; ++bi) {
+                const uint32_t bin = le32(idx.data() + p), n_chunk = le32(idx.data() + p + 4);
+                p += 8;
+                for (uint32_t ci = 0; ci < n_chunk; ++ci) {
+                    const uint64_t beg = le64(idx.data() + p);
+                    p += 16;
+                    if (bin != 37450 && beg < best) best = beg; // 37450 = metadata pseudo-bin
+                }
+            }
+            const uint32_t n_intv = le32(idx.data() + p);
+            p += 4 + (size_t)n_intv * 8;
+            b->ref_start[r] = best;
+        }
+    } catch (const np2h::Np2Error &e) {
+        if (b->z.f) fclose(b->z.f);
+        delete b;
+        return io_fail(e.code, e.what());
+    }
+    *out = b;
+    return NP2_OK;
+}
+void np2_bam_close(np2_bam_t *b) {
+    if (!b) return;
+    if (b->z.f) fclose(b->z.f);
+    delete b;
+}
+int np2_bam_n_refs(np2_bam_t *b) { return b ? (int)b->ref_names.size() : 0; }
+const char *np2_bam_ref_name(np2_bam_t *b, int tid, uint32_t *len) {
+    if (!b || tid < 0 || (size_t)tid >= b->ref_names.size()) return nullptr;
+    if (len) *len = b->ref_lens[tid];
+    return b->ref_names[tid].c_str();
+}
+
+int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs, uint32_t n_recs,
+                            const uint32_t *cigar, const uint8_t *seq4, const np2_front_opts_t *opts,
+                            np2_contig_t **out) {
+    if (!cx || !ref || !opts || !out) return NP2_E_ARG;
+    *out = nullptr;
+    try {
+        uint64_t sbytes = 0;
+        for (uint32_t i = 0; i < n_recs; ++i) sbytes = std::max<uint64_t>(sbytes, recs[i].seq_off + ((uint64_t)recs[i].l_seq + 1) / 2);
+        contig_from_records(cx, ref, L, recs, n_recs, cigar, seq4, sbytes, opts, out);
+        np2h::flush_timings(cx);
+    } catch (const np2h::Np2Error &e) {
+        (void)hipStreamSynchronize(cx->stream);
+        np2h::flush_timings(cx);
+        return np2h::fail(cx, e);
+    }
+    return NP2_OK;
+}
+
+int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L,
+                        const np2_front_opts_t *opts, np2_contig_t **out) {
+    if (!cx || !bam || !name || !ref || !opts || !out) return NP2_E_ARG;
+    *out = nullptr;
+    try {
+        int tid = -1;
+        for (size_t i = 0; i < bam->ref_names.size(); ++i)
+            if (bam->ref_names[i] == name) tid = (int)i;
+        if (tid < 0) throw np2h::Np2Error(NP2_E_ARG, std::string("Faield random access BAM/SAM! (contig not in the BAM header: ") + name + ")");
+        std::vector<np2_bamrec_t> recs;
+        std::vector<uint32_t> cigar;
+        std::vector<uint8_t> seq4;
+        if (bam->ref_start[tid] != ~0ull) {
+            bam->z.seek(bam->ref_start[tid]);
+            std::vector<uint8_t> rec;
+            for (;;) {
+                uint8_t h4[4];
+                if (!bam->z.read(h4, 4)) break;
+                const uint32_t bs = le32(h4);
+                rec.resize(bs);
+                bam->z.read(rec.data(), bs);
+                const int32_t refID = (int32_t)le32(rec.data());
+                if (refID != tid) {
+                    if (refID > tid || refID < 0) break;
+                    continue;
+                }
+                const int32_t pos = (int32_t)le32(rec.data() + 4);
+                if ((uint32_t)pos >= L) continue; // fetch(tid, 0, len): records starting beyond the region
+                const uint32_t l_read_name = rec[8], mapq = rec[9];
+                const uint32_t n_cigar = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8);
+                const uint32_t l_seq = le32(rec.data() + 16);
+                const uint8_t *pc = rec.data() + 32 + l_read_name;
+                const uint8_t *ps = pc + (size_t)n_cigar * 4;
+                if ((size_t)(ps - rec.data()) + (l_seq + 1) / 2 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                np2_bamrec_t r;
+                memset(&r, 0, sizeof r);
+                r.pos = pos;
+                r.flag = (uint16_t)flag;
+                r.mapq = (uint8_t)mapq;
+                r.n_cigar = n_cigar;
+                r.cigar_off = cigar.size();
+                r.l_seq = l_seq;
+                r.seq_off = seq4.size();
+                for (uint32_t k = 0; k < n_cigar; ++k) cigar.push_back(le32(pc + 4 * k));
+                seq4.insert(seq4.end(), ps, ps + (l_seq + 1) / 2);
+                recs.push_back(r);
+            }
+        }
+        seq4.resize(seq4.size() + 16, 0);
+        contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
+        np2h::flush_timings(cx);
+    } catch (const np2h::Np2Error &e) {
+        (void)hipStreamSynchronize(cx->stream);
+        np2h::flush_timings(cx);
+        return np2h::fail(cx, e);
+    }
+    return NP2_OK;
+}
+
+int np2_contig_export(np2_ctx_t *cx, np2_contig_t *c, np2_read_t **reads, uint32_t *n_reads, uint8_t **nibbles,
+                      uint64_t *nib_bytes) {
+    if (!cx || !c || !reads || !n_reads || !nibbles || !nib_bytes) return NP2_E_ARG;
+    try {
+        HIPCHK(hipSetDevice(cx->device));
+        *reads = (np2_read_t *)malloc((size_t)c->R * sizeof(np2_read_t));
+        *nibbles = (uint8_t *)malloc(c->nib_bytes);
+        HIPCHK(hipMemcpy(*reads, c->reads.p, (size_t)c->R * sizeof(np2_read_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(*nibbles, c->nib.p, c->nib_bytes, hipMemcpyDeviceToHost));
+        *n_reads = c->R;
+        *nib_bytes = c->nib_bytes;
+    } catch (const np2h::Np2Error &e) {
+        return np2h::fail(cx, e);
+    }
+    return NP2_OK;
+}
+}

@@ -162,6 +162,26 @@ void launch_rech_select(hipStream_t s, const uint32_t *rech, const uint32_t *n_r
                         const uint32_t *order, bool first_yak, uint8_t *reg_lable, uint32_t *seed_cand);
 void launch_rech_relabel(hipStream_t s, uint8_t *reg_lable, uint32_t n_reg);
 
+// ---- np2_front.hip: BAM record -> packed pileup columnariser ---------------------------------------
+struct FrontOp { // one column-producing CIGAR op (M = X I D), prefix sums precomputed by the host
+    uint32_t col0, q0, t0; // first alignment column / query index / target offset (relative to pos)
+    uint32_t len_type;     // len << 4 | BAM op code
+};
+struct FrontRec {
+    uint32_t pos, n_ops;
+    uint64_t op_off;  // index into ops[]
+    uint64_t seq_off; // byte offset into the 4-bit SEQ buffer
+    uint64_t out_off; // byte offset of the output nibble slot (16-B aligned, pre-zeroed)
+    uint32_t n_cols;  // untrimmed alignment columns
+    uint32_t pad;
+};
+struct FrontOut {
+    uint32_t aln_t_s, aln_t_e, n_cols, pad;
+};
+void launch_columnarise(hipStream_t s, const FrontRec *recs, uint32_t n_recs, const FrontOp *ops, const uint8_t *ref,
+                        const uint8_t *seq4, uint8_t *nib, FrontOut *out);
+void launch_pack_ref(hipStream_t s, const uint8_t *ref, uint32_t L, uint8_t *dst);
+
 // ---- np2_prims.hip: device-wide sort / scan plumbing (rocPRIM) -------------------------------
 // All take a caller-provided temp buffer; *_temp_bytes report the requirement for n elements.
 size_t prim_temp_bytes(size_t n);

@@ -1,0 +1,178 @@
+"""ctypes binding of include/np2_io.h: FASTA[.gz] / yak / indexed BAM readers and the GPU columnariser."""
+import ctypes as C
+
+import numpy as np
+
+from ._types import READ_DTYPE, Pileup, Yak, np2_read_t, np2_yak_t
+from .api import Np2Error, ResidentContig, lib
+
+BAMREC_DTYPE = np.dtype([("pos", "<i4"), ("flag", "<u2"), ("mapq", "u1"), ("pad", "u1"), ("n_cigar", "<u4"),
+                         ("pad2", "<u4"), ("cigar_off", "<u8"), ("l_seq", "<u4"), ("pad3", "<u4"), ("seq_off", "<u8")])
+assert BAMREC_DTYPE.itemsize == 40
+
+IO_SYMBOLS = ["np2_fasta_open", "np2_fasta_next", "np2_fasta_close", "np2_yak_load", "np2_yak_free", "np2_bam_open",
+              "np2_bam_close", "np2_bam_n_refs", "np2_bam_ref_name", "np2_io_last_error", "np2_contig_from_records",
+              "np2_contig_from_bam", "np2_contig_export"]
+
+
+class np2_front_opts_t(C.Structure):
+    _fields_ = [("min_read_len", C.c_uint32), ("min_map_len", C.c_uint32), ("min_map_fra", C.c_float),
+                ("min_map_qual", C.c_int16), ("max_clip_len", C.c_uint32), ("use_supplementary", C.c_uint8),
+                ("use_secondary", C.c_uint8)]
+
+
+class FrontOpts:
+    """Read-admission options with the reference defaults (src/utils/option.rs:267-292; -a 500.5 splits into
+    min_map_len = 500 and min_map_fra = 0.5, option.rs:232,258-259)."""
+
+    def __init__(self, min_read_len=1000, min_map_len=500, min_map_fra=0.5, min_map_qual=1, max_clip_len=100,
+                 use_supplementary=False, use_secondary=False):
+        self.min_read_len, self.min_map_len, self.min_map_fra = min_read_len, min_map_len, min_map_fra
+        self.min_map_qual, self.max_clip_len = min_map_qual, max_clip_len
+        self.use_supplementary, self.use_secondary = use_supplementary, use_secondary
+
+    def c(self):
+        return np2_front_opts_t(self.min_read_len, self.min_map_len, self.min_map_fra, self.min_map_qual,
+                                self.max_clip_len, 1 if self.use_supplementary else 0, 1 if self.use_secondary else 0)
+
+
+_BOUND = False
+
+
+def _bind():
+    global _BOUND
+    L = lib()
+    if not _BOUND:
+        vp = C.c_void_p
+        L.np2_fasta_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.np2_fasta_next.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.np2_fasta_close.argtypes = [vp]
+        L.np2_yak_load.argtypes = [C.c_char_p, C.POINTER(np2_yak_t)]
+        L.np2_yak_free.argtypes = [C.POINTER(np2_yak_t)]
+        L.np2_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.np2_bam_close.argtypes = [vp]
+        L.np2_bam_n_refs.argtypes = [vp]
+        L.np2_bam_ref_name.restype = C.c_char_p
+        L.np2_bam_ref_name.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
+        L.np2_io_last_error.restype = C.c_char_p
+        L.np2_contig_from_records.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.POINTER(np2_front_opts_t),
+                                              C.POINTER(vp)]
+        L.np2_contig_from_bam.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.POINTER(np2_front_opts_t), C.POINTER(vp)]
+        L.np2_contig_export.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        _BOUND = True
+    return L
+
+
+def _io_check(rc):
+    if rc != 0:
+        raise Np2Error(rc, _bind().np2_io_last_error().decode())
+
+
+def read_fasta(path):
+    """Yield (name, sequence bytes) like kseq (src/main.rs:1705-1714): name = header up to the first whitespace."""
+    L = _bind()
+    h = C.c_void_p()
+    _io_check(L.np2_fasta_open(path.encode(), C.byref(h)))
+    try:
+        name, seq, n = C.c_char_p(), C.c_void_p(), C.c_uint64()
+        while True:
+            rc = L.np2_fasta_next(h, C.byref(name), C.byref(seq), C.byref(n))
+            if rc == 0:
+                break
+            if rc < 0:
+                _io_check(rc)
+            yield name.value.decode(), C.string_at(seq.value, n.value) if n.value else b""
+    finally:
+        L.np2_fasta_close(h)
+
+
+def load_yak(path):
+    """yak v2 dump -> Yak (src/utils/kmer.rs:72-170)."""
+    L = _bind()
+    y = np2_yak_t()
+    _io_check(L.np2_yak_load(path.encode(), C.byref(y)))
+    try:
+        nb = (1 << y.pre) + 1
+        off = np.ctypeslib.as_array(y.bucket_off, shape=(nb,)).copy()
+        words = np.ctypeslib.as_array(y.words, shape=(max(int(y.n_words), 1),))[: int(y.n_words)].copy()
+        return Yak(y.k, words, off, pre=y.pre)
+    finally:
+        L.np2_yak_free(C.byref(y))
+
+
+def write_yak(path, yak):
+    """Write a Yak as a yak v2 dump ("YAK\\2", k, pre, counter_bits = 10, then per bucket: u32, u32 n, n x u64)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"YAK\x02" + struct.pack("<III", yak.k, yak.pre, 10))
+        for b in range(1 << yak.pre):
+            s, e = int(yak.bucket_off[b]), int(yak.bucket_off[b + 1])
+            f.write(struct.pack("<II", 0, e - s))
+            f.write(yak.words[s:e].tobytes())
+
+
+class Bam:
+    def __init__(self, path):
+        L = _bind()
+        self._h = C.c_void_p()
+        _io_check(L.np2_bam_open(path.encode(), C.byref(self._h)))
+
+    def refs(self):
+        L = _bind()
+        out = []
+        for i in range(L.np2_bam_n_refs(self._h)):
+            n = C.c_uint32()
+            out.append((L.np2_bam_ref_name(self._h, i, C.byref(n)).decode(), n.value))
+        return out
+
+    def close(self):
+        if self._h:
+            _bind().np2_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _resident(pol, h, name, L_, n_reads=0, n_cols=0):
+    rc = ResidentContig.__new__(ResidentContig)
+    rc._p, rc._h, rc.L, rc.n_reads, rc.n_columns, rc.name = pol, h, L_, n_reads, n_cols, name
+    return rc
+
+
+def contig_from_bam(pol, bam, name, ref, opts=None):
+    """BAM records of contig `name` -> packed pileup resident in HBM (GPU columnariser)."""
+    L = _bind()
+    ref = np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else np.ascontiguousarray(ref, dtype=np.uint8)
+    o = (opts or FrontOpts()).c()
+    h = C.c_void_p()
+    pol._check(L.np2_contig_from_bam(pol._h, bam._h, name.encode(), ref.ctypes.data, ref.shape[0], C.byref(o), C.byref(h)))
+    return _resident(pol, h, name, int(ref.shape[0]))
+
+
+def contig_from_records(pol, ref, recs, cigar, seq4, opts=None, name="ctg"):
+    L = _bind()
+    ref = np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else np.ascontiguousarray(ref, dtype=np.uint8)
+    recs = np.ascontiguousarray(recs, dtype=BAMREC_DTYPE)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+    o = (opts or FrontOpts()).c()
+    h = C.c_void_p()
+    pol._check(L.np2_contig_from_records(pol._h, ref.ctypes.data, ref.shape[0], recs.ctypes.data, recs.shape[0],
+                                         cigar.ctypes.data, seq4.ctypes.data, C.byref(o), C.byref(h)))
+    return _resident(pol, h, name, int(ref.shape[0]))
+
+
+def export_contig(pol, contig, ref):
+    """Copy a resident packed pileup back to the host as a Pileup (parity tests)."""
+    L = _bind()
+    pr, pn, nr, nb = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint64()
+    pol._check(L.np2_contig_export(pol._h, contig._h, C.byref(pr), C.byref(nr), C.byref(pn), C.byref(nb)))
+    reads = np.frombuffer(C.string_at(pr.value, nr.value * C.sizeof(np2_read_t)), dtype=READ_DTYPE).copy()
+    nib = np.frombuffer(C.string_at(pn.value, nb.value), dtype=np.uint8).copy()
+    L.np2_free(pr)
+    L.np2_free(pn)
+    return Pileup(ref, reads, nib)

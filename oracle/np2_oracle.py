@@ -164,3 +164,39 @@ def phase_communities(edges, ref=None):
     if rc != 0:
         raise RefPanic("phase_communities")
     return out[: n.value].tolist()
+
+
+class np2o_front_opts_t(C.Structure):
+    _fields_ = [("min_read_len", C.c_uint32), ("min_map_len", C.c_uint32), ("min_map_fra", C.c_float),
+                ("min_map_qual", C.c_int16), ("max_clip_len", C.c_uint32), ("use_supplementary", C.c_uint8),
+                ("use_secondary", C.c_uint8)]
+
+
+def front_end(ref, recs, cigar, ascii_seq, ascii_off, fopts):
+    """Oracle of the read admission + columnarisation (oracle/np2_oracle_front.cpp) -> Pileup.
+
+    recs: BAMREC_DTYPE array (seq_off is replaced by ascii_off); ascii_seq: SEQ as rust-htslib decodes it."""
+    from nextpolish2_amd._types import READ_DTYPE, Pileup
+    L_ = lib()
+    L_.np2o_front_end.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p,
+                                  C.POINTER(np2o_front_opts_t), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L_.np2o_front_free.argtypes = [C.c_void_p]
+    ref = bytes(ref)
+    r2 = np.array(recs, copy=True)
+    r2["seq_off"] = np.asarray(ascii_off, dtype=np.uint64)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    o = np2o_front_opts_t(fopts.min_read_len, fopts.min_map_len, fopts.min_map_fra, fopts.min_map_qual,
+                          fopts.max_clip_len, 1 if fopts.use_supplementary else 0, 1 if fopts.use_secondary else 0)
+    pr, pn, nr, nb = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint64()
+    rc = L_.np2o_front_end(ref, len(ref), r2.ctypes.data, r2.shape[0], cigar.ctypes.data, bytes(ascii_seq) + b"\0",
+                           C.byref(o), C.byref(pr), C.byref(nr), C.byref(pn), C.byref(nb))
+    if rc == -5:
+        raise RefPanic("front end")
+    if rc != 0:
+        raise RuntimeError(f"oracle front end rc={rc}")
+    reads = np.frombuffer(C.string_at(pr.value, nr.value * 24), dtype=READ_DTYPE).copy()
+    nib = np.frombuffer(C.string_at(pn.value, nb.value), dtype=np.uint8).copy()
+    L_.np2o_front_free(pr)
+    L_.np2o_front_free(pn)
+    return Pileup(np.frombuffer(ref, dtype=np.uint8), reads, nib)
