@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void k_columnarise(const FrontRec *__restrict_
         tail = __shfl(s.eq, 63);
     }
     if (shift == 0xFFFFFFFFu) { // no anchor: shift = len -> zero columns (main.rs:510-512)
-        if (lane == 0) out[r] = FrontOut{rc.pos, rc.pos, 0, 0};
+        if (lane == 0) {
+            out[r] = FrontOut{rc.pos, rc.pos, 0, 0};
+            nib[rc.out_off] = 0xFF;
+        }
         return;
     }
     // ---- backward: last run of 8 equal columns -> new_len ------------------------------------------
@@ -146,7 +149,10 @@ __global__ __launch_bounds__(256) void k_columnarise(const FrontRec *__restrict_
     const uint32_t n_out = new_len - shift;
     uint8_t *dst = nib + rc.out_off;
     uint32_t t_s = 0, t_e = 0;
-    for (uint32_t oc = 0; oc <= n_out; oc += 2048) {
+    // the wave owns its whole output slot (roundup16((N+1)/2 + 1) bytes): chunks past the terminator are zeroed here,
+    // so no pre-clearing of the buffer is needed
+    const uint32_t slot_cols = (uint32_t)((((((uint64_t)N + 1) >> 1) + 1 + 15) & ~15ull) * 2);
+    for (uint32_t oc = 0; oc < slot_cols; oc += 2048) {
         const uint32_t lo0 = oc + lane * 32;
         const uint32_t nv = lo0 < n_out ? min(32u, n_out - lo0) : 0u;
         Seg32 s = walk32(rc, ops, ref, seq4, shift + lo0, nv);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void k_columnarise(const FrontRec *__restrict_
                 if (j1 < 16) s.lo |= 0xFULL << (4 * j1); else s.hi |= 0xFULL << (4 * (j1 - 16));
             }
         }
-        if (nv || has_term) {
+        if (lo0 < slot_cols) {
             auto sw = [](uint32_t w) { return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu); };
             uint4 v;
             v.x = sw((uint32_t)s.lo);

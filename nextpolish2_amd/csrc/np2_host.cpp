@@ -946,6 +946,7 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
             const size_t slots = (size_t)1024 << cl;
             t.table.ensure(slots);
             HIPCHK(hipMemsetAsync(t.table.p, 0xFF, slots * 8, cx->stream));
+            HIPCHK(hipStreamSynchronize(cx->stream)); // large fill + pageable H2D below: do not rely on their ordering
             DevBuf<uint64_t> dw, doff;
             dw.ensure(y.n_words + 1);
             doff.ensure(1025);

@@ -219,8 +219,7 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
 
     np2_contig *c = new np2_contig();
     try {
-        c->nib.ensure(nib_bytes + 64);
-        HIPCHK(hipMemsetAsync(c->nib.p, 0, nib_bytes + 64, s));
+        c->nib.ensure(nib_bytes + 64); // every slot is written completely by its producer kernel
         np2h::DevBuf<uint8_t> d_ref, d_seq;
         np2h::DevBuf<FrontRec> d_rec;
         np2h::DevBuf<FrontOp> d_ops;
