@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# HBM traffic of one k_diff_reads launch on the default workload, from rocprofv3 PMC passes
+# (profiles/r01b_pmc_fetch_write.json: 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE)
+PMC_TRAFFIC_DEFAULT_WORKLOAD = int((2 * 47589.7 + 21757.8) * 1024)
 
 
 def main():
@@ -105,7 +108,8 @@ def main():
                    "contig_bp": L, "depth": a.depth, "reads": syn.pileup.n_reads, "pileup_columns": int(n_cols),
                    "yak_k": [21], "iter_count": 2, "parallelism": f"contig-sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_diff_reads", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": PMC_TRAFFIC_DEFAULT_WORKLOAD if (a.length == 4_600_000 and a.depth == 30) else None,
                      "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4)},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
     }
