@@ -190,6 +190,8 @@ struct np2_ctx {
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
+    DevBuf<uint2> nrec;
+    DevBuf<int64_t> run_gain;
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;

@@ -482,7 +482,8 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
                              cx->scal.p + S_NNODES);
     }
     exclusive_total(cx, cx->node_cnt.p, cx->node_off.p, (size_t)L + 1);
-    launch_order_nodes(s, cx->node_off.p, L, nd);
+    cx->nrec.ensure(T + 1);
+    launch_order_nodes(s, cx->node_off.p, L, nd, cx->nrec.p);
     zero32(cx, cx->covd.p, L + 2);
     launch_cov_delta(s, c->reads.p, R, cx->alive.p, cx->covd.p);
     if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->covd.p, cx->cov.p, (size_t)L + 1))
@@ -545,15 +546,16 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     const uint32_t L = c->L;
     GraphPtrs gp = graph_ptrs(cx, c);
     cx->n0_besti.ensure(L + 2);
+    cx->run_gain.ensure((size_t)n_runs + 2);
     cx->emit.ensure(L + 2);
     cx->eoff.ensure(L + 2);
     {
         EventTimer t(cx, "dp_backtrack");
         zero32(cx, cx->n0_besti.p, L + 2);
         zero32(cx, cx->scal.p + S_BEST, S_COUNT - S_BEST); // best, path_begin, n_raw, n_reg, dup, last, gain
-        launch_dp(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
+        launch_dp(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
                   cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
-                  cx->scal.p + S_BEST);
+                  cx->scal.p + S_BEST, cx->run_gain.p);
         launch_bt_count(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
                         cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN);
         zero32(cx, cx->emit.p + L, 1);

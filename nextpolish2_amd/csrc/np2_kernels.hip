@@ -487,12 +487,14 @@ __global__ void k_scatter_nodes(const uint64_t *__restrict__ keys, const uint32_
     if (i == T - 1) *n_nodes = idx[i] + (c ? 1u : 0u);
 }
 
-// order the nodes of one position like Msa::sort over first-seen order: (delta3, first read)
-__global__ void k_order_nodes(const uint32_t *__restrict__ node_off, uint32_t L, NodeArrays nd) {
+// order the nodes of one position like Msa::sort over first-seen order: (delta3, first read); also emits the
+// packed 8-byte records {bases | delta << 16, count} the DP kernels read
+__global__ void k_order_nodes(const uint32_t *__restrict__ node_off, uint32_t L, NodeArrays nd,
+                              uint2 *__restrict__ nrec) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= L) return;
     const uint32_t o0 = node_off[p], o1 = node_off[p + 1];
-    if (o1 - o0 < 2) return;
+    if (o1 == o0) return;
     for (uint32_t i = o0 + 1; i < o1; ++i) {
         const uint16_t b = nd.bases[i], d = nd.delta[i];
         const uint32_t c = nd.count[i], m = nd.minr[i];
@@ -512,6 +514,8 @@ __global__ void k_order_nodes(const uint32_t *__restrict__ node_off, uint32_t L,
         nd.count[j] = c;
         nd.minr[j] = m;
     }
+    for (uint32_t i = o0; i < o1; ++i)
+        nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
 }
 
 // coverage(p) = number of live reads spanning p (Msa::coverage, main.rs:232-241)
@@ -602,37 +606,67 @@ __device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q,
     return pb2.eq(kb1) && pb3.eq(kb2);
 }
 
-__global__ void k_dp_runs(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ n_runs, Graph g,
-                          int64_t *__restrict__ nscore, uint32_t *__restrict__ nbesti,
-                          uint32_t *__restrict__ n0_besti, uint32_t *__restrict__ run_end,
-                          int64_t *__restrict__ last_n0_score, unsigned long long *__restrict__ total_gain) {
+// One thread per dirty run.  A position costs two dependent memory rounds: {node_off, cov, contig codes} then the
+// packed node records; the nodes and scores of the current and the previous position live in LDS (element-major,
+// one 4-byte bank per thread: conflict free), nodes beyond DP_CACHE per position fall back to global memory.
+static constexpr uint32_t DP_CACHE = 8;
+static constexpr uint32_t DP_BLOCK = 64;
+
+__global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict__ run_start,
+                                                      const uint32_t *__restrict__ n_runs, Graph g,
+                                                      const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
+                                                      uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
+                                                      uint32_t *__restrict__ run_end,
+                                                      int64_t *__restrict__ last_n0_score,
+                                                      int64_t *__restrict__ run_gain) {
+    __shared__ uint32_t s_key[2][DP_CACHE][DP_BLOCK];
+    __shared__ uint32_t s_cnt[2][DP_CACHE][DP_BLOCK];
+    __shared__ uint32_t s_slo[2][DP_CACHE][DP_BLOCK];
+    __shared__ uint32_t s_shi[2][DP_CACHE][DP_BLOCK];
+    const uint32_t t = threadIdx.x;
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], L = g.L;
-    // previous position view (starts as the clean position a-1, score 0 by convention)
-    uint32_t pv_o0 = 0, pv_o1 = 0;
+    uint32_t cur = 0;
+    // previous position (starts as the clean position a-1: only N0, score 0 by convention)
+    uint32_t pv_o0 = 0, pv_n = 0; // exception nodes of the previous position
     uint16_t pv_b0 = 0, pv_d0 = 0;
     int64_t pv_s0 = 0;
     bool pv_valid = a > 0;
     if (pv_valid) n0_key(g, a - 1, pv_b0, pv_d0);
-    uint32_t p = a;
-    for (;; ++p) {
-        const bool in_run = p < L && g.node_off[p + 1] > g.node_off[p];
-        if (p >= L) break;
+    auto rec_of = [&](uint32_t which, uint32_t o0, uint32_t k) -> uint2 {
+        return k < DP_CACHE ? make_uint2(s_key[which][k][t], s_cnt[which][k][t]) : nrec[o0 + k];
+    };
+    auto score_of = [&](uint32_t which, uint32_t o0, uint32_t k) -> int64_t {
+        return k < DP_CACHE ? (int64_t)(((uint64_t)s_shi[which][k][t] << 32) | s_slo[which][k][t]) : nscore[o0 + k];
+    };
+    for (uint32_t p = a; p < L; ++p) {
+        // round 1
         const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
+        const int64_t cov = g.cov[p];
         uint16_t b0, d0;
         n0_key(g, p, b0, d0);
-        const int64_t cov = g.cov[p];
+        const bool in_run = o1 > o0;
+        const uint32_t n = o1 - o0;
+        // round 2: node records -> LDS
         uint32_t e0 = 0;
-        for (uint32_t i = o0; i < o1; ++i)
-            if (node_delta3(g.nd.bases[i], g.nd.delta[i]) == 0) e0 += g.nd.count[i];
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint2 rc = nrec[o0 + k];
+            if (k < DP_CACHE) {
+                s_key[cur][k][t] = rc.x;
+                s_cnt[cur][k][t] = rc.y;
+            }
+            if (node_delta3((uint16_t)rc.x, (uint16_t)(rc.x >> 16)) == 0) e0 += rc.y;
+        }
         const int64_t c0 = cov - (int64_t)e0;
         int64_t s0_cur = 0;
-        const uint32_t nn = 1 + (o1 - o0);
-        for (uint32_t idx = 0; idx < nn; ++idx) {
-            const uint16_t kb = idx ? g.nd.bases[o0 + idx - 1] : b0;
-            const uint16_t kd = idx ? g.nd.delta[o0 + idx - 1] : d0;
-            const int64_t cnt = idx ? (int64_t)g.nd.count[o0 + idx - 1] : c0;
+        for (uint32_t idx = 0; idx <= n; ++idx) {
+            uint16_t kb = b0, kd = d0;
+            int64_t cnt = c0;
+            if (idx) {
+                const uint2 rc = rec_of(cur, o0, idx - 1);
+                kb = (uint16_t)rc.x, kd = (uint16_t)(rc.x >> 16), cnt = rc.y;
+            }
             AlignBase k1, k2, k3;
             node_decode(kb, kd, p, k1, k2, k3);
             int64_t score;
@@ -642,34 +676,42 @@ __global__ void k_dp_runs(const uint32_t *__restrict__ run_start, const uint32_t
             } else {
                 score = SCORE_NEG;
                 const uint32_t q = k2.t_pos;
-                uint32_t qo0, qn;
-                uint16_t qb0, qd0;
-                int64_t qs0;
+                uint32_t which = 0, qo0 = 0, qn = 0;
+                uint16_t qb0 = 0, qd0 = 0;
+                int64_t qs0 = 0;
                 bool ok = false;
                 if (q == p) { // same position: only nodes before K can match (their b3.delta = K.b2.delta)
-                    qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
+                    which = cur, qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
                 } else if (q + 1 == p && pv_valid) {
-                    qo0 = pv_o0, qn = 1 + (pv_o1 - pv_o0), qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
+                    which = cur ^ 1, qo0 = pv_o0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
                 }
                 if (ok) {
                     for (uint32_t pi = 0; pi < qn; ++pi) {
-                        const uint16_t vb = pi ? g.nd.bases[qo0 + pi - 1] : qb0;
-                        const uint16_t vd = pi ? g.nd.delta[qo0 + pi - 1] : qd0;
+                        uint16_t vb = qb0, vd = qd0;
+                        if (pi) {
+                            const uint2 rc = rec_of(which, qo0, pi - 1);
+                            vb = (uint16_t)rc.x, vd = (uint16_t)(rc.x >> 16);
+                        }
                         AlignBase pb1;
                         if (!pred_match(vb, vd, q, k1, k2, pb1)) continue;
                         if (q >= 3 && pb1.is_head()) continue; // main.rs:1666-1668
-                        const int64_t ps = pi ? nscore[qo0 + pi - 1] : qs0;
-                        const int64_t s = ps + 10 * cnt - 4 * cov;
-                        if (s > score || (s == score && pb1.q != 4)) { // main.rs:1670
-                            score = s;
+                        const int64_t ps = pi ? score_of(which, qo0, pi - 1) : qs0;
+                        const int64_t sc = ps + 10 * cnt - 4 * cov;
+                        if (sc > score || (sc == score && pb1.q != 4)) { // main.rs:1670
+                            score = sc;
                             besti = pi;
                         }
                     }
                 }
             }
             if (idx) {
-                nscore[o0 + idx - 1] = score;
-                nbesti[o0 + idx - 1] = besti;
+                const uint32_t k = idx - 1;
+                if (k < DP_CACHE) {
+                    s_slo[cur][k][t] = (uint32_t)(uint64_t)score;
+                    s_shi[cur][k][t] = (uint32_t)((uint64_t)score >> 32);
+                }
+                nscore[o0 + k] = score;
+                nbesti[o0 + k] = besti;
             } else {
                 s0_cur = score;
                 n0_besti[p] = besti;
@@ -677,25 +719,31 @@ __global__ void k_dp_runs(const uint32_t *__restrict__ run_start, const uint32_t
         }
         if (!in_run) { // p == b+1: the clean position closing the run; its N0 is scored above
             run_end[r] = p - 1;
-            atomicAdd(total_gain, (unsigned long long)s0_cur);
+            run_gain[r] = s0_cur; // summed by k_clean_gain (one same-address atomic per run would serialise at L2)
             return;
         }
-        pv_o0 = o0, pv_o1 = o1, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
+        pv_o0 = o0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
+        cur ^= 1;
     }
     // the run reaches the contig end
     run_end[r] = L - 1;
+    run_gain[r] = 0;
     *last_n0_score = pv_s0;
 }
 
 // sum of the gains of clean positions whose predecessor is clean (or p == 0): 10*c0 - 4*cov = 6*cov
 __global__ void k_clean_gain(const uint32_t *__restrict__ node_off, const int32_t *__restrict__ cov, uint32_t L,
+                             const int64_t *__restrict__ run_gain, const uint32_t *__restrict__ n_runs,
                              unsigned long long *__restrict__ total_gain) {
     long long v = 0;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < L; p += gridDim.x * blockDim.x) {
+    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t p = t0; p < L; p += stride) {
         const bool d = node_off[p + 1] > node_off[p];
         const bool dp = p > 0 && node_off[p] > node_off[p - 1];
         if (!d && !dp) v += 6LL * cov[p];
     }
+    const uint32_t nr = *n_runs;
+    for (uint32_t r = t0; r < nr; r += stride) v += run_gain[r];
     __shared__ long long sm[4];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -1315,8 +1363,8 @@ void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *g
                           const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes) {
     hipLaunchKernelGGL(k_scatter_nodes, grid1(T), dim3(256), 0, s, keys, gcount, gmin, idx, T, nd, node_cnt, n_nodes);
 }
-void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd) {
-    hipLaunchKernelGGL(k_order_nodes, grid1(L), dim3(256), 0, s, node_off, L, nd);
+void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd, uint2 *nrec) {
+    hipLaunchKernelGGL(k_order_nodes, grid1(L), dim3(256), 0, s, node_off, L, nd, nrec);
 }
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd) {
     hipLaunchKernelGGL(k_cov_delta, grid1(R), dim3(256), 0, s, reads, R, alive, covd);
@@ -1331,13 +1379,14 @@ void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L}; }
 
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
-               uint32_t max_runs, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,
-               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx) {
+               uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,
+               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain) {
     Graph g = mk_graph(gp);
     if (max_runs)
-        hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, 64), dim3(64), 0, s, run_start, n_runs, g, nscore, nbesti,
-                           n0_besti, run_end, last_n0_score, total_gain);
-    hipLaunchKernelGGL(k_clean_gain, dim3(min(1024u, (gp.L + 255) / 256)), dim3(256), 0, s, gp.node_off, gp.cov, gp.L, total_gain);
+        hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, DP_BLOCK), dim3(DP_BLOCK), 0, s, run_start, n_runs, g, nrec, nscore,
+                           nbesti, n0_besti, run_end, last_n0_score, run_gain);
+    hipLaunchKernelGGL(k_clean_gain, dim3(min(1024u, (gp.L + 255) / 256)), dim3(256), 0, s, gp.node_off, gp.cov, gp.L,
+                       run_gain, n_runs, total_gain);
     hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
 }
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,

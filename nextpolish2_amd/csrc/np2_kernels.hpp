@@ -56,13 +56,13 @@ void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *val
 void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag);
 void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *gcount, const uint32_t *gmin,
                           const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes);
-void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd);
+void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd, uint2 *nrec);
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd);
 void launch_mark_runs(hipStream_t s, const uint32_t *node_off, uint32_t L, uint32_t *flag);
 void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx, uint32_t n, uint32_t *out, uint32_t *n_out);
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
-               int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
-               unsigned long long *total_gain, uint32_t *best_idx);
+               const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
+               unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain);
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin);
