@@ -147,7 +147,7 @@ struct np2_contig {
     DevBuf<uint32_t> ckpt;
     // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
     uint32_t n_chunks = 0;
-    DevBuf<uint32_t> chunk_read, chunk_base;
+    DevBuf<ChunkDesc> descs;
 };
 
 struct np2_ctx {

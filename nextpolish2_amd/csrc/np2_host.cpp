@@ -29,7 +29,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // region state (device-resident; host keeps only counters)
 // ------------------------------------------------------------------------------------------
-static const uint8_t LB_TEMP = 0x01, LB_SUCC = 0x80, LB_HETE = 0x40, LB_RECH = 0x20; // main.rs:655-658
+static const uint8_t LB_SUCC = 0x80, LB_RECH = 0x20; // main.rs:655-658
 
 struct Cns {
     std::vector<uint32_t> pos;
@@ -371,80 +371,80 @@ struct PassOut {
 
 void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     hipStream_t s = cx->stream;
-    const uint32_t L = c->L, R = c->R;
-    uint64_t cap_total = std::max<uint64_t>(c->n_cols / 24 + (uint64_t)R * 8 + 65536, 1u << 20);
+    const uint32_t L = c->L, R = c->R, NCH = c->n_chunks;
+    const uint64_t slots = (uint64_t)NCH * SLOT_CAP;
+    uint64_t ovf_total = std::max<uint64_t>(c->n_cols / 256 + 65536, 1u << 18); // overflow area (chunks with > SLOT_CAP)
+    cx->chunk_n.ensure(NCH + 2);
+    cx->chunk_pre.ensure(NCH + 2);
+    cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)NCH + 2, (size_t)L + 2)));
+    {
+        EventTimer t(cx, "chunk_prefix");
+        launch_chunk_count(s, c->descs.p, c->nib.p, NCH, cx->chunk_n.p);
+        zero32(cx, cx->chunk_n.p + NCH, 1);
+        exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)NCH + 1);
+        launch_fill_carry(s, c->descs.p, cx->chunk_pre.p, NCH);
+    }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        const double tA = now_ms();
-        uint32_t shard_cap = (uint32_t)((cap_total + NSHARD - 1) / NSHARD);
-        uint64_t cap = (uint64_t)shard_cap * NSHARD;
-        cx->keys_raw.ensure(cap);
-        cx->vals_raw.ensure(cap);
+        const uint32_t shard_cap = (uint32_t)((ovf_total + NSHARD - 1) / NSHARD);
+        const uint64_t cap = slots + (uint64_t)shard_cap * NSHARD;
+        cx->keys_raw.ensure(cap + 1);
+        cx->vals_raw.ensure(cap + 1);
         cx->shard_cnt.ensure(NSHARD * SHARD_STRIDE);
         zero32(cx, cx->shard_cnt.p, NSHARD * SHARD_STRIDE);
         zero32(cx, cx->scal.p, S_COUNT);
-        cx->chunk_n.ensure(c->n_chunks + 2);
-        cx->chunk_pre.ensure(c->n_chunks + 2);
-        cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)c->n_chunks + 2, (size_t)L + 2)));
-        {
-            EventTimer t(cx, "chunk_prefix");
-            launch_chunk_count(s, c->reads.p, c->nib.p, c->chunk_read.p, c->chunk_base.p, c->n_chunks, cx->chunk_n.p);
-            zero32(cx, cx->chunk_n.p + c->n_chunks, 1);
-            exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)c->n_chunks + 1);
-        }
         {
             EventTimer t(cx, "diff_reads");
-            launch_diff_reads(s, c->reads.p, R, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
-                              c->chunk_read.p, c->chunk_base.p, cx->chunk_pre.p, c->n_chunks, cx->keys_raw.p,
-                              cx->vals_raw.p, cx->shard_cnt.p, shard_cap, c->ck_off.p, c->ckpt.p, cx->scal.p + S_ERR);
+            // chunk_n is reused as the per-chunk tuple count
+            launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
+                              cx->keys_raw.p, cx->vals_raw.p, cx->chunk_n.p, slots, cx->shard_cnt.p, shard_cap, c->ckpt.p,
+                              cx->scal.p + S_ERR);
         }
-        const double tB = now_ms();
+        uint32_t n_slot = 0;
+        {
+            EventTimer t(cx, "sort_exceptions");
+            zero32(cx, cx->chunk_n.p + NCH, 1);
+            exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)NCH + 1);
+        }
         std::vector<uint32_t> cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
         std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        n_slot = d2h(cx, cx->chunk_pre.p + NCH, 1)[0];
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
-        const double tC = now_ms();
         uint32_t mx = 0;
-        uint64_t total = 0;
         std::vector<uint64_t> off(NSHARD + 1, 0);
+        off[0] = n_slot;
         for (int i = 0; i < NSHARD; ++i) {
             mx = std::max(mx, cnt[(size_t)i * SHARD_STRIDE]);
             off[i + 1] = off[i] + cnt[(size_t)i * SHARD_STRIDE];
         }
-        total = off[NSHARD];
-        if (mx > shard_cap) { // a shard overflowed: grow and redo the dense pass
-            cap_total = (uint64_t)mx * NSHARD * 5 / 4 + 65536;
+        const uint64_t total = off[NSHARD];
+        if (mx > shard_cap) { // an overflow shard overflowed: grow and redo the dense pass
+            ovf_total = (uint64_t)mx * NSHARD * 5 / 4 + 65536;
             continue;
         }
         if (total >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
         T = (uint32_t)total;
         cx->keys.ensure(T + 1);
         cx->vals.ensure(T + 1);
-        cx->keys_raw.ensure(std::max<uint64_t>(cap, T + 1));
         cx->shard_off.ensure(NSHARD + 1);
         h2d_staged(cx, cx->shard_off.p, off.data(), (NSHARD + 1) * 8);
-        const double tD = now_ms();
         cx->tmp.ensure(prim_temp_bytes(std::max<size_t>({(size_t)T + 1, (size_t)L + 2, (size_t)R + 1})));
-        const double tE = now_ms();
         {
             EventTimer t(cx, "sort_exceptions");
-            // compact into keys/vals, sort back into keys_raw/vals_raw, then swap roles
-            launch_compact_shards(s, cx->keys_raw.p, cx->vals_raw.p, shard_cap, cx->shard_cnt.p, cx->shard_off.p,
-                                  cx->keys.p, cx->vals.p);
+            // gather slots + overflow shards into keys/vals, sort back into keys_raw/vals_raw
+            launch_compact_slots(s, cx->keys_raw.p, cx->vals_raw.p, cx->chunk_n.p, cx->chunk_pre.p, NCH, cx->keys.p,
+                                 cx->vals.p);
+            if (total > n_slot)
+                launch_compact_shards(s, cx->keys_raw.p, cx->vals_raw.p, slots, shard_cap, cx->shard_cnt.p,
+                                      cx->shard_off.p, cx->keys.p, cx->vals.p);
+            launch_make_nodes(s, c->reads.p, c->nib.p, cx->keys.p, cx->vals.p, T); // raw records -> node keys
             unsigned pos_bits = 1;
             while ((1ull << pos_bits) < (uint64_t)L + 1) ++pos_bits;
             int rc = prim_sort_pairs_u64_u32(s, cx->tmp.p, cx->tmp.cap, cx->keys.p, cx->keys_raw.p, cx->vals.p,
                                              cx->vals_raw.p, T, 32 + pos_bits);
             if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
         }
-        const double tF = now_ms();
-        HIPCHK(hipStreamSynchronize(s)); // shard_off host vector goes out of scope
-        const double tG = now_ms();
-        cx->timing.host.push_back({"w_diff_launch", (float)(tB - tA)});
-        cx->timing.host.push_back({"w_diff_d2h", (float)(tC - tB)});
-        cx->timing.host.push_back({"w_diff_host", (float)(tD - tC)});
-        cx->timing.host.push_back({"w_diff_tmpbytes", (float)(tE - tD)});
-        cx->timing.host.push_back({"w_diff_sortlaunch", (float)(tF - tE)});
-        cx->timing.host.push_back({"w_diff_sync", (float)(tG - tF)});
+        HIPCHK(hipStreamSynchronize(s));
         return;
     }
     throw Np2Error(NP2_E_NOMEM, "exception buffer kept overflowing");
@@ -866,7 +866,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         (reads[0].flags & NP2_READ_DROPPED))
         throw Np2Error(NP2_E_ARG, "reads[0] must be the contig aligned to itself (main.rs:1732-1739)");
     std::vector<uint64_t> ck(n_reads + 1, 0);
-    std::vector<uint32_t> chunk_base(n_reads + 1, 0), chunk_read;
+    std::vector<ChunkDesc> descs;
     uint64_t cols = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
         const np2_read_t &rd = reads[r];
@@ -884,8 +884,21 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
             cols += rd.n_cols;
         }
         ck[r + 1] = ck[r] + nck;
-        chunk_base[r + 1] = chunk_base[r] + nch;
-        for (uint32_t k = 0; k < nch; ++k) chunk_read.push_back(r);
+        const uint32_t first_chunk = (uint32_t)descs.size();
+        for (uint32_t k = 0; k < nch; ++k) {
+            ChunkDesc d;
+            memset(&d, 0, sizeof d);
+            d.nib_off = rd.nib_off;
+            d.ckbase = ck[r];
+            d.read = r;
+            d.ts = rd.aln_t_s;
+            d.c0 = k * 2048;
+            d.ncols = rd.n_cols;
+            d.first_chunk = first_chunk;
+            d.aln_t_e = rd.aln_t_e;
+            d.nck = nck;
+            descs.push_back(d);
+        }
     }
     hipStream_t s = cx->stream;
     c->L = L;
@@ -893,19 +906,17 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     c->nib_bytes = nib_bytes;
     c->n_cols = cols;
     c->n_ckpt = ck[n_reads];
-    c->n_chunks = chunk_base[n_reads];
+    c->n_chunks = (uint32_t)descs.size();
     c->reads.ensure(n_reads);
     const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds
-    c->refnib.ensure(((size_t)refbytes + 7) & ~(size_t)7);
+    c->refnib.ensure(((size_t)refbytes + 15) & ~(size_t)15);
     c->ck_off.ensure(n_reads + 1);
     c->ckpt.ensure(c->n_ckpt + 1);
-    c->chunk_base.ensure(n_reads + 1);
-    c->chunk_read.ensure(c->n_chunks + 1);
+    c->descs.ensure(c->n_chunks + 1);
     HIPCHK(hipMemcpyAsync(c->reads.p, reads, (size_t)n_reads * sizeof(np2_read_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->ck_off.p, ck.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->chunk_base.p, chunk_base.data(), (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, s));
     if (c->n_chunks)
-        HIPCHK(hipMemcpyAsync(c->chunk_read.p, chunk_read.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)c->n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
     cx->scal.ensure(64);
     zero32(cx, cx->scal.p, 24);
     launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p);

@@ -79,147 +79,12 @@ __global__ void k_encode_ref(const uint8_t *__restrict__ read0, uint32_t L, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: dense pass — compare every read column with the contig, emit exception nodes and
-//     per-read checkpoints.  One wavefront per read; each lane owns 32 columns (16 B) per
-//     iteration, i.e. a coalesced 1 KiB per wave-instruction.
+// K1: dense pass — compare every read column with the contig, emit exception records and
+//     per-read checkpoints.  One wavefront per 2048-column chunk; each lane owns 32 columns
+//     (16 B), i.e. a coalesced 1 KiB per wave-instruction.
 // ------------------------------------------------------------------------------------------
-struct EmitCtx {
-    const uint8_t *base; // nibble stream of this read
-    uint32_t ts;         // aln_t_s
-    uint32_t read;
-};
-
-__device__ __forceinline__ AlignBase make_col(const EmitCtx &cx, int64_t gc, uint32_t n_upto) {
-    // AlignBase of global column gc (gc == -2 / -1: the two head sentinels, main.rs:579-580);
-    // n_upto = number of non-insertion columns in [0..gc]
-    if (gc == -2) return ab_head(cx.ts - 1, 0);
-    if (gc == -1) return ab_head(cx.ts - 1, 1);
-    uint8_t nb = nib_at(cx.base, (uint32_t)gc);
-    AlignBase a;
-    a.q = nb & 7;
-    a.t_pos = cx.ts + n_upto - 1;
-    a.delta = 0;
-    if (gc > 0 && (nb & 8)) {
-        uint16_t d = 1;
-        int64_t c = gc - 1;
-        while (c > 0 && (nib_at(cx.base, (uint32_t)c) & 8)) {
-            d = (uint16_t)(d + 1);
-            --c;
-        }
-        a.delta = d;
-    }
-    return a;
-}
-
-__device__ void emit_lane(const EmitCtx &cx, uint32_t lc0, uint32_t Nb, uint32_t im, uint32_t E,
-                          uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint64_t out_base,
-                          uint64_t out_limit) {
-    const uint32_t first = __builtin_ctz(E), last = 31 - __builtin_clz(E);
-    const uint32_t j0 = first >= 2 ? first - 2 : 0;
-    // N(lc0 + j0 - 1): non-insertion columns before lane column j0
-    uint32_t n = Nb + __builtin_popcount(~im & ((1u << j0) - 1u));
-    const int64_t g = (int64_t)lc0 + j0;
-    AlignBase b2 = make_col(cx, g - 1, n);
-    bool prev_nonins = (g - 1 >= 0) && ((g - 1 == 0) || !(nib_at(cx.base, (uint32_t)(g - 1)) & 8));
-    AlignBase b1 = make_col(cx, g - 2, n - (prev_nonins ? 1u : 0u));
-    uint64_t o = out_base;
-    for (uint32_t j = j0; j <= last; ++j) {
-        const uint32_t gc = lc0 + j;
-        const uint8_t nb = nib_at(cx.base, gc);
-        AlignBase b3;
-        b3.q = nb & 7;
-        if (gc == 0) { // get_align_tag, p == 0 (main.rs:332-335)
-            b3.t_pos = cx.ts;
-            b3.delta = 0;
-        } else if (nb & 8) {
-            b3.t_pos = b2.t_pos;
-            b3.delta = (uint16_t)(b2.delta + 1);
-        } else {
-            b3.t_pos = b2.t_pos + 1;
-            b3.delta = 0;
-        }
-        if ((E >> j) & 1u) {
-            if (o < out_limit) {
-                out_keys[o] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
-                out_vals[o] = cx.read;
-            }
-            ++o;
-        }
-        b1 = b2;
-        b2 = b3;
-    }
-}
-
-// register-resident emission: the lane's 32 columns live in (lo, hi, im); the two columns before
-// the lane come from the previous lane (or the previous chunk) as (code, insertion flag, delta)
-struct PrevCols {
-    uint8_t q31, q30;   // codes of the previous lane's columns 31 / 30
-    uint8_t i31, i30;   // insertion flags
-    uint16_t d31, d30;  // their deltas
-};
 __device__ __forceinline__ uint8_t reg_nib(uint64_t lo, uint64_t hi, uint32_t j) {
     return (uint8_t)(((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16)))) & 7);
-}
-__device__ void emit_lane_regs(uint64_t lo, uint64_t hi, uint32_t im, uint32_t E, uint32_t ts, uint32_t lc0,
-                               uint32_t Nb, const PrevCols &pv, uint32_t read, uint64_t *__restrict__ out_keys,
-                               uint32_t *__restrict__ out_vals, uint64_t out_base, uint64_t out_limit) {
-    const uint32_t first = __builtin_ctz(E), last = 31 - __builtin_clz(E);
-    // AlignBase of lane column j in [-2, 31]
-    auto col = [&](int j) -> AlignBase {
-        const int64_t gc = (int64_t)lc0 + j;
-        if (gc == -2) return ab_head(ts - 1, 0);
-        if (gc == -1) return ab_head(ts - 1, 1);
-        AlignBase a;
-        if (j == -1) {
-            a.q = pv.q31;
-            a.t_pos = ts + Nb - 1;
-            a.delta = pv.i31 ? pv.d31 : 0;
-        } else if (j == -2) {
-            a.q = pv.q30;
-            a.t_pos = ts + Nb - 1 - (pv.i31 ? 0u : 1u);
-            a.delta = pv.i30 ? pv.d30 : 0;
-        } else {
-            a.q = reg_nib(lo, hi, (uint32_t)j);
-            const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
-            a.t_pos = ts + Nb + __builtin_popcount(~im & low) - 1;
-            a.delta = 0;
-            if ((im >> j) & 1u) {
-                // consecutive insertion columns ending at j (within the lane)
-                const uint32_t inv = ~(im << (31 - j));
-                const uint32_t run = inv ? (uint32_t)__builtin_clz(inv) : 32u;
-                uint32_t d = run > (uint32_t)j + 1 ? (uint32_t)j + 1 : run;
-                if (d == (uint32_t)j + 1 && pv.i31) d += pv.d31; // the run continues into the previous lane
-                a.delta = (uint16_t)d;
-            }
-        }
-        return a;
-    };
-    AlignBase b1 = col((int)first - 2), b2 = col((int)first - 1);
-    uint64_t o = out_base;
-    for (uint32_t j = first; j <= last; ++j) {
-        const uint32_t gc = lc0 + j;
-        AlignBase b3;
-        b3.q = reg_nib(lo, hi, j);
-        if (gc == 0) {
-            b3.t_pos = ts;
-            b3.delta = 0;
-        } else if ((im >> j) & 1u) {
-            b3.t_pos = b2.t_pos;
-            b3.delta = (uint16_t)(b2.delta + 1);
-        } else {
-            b3.t_pos = b2.t_pos + 1;
-            b3.delta = 0;
-        }
-        if ((E >> j) & 1u) {
-            if (o < out_limit) {
-                out_keys[o] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
-                out_vals[o] = read;
-            }
-            ++o;
-        }
-        b1 = b2;
-        b2 = b3;
-    }
 }
 
 // decode the lane's 16 bytes into codes (lo, hi), the compact insertion mask and the valid count
@@ -255,64 +120,54 @@ __device__ __forceinline__ LaneCols load_lane(const uint8_t *__restrict__ base, 
 }
 
 // pre-pass: non-insertion columns per 2048-column chunk (one wavefront per chunk)
-__global__ __launch_bounds__(256) void k_chunk_count(const np2_read_t *__restrict__ reads,
-                                                     const uint8_t *__restrict__ nib,
-                                                     const uint32_t *__restrict__ chunk_read,
-                                                     const uint32_t *__restrict__ chunk_base, uint32_t n_chunks,
+__global__ __launch_bounds__(256) void k_chunk_count(const ChunkDesc *__restrict__ descs,
+                                                     const uint8_t *__restrict__ nib, uint32_t n_chunks,
                                                      uint32_t *__restrict__ chunk_n) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (ch >= n_chunks) return;
-    const uint32_t r = chunk_read[ch];
-    const np2_read_t rd = reads[r];
-    const uint32_t lc0 = (ch - chunk_base[r]) * 2048 + lane * 32;
-    const LaneCols c = load_lane(nib + rd.nib_off, lc0, rd.n_cols);
+    const ChunkDesc d = descs[ch];
+    const LaneCols c = load_lane(nib + d.nib_off, d.c0 + lane * 32, d.ncols);
     uint32_t v = c.nv - c.n_ins;
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) chunk_n[ch] = v;
 }
+// fold the scan into the descriptors: non-insertion columns of the read before this chunk
+__global__ void k_fill_carry(ChunkDesc *__restrict__ descs, const uint32_t *__restrict__ chunk_pre, uint32_t n_chunks) {
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < n_chunks) descs[ch].carryN = chunk_pre[ch] - chunk_pre[descs[ch].first_chunk];
+}
 
+// Dense pass: one wavefront per 2048-column chunk.  The kernel is VALU-issue bound (not latency bound), so it does
+// the minimum per column: classify columns as exceptions and emit raw (read, column, t_pos) records; the 3-column
+// node keys are built afterwards by k_make_nodes, one thread per exception.  Exception records go to the chunk's
+// private output slot (SLOT_CAP records); only a chunk with more exceptions reserves space in the sharded overflow area.
 __global__ __launch_bounds__(256) void k_diff_reads(
-    const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ nib,
+    const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
     const uint64_t *__restrict__ refw, const uint8_t *__restrict__ refnib, uint32_t L,
-    const uint32_t *__restrict__ chunk_read, const uint32_t *__restrict__ chunk_base,
-    const uint32_t *__restrict__ chunk_pre, uint32_t n_chunks, uint64_t *__restrict__ out_keys,
-    uint32_t *__restrict__ out_vals, uint32_t *__restrict__ shard_cnt, uint32_t shard_cap,
-    const uint64_t *__restrict__ ck_off, uint32_t *__restrict__ ckpt, uint32_t *__restrict__ err) {
+    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ chunk_cnt,
+    uint64_t ovf_base, uint32_t *__restrict__ shard_cnt, uint32_t shard_cap, uint32_t *__restrict__ ckpt,
+    uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (ch >= n_chunks) return;
-    const uint32_t r = chunk_read[ch];
-    const np2_read_t rd = reads[r];
-    const uint8_t *base = nib + rd.nib_off;
-    const uint32_t ncols = rd.n_cols, ts = rd.aln_t_s;
-    const uint32_t cb = chunk_base[r];
-    const uint32_t c0 = (ch - cb) * 2048;
-    const uint32_t carryN = chunk_pre[ch] - chunk_pre[cb]; // non-insertion columns before this chunk
-    const uint32_t shard = ch & (NSHARD - 1);
-    const uint64_t ckbase = ck_off[r];
+    const ChunkDesc d = descs[ch];
+    const uint8_t *base = nib + d.nib_off; // start of the READ's stream
+    const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0, carryN = d.carryN;
     const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
-    const uint32_t nck = (uint32_t)(ck_off[r + 1] - ckbase);
     const uint32_t lc0 = c0 + lane * 32;
 
-    // lane 0 of a non-first chunk: the two columns before the chunk (issued early, off the critical path)
-    uint32_t pbad = 0; // bad bits of previous columns: bit 31 = column c0-1, bit 30 = column c0-2
-    PrevCols pv{0, 0, 0, 0, 0, 0};
-    bool prev_slow = false;
+    const LaneCols c = load_lane(base, lc0, ncols);
+    uint32_t pbad = 0; // bad bits of the two columns before the chunk: bit 31 = column c0-1, bit 30 = column c0-2
     if (lane == 0 && c0 > 0) {
         const uint8_t byte = base[(c0 - 2) >> 1];
-        const uint8_t n2 = byte >> 4, n1 = byte & 15; // columns c0-2, c0-1
+        const uint8_t n2 = byte >> 4, n1 = byte & 15;
         const uint32_t t1 = ts + carryN - 1;
         const uint32_t t2 = t1 - ((n1 & 8) ? 0u : 1u);
         const bool b1 = (n1 & 8) || t1 >= L || (n1 & 7) != ref_code(refnib, t1);
         const bool b2 = (n2 & 8) || t2 >= L || (n2 & 7) != ref_code(refnib, t2);
         pbad = (b1 ? 0x80000000u : 0u) | (b2 ? 0x40000000u : 0u);
-        pv.q31 = n1 & 7, pv.q30 = n2 & 7;
-        pv.i31 = (n1 & 8) ? 1 : 0, pv.i30 = (n2 & 8) ? 1 : 0;
-        prev_slow = pv.i31 || pv.i30; // their deltas need a walk back through memory
     }
-
-    const LaneCols c = load_lane(base, lc0, ncols);
     const uint64_t lo = c.lo, hi = c.hi;
     const uint32_t nv = c.nv, n_ins = c.n_ins;
     const uint32_t nonins = nv - n_ins;
@@ -371,67 +226,116 @@ __global__ __launch_bounds__(256) void k_diff_reads(
                     }
                 }
                 const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                if (idx < nck) ckpt[ckbase + idx] = lc0 + j;
+                if (idx < d.nck) ckpt[d.ckbase + idx] = lc0 + j;
             }
         }
     }
-    // previous-lane context (wave-uniform shuffles)
     uint32_t pb = __shfl_up(bad, 1);
-    {
-        // deltas of this lane's columns 31 / 30 (insertion runs ending there), for the next lane
-        const uint32_t r31 = ((im >> 31) & 1u) ? (~im ? (uint32_t)__builtin_clz(~im) : 32u) : 0u;
-        const uint32_t r30 = ((im >> 30) & 1u) ? (uint32_t)__builtin_clz(~(im << 1)) : 0u;
-        const uint32_t packed = (uint32_t)reg_nib(lo, hi, 31) | ((uint32_t)reg_nib(lo, hi, 30) << 4) |
-                                (((im >> 31) & 1u) << 8) | (((im >> 30) & 1u) << 9) | (min(r31, 63u) << 10) |
-                                (min(r30, 63u) << 16);
-        const uint32_t pp = __shfl_up(packed, 1);
-        if (lane != 0) {
-            pv.q31 = pp & 7, pv.q30 = (pp >> 4) & 7;
-            pv.i31 = (pp >> 8) & 1, pv.i30 = (pp >> 9) & 1;
-            pv.d31 = (pp >> 10) & 63, pv.d30 = (pp >> 16) & 63;
-        } else {
-            pb = pbad;
-        }
-    }
+    if (lane == 0) pb = pbad;
     uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
     if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
     E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-    // an insertion run that reaches a lane's first column from column 30/31 needs the memory walk
-    const bool longrun = (im == 0xFFFFFFFFu) || ((im >> 30) == 3u && (im | 0xC0000000u) == 0xFFFFFFFFu) ||
-                         ((im & 0x7FFFFFFFu) == 0x7FFFFFFFu);
-    const bool any_long = __ballot(longrun) != 0;
+    uint32_t n_tuples = 0;
     if (__ballot(E != 0)) {
         const uint32_t cnt = __builtin_popcount(E);
         const uint32_t inc2 = wave_incl_scan(cnt);
         const uint32_t tot = __shfl(inc2, 63);
-        uint32_t basepos = 0;
-        if (lane == 0) basepos = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
-        basepos = __shfl(basepos, 0);
-        if (E) {
-            const uint64_t sb = (uint64_t)shard * shard_cap;
-            if (any_long || prev_slow) {
-                EmitCtx cx{base, ts, r};
-                emit_lane(cx, lc0, Nb, im, E, out_keys, out_vals, sb + basepos + (inc2 - cnt), sb + shard_cap);
-            } else {
-                emit_lane_regs(lo, hi, im, E, ts, lc0, Nb, pv, r, out_keys, out_vals, sb + basepos + (inc2 - cnt),
-                               sb + shard_cap);
+        uint64_t obase, olimit;
+        if (tot <= SLOT_CAP) { // private slot: no reservation round trip
+            obase = (uint64_t)ch * SLOT_CAP;
+            olimit = obase + SLOT_CAP;
+            n_tuples = tot;
+        } else {
+            const uint32_t shard = ch & (NSHARD - 1);
+            uint32_t bp = 0;
+            if (lane == 0) bp = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
+            bp = __shfl(bp, 0);
+            obase = ovf_base + (uint64_t)shard * shard_cap + bp;
+            olimit = ovf_base + (uint64_t)(shard + 1) * shard_cap;
+        }
+        uint64_t o = obase + (inc2 - cnt);
+        uint32_t e = E;
+        while (e) { // raw record: t_pos << 32 | column, read
+            const uint32_t j = __builtin_ctz(e);
+            e &= e - 1;
+            const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
+            const uint32_t t = ts + Nb + __builtin_popcount(~im & low) - 1;
+            if (o < olimit) {
+                out_keys[o] = ((uint64_t)t << 32) | (lc0 + j);
+                out_vals[o] = d.read;
             }
+            ++o;
         }
     }
-    if (lane == 0 && c0 + 2048 >= ncols) {
-        // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
-        if (ncols == 0 || ts + carryN + total - 1 != rd.aln_t_e || rd.aln_t_e >= L) atomicOr(err, 2u);
-        if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
+    if (lane == 0) {
+        chunk_cnt[ch] = n_tuples;
+        if (c0 + 2048 >= ncols) {
+            // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
+            if (ncols == 0 || ts + carryN + total - 1 != d.aln_t_e || d.aln_t_e >= L) atomicOr(err, 2u);
+            if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
+        }
     }
 }
 
+// one thread per exception record: (read, column, t_pos) -> node key pos << 32 | bases << 16 | delta1
+// (Kmer::new over the columns c-2, c-1, c; head sentinels before a read's first column, main.rs:579-585)
+__global__ void k_make_nodes(const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib,
+                             uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t T) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const uint64_t rec = keys[i];
+    const uint32_t col = (uint32_t)rec, t3 = (uint32_t)(rec >> 32), r = vals[i];
+    const np2_read_t rd = reads[r];
+    const uint8_t *base = nib + rd.nib_off;
+    const uint32_t ts = rd.aln_t_s;
+    // AlignBase of column c whose t_pos is known; delta = insertion run length ending at c
+    auto mk = [&](int64_t c, uint32_t t) -> AlignBase {
+        if (c == -2) return ab_head(ts - 1, 0);
+        if (c == -1) return ab_head(ts - 1, 1);
+        const uint8_t nb = nib_at(base, (uint32_t)c);
+        AlignBase a;
+        a.q = nb & 7;
+        a.t_pos = t;
+        a.delta = 0;
+        if (c > 0 && (nb & 8)) {
+            uint16_t dl = 1;
+            int64_t x = c - 1;
+            while (x > 0 && (nib_at(base, (uint32_t)x) & 8)) {
+                dl = (uint16_t)(dl + 1);
+                --x;
+            }
+            a.delta = dl;
+        }
+        return a;
+    };
+    auto is_ins = [&](int64_t c) -> bool { return c > 0 && (nib_at(base, (uint32_t)c) & 8); };
+    const int64_t c3 = col;
+    const AlignBase b3 = mk(c3, t3);
+    const uint32_t t2 = is_ins(c3) ? t3 : t3 - 1;
+    const AlignBase b2 = mk(c3 - 1, t2);
+    const uint32_t t1 = is_ins(c3 - 1) ? t2 : t2 - 1;
+    const AlignBase b1 = mk(c3 - 2, t1);
+    keys[i] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
+}
+
+// gather the per-chunk slots into the compact tuple array
+__global__ void k_compact_slots(const uint64_t *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
+                                const uint32_t *__restrict__ chunk_cnt, const uint32_t *__restrict__ chunk_out,
+                                uint32_t n_chunks, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ch = i / SLOT_CAP, k = i % SLOT_CAP;
+    if (ch >= n_chunks || k >= chunk_cnt[ch]) return;
+    out_keys[chunk_out[ch] + k] = in_keys[(uint64_t)ch * SLOT_CAP + k];
+    out_vals[chunk_out[ch] + k] = in_vals[(uint64_t)ch * SLOT_CAP + k];
+}
+
 __global__ void k_compact_shards(const uint64_t *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
-                                 uint32_t shard_cap, const uint32_t *__restrict__ shard_cnt,
+                                 uint64_t ovf_base, uint32_t shard_cap, const uint32_t *__restrict__ shard_cnt,
                                  const uint64_t *__restrict__ shard_off, uint64_t *__restrict__ out_keys,
                                  uint32_t *__restrict__ out_vals) {
     const uint32_t s = blockIdx.x;
     const uint32_t n = shard_cnt[s * SHARD_STRIDE];
-    const uint64_t src = (uint64_t)s * shard_cap, dst = shard_off[s];
+    const uint64_t src = ovf_base + (uint64_t)s * shard_cap, dst = shard_off[s];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         out_keys[dst + i] = in_keys[src + i];
         out_vals[dst + i] = in_vals[src + i];
@@ -1324,25 +1228,35 @@ void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t 
                        uint32_t *err) {
     hipLaunchKernelGGL(k_encode_ref, grid1(nbytes), dim3(256), 0, s, read0, L, refnib, nbytes, err);
 }
-void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, const uint32_t *chunk_read, const uint32_t *chunk_base,
-                       const uint32_t *chunk_pre, uint32_t n_chunks, uint64_t *keys, uint32_t *vals,
-                       uint32_t *shard_cnt, uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err) {
+void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
+                       const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
+                       uint32_t *chunk_cnt, uint64_t ovf_base, uint32_t *shard_cnt, uint32_t shard_cap, uint32_t *ckpt,
+                       uint32_t *err) {
     if (n_chunks)
-        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 3) / 4), dim3(256), 0, s, reads, R, nib, refw, refnib, L,
-                           chunk_read, chunk_base, chunk_pre, n_chunks, keys, vals, shard_cnt, shard_cap, ck_off, ckpt,
-                           err);
+        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 3) / 4), dim3(256), 0, s, descs, n_chunks, nib, refw, refnib, L,
+                           keys, vals, chunk_cnt, ovf_base, shard_cnt, shard_cap, ckpt, err);
 }
-void launch_chunk_count(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *chunk_read,
-                        const uint32_t *chunk_base, uint32_t n_chunks, uint32_t *chunk_n) {
+void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n) {
     if (n_chunks)
-        hipLaunchKernelGGL(k_chunk_count, dim3((n_chunks + 3) / 4), dim3(256), 0, s, reads, nib, chunk_read, chunk_base,
-                           n_chunks, chunk_n);
+        hipLaunchKernelGGL(k_chunk_count, dim3((n_chunks + 3) / 4), dim3(256), 0, s, descs, nib, n_chunks, chunk_n);
 }
-void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
-                           const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
+void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks) {
+    if (n_chunks) hipLaunchKernelGGL(k_fill_carry, grid1(n_chunks), dim3(256), 0, s, descs, chunk_pre, n_chunks);
+}
+void launch_make_nodes(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, uint64_t *keys, const uint32_t *vals,
+                       uint32_t T) {
+    if (T) hipLaunchKernelGGL(k_make_nodes, grid1(T), dim3(256), 0, s, reads, nib, keys, vals, T);
+}
+void launch_compact_slots(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, const uint32_t *chunk_cnt,
+                          const uint32_t *chunk_out, uint32_t n_chunks, uint64_t *out_keys, uint32_t *out_vals) {
+    if (n_chunks)
+        hipLaunchKernelGGL(k_compact_slots, grid1((uint64_t)n_chunks * SLOT_CAP), dim3(256), 0, s, in_keys, in_vals,
+                           chunk_cnt, chunk_out, n_chunks, out_keys, out_vals);
+}
+void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint64_t ovf_base,
+                           uint32_t shard_cap, const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
                            uint32_t *out_vals) {
-    hipLaunchKernelGGL(k_compact_shards, dim3(NSHARD), dim3(256), 0, s, in_keys, in_vals, shard_cap, shard_cnt,
+    hipLaunchKernelGGL(k_compact_shards, dim3(NSHARD), dim3(256), 0, s, in_keys, in_vals, ovf_base, shard_cap, shard_cnt,
                        shard_off, out_keys, out_vals);
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {

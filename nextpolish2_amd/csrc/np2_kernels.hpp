@@ -9,6 +9,18 @@ namespace np2 {
 
 static constexpr int NSHARD = 256;          // exception-tuple output shards (atomic counters 128 B apart)
 static constexpr int SHARD_STRIDE = 32;     // in uint32_t
+static constexpr uint32_t SLOT_CAP = 64;    // exception tuples a chunk can emit into its private slot
+
+struct ChunkDesc { // one 2048-column chunk of a streamed read (built on the host at upload)
+    uint64_t nib_off;     // byte offset of the READ's nibble stream
+    uint64_t ckbase;      // first checkpoint slot of the read
+    uint32_t read, ts;    // read index, aln_t_s
+    uint32_t c0, ncols;   // first column of the chunk, columns of the read
+    uint32_t first_chunk; // index of the read's first chunk
+    uint32_t aln_t_e, nck;
+    uint32_t carryN;      // non-insertion columns of the read before this chunk (filled on the device)
+    uint32_t pad[4];
+};
 
 struct NodeArrays { // exception nodes, grouped by position, ordered like Msa::sort (main.rs:227-229)
     uint32_t *pos;
@@ -41,14 +53,18 @@ struct YakDev {
 };
 
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t *err);
-void launch_diff_reads(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, const uint32_t *chunk_read, const uint32_t *chunk_base,
-                       const uint32_t *chunk_pre, uint32_t n_chunks, uint64_t *keys, uint32_t *vals, uint32_t *shard_cnt,
-                       uint32_t shard_cap, const uint64_t *ck_off, uint32_t *ckpt, uint32_t *err);
-void launch_chunk_count(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *chunk_read,
-                        const uint32_t *chunk_base, uint32_t n_chunks, uint32_t *chunk_n);
-void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint32_t shard_cap,
-                           const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys, uint32_t *out_vals);
+void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, const uint64_t *refw,
+                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *chunk_cnt,
+                       uint64_t ovf_base, uint32_t *shard_cnt, uint32_t shard_cap, uint32_t *ckpt, uint32_t *err);
+void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n);
+void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks);
+void launch_make_nodes(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, uint64_t *keys, const uint32_t *vals,
+                       uint32_t T);
+void launch_compact_slots(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, const uint32_t *chunk_cnt,
+                          const uint32_t *chunk_out, uint32_t n_chunks, uint64_t *out_keys, uint32_t *out_vals);
+void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint64_t ovf_base,
+                           uint32_t shard_cap, const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
+                           uint32_t *out_vals);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,
