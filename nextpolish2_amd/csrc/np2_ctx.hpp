@@ -191,6 +191,7 @@ struct np2_ctx {
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
     DevBuf<uint2> nrec;
+    DevBuf<uint8_t> votebuf;
     DevBuf<int64_t> run_gain;
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
@@ -203,7 +204,7 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_COUNT = 24 };
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_COUNT = 24 };
 
 struct WallTimer {
     np2_ctx *cx;

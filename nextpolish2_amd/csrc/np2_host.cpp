@@ -107,8 +107,8 @@ void trace_region_tables(np2_ctx *cx, int pass, const std::string &tag, const Pa
     if (tag == "cand") trace_put(cx, pass, "cand.kmer", d2h(cx, cx->cand_kmer.p, pc.NC));
 }
 
-void check_region_err(np2_ctx *cx) {
-    const uint32_t e = d2h(cx, cx->scal.p + S_ERR, 1)[0];
+void check_region_err(np2_ctx *cx, uint32_t e) {
+    (void)cx;
     if (e & 4u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: seq2 order is equal to 0");
     if (e & 8u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: index out of bounds: lqseq.seqs[max1_p]");
     if (e & 16u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: the first lqseq is not ref.");
@@ -130,22 +130,26 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
         cx->grp.ensure(pc.NC + 2);
         cx->ecount.ensure(n_reg + 2);
         cx->eoff.ensure(std::max<size_t>(n_reg + 2, (size_t)c->L + 2));
-        cx->ref_w.ensure(R + 2);
-        cx->ref_seen.ensure(R + 2);
-        cx->bad.ensure(R + 2);
-        cx->first_reg.ensure(R + 2);
-        zero32(cx, cx->ref_w.p, R + 2);
-        zero32(cx, cx->ref_seen.p, R + 2, 1);
-        zero32(cx, cx->bad.p, R + 2, 1);
-        HIPCHK(hipMemsetAsync(cx->first_reg.p, 0xFF, (size_t)(R + 2) * 4, s));
+        // per-read vote outputs live in one buffer: [first_reg u32 x RP][ref_w i32 x RP][ref_seen u8 x RP][bad u8 x RP]
+        const size_t RP = ((size_t)R + 63) & ~(size_t)63;
+        cx->votebuf.ensure(RP * 10);
+        uint32_t *v_first = (uint32_t *)cx->votebuf.p;
+        int32_t *v_refw = (int32_t *)(cx->votebuf.p + RP * 4);
+        uint8_t *v_seen = cx->votebuf.p + RP * 8, *v_bad = cx->votebuf.p + RP * 9;
+        HIPCHK(hipMemsetAsync(v_first, 0xFF, RP * 4, s));
+        HIPCHK(hipMemsetAsync(v_refw, 0, RP * 6, s));
         zero32(cx, cx->scal.p + S_ERR, 1);
-        launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, cx->ref_w.p, cx->ref_seen.p,
-                          cx->bad.p, cx->first_reg.p, cx->scal.p + S_ERR);
+        launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, v_refw, v_seen, v_bad, v_first,
+                          cx->scal.p + S_ERR);
         zero32(cx, cx->ecount.p + n_reg, 1);
         exclusive_total(cx, cx->ecount.p, cx->eoff.p, (size_t)n_reg + 1);
-        NE = d2h(cx, cx->eoff.p + n_reg, 1)[0];
+        launch_mail(s, cx->scal.p + S_M0, cx->eoff.p + n_reg);
     }
-    check_region_err(cx);
+    {
+        std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        check_region_err(cx, sc[S_ERR]);
+        NE = sc[S_M0];
+    }
     std::vector<uint64_t> ukey;
     std::vector<int32_t> uw;
     if (NE) {
@@ -170,10 +174,11 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
         ukey = d2h(cx, cx->ekey.p, NU);
         uw = d2h(cx, (const int32_t *)cx->eval.p, NU);
     }
-    auto first_reg = d2h(cx, cx->first_reg.p, R);
-    auto ref_w = d2h(cx, cx->ref_w.p, R);
-    auto ref_seen = d2h(cx, cx->ref_seen.p, R);
-    auto badv = d2h(cx, cx->bad.p, R);
+    const size_t RP = ((size_t)R + 63) & ~(size_t)63;
+    std::vector<uint8_t> vb = d2h(cx, cx->votebuf.p, RP * 10);
+    const uint32_t *first_reg = (const uint32_t *)vb.data();
+    const int32_t *ref_w = (const int32_t *)(vb.data() + RP * 4);
+    const uint8_t *ref_seen = vb.data() + RP * 8, *badv = vb.data() + RP * 9;
     if (cx->trace) {
         trace_put(cx, pass, "hete.lable", d2h(cx, cx->reg_lable.p, n_reg));
         trace_put(cx, pass, "hete.kscore", d2h(cx, cx->kscore.p, pc.NC));
@@ -248,15 +253,16 @@ CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, 
     launch_splice_find(s, in.pos, in.M, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
                        cx->sp_idx_e.p, cx->scal.p + S_STUCK, cx->sp_flag.p);
     exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
+    zero32(cx, cx->ap_delta.p, n_reg + 2); // slots past n_ap stay 0, so the scan can run over the n_reg bound
     launch_splice_slots(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p,
                         cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->scal.p + S_NAP);
-    const uint32_t n_ap = d2h(cx, cx->scal.p + S_NAP, 1)[0];
-    int32_t total_shift = 0;
-    if (n_ap) {
-        if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->ap_delta.p, cx->ap_shift.p, n_ap))
-            throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
-        total_shift = d2h(cx, cx->ap_shift.p + (n_ap - 1), 1)[0];
-    }
+    if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->ap_delta.p, cx->ap_shift.p, n_reg))
+        throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+    launch_mail(s, cx->scal.p + S_M0, (const uint32_t *)cx->ap_shift.p + (n_reg - 1));
+    std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+    check_region_err(cx, sc[S_ERR]);
+    const uint32_t n_ap = sc[S_NAP];
+    const int32_t total_shift = (int32_t)sc[S_M0];
     launch_splice_write(s, in.pos, in.base, in.M, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p,
                         cx->scal.p + S_NAP, n_ap, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->cand_seq.p,
                         opos, obase);
@@ -277,37 +283,37 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
     const uint32_t n_reg = pc.n_reg, ksize = cx->yaks[yak_idx].k;
     uint32_t n_rech = 0, n_groups = 0, n_jobs = 0;
     {
+        // everything up to the job count runs on the n_reg bound with zero-padded flag arrays: one read-back
         EventTimer t(cx, "recheck");
         cx->sp_flag.ensure(n_reg + 2);
         cx->sp_slot.ensure(n_reg + 2);
         cx->rech.ensure(n_reg + 2);
-        zero32(cx, cx->scal.p + S_ERR, 1);
+        cx->rech_head.ensure(n_reg + 2);
+        cx->rech_gslot.ensure(n_reg + 2);
+        cx->rech_groups.ensure((size_t)(n_reg + 2) * rech_group_bytes());
+        cx->rech_njobs.ensure(n_reg + 2);
+        cx->rech_joboff.ensure(n_reg + 2);
         zero32(cx, cx->scal.p + S_NRECH, 2);
+        zero32(cx, cx->rech_head.p, n_reg + 2);
+        zero32(cx, cx->rech_njobs.p, n_reg + 2);
         launch_rech_list(s, cx->reg_lable.p, n_reg, cx->sp_flag.p);
         exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
         launch_rech_list2(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH);
-        n_rech = d2h(cx, cx->scal.p + S_NRECH, 1)[0];
+        launch_rech_heads(s, cx->rech.p, cx->scal.p + S_NRECH, n_reg, cx->lq_start.p, cx->lq_end.p, ksize,
+                          cx->rech_head.p);
+        exclusive_total(cx, cx->rech_head.p, cx->rech_gslot.p, n_reg);
+        launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M,
+                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_njobs.p,
+                           cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
+        exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_reg + 1);
+        launch_mail(s, cx->scal.p + S_M0, cx->rech_joboff.p + n_reg);
+        std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        check_region_err(cx, sc[S_ERR]);
+        n_rech = sc[S_NRECH];
+        n_groups = sc[S_NGROUPS];
+        n_jobs = sc[S_M0];
     }
     if (n_rech) {
-        {
-            EventTimer t(cx, "recheck");
-            cx->rech_head.ensure(n_rech + 2);
-            cx->rech_gslot.ensure(n_rech + 2);
-            cx->rech_groups.ensure((size_t)(n_rech + 2) * rech_group_bytes());
-            cx->rech_njobs.ensure(n_rech + 2);
-            cx->rech_joboff.ensure(n_rech + 2);
-            launch_rech_heads(s, cx->rech.p, cx->scal.p + S_NRECH, n_rech, cx->lq_start.p, cx->lq_end.p, ksize,
-                              cx->rech_head.p);
-            exclusive_total(cx, cx->rech_head.p, cx->rech_gslot.p, n_rech);
-            zero32(cx, cx->rech_njobs.p, n_rech + 2);
-            launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_rech, in.pos,
-                               in.M, cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p,
-                               cx->rech_njobs.p, cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
-            n_groups = d2h(cx, cx->scal.p + S_NGROUPS, 1)[0];
-            exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_groups + 1);
-            n_jobs = d2h(cx, cx->rech_joboff.p + n_groups, 1)[0];
-        }
-        check_region_err(cx);
         RechPtrs rp{cx->rech_groups.p, cx->rech_joboff.p, cx->rech.p, cx->cand_off.p, cx->keep_list.p,
                     cx->cand_seq_off.p, cx->cand_seq.p, in.base, n_groups};
         if (n_jobs) {
@@ -389,8 +395,8 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         const uint64_t cap = slots + (uint64_t)shard_cap * NSHARD;
         cx->keys_raw.ensure(cap + 1);
         cx->vals_raw.ensure(cap + 1);
-        cx->shard_cnt.ensure(NSHARD * SHARD_STRIDE);
-        zero32(cx, cx->shard_cnt.p, NSHARD * SHARD_STRIDE);
+        cx->shard_cnt.ensure(NSHARD * SHARD_STRIDE + 8);
+        zero32(cx, cx->shard_cnt.p, NSHARD * SHARD_STRIDE + 8);
         zero32(cx, cx->scal.p, S_COUNT);
         {
             EventTimer t(cx, "diff_reads");
@@ -405,9 +411,12 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
             zero32(cx, cx->chunk_n.p + NCH, 1);
             exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)NCH + 1);
         }
-        std::vector<uint32_t> cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
+        launch_mail(s, cx->scal.p + S_M0, cx->chunk_pre.p + NCH, cx->scal.p + S_M1, cx->shard_cnt.p + NSHARD * SHARD_STRIDE);
+        // shard counters + overflow total in one read: the last word of shard_cnt holds the sum of all shards
         std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
-        n_slot = d2h(cx, cx->chunk_pre.p + NCH, 1)[0];
+        n_slot = sc[S_M0];
+        std::vector<uint32_t> cnt((size_t)NSHARD * SHARD_STRIDE, 0);
+        if (sc[S_M1]) cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
         uint32_t mx = 0;
@@ -491,9 +500,10 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     launch_mark_runs(s, cx->node_off.p, L, cx->flag.p);
     exclusive_total(cx, cx->flag.p, cx->idx.p, L);
     launch_scatter_idx(s, cx->flag.p, cx->idx.p, L, cx->run_start.p, cx->scal.p + S_NRUNS);
-    std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
-    n_nodes = sc[S_NNODES];
-    n_runs = sc[S_NRUNS];
+    // no read-back: downstream kernels are launched with the bound below and check the device-side counters
+    n_runs = std::min<uint32_t>(T, L);
+    n_nodes = T;
+    if (cx->trace) n_nodes = d2h(cx, cx->scal.p + S_NNODES, 1)[0];
 }
 
 GraphPtrs graph_ptrs(np2_ctx *cx, np2_contig *c) {
@@ -561,11 +571,12 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
     }
+    launch_mail(s, cx->scal.p + S_M0, cx->eoff.p + L);
     std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
     if (sc[S_BEST] == 0xFFFFFFFFu)
         throw Np2Error(NP2_E_UNSUPPORTED,
                        "best path score is negative at the contig end (reference would emit its default node)");
-    M = d2h(cx, cx->eoff.p + L, 1)[0];
+    M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
     cx->cns_pos.ensure(M + 2);
     cx->cns_base.ensure(M + 2);
@@ -684,8 +695,10 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
             launch_flag_nonzero(s, cx->pair_keep.p, NP, cx->keepflag.p);
             zero32(cx, cx->keepflag.p + NP, 1);
             exclusive_total(cx, cx->keepflag.p, cx->cand_idx.p, (size_t)NP + 1);
-            NC = d2h(cx, cx->cand_idx.p + NP, 1)[0];
-            SB = d2h(cx, cx->seq_off.p + NP, 1)[0];
+            launch_mail(s, cx->scal.p + S_M0, cx->cand_idx.p + NP, cx->scal.p + S_M1, cx->seq_off.p + NP);
+            std::vector<uint32_t> m2 = d2h(cx, cx->scal.p + S_M0, 2);
+            NC = m2[0];
+            SB = m2[1];
         }
     }
     cx->cand_order.ensure(NC + 2);
@@ -830,7 +843,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
                 launch_seed(s, rt, o->max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
                             cx->keep_ks.p, cx->scal.p + S_ERR);
             }
-            check_region_err(cx);
+            if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
             trace_region_tables(cx, (int)pass, "seed", pc, true);
             CnsDev cur{cx->cns_pos.p, cx->cns_base.p, M};
             bool to_b = true;

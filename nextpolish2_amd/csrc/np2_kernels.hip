@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256) void k_diff_reads(
         } else {
             const uint32_t shard = ch & (NSHARD - 1);
             uint32_t bp = 0;
-            if (lane == 0) bp = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
+            if (lane == 0) {
+                bp = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
+                atomicAdd(&shard_cnt[NSHARD * SHARD_STRIDE], tot); // grand total (overflow chunks are rare)
+            }
             bp = __shfl(bp, 0);
             obase = ovf_base + (uint64_t)shard * shard_cap + bp;
             olimit = ovf_base + (uint64_t)(shard + 1) * shard_cap;
@@ -431,6 +434,16 @@ __global__ void k_cov_delta(const np2_read_t *__restrict__ reads, uint32_t R, co
     atomicAdd(&covd[reads[r].aln_t_e + 1], -1);
 }
 
+// gather up to four device-resident counters into the scalar mailbox (so one D2H read serves a whole stage)
+__global__ void k_mail(uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
+                       const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
+                       uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (dst0) *dst0 = *src0;
+    if (dst1) *dst1 = *src1;
+    if (dst2) *dst2 = *src2;
+    if (dst3) *dst3 = *src3;
+}
 __global__ void k_init_alive(const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
@@ -1258,6 +1271,10 @@ void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_
                            uint32_t *out_vals) {
     hipLaunchKernelGGL(k_compact_shards, dim3(NSHARD), dim3(256), 0, s, in_keys, in_vals, ovf_base, shard_cap, shard_cnt,
                        shard_off, out_keys, out_vals);
+}
+void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2,
+                 const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, d0, s0, d1, s1, d2, s2, d3, s3);
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
     hipLaunchKernelGGL(k_init_alive, grid1(R), dim3(256), 0, s, reads, R, alive);

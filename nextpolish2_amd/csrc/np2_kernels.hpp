@@ -65,6 +65,8 @@ void launch_compact_slots(hipStream_t s, const uint64_t *in_keys, const uint32_t
 void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint64_t ovf_base,
                            uint32_t shard_cap, const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
                            uint32_t *out_vals);
+void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr,
+                 uint32_t *d2 = nullptr, const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_seed(RegionTables rt, int32_t max_indel
             atomicOr(err, 8u);
             reg_lable[g] = 0;
             keep_n[g] = 0;
-            seed_cand[g] = 0xFFFFFFFFu;
+            seed_cand[g] = 0; // in-bounds dummy; the error flag aborts the polish at the next read-back
         }
         return;
     }

@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nextpolish2_amd import Opts, Polisher  # noqa: E402
 from nextpolish2_amd.synth import Synth  # noqa: E402
 from oracle.np2_oracle import Oracle  # noqa: E402
