@@ -190,36 +190,46 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
     for (uint32_t r = 0; r < R; ++r)
         if (first_reg[r] != 0xFFFFFFFFu) keys.emplace_back(first_reg[r], r);
     std::sort(keys.begin(), keys.end());
-    phase::Weights data;
-    for (auto &k : keys) data.put_vacant(k.second, phase::Row());
+    const double t_host0 = now_ms();
+    phase::Graph data;
+    data.reserve_ids(R);
+    for (auto &k : keys) data.add_key(k.second);
     for (uint32_t i = 0; i < NU; ++i) {
         const uint32_t a = (uint32_t)(ukey[i] >> 32), b = (uint32_t)ukey[i];
         const float w = (float)uw[i];
-        phase::Row *ra = data.get(a), *rb = data.get(b);
-        if (!ra || !rb) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
-        (*ra)[b] = w;
-        (*rb)[a] = w;
+        if (!data.keys.has(a) || !data.keys.has(b)) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
+        data.adj[a].emplace_back(b, w);
+        data.adj[b].emplace_back(a, w);
     }
-    std::unordered_set<uint32_t> bad;
+    std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
-        if (badv[r]) bad.insert(r);
-    if (!use_all) {
-        data.keep_if([&](uint32_t k, phase::Row &) { return bad.count(k) == 0; });
-        data.each_mut([&](uint32_t, phase::Row &row) {
-            for (auto it = row.begin(); it != row.end();) it = bad.count(it->first) ? row.erase(it) : std::next(it);
-        });
+        if (badv[r]) bad.push_back(r);
+    if (!use_all) { // data.retain(..) + per-row retain (main.rs:1004-1010): erase order = bucket order
+        data.keys.keep_if([&](uint32_t k, phase::Nil &) { return !badv[k]; });
+        for (uint32_t r = 0; r < R; ++r) {
+            auto &row = data.adj[r];
+            if (badv[r]) {
+                row.clear();
+                continue;
+            }
+            row.erase(std::remove_if(row.begin(), row.end(), [&](const std::pair<uint32_t, float> &e) { return badv[e.first] != 0; }),
+                      row.end());
+        }
     }
-    phase::Row ref_row;
+    std::vector<float> ref_row(R, 0.f);
+    std::vector<uint8_t> ref_have(R, 0);
     bool have_ref = false;
     for (uint32_t r = 0; r < R; ++r)
         if (ref_seen[r]) {
             ref_row[r] = (float)ref_w[r];
+            ref_have[r] = 1;
             have_ref = true;
         }
     std::vector<uint32_t> losers;
-    if (!phase::losing_reads(std::move(data), have_ref ? &ref_row : nullptr, losers))
+    if (!phase::losing_reads(std::move(data), have_ref, ref_row, ref_have, losers))
         throw Np2Error(NP2_E_REFPANIC,
                        "reference would panic: the weight of two conflicting community is not less than 0");
+    cx->timing.host.push_back({"wall_louvain", (float)(now_ms() - t_host0)});
     for (uint32_t b : bad) losers.push_back(b);
     std::sort(losers.begin(), losers.end());
     losers.erase(std::unique(losers.begin(), losers.end()), losers.end());

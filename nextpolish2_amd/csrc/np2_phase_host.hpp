@@ -241,27 +241,21 @@ template <class V> class SwissOrderMap {
 
 struct Nil {};
 typedef SwissOrderMap<Nil> OrderSet;
-typedef std::unordered_map<uint32_t, float> Row; // inner maps only feed exact small-integer f32 sums
-typedef SwissOrderMap<Row> Weights;
 
-inline void add_weight(Weights &w, uint32_t a, uint32_t b, float v) { // insert_data, louvain.rs:273-279
-    if (Row *r = w.get(a)) {
-        (*r)[b] += v;
-    } else {
-        Row n;
-        n[b] = v;
-        w.put_vacant(a, std::move(n));
+// Signed weighted read graph.  `keys` reproduces the creation order of the outer keys of the reference's
+// HashMap<u32, HashMap<u32, f32>> (only that order is observable); the rows are plain adjacency vectors
+// (row iteration order only feeds exact small-integer f32 sums, so it is free).
+struct Graph {
+    OrderSet keys;
+    std::vector<std::vector<std::pair<uint32_t, float>>> adj; // indexed by node id; symmetric
+    void reserve_ids(uint32_t n) {
+        if (n > adj.size()) adj.resize(n);
     }
-}
-inline void set_weight(Weights &w, uint32_t a, uint32_t b, float v) { // assign_data, louvain.rs:282-288
-    if (Row *r = w.get(a)) {
-        (*r)[b] = v;
-    } else {
-        Row n;
-        n[b] = v;
-        w.put_vacant(a, std::move(n));
+    void add_key(uint32_t k) { // Entry::or_insert_with on a vacant key
+        reserve_ids(k + 1);
+        if (!keys.has(k)) keys.put_vacant(k, Nil{});
     }
-}
+};
 
 struct Community {
     uint32_t id = 0;
@@ -269,49 +263,56 @@ struct Community {
     std::vector<uint32_t> members; // union of original read ids
 };
 
+// Louvain with signed weights (louvain.rs:59-257).  Same decisions as the reference — sorted visit order,
+// max-gain / smallest-id moves, negative-community declustering and community ordering follow the emulated
+// hashbrown iteration order — but gains and inter-community weights are accumulated edge-wise (O(E)) instead of
+// the reference's O(deg^2) / O(C^2) membership scans; all sums are exact small-integer f32, so results are equal.
 class SignedLouvain {
   public:
-    explicit SignedLouvain(Weights w) : w_(std::move(w)) {
-        for (uint32_t v : w_.key_list()) { // louvain.rs:65-68
+    explicit SignedLouvain(Graph g) : g_(std::move(g)) {
+        const uint32_t n = (uint32_t)g_.adj.size();
+        node_id_.resize(n);
+        node_w_.assign(n, 0.f);
+        members_.resize(n);
+        for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68
             comm_.put(v, OrderSet::single(v, Nil{}));
-            Community c;
-            c.id = v;
-            c.members.push_back(v);
-            node_[v] = c;
+            node_id_[v] = v;
+            members_[v] = {v};
         }
     }
     // returns false if the reference's weight<0 assertion (louvain.rs:234-237) would fire
-    bool run(Weights &conflicts, std::vector<Community> &out) {
+    bool run(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts, std::vector<Community> &out) {
         while (local_moving()) aggregate();
         return collect(conflicts, out);
     }
 
   private:
-    Weights w_;
+    Graph g_;
     SwissOrderMap<OrderSet> comm_;
-    std::unordered_map<uint32_t, Community> node_;
+    std::vector<uint32_t> node_id_; // community of each (possibly aggregated) node
+    std::vector<float> node_w_;     // weight carried by an aggregated node
+    std::vector<std::vector<uint32_t>> members_;
 
     bool local_moving() { // first_stage, louvain.rs:72-117
         bool moved_any = false;
-        std::vector<uint32_t> visit = w_.key_list();
+        std::vector<uint32_t> visit = g_.keys.key_list();
         std::sort(visit.begin(), visit.end());
         std::vector<std::pair<uint32_t, float>> gains;
         for (bool again = true; again;) {
             again = false;
             for (uint32_t v : visit) {
-                const uint32_t cur = node_[v].id;
-                const Row &row = *w_.get(v);
+                const uint32_t cur = node_id_[v];
                 gains.clear();
-                for (const auto &e : row) {
-                    const uint32_t c = node_[e.first].id;
-                    bool seen = false;
-                    for (const auto &g : gains) seen |= (g.first == c);
-                    if (seen) continue;
-                    const OrderSet &set = *comm_.get(c);
-                    float s = 0.f;
-                    for (const auto &e2 : row)
-                        if (set.has(e2.first)) s += e2.second;
-                    gains.emplace_back(c, s);
+                for (const auto &e : g_.adj[v]) {
+                    const uint32_t c = node_id_[e.first];
+                    bool hit = false;
+                    for (auto &gn : gains)
+                        if (gn.first == c) {
+                            gn.second += e.second;
+                            hit = true;
+                            break;
+                        }
+                    if (!hit) gains.emplace_back(c, e.second);
                 }
                 if (gains.empty()) continue;
                 size_t best = 0; // max weight, ties -> smaller community id (louvain.rs:99-101)
@@ -320,7 +321,7 @@ class SignedLouvain {
                         (gains[i].second == gains[best].second && gains[i].first < gains[best].first))
                         best = i;
                 if (gains[best].second > 0.f && gains[best].first != cur) {
-                    node_[v].id = gains[best].first;
+                    node_id_[v] = gains[best].first;
                     comm_.get(gains[best].first)->put(v, Nil{});
                     comm_.get(cur)->take(v, nullptr);
                     again = true;
@@ -331,29 +332,27 @@ class SignedLouvain {
         return moved_any;
     }
 
-    float internal_weight(const OrderSet &set, std::vector<uint32_t> &members) const {
-        float wsum = 0.f;
+    // weight of a community = carried weights + half of every directed internal edge (louvain.rs:124-134)
+    float internal_weight(uint32_t cid, const OrderSet &set, std::vector<uint32_t> &mem) const {
+        float w = 0.f;
         set.each([&](uint32_t v, const Nil &) {
-            const Community &c = node_.at(v);
-            for (uint32_t m : c.members)
-                if (std::find(members.begin(), members.end(), m) == members.end()) members.push_back(m);
-            wsum += c.weight;
-            if (const Row *row = w_.get(v))
-                for (const auto &e : *row)
-                    if (set.has(e.first)) wsum += e.second / 2.0f;
+            mem.insert(mem.end(), members_[v].begin(), members_[v].end());
+            w += node_w_[v];
+            for (const auto &e : g_.adj[v])
+                if (node_id_[e.first] == cid) w += e.second / 2.0f;
         });
-        return wsum;
+        return w;
     }
 
     void aggregate() { // second_stage, louvain.rs:119-195
-        std::unordered_map<uint32_t, Community> nnode;
         SwissOrderMap<OrderSet> ncomm;
+        std::unordered_map<uint32_t, Community> nnode;
         std::vector<uint32_t> split;
         comm_.each([&](uint32_t id, const OrderSet &set) {
             if (set.empty()) return;
             Community c;
             c.id = id;
-            c.weight = internal_weight(set, c.members);
+            c.weight = internal_weight(id, set, c.members);
             if (c.weight < 0.f) {
                 split.push_back(id);
             } else {
@@ -361,6 +360,9 @@ class SignedLouvain {
                 nnode[id] = std::move(c);
             }
         });
+        // new community key of every current node (members of split communities get their own key)
+        std::vector<uint32_t> key_of(node_id_.size(), 0xFFFFFFFFu);
+        comm_.each([&](uint32_t id, const OrderSet &set) { set.each([&](uint32_t v, const Nil &) { key_of[v] = id; }); });
         for (uint32_t id : split) { // decluster negative communities, louvain.rs:145-165
             OrderSet set;
             comm_.take(id, &set);
@@ -368,82 +370,124 @@ class SignedLouvain {
                 uint32_t nid = v;
                 while (ncomm.has(nid) || nnode.count(nid)) ++nid;
                 ncomm.put(nid, OrderSet::single(nid, Nil{}));
-                Community c = node_[v];
+                Community c;
                 c.id = nid;
+                c.weight = node_w_[v];
+                c.members = members_[v];
                 nnode[nid] = std::move(c);
                 comm_.put(nid, OrderSet::single(v, Nil{}));
+                key_of[v] = nid;
             }
         }
-        Weights nw;
-        comm_.each([&](uint32_t a, const OrderSet &sa) {
-            if (sa.empty()) return;
-            comm_.each([&](uint32_t b, const OrderSet &sb) {
-                if (b <= a || sb.empty()) return;
-                float e = 0.f;
-                sa.each([&](uint32_t v, const Nil &) {
-                    if (const Row *row = w_.get(v))
-                        for (const auto &x : *row)
-                            if (sb.has(x.first)) e += x.second;
-                });
-                if (e != 0.f) {
-                    add_weight(nw, a, b, e);
-                    add_weight(nw, b, a, e);
+        // inter-community weights, accumulated over the directed edges (louvain.rs:167-188 computes the same sums);
+        // one pass per new community with a small local accumulator (a community touches few others)
+        uint32_t max_id = 0;
+        for (const auto &kv : nnode) max_id = std::max(max_id, kv.first);
+        Graph ng;
+        ng.reserve_ids(max_id + 1);
+        std::vector<std::vector<uint32_t>> of_key(max_id + 1);
+        for (uint32_t v = 0; v < key_of.size(); ++v)
+            if (key_of[v] != 0xFFFFFFFFu) of_key[key_of[v]].push_back(v);
+        std::vector<std::pair<uint32_t, float>> local;
+        for (uint32_t a = 0; a <= max_id; ++a) {
+            if (of_key[a].empty()) continue;
+            local.clear();
+            for (uint32_t v : of_key[a])
+                for (const auto &e : g_.adj[v]) {
+                    const uint32_t b = key_of[e.first];
+                    if (b == a) continue;
+                    bool hit = false;
+                    for (auto &l : local)
+                        if (l.first == b) {
+                            l.second += e.second;
+                            hit = true;
+                            break;
+                        }
+                    if (!hit) local.emplace_back(b, e.second);
                 }
-            });
-        });
-        w_ = std::move(nw);
+            for (const auto &l : local)
+                if (l.second != 0.f) {
+                    ng.add_key(a);
+                    ng.adj[a].push_back(l);
+                }
+        }
+        g_ = std::move(ng);
         comm_ = std::move(ncomm);
-        node_ = std::move(nnode);
+        node_id_.assign(max_id + 1, 0);
+        node_w_.assign(max_id + 1, 0.f);
+        members_.assign(max_id + 1, {});
+        for (auto &kv : nnode) {
+            node_id_[kv.first] = kv.first;
+            node_w_[kv.first] = kv.second.weight;
+            members_[kv.first] = std::move(kv.second.members);
+        }
+        g_.reserve_ids(max_id + 1);
     }
 
-    bool collect(Weights &conflicts, std::vector<Community> &out) { // get_communities, louvain.rs:197-245
+    bool collect(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts,
+                 std::vector<Community> &out) { // get_communities, louvain.rs:197-245
         out.clear();
         comm_.each([&](uint32_t id, const OrderSet &set) {
             if (set.empty()) return;
             Community c;
             c.id = id;
-            c.weight = internal_weight(set, c.members);
+            c.weight = internal_weight(id, set, c.members);
             out.push_back(std::move(c));
         });
+        // conflicts between final communities: sum of the weights between their members (must be < 0)
+        std::vector<std::vector<uint32_t>> of_comm;
+        for (uint32_t v = 0; v < g_.adj.size(); ++v) {
+            if (g_.adj[v].empty()) continue;
+            const uint32_t a = node_id_[v];
+            if (a >= of_comm.size()) of_comm.resize(a + 1);
+            of_comm[a].push_back(v);
+        }
         bool ok = true;
-        for (const Community &a : out)
-            for (const Community &b : out) {
-                if (b.id <= a.id) continue;
-                float e = 0.f;
-                comm_.get(a.id)->each([&](uint32_t x, const Nil &) {
-                    const Row *row = w_.get(x);
-                    if (!row) return;
-                    comm_.get(b.id)->each([&](uint32_t y, const Nil &) {
-                        auto it = row->find(y);
-                        if (it != row->end()) e += it->second;
-                    });
-                });
-                if (e != 0.f) {
-                    if (!(e < 0.f)) ok = false;
-                    add_weight(conflicts, a.id, b.id, e);
-                    add_weight(conflicts, b.id, a.id, e);
+        std::vector<std::pair<uint32_t, float>> local;
+        for (uint32_t a = 0; a < of_comm.size(); ++a) {
+            if (of_comm[a].empty()) continue;
+            local.clear();
+            for (uint32_t v : of_comm[a])
+                for (const auto &e : g_.adj[v]) {
+                    const uint32_t b = node_id_[e.first];
+                    if (b <= a) continue;
+                    bool hit = false;
+                    for (auto &l : local)
+                        if (l.first == b) {
+                            l.second += e.second;
+                            hit = true;
+                            break;
+                        }
+                    if (!hit) local.emplace_back(b, e.second);
                 }
+            for (const auto &l : local) {
+                if (l.second == 0.f) continue;
+                if (!(l.second < 0.f)) ok = false;
+                conflicts[a].insert(l.first);
+                conflicts[l.first].insert(a);
             }
+        }
         return ok;
     }
 };
 
-// phase_communities (louvain.rs:290-356): reads of the losing communities
-inline bool losing_reads(Weights graph, const Row *ref_row, std::vector<uint32_t> &losers) {
+// phase_communities (louvain.rs:290-356): reads of the losing communities.
+// ref_w / ref_seen: the reference haplotype's row (ref_data[0]), indexed by read id; have_ref = row exists
+inline bool losing_reads(Graph graph, bool have_ref, const std::vector<float> &ref_w,
+                         const std::vector<uint8_t> &ref_seen, std::vector<uint32_t> &losers) {
     SignedLouvain lv(std::move(graph));
-    Weights conflicts;
+    std::unordered_map<uint32_t, std::unordered_set<uint32_t>> conflicts;
     std::vector<Community> comms;
     if (!lv.run(conflicts, comms)) return false;
-    if (ref_row) {
+    if (have_ref) {
         std::vector<std::pair<int32_t, float>> key(comms.size());
         for (size_t i = 0; i < comms.size(); ++i) {
             int32_t cnt = 0;
             float w = 0.f;
             for (uint32_t m : comms[i].members) {
-                auto it = ref_row->find(m);
-                if (it == ref_row->end()) continue;
-                cnt += (it->second > 0.f) - (it->second < 0.f);
-                w += it->second;
+                if (m >= ref_seen.size() || !ref_seen[m]) continue;
+                cnt += (ref_w[m] > 0.f) - (ref_w[m] < 0.f);
+                w += ref_w[m];
             }
             key[i] = {cnt, w};
         }
@@ -461,10 +505,10 @@ inline bool losing_reads(Weights graph, const Row *ref_row, std::vector<uint32_t
     std::unordered_set<uint32_t> lost;
     for (size_t p = 0; p < comms.size(); ++p) {
         if (lost.count(comms[p].id)) continue;
-        const Row *adj = conflicts.get(comms[p].id);
-        if (!adj) continue;
+        auto it = conflicts.find(comms[p].id);
+        if (it == conflicts.end()) continue;
         for (size_t q = p + 1; q < comms.size(); ++q)
-            if (!lost.count(comms[q].id) && adj->count(comms[q].id)) lost.insert(comms[q].id);
+            if (!lost.count(comms[q].id) && it->second.count(comms[q].id)) lost.insert(comms[q].id);
     }
     for (const Community &c : comms)
         if (lost.count(c.id)) losers.insert(losers.end(), c.members.begin(), c.members.end());

@@ -165,6 +165,26 @@ def test_identical_pass_reuse_and_bases_only_output(small_haploid, small_diploid
         assert np.array_equal(b4, ob)
 
 
+def test_phasing_vote_at_moderate_scale():
+    # thousands of reads in the signed read graph: the edge-driven product Louvain must pick exactly the reads
+    # the oracle's literal (O(C^2)) restatement picks
+    s = Synth(1_500_000, depth=30, seed=77, diploid=True)
+    yaks = [s.yak(21), s.yak(31)]
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    ob, op = o.polish(s.pileup, Opts())
+    g = Polisher(yaks)
+    g.set_trace(True)
+    gb, gp = g.polish(s.pileup, Opts())
+    assert np.array_equal(o.trace(0, "invalid_ids"), g.trace(0, "invalid_ids"))
+    assert len(o.trace(0, "invalid_ids")) > 1000
+    assert np.array_equal(ob, gb) and np.array_equal(op, gp)
+    g.set_trace(False)
+    gb2, _ = g.polish(s.pileup, Opts(model="len"))
+    ob2, _ = orc.Oracle(yaks).polish(s.pileup, Opts(model="len"))
+    assert np.array_equal(ob2, gb2)
+
+
 def test_full_size_properties():
     """BASELINE.json configs[1] scale (4.6 Mb, 30x, k21): size-independent properties — the polished
     sequence equals the simulated truth, positions are non-decreasing, and a second call is identical."""
