@@ -93,6 +93,56 @@ def test_hand_made_edge_cases():
     check_all_stages(pu, [yak_from_seqs([truth], k)], Opts())
 
 
+def wild_pileup(seed, L=9000, n_reads=36, ins_p=0.03, del_p=0.03, sub_p=0.03, long_ins=True):
+    """Random alignments far outside HiFi statistics: dense indels, insertion runs up to 100 columns (crossing the
+    32-column lanes and 2048-column chunks of the dense kernel), N/M letters, reads starting at positions 0..2."""
+    rng = np.random.default_rng(seed)
+    ref = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    alns = []
+    for r in range(n_reads):
+        s = int(rng.choice([0, 0, 1, 2, int(rng.integers(0, L // 2))]))
+        e = int(min(L, s + rng.integers(1200, L)))
+        t, q = [], []
+        p = s
+        while p < e:
+            u = rng.random()
+            edge = p < s + 8 or p >= e - 8  # 8-match anchors like trim(8) leaves them
+            if edge or u > ins_p + del_p + sub_p:
+                t.append(ref[p]); q.append(ref[p]); p += 1
+            elif u < ins_p:
+                n = int(rng.integers(1, 4))
+                if long_ins and rng.random() < 0.15:
+                    n = int(rng.integers(20, 100))
+                for _ in range(n):
+                    t.append("-"); q.append("ACGTNM"[int(rng.integers(0, 6 if rng.random() < 0.1 else 4))])
+            elif u < ins_p + del_p:
+                n = int(rng.integers(1, 4))
+                for _ in range(n):
+                    if p < e - 8:
+                        t.append(ref[p]); q.append("-"); p += 1
+            else:
+                t.append(ref[p]); q.append("ACGT"[("ACGT".index(ref[p]) + int(rng.integers(1, 4))) % 4]); p += 1
+        alns.append((s, "".join(t), "".join(q)))
+    alns.sort(key=lambda a: a[0])
+    return ref, pileup_from_alignments(ref, alns)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_wild_pileups_all_stages(seed):
+    from test_oracle import yak_from_seqs
+    ref, pu = wild_pileup(seed, ins_p=0.01 * seed, del_p=0.02, sub_p=0.02)
+    yaks = [yak_from_seqs([ref], 21, count=30), yak_from_seqs([ref], 27, count=9)]
+    check_all_stages(pu, yaks, Opts())
+    check_all_stages(pu, yaks[:1], Opts(use_all_reads=True, model="len"))
+
+
+def test_wild_pileup_long_reads_cross_chunks():
+    from test_oracle import yak_from_seqs
+    ref, pu = wild_pileup(11, L=30000, n_reads=24, ins_p=0.02, del_p=0.01, sub_p=0.01)
+    assert int(pu.reads["n_cols"][1:].max()) > 3 * 2048
+    check_all_stages(pu, [yak_from_seqs([ref], 21, count=30)], Opts())
+
+
 def test_non_acgt_reference_letters():
     rng = np.random.default_rng(9)
     base = "".join("ACGT"[i] for i in rng.integers(0, 4, 300))
