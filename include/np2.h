@@ -116,6 +116,14 @@ void np2_ctx_set_trace(np2_ctx_t *ctx, int enable);
 int np2_trace_get(np2_ctx_t *ctx, int pass, const char *name, const void **data,
                   uint64_t *nbytes);
 
+/* Host-side phasing vote (louvain.rs:290-356) on an explicit signed read graph — no device needed.
+ * keys[n_keys]: graph nodes in the creation order of the reference's outer HashMap keys; pairs (pa[i], pb[i], pw[i])
+ * are undirected weights; ref_ids/ref_w: the reference haplotype's row (ref_data[0]) or n_ref = 0 with has_ref = 0.
+ * Writes the losing reads (sorted) to out_ids (capacity n_keys) and their number to n_out. */
+int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, const uint32_t *pb, const float *pw,
+                   uint64_t n_pairs, const uint32_t *ref_ids, const float *ref_w, uint32_t n_ref, int has_ref,
+                   uint32_t *out_ids, uint32_t *n_out);
+
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
  * names: NUL-separated list terminated by an empty string; ms[i] matches names[i]. */
 int np2_last_timings(np2_ctx_t *ctx, const char **names, const float **ms, int *n);

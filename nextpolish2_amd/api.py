@@ -19,7 +19,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
-    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings", "np2_last_span",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_phase_vote",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -59,6 +59,7 @@ def lib():
         L.np2_trace_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
         L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.np2_last_span.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+        L.np2_phase_vote.argtypes = [vp, u32, vp, vp, vp, u64, vp, vp, u32, C.c_int, vp, C.POINTER(u32)]
         _LIB = L
     return _LIB
 
@@ -215,3 +216,22 @@ def fasta_record(name, bases, pos):
     """display_consensusbase_vec (src/main.rs:607-645): '>{name} start:{first} end:{last}\\n{seq}\\n'."""
     return b">%s start:%d end:%d\n%s\n" % (name.encode() if isinstance(name, str) else name, int(pos[0]), int(pos[-1]),
                                            bytes(bases))
+
+
+def phase_vote(keys, pairs, ref=None):
+    """Host-only phasing vote of the product library (np2_phase_vote): keys in creation order, pairs [(a, b, w)],
+    ref = {read: weight} or None -> sorted losing reads."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    pa = np.array([p[0] for p in pairs], dtype=np.uint32)
+    pb = np.array([p[1] for p in pairs], dtype=np.uint32)
+    pw = np.array([p[2] for p in pairs], dtype=np.float32)
+    ri = np.array(list(ref.keys()) if ref else [], dtype=np.uint32)
+    rw = np.array(list(ref.values()) if ref else [], dtype=np.float32)
+    out = np.zeros(max(1, len(keys)), dtype=np.uint32)
+    n = C.c_uint32()
+    rc = lib().np2_phase_vote(keys.ctypes.data, len(keys), pa.ctypes.data, pb.ctypes.data, pw.ctypes.data, len(pairs),
+                              ri.ctypes.data, rw.ctypes.data, len(ri), 1 if ref is not None else 0, out.ctypes.data,
+                              C.byref(n))
+    if rc != 0:
+        raise Np2Error(rc, "np2_phase_vote")
+    return out[: n.value].tolist()

@@ -1123,6 +1123,36 @@ int np2_last_span(np2_ctx_t *cx, uint32_t *first_pos, uint32_t *last_pos) {
     return NP2_OK;
 }
 
+int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, const uint32_t *pb, const float *pw,
+                   uint64_t n_pairs, const uint32_t *ref_ids, const float *ref_w, uint32_t n_ref, int has_ref,
+                   uint32_t *out_ids, uint32_t *n_out) {
+    if (!keys || !out_ids || !n_out) return NP2_E_ARG;
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n_keys; ++i) mx = std::max(mx, keys[i]);
+    for (uint32_t i = 0; i < n_ref; ++i) mx = std::max(mx, ref_ids[i]);
+    phase::Graph g;
+    g.reserve_ids(mx + 1);
+    for (uint32_t i = 0; i < n_keys; ++i) g.add_key(keys[i]);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        if (!g.keys.has(pa[i]) || !g.keys.has(pb[i])) return NP2_E_ARG;
+        g.adj[pa[i]].emplace_back(pb[i], pw[i]);
+        g.adj[pb[i]].emplace_back(pa[i], pw[i]);
+    }
+    std::vector<float> rw(mx + 1, 0.f);
+    std::vector<uint8_t> rs(mx + 1, 0);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        rw[ref_ids[i]] = ref_w[i];
+        rs[ref_ids[i]] = 1;
+    }
+    std::vector<uint32_t> losers;
+    if (!phase::losing_reads(std::move(g), has_ref != 0, rw, rs, losers)) return NP2_E_REFPANIC;
+    std::sort(losers.begin(), losers.end());
+    losers.erase(std::unique(losers.begin(), losers.end()), losers.end());
+    *n_out = (uint32_t)losers.size();
+    for (size_t i = 0; i < losers.size(); ++i) out_ids[i] = losers[i];
+    return NP2_OK;
+}
+
 int np2_trace_get(np2_ctx_t *cx, int pass, const char *name, const void **data, uint64_t *nbytes) {
     if (!cx) return NP2_E_ARG;
     auto it = cx->trace_items.find(std::to_string(pass) + ":" + name);

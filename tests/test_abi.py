@@ -55,3 +55,48 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(api.Np2Error) as e:
         Polisher([y])
     assert e.value.code == -2  # NP2_E_DEVICE
+
+
+def test_product_phasing_vote_agrees_with_the_oracle_on_random_signed_graphs():
+    """Two independent restatements of louvain.rs + hashbrown iteration order (oracle/hashbrown_emul.hpp vs
+    csrc/np2_phase_host.hpp, the latter with edge-driven aggregation) must pick the same losing reads, including on
+    tie-heavy graphs where only the emulated bucket order decides."""
+    import numpy as np
+    from nextpolish2_amd.api import phase_vote
+    from oracle import np2_oracle as orc
+    rng = np.random.default_rng(12)
+    for trial in range(120):
+        n = int(rng.integers(3, 70))
+        ids = rng.choice(np.arange(1, 400), size=n, replace=False)
+        pairs = {}
+        m = int(rng.integers(n, 4 * n))
+        for _ in range(m):
+            a, b = rng.choice(ids, size=2, replace=False)
+            a, b = int(min(a, b)), int(max(a, b))
+            # clustered signs: same "haplotype" (id parity) mostly positive, so conflicts are genuine; small integer
+            # weights make ties between communities frequent
+            same = (a % 2) == (b % 2)
+            w = float(rng.integers(1, 3)) * (1.0 if (same or rng.random() < 0.1) else -1.0)
+            if rng.random() < 0.05:
+                w = -3.0
+            pairs[(a, b)] = pairs.get((a, b), 0.0) + w
+        plist = [(a, b, w) for (a, b), w in pairs.items()]
+        # the oracle applies insert_data(a, b) then insert_data(b, a) per pair in this order
+        edges, keys, seen = [], [], set()
+        for a, b, w in plist:
+            edges.append((a, b, w))
+            edges.append((b, a, w))
+            for k in (a, b):
+                if k not in seen:
+                    seen.add(k)
+                    keys.append(k)
+        ref = None
+        if trial % 3 == 0:
+            ref = {int(k): float(rng.choice([-1.0, 1.0, 2.0])) for k in rng.choice(ids, size=max(1, n // 3), replace=False)}
+        try:
+            exp = orc.phase_communities(edges, ref)
+        except orc.RefPanic:
+            with pytest.raises(api.Np2Error):
+                phase_vote(keys, plist, ref)
+            continue
+        assert phase_vote(keys, plist, ref) == exp, trial
