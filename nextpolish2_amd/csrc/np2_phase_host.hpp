@@ -294,13 +294,19 @@ class SignedLouvain {
     std::vector<std::vector<uint32_t>> members_;
 
     bool local_moving() { // first_stage, louvain.rs:72-117
+        // The reference re-evaluates every node in every sweep until a sweep moves nothing.  A node's decision is a
+        // pure function of its neighbours' community ids, so a node none of whose neighbours moved since its last
+        // evaluation cannot move: only "dirty" nodes are evaluated (same visit order, identical outcome).
         bool moved_any = false;
         std::vector<uint32_t> visit = g_.keys.key_list();
         std::sort(visit.begin(), visit.end());
+        std::vector<uint8_t> dirty(g_.adj.size(), 1);
         std::vector<std::pair<uint32_t, float>> gains;
         for (bool again = true; again;) {
             again = false;
             for (uint32_t v : visit) {
+                if (!dirty[v]) continue;
+                dirty[v] = 0;
                 const uint32_t cur = node_id_[v];
                 gains.clear();
                 for (const auto &e : g_.adj[v]) {
@@ -324,6 +330,7 @@ class SignedLouvain {
                     node_id_[v] = gains[best].first;
                     comm_.get(gains[best].first)->put(v, Nil{});
                     comm_.get(cur)->take(v, nullptr);
+                    for (const auto &e : g_.adj[v]) dirty[e.first] = 1; // their gains changed
                     again = true;
                     moved_any = true;
                 }
