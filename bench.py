@@ -26,8 +26,8 @@ PMC_TRAFFIC_DEFAULT_WORKLOAD = int((2 * 48348.5 + 22074.9) * 1024)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--length", type=int, default=4_600_000, help="contig length (bp); default = E. coli")
     ap.add_argument("--depth", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")

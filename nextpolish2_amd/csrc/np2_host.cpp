@@ -999,6 +999,12 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         if (cx->stream) (void)hipStreamDestroy(cx->stream);
         delete cx;
         return code;
+    } catch (const std::exception &ex) {
+        fprintf(stderr, "np2_ctx_create: %s\n", ex.what());
+        int code = NP2_E_NOMEM;
+        if (cx->stream) (void)hipStreamDestroy(cx->stream);
+        delete cx;
+        return code;
     }
     *out = cx;
     return NP2_OK;
@@ -1034,6 +1040,9 @@ int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
     } catch (const Np2Error &e) {
         delete c;
         return fail(cx, e);
+    } catch (const std::exception &ex) {
+        delete c;
+        return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     *out = c;
     return NP2_OK;
@@ -1059,6 +1068,12 @@ int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, 
         if (r.bases) pinned_pool().put(r.bases);
         if (r.pos) pinned_pool().put(r.pos);
         return fail(cx, e);
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        flush_timings(cx);
+        if (r.bases) pinned_pool().put(r.bases);
+        if (r.pos) pinned_pool().put(r.pos);
+        return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     *out_len = r.len;
     *out_bases = r.bases;
@@ -1095,6 +1110,8 @@ int np2_score_strings(np2_ctx_t *cx, int yak_idx, const uint8_t *strs, const uin
         flush_timings(cx);
     } catch (const Np2Error &e) {
         return fail(cx, e);
+    } catch (const std::exception &ex) {
+        return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
 }
@@ -1112,6 +1129,8 @@ int np2_lookup_hashes(np2_ctx_t *cx, int yak_idx, const uint64_t *hashes, uint64
         HIPCHK(hipStreamSynchronize(cx->stream));
     } catch (const Np2Error &e) {
         return fail(cx, e);
+    } catch (const std::exception &ex) {
+        return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
 }
@@ -1127,6 +1146,7 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
                    uint64_t n_pairs, const uint32_t *ref_ids, const float *ref_w, uint32_t n_ref, int has_ref,
                    uint32_t *out_ids, uint32_t *n_out) {
     if (!keys || !out_ids || !n_out) return NP2_E_ARG;
+    try {
     uint32_t mx = 0;
     for (uint32_t i = 0; i < n_keys; ++i) mx = std::max(mx, keys[i]);
     for (uint32_t i = 0; i < n_ref; ++i) mx = std::max(mx, ref_ids[i]);
@@ -1150,6 +1170,9 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
     losers.erase(std::unique(losers.begin(), losers.end()), losers.end());
     *n_out = (uint32_t)losers.size();
     for (size_t i = 0; i < losers.size(); ++i) out_ids[i] = losers[i];
+    } catch (const std::exception &) {
+        return NP2_E_NOMEM;
+    }
     return NP2_OK;
 }
 

@@ -19,7 +19,6 @@ int io_fail(int code, const std::string &m) {
 struct Fasta {
     gzFile f = nullptr;
     std::string name, seq, pending; // pending = next header line
-    bool eof = false;
     std::vector<char> buf;
     bool getline(std::string &out) {
         out.clear();
@@ -41,11 +40,9 @@ struct Bgzf {
     FILE *f = nullptr;
     std::vector<uint8_t> block, cdata;
     size_t bpos = 0;
-    uint64_t block_coffset = 0;
     bool read_block() { // returns false at EOF
         block.clear();
         bpos = 0;
-        block_coffset = (uint64_t)ftello(f);
         uint8_t hd[18];
         size_t n = fread(hd, 1, 18, f);
         if (n == 0) return false;
@@ -126,7 +123,6 @@ struct np2_bam {
     std::vector<std::string> ref_names;
     std::vector<uint32_t> ref_lens;
     std::vector<uint64_t> ref_start; // virtual offset of the first record of each reference (~0 = none)
-    uint64_t first_record_voffset = 0;
 };
 
 namespace {
@@ -333,7 +329,7 @@ int np2_fasta_open(const char *path, np2_fasta_t **out) {
     *out = h;
     return NP2_OK;
 }
-int np2_fasta_next(np2_fasta_t *h, const char **name, const uint8_t **seq, uint64_t *len) {
+int np2_fasta_next(np2_fasta_t *h, const char **name, const uint8_t **seq, uint64_t *len) try {
     Fasta &f = h->f;
     if (f.pending.empty()) return 0;
     size_t e = 1;
@@ -353,6 +349,8 @@ int np2_fasta_next(np2_fasta_t *h, const char **name, const uint8_t **seq, uint6
     *seq = (const uint8_t *)f.seq.data();
     *len = f.seq.size();
     return 1;
+} catch (const std::exception &ex) {
+    return io_fail(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what());
 }
 void np2_fasta_close(np2_fasta_t *h) {
     if (!h) return;
@@ -361,7 +359,7 @@ void np2_fasta_close(np2_fasta_t *h) {
 }
 
 // ---- yak v2 (kmer.rs:72-170) -----------------------------------------------------------------------
-int np2_yak_load(const char *path, np2_yak_t *out) {
+int np2_yak_load(const char *path, np2_yak_t *out) try {
     FILE *f = fopen(path, "rb");
     if (!f) return io_fail(NP2_E_ARG, std::string("cannot open ") + path);
     uint8_t hd[16];
@@ -405,6 +403,8 @@ int np2_yak_load(const char *path, np2_yak_t *out) {
     out->words = w;
     out->bucket_off = off;
     return NP2_OK;
+} catch (const std::exception &ex) {
+    return io_fail(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what());
 }
 void np2_yak_free(np2_yak_t *y) {
     if (!y) return;
@@ -485,6 +485,10 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
         if (b->z.f) fclose(b->z.f);
         delete b;
         return io_fail(e.code, e.what());
+    } catch (const std::exception &ex) {
+        if (b->z.f) fclose(b->z.f);
+        delete b;
+        return io_fail(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what());
     }
     *out = b;
     return NP2_OK;
@@ -515,6 +519,10 @@ int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const
         (void)hipStreamSynchronize(cx->stream);
         np2h::flush_timings(cx);
         return np2h::fail(cx, e);
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        np2h::flush_timings(cx);
+        return np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
 }
@@ -574,6 +582,10 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         (void)hipStreamSynchronize(cx->stream);
         np2h::flush_timings(cx);
         return np2h::fail(cx, e);
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        np2h::flush_timings(cx);
+        return np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
 }
@@ -591,6 +603,8 @@ int np2_contig_export(np2_ctx_t *cx, np2_contig_t *c, np2_read_t **reads, uint32
         *nib_bytes = c->nib_bytes;
     } catch (const np2h::Np2Error &e) {
         return np2h::fail(cx, e);
+    } catch (const std::exception &ex) {
+        return np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
 }

@@ -502,16 +502,6 @@ __global__ void k_scatter_idx(const uint32_t *__restrict__ flag, const uint32_t 
     if (i == n - 1) *n_out = idx[i] + (flag[i] ? 1u : 0u);
 }
 
-// score one node K at position p given the already-scored candidates of its predecessor
-// position q (q == p: nodes before K in the same position; q == p-1: previous position).
-struct PosView {
-    uint32_t p;      // position
-    uint32_t o0, o1; // exception node range
-    uint16_t b0, d0; // N0 key
-    int64_t s0;      // N0 score
-    bool has_n0_score;
-};
-
 __device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q, const AlignBase &kb1,
                                            const AlignBase &kb2, AlignBase &pb1) {
     // Msa::get(base2 = K.b1, base3 = K.b2) (main.rs:209-225)
