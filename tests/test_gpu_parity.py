@@ -143,6 +143,66 @@ def test_wild_pileup_long_reads_cross_chunks():
     check_all_stages(pu, [yak_from_seqs([ref], 21, count=30)], Opts())
 
 
+def test_scaffold_gap_uncovered_stretch_and_soft_masking():
+    # a contig with an N gap (reads stop before it and resume after it), an uncovered stretch (coverage 1: only the
+    # contig's own row, main.rs:1586-1588 resets the LQ state there) and lower-case (soft-masked) letters
+    from test_oracle import yak_from_seqs
+    s1 = Synth(24000, depth=25, seed=71, read_len_mean=3000.0, read_len_sd=500.0)
+    ref = bytearray(s1.pileup.ref.tobytes())
+    L = len(ref)
+    gap_a, gap_b = 9000, 9600      # N gap
+    hole_a, hole_b = 15000, 16200  # no read covers this
+    ref[gap_a:gap_b] = b"N" * (gap_b - gap_a)
+    ref[3000:3300] = bytes(ref[3000:3300]).lower()
+    alns = []
+    recs = pileup_to_alignments(s1.pileup)
+    for (ts, t, q) in recs:
+        te = ts + sum(1 for c in t if c != "-") - 1
+        if ts < gap_b + 20 and te > gap_a - 20:
+            continue  # drop reads touching the gap
+        if ts < hole_b and te > hole_a:
+            continue  # and the uncovered stretch
+        alns.append((ts, t, q))
+    # rebuild target strings against the edited contig (case / N changes only affect reads we dropped or the mask)
+    fixed = []
+    for (ts, t, q) in alns:
+        tt, p = [], ts
+        for c in t:
+            if c == "-":
+                tt.append("-")
+            else:
+                tt.append(chr(ref[p])); p += 1
+        fixed.append((ts, "".join(tt), q))
+    pu = pileup_from_alignments(bytes(ref).decode(), fixed)
+    yaks = [yak_from_seqs([s1.hap1.decode()], 21, count=40)]
+    gb, gp = check_all_stages(pu, yaks, Opts())
+    out = gb.tobytes()
+    assert b"N" * (gap_b - gap_a) in out and out == out.upper()
+
+
+def pileup_to_alignments(pu):
+    """packed reads (index >= 1) -> [(aln_t_s, gapped target, gapped query)]"""
+    code2 = "ACGT-NM"
+    ref = pu.ref.tobytes().decode()
+    out = []
+    for r in range(1, pu.n_reads):
+        rd = pu.reads[r]
+        n = int(rd["n_cols"])
+        b = pu.nibbles[int(rd["nib_off"]):int(rd["nib_off"]) + (n + 1) // 2 + 1]
+        nib = np.empty(2 * len(b), dtype=np.uint8)
+        nib[0::2] = b >> 4
+        nib[1::2] = b & 15
+        t, q, p = [], [], int(rd["aln_t_s"])
+        for c in nib[:n]:
+            if c & 8:
+                t.append("-")
+            else:
+                t.append(ref[p]); p += 1
+            q.append(code2[c & 7])
+        out.append((int(rd["aln_t_s"]), "".join(t), "".join(q)))
+    return out
+
+
 def test_non_acgt_reference_letters():
     rng = np.random.default_rng(9)
     base = "".join("ACGT"[i] for i in rng.integers(0, 4, 300))
