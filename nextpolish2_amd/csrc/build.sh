@@ -12,5 +12,5 @@ for f in np2_kernels.hip np2_regions.hip np2_front.hip np2_prims.hip np2_host.cp
     hipcc $FLAGS -x hip -c $f -o $o
   fi
 done
-hipcc --offload-arch=$ARCH -shared -fPIC -o ../libnp2_hip.so obj/np2_kernels.o obj/np2_regions.o obj/np2_front.o obj/np2_prims.o obj/np2_host.o obj/np2_io.o -lz
+hipcc --offload-arch=$ARCH -shared -fPIC -o ../libnp2_hip.so obj/np2_kernels.o obj/np2_regions.o obj/np2_front.o obj/np2_prims.o obj/np2_host.o obj/np2_io.o -lz -lpthread
 echo "built nextpolish2_amd/libnp2_hip.so"

@@ -5,6 +5,8 @@
 
 #include <zlib.h>
 
+#include <thread>
+
 namespace {
 
 thread_local std::string g_io_err;
@@ -107,6 +109,119 @@ struct Bgzf {
             bpos += k;
         }
         return true;
+    }
+};
+
+// Reads BGZF blocks in batches and inflates each batch with several host threads (blocks are independent).
+struct BgzfBatch {
+    FILE *f = nullptr;
+    struct Blk {
+        std::vector<uint8_t> c; // raw deflate payload
+        uint32_t isize = 0;
+        size_t out_off = 0;
+    };
+    std::vector<uint8_t> buf; // inflated bytes not yet consumed (+ the current batch)
+    size_t pos = 0;
+    bool eof = false;
+    bool read_raw(Blk &b) {
+        uint8_t hd[18];
+        const size_t n = fread(hd, 1, 18, f);
+        if (n == 0) return false;
+        if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
+            throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+        const uint32_t xlen = hd[10] | (hd[11] << 8);
+        std::vector<uint8_t> extra(xlen);
+        memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6)
+            throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF header");
+        uint32_t bsize = 0;
+        for (size_t p = 0; p + 4 <= xlen;) {
+            const uint32_t slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
+            p += 4 + slen;
+        }
+        if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+        const size_t clen = bsize - 12 - xlen - 8;
+        b.c.resize(clen + 8);
+        if (fread(b.c.data(), 1, clen + 8, f) != clen + 8) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+        b.isize = b.c[clen + 4] | (b.c[clen + 5] << 8) | (b.c[clen + 6] << 16) | ((uint32_t)b.c[clen + 7] << 24);
+        b.c.resize(clen);
+        return true;
+    }
+    // start at a virtual offset
+    void seek(uint64_t voffset) {
+        fseeko(f, (off_t)(voffset >> 16), SEEK_SET);
+        buf.clear();
+        pos = 0;
+        eof = false;
+        fill(8);
+        pos = std::min<size_t>(voffset & 0xFFFF, buf.size());
+    }
+    void fill(size_t n_blocks) {
+        if (eof) return;
+        if (pos) { // drop consumed bytes
+            buf.erase(buf.begin(), buf.begin() + (long)pos);
+            pos = 0;
+        }
+        std::vector<Blk> blks;
+        size_t total = 0;
+        for (size_t i = 0; i < n_blocks; ++i) {
+            Blk b;
+            if (!read_raw(b)) {
+                eof = true;
+                break;
+            }
+            b.out_off = total;
+            total += b.isize;
+            blks.push_back(std::move(b));
+        }
+        const size_t base = buf.size();
+        buf.resize(base + total);
+        unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blks.size() / 4));
+        std::vector<int> bad(nt, 0);
+        auto work = [&](unsigned t) {
+            for (size_t i = t; i < blks.size(); i += nt) {
+                if (!blks[i].isize) continue;
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) {
+                    bad[t] = 1;
+                    return;
+                }
+                zs.next_in = blks[i].c.data();
+                zs.avail_in = (uInt)blks[i].c.size();
+                zs.next_out = buf.data() + base + blks[i].out_off;
+                zs.avail_out = blks[i].isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) bad[t] = 1;
+            }
+        };
+        if (nt <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int b : bad)
+            if (b) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
+    }
+    // pointer to n contiguous bytes (nullptr on clean EOF before the first byte)
+    const uint8_t *take(size_t n) {
+        size_t batch = 256;
+        while (buf.size() - pos < n) {
+            if (eof) {
+                if (buf.size() == pos) return nullptr;
+                throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+            }
+            fill(batch);
+            batch = 1024;
+        }
+        const uint8_t *p = buf.data() + pos;
+        pos += n;
+        return p;
     }
 };
 
@@ -540,27 +655,28 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         std::vector<uint32_t> cigar;
         std::vector<uint8_t> seq4;
         if (bam->ref_start[tid] != ~0ull) {
-            bam->z.seek(bam->ref_start[tid]);
-            std::vector<uint8_t> rec;
+            BgzfBatch z;
+            z.f = bam->z.f;
+            z.seek(bam->ref_start[tid]);
             for (;;) {
-                uint8_t h4[4];
-                if (!bam->z.read(h4, 4)) break;
+                const uint8_t *h4 = z.take(4);
+                if (!h4) break;
                 const uint32_t bs = le32(h4);
-                rec.resize(bs);
-                bam->z.read(rec.data(), bs);
-                const int32_t refID = (int32_t)le32(rec.data());
+                const uint8_t *rec = z.take(bs);
+                if (!rec) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+                const int32_t refID = (int32_t)le32(rec);
                 if (refID != tid) {
                     if (refID > tid || refID < 0) break;
                     continue;
                 }
-                const int32_t pos = (int32_t)le32(rec.data() + 4);
+                const int32_t pos = (int32_t)le32(rec + 4);
                 if ((uint32_t)pos >= L) continue; // fetch(tid, 0, len): records starting beyond the region
                 const uint32_t l_read_name = rec[8], mapq = rec[9];
                 const uint32_t n_cigar = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8);
-                const uint32_t l_seq = le32(rec.data() + 16);
-                const uint8_t *pc = rec.data() + 32 + l_read_name;
+                const uint32_t l_seq = le32(rec + 16);
+                const uint8_t *pc = rec + 32 + l_read_name;
                 const uint8_t *ps = pc + (size_t)n_cigar * 4;
-                if ((size_t)(ps - rec.data()) + (l_seq + 1) / 2 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                if ((size_t)(ps - rec) + (l_seq + 1) / 2 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
                 np2_bamrec_t r;
                 memset(&r, 0, sizeof r);
                 r.pos = pos;
