@@ -166,9 +166,8 @@ struct np2_ctx {
     // scratch (reused across contigs)
     DevBuf<uint8_t> tmp;
     DevBuf<uint64_t> keys_raw, keys;
-    DevBuf<uint32_t> vals_raw, vals, shard_cnt, gcount, gmin, flag, idx;
-    DevBuf<uint64_t> shard_off;
-    DevBuf<uint32_t> npos, ncount, nminr, nbesti, node_cnt, node_off, run_start, run_end, n0_besti, emit, eoff;
+    DevBuf<uint32_t> vals_raw, vals;
+    DevBuf<uint32_t> npos, ncount, nminr, nbesti, node_off, run_start, run_end, n0_besti, emit, eoff;
     DevBuf<uint16_t> nbases, ndelta;
     DevBuf<int64_t> nscore;
     DevBuf<int32_t> covd, cov, mval, smin;
@@ -190,6 +189,9 @@ struct np2_ctx {
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
+    DevBuf<uint32_t> tile_cur, tile_n, tile_scan, tile_scanb, tile_nn, tile_nr, tile_noff, tile_roff;
+    uint32_t tile_cap = TILE_CAP; // records per tile bucket (tests lower it to force the spill path)
+    uint32_t bucket_cap = 0;      // layout of the sorted records of the current contig (0 = compact)
     DevBuf<uint2> nrec;
     DevBuf<uint8_t> votebuf;
     DevBuf<int64_t> run_gain;
@@ -204,7 +206,7 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_COUNT = 24 };
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_COUNT = 24 };
 
 struct WallTimer {
     np2_ctx *cx;

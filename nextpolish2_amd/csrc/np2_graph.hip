@@ -1,0 +1,484 @@
+// Sparse-graph construction by contig tiles (gfx950, wave64).
+//
+// The exception records of the dense pass are bucketed by contig tile (TILE positions), sorted inside LDS
+// (one workgroup per tile) and, per pass, turned into the exception nodes of the 3-column-mer graph
+// (Msa::push / Msa::sort, main.rs:193-229), the per-position node offsets and the list of dirty runs by
+// one workgroup per tile.  This replaces a device-wide radix sort, three device-wide scans over the
+// contig and half a dozen L-sized passes by three short launches per pass.
+#include "np2_common.hpp"
+#include "np2_kernels.hpp"
+
+namespace np2 {
+
+// ------------------------------------------------------------------------------------------------------
+// small block-level helpers (256-thread blocks = 4 wavefronts)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += t;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+// exclusive scan of one value per thread over a 256-thread block; `sh` = 8 words of LDS scratch
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *sh, uint32_t &total) {
+    const uint32_t w = threadIdx.x >> 6;
+    uint32_t wt;
+    const uint32_t e = wave_excl_scan_u32(v, wt);
+    __syncthreads(); // sh may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sh[w] = wt;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; ++i) base += sh[i];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    return base + e;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// raw exception record (read, column, t_pos) -> node key pos << 32 | bases << 16 | delta1
+// (Kmer::new over the columns c-2, c-1, c; head sentinels before a read's first column, main.rs:579-585)
+// ------------------------------------------------------------------------------------------------------
+__device__ uint64_t make_node_key(const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib, uint64_t rec,
+                                  uint32_t r) {
+    const uint32_t col = (uint32_t)rec, t3 = (uint32_t)(rec >> 32);
+    const np2_read_t rd = reads[r];
+    const uint8_t *base = nib + rd.nib_off;
+    const uint32_t ts = rd.aln_t_s;
+    // AlignBase of column c whose t_pos is known; delta = insertion run length ending at c
+    auto mk = [&](int64_t c, uint32_t t) -> AlignBase {
+        if (c == -2) return ab_head(ts - 1, 0);
+        if (c == -1) return ab_head(ts - 1, 1);
+        const uint8_t nb = nib_at(base, (uint32_t)c);
+        AlignBase a;
+        a.q = nb & 7;
+        a.t_pos = t;
+        a.delta = 0;
+        if (c > 0 && (nb & 8)) {
+            uint16_t dl = 1;
+            int64_t x = c - 1;
+            while (x > 0 && (nib_at(base, (uint32_t)x) & 8)) {
+                dl = (uint16_t)(dl + 1);
+                --x;
+            }
+            a.delta = dl;
+        }
+        return a;
+    };
+    auto is_ins = [&](int64_t c) -> bool { return c > 0 && (nib_at(base, (uint32_t)c) & 8); };
+    const int64_t c3 = col;
+    const AlignBase b3 = mk(c3, t3);
+    const uint32_t t2 = is_ins(c3) ? t3 : t3 - 1;
+    const AlignBase b2 = mk(c3 - 1, t2);
+    const uint32_t t1 = is_ins(c3 - 1) ? t2 : t2 - 1;
+    const AlignBase b1 = mk(c3 - 2, t1);
+    return ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// once per contig: bucket layout, in-LDS tile sort (or the device-wide sort for oversized tiles)
+// ------------------------------------------------------------------------------------------------------
+// single block: per-tile record counts -> tile_n (the cursors are reset for the next contig), exclusive scans of
+// the true counts (tile_scan: compact layout) and of the bucket-resident counts (tile_scanb), and the mailbox:
+// out[0] = T, out[1] = largest tile, out[2] = records spilled to the overflow area
+__global__ __launch_bounds__(1024) void k_tile_layout(uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
+                                                      uint32_t bucket_cap, uint32_t *__restrict__ tile_n,
+                                                      uint32_t *__restrict__ tile_scan, uint32_t *__restrict__ tile_scanb,
+                                                      const uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ out) {
+    __shared__ uint32_t pa[1024];
+    __shared__ uint32_t pb[1024];
+    __shared__ uint32_t red[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023) / 1024;
+    const uint32_t a = min(n_tiles, tid * per), b = min(n_tiles, a + per);
+    uint32_t sa = 0, sb = 0, mx = 0;
+    for (uint32_t i = a; i < b; ++i) {
+        const uint32_t v = tile_cur[i];
+        sa += v;
+        sb += min(v, bucket_cap);
+        mx = max(mx, v);
+    }
+    pa[tid] = sa;
+    pb[tid] = sb;
+    red[tid] = mx;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scans + running max
+        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
+        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
+        const uint32_t m = tid >= o ? red[tid - o] : 0u;
+        __syncthreads();
+        pa[tid] += va;
+        pb[tid] += vb;
+        red[tid] = max(red[tid], m);
+        __syncthreads();
+    }
+    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
+    for (uint32_t i = a; i < b; ++i) {
+        const uint32_t v = tile_cur[i];
+        tile_n[i] = v;
+        tile_scan[i] = ra;
+        tile_scanb[i] = rb;
+        tile_cur[i] = 0;
+        ra += v;
+        rb += min(v, bucket_cap);
+    }
+    if (tid == 1023) {
+        tile_scan[n_tiles] = pa[1023];
+        tile_scanb[n_tiles] = pb[1023];
+        out[0] = pa[1023];
+        out[1] = red[1023];
+        out[2] = *ovf_cnt;
+    }
+}
+
+// one block per tile: raw records of the tile's bucket -> node keys, bitonic sort of the (key, read) pairs in LDS,
+// written back in place.  Pairs are unique, so the result does not depend on the order the bucket was filled in.
+template <uint32_t CAP>
+__global__ __launch_bounds__(256) void k_tile_sort(const np2_read_t *__restrict__ reads,
+                                                   const uint8_t *__restrict__ nib, const uint32_t *__restrict__ tile_n,
+                                                   uint32_t bucket_cap, uint64_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ vals, uint32_t *__restrict__ err) {
+    __shared__ uint64_t sk[CAP];
+    __shared__ uint32_t sv[CAP];
+    const uint32_t n = tile_n[blockIdx.x];
+    const uint64_t a = (uint64_t)blockIdx.x * bucket_cap;
+    if (n == 0) return;
+    if (n > CAP) {
+        if (threadIdx.x == 0) atomicOr(err, 8u);
+        return;
+    }
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += 256) {
+        uint64_t k = ~0ULL;
+        uint32_t r = ~0u;
+        if (i < n) {
+            r = vals[a + i];
+            k = make_node_key(reads, nib, keys[a + i], r);
+        }
+        sk[i] = k;
+        sv[i] = r;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256) {
+                // t-th compare-exchange of this stage: i has bit j clear
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t x = i | j;
+                const bool asc = (i & k) == 0;
+                const uint64_t ki = sk[i], kx = sk[x];
+                const uint32_t vi = sv[i], vx = sv[x];
+                const bool gt = ki > kx || (ki == kx && vi > vx);
+                if (gt == asc) {
+                    sk[i] = kx;
+                    sk[x] = ki;
+                    sv[i] = vx;
+                    sv[x] = vi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        keys[a + i] = sk[i];
+        vals[a + i] = sv[i];
+    }
+}
+
+// oversized tiles: gather bucket-resident and spilled raw records into one compact array of node keys
+// (sorted device-wide afterwards)
+__global__ __launch_bounds__(256) void k_gather_buckets(const np2_read_t *__restrict__ reads,
+                                                        const uint8_t *__restrict__ nib,
+                                                        const uint32_t *__restrict__ tile_n,
+                                                        const uint32_t *__restrict__ tile_scanb, uint32_t bucket_cap,
+                                                        const uint64_t *__restrict__ bkeys,
+                                                        const uint32_t *__restrict__ bvals, uint64_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals) {
+    const uint32_t n = min(tile_n[blockIdx.x], bucket_cap);
+    const uint64_t a = (uint64_t)blockIdx.x * bucket_cap;
+    const uint32_t dst = tile_scanb[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t r = bvals[a + i];
+        keys[dst + i] = make_node_key(reads, nib, bkeys[a + i], r);
+        vals[dst + i] = r;
+    }
+}
+__global__ void k_gather_spill(const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib,
+                               const uint64_t *__restrict__ okeys, const uint32_t *__restrict__ ovals, uint32_t n,
+                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = ovals[i];
+    keys[i] = make_node_key(reads, nib, okeys[i], r);
+    vals[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per pass: nodes of the live reads, node offsets, dirty runs
+// ------------------------------------------------------------------------------------------------------
+// is record i the head of a key group with at least one live read?  (count / first read of the group)
+__device__ __forceinline__ bool group_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                           const uint8_t *__restrict__ alive, uint64_t i, uint64_t a, uint64_t b,
+                                           uint32_t &cnt, uint32_t &mn) {
+    const uint64_t k = keys[i];
+    if (i > a && keys[i - 1] == k) return false;
+    cnt = 0;
+    mn = 0xFFFFFFFFu;
+    for (uint64_t j = i; j < b && keys[j] == k; ++j) {
+        const uint32_t r = vals[j];
+        if (alive[r]) {
+            ++cnt;
+            mn = min(mn, r);
+        }
+    }
+    return cnt != 0;
+}
+// does position p (the last position of the previous tile, whose records are [a, b)) hold a live exception node?
+__device__ __forceinline__ bool prev_pos_dirty(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                               const uint8_t *__restrict__ alive, uint64_t a, uint64_t b, uint32_t p) {
+    for (uint64_t i = b; i-- > a;) {
+        if ((uint32_t)(keys[i] >> 32) != p) return false;
+        if (alive[vals[i]]) return true;
+    }
+    return false;
+}
+
+// records of tile t: [a, a + tile_n[t]) with a = t * bucket_cap (bucketed layout) or tile_scan[t] (compact layout)
+struct TileLayout {
+    const uint32_t *tile_n;
+    const uint32_t *tile_scan;
+    uint32_t bucket_cap; // 0 = compact layout
+    __device__ __forceinline__ uint64_t begin(uint32_t t) const {
+        return bucket_cap ? (uint64_t)t * bucket_cap : (uint64_t)tile_scan[t];
+    }
+};
+
+__global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ keys,
+                                                    const uint32_t *__restrict__ vals, TileLayout tl,
+                                                    const uint8_t *__restrict__ alive,
+                                                    uint32_t *__restrict__ tile_nn, uint32_t *__restrict__ tile_nr) {
+    __shared__ uint32_t dirty[TILE / 32];
+    __shared__ uint32_t acc[2];
+    __shared__ uint32_t prevd;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t a = tl.begin(blockIdx.x), b = a + tl.tile_n[blockIdx.x];
+    const uint32_t start = blockIdx.x << TILE_SHIFT;
+    if (tid < TILE / 32) dirty[tid] = 0;
+    if (tid < 2) acc[tid] = 0;
+    if (tid == 0) {
+        prevd = 0;
+        if (start && b > a) {
+            const uint64_t pa = tl.begin(blockIdx.x - 1);
+            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    uint32_t nn = 0;
+    for (uint64_t i = a + tid; i < b; i += 256) {
+        uint32_t cnt, mn;
+        if (group_head(keys, vals, alive, i, a, b, cnt, mn)) {
+            ++nn;
+            const uint32_t q = (uint32_t)(keys[i] >> 32) - start;
+            atomicOr(&dirty[q >> 5], 1u << (q & 31));
+        }
+    }
+    if (nn) atomicAdd(&acc[0], nn);
+    __syncthreads();
+    if (tid < TILE / 32) {
+        const uint32_t d = dirty[tid];
+        const uint32_t carry = tid ? dirty[tid - 1] >> 31 : prevd;
+        const uint32_t starts = d & ~((d << 1) | carry);
+        if (starts) atomicAdd(&acc[1], (uint32_t)__builtin_popcount(starts));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tile_nn[blockIdx.x] = acc[0];
+        tile_nr[blockIdx.x] = acc[1];
+    }
+}
+
+// single block: exclusive scans of the per-tile node and run counts; totals -> n_nodes / n_runs
+__global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restrict__ tile_nn,
+                                                       const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
+                                                       uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
+                                                       uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs) {
+    __shared__ uint32_t pa[1024];
+    __shared__ uint32_t pb[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023) / 1024;
+    const uint32_t a = min(n_tiles, tid * per), b = min(n_tiles, a + per);
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t i = a; i < b; ++i) {
+        sa += tile_nn[i];
+        sb += tile_nr[i];
+    }
+    pa[tid] = sa;
+    pb[tid] = sb;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
+        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
+        __syncthreads();
+        pa[tid] += va;
+        pb[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
+    for (uint32_t i = a; i < b; ++i) {
+        tile_noff[i] = ra;
+        tile_roff[i] = rb;
+        ra += tile_nn[i];
+        rb += tile_nr[i];
+    }
+    if (tid == 1023) {
+        *n_nodes = pa[1023];
+        *n_runs = pb[1023];
+    }
+}
+
+// one block per tile: write the tile's nodes (ordered like Msa::sort over first-seen order: delta3, first read),
+// the packed DP records, node_off for every position of the tile and the tile's dirty-run starts
+__global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__ keys,
+                                                    const uint32_t *__restrict__ vals, TileLayout tl,
+                                                    const uint32_t *__restrict__ tile_noff,
+                                                    const uint32_t *__restrict__ tile_roff,
+                                                    const uint8_t *__restrict__ alive, uint32_t L,
+                                                    uint32_t n_tiles, NodeArrays nd, uint2 *__restrict__ nrec,
+                                                    uint32_t *__restrict__ node_off, uint32_t *__restrict__ run_start) {
+    __shared__ uint32_t cnt[TILE];
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t prevd;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t a = tl.begin(blockIdx.x), b = a + tl.tile_n[blockIdx.x];
+    const uint32_t start = blockIdx.x << TILE_SHIFT;
+    const uint32_t npos = min((uint32_t)TILE, L - start);
+    const uint32_t nbase = tile_noff[blockIdx.x];
+    for (uint32_t i = tid; i < TILE; i += 256) cnt[i] = 0;
+    if (tid == 0) {
+        prevd = 0;
+        if (start && b > a) {
+            const uint64_t pa = tl.begin(blockIdx.x - 1);
+            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    // ---- nodes in key order ---------------------------------------------------------------------------
+    uint32_t carry = 0;
+    for (uint64_t c0 = a; c0 < b; c0 += 256) { // uniform trip count: the block scans below need every thread
+        const uint64_t i = c0 + tid;
+        uint32_t gc = 0, gm = 0;
+        const bool isnode = i < b && group_head(keys, vals, alive, i, a, b, gc, gm);
+        uint32_t tot;
+        const uint32_t rank = block_excl_scan_256(isnode ? 1u : 0u, sh, tot);
+        if (isnode) {
+            const uint64_t k = keys[i];
+            const uint32_t o = nbase + carry + rank;
+            nd.pos[o] = (uint32_t)(k >> 32);
+            nd.bases[o] = (uint16_t)(k >> 16);
+            nd.delta[o] = (uint16_t)k;
+            nd.count[o] = gc;
+            nd.minr[o] = gm;
+            atomicAdd(&cnt[(uint32_t)(k >> 32) - start], 1u);
+        }
+        carry += tot;
+    }
+    __syncthreads();
+    // ---- node_off of the tile's positions (4 consecutive positions per thread) --------------------------
+    const uint32_t q0 = tid * 4;
+    const uint32_t c0 = cnt[q0], c1 = cnt[q0 + 1], c2 = cnt[q0 + 2], c3 = cnt[q0 + 3];
+    uint32_t tot;
+    const uint32_t e0 = nbase + block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot);
+    const uint32_t off[5] = {e0, e0 + c0, e0 + c0 + c1, e0 + c0 + c1 + c2, e0 + c0 + c1 + c2 + c3};
+    for (uint32_t j = 0; j < 4; ++j)
+        if (q0 + j < npos) node_off[start + q0 + j] = off[j];
+    if (blockIdx.x == n_tiles - 1 && tid == 255) node_off[L] = off[4];
+    // ---- order the nodes of each position, emit the packed records ---------------------------------------
+    const uint32_t cj[4] = {c0, c1, c2, c3};
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (cj[j] == 0) continue;
+        const uint32_t o0 = off[j], o1 = off[j + 1];
+        for (uint32_t i = o0 + 1; i < o1; ++i) {
+            const uint16_t bb = nd.bases[i], d = nd.delta[i];
+            const uint32_t c = nd.count[i], m = nd.minr[i];
+            const uint32_t kd = node_delta3(bb, d);
+            uint32_t x = i;
+            while (x > o0) {
+                const uint32_t pd = node_delta3(nd.bases[x - 1], nd.delta[x - 1]);
+                if (pd < kd || (pd == kd && nd.minr[x - 1] < m)) break;
+                nd.bases[x] = nd.bases[x - 1];
+                nd.delta[x] = nd.delta[x - 1];
+                nd.count[x] = nd.count[x - 1];
+                nd.minr[x] = nd.minr[x - 1];
+                --x;
+            }
+            nd.bases[x] = bb;
+            nd.delta[x] = d;
+            nd.count[x] = c;
+            nd.minr[x] = m;
+        }
+        for (uint32_t i = o0; i < o1; ++i)
+            nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
+    }
+    // ---- dirty-run starts ----------------------------------------------------------------------------------
+    const bool pd0 = q0 ? cnt[q0 - 1] != 0 : prevd != 0;
+    const bool s0 = c0 && !pd0, s1 = c1 && !c0, s2 = c2 && !c1, s3 = c3 && !c2;
+    uint32_t r = tile_roff[blockIdx.x] +
+                 block_excl_scan_256((uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3, sh, tot);
+    if (s0) run_start[r++] = start + q0;
+    if (s1) run_start[r++] = start + q0 + 1;
+    if (s2) run_start[r++] = start + q0 + 2;
+    if (s3) run_start[r++] = start + q0 + 3;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
+                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out) {
+    hipLaunchKernelGGL(k_tile_layout, dim3(1), dim3(1024), 0, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan,
+                       tile_scanb, ovf_cnt, out);
+}
+void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+                      uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
+                      uint32_t *err) {
+    if (max_tile <= 1024)
+        hipLaunchKernelGGL(k_tile_sort<1024>, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, bucket_cap, keys, vals,
+                           err);
+    else
+        hipLaunchKernelGGL(k_tile_sort<TILE_CAP>, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, bucket_cap, keys,
+                           vals, err);
+}
+void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+                           const uint32_t *tile_scanb, uint32_t n_tiles, uint32_t bucket_cap, const uint64_t *bkeys,
+                           const uint32_t *bvals, uint64_t *keys, uint32_t *vals) {
+    hipLaunchKernelGGL(k_gather_buckets, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, tile_scanb, bucket_cap, bkeys,
+                       bvals, keys, vals);
+}
+void launch_gather_spill(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint64_t *okeys,
+                         const uint32_t *ovals, uint32_t n, uint64_t *keys, uint32_t *vals) {
+    if (n) hipLaunchKernelGGL(k_gather_spill, dim3((n + 255) / 256), dim3(256), 0, s, reads, nib, okeys, ovals, n, keys, vals);
+}
+void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
+                       const uint32_t *tile_scan, uint32_t bucket_cap, uint32_t n_tiles, const uint8_t *alive,
+                       uint32_t *tile_nn, uint32_t *tile_nr) {
+    hipLaunchKernelGGL(k_tile_count, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
+                       alive, tile_nn, tile_nr);
+}
+void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
+                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs) {
+    hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes,
+                       n_runs);
+}
+void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
+                       const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
+                       uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
+                       uint32_t *run_start) {
+    hipLaunchKernelGGL(k_tile_write, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
+                       tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start);
+}
+
+} // namespace np2

@@ -385,14 +385,30 @@ struct PassOut {
     Cns cns; // raw consensus of this pass (host copy, only when needed)
 };
 
+// Dense pass + exception sort.  Afterwards the sorted (node key, read) records of contig tile t are
+// keys_raw / vals_raw [a, a + tile_n[t]) with a = t * cx->bucket_cap (bucketed layout, the normal case) or
+// a = tile_scan[t] when cx->bucket_cap == 0 (compact layout after the device-wide sort).
 void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L, R = c->R, NCH = c->n_chunks;
-    const uint64_t slots = (uint64_t)NCH * SLOT_CAP;
-    uint64_t ovf_total = std::max<uint64_t>(c->n_cols / 256 + 65536, 1u << 18); // overflow area (chunks with > SLOT_CAP)
+    const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
+    const uint32_t bcap = cx->tile_cap;
+    const uint64_t buckets = (uint64_t)n_tiles * bcap;
+    uint64_t ovf_cap = std::max<uint64_t>(c->n_cols / 256 + 65536, 1u << 18); // spill area of full buckets
     cx->chunk_n.ensure(NCH + 2);
     cx->chunk_pre.ensure(NCH + 2);
     cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)NCH + 2, (size_t)L + 2)));
+    cx->tile_n.ensure(n_tiles + 2);
+    cx->tile_scan.ensure(n_tiles + 2);
+    cx->tile_scanb.ensure(n_tiles + 2);
+    cx->tile_nn.ensure(n_tiles + 2);
+    cx->tile_nr.ensure(n_tiles + 2);
+    cx->tile_noff.ensure(n_tiles + 2);
+    cx->tile_roff.ensure(n_tiles + 2);
+    if (cx->tile_cur.cap < (size_t)n_tiles + 2) { // the cursors are left zeroed by k_tile_layout; clear new storage
+        cx->tile_cur.ensure(n_tiles + 2);
+        zero32(cx, cx->tile_cur.p, cx->tile_cur.cap);
+    }
     {
         EventTimer t(cx, "chunk_prefix");
         launch_chunk_count(s, c->descs.p, c->nib.p, NCH, cx->chunk_n.p);
@@ -401,83 +417,66 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         launch_fill_carry(s, c->descs.p, cx->chunk_pre.p, NCH);
     }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        const uint32_t shard_cap = (uint32_t)((ovf_total + NSHARD - 1) / NSHARD);
-        const uint64_t cap = slots + (uint64_t)shard_cap * NSHARD;
-        cx->keys_raw.ensure(cap + 1);
-        cx->vals_raw.ensure(cap + 1);
-        cx->shard_cnt.ensure(NSHARD * SHARD_STRIDE + 8);
-        zero32(cx, cx->shard_cnt.p, NSHARD * SHARD_STRIDE + 8);
+        if (ovf_cap >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
+        cx->keys_raw.ensure(buckets + ovf_cap + 1);
+        cx->vals_raw.ensure(buckets + ovf_cap + 1);
         zero32(cx, cx->scal.p, S_COUNT);
         {
             EventTimer t(cx, "diff_reads");
-            // chunk_n is reused as the per-chunk tuple count
             launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
-                              cx->keys_raw.p, cx->vals_raw.p, cx->chunk_n.p, slots, cx->shard_cnt.p, shard_cap, c->ckpt.p,
-                              cx->scal.p + S_ERR);
+                              cx->keys_raw.p, cx->vals_raw.p, cx->tile_cur.p, n_tiles, bcap, buckets, (uint32_t)ovf_cap,
+                              cx->scal.p + S_M3, c->ckpt.p, cx->scal.p + S_ERR);
         }
-        uint32_t n_slot = 0;
         {
             EventTimer t(cx, "sort_exceptions");
-            zero32(cx, cx->chunk_n.p + NCH, 1);
-            exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)NCH + 1);
+            // per-tile counts / layouts + the counters the host needs, all in the mailbox: S_M0 = T, S_M1 = largest
+            // tile, S_M2 = records spilled from full buckets
+            launch_tile_layout(s, cx->tile_cur.p, n_tiles, bcap, cx->tile_n.p, cx->tile_scan.p, cx->tile_scanb.p,
+                               cx->scal.p + S_M3, cx->scal.p + S_M0);
         }
-        launch_mail(s, cx->scal.p + S_M0, cx->chunk_pre.p + NCH, cx->scal.p + S_M1, cx->shard_cnt.p + NSHARD * SHARD_STRIDE);
-        // shard counters + overflow total in one read: the last word of shard_cnt holds the sum of all shards
         std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
-        n_slot = sc[S_M0];
-        std::vector<uint32_t> cnt((size_t)NSHARD * SHARD_STRIDE, 0);
-        if (sc[S_M1]) cnt = d2h(cx, cx->shard_cnt.p, (size_t)NSHARD * SHARD_STRIDE);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
-        uint32_t mx = 0;
-        std::vector<uint64_t> off(NSHARD + 1, 0);
-        off[0] = n_slot;
-        for (int i = 0; i < NSHARD; ++i) {
-            mx = std::max(mx, cnt[(size_t)i * SHARD_STRIDE]);
-            off[i + 1] = off[i] + cnt[(size_t)i * SHARD_STRIDE];
-        }
-        const uint64_t total = off[NSHARD];
-        if (mx > shard_cap) { // an overflow shard overflowed: grow and redo the dense pass
-            ovf_total = (uint64_t)mx * NSHARD * 5 / 4 + 65536;
+        if (sc[S_M2] > ovf_cap) { // the spill area itself overflowed: grow and redo the dense pass
+            ovf_cap = (uint64_t)sc[S_M2] * 5 / 4 + 65536;
             continue;
         }
-        if (total >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
-        T = (uint32_t)total;
-        cx->keys.ensure(T + 1);
-        cx->vals.ensure(T + 1);
-        cx->shard_off.ensure(NSHARD + 1);
-        h2d_staged(cx, cx->shard_off.p, off.data(), (NSHARD + 1) * 8);
+        T = sc[S_M0];
+        if (T >= 0xFFFFFFF0u) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
         cx->tmp.ensure(prim_temp_bytes(std::max<size_t>({(size_t)T + 1, (size_t)L + 2, (size_t)R + 1})));
-        {
-            EventTimer t(cx, "sort_exceptions");
-            // gather slots + overflow shards into keys/vals, sort back into keys_raw/vals_raw
-            launch_compact_slots(s, cx->keys_raw.p, cx->vals_raw.p, cx->chunk_n.p, cx->chunk_pre.p, NCH, cx->keys.p,
-                                 cx->vals.p);
-            if (total > n_slot)
-                launch_compact_shards(s, cx->keys_raw.p, cx->vals_raw.p, slots, shard_cap, cx->shard_cnt.p,
-                                      cx->shard_off.p, cx->keys.p, cx->vals.p);
-            launch_make_nodes(s, c->reads.p, c->nib.p, cx->keys.p, cx->vals.p, T); // raw records -> node keys
+        EventTimer t(cx, "sort_exceptions");
+        if (sc[S_M2] == 0) {
+            // raw records -> node keys, sorted by (key, read) inside LDS, tile by tile, in place
+            launch_tile_sort(s, c->reads.p, c->nib.p, cx->tile_n.p, n_tiles, bcap, sc[S_M1], cx->keys_raw.p,
+                             cx->vals_raw.p, cx->scal.p + S_ERR);
+            cx->bucket_cap = bcap;
+        } else {
+            // some tile holds more records than a bucket (e.g. a long insertion carried by every read): gather
+            // buckets + spill area into one array and sort it device-wide
+            cx->keys.ensure((size_t)T + 1);
+            cx->vals.ensure((size_t)T + 1);
+            const uint32_t nb = T - sc[S_M2];
+            launch_gather_buckets(s, c->reads.p, c->nib.p, cx->tile_n.p, cx->tile_scanb.p, n_tiles, bcap, cx->keys_raw.p,
+                                  cx->vals_raw.p, cx->keys.p, cx->vals.p);
+            launch_gather_spill(s, c->reads.p, c->nib.p, cx->keys_raw.p + buckets, cx->vals_raw.p + buckets, sc[S_M2],
+                                cx->keys.p + nb, cx->vals.p + nb);
             unsigned pos_bits = 1;
             while ((1ull << pos_bits) < (uint64_t)L + 1) ++pos_bits;
             int rc = prim_sort_pairs_u64_u32(s, cx->tmp.p, cx->tmp.cap, cx->keys.p, cx->keys_raw.p, cx->vals.p,
                                              cx->vals_raw.p, T, 32 + pos_bits);
             if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
+            cx->bucket_cap = 0;
         }
-        HIPCHK(hipStreamSynchronize(s));
         return;
     }
     throw Np2Error(NP2_E_NOMEM, "exception buffer kept overflowing");
 }
 
-// sorted exception tuples live in keys_raw / vals_raw after run_diff
 void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint32_t &n_runs) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L, R = c->R;
+    const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
     EventTimer t(cx, "build_graph");
-    cx->gcount.ensure(T + 1);
-    cx->gmin.ensure(T + 1);
-    cx->flag.ensure(std::max<size_t>((size_t)T + 1, (size_t)L + 2));
-    cx->idx.ensure(std::max<size_t>((size_t)T + 1, (size_t)L + 2));
     cx->npos.ensure(T + 1);
     cx->nbases.ensure(T + 1);
     cx->ndelta.ensure(T + 1);
@@ -485,31 +484,24 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->nminr.ensure(T + 1);
     cx->nscore.ensure(T + 1);
     cx->nbesti.ensure(T + 1);
-    cx->node_cnt.ensure(L + 2);
+    cx->nrec.ensure(T + 1);
     cx->node_off.ensure(L + 2);
     cx->covd.ensure(L + 2);
     cx->cov.ensure(L + 2);
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
-    zero32(cx, cx->node_cnt.p, L + 2);
     zero32(cx, cx->scal.p, S_COUNT);
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
-    if (T) {
-        launch_group_nodes(s, cx->keys_raw.p, cx->vals_raw.p, T, cx->alive.p, cx->gcount.p, cx->gmin.p, cx->flag.p);
-        exclusive_total(cx, cx->flag.p, cx->idx.p, T);
-        launch_scatter_nodes(s, cx->keys_raw.p, cx->gcount.p, cx->gmin.p, cx->idx.p, T, nd, cx->node_cnt.p,
-                             cx->scal.p + S_NNODES);
-    }
-    exclusive_total(cx, cx->node_cnt.p, cx->node_off.p, (size_t)L + 1);
-    cx->nrec.ensure(T + 1);
-    launch_order_nodes(s, cx->node_off.p, L, nd, cx->nrec.p);
+    launch_tile_count(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, n_tiles,
+                      cx->alive.p, cx->tile_nn.p, cx->tile_nr.p);
+    launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
+                        cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS);
+    launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
+                      cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p);
     zero32(cx, cx->covd.p, L + 2);
     launch_cov_delta(s, c->reads.p, R, cx->alive.p, cx->covd.p);
     if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->covd.p, cx->cov.p, (size_t)L + 1))
         throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
-    launch_mark_runs(s, cx->node_off.p, L, cx->flag.p);
-    exclusive_total(cx, cx->flag.p, cx->idx.p, L);
-    launch_scatter_idx(s, cx->flag.p, cx->idx.p, L, cx->run_start.p, cx->scal.p + S_NRUNS);
     // no read-back: downstream kernels are launched with the bound below and check the device-side counters
     n_runs = std::min<uint32_t>(T, L);
     n_nodes = T;
@@ -966,6 +958,8 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
         cx->scal.ensure(S_COUNT);
+        if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
+            cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
         cx->yaks.resize(n_yak);
         for (int i = 0; i < n_yak; ++i) {
             const np2_yak_t &y = yaks[i];

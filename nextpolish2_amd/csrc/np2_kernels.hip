@@ -140,14 +140,14 @@ __global__ void k_fill_carry(ChunkDesc *__restrict__ descs, const uint32_t *__re
 
 // Dense pass: one wavefront per 2048-column chunk.  The kernel is VALU-issue bound (not latency bound), so it does
 // the minimum per column: classify columns as exceptions and emit raw (read, column, t_pos) records; the 3-column
-// node keys are built afterwards by k_make_nodes, one thread per exception.  Exception records go to the chunk's
-// private output slot (SLOT_CAP records); only a chunk with more exceptions reserves space in the sharded overflow area.
+// node keys are built afterwards by the tile sort (np2_graph.hip).  Records go straight into the fixed-capacity
+// bucket of their contig tile (TILE positions); a full bucket spills to a shared overflow area (rare).
 __global__ __launch_bounds__(256) void k_diff_reads(
     const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
     const uint64_t *__restrict__ refw, const uint8_t *__restrict__ refnib, uint32_t L,
-    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ chunk_cnt,
-    uint64_t ovf_base, uint32_t *__restrict__ shard_cnt, uint32_t shard_cap, uint32_t *__restrict__ ckpt,
-    uint32_t *__restrict__ err) {
+    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
+    uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
+    uint32_t *__restrict__ ckpt, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (ch >= n_chunks) return;
@@ -235,43 +235,70 @@ __global__ __launch_bounds__(256) void k_diff_reads(
     uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
     if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
     E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-    uint32_t n_tuples = 0;
     if (__ballot(E != 0)) {
+        // The chunk's columns sit at contig positions [ts + carryN - 1, ts + carryN + 2047]: at most three contig
+        // tiles.  Records are position-ordered across the wave, so the tile boundaries split them into three
+        // consecutive groups; each group reserves its place in its tile's bucket with one wave-level atomic.
         const uint32_t cnt = __builtin_popcount(E);
         const uint32_t inc2 = wave_incl_scan(cnt);
         const uint32_t tot = __shfl(inc2, 63);
-        uint64_t obase, olimit;
-        if (tot <= SLOT_CAP) { // private slot: no reservation round trip
-            obase = (uint64_t)ch * SLOT_CAP;
-            olimit = obase + SLOT_CAP;
-            n_tuples = tot;
-        } else {
-            const uint32_t shard = ch & (NSHARD - 1);
-            uint32_t bp = 0;
-            if (lane == 0) {
-                bp = atomicAdd(&shard_cnt[shard * SHARD_STRIDE], tot);
-                atomicAdd(&shard_cnt[NSHARD * SHARD_STRIDE], tot); // grand total (overflow chunks are rare)
+        const uint32_t s0 = ts + carryN;
+        const uint32_t tA = (s0 ? s0 - 1 : 0u) >> TILE_SHIFT;
+        const uint32_t P1 = (tA + 1) << TILE_SHIFT, P2 = (tA + 2) << TILE_SHIFT;
+        const uint32_t t_last = t0 + nonins - 1;              // t_pos of the lane's last column
+        const uint32_t t_first = t0 - ((im & 1u) ? 1u : 0u);  // a leading insertion column belongs to t0 - 1
+        auto below = [&](uint32_t P) -> uint32_t { // records of the wave with t_pos < P
+            const uint32_t nb = __builtin_popcountll(__ballot(nv != 0 && t_last < P)); // lanes entirely below: a prefix
+            uint32_t c = nb ? __shfl(inc2, nb - 1) : 0u;
+            uint32_t part = 0;
+            if (lane == nb && cnt && t_first < P) { // the one lane straddling the boundary
+                uint32_t e = E;
+                while (e) {
+                    const uint32_t j = __builtin_ctz(e);
+                    e &= e - 1;
+                    const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
+                    if (t0 + __builtin_popcount(~im & low) - 1 < P) ++part; else break;
+                }
             }
-            bp = __shfl(bp, 0);
-            obase = ovf_base + (uint64_t)shard * shard_cap + bp;
-            olimit = ovf_base + (uint64_t)(shard + 1) * shard_cap;
+            if (nb < 64) c += __shfl(part, nb);
+            return c;
+        };
+        const uint32_t nb1 = below(P1), nb2 = below(P2);
+        uint32_t rb = 0; // lane j < 3: reservation of group j in bucket tA + j
+        if (lane < 3) {
+            const uint32_t cj = lane == 0 ? nb1 : (lane == 1 ? nb2 - nb1 : tot - nb2);
+            if (cj) {
+                if (tA + lane < n_tiles) rb = atomicAdd(&tile_cur[tA + lane], cj);
+                else rb = 0xFFFFFFFFu - cj; // position >= L: the descriptor check below reports the read
+            }
         }
-        uint64_t o = obase + (inc2 - cnt);
+        const uint32_t b0 = __shfl(rb, 0), b1 = __shfl(rb, 1), b2 = __shfl(rb, 2);
+        uint32_t o = inc2 - cnt; // rank of the lane's first record within the wave
         uint32_t e = E;
         while (e) { // raw record: t_pos << 32 | column, read
             const uint32_t j = __builtin_ctz(e);
             e &= e - 1;
             const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
-            const uint32_t t = ts + Nb + __builtin_popcount(~im & low) - 1;
-            if (o < olimit) {
-                out_keys[o] = ((uint64_t)t << 32) | (lc0 + j);
-                out_vals[o] = d.read;
+            const uint32_t t = t0 + __builtin_popcount(~im & low) - 1;
+            const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
+            const uint32_t slot = (g == 0 ? b0 + o : (g == 1 ? b1 + (o - nb1) : b2 + (o - nb2)));
+            uint64_t dst;
+            bool ok = tA + g < n_tiles;
+            if (slot < bucket_cap) {
+                dst = (uint64_t)(tA + g) * bucket_cap + slot;
+            } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
+                const uint32_t x = atomicAdd(ovf_cnt, 1u);
+                dst = ovf_base + x;
+                ok = ok && x < ovf_cap;
+            }
+            if (ok) {
+                out_keys[dst] = ((uint64_t)t << 32) | (lc0 + j);
+                out_vals[dst] = d.read;
             }
             ++o;
         }
     }
     if (lane == 0) {
-        chunk_cnt[ch] = n_tuples;
         if (c0 + 2048 >= ncols) {
             // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
             if (ncols == 0 || ts + carryN + total - 1 != d.aln_t_e || d.aln_t_e >= L) atomicOr(err, 2u);
@@ -280,149 +307,9 @@ __global__ __launch_bounds__(256) void k_diff_reads(
     }
 }
 
-// one thread per exception record: (read, column, t_pos) -> node key pos << 32 | bases << 16 | delta1
-// (Kmer::new over the columns c-2, c-1, c; head sentinels before a read's first column, main.rs:579-585)
-__global__ void k_make_nodes(const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib,
-                             uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t T) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
-    const uint64_t rec = keys[i];
-    const uint32_t col = (uint32_t)rec, t3 = (uint32_t)(rec >> 32), r = vals[i];
-    const np2_read_t rd = reads[r];
-    const uint8_t *base = nib + rd.nib_off;
-    const uint32_t ts = rd.aln_t_s;
-    // AlignBase of column c whose t_pos is known; delta = insertion run length ending at c
-    auto mk = [&](int64_t c, uint32_t t) -> AlignBase {
-        if (c == -2) return ab_head(ts - 1, 0);
-        if (c == -1) return ab_head(ts - 1, 1);
-        const uint8_t nb = nib_at(base, (uint32_t)c);
-        AlignBase a;
-        a.q = nb & 7;
-        a.t_pos = t;
-        a.delta = 0;
-        if (c > 0 && (nb & 8)) {
-            uint16_t dl = 1;
-            int64_t x = c - 1;
-            while (x > 0 && (nib_at(base, (uint32_t)x) & 8)) {
-                dl = (uint16_t)(dl + 1);
-                --x;
-            }
-            a.delta = dl;
-        }
-        return a;
-    };
-    auto is_ins = [&](int64_t c) -> bool { return c > 0 && (nib_at(base, (uint32_t)c) & 8); };
-    const int64_t c3 = col;
-    const AlignBase b3 = mk(c3, t3);
-    const uint32_t t2 = is_ins(c3) ? t3 : t3 - 1;
-    const AlignBase b2 = mk(c3 - 1, t2);
-    const uint32_t t1 = is_ins(c3 - 1) ? t2 : t2 - 1;
-    const AlignBase b1 = mk(c3 - 2, t1);
-    keys[i] = ((uint64_t)b3.t_pos << 32) | ((uint64_t)node_bases(b1, b2, b3) << 16) | b1.delta;
-}
-
-// gather the per-chunk slots into the compact tuple array
-__global__ void k_compact_slots(const uint64_t *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
-                                const uint32_t *__restrict__ chunk_cnt, const uint32_t *__restrict__ chunk_out,
-                                uint32_t n_chunks, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ch = i / SLOT_CAP, k = i % SLOT_CAP;
-    if (ch >= n_chunks || k >= chunk_cnt[ch]) return;
-    out_keys[chunk_out[ch] + k] = in_keys[(uint64_t)ch * SLOT_CAP + k];
-    out_vals[chunk_out[ch] + k] = in_vals[(uint64_t)ch * SLOT_CAP + k];
-}
-
-__global__ void k_compact_shards(const uint64_t *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
-                                 uint64_t ovf_base, uint32_t shard_cap, const uint32_t *__restrict__ shard_cnt,
-                                 const uint64_t *__restrict__ shard_off, uint64_t *__restrict__ out_keys,
-                                 uint32_t *__restrict__ out_vals) {
-    const uint32_t s = blockIdx.x;
-    const uint32_t n = shard_cnt[s * SHARD_STRIDE];
-    const uint64_t src = ovf_base + (uint64_t)s * shard_cap, dst = shard_off[s];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        out_keys[dst + i] = in_keys[src + i];
-        out_vals[dst + i] = in_vals[src + i];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K3: per pass — group identical exception nodes of live reads (Msa::push, main.rs:193-207)
-// ------------------------------------------------------------------------------------------
-__global__ void k_group_nodes(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t T,
-                              const uint8_t *__restrict__ alive, uint32_t *__restrict__ gcount,
-                              uint32_t *__restrict__ gmin) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
-    const uint64_t k = keys[i];
-    if (i > 0 && keys[i - 1] == k) {
-        gcount[i] = 0;
-        return;
-    }
-    uint32_t cnt = 0, mn = 0xFFFFFFFFu;
-    for (uint32_t j = i; j < T && keys[j] == k; ++j) {
-        const uint32_t r = vals[j];
-        if (alive[r]) {
-            ++cnt;
-            mn = min(mn, r);
-        }
-    }
-    gcount[i] = cnt;
-    gmin[i] = mn;
-}
-
 __global__ void k_flag_nonzero(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = in[i] != 0;
-}
-
-__global__ void k_scatter_nodes(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ gcount,
-                                const uint32_t *__restrict__ gmin, const uint32_t *__restrict__ idx, uint32_t T,
-                                NodeArrays nd, uint32_t *__restrict__ node_cnt, uint32_t *__restrict__ n_nodes) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
-    const uint32_t c = gcount[i];
-    if (c) {
-        const uint32_t o = idx[i];
-        const uint64_t k = keys[i];
-        nd.pos[o] = (uint32_t)(k >> 32);
-        nd.bases[o] = (uint16_t)(k >> 16);
-        nd.delta[o] = (uint16_t)k;
-        nd.count[o] = c;
-        nd.minr[o] = gmin[i];
-        atomicAdd(&node_cnt[(uint32_t)(k >> 32)], 1u);
-    }
-    if (i == T - 1) *n_nodes = idx[i] + (c ? 1u : 0u);
-}
-
-// order the nodes of one position like Msa::sort over first-seen order: (delta3, first read); also emits the
-// packed 8-byte records {bases | delta << 16, count} the DP kernels read
-__global__ void k_order_nodes(const uint32_t *__restrict__ node_off, uint32_t L, NodeArrays nd,
-                              uint2 *__restrict__ nrec) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= L) return;
-    const uint32_t o0 = node_off[p], o1 = node_off[p + 1];
-    if (o1 == o0) return;
-    for (uint32_t i = o0 + 1; i < o1; ++i) {
-        const uint16_t b = nd.bases[i], d = nd.delta[i];
-        const uint32_t c = nd.count[i], m = nd.minr[i];
-        const uint32_t kd = node_delta3(b, d);
-        uint32_t j = i;
-        while (j > o0) {
-            const uint32_t pd = node_delta3(nd.bases[j - 1], nd.delta[j - 1]);
-            if (pd < kd || (pd == kd && nd.minr[j - 1] < m)) break;
-            nd.bases[j] = nd.bases[j - 1];
-            nd.delta[j] = nd.delta[j - 1];
-            nd.count[j] = nd.count[j - 1];
-            nd.minr[j] = nd.minr[j - 1];
-            --j;
-        }
-        nd.bases[j] = b;
-        nd.delta[j] = d;
-        nd.count[j] = c;
-        nd.minr[j] = m;
-    }
-    for (uint32_t i = o0; i < o1; ++i)
-        nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
 }
 
 // coverage(p) = number of live reads spanning p (Msa::coverage, main.rs:232-241)
@@ -487,21 +374,6 @@ __device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
 // ------------------------------------------------------------------------------------------
 // K5/K6: dirty runs and the per-run DP (get_cns_from_align_tags, main.rs:1645-1687)
 // ------------------------------------------------------------------------------------------
-__global__ void k_mark_runs(const uint32_t *__restrict__ node_off, uint32_t L, uint32_t *__restrict__ flag) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= L) return;
-    const bool d = node_off[p + 1] > node_off[p];
-    const bool dp = p > 0 && node_off[p] > node_off[p - 1];
-    flag[p] = d && !dp;
-}
-__global__ void k_scatter_idx(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n,
-                              uint32_t *__restrict__ out, uint32_t *__restrict__ n_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) out[idx[i]] = i;
-    if (i == n - 1) *n_out = idx[i] + (flag[i] ? 1u : 0u);
-}
-
 __device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q, const AlignBase &kb1,
                                            const AlignBase &kb2, AlignBase &pb1) {
     // Msa::get(base2 = K.b1, base3 = K.b2) (main.rs:209-225)
@@ -1233,11 +1105,11 @@ void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t 
 }
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
                        const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
-                       uint32_t *chunk_cnt, uint64_t ovf_base, uint32_t *shard_cnt, uint32_t shard_cap, uint32_t *ckpt,
-                       uint32_t *err) {
+                       uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
+                       uint32_t *ovf_cnt, uint32_t *ckpt, uint32_t *err) {
     if (n_chunks)
         hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 3) / 4), dim3(256), 0, s, descs, n_chunks, nib, refw, refnib, L,
-                           keys, vals, chunk_cnt, ovf_base, shard_cnt, shard_cap, ckpt, err);
+                           keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, err);
 }
 void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n) {
     if (n_chunks)
@@ -1245,22 +1117,6 @@ void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *ni
 }
 void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks) {
     if (n_chunks) hipLaunchKernelGGL(k_fill_carry, grid1(n_chunks), dim3(256), 0, s, descs, chunk_pre, n_chunks);
-}
-void launch_make_nodes(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, uint64_t *keys, const uint32_t *vals,
-                       uint32_t T) {
-    if (T) hipLaunchKernelGGL(k_make_nodes, grid1(T), dim3(256), 0, s, reads, nib, keys, vals, T);
-}
-void launch_compact_slots(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, const uint32_t *chunk_cnt,
-                          const uint32_t *chunk_out, uint32_t n_chunks, uint64_t *out_keys, uint32_t *out_vals) {
-    if (n_chunks)
-        hipLaunchKernelGGL(k_compact_slots, grid1((uint64_t)n_chunks * SLOT_CAP), dim3(256), 0, s, in_keys, in_vals,
-                           chunk_cnt, chunk_out, n_chunks, out_keys, out_vals);
-}
-void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint64_t ovf_base,
-                           uint32_t shard_cap, const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
-                           uint32_t *out_vals) {
-    hipLaunchKernelGGL(k_compact_shards, dim3(NSHARD), dim3(256), 0, s, in_keys, in_vals, ovf_base, shard_cap, shard_cnt,
-                       shard_off, out_keys, out_vals);
 }
 void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2,
                  const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
@@ -1272,30 +1128,11 @@ void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) hipLaunchKernelGGL(k_kill_reads, grid1(n), dim3(256), 0, s, ids, n, alive);
 }
-void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,
-                        uint32_t *gcount, uint32_t *gmin, uint32_t *flag) {
-    hipLaunchKernelGGL(k_group_nodes, grid1(T), dim3(256), 0, s, keys, vals, T, alive, gcount, gmin);
-    hipLaunchKernelGGL(k_flag_nonzero, grid1(T), dim3(256), 0, s, gcount, T, flag);
-}
 void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag) {
     if (n) hipLaunchKernelGGL(k_flag_nonzero, grid1(n), dim3(256), 0, s, in, n, flag);
 }
-void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *gcount, const uint32_t *gmin,
-                          const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes) {
-    hipLaunchKernelGGL(k_scatter_nodes, grid1(T), dim3(256), 0, s, keys, gcount, gmin, idx, T, nd, node_cnt, n_nodes);
-}
-void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd, uint2 *nrec) {
-    hipLaunchKernelGGL(k_order_nodes, grid1(L), dim3(256), 0, s, node_off, L, nd, nrec);
-}
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd) {
     hipLaunchKernelGGL(k_cov_delta, grid1(R), dim3(256), 0, s, reads, R, alive, covd);
-}
-void launch_mark_runs(hipStream_t s, const uint32_t *node_off, uint32_t L, uint32_t *flag) {
-    hipLaunchKernelGGL(k_mark_runs, grid1(L), dim3(256), 0, s, node_off, L, flag);
-}
-void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx, uint32_t n, uint32_t *out,
-                        uint32_t *n_out) {
-    hipLaunchKernelGGL(k_scatter_idx, grid1(n), dim3(256), 0, s, flag, idx, n, out, n_out);
 }
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L}; }
 

@@ -7,9 +7,10 @@
 
 namespace np2 {
 
-static constexpr int NSHARD = 256;          // exception-tuple output shards (atomic counters 128 B apart)
-static constexpr int SHARD_STRIDE = 32;     // in uint32_t
-static constexpr uint32_t SLOT_CAP = 64;    // exception tuples a chunk can emit into its private slot
+static constexpr uint32_t TILE_SHIFT = 10;  // contig tile = 1024 positions: unit of the bucketed exception sort
+static constexpr uint32_t TILE = 1u << TILE_SHIFT;
+static constexpr uint32_t TILE_CAP = 4096;  // records per tile bucket = what a tile can sort inside LDS (larger
+                                            // tiles spill to the overflow area and take the device-wide sort)
 
 struct ChunkDesc { // one 2048-column chunk of a streamed read (built on the host at upload)
     uint64_t nib_off;     // byte offset of the READ's nibble stream
@@ -54,30 +55,17 @@ struct YakDev {
 
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t *err);
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *chunk_cnt,
-                       uint64_t ovf_base, uint32_t *shard_cnt, uint32_t shard_cap, uint32_t *ckpt, uint32_t *err);
+                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *tile_cur,
+                       uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *ovf_cnt,
+                       uint32_t *ckpt, uint32_t *err);
 void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n);
 void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks);
-void launch_make_nodes(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, uint64_t *keys, const uint32_t *vals,
-                       uint32_t T);
-void launch_compact_slots(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, const uint32_t *chunk_cnt,
-                          const uint32_t *chunk_out, uint32_t n_chunks, uint64_t *out_keys, uint32_t *out_vals);
-void launch_compact_shards(hipStream_t s, const uint64_t *in_keys, const uint32_t *in_vals, uint64_t ovf_base,
-                           uint32_t shard_cap, const uint32_t *shard_cnt, const uint64_t *shard_off, uint64_t *out_keys,
-                           uint32_t *out_vals);
 void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr,
                  uint32_t *d2 = nullptr, const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
-void launch_group_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *vals, uint32_t T, const uint8_t *alive,
-                        uint32_t *gcount, uint32_t *gmin, uint32_t *flag);
 void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag);
-void launch_scatter_nodes(hipStream_t s, const uint64_t *keys, const uint32_t *gcount, const uint32_t *gmin,
-                          const uint32_t *idx, uint32_t T, NodeArrays nd, uint32_t *node_cnt, uint32_t *n_nodes);
-void launch_order_nodes(hipStream_t s, const uint32_t *node_off, uint32_t L, NodeArrays nd, uint2 *nrec);
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd);
-void launch_mark_runs(hipStream_t s, const uint32_t *node_off, uint32_t L, uint32_t *flag);
-void launch_scatter_idx(hipStream_t s, const uint32_t *flag, const uint32_t *idx, uint32_t n, uint32_t *out, uint32_t *n_out);
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
                const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
                unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain);
@@ -120,6 +108,28 @@ void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_
                        const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
                        uint32_t *long_list, uint32_t *n_long);
 
+
+// ---- np2_graph.hip: tile-bucketed exception sort and per-pass graph construction ---------------------
+void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
+                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out);
+void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+                      uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
+                      uint32_t *err);
+void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+                           const uint32_t *tile_scanb, uint32_t n_tiles, uint32_t bucket_cap, const uint64_t *bkeys,
+                           const uint32_t *bvals, uint64_t *keys, uint32_t *vals);
+void launch_gather_spill(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint64_t *okeys,
+                         const uint32_t *ovals, uint32_t n, uint64_t *keys, uint32_t *vals);
+// tile t's sorted records: [a, a + tile_n[t]) with a = t * bucket_cap, or tile_scan[t] when bucket_cap == 0
+void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
+                       const uint32_t *tile_scan, uint32_t bucket_cap, uint32_t n_tiles, const uint8_t *alive,
+                       uint32_t *tile_nn, uint32_t *tile_nr);
+void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
+                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs);
+void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
+                       const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
+                       uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
+                       uint32_t *run_start);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)

@@ -143,6 +143,37 @@ def test_wild_pileup_long_reads_cross_chunks():
     check_all_stages(pu, [yak_from_seqs([ref], 21, count=30)], Opts())
 
 
+@pytest.mark.parametrize("cap", ["1", "64"])
+def test_device_wide_sort_fallback_matches_tile_sort(monkeypatch, cap):
+    # a tile with more records than its bucket spills and takes the device-wide sort: force that with tiny buckets
+    # (cap 1: nearly every record spills; cap 64: a mix of bucket-resident and spilled records)
+    monkeypatch.setenv("NP2_TILE_CAP", cap)
+    s = Synth(40000, depth=25, seed=77, diploid=True, read_len_mean=6000.0, read_len_sd=1000.0)
+    check_all_stages(s.pileup, [s.yak(21)], Opts())
+    from test_oracle import yak_from_seqs
+    ref, pu = wild_pileup(3, ins_p=0.03, del_p=0.02, sub_p=0.02)
+    check_all_stages(pu, [yak_from_seqs([ref], 21, count=30)], Opts())
+
+
+def test_long_insertion_overflows_a_tile():
+    # a 3 kb insertion carried by every read puts > TILE_CAP exception records into one contig tile
+    rng = np.random.default_rng(5)
+    L = 6000
+    ref = "".join(rng.choice(list("ACGT"), L))
+    ins = "".join(rng.choice(list("ACGT"), 3000))
+    alns = []
+    for i in range(12):
+        t = ref[:3000] + "-" * len(ins) + ref[3000:]
+        q = ref[:3000] + ins + ref[3000:]
+        s0 = 10 * i
+        cut = s0  # reads start at staggered positions, all span the insertion
+        alns.append((s0, t[cut:], q[cut:]))
+    pu = pileup_from_alignments(ref, alns)
+    from test_oracle import yak_from_seqs
+    truth = ref[:3000] + ins + ref[3000:]
+    check_all_stages(pu, [yak_from_seqs([truth], 21, count=30)], Opts())
+
+
 def test_scaffold_gap_uncovered_stretch_and_soft_masking():
     # a contig with an N gap (reads stop before it and resume after it), an uncovered stretch (coverage 1: only the
     # contig's own row, main.rs:1586-1588 resets the LQ state there) and lower-case (soft-masked) letters
