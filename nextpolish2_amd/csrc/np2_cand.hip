@@ -1,0 +1,376 @@
+// Candidate extraction (get_lqseqs_from_align_tags, src/main.rs:1433-1530), region-major.
+//
+// Every live read covers a contiguous interval [pj, pj + pcount) of the (descending) LQ region list.  One wavefront
+// per region finds its reads through the per-tile read lists built at upload, measures their candidate strings
+// 8 columns at a time, keeps the first 60 non-empty ones (main.rs:1474,1509) in per-region slots, and a second pass
+// writes strings and first k-mers once the offsets are known.  No (read, region) pair list is ever materialised.
+#include "np2_common.hpp"
+#include "np2_kernels.hpp"
+
+namespace np2 {
+
+// ------------------------------------------------------------------------------------------------------
+// single-block scans for short arrays (region / read / pair counts): no temp storage, no init launch, the
+// element count may live on the device
+// ------------------------------------------------------------------------------------------------------
+template <int MODE> // 0: exclusive sum (out[n] = total), 1: inclusive sum, 2: inclusive min (signed)
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                     uint32_t n_host, const uint32_t *__restrict__ n_dev,
+                                                     uint32_t *__restrict__ total_out, bool write_end) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t a = min(n, tid * per), b = min(n, a + per);
+    const uint32_t ident = MODE == 2 ? 0x7FFFFFFFu : 0u;
+    auto op = [](uint32_t x, uint32_t y) -> uint32_t {
+        if (MODE == 2) return (uint32_t)min((int32_t)x, (int32_t)y);
+        return x + y;
+    };
+    uint32_t acc = ident;
+    for (uint32_t i = a; i < b; ++i) acc = op(acc, in[i]);
+    part[tid] = acc;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : ident;
+        __syncthreads();
+        part[tid] = op(part[tid], v);
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : ident; // everything before this thread's segment
+    for (uint32_t i = a; i < b; ++i) {
+        const uint32_t v = in[i];
+        if (MODE == 0) {
+            out[i] = run;
+            run += v;
+        } else {
+            run = op(run, v);
+            out[i] = run;
+        }
+    }
+    if (tid == 1023) {
+        if (MODE == 0 && write_end) out[n] = part[1023];
+        if (total_out) *total_out = part[1023];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// candidate decode
+// ------------------------------------------------------------------------------------------------------
+struct CandCtx {
+    const np2_read_t *reads;
+    const uint8_t *nib;
+    const uint64_t *ck_off;
+    const uint32_t *ckpt;
+    const uint32_t *lq_start;
+    const uint32_t *lq_end;
+    const uint32_t *pj;
+    const uint32_t *pcount;
+    const uint8_t *alive;
+    const uint32_t *tile_rd_off; // reads overlapping each contig tile, ascending read index (built at upload)
+    const uint32_t *tile_rd;
+    uint32_t n_tiles;
+    uint32_t ksize;
+};
+
+// checkpoint lookup: a non-insertion column at or before the first column of t_pos == start, and its t_pos
+__device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t start,
+                                            uint32_t &col, uint32_t &t) {
+    col = 0;
+    t = rd.aln_t_s;
+    const uint32_t ck_first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT;
+    const uint32_t cki = start >> CKPT_SHIFT;
+    if (r == 0) { // the contig aligned to itself: column index == position (the dense pass skips read 0)
+        col = start;
+        t = start;
+    } else if (cki >= ck_first) {
+        col = cx.ckpt[cx.ck_off[r] + (cki - ck_first)];
+        t = cki << CKPT_SHIFT;
+    }
+}
+
+// position (0..7) of the n-th (1-based) set bit of a nibble-spaced mask (bits 0, 4, 8, ...)
+__device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) {
+    for (uint32_t i = 1; i < n; ++i) m &= m - 1;
+    return (uint32_t)__builtin_ctz(m) >> 2;
+}
+
+// Length of the candidate string of (read, region) and the column it starts at, 8 columns per step
+// (the emission rule of main.rs:1478-1521: every non-gap column whose t_pos lies in [start, end], from the reference
+// column of `start` on; the early exits of that loop all sit behind t_pos > end).
+__device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t start, uint32_t end,
+                                 uint32_t &col_start) {
+    uint32_t col_ck, t_ck;
+    cand_anchor(cx, r, rd, start, col_ck, t_ck);
+    col_start = col_ck;
+    if (end < t_ck) return 0;                                   // the read begins behind the region
+    const uint32_t want_s = (start > t_ck ? start - t_ck : 0u) + 1; // col_start = want_s-th non-insertion column from col_ck
+    const uint32_t want_e = end + 1 - t_ck + 1;                 // first column past the region, counted the same way
+    const uint8_t *base = cx.nib + rd.nib_off;
+    const uint32_t n_cols = rd.n_cols;
+    uint32_t seen = 0, len = 0;
+    bool started = false;
+    uint4 win = make_uint4(0, 0, 0, 0);
+    uint32_t win_blk = 0xFFFFFFFFu;
+    for (uint32_t wi = col_ck >> 3;; ++wi) {
+        const uint32_t c0 = wi << 3;
+        if (c0 >= n_cols) break;
+        if ((wi >> 2) != win_blk) {
+            win_blk = wi >> 2;
+            win = *reinterpret_cast<const uint4 *>(base + ((size_t)win_blk << 4));
+        }
+        const uint32_t k = wi & 3;
+        const uint32_t raw = k == 0 ? win.x : (k == 1 ? win.y : (k == 2 ? win.z : win.w));
+        const uint32_t w = ((raw & 0x0F0F0F0Fu) << 4) | ((raw >> 4) & 0x0F0F0F0Fu); // column j at bits 4j
+        uint32_t valid = 0x11111111u;
+        if (c0 < col_ck) valid &= ~((1u << (4 * (col_ck - c0))) - 1u);            // columns before the anchor
+        if (n_cols - c0 < 8) valid &= (1u << (4 * (n_cols - c0))) - 1u;           // columns past the read
+        uint32_t nonins = (~(w >> 3)) & valid;
+        if (c0 == 0) nonins |= valid & 1u; // column 0 is never an insertion column (main.rs:325,332-335)
+        const uint32_t x = (w & 0x77777777u) ^ 0x44444444u;
+        const uint32_t nongap = (x | (x >> 1) | (x >> 2)) & valid;
+        const uint32_t cn = __builtin_popcount(nonins);
+        uint32_t lo = 0, hi = 8;
+        bool done = false;
+        if (!started && seen + cn >= want_s) {
+            lo = nth_col(nonins, want_s - seen);
+            col_start = c0 + lo;
+            started = true;
+        }
+        if (seen + cn >= want_e) {
+            hi = nth_col(nonins, want_e - seen);
+            done = true;
+        }
+        if (started) {
+            uint32_t m = nongap;
+            if (lo) m &= ~((1u << (4 * lo)) - 1u);
+            if (hi < 8) m &= (1u << (4 * hi)) - 1u;
+            len += __builtin_popcount(m);
+        }
+        seen += cn;
+        if (done) break;
+    }
+    return started ? len : 0u;
+}
+
+// sequential nibble reader with a 16-column (8-byte) register window; `base` is 16-byte aligned
+struct NibReader {
+    const uint8_t *base;
+    uint64_t w;     // current window, nibble of column c at bits 4*(c & 15)
+    uint32_t wbase; // first column of the window (multiple of 16), 0xFFFFFFFF = empty
+    __device__ __forceinline__ uint8_t get(uint32_t c) {
+        const uint32_t b = c & ~15u;
+        if (b != wbase) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(base + (b >> 1));
+            const uint32_t x = ((v.x & 0x0F0F0F0Fu) << 4) | ((v.x >> 4) & 0x0F0F0F0Fu);
+            const uint32_t y = ((v.y & 0x0F0F0F0Fu) << 4) | ((v.y >> 4) & 0x0F0F0F0Fu);
+            w = (uint64_t)x | ((uint64_t)y << 32);
+            wbase = b;
+        }
+        return (uint8_t)((w >> (4 * (c & 15))) & 15);
+    }
+};
+
+// Write the candidate string (its length is known) and the hashed first k-mer (main.rs:1478-1521), starting at the
+// candidate's first column `col` whose t_pos is `t`.
+__device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t g, uint32_t col, uint32_t t,
+                           uint8_t *__restrict__ seq_out, uint64_t *kmer_out) {
+    NibReader nr{cx.nib + rd.nib_off, 0, 0xFFFFFFFFu};
+    const uint32_t end = cx.lq_end[g];
+    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
+    const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
+    uint64_t fw = 0, rv = 0, l = 0;
+    uint32_t len = 0;
+    for (uint32_t c = col; c < rd.n_cols; ++c) {
+        const uint8_t nb = nr.get(c);
+        if (c != col && !(nb & 8)) ++t;
+        const uint8_t q = nb & 7;
+        if (q != 4) {
+            if (t <= end) seq_out[len++] = code_to_ascii(q);
+            if (l < ksize) { // N/M codes are not filtered here (main.rs:1488-1492)
+                fw = ((fw << 2) | (uint64_t)q) & mask;
+                rv = (rv >> 2) | ((3ULL ^ (uint64_t)q) << shift);
+                ++l;
+            }
+            if (t > end && l >= ksize) break;
+        }
+        if (t > limit) break; // this column was the last one decoded
+    }
+    uint64_t km = INVALID_KMER;
+    if (l >= ksize) km = yak_hash64(fw < rv ? fw : rv, mask);
+    *kmer_out = km;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// one wavefront per region
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix sum across the wave
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += t;
+    }
+    return x - v;
+}
+
+// Reads paired with region g (main.rs:1445-1476): those whose region interval [pj, pj + pcount) holds g.  A pair that
+// yields a non-empty string has lq_end[g] inside the read, so the reads overlapping that position's contig tile are
+// the only ones to test; the list is ascending in read index = the order the reference visits alignseqs in.
+// Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col.
+__global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
+                                                        uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
+                                                        uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_reg) return;
+    const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
+    const uint32_t tile = min(end >> TILE_SHIFT, cx.n_tiles - 1);
+    const uint32_t la = cx.tile_rd_off[tile], lb = cx.tile_rd_off[tile + 1];
+    uint32_t kept = 0, bytes = 0;
+    for (uint32_t c0 = la; c0 < lb && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        uint32_t r = 0, len = 0, col = 0;
+        bool ok = false;
+        if (i < lb) {
+            r = cx.tile_rd[i];
+            const uint32_t j = cx.pj[r], n = cx.pcount[r];
+            ok = cx.alive[r] && n != 0 && j <= g && g - j < n;
+        }
+        if (ok) {
+            const np2_read_t rd = cx.reads[r];
+            len = cand_measure(cx, r, rd, start, end, col);
+        }
+        const uint64_t ne = __ballot(len > 0);
+        const uint32_t before = kept + (uint32_t)__builtin_popcountll(ne & ((1ULL << lane) - 1ULL));
+        const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
+        if (keep) {
+            const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
+            kept_read[slot] = r;
+            kept_len[slot] = len;
+            kept_col[slot] = col;
+        }
+        kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
+        bytes += wave_sum(keep ? len : 0u);
+    }
+    if (lane == 0) {
+        reg_ncand[g] = kept;
+        reg_bytes[g] = bytes;
+    }
+}
+
+// candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
+__global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restrict__ reg_ncand,
+                                                       const uint32_t *__restrict__ reg_bytes, uint32_t n_reg,
+                                                       uint32_t *__restrict__ cand_off, uint32_t *__restrict__ reg_soff,
+                                                       uint32_t *__restrict__ n_cand, uint32_t *__restrict__ n_bytes) {
+    __shared__ uint32_t pa[1024];
+    __shared__ uint32_t pb[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_reg + 1023) / 1024;
+    const uint32_t a = min(n_reg, tid * per), b = min(n_reg, a + per);
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t i = a; i < b; ++i) {
+        sa += reg_ncand[i];
+        sb += reg_bytes[i];
+    }
+    pa[tid] = sa;
+    pb[tid] = sb;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
+        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
+        __syncthreads();
+        pa[tid] += va;
+        pb[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
+    for (uint32_t i = a; i < b; ++i) {
+        cand_off[i] = ra;
+        reg_soff[i] = rb;
+        ra += reg_ncand[i];
+        rb += reg_bytes[i];
+    }
+    if (tid == 1023) {
+        cand_off[n_reg] = pa[1023];
+        reg_soff[n_reg] = pb[1023];
+        *n_cand = pa[1023];
+        *n_bytes = pb[1023];
+    }
+}
+
+// one lane per kept candidate (at most 60 per region = one pass of the wave)
+__global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
+                                                      const uint32_t *__restrict__ kept_len,
+                                                      const uint32_t *__restrict__ kept_col,
+                                                      const uint32_t *__restrict__ reg_ncand,
+                                                      const uint32_t *__restrict__ cand_off,
+                                                      const uint32_t *__restrict__ reg_soff, uint32_t cand_cap,
+                                                      uint32_t seq_cap, uint32_t *__restrict__ cand_order,
+                                                      uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
+                                                      uint8_t *__restrict__ cand_seq) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_reg) return;
+    if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
+    const uint32_t n = reg_ncand[g];
+    const bool act = lane < n;
+    const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + lane;
+    const uint32_t len = act ? kept_len[slot] : 0u;
+    const uint32_t so = reg_soff[g] + wave_excl(len);
+    const uint32_t ci = cand_off[g] + lane;
+    if (!act || ci >= cand_cap || (uint64_t)so + len > seq_cap) return;
+    const uint32_t r = kept_read[slot];
+    const np2_read_t rd = cx.reads[r];
+    cand_order[ci] = r;
+    cand_seq_off[ci] = so;
+    cand_write(cx, r, rd, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), cand_seq + so, &cand_kmer[ci]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
+                            uint32_t *total_out, bool write_end) {
+    hipLaunchKernelGGL(k_scan_small<0>, dim3(1), dim3(1024), 0, s, in, out, n, n_dev, total_out, write_end);
+}
+void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev) {
+    hipLaunchKernelGGL(k_scan_small<1>, dim3(1), dim3(1024), 0, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev,
+                       (uint32_t *)nullptr, false);
+}
+void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev) {
+    hipLaunchKernelGGL(k_scan_small<2>, dim3(1), dim3(1024), 0, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev,
+                       (uint32_t *)nullptr, false);
+}
+static CandCtx mk_cand(const CandPtrs &c) {
+    return CandCtx{c.reads, c.nib,    c.ck_off, c.ckpt,        c.lq_start, c.lq_end, c.pj,
+                   c.pcount, c.alive, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
+}
+void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes) {
+    if (n_reg)
+        hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
+                           kept_col, reg_ncand, reg_bytes);
+}
+void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, uint32_t n_reg,
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, reg_ncand, reg_bytes, n_reg, cand_off, reg_soff, n_cand,
+                       n_bytes);
+}
+void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
+                         const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
+                         const uint32_t *cand_off, const uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap,
+                         uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq) {
+    if (n_reg)
+        hipLaunchKernelGGL(k_region_write, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
+                           kept_col, reg_ncand, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off,
+                           cand_seq);
+}
+
+} // namespace np2

@@ -148,9 +148,15 @@ struct np2_contig {
     // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
     uint32_t n_chunks = 0;
     DevBuf<ChunkDesc> descs;
+    // reads overlapping each contig tile (ascending read index), CSR
+    uint32_t n_tiles = 0;
+    DevBuf<uint32_t> tile_rd_off, tile_rd;
 };
 
 struct np2_ctx {
+    ~np2_ctx() {
+        if (mbox_host) (void)hipHostFree(mbox_host);
+    }
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<YakTable> yaks;
@@ -161,6 +167,8 @@ struct np2_ctx {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 
     PinnedBuf pin_d2h, pin_h2d;
+    uint32_t *mbox_host = nullptr, *mbox_dev = nullptr; // host-mapped scalar mailbox: [0] = sequence, [1..] = scal
+    uint32_t mbox_seq = 0;
     uint32_t last_first_pos = 0, last_last_pos = 0;
     bool reuse_identical_pass = true;
     // scratch (reused across contigs)
@@ -175,7 +183,7 @@ struct np2_ctx {
     DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
         lq_end;
     DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
-        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, cand_off, cand_order, cand_seq_off, kill_ids;
+        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
     DevBuf<uint64_t> cand_kmer;
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;
@@ -270,6 +278,14 @@ template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
     }
     return v;
 }
+// Read the device scalar block (enum Scal) with low latency: a one-thread kernel first gathers up to four device
+// counters into scal slots (dst = scal + S_x), then posts the block to the host-mapped mailbox; the host spins on the
+// sequence word.  Everything queued on the stream before the call has completed when it returns.
+inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0 = nullptr, const uint32_t *s0 = nullptr,
+                                        uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
+                                        const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr,
+                                        const uint32_t *s3 = nullptr);
+
 // host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
 inline void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
@@ -285,11 +301,48 @@ template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name
     if (!v.empty()) memcpy(dst.data(), v.data(), dst.size());
 }
 
+inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1,
+                                        uint32_t *d2, const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
+    const uint32_t seq = ++cx->mbox_seq;
+    launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, d0, s0, d1, s1, d2, s2, d3, s3);
+    uint64_t spins = 0;
+    while (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFF) == 0) { // a failed launch / device fault would never post: surface it
+            hipError_t e = hipStreamQuery(cx->stream);
+            if (e != hipSuccess && e != hipErrorNotReady)
+                throw Np2Error(NP2_E_DEVICE, std::string("device error while waiting for the mailbox: ") + hipGetErrorString(e));
+            if (e == hipSuccess && __atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
+                throw Np2Error(NP2_E_DEVICE, "mailbox kernel completed without posting");
+        }
+    }
+    return std::vector<uint32_t>(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
+}
+
+// short arrays: one single-block kernel (no temp storage, no init launch); long ones: rocPRIM
+static constexpr size_t SCAN_SMALL_MAX = 1u << 12;
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
     // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
+    if (n_plus1 <= SCAN_SMALL_MAX) {
+        launch_scan_small_excl(cx->stream, in, out, (uint32_t)n_plus1, nullptr, nullptr, false);
+        return 0;
+    }
     int rc = prim_exclusive_sum_u32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n_plus1);
     if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim exclusive_scan failed");
     return 0;
+}
+inline void scan_incl_min(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n) {
+    if (n <= SCAN_SMALL_MAX) {
+        launch_scan_small_min(cx->stream, in, out, (uint32_t)n, nullptr);
+    } else if (prim_inclusive_min_i32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n)) {
+        throw Np2Error(NP2_E_DEVICE, "rocprim min-scan failed");
+    }
+}
+inline void scan_incl_sum(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n) {
+    if (n <= SCAN_SMALL_MAX) {
+        launch_scan_small_incl(cx->stream, in, out, (uint32_t)n, nullptr);
+    } else if (prim_inclusive_sum_i32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n)) {
+        throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+    }
 }
 inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
     if (n_elems) HIPCHK(hipMemsetAsync(p, 0, n_elems * elem, cx->stream));

@@ -143,10 +143,9 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
                           cx->scal.p + S_ERR);
         zero32(cx, cx->ecount.p + n_reg, 1);
         exclusive_total(cx, cx->ecount.p, cx->eoff.p, (size_t)n_reg + 1);
-        launch_mail(s, cx->scal.p + S_M0, cx->eoff.p + n_reg);
     }
     {
-        std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
         check_region_err(cx, sc[S_ERR]);
         NE = sc[S_M0];
     }
@@ -170,7 +169,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
         // compact into ekey / eval (reused as int32 weights)
         launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, cx->ew.p, NE, cx->ekey.p, (int32_t *)cx->eval.p,
                             cx->scal.p + S_NRAW);
-        NU = d2h(cx, cx->scal.p + S_NRAW, 1)[0];
+        NU = fetch_scal(cx)[S_NRAW];
         ukey = d2h(cx, cx->ekey.p, NU);
         uw = d2h(cx, (const int32_t *)cx->eval.p, NU);
     }
@@ -266,10 +265,8 @@ CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, 
     zero32(cx, cx->ap_delta.p, n_reg + 2); // slots past n_ap stay 0, so the scan can run over the n_reg bound
     launch_splice_slots(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p,
                         cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->scal.p + S_NAP);
-    if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->ap_delta.p, cx->ap_shift.p, n_reg))
-        throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
-    launch_mail(s, cx->scal.p + S_M0, (const uint32_t *)cx->ap_shift.p + (n_reg - 1));
-    std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+    scan_incl_sum(cx, cx->ap_delta.p, cx->ap_shift.p, n_reg);
+    std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, (const uint32_t *)cx->ap_shift.p + (n_reg - 1));
     check_region_err(cx, sc[S_ERR]);
     const uint32_t n_ap = sc[S_NAP];
     const int32_t total_shift = (int32_t)sc[S_M0];
@@ -316,8 +313,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
                            cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_njobs.p,
                            cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
         exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_reg + 1);
-        launch_mail(s, cx->scal.p + S_M0, cx->rech_joboff.p + n_reg);
-        std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->rech_joboff.p + n_reg);
         check_region_err(cx, sc[S_ERR]);
         n_rech = sc[S_NRECH];
         n_groups = sc[S_NGROUPS];
@@ -336,7 +332,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
             launch_rech_job_len(s, rp, n_jobs, cx->job_len.p);
             zero32(cx, cx->job_len.p + n_jobs, 1);
             exclusive_total(cx, cx->job_len.p, cx->job_off32.p, (size_t)n_jobs + 1);
-            const uint32_t blob_bytes = d2h(cx, cx->job_off32.p + n_jobs, 1)[0];
+            const uint32_t blob_bytes = fetch_scal(cx, cx->scal.p + S_M0, cx->job_off32.p + n_jobs)[S_M0];
             cx->sstr.ensure((size_t)blob_bytes + 64);
             launch_rech_job_build(s, rp, n_jobs, cx->job_off32.p, cx->soff.p, cx->sstr.p);
             launch_score_strings(s, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n_jobs, min_kmer_count,
@@ -434,7 +430,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
             launch_tile_layout(s, cx->tile_cur.p, n_tiles, bcap, cx->tile_n.p, cx->tile_scan.p, cx->tile_scanb.p,
                                cx->scal.p + S_M3, cx->scal.p + S_M0);
         }
-        std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+        std::vector<uint32_t> sc = fetch_scal(cx);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
         if (sc[S_M2] > ovf_cap) { // the spill area itself overflowed: grow and redo the dense pass
@@ -573,8 +569,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
     }
-    launch_mail(s, cx->scal.p + S_M0, cx->eoff.p + L);
-    std::vector<uint32_t> sc = d2h(cx, cx->scal.p, S_COUNT);
+    std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + L);
     if (sc[S_BEST] == 0xFFFFFFFFu)
         throw Np2Error(NP2_E_UNSUPPORTED,
                        "best path score is negative at the contig end (reference would emit its default node)");
@@ -608,7 +603,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         cx->raw_end.ensure(M + 2);
         launch_scatter_regions(s, cx->rflag.p, cx->ridx.p, cx->rstart.p, cx->rend.p, M, cx->raw_start.p,
                                cx->raw_end.p, cx->scal.p + S_NRAW);
-        n_raw = d2h(cx, cx->scal.p + S_NRAW, 1)[0];
+        n_raw = fetch_scal(cx)[S_NRAW];
         n_reg = 0;
         if (n_raw) {
             cx->headflag.ensure(n_raw + 2);
@@ -619,7 +614,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
             exclusive_total(cx, cx->headflag.p, cx->hidx.p, n_raw);
             launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, n_raw, cx->headflag.p,
                                   cx->hidx.p, cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
-            n_reg = d2h(cx, cx->scal.p + S_NREG, 1)[0];
+            n_reg = fetch_scal(cx)[S_NREG];
         }
     }
 }
@@ -630,78 +625,35 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     hipStream_t s = cx->stream;
     const uint32_t R = c->R;
     REFPANIC_IF(cx->yaks.empty(), "index out of bounds: opt.yak[0]");
-    uint32_t NP = 0, NC = 0, SB = 0;
+    uint32_t NC = 0, SB = 0;
+    cx->mval.ensure(R + 2);
+    cx->smin.ensure(R + 2);
+    cx->pj.ensure(R + 2);
+    cx->pcount.ensure(R + 2);
+    cx->reg_ncand.ensure(n_reg + 2);
+    cx->reg_bytes.ensure(n_reg + 2);
+    cx->reg_soff.ensure(n_reg + 2);
+    cx->cand_off.ensure(n_reg + 2);
+    cx->kept_read.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
+    cx->kept_len.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
+    cx->kept_col.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
+    CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
+                cx->pcount.p, cx->alive.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles,     cx->yaks[0].k};
     {
         EventTimer t(cx, "candidates");
-        cx->mval.ensure(R + 2);
-        cx->smin.ensure(R + 2);
-        cx->pj.ensure(R + 2);
-        cx->pcount.ensure(R + 2);
-        cx->poff.ensure(R + 2);
+        // every live read covers a contiguous interval [pj, pj + pcount) of the region list
         launch_read_m(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, n_reg, cx->mval.p);
-        if (prim_inclusive_min_i32(s, cx->tmp.p, cx->tmp.cap, cx->mval.p, cx->smin.p, R))
-            throw Np2Error(NP2_E_DEVICE, "rocprim min-scan failed");
+        scan_incl_min(cx, cx->mval.p, cx->smin.p, R);
         launch_pair_count(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, cx->lq_end.p, n_reg, cx->smin.p, cx->pj.p,
                           cx->pcount.p);
-        zero32(cx, cx->pcount.p + R, 1);
-        exclusive_total(cx, cx->pcount.p, cx->poff.p, (size_t)R + 1);
-        NP = d2h(cx, cx->poff.p + R, 1)[0];
-    }
-    cx->reg_npairs.ensure(n_reg + 2);
-    cx->reg_poff.ensure(n_reg + 2);
-    cx->reg_ncand.ensure(n_reg + 2);
-    cx->cand_off.ensure(n_reg + 2);
-    cx->pair_region.ensure(NP + 2);
-    cx->pair_read.ensure(NP + 2);
-    cx->pair_region_s.ensure(NP + 2);
-    cx->pair_read_s.ensure(NP + 2);
-    cx->pair_len.ensure(NP + 2);
-    cx->pair_keep.ensure(NP + 2);
-    cx->keepflag.ensure(NP + 2);
-    cx->cand_idx.ensure(NP + 2);
-    cx->seq_off.ensure(NP + 2);
-    cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)NP + 2, (size_t)n_reg + 2)));
-    CandPtrs cp{c->reads.p, c->nib.p, c->ck_off.p, c->ckpt.p, cx->lq_start.p, cx->lq_end.p, cx->pj.p, cx->yaks[0].k};
-    {
-        EventTimer t(cx, "candidates");
-        // pairs per region via a difference array over each read's region interval [j, s]
-        zero32(cx, cx->reg_npairs.p, n_reg + 2);
-        launch_pair_fill(s, R, cx->pj.p, cx->pcount.p, cx->poff.p, NP, cx->pair_region.p, cx->pair_read.p,
-                         (int32_t *)cx->reg_npairs.p);
-        if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, (const int32_t *)cx->reg_npairs.p,
-                                   (int32_t *)cx->reg_ncand.p, (size_t)n_reg + 1))
-            throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
-        // reg_ncand temporarily holds pairs-per-region; its exclusive scan gives the sorted segment offsets
-        unsigned bits = 1;
-        while ((1ull << bits) < (uint64_t)n_reg + 1) ++bits;
-        if (prim_sort_pairs_u32_u32(s, cx->tmp.p, cx->tmp.cap, cx->pair_region.p, cx->pair_region_s.p,
-                                    cx->pair_read.p, cx->pair_read_s.p, NP, bits))
-            throw Np2Error(NP2_E_DEVICE, "rocprim pair sort failed");
-        zero32(cx, cx->reg_ncand.p + n_reg, 1);
-        exclusive_total(cx, cx->reg_ncand.p, cx->reg_poff.p, (size_t)n_reg + 1);
-        launch_cand_measure(s, cp, cx->pair_region_s.p, cx->pair_read_s.p, NP, cx->pair_len.p);
-        launch_region_rank(s, cx->reg_poff.p, n_reg, cx->pair_len.p, cx->pair_keep.p, cx->reg_ncand.p);
-        zero32(cx, cx->reg_ncand.p + n_reg, 1);
-        exclusive_total(cx, cx->reg_ncand.p, cx->cand_off.p, (size_t)n_reg + 1);
-        if (NP) {
-            // candidate slot = exclusive count of kept pairs; sequence offset = exclusive sum of kept lengths
-            // (pair_keep holds the kept length, 0 for dropped pairs)
-            zero32(cx, cx->pair_keep.p + NP, 1);
-            exclusive_total(cx, cx->pair_keep.p, cx->seq_off.p, (size_t)NP + 1);
-        }
-    }
-    // keep flags -> candidate index
-    {
-        EventTimer t(cx, "candidates");
-        if (NP) {
-            launch_flag_nonzero(s, cx->pair_keep.p, NP, cx->keepflag.p);
-            zero32(cx, cx->keepflag.p + NP, 1);
-            exclusive_total(cx, cx->keepflag.p, cx->cand_idx.p, (size_t)NP + 1);
-            launch_mail(s, cx->scal.p + S_M0, cx->cand_idx.p + NP, cx->scal.p + S_M1, cx->seq_off.p + NP);
-            std::vector<uint32_t> m2 = d2h(cx, cx->scal.p + S_M0, 2);
-            NC = m2[0];
-            SB = m2[1];
-        }
+        // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
+        launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
+                              cx->reg_bytes.p);
+        launch_cand_offsets(s, cx->reg_ncand.p, cx->reg_bytes.p, n_reg, cx->cand_off.p, cx->reg_soff.p,
+                            cx->scal.p + S_M1, cx->scal.p + S_M2);
+        std::vector<uint32_t> m2 = fetch_scal(cx);
+        NC = m2[S_M1];
+        SB = m2[S_M2];
     }
     cx->cand_order.ensure(NC + 2);
     cx->cand_kmer.ensure(NC + 2);
@@ -710,9 +662,9 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->kscore.ensure(NC + 2);
     {
         EventTimer t(cx, "candidates");
-        launch_cand_write(s, cp, cx->pair_region_s.p, cx->pair_read_s.p, cx->pair_keep.p, cx->cand_idx.p,
-                          cx->seq_off.p, NP, cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
-        h2d_staged(cx, cx->cand_seq_off.p + NC, &SB, 4);
+        launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
+                            cx->cand_off.p, cx->reg_soff.p, NC + 1, SB, cx->cand_order.p, cx->cand_kmer.p,
+                            cx->cand_seq_off.p, cx->cand_seq.p);
     }
     {
         EventTimer t(cx, "kmer_score");
@@ -915,9 +867,28 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
             descs.push_back(d);
         }
     }
+    // reads overlapping each contig tile, ascending read index (candidate extraction looks reads up by position)
+    const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
+    std::vector<uint32_t> trd_off((size_t)n_tiles + 1, 0), trd;
+    for (uint32_t r = 0; r < n_reads; ++r)
+        if (!(reads[r].flags & NP2_READ_DROPPED))
+            for (uint32_t t = reads[r].aln_t_s >> TILE_SHIFT; t <= reads[r].aln_t_e >> TILE_SHIFT; ++t) ++trd_off[t + 1];
+    for (uint32_t t = 0; t < n_tiles; ++t) trd_off[t + 1] += trd_off[t];
+    trd.resize(trd_off[n_tiles]);
+    {
+        std::vector<uint32_t> cur(trd_off.begin(), trd_off.end() - 1);
+        for (uint32_t r = 0; r < n_reads; ++r)
+            if (!(reads[r].flags & NP2_READ_DROPPED))
+                for (uint32_t t = reads[r].aln_t_s >> TILE_SHIFT; t <= reads[r].aln_t_e >> TILE_SHIFT; ++t) trd[cur[t]++] = r;
+    }
     hipStream_t s = cx->stream;
     c->L = L;
     c->R = n_reads;
+    c->n_tiles = n_tiles;
+    c->tile_rd_off.ensure(trd_off.size());
+    c->tile_rd.ensure(trd.size() + 1);
+    HIPCHK(hipMemcpyAsync(c->tile_rd_off.p, trd_off.data(), trd_off.size() * 4, hipMemcpyHostToDevice, s));
+    if (!trd.empty()) HIPCHK(hipMemcpyAsync(c->tile_rd.p, trd.data(), trd.size() * 4, hipMemcpyHostToDevice, s));
     c->nib_bytes = nib_bytes;
     c->n_cols = cols;
     c->n_ckpt = ck[n_reads];
@@ -958,6 +929,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
         cx->scal.ensure(S_COUNT);
+        HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
+        HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
         if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
             cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
         cx->yaks.resize(n_yak);

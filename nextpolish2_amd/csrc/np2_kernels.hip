@@ -331,6 +331,22 @@ __global__ void k_mail(uint32_t *__restrict__ dst0, const uint32_t *__restrict__
     if (dst2) *dst2 = *src2;
     if (dst3) *dst3 = *src3;
 }
+// the same gather, then the whole scalar block is posted to host-mapped memory followed by a sequence number the
+// host spins on (no copy command, no stream synchronisation)
+__global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *__restrict__ mbox, uint32_t seq,
+                       uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
+                       const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
+                       uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (dst0) *dst0 = *src0;
+    if (dst1) *dst1 = *src1;
+    if (dst2) *dst2 = *src2;
+    if (dst3) *dst3 = *src3;
+    __threadfence();
+    for (uint32_t i = 0; i < n_scal; ++i) mbox[1 + i] = __hip_atomic_load(&scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_init_alive(const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
@@ -828,148 +844,6 @@ __global__ void k_pair_count(const np2_read_t *__restrict__ reads, uint32_t R, c
     pcount[r] = cnt;
 }
 
-// one thread per (read, region) pair: the read is found by binary search in the pair offsets
-__global__ void k_pair_fill(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ poff,
-                            uint32_t n_pairs, uint32_t *__restrict__ pair_region, uint32_t *__restrict__ pair_read) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pairs) return;
-    uint32_t lo = 0, hi = R; // last read with poff[r] <= i
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (poff[mid] <= i) lo = mid + 1; else hi = mid;
-    }
-    const uint32_t r = lo - 1;
-    pair_region[i] = pj[r] + (i - poff[r]);
-    pair_read[i] = r;
-}
-// pairs per region = number of reads whose region interval [j, s] covers it: difference array
-__global__ void k_pair_region_diff(uint32_t R, const uint32_t *__restrict__ pj, const uint32_t *__restrict__ pcount,
-                                   int32_t *__restrict__ reg_diff) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R || pcount[r] == 0) return;
-    atomicAdd(&reg_diff[pj[r]], 1);
-    atomicAdd(&reg_diff[pj[r] + pcount[r]], -1);
-}
-
-struct CandCtx {
-    const np2_read_t *reads;
-    const uint8_t *nib;
-    const uint64_t *ck_off;
-    const uint32_t *ckpt;
-    const uint32_t *lq_start;
-    const uint32_t *lq_end;
-    const uint32_t *pj;
-    uint32_t ksize;
-};
-
-// sequential nibble reader with a 16-column (8-byte) register window; `base` is 16-byte aligned
-struct NibReader {
-    const uint8_t *base;
-    uint64_t w;     // current window, nibble of column c at bits 4*(c & 15)
-    uint32_t wbase; // first column of the window (multiple of 16), 0xFFFFFFFF = empty
-    __device__ __forceinline__ uint8_t get(uint32_t c) {
-        const uint32_t b = c & ~15u;
-        if (b != wbase) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(base + (b >> 1));
-            const uint32_t x = ((v.x & 0x0F0F0F0Fu) << 4) | ((v.x >> 4) & 0x0F0F0F0Fu);
-            const uint32_t y = ((v.y & 0x0F0F0F0Fu) << 4) | ((v.y >> 4) & 0x0F0F0F0Fu);
-            w = (uint64_t)x | ((uint64_t)y << 32);
-            wbase = b;
-        }
-        return (uint8_t)((w >> (4 * (c & 15))) & 15);
-    }
-};
-
-// Decode the candidate of (read r, region g): returns seq length; optionally writes the
-// sequence and the hashed first k-mer (main.rs:1478-1521).
-template <bool WRITE>
-__device__ uint32_t cand_decode(const CandCtx &cx, uint32_t r, uint32_t g, uint8_t *__restrict__ seq_out,
-                                uint64_t *kmer_out) {
-    const np2_read_t rd = cx.reads[r];
-    NibReader nr{cx.nib + rd.nib_off, 0, 0xFFFFFFFFu};
-    const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
-    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
-    // locate the reference column of t_pos == start from the nearest checkpoint at or before it
-    uint32_t col = 0, t = rd.aln_t_s;
-    const uint32_t ck_first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT;
-    const uint32_t cki = start >> CKPT_SHIFT;
-    if (r == 0) { // the contig aligned to itself: column index == position (k_diff_reads skips read 0)
-        col = start;
-        t = start;
-    } else if (cki >= ck_first) {
-        col = cx.ckpt[cx.ck_off[r] + (cki - ck_first)];
-        t = cki << CKPT_SHIFT;
-    }
-    while (t < start) {
-        ++col;
-        if (!(nr.get(col) & 8)) ++t;
-    }
-    const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
-    uint64_t fw = 0, rv = 0, l = 0;
-    uint32_t len = 0;
-    for (uint32_t c = col; c < rd.n_cols; ++c) {
-        const uint8_t nb = nr.get(c);
-        if (c != col && !(nb & 8)) ++t;
-        const uint8_t q = nb & 7;
-        if (q != 4) {
-            if (t <= end) {
-                if (WRITE) seq_out[len] = code_to_ascii(q);
-                ++len;
-            }
-            if (l < ksize) { // N/M codes are not filtered here (main.rs:1488-1492)
-                fw = ((fw << 2) | (uint64_t)q) & mask;
-                rv = (rv >> 2) | ((3ULL ^ (uint64_t)q) << shift);
-                ++l;
-            }
-            if (t > end && l >= ksize) break;
-        }
-        if (t > limit) break; // this column was the last one decoded
-    }
-    if (WRITE) {
-        uint64_t km = INVALID_KMER;
-        if (l >= ksize) km = yak_hash64(fw < rv ? fw : rv, mask);
-        *kmer_out = km;
-    }
-    return len;
-}
-
-__global__ void k_cand_measure(CandCtx cx, const uint32_t *__restrict__ pair_region,
-                               const uint32_t *__restrict__ pair_read, uint32_t n_pairs,
-                               uint32_t *__restrict__ pair_len) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pairs) return;
-    pair_len[i] = cand_decode<false>(cx, pair_read[i], pair_region[i], nullptr, nullptr);
-}
-
-// per region: keep the first 60 non-empty candidates in read order (main.rs:1474,1509)
-__global__ void k_region_rank(const uint32_t *__restrict__ reg_poff, uint32_t n_reg,
-                              const uint32_t *__restrict__ pair_len, uint32_t *__restrict__ pair_keep,
-                              uint32_t *__restrict__ reg_ncand) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_reg) return;
-    uint32_t c = 0;
-    for (uint32_t i = reg_poff[g]; i < reg_poff[g + 1]; ++i) {
-        const bool keep = pair_len[i] > 0 && c < LQSEQ_MAX_CAN_COUNT;
-        pair_keep[i] = keep ? pair_len[i] : 0; // kept length (0 = dropped)
-        c += keep;
-    }
-    reg_ncand[g] = c;
-}
-
-__global__ void k_cand_write(CandCtx cx, const uint32_t *__restrict__ pair_region,
-                             const uint32_t *__restrict__ pair_read, const uint32_t *__restrict__ pair_keep,
-                             const uint32_t *__restrict__ cand_idx, const uint32_t *__restrict__ seq_off,
-                             uint32_t n_pairs, uint32_t *__restrict__ cand_order, uint64_t *__restrict__ cand_kmer,
-                             uint32_t *__restrict__ cand_seq_off, uint8_t *__restrict__ cand_seq) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pairs || pair_keep[i] == 0) return;
-    const uint32_t ci = cand_idx[i];
-    const uint32_t so = seq_off[i];
-    cand_order[ci] = pair_read[i];
-    cand_seq_off[ci] = so;
-    cand_decode<true>(cx, pair_read[i], pair_region[i], cand_seq + so, &cand_kmer[ci]);
-}
-
 // ------------------------------------------------------------------------------------------
 // K10/K11: HBM-resident yak table.  1024 sub-tables (one per file bucket, x & 1023), each
 // open-addressed with linear probing on (x >> 10); the slot holds the file word verbatim
@@ -1122,6 +996,11 @@ void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1, 
                  const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, d0, s0, d1, s1, d2, s2, d3, s3);
 }
+void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
+                 const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,
+                 const uint32_t *s3) {
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, s, scal, n_scal, mbox, seq, d0, s0, d1, s1, d2, s2, d3, s3);
+}
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
     hipLaunchKernelGGL(k_init_alive, grid1(R), dim3(256), 0, s, reads, R, alive);
 }
@@ -1201,33 +1080,6 @@ void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const
                        uint32_t *pj, uint32_t *pcount) {
     hipLaunchKernelGGL(k_pair_count, grid1(R), dim3(256), 0, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj,
                        pcount);
-}
-void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
-                      uint32_t n_pairs, uint32_t *pair_region, uint32_t *pair_read, int32_t *reg_diff) {
-    hipLaunchKernelGGL(k_pair_region_diff, grid1(R), dim3(256), 0, s, R, pj, pcount, reg_diff);
-    if (n_pairs)
-        hipLaunchKernelGGL(k_pair_fill, grid1(n_pairs), dim3(256), 0, s, R, pj, poff, n_pairs, pair_region, pair_read);
-}
-static CandCtx mk_cand(const CandPtrs &c) {
-    return CandCtx{c.reads, c.nib, c.ck_off, c.ckpt, c.lq_start, c.lq_end, c.pj, c.ksize};
-}
-void launch_cand_measure(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
-                         uint32_t n_pairs, uint32_t *pair_len) {
-    if (n_pairs)
-        hipLaunchKernelGGL(k_cand_measure, grid1(n_pairs, 64), dim3(64), 0, s, mk_cand(c), pair_region, pair_read,
-                           n_pairs, pair_len);
-}
-void launch_region_rank(hipStream_t s, const uint32_t *reg_poff, uint32_t n_reg, const uint32_t *pair_len,
-                        uint32_t *pair_keep, uint32_t *reg_ncand) {
-    hipLaunchKernelGGL(k_region_rank, grid1(n_reg, 64), dim3(64), 0, s, reg_poff, n_reg, pair_len, pair_keep,
-                       reg_ncand);
-}
-void launch_cand_write(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
-                       const uint32_t *pair_keep, const uint32_t *cand_idx, const uint32_t *seq_off, uint32_t n_pairs,
-                       uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq) {
-    if (n_pairs)
-        hipLaunchKernelGGL(k_cand_write, grid1(n_pairs, 64), dim3(64), 0, s, mk_cand(c), pair_region, pair_read,
-                           pair_keep, cand_idx, seq_off, n_pairs, cand_order, cand_kmer, cand_seq_off, cand_seq);
 }
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag) {

@@ -45,6 +45,11 @@ struct CandPtrs {
     const uint32_t *lq_start;
     const uint32_t *lq_end;
     const uint32_t *pj;
+    const uint32_t *pcount;
+    const uint8_t *alive;
+    const uint32_t *tile_rd_off; // per contig tile: reads overlapping it, ascending read index (built at upload)
+    const uint32_t *tile_rd;
+    uint32_t n_tiles;
     uint32_t ksize;
 };
 struct YakDev {
@@ -62,6 +67,9 @@ void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *ni
 void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks);
 void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr,
                  uint32_t *d2 = nullptr, const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
+void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0 = nullptr,
+                 const uint32_t *s0 = nullptr, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
+                 const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag);
@@ -88,17 +96,6 @@ void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint3
                            uint32_t *lq_end, uint32_t *n_reg);
 void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                    uint32_t n_reg, int32_t *mval);
-void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
-                       const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
-void launch_pair_fill(hipStream_t s, uint32_t R, const uint32_t *pj, const uint32_t *pcount, const uint32_t *poff,
-                      uint32_t n_pairs, uint32_t *pair_region, uint32_t *pair_read, int32_t *reg_diff);
-void launch_cand_measure(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
-                         uint32_t n_pairs, uint32_t *pair_len);
-void launch_region_rank(hipStream_t s, const uint32_t *reg_poff, uint32_t n_reg, const uint32_t *pair_len,
-                        uint32_t *pair_keep, uint32_t *reg_ncand);
-void launch_cand_write(hipStream_t s, const CandPtrs &c, const uint32_t *pair_region, const uint32_t *pair_read,
-                       const uint32_t *pair_keep, const uint32_t *cand_idx, const uint32_t *seq_off, uint32_t n_pairs,
-                       uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq);
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag);
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count, uint16_t *out);
@@ -108,6 +105,22 @@ void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_
                        const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
                        uint32_t *long_list, uint32_t *n_long);
 
+
+// ---- np2_cand.hip: region-major candidate extraction, single-block scans -----------------------------
+void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
+                       const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
+void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
+                            uint32_t *total_out, bool write_end); // write_end: also out[n] = total
+void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
+void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
+void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes);
+void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, uint32_t n_reg,
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes);
+void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
+                         const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
+                         const uint32_t *cand_off, const uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap,
+                         uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq);
 
 // ---- np2_graph.hip: tile-bucketed exception sort and per-pass graph construction ---------------------
 void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-step view of a rocprofv3 --stats kernel_stats.csv: python tools/kstats.py <csv> <steps_incl_warmup>"""
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+tot = 0.0
+out = []
+for r in rows:
+    n = r["Name"]
+    m = re.search(r"np2::(\w+)", n)
+    if m:
+        nm = m.group(1)
+    elif "init_lookback" in n:
+        nm = "prim:init_lookback"
+    else:
+        m = re.search(r"wrapped_(\w+?)_config", n)
+        nm = "prim:" + (m.group(1) if m else n[:40])
+    us = float(r["TotalDurationNs"]) / steps / 1e3
+    tot += us
+    out.append((us, nm, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3))
+for us, nm, calls, avg in sorted(out, reverse=True):
+    print(f"{nm:34s} calls/step {calls:6.1f}  us/step {us:8.1f}  avg {avg:7.1f}")
+print(f"total us/step {tot:.1f}; launches/step {sum(o[2] for o in out):.1f}")
