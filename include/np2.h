@@ -125,7 +125,10 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
                    uint32_t *out_ids, uint32_t *n_out);
 
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
- * names: NUL-separated list terminated by an empty string; ms[i] matches names[i]. */
+ * names: NUL-separated list terminated by an empty string; ms[i] matches names[i].
+ * By default only the dense pass ("diff_reads") is timed; np2_ctx_set_timing(ctx, 1) arms every stage timer
+ * (each one costs two event packets on the stream). */
+void np2_ctx_set_timing(np2_ctx_t *ctx, int enable);
 int np2_last_timings(np2_ctx_t *ctx, const char **names, const float **ms, int *n);
 
 #ifdef __cplusplus

@@ -19,7 +19,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
-    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_phase_vote",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_phase_vote",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -56,6 +56,8 @@ def lib():
         L.np2_score_strings.argtypes = [vp, C.c_int, vp, vp, u64, u16, vp]
         L.np2_lookup_hashes.argtypes = [vp, C.c_int, vp, u64, u16, vp]
         L.np2_ctx_set_trace.argtypes = [vp, C.c_int]
+        L.np2_ctx_set_timing.argtypes = [vp, C.c_int]
+        L.np2_ctx_set_timing.restype = None
         L.np2_trace_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
         L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.np2_last_span.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
@@ -141,6 +143,10 @@ class Polisher:
 
     def set_trace(self, on=True):
         lib().np2_ctx_set_trace(self._h, 1 if on else 0)
+
+    def set_timing(self, on=True):
+        """Arm every per-stage HIP-event timer (default: only the dense pass is timed)."""
+        lib().np2_ctx_set_timing(self._h, 1 if on else 0)
 
     def upload(self, pileup: Pileup) -> ResidentContig:
         h = C.c_void_p()

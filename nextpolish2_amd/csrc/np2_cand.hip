@@ -6,6 +6,7 @@
 // writes strings and first k-mers once the offsets are known.  No (read, region) pair list is ever materialised.
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_blockscan.hpp"
 
 namespace np2 {
 
@@ -13,44 +14,25 @@ namespace np2 {
 // single-block scans for short arrays (region / read / pair counts): no temp storage, no init launch, the
 // element count may live on the device
 // ------------------------------------------------------------------------------------------------------
-template <int MODE> // 0: exclusive sum (out[n] = total), 1: inclusive sum, 2: inclusive min (signed)
+template <int MODE> // 0: exclusive sum (optionally out[n] = total), 1: inclusive sum, 2: inclusive min (signed)
 __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                      uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                      uint32_t *__restrict__ total_out, bool write_end) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t sh[16];
     const uint32_t n = n_dev ? min(*n_dev, n_host) : n_host;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t a = min(n, tid * per), b = min(n, a + per);
-    const uint32_t ident = MODE == 2 ? 0x7FFFFFFFu : 0u;
-    auto op = [](uint32_t x, uint32_t y) -> uint32_t {
-        if (MODE == 2) return (uint32_t)min((int32_t)x, (int32_t)y);
-        return x + y;
-    };
-    uint32_t acc = ident;
-    for (uint32_t i = a; i < b; ++i) acc = op(acc, in[i]);
-    part[tid] = acc;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = tid >= o ? part[tid - o] : ident;
-        __syncthreads();
-        part[tid] = op(part[tid], v);
-        __syncthreads();
+    uint32_t total;
+    if (MODE == 2) {
+        total = block_scan_array<OpMinI32>(
+            n, sh, [&](uint32_t i) { return in[i]; },
+            [&](uint32_t i, uint32_t pre, uint32_t v) { out[i] = OpMinI32::apply(pre, v); });
+    } else {
+        total = block_scan_array<OpAdd>(
+            n, sh, [&](uint32_t i) { return in[i]; },
+            [&](uint32_t i, uint32_t pre, uint32_t v) { out[i] = MODE == 0 ? pre : pre + v; });
     }
-    uint32_t run = tid ? part[tid - 1] : ident; // everything before this thread's segment
-    for (uint32_t i = a; i < b; ++i) {
-        const uint32_t v = in[i];
-        if (MODE == 0) {
-            out[i] = run;
-            run += v;
-        } else {
-            run = op(run, v);
-            out[i] = run;
-        }
-    }
-    if (tid == 1023) {
-        if (MODE == 0 && write_end) out[n] = part[1023];
-        if (total_out) *total_out = part[1023];
+    if (threadIdx.x == 0) {
+        if (MODE == 0 && write_end) out[n] = total;
+        if (total_out) *total_out = total;
     }
 }
 
@@ -269,39 +251,16 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restric
                                                        const uint32_t *__restrict__ reg_bytes, uint32_t n_reg,
                                                        uint32_t *__restrict__ cand_off, uint32_t *__restrict__ reg_soff,
                                                        uint32_t *__restrict__ n_cand, uint32_t *__restrict__ n_bytes) {
-    __shared__ uint32_t pa[1024];
-    __shared__ uint32_t pb[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_reg + 1023) / 1024;
-    const uint32_t a = min(n_reg, tid * per), b = min(n_reg, a + per);
-    uint32_t sa = 0, sb = 0;
-    for (uint32_t i = a; i < b; ++i) {
-        sa += reg_ncand[i];
-        sb += reg_bytes[i];
-    }
-    pa[tid] = sa;
-    pb[tid] = sb;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
-        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
-        __syncthreads();
-        pa[tid] += va;
-        pb[tid] += vb;
-        __syncthreads();
-    }
-    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
-    for (uint32_t i = a; i < b; ++i) {
-        cand_off[i] = ra;
-        reg_soff[i] = rb;
-        ra += reg_ncand[i];
-        rb += reg_bytes[i];
-    }
-    if (tid == 1023) {
-        cand_off[n_reg] = pa[1023];
-        reg_soff[n_reg] = pb[1023];
-        *n_cand = pa[1023];
-        *n_bytes = pb[1023];
+    __shared__ uint32_t sh[16];
+    const uint32_t ta = block_scan_array<OpAdd>(
+        n_reg, sh, [&](uint32_t i) { return reg_ncand[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { cand_off[i] = pre; });
+    const uint32_t tb = block_scan_array<OpAdd>(
+        n_reg, sh, [&](uint32_t i) { return reg_bytes[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { reg_soff[i] = pre; });
+    if (threadIdx.x == 0) {
+        cand_off[n_reg] = ta;
+        reg_soff[n_reg] = tb;
+        *n_cand = ta;
+        *n_bytes = tb;
     }
 }
 

@@ -7,6 +7,7 @@
 // contig and half a dozen L-sized passes by three short launches per pass.
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_blockscan.hpp"
 
 namespace np2 {
 
@@ -88,48 +89,23 @@ __global__ __launch_bounds__(1024) void k_tile_layout(uint32_t *__restrict__ til
                                                       uint32_t bucket_cap, uint32_t *__restrict__ tile_n,
                                                       uint32_t *__restrict__ tile_scan, uint32_t *__restrict__ tile_scanb,
                                                       const uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ out) {
-    __shared__ uint32_t pa[1024];
-    __shared__ uint32_t pb[1024];
-    __shared__ uint32_t red[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_tiles + 1023) / 1024;
-    const uint32_t a = min(n_tiles, tid * per), b = min(n_tiles, a + per);
-    uint32_t sa = 0, sb = 0, mx = 0;
-    for (uint32_t i = a; i < b; ++i) {
-        const uint32_t v = tile_cur[i];
-        sa += v;
-        sb += min(v, bucket_cap);
-        mx = max(mx, v);
-    }
-    pa[tid] = sa;
-    pb[tid] = sb;
-    red[tid] = mx;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scans + running max
-        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
-        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
-        const uint32_t m = tid >= o ? red[tid - o] : 0u;
-        __syncthreads();
-        pa[tid] += va;
-        pb[tid] += vb;
-        red[tid] = max(red[tid], m);
-        __syncthreads();
-    }
-    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
-    for (uint32_t i = a; i < b; ++i) {
-        const uint32_t v = tile_cur[i];
-        tile_n[i] = v;
-        tile_scan[i] = ra;
-        tile_scanb[i] = rb;
-        tile_cur[i] = 0;
-        ra += v;
-        rb += min(v, bucket_cap);
-    }
-    if (tid == 1023) {
-        tile_scan[n_tiles] = pa[1023];
-        tile_scanb[n_tiles] = pb[1023];
-        out[0] = pa[1023];
-        out[1] = red[1023];
+    __shared__ uint32_t sh[16];
+    const uint32_t ta = block_scan_array<OpAdd>(
+        n_tiles, sh, [&](uint32_t i) { return tile_cur[i]; },
+        [&](uint32_t i, uint32_t pre, uint32_t v) {
+            tile_scan[i] = pre;
+            tile_n[i] = v;
+        });
+    const uint32_t tb = block_scan_array<OpAdd>(
+        n_tiles, sh, [&](uint32_t i) { return min(tile_n[i], bucket_cap); },
+        [&](uint32_t i, uint32_t pre, uint32_t) { tile_scanb[i] = pre; });
+    const uint32_t mx = block_scan_array<OpMaxU32>(
+        n_tiles, sh, [&](uint32_t i) { return tile_n[i]; }, [&](uint32_t i, uint32_t, uint32_t) { tile_cur[i] = 0; });
+    if (threadIdx.x == 0) {
+        tile_scan[n_tiles] = ta;
+        tile_scanb[n_tiles] = tb;
+        out[0] = ta;
+        out[1] = mx;
         out[2] = *ovf_cnt;
     }
 }
@@ -306,37 +282,14 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
                                                        const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
                                                        uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
                                                        uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs) {
-    __shared__ uint32_t pa[1024];
-    __shared__ uint32_t pb[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_tiles + 1023) / 1024;
-    const uint32_t a = min(n_tiles, tid * per), b = min(n_tiles, a + per);
-    uint32_t sa = 0, sb = 0;
-    for (uint32_t i = a; i < b; ++i) {
-        sa += tile_nn[i];
-        sb += tile_nr[i];
-    }
-    pa[tid] = sa;
-    pb[tid] = sb;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t va = tid >= o ? pa[tid - o] : 0u;
-        const uint32_t vb = tid >= o ? pb[tid - o] : 0u;
-        __syncthreads();
-        pa[tid] += va;
-        pb[tid] += vb;
-        __syncthreads();
-    }
-    uint32_t ra = pa[tid] - sa, rb = pb[tid] - sb;
-    for (uint32_t i = a; i < b; ++i) {
-        tile_noff[i] = ra;
-        tile_roff[i] = rb;
-        ra += tile_nn[i];
-        rb += tile_nr[i];
-    }
-    if (tid == 1023) {
-        *n_nodes = pa[1023];
-        *n_runs = pb[1023];
+    __shared__ uint32_t sh[16];
+    const uint32_t ta = block_scan_array<OpAdd>(
+        n_tiles, sh, [&](uint32_t i) { return tile_nn[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { tile_noff[i] = pre; });
+    const uint32_t tb = block_scan_array<OpAdd>(
+        n_tiles, sh, [&](uint32_t i) { return tile_nr[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { tile_roff[i] = pre; });
+    if (threadIdx.x == 0) {
+        *n_nodes = ta;
+        *n_runs = tb;
     }
 }
 

@@ -418,7 +418,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         cx->vals_raw.ensure(buckets + ovf_cap + 1);
         zero32(cx, cx->scal.p, S_COUNT);
         {
-            EventTimer t(cx, "diff_reads");
+            EventTimer t(cx, "diff_reads", true);
             launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
                               cx->keys_raw.p, cx->vals_raw.p, cx->tile_cur.p, n_tiles, bcap, buckets, (uint32_t)ovf_cap,
                               cx->scal.p + S_M3, c->ckpt.p, cx->scal.p + S_ERR);
@@ -991,6 +991,9 @@ const char *np2_last_error(np2_ctx_t *cx) { return cx ? cx->err.c_str() : "null 
 void *np2_ctx_stream(np2_ctx_t *cx) { return cx ? (void *)cx->stream : nullptr; }
 void np2_ctx_set_trace(np2_ctx_t *cx, int enable) {
     if (cx) cx->trace = enable != 0;
+}
+void np2_ctx_set_timing(np2_ctx_t *cx, int enable) {
+    if (cx) cx->stage_timing = enable != 0;
 }
 
 int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_read_t *reads, uint32_t n_reads,

@@ -337,15 +337,17 @@ __global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *_
                        uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
                        const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
                        uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3) {
-    if (threadIdx.x || blockIdx.x) return;
-    if (dst0) *dst0 = *src0;
-    if (dst1) *dst1 = *src1;
-    if (dst2) *dst2 = *src2;
-    if (dst3) *dst3 = *src3;
+    if (threadIdx.x == 0) {
+        if (dst0) *dst0 = *src0;
+        if (dst1) *dst1 = *src1;
+        if (dst2) *dst2 = *src2;
+        if (dst3) *dst3 = *src3;
+    }
     __threadfence();
-    for (uint32_t i = 0; i < n_scal; ++i) mbox[1 + i] = __hip_atomic_load(&scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < n_scal) // one wavefront: a single store instruction posts the whole block
+        mbox[1 + threadIdx.x] = __hip_atomic_load(&scal[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
-    __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_init_alive(const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
