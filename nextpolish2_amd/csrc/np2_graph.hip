@@ -233,6 +233,8 @@ struct TileLayout {
     }
 };
 
+static constexpr uint32_t TC_CAP = 2048; // records of a tile staged in LDS by k_tile_count
+
 __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
                                                     const uint8_t *__restrict__ alive,
@@ -240,25 +242,46 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__
     __shared__ uint32_t dirty[TILE / 32];
     __shared__ uint32_t acc[2];
     __shared__ uint32_t prevd;
+    __shared__ uint64_t s_k[TC_CAP];
+    __shared__ uint8_t s_live[TC_CAP];
     const uint32_t tid = threadIdx.x;
-    const uint64_t a = tl.begin(blockIdx.x), b = a + tl.tile_n[blockIdx.x];
+    const uint64_t a = tl.begin(blockIdx.x);
+    const uint32_t n = tl.tile_n[blockIdx.x];
+    const uint64_t b = a + n;
     const uint32_t start = blockIdx.x << TILE_SHIFT;
+    const bool fast = n <= TC_CAP;
     if (tid < TILE / 32) dirty[tid] = 0;
     if (tid < 2) acc[tid] = 0;
     if (tid == 0) {
         prevd = 0;
-        if (start && b > a) {
+        if (start && n) {
             const uint64_t pa = tl.begin(blockIdx.x - 1);
             prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
         }
     }
+    if (fast) {
+        for (uint32_t i = tid; i < n; i += 256) {
+            s_k[i] = keys[a + i];
+            s_live[i] = alive[vals[a + i]];
+        }
+    }
     __syncthreads();
     uint32_t nn = 0;
-    for (uint64_t i = a + tid; i < b; i += 256) {
-        uint32_t cnt, mn;
-        if (group_head(keys, vals, alive, i, a, b, cnt, mn)) {
+    for (uint32_t i = tid; i < n; i += 256) {
+        bool isnode = false;
+        uint64_t k;
+        if (fast) {
+            k = s_k[i];
+            if (i == 0 || s_k[i - 1] != k)
+                for (uint32_t j = i; j < n && s_k[j] == k && !isnode; ++j) isnode = s_live[j] != 0;
+        } else {
+            uint32_t cnt, mn;
+            k = keys[a + i];
+            isnode = group_head(keys, vals, alive, a + i, a, b, cnt, mn);
+        }
+        if (isnode) {
             ++nn;
-            const uint32_t q = (uint32_t)(keys[i] >> 32) - start;
+            const uint32_t q = (uint32_t)(k >> 32) - start;
             atomicOr(&dirty[q >> 5], 1u << (q & 31));
         }
     }
@@ -294,7 +317,11 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
 }
 
 // one block per tile: write the tile's nodes (ordered like Msa::sort over first-seen order: delta3, first read),
-// the packed DP records, node_off for every position of the tile and the tile's dirty-run starts
+// the packed DP records, node_off for every position of the tile and the tile's dirty-run starts.
+// Fast path (tile has at most TW_CAP records): records and nodes are staged in LDS, grouping and per-position
+// ordering never touch global memory.  Larger tiles take the same steps on the global arrays.
+static constexpr uint32_t TW_CAP = 1024;
+
 __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
                                                     const uint32_t *__restrict__ tile_noff,
@@ -305,76 +332,149 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     __shared__ uint32_t cnt[TILE];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t prevd;
+    __shared__ uint64_t s_k[TW_CAP];    // record keys
+    __shared__ uint32_t s_v[TW_CAP];    // record read | live << 31
+    __shared__ uint32_t s_nkey[TW_CAP]; // node: bases | delta << 16
+    __shared__ uint32_t s_ncnt[TW_CAP];
+    __shared__ uint32_t s_nmin[TW_CAP];
     const uint32_t tid = threadIdx.x;
-    const uint64_t a = tl.begin(blockIdx.x), b = a + tl.tile_n[blockIdx.x];
+    const uint64_t a = tl.begin(blockIdx.x);
+    const uint32_t n = tl.tile_n[blockIdx.x];
+    const uint64_t b = a + n;
     const uint32_t start = blockIdx.x << TILE_SHIFT;
     const uint32_t npos = min((uint32_t)TILE, L - start);
     const uint32_t nbase = tile_noff[blockIdx.x];
+    const bool fast = n <= TW_CAP;
     for (uint32_t i = tid; i < TILE; i += 256) cnt[i] = 0;
     if (tid == 0) {
         prevd = 0;
-        if (start && b > a) {
+        if (start && n) {
             const uint64_t pa = tl.begin(blockIdx.x - 1);
             prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
+        }
+    }
+    if (fast) {
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t r = vals[a + i];
+            s_k[i] = keys[a + i];
+            s_v[i] = r | (alive[r] ? 0x80000000u : 0u);
         }
     }
     __syncthreads();
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
-    for (uint64_t c0 = a; c0 < b; c0 += 256) { // uniform trip count: the block scans below need every thread
-        const uint64_t i = c0 + tid;
-        uint32_t gc = 0, gm = 0;
-        const bool isnode = i < b && group_head(keys, vals, alive, i, a, b, gc, gm);
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) { // uniform trip count: the block scans below need every thread
+        const uint32_t i = c0 + tid;
+        uint32_t gc = 0, gm = 0xFFFFFFFFu;
+        bool isnode = false;
+        uint64_t k = 0;
+        if (i < n) {
+            if (fast) {
+                k = s_k[i];
+                if (i == 0 || s_k[i - 1] != k) {
+                    for (uint32_t j = i; j < n && s_k[j] == k; ++j) {
+                        const uint32_t v = s_v[j];
+                        if (v >> 31) {
+                            ++gc;
+                            gm = min(gm, v & 0x7FFFFFFFu);
+                        }
+                    }
+                    isnode = gc != 0;
+                }
+            } else {
+                k = keys[a + i];
+                isnode = group_head(keys, vals, alive, a + i, a, b, gc, gm);
+            }
+        }
         uint32_t tot;
         const uint32_t rank = block_excl_scan_256(isnode ? 1u : 0u, sh, tot);
         if (isnode) {
-            const uint64_t k = keys[i];
-            const uint32_t o = nbase + carry + rank;
-            nd.pos[o] = (uint32_t)(k >> 32);
-            nd.bases[o] = (uint16_t)(k >> 16);
-            nd.delta[o] = (uint16_t)k;
-            nd.count[o] = gc;
-            nd.minr[o] = gm;
-            atomicAdd(&cnt[(uint32_t)(k >> 32) - start], 1u);
+            const uint32_t li = carry + rank; // node index inside the tile
+            const uint32_t q = (uint32_t)(k >> 32) - start;
+            if (fast) {
+                s_nkey[li] = (uint32_t)k; // bases << 16 | delta1 in the key's low word
+                s_ncnt[li] = gc;
+                s_nmin[li] = gm;
+            } else {
+                const uint32_t o = nbase + li;
+                nd.bases[o] = (uint16_t)(k >> 16);
+                nd.delta[o] = (uint16_t)k;
+                nd.count[o] = gc;
+                nd.minr[o] = gm;
+            }
+            atomicAdd(&cnt[q], 1u);
         }
         carry += tot;
     }
     __syncthreads();
+    const uint32_t nn = carry; // nodes of the tile
     // ---- node_off of the tile's positions (4 consecutive positions per thread) --------------------------
     const uint32_t q0 = tid * 4;
     const uint32_t c0 = cnt[q0], c1 = cnt[q0 + 1], c2 = cnt[q0 + 2], c3 = cnt[q0 + 3];
     uint32_t tot;
-    const uint32_t e0 = nbase + block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot);
-    const uint32_t off[5] = {e0, e0 + c0, e0 + c0 + c1, e0 + c0 + c1 + c2, e0 + c0 + c1 + c2 + c3};
+    const uint32_t l0 = block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot); // tile-local node index of position q0
+    const uint32_t off[5] = {l0, l0 + c0, l0 + c0 + c1, l0 + c0 + c1 + c2, l0 + c0 + c1 + c2 + c3};
     for (uint32_t j = 0; j < 4; ++j)
-        if (q0 + j < npos) node_off[start + q0 + j] = off[j];
-    if (blockIdx.x == n_tiles - 1 && tid == 255) node_off[L] = off[4];
+        if (q0 + j < npos) node_off[start + q0 + j] = nbase + off[j];
+    if (blockIdx.x == n_tiles - 1 && tid == 255) node_off[L] = nbase + off[4];
     // ---- order the nodes of each position, emit the packed records ---------------------------------------
     const uint32_t cj[4] = {c0, c1, c2, c3};
-    for (uint32_t j = 0; j < 4; ++j) {
-        if (cj[j] == 0) continue;
-        const uint32_t o0 = off[j], o1 = off[j + 1];
-        for (uint32_t i = o0 + 1; i < o1; ++i) {
-            const uint16_t bb = nd.bases[i], d = nd.delta[i];
-            const uint32_t c = nd.count[i], m = nd.minr[i];
-            const uint32_t kd = node_delta3(bb, d);
-            uint32_t x = i;
-            while (x > o0) {
-                const uint32_t pd = node_delta3(nd.bases[x - 1], nd.delta[x - 1]);
-                if (pd < kd || (pd == kd && nd.minr[x - 1] < m)) break;
-                nd.bases[x] = nd.bases[x - 1];
-                nd.delta[x] = nd.delta[x - 1];
-                nd.count[x] = nd.count[x - 1];
-                nd.minr[x] = nd.minr[x - 1];
-                --x;
+    if (fast) {
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t o0 = off[j], o1 = off[j + 1];
+            for (uint32_t i = o0 + 1; i < o1; ++i) {
+                const uint32_t kk = s_nkey[i], c = s_ncnt[i], m = s_nmin[i];
+                const uint32_t kd = node_delta3((uint16_t)(kk >> 16), (uint16_t)kk);
+                uint32_t x = i;
+                while (x > o0) {
+                    const uint32_t pk = s_nkey[x - 1];
+                    const uint32_t pd = node_delta3((uint16_t)(pk >> 16), (uint16_t)pk);
+                    if (pd < kd || (pd == kd && s_nmin[x - 1] < m)) break;
+                    s_nkey[x] = pk;
+                    s_ncnt[x] = s_ncnt[x - 1];
+                    s_nmin[x] = s_nmin[x - 1];
+                    --x;
+                }
+                s_nkey[x] = kk;
+                s_ncnt[x] = c;
+                s_nmin[x] = m;
             }
-            nd.bases[x] = bb;
-            nd.delta[x] = d;
-            nd.count[x] = c;
-            nd.minr[x] = m;
         }
-        for (uint32_t i = o0; i < o1; ++i)
-            nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
+        __syncthreads();
+        for (uint32_t i = tid; i < nn; i += 256) { // coalesced write-out
+            const uint32_t kk = s_nkey[i], c = s_ncnt[i];
+            const uint32_t o = nbase + i;
+            nd.bases[o] = (uint16_t)(kk >> 16);
+            nd.delta[o] = (uint16_t)kk;
+            nd.count[o] = c;
+            nrec[o] = make_uint2((kk >> 16) | (kk << 16), c);
+        }
+    } else {
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (cj[j] == 0) continue;
+            const uint32_t o0 = nbase + off[j], o1 = nbase + off[j + 1];
+            for (uint32_t i = o0 + 1; i < o1; ++i) {
+                const uint16_t bb = nd.bases[i], d = nd.delta[i];
+                const uint32_t c = nd.count[i], m = nd.minr[i];
+                const uint32_t kd = node_delta3(bb, d);
+                uint32_t x = i;
+                while (x > o0) {
+                    const uint32_t pd = node_delta3(nd.bases[x - 1], nd.delta[x - 1]);
+                    if (pd < kd || (pd == kd && nd.minr[x - 1] < m)) break;
+                    nd.bases[x] = nd.bases[x - 1];
+                    nd.delta[x] = nd.delta[x - 1];
+                    nd.count[x] = nd.count[x - 1];
+                    nd.minr[x] = nd.minr[x - 1];
+                    --x;
+                }
+                nd.bases[x] = bb;
+                nd.delta[x] = d;
+                nd.count[x] = c;
+                nd.minr[x] = m;
+            }
+            for (uint32_t i = o0; i < o1; ++i)
+                nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
+        }
     }
     // ---- dirty-run starts ----------------------------------------------------------------------------------
     const bool pd0 = q0 ? cnt[q0 - 1] != 0 : prevd != 0;

@@ -480,7 +480,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->nminr.ensure(T + 1);
     cx->nscore.ensure(T + 1);
     cx->nbesti.ensure(T + 1);
-    cx->nrec.ensure(T + 1);
+    cx->nrec.ensure((size_t)T + 32); // k_dp_runs prefetches a fixed number of records per run
     cx->node_off.ensure(L + 2);
     cx->covd.ensure(L + 2);
     cx->cov.ensure(L + 2);
@@ -506,7 +506,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
 
 GraphPtrs graph_ptrs(np2_ctx *cx, np2_contig *c) {
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
-    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L};
+    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L, cx->nrec.p};
 }
 
 void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {

@@ -368,6 +368,7 @@ struct Graph {
     NodeArrays nd;
     const int32_t *cov;
     uint32_t L;
+    const uint2 *nrec; // packed node records {bases | delta << 16, count}
 };
 __device__ __forceinline__ void n0_key(const Graph &g, uint32_t p, uint16_t &bases, uint16_t &delta) {
     const uint8_t c = ref_code(g.refnib, p);
@@ -385,7 +386,10 @@ __device__ __forceinline__ void n0_key(const Graph &g, uint32_t p, uint16_t &bas
 __device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
     uint32_t e0 = 0;
     for (uint32_t i = g.node_off[p]; i < g.node_off[p + 1]; ++i)
-        if (node_delta3(g.nd.bases[i], g.nd.delta[i]) == 0) e0 += g.nd.count[i];
+    {
+        const uint2 rc = g.nrec[i];
+        if (node_delta3((uint16_t)rc.x, (uint16_t)(rc.x >> 16)) == 0) e0 += rc.y;
+    }
     return (uint32_t)g.cov[p] - e0;
 }
 
@@ -406,9 +410,26 @@ __device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q,
 // One thread per dirty run.  A position costs two dependent memory rounds: {node_off, cov, contig codes} then the
 // packed node records; the nodes and scores of the current and the previous position live in LDS (element-major,
 // one 4-byte bank per thread: conflict free), nodes beyond DP_CACHE per position fall back to global memory.
-static constexpr uint32_t DP_CACHE = 8;
+static constexpr uint32_t DP_NR = 16;    // node records of a run cached in LDS (per thread)
 static constexpr uint32_t DP_BLOCK = 64;
 
+__device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1, uint8_t c0, uint16_t &bases,
+                                              uint16_t &delta) {
+    if (p >= 2) {
+        bases = (uint16_t)((c2 << 8) | (c1 << 4) | c0);
+        delta = 0;
+    } else if (p == 1) { // (head(-1,1), c0, c1)
+        bases = (uint16_t)(0x0F00 | (c1 << 4) | c0);
+        delta = 1;
+    } else { // (head(-1,0), head(-1,1), c0)
+        bases = (uint16_t)(0x4FF0 | c0);
+        delta = 0;
+    }
+}
+
+// One thread per dirty run.  The run's first DP_NR node records are fetched into LDS up front (one round trip) and
+// the per-position scalars (node_off, coverage, contig code) are requested one position ahead, so the serial DP over
+// the run's positions does not wait on HBM for every position.
 __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict__ run_start,
                                                       const uint32_t *__restrict__ n_runs, Graph g,
                                                       const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
@@ -416,52 +437,67 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
                                                       uint32_t *__restrict__ run_end,
                                                       int64_t *__restrict__ last_n0_score,
                                                       int64_t *__restrict__ run_gain) {
-    __shared__ uint32_t s_key[2][DP_CACHE][DP_BLOCK];
-    __shared__ uint32_t s_cnt[2][DP_CACHE][DP_BLOCK];
-    __shared__ uint32_t s_slo[2][DP_CACHE][DP_BLOCK];
-    __shared__ uint32_t s_shi[2][DP_CACHE][DP_BLOCK];
+    __shared__ uint32_t s_key[DP_NR][DP_BLOCK];
+    __shared__ uint32_t s_cnt[DP_NR][DP_BLOCK];
+    __shared__ uint32_t s_slo[DP_NR][DP_BLOCK];
+    __shared__ uint32_t s_shi[DP_NR][DP_BLOCK];
     const uint32_t t = threadIdx.x;
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], L = g.L;
-    uint32_t cur = 0;
+    const uint32_t o_base = g.node_off[a];
+    uint32_t o0 = o_base, o1 = g.node_off[a + 1];
+    int64_t cov = g.cov[a];
+    uint8_t c2 = a >= 2 ? ref_code(g.refnib, a - 2) : 0, c1 = a >= 1 ? ref_code(g.refnib, a - 1) : 0;
+    uint8_t c0 = ref_code(g.refnib, a);
+    const uint8_t c3 = a >= 3 ? ref_code(g.refnib, a - 3) : 0;
+#pragma unroll
+    for (uint32_t k = 0; k < DP_NR; ++k) { // the node arrays are padded by DP_NR entries
+        const uint2 rc = nrec[o_base + k];
+        s_key[k][t] = rc.x;
+        s_cnt[k][t] = rc.y;
+    }
+    // node records / scores by absolute node index
+    auto rec_of = [&](uint32_t o) -> uint2 {
+        const uint32_t i = o - o_base;
+        return i < DP_NR ? make_uint2(s_key[i][t], s_cnt[i][t]) : nrec[o];
+    };
+    auto score_of = [&](uint32_t o) -> int64_t {
+        const uint32_t i = o - o_base;
+        return i < DP_NR ? (int64_t)(((uint64_t)s_shi[i][t] << 32) | s_slo[i][t]) : nscore[o];
+    };
     // previous position (starts as the clean position a-1: only N0, score 0 by convention)
     uint32_t pv_o0 = 0, pv_n = 0; // exception nodes of the previous position
     uint16_t pv_b0 = 0, pv_d0 = 0;
     int64_t pv_s0 = 0;
     bool pv_valid = a > 0;
-    if (pv_valid) n0_key(g, a - 1, pv_b0, pv_d0);
-    auto rec_of = [&](uint32_t which, uint32_t o0, uint32_t k) -> uint2 {
-        return k < DP_CACHE ? make_uint2(s_key[which][k][t], s_cnt[which][k][t]) : nrec[o0 + k];
-    };
-    auto score_of = [&](uint32_t which, uint32_t o0, uint32_t k) -> int64_t {
-        return k < DP_CACHE ? (int64_t)(((uint64_t)s_shi[which][k][t] << 32) | s_slo[which][k][t]) : nscore[o0 + k];
-    };
+    if (pv_valid) n0_from_codes(a - 1, c3, c2, c1, pv_b0, pv_d0);
     for (uint32_t p = a; p < L; ++p) {
-        // round 1
-        const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
-        const int64_t cov = g.cov[p];
+        // request the next position's scalars now; they are consumed at the end of this iteration
+        uint32_t nx_o1 = o1;
+        int64_t nx_cov = 0;
+        uint8_t nx_c = 0;
+        if (p + 1 < L) {
+            nx_o1 = g.node_off[p + 2];
+            nx_cov = g.cov[p + 1];
+            nx_c = ref_code(g.refnib, p + 1);
+        }
         uint16_t b0, d0;
-        n0_key(g, p, b0, d0);
+        n0_from_codes(p, c2, c1, c0, b0, d0);
         const bool in_run = o1 > o0;
         const uint32_t n = o1 - o0;
-        // round 2: node records -> LDS
         uint32_t e0 = 0;
         for (uint32_t k = 0; k < n; ++k) {
-            const uint2 rc = nrec[o0 + k];
-            if (k < DP_CACHE) {
-                s_key[cur][k][t] = rc.x;
-                s_cnt[cur][k][t] = rc.y;
-            }
+            const uint2 rc = rec_of(o0 + k);
             if (node_delta3((uint16_t)rc.x, (uint16_t)(rc.x >> 16)) == 0) e0 += rc.y;
         }
-        const int64_t c0 = cov - (int64_t)e0;
+        const int64_t cn0 = cov - (int64_t)e0;
         int64_t s0_cur = 0;
         for (uint32_t idx = 0; idx <= n; ++idx) {
             uint16_t kb = b0, kd = d0;
-            int64_t cnt = c0;
+            int64_t cnt = cn0;
             if (idx) {
-                const uint2 rc = rec_of(cur, o0, idx - 1);
+                const uint2 rc = rec_of(o0 + idx - 1);
                 kb = (uint16_t)rc.x, kd = (uint16_t)(rc.x >> 16), cnt = rc.y;
             }
             AlignBase k1, k2, k3;
@@ -473,26 +509,26 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
             } else {
                 score = SCORE_NEG;
                 const uint32_t q = k2.t_pos;
-                uint32_t which = 0, qo0 = 0, qn = 0;
+                uint32_t qo0 = 0, qn = 0;
                 uint16_t qb0 = 0, qd0 = 0;
                 int64_t qs0 = 0;
                 bool ok = false;
                 if (q == p) { // same position: only nodes before K can match (their b3.delta = K.b2.delta)
-                    which = cur, qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
+                    qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
                 } else if (q + 1 == p && pv_valid) {
-                    which = cur ^ 1, qo0 = pv_o0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
+                    qo0 = pv_o0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
                 }
                 if (ok) {
                     for (uint32_t pi = 0; pi < qn; ++pi) {
                         uint16_t vb = qb0, vd = qd0;
                         if (pi) {
-                            const uint2 rc = rec_of(which, qo0, pi - 1);
+                            const uint2 rc = rec_of(qo0 + pi - 1);
                             vb = (uint16_t)rc.x, vd = (uint16_t)(rc.x >> 16);
                         }
                         AlignBase pb1;
                         if (!pred_match(vb, vd, q, k1, k2, pb1)) continue;
                         if (q >= 3 && pb1.is_head()) continue; // main.rs:1666-1668
-                        const int64_t ps = pi ? score_of(which, qo0, pi - 1) : qs0;
+                        const int64_t ps = pi ? score_of(qo0 + pi - 1) : qs0;
                         const int64_t sc = ps + 10 * cnt - 4 * cov;
                         if (sc > score || (sc == score && pb1.q != 4)) { // main.rs:1670
                             score = sc;
@@ -502,13 +538,13 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
                 }
             }
             if (idx) {
-                const uint32_t k = idx - 1;
-                if (k < DP_CACHE) {
-                    s_slo[cur][k][t] = (uint32_t)(uint64_t)score;
-                    s_shi[cur][k][t] = (uint32_t)((uint64_t)score >> 32);
+                const uint32_t o = o0 + idx - 1, i = o - o_base;
+                if (i < DP_NR) {
+                    s_slo[i][t] = (uint32_t)(uint64_t)score;
+                    s_shi[i][t] = (uint32_t)((uint64_t)score >> 32);
                 }
-                nscore[o0 + k] = score;
-                nbesti[o0 + k] = besti;
+                nscore[o] = score;
+                nbesti[o] = besti;
             } else {
                 s0_cur = score;
                 n0_besti[p] = besti;
@@ -520,7 +556,8 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
             return;
         }
         pv_o0 = o0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
-        cur ^= 1;
+        o0 = o1, o1 = nx_o1, cov = nx_cov;
+        c2 = c1, c1 = c0, c0 = nx_c;
     }
     // the run reaches the contig end
     run_end[r] = L - 1;
@@ -596,9 +633,10 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
             cnt = n0_count(g, pos);
             bi = n0_besti[pos];
         } else {
-            kb = g.nd.bases[o0 + idx - 1];
-            kd = g.nd.delta[o0 + idx - 1];
-            cnt = g.nd.count[o0 + idx - 1];
+            const uint2 rc = g.nrec[o0 + idx - 1];
+            kb = (uint16_t)rc.x;
+            kd = (uint16_t)(rc.x >> 16);
+            cnt = rc.y;
             bi = nbesti[o0 + idx - 1];
         }
         AlignBase k1, k2, k3;
@@ -606,11 +644,12 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
         if (k3.q != 4) {
             if (WRITE) {
                 const int64_t cov = g.cov[k3.t_pos];
-                const int64_t qv = cov > 0 ? (int64_t)cnt * 100 / cov : 0;
+                // qv = count * 100 / coverage (integer division); qv < 95 <=> count * 100 < 95 * coverage
+                const bool lq = (int64_t)cnt * 100 < 95 * cov;
                 const uint32_t o = out_end - 1 - n;
                 cns_pos[o] = k3.t_pos;
                 cns_base[o] = code_to_ascii(k3.q);
-                cns_cls[o] = cov < 2 ? CLS_RESET : (qv < 95 ? CLS_LQ : CLS_HQ);
+                cns_cls[o] = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
             }
             ++n;
         }
@@ -1015,7 +1054,7 @@ void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd) {
     hipLaunchKernelGGL(k_cov_delta, grid1(R), dim3(256), 0, s, reads, R, alive, covd);
 }
-static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L}; }
+static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec}; }
 
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,

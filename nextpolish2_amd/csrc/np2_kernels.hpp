@@ -36,6 +36,7 @@ struct GraphPtrs {
     NodeArrays nd;
     const int32_t *cov;
     uint32_t L;
+    const uint2 *nrec; // packed node records {bases | delta << 16, count}
 };
 struct CandPtrs {
     const np2_read_t *reads;

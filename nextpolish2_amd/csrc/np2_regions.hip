@@ -390,16 +390,31 @@ __global__ void k_splice_slots(const uint32_t *__restrict__ flag, const uint32_t
     }
     if (rr == n_reg - 1) *n_ap = slot[rr] + flag[rr];
 }
-__global__ void k_splice_bases(const uint32_t *__restrict__ in_pos, const uint8_t *__restrict__ in_base, uint32_t M,
-                               const uint32_t *__restrict__ ap_s, const uint32_t *__restrict__ ap_e,
-                               const int32_t *__restrict__ ap_shift_incl, const uint32_t *__restrict__ n_ap_p,
-                               uint32_t *__restrict__ out_pos, uint8_t *__restrict__ out_base) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+// copy the bases outside the applied regions to their shifted places.  The slot search is done once per block for
+// the block's first and last index; threads only search the (usually empty) slot range in between.
+__global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict__ in_pos,
+                                                      const uint8_t *__restrict__ in_base, uint32_t M,
+                                                      const uint32_t *__restrict__ ap_s, const uint32_t *__restrict__ ap_e,
+                                                      const int32_t *__restrict__ ap_shift_incl,
+                                                      const uint32_t *__restrict__ n_ap_p, uint32_t *__restrict__ out_pos,
+                                                      uint8_t *__restrict__ out_base) {
+    __shared__ uint32_t s_lo[2];
+    const uint32_t i0 = blockIdx.x * blockDim.x;
+    const uint32_t i = i0 + threadIdx.x;
     const uint32_t n_ap = *n_ap_p;
-    // last slot with ap_s <= i
-    uint32_t lo = 0, hi = n_ap;
-    while (lo < hi) {
+    if (threadIdx.x < 2) { // number of slots with ap_s <= first / last index of the block
+        const uint32_t key = threadIdx.x == 0 ? i0 : min(M - 1, i0 + blockDim.x - 1);
+        uint32_t lo = 0, hi = n_ap;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ap_s[mid] <= key) lo = mid + 1; else hi = mid;
+        }
+        s_lo[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    if (i >= M) return;
+    uint32_t lo = s_lo[0], hi = s_lo[1];
+    while (lo < hi) { // last slot with ap_s <= i
         const uint32_t mid = (lo + hi) >> 1;
         if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
     }
