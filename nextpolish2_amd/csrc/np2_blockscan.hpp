@@ -1,6 +1,6 @@
-// Single-workgroup scans over short device arrays (1024 threads, 4 consecutive elements per thread and tile).
-// Used by the "offsets" kernels that turn per-tile / per-region counts into offsets without temp storage,
-// init launches or host-side element counts.
+// Single-workgroup scans over short device arrays (1024 threads).  A thread owns 4 consecutive elements of each
+// 4096-element tile (coalesced 16-byte accesses); the loads of 8 tiles are issued before the first block-wide scan,
+// so 32 K elements cost one memory round trip plus 8 short scans.
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime.h>
@@ -9,6 +9,7 @@ namespace np2 {
 
 static constexpr uint32_t BS_THREADS = 1024;
 static constexpr uint32_t BS_ITEMS = 4;
+static constexpr uint32_t BS_BATCH = 8; // tiles loaded ahead
 static constexpr uint32_t BS_TILE = BS_THREADS * BS_ITEMS;
 
 struct OpAdd {
@@ -56,23 +57,31 @@ template <class Op> __device__ __forceinline__ uint32_t block_excl_1024(uint32_t
 template <class Op, class Load, class Store>
 __device__ __forceinline__ uint32_t block_scan_array(uint32_t n, uint32_t *sh, Load load, Store store) {
     uint32_t carry = Op::ident();
-    for (uint32_t t0 = 0; t0 < n; t0 += BS_TILE) {
-        const uint32_t i0 = t0 + threadIdx.x * BS_ITEMS;
-        uint32_t v[BS_ITEMS];
-        uint32_t acc = Op::ident();
+    for (uint32_t s0 = 0; s0 < n; s0 += BS_TILE * BS_BATCH) {
+        uint32_t v[BS_BATCH][BS_ITEMS];
 #pragma unroll
-        for (uint32_t k = 0; k < BS_ITEMS; ++k) {
-            v[k] = i0 + k < n ? load(i0 + k) : Op::ident();
-            acc = Op::apply(acc, v[k]);
-        }
-        uint32_t tot;
-        uint32_t run = Op::apply(carry, block_excl_1024<Op>(acc, sh, tot));
+        for (uint32_t b = 0; b < BS_BATCH; ++b) {
+            const uint32_t i0 = s0 + b * BS_TILE + threadIdx.x * BS_ITEMS;
 #pragma unroll
-        for (uint32_t k = 0; k < BS_ITEMS; ++k) {
-            if (i0 + k < n) store(i0 + k, run, v[k]);
-            run = Op::apply(run, v[k]);
+            for (uint32_t k = 0; k < BS_ITEMS; ++k) v[b][k] = i0 + k < n ? load(i0 + k) : Op::ident();
         }
-        carry = Op::apply(carry, tot);
+#pragma unroll
+        for (uint32_t b = 0; b < BS_BATCH; ++b) {
+            const uint32_t t0 = s0 + b * BS_TILE;
+            if (t0 >= n) break; // uniform
+            const uint32_t i0 = t0 + threadIdx.x * BS_ITEMS;
+            uint32_t acc = Op::ident();
+#pragma unroll
+            for (uint32_t k = 0; k < BS_ITEMS; ++k) acc = Op::apply(acc, v[b][k]);
+            uint32_t tot;
+            uint32_t run = Op::apply(carry, block_excl_1024<Op>(acc, sh, tot));
+#pragma unroll
+            for (uint32_t k = 0; k < BS_ITEMS; ++k) {
+                if (i0 + k < n) store(i0 + k, run, v[b][k]);
+                run = Op::apply(run, v[b][k]);
+            }
+            carry = Op::apply(carry, tot);
+        }
     }
     return carry;
 }

@@ -328,7 +328,7 @@ inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_
 }
 
 // short arrays: one single-block kernel (no temp storage, no init launch); long ones: rocPRIM
-static constexpr size_t SCAN_SMALL_MAX = 1u << 15;
+static constexpr size_t SCAN_SMALL_MAX = 1u << 16;
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
     // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
     if (n_plus1 <= SCAN_SMALL_MAX) {

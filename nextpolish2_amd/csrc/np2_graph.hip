@@ -328,8 +328,12 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
                                                     const uint32_t *__restrict__ tile_roff,
                                                     const uint8_t *__restrict__ alive, uint32_t L,
                                                     uint32_t n_tiles, NodeArrays nd, uint2 *__restrict__ nrec,
-                                                    uint32_t *__restrict__ node_off, uint32_t *__restrict__ run_start) {
+                                                    uint32_t *__restrict__ node_off, uint32_t *__restrict__ run_start,
+                                                    const np2_read_t *__restrict__ reads,
+                                                    const uint32_t *__restrict__ tile_rd_off,
+                                                    const uint32_t *__restrict__ tile_rd, int32_t *__restrict__ cov) {
     __shared__ uint32_t cnt[TILE];
+    __shared__ int32_t dcov[TILE + 1];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t prevd;
     __shared__ uint64_t s_k[TW_CAP];    // record keys
@@ -345,8 +349,12 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     const uint32_t npos = min((uint32_t)TILE, L - start);
     const uint32_t nbase = tile_noff[blockIdx.x];
     const bool fast = n <= TW_CAP;
-    for (uint32_t i = tid; i < TILE; i += 256) cnt[i] = 0;
+    for (uint32_t i = tid; i < TILE; i += 256) {
+        cnt[i] = 0;
+        dcov[i] = 0;
+    }
     if (tid == 0) {
+        dcov[TILE] = 0;
         prevd = 0;
         if (start && n) {
             const uint64_t pa = tl.begin(blockIdx.x - 1);
@@ -361,6 +369,27 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
         }
     }
     __syncthreads();
+    // ---- coverage of the tile's positions (Msa::coverage, main.rs:232-241): difference array over the live reads
+    //      overlapping the tile, then a block-wide inclusive scan ----------------------------------------------
+    for (uint32_t i = tile_rd_off[blockIdx.x] + tid; i < tile_rd_off[blockIdx.x + 1]; i += 256) {
+        const uint32_t r = tile_rd[i];
+        if (!alive[r]) continue;
+        const uint32_t ts = reads[r].aln_t_s, te = reads[r].aln_t_e;
+        atomicAdd(&dcov[max(ts, start) - start], 1);
+        atomicAdd(&dcov[min(te, start + TILE - 1) - start + 1], -1);
+    }
+    __syncthreads();
+    {
+        const uint32_t q = tid * 4;
+        const int32_t d0 = dcov[q], d1 = dcov[q + 1], d2 = dcov[q + 2], d3 = dcov[q + 3];
+        uint32_t tot;
+        const int32_t pre = (int32_t)block_excl_scan_256((uint32_t)(d0 + d1 + d2 + d3), sh, tot);
+        const int32_t v0 = pre + d0, v1 = v0 + d1, v2 = v1 + d2, v3 = v2 + d3;
+        if (q < npos) cov[start + q] = v0;
+        if (q + 1 < npos) cov[start + q + 1] = v1;
+        if (q + 2 < npos) cov[start + q + 2] = v2;
+        if (q + 3 < npos) cov[start + q + 3] = v3;
+    }
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < n; c0 += 256) { // uniform trip count: the block scans below need every thread
@@ -529,9 +558,11 @@ void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t 
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
-                       uint32_t *run_start) {
+                       uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
+                       int32_t *cov) {
     hipLaunchKernelGGL(k_tile_write, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
-                       tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start);
+                       tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd,
+                       cov);
 }
 
 } // namespace np2

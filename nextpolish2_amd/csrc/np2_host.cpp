@@ -470,7 +470,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
 
 void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint32_t &n_runs) {
     hipStream_t s = cx->stream;
-    const uint32_t L = c->L, R = c->R;
+    const uint32_t L = c->L;
     const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
     EventTimer t(cx, "build_graph");
     cx->npos.ensure(T + 1);
@@ -482,7 +482,6 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->nbesti.ensure(T + 1);
     cx->nrec.ensure((size_t)T + 32); // k_dp_runs prefetches a fixed number of records per run
     cx->node_off.ensure(L + 2);
-    cx->covd.ensure(L + 2);
     cx->cov.ensure(L + 2);
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
@@ -493,11 +492,8 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
                         cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS);
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
-                      cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p);
-    zero32(cx, cx->covd.p, L + 2);
-    launch_cov_delta(s, c->reads.p, R, cx->alive.p, cx->covd.p);
-    if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, cx->covd.p, cx->cov.p, (size_t)L + 1))
-        throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+                      cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
+                      c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p);
     // no read-back: downstream kernels are launched with the bound below and check the device-side counters
     n_runs = std::min<uint32_t>(T, L);
     n_nodes = T;
