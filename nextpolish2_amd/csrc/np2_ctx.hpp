@@ -203,7 +203,7 @@ struct np2_ctx {
     uint32_t bucket_cap = 0;      // layout of the sorted records of the current contig (0 = compact)
     DevBuf<uint2> nrec;
     DevBuf<uint8_t> votebuf;
-    DevBuf<int64_t> run_gain;
+    DevBuf<int64_t> run_gain, tile_gain;
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
                                                     uint32_t *__restrict__ node_off, uint32_t *__restrict__ run_start,
                                                     const np2_read_t *__restrict__ reads,
                                                     const uint32_t *__restrict__ tile_rd_off,
-                                                    const uint32_t *__restrict__ tile_rd, int32_t *__restrict__ cov) {
+                                                    const uint32_t *__restrict__ tile_rd, int32_t *__restrict__ cov,
+                                                    const uint8_t *__restrict__ refnib, uint32_t *__restrict__ emit,
+                                                    long long *__restrict__ tile_gain) {
     __shared__ uint32_t cnt[TILE];
     __shared__ int32_t dcov[TILE + 1];
     __shared__ uint32_t sh[8];
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     if (tid == 0) {
         dcov[TILE] = 0;
         prevd = 0;
-        if (start && n) {
+        if (start) {
             const uint64_t pa = tl.begin(blockIdx.x - 1);
             prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
         }
@@ -379,16 +381,15 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
         atomicAdd(&dcov[min(te, start + TILE - 1) - start + 1], -1);
     }
     __syncthreads();
+    int32_t cv[4]; // coverage of this thread's four positions
     {
         const uint32_t q = tid * 4;
         const int32_t d0 = dcov[q], d1 = dcov[q + 1], d2 = dcov[q + 2], d3 = dcov[q + 3];
         uint32_t tot;
         const int32_t pre = (int32_t)block_excl_scan_256((uint32_t)(d0 + d1 + d2 + d3), sh, tot);
-        const int32_t v0 = pre + d0, v1 = v0 + d1, v2 = v1 + d2, v3 = v2 + d3;
-        if (q < npos) cov[start + q] = v0;
-        if (q + 1 < npos) cov[start + q + 1] = v1;
-        if (q + 2 < npos) cov[start + q + 2] = v2;
-        if (q + 3 < npos) cov[start + q + 3] = v3;
+        cv[0] = pre + d0, cv[1] = cv[0] + d1, cv[2] = cv[1] + d2, cv[3] = cv[2] + d3;
+        for (uint32_t j = 0; j < 4; ++j)
+            if (q + j < npos) cov[start + q + j] = cv[j];
     }
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
@@ -505,8 +506,28 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
                 nrec[i] = make_uint2((uint32_t)nd.bases[i] | ((uint32_t)nd.delta[i] << 16), nd.count[i]);
         }
     }
-    // ---- dirty-run starts ----------------------------------------------------------------------------------
+    // ---- clean positions: consensus emission flag (the contig base, unless it is a gap code) and their share of the
+    //      best-path score: a clean position after a clean one adds 10 * c0 - 4 * cov = 6 * cov -------------------
     const bool pd0 = q0 ? cnt[q0 - 1] != 0 : prevd != 0;
+    {
+        long long gain = 0;
+        bool pdirty = pd0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const bool d = cj[j] != 0;
+            if (q0 + j < npos) {
+                emit[start + q0 + j] = d ? 0u : (((refnib[(start + q0 + j) >> 1] >> (4 * ((start + q0 + j) & 1))) & 7) != 4 ? 1u : 0u);
+                if (!d && !pdirty) gain += 6LL * cv[j];
+            }
+            pdirty = d;
+        }
+        for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
+        __shared__ long long s_gain[4];
+        if ((tid & 63) == 0) s_gain[tid >> 6] = gain;
+        __syncthreads();
+        // one value per tile, summed later (same-address atomics from every tile would serialise at L2)
+        if (tid == 0) tile_gain[blockIdx.x] = s_gain[0] + s_gain[1] + s_gain[2] + s_gain[3];
+    }
+    // ---- dirty-run starts ----------------------------------------------------------------------------------
     const bool s0 = c0 && !pd0, s1 = c1 && !c0, s2 = c2 && !c1, s3 = c3 && !c2;
     uint32_t r = tile_roff[blockIdx.x] +
                  block_excl_scan_256((uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3, sh, tot);
@@ -559,10 +580,10 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov) {
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain) {
     hipLaunchKernelGGL(k_tile_write, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
                        tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd,
-                       cov);
+                       cov, refnib, emit, tile_gain);
 }
 
 } // namespace np2

@@ -401,6 +401,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     cx->tile_nr.ensure(n_tiles + 2);
     cx->tile_noff.ensure(n_tiles + 2);
     cx->tile_roff.ensure(n_tiles + 2);
+    cx->tile_gain.ensure(n_tiles + 2);
     if (cx->tile_cur.cap < (size_t)n_tiles + 2) { // the cursors are left zeroed by k_tile_layout; clear new storage
         cx->tile_cur.ensure(n_tiles + 2);
         zero32(cx, cx->tile_cur.p, cx->tile_cur.cap);
@@ -485,6 +486,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->cov.ensure(L + 2);
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
+    cx->emit.ensure(L + 2);
     zero32(cx, cx->scal.p, S_COUNT);
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
     launch_tile_count(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, n_tiles,
@@ -493,7 +495,8 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
                         cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS);
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
                       cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
-                      c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p);
+                      c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p, c->refnib.p, cx->emit.p,
+                      (long long *)cx->tile_gain.p);
     // no read-back: downstream kernels are launched with the bound below and check the device-side counters
     n_runs = std::min<uint32_t>(T, L);
     n_nodes = T;
@@ -555,11 +558,10 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     cx->eoff.ensure(L + 2);
     {
         EventTimer t(cx, "dp_backtrack");
-        zero32(cx, cx->n0_besti.p, L + 2);
-        zero32(cx, cx->scal.p + S_BEST, S_COUNT - S_BEST); // best, path_begin, n_raw, n_reg, dup, last, gain
+        // (scalars were zeroed by build_graph; S_GAIN already holds the clean-position gains)
         launch_dp(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
                   cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
-                  cx->scal.p + S_BEST, cx->run_gain.p);
+                  cx->scal.p + S_BEST, cx->run_gain.p, (const long long *)cx->tile_gain.p, (c->L + TILE - 1) >> TILE_SHIFT);
         launch_bt_count(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
                         cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN);
         zero32(cx, cx->emit.p + L, 1);

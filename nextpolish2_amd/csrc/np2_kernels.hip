@@ -565,26 +565,23 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
     *last_n0_score = pv_s0;
 }
 
-// sum of the gains of clean positions whose predecessor is clean (or p == 0): 10*c0 - 4*cov = 6*cov
-__global__ void k_clean_gain(const uint32_t *__restrict__ node_off, const int32_t *__restrict__ cov, uint32_t L,
-                             const int64_t *__restrict__ run_gain, const uint32_t *__restrict__ n_runs,
-                             unsigned long long *__restrict__ total_gain) {
+// absolute best-path score = clean-position gains (one partial per contig tile, from the graph build) + the gains
+// of all dirty runs: grid-stride partial sums, one atomic per block
+__global__ __launch_bounds__(256) void k_sum_gains(const int64_t *__restrict__ run_gain,
+                                                   const uint32_t *__restrict__ n_runs,
+                                                   const long long *__restrict__ tile_gain, uint32_t n_tiles,
+                                                   unsigned long long *__restrict__ total_gain) {
     long long v = 0;
     const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t p = t0; p < L; p += stride) {
-        const bool d = node_off[p + 1] > node_off[p];
-        const bool dp = p > 0 && node_off[p] > node_off[p - 1];
-        if (!d && !dp) v += 6LL * cov[p];
-    }
     const uint32_t nr = *n_runs;
     for (uint32_t r = t0; r < nr; r += stride) v += run_gain[r];
+    for (uint32_t t = t0; t < n_tiles; t += stride) v += tile_gain[t];
     __shared__ long long sm[4];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long s = 0;
-        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) s += sm[w];
+        const long long s = sm[0] + sm[1] + sm[2] + sm[3];
         if (s) atomicAdd(total_gain, (unsigned long long)s);
     }
 }
@@ -663,14 +660,6 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
         idx = bi;
     }
     return n;
-}
-
-__global__ void k_emit_init(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib, uint32_t L,
-                            uint32_t *__restrict__ emit) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= L) return;
-    const bool d = node_off[p + 1] > node_off[p];
-    emit[p] = d ? 0u : (ref_code(refnib, p) != 4 ? 1u : 0u);
 }
 
 __global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
@@ -1058,20 +1047,19 @@ static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off
 
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,
-               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain) {
+               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain,
+               const long long *tile_gain, uint32_t n_tiles) {
     Graph g = mk_graph(gp);
     if (max_runs)
         hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, DP_BLOCK), dim3(DP_BLOCK), 0, s, run_start, n_runs, g, nrec, nscore,
                            nbesti, n0_besti, run_end, last_n0_score, run_gain);
-    hipLaunchKernelGGL(k_clean_gain, dim3(min(1024u, (gp.L + 255) / 256)), dim3(256), 0, s, gp.node_off, gp.cov, gp.L,
-                       run_gain, n_runs, total_gain);
+    hipLaunchKernelGGL(k_sum_gains, dim3(64), dim3(256), 0, s, run_gain, n_runs, tile_gain, n_tiles, total_gain);
     hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
 }
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin) {
     Graph g = mk_graph(gp);
-    hipLaunchKernelGGL(k_emit_init, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.L, emit);
     if (max_runs)
         hipLaunchKernelGGL(k_bt_count, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
                            n0_besti, best_idx, emit, path_begin);

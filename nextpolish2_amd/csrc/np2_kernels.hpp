@@ -77,7 +77,8 @@ void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t
 void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd);
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
                const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
-               unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain);
+               unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain, const long long *tile_gain,
+               uint32_t n_tiles);
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin);
@@ -144,7 +145,7 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov);
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)
