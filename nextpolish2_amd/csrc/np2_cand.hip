@@ -207,11 +207,13 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 // Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col.
 __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
-                                                        uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes) {
+                                                        uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
+                                                        uint32_t *__restrict__ reg_maxlen) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_reg) return;
     const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
+    uint32_t mx = 0;
     const uint32_t tile = min(end >> TILE_SHIFT, cx.n_tiles - 1);
     const uint32_t la = cx.tile_rd_off[tile], lb = cx.tile_rd_off[tile + 1];
     uint32_t kept = 0, bytes = 0;
@@ -239,28 +241,36 @@ __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_r
         }
         kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
         bytes += wave_sum(keep ? len : 0u);
+        mx = max(mx, keep ? len : 0u);
     }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
     if (lane == 0) {
         reg_ncand[g] = kept;
         reg_bytes[g] = bytes;
+        reg_maxlen[g] = mx; // the longest string a splice can put in place of this region
     }
 }
 
 // candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
 __global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restrict__ reg_ncand,
                                                        const uint32_t *__restrict__ reg_bytes, uint32_t n_reg,
+                                                       const uint32_t *__restrict__ reg_maxlen,
                                                        uint32_t *__restrict__ cand_off, uint32_t *__restrict__ reg_soff,
-                                                       uint32_t *__restrict__ n_cand, uint32_t *__restrict__ n_bytes) {
+                                                       uint32_t *__restrict__ n_cand, uint32_t *__restrict__ n_bytes,
+                                                       uint32_t *__restrict__ grow) {
     __shared__ uint32_t sh[16];
     const uint32_t ta = block_scan_array<OpAdd>(
         n_reg, sh, [&](uint32_t i) { return reg_ncand[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { cand_off[i] = pre; });
     const uint32_t tb = block_scan_array<OpAdd>(
         n_reg, sh, [&](uint32_t i) { return reg_bytes[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { reg_soff[i] = pre; });
+    const uint32_t tc = block_scan_array<OpAdd>(
+        n_reg, sh, [&](uint32_t i) { return reg_maxlen[i]; }, [&](uint32_t, uint32_t, uint32_t) {});
     if (threadIdx.x == 0) {
         cand_off[n_reg] = ta;
         reg_soff[n_reg] = tb;
         *n_cand = ta;
         *n_bytes = tb;
+        *grow = tc; // upper bound of the consensus growth of one splice round
     }
 }
 
@@ -312,15 +322,16 @@ static CandCtx mk_cand(const CandPtrs &c) {
                    c.pcount, c.alive, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
 }
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes) {
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen) {
     if (n_reg)
         hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, reg_bytes);
+                           kept_col, reg_ncand, reg_bytes, reg_maxlen);
 }
-void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, uint32_t n_reg,
-                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes) {
-    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, reg_ncand, reg_bytes, n_reg, cand_off, reg_soff, n_cand,
-                       n_bytes);
+void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, const uint32_t *reg_maxlen,
+                         uint32_t n_reg, uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes,
+                         uint32_t *grow) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, reg_ncand, reg_bytes, n_reg, reg_maxlen, cand_off, reg_soff,
+                       n_cand, n_bytes, grow);
 }
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,

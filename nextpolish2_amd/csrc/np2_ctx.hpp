@@ -184,11 +184,17 @@ struct np2_ctx {
     DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
         lq_end;
     DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
-        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
+        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, reg_maxlen, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
     DevBuf<uint64_t> cand_kmer;
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;
     DevBuf<uint32_t> scal; // device scalars: see enum below
+    // decoupled look-back state (np2_lookback.hpp): status words per block, ticket counter, launch epoch
+    DevBuf<uint64_t> lb_status;
+    DevBuf<uint32_t> lb_ticket;
+    uint32_t lb_ticket_total = 0, lb_epoch = 0;
+    static constexpr size_t LB_MAX_BLOCKS = 1u << 20;
+    DevBuf<uint32_t> mlen; // consensus length after each splice round of the final pass (device-side chain)
     // region logic
     DevBuf<uint8_t> reg_lable, grp, ref_seen, bad, cns_base2, rech_groups;
     DevBuf<uint32_t> ecount, first_reg, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
@@ -329,6 +335,27 @@ inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_
 
 // short arrays: one single-block kernel (no temp storage, no init launch); long ones: rocPRIM
 static constexpr size_t SCAN_SMALL_MAX = 1u << 16;
+// look-back descriptor for one launch of n_blocks blocks (fresh epoch, ticket base advanced)
+inline Lookback next_lookback(np2_ctx *cx, uint32_t n_blocks) {
+    if (n_blocks > np2_ctx::LB_MAX_BLOCKS) throw Np2Error(NP2_E_UNSUPPORTED, "look-back scan over too many blocks");
+    if (!cx->lb_status.p) {
+        cx->lb_status.ensure(2 * np2_ctx::LB_MAX_BLOCKS);
+        cx->lb_ticket.ensure(4);
+        HIPCHK(hipMemsetAsync(cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t), cx->stream));
+        HIPCHK(hipMemsetAsync(cx->lb_ticket.p, 0, 16, cx->stream));
+        cx->lb_ticket_total = 0;
+        cx->lb_epoch = 0;
+    }
+    if (++cx->lb_epoch >= (1u << 30)) { // epochs exhausted: start over with cleared status words
+        HIPCHK(hipMemsetAsync(cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t), cx->stream));
+        cx->lb_epoch = 1;
+    }
+    Lookback lb{cx->lb_status.p, cx->lb_status.p + np2_ctx::LB_MAX_BLOCKS, cx->lb_ticket.p, cx->lb_ticket_total,
+                cx->lb_epoch};
+    cx->lb_ticket_total += n_blocks;
+    return lb;
+}
+
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
     // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
     if (n_plus1 <= SCAN_SMALL_MAX) {

@@ -14,29 +14,9 @@ namespace np2 {
 // ------------------------------------------------------------------------------------------------------
 // small block-level helpers (256-thread blocks = 4 wavefronts)
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t &total) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(x, o);
-        if (lane >= (uint32_t)o) x += t;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-}
 // exclusive scan of one value per thread over a 256-thread block; `sh` = 8 words of LDS scratch
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *sh, uint32_t &total) {
-    const uint32_t w = threadIdx.x >> 6;
-    uint32_t wt;
-    const uint32_t e = wave_excl_scan_u32(v, wt);
-    __syncthreads(); // sh may still be read from a previous call
-    if ((threadIdx.x & 63) == 0) sh[w] = wt;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t i = 0; i < w; ++i) base += sh[i];
-    total = sh[0] + sh[1] + sh[2] + sh[3];
-    return base + e;
+    return block_excl_scan<OpAdd, 4>(v, sh, total);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ void trace_cns(np2_ctx *cx, int pass, const std::string &tag, const Cns &c) {
 
 struct PassCounts {
     uint32_t n_reg = 0, NC = 0, SB = 0, M = 0;
+    uint32_t grow = 0; // upper bound of the consensus growth of one splice round (sum of the longest kept candidates)
 };
 
 RegionTables region_tables(np2_ctx *cx, uint32_t n_reg) {
@@ -115,6 +116,7 @@ void check_region_err(np2_ctx *cx, uint32_t e) {
     if (e & 32u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: lqseq.seqs[0] after retain_sort_seqs");
     if (e & 64u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: consensus index out of bounds in reupdate");
     if (e & 128u) throw Np2Error(NP2_E_NOMEM, "cartesian product of chained LQ regions is too large");
+    if (e & LB_ERR) throw Np2Error(NP2_E_DEVICE, "device-wide scan timed out waiting for a predecessor block");
 }
 
 // phasing pass on the GPU tables: mark_hete (main.rs:916-946), pair edges (948-1002); Louvain on the host
@@ -235,57 +237,57 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
     return losers;
 }
 
-// consensus double buffer: cns_pos/cns_base (A) <-> cns_pos2/cns_base2 (B)
+// consensus double buffer: cns_pos/cns_base (A) <-> cns_pos2/cns_base2 (B).  The length lives on the device
+// (M_p); the host only carries an upper bound (M_cap) to size launches and buffers.
 struct CnsDev {
     uint32_t *pos;
     uint8_t *base;
-    uint32_t M;
+    const uint32_t *M_p;
+    uint32_t M_cap;
 };
 
-// update_consensus_with_lqseqs on the device; returns the new consensus (in the other buffer)
-CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, uint32_t grow_bound, bool to_b) {
+// update_consensus_with_lqseqs on the device; returns the new consensus (in the other buffer).  No read-back: the
+// new length is chained on the device into cx->mlen[version].
+CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, uint32_t grow_bound, bool to_b,
+                  uint32_t version) {
     hipStream_t s = cx->stream;
     EventTimer t(cx, "splice");
     cx->sp_idx_s.ensure(n_reg + 2);
     cx->sp_idx_e.ensure(n_reg + 2);
-    cx->sp_flag.ensure(n_reg + 2);
-    cx->sp_slot.ensure(n_reg + 2);
     cx->ap_g.ensure(n_reg + 2);
     cx->ap_s.ensure(n_reg + 2);
     cx->ap_e.ensure(n_reg + 2);
     cx->ap_delta.ensure(n_reg + 2);
     cx->ap_shift.ensure(n_reg + 2);
-    const size_t cap = (size_t)in.M + grow_bound + 64;
+    cx->mlen.ensure(16);
+    const uint32_t out_cap = in.M_cap + grow_bound;
+    const size_t cap = (size_t)out_cap + 64;
     uint32_t *opos = to_b ? cx->cns_pos2.ensure(cap) : cx->cns_pos.ensure(cap);
     uint8_t *obase = to_b ? cx->cns_base2.ensure(cap) : cx->cns_base.ensure(cap);
     zero32(cx, cx->scal.p + S_STUCK, 2); // stuck, n_ap
-    launch_splice_find(s, in.pos, in.M, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
-                       cx->sp_idx_e.p, cx->scal.p + S_STUCK, cx->sp_flag.p);
-    exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
-    zero32(cx, cx->ap_delta.p, n_reg + 2); // slots past n_ap stay 0, so the scan can run over the n_reg bound
-    launch_splice_slots(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p,
-                        cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->scal.p + S_NAP);
-    scan_incl_sum(cx, cx->ap_delta.p, cx->ap_shift.p, n_reg);
-    std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, (const uint32_t *)cx->ap_shift.p + (n_reg - 1));
-    check_region_err(cx, sc[S_ERR]);
-    const uint32_t n_ap = sc[S_NAP];
-    const int32_t total_shift = (int32_t)sc[S_M0];
-    launch_splice_write(s, in.pos, in.base, in.M, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p,
-                        cx->scal.p + S_NAP, n_ap, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->cand_seq.p,
-                        opos, obase);
-    return CnsDev{opos, obase, (uint32_t)((int64_t)in.M + total_shift)};
+    launch_splice_find(s, in.pos, in.M_p, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
+                       cx->sp_idx_e.p, cx->scal.p + S_STUCK);
+    launch_splice_plan(s, next_lookback(cx, (n_reg + 255) / 256), cx->reg_lable.p, lable, n_reg, cx->scal.p + S_STUCK,
+                       cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p,
+                       cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, cx->scal.p + S_NAP, in.M_p, cx->mlen.p + version,
+                       cx->scal.p + S_ERR);
+    launch_splice_write(s, in.pos, in.base, in.M_p, in.M_cap, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p,
+                        cx->ap_shift.p, cx->scal.p + S_NAP, n_reg, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p,
+                        cx->cand_seq.p, opos, obase);
+    return CnsDev{opos, obase, cx->mlen.p + version, out_cap};
 }
 
-Cns fetch_cns_dev(np2_ctx *cx, const CnsDev &c) {
+Cns fetch_cns_dev(np2_ctx *cx, const CnsDev &c) { // trace only
     Cns r;
-    r.pos = d2h(cx, c.pos, c.M);
-    r.base = d2h(cx, c.base, c.M);
+    const uint32_t M = d2h(cx, c.M_p, 1)[0];
+    r.pos = d2h(cx, c.pos, M);
+    r.base = d2h(cx, c.base, M);
     return r;
 }
 
 // reupdate_consensus_with_lqseqs for one yak table, on the device
 CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_idx, uint16_t min_kmer_count,
-                   bool first_yak, bool to_b) {
+                   bool first_yak, bool to_b, uint32_t version) {
     hipStream_t s = cx->stream;
     const uint32_t n_reg = pc.n_reg, ksize = cx->yaks[yak_idx].k;
     uint32_t n_rech = 0, n_groups = 0, n_jobs = 0;
@@ -309,7 +311,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         launch_rech_heads(s, cx->rech.p, cx->scal.p + S_NRECH, n_reg, cx->lq_start.p, cx->lq_end.p, ksize,
                           cx->rech_head.p);
         exclusive_total(cx, cx->rech_head.p, cx->rech_gslot.p, n_reg);
-        launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M,
+        launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
                            cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_njobs.p,
                            cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
         exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_reg + 1);
@@ -343,7 +345,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         launch_rech_select(s, cx->rech.p, cx->scal.p + S_NRECH, n_rech, cx->cand_off.p, cx->keep_n.p, cx->keep_list.p,
                            cx->keep_ks.p, cx->cand_order.p, first_yak, cx->reg_lable.p, cx->seed_cand.p);
     }
-    CnsDev out = splice_gpu(cx, in, n_reg, LB_RECH, pc.SB, to_b);
+    CnsDev out = splice_gpu(cx, in, n_reg, LB_RECH, pc.grow, to_b, version);
     launch_rech_relabel(s, cx->reg_lable.p, n_reg);
     return out;
 }
@@ -631,6 +633,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->reg_ncand.ensure(n_reg + 2);
     cx->reg_bytes.ensure(n_reg + 2);
     cx->reg_soff.ensure(n_reg + 2);
+    cx->reg_maxlen.ensure(n_reg + 2);
     cx->cand_off.ensure(n_reg + 2);
     cx->kept_read.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
     cx->kept_len.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
@@ -646,12 +649,13 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
                           cx->pcount.p);
         // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
-                              cx->reg_bytes.p);
-        launch_cand_offsets(s, cx->reg_ncand.p, cx->reg_bytes.p, n_reg, cx->cand_off.p, cx->reg_soff.p,
-                            cx->scal.p + S_M1, cx->scal.p + S_M2);
+                              cx->reg_bytes.p, cx->reg_maxlen.p);
+        launch_cand_offsets(s, cx->reg_ncand.p, cx->reg_bytes.p, cx->reg_maxlen.p, n_reg, cx->cand_off.p, cx->reg_soff.p,
+                            cx->scal.p + S_M1, cx->scal.p + S_M2, cx->scal.p + S_M3);
         std::vector<uint32_t> m2 = fetch_scal(cx);
         NC = m2[S_M1];
         SB = m2[S_M2];
+        pc.grow = m2[S_M3];
     }
     cx->cand_order.ensure(NC + 2);
     cx->cand_kmer.ensure(NC + 2);
@@ -691,8 +695,13 @@ struct ResultOut {
     uint64_t len = 0;
     bool want_pos = true;
 };
-void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, uint32_t M, ResultOut &r) {
+void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, ResultOut &r) {
     const double t0 = now_ms();
+    // final length + the error word of everything that ran without a read-back since the last one
+    const std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
+    check_region_err(cx, sc[S_ERR]);
+    const uint32_t M = sc[S_M0];
+    if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
     r.len = M;
     r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
     if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
@@ -705,7 +714,7 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, uint3
     HIPCHK(hipStreamSynchronize(cx->stream));
     cx->last_first_pos = span[0];
     cx->last_last_pos = span[1];
-    cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
+    if (cx->stage_timing) cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
 }
 
 void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
@@ -748,7 +757,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
         }
         if (n_reg == 0) {
             if (out_cns) {
-                fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, M, result);
+                fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, result);
                 return;
             }
             reuse = cx->reuse_identical_pass && !cx->trace; // no region -> no read is voted out
@@ -797,18 +806,19 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             }
             if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
             trace_region_tables(cx, (int)pass, "seed", pc, true);
-            CnsDev cur{cx->cns_pos.p, cx->cns_base.p, M};
+            CnsDev cur{cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, M}; // eoff[L] = length of the raw consensus
             bool to_b = true;
-            cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.SB, to_b);
+            uint32_t version = 0;
+            cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.grow, to_b, version++);
             to_b = !to_b;
             if (cx->trace) trace_cns(cx, (int)pass, "cns_succ", fetch_cns_dev(cx, cur));
             for (size_t y = 0; y < cx->yaks.size(); ++y) {
-                cur = recheck_gpu(cx, cur, pc, (int)y, o->min_kmer_count, y == 0, to_b);
+                cur = recheck_gpu(cx, cur, pc, (int)y, o->min_kmer_count, y == 0, to_b, version++);
                 to_b = !to_b;
                 trace_region_tables(cx, (int)pass, "rech" + std::to_string(y), pc, true);
                 if (cx->trace) trace_cns(cx, (int)pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
             }
-            fetch_result(cx, cur.pos, cur.base, cur.M, result);
+            fetch_result(cx, cur.pos, cur.base, cur.M_p, result);
             return;
         }
     }

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <hip/hip_runtime.h>
 #include "../../include/np2.h"
+#include "np2_lookback.hpp"
 
 namespace np2 {
 
@@ -116,9 +117,10 @@ void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, ui
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes);
-void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, uint32_t n_reg,
-                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes);
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen);
+void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, const uint32_t *reg_maxlen,
+                         uint32_t n_reg, uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes,
+                         uint32_t *grow);
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
                          const uint32_t *cand_off, const uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap,
@@ -177,23 +179,26 @@ void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *fl
                          uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out);
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
                  uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err);
-void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, uint32_t M, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg, uint32_t *idx_s, uint32_t *idx_e,
-                        uint32_t *stuck, uint32_t *flag);
-void launch_splice_slots(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, const uint32_t *idx_s,
-                         const uint32_t *idx_e, const uint32_t *seed_cand, const uint32_t *seq_off, uint32_t *ap_g,
-                         uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta, uint32_t *n_ap);
-void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, uint32_t M, const uint32_t *ap_g,
-                         const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta, const int32_t *ap_shift_incl,
-                         const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start, const uint32_t *seed_cand,
-                         const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos, uint8_t *out_base);
+void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
+                        const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg, uint32_t *idx_s,
+                        uint32_t *idx_e, uint32_t *stuck);
+void launch_splice_plan(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
+                        const uint32_t *stuck, const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
+                        const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
+                        int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t *err);
+// M_p: consensus length on the device; M_cap: host-side upper bound used for the launch
+void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, const uint32_t *M_p, uint32_t M_cap,
+                         const uint32_t *ap_g, const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta,
+                         const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
+                         const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
+                         uint8_t *out_base);
 void launch_rech_list(hipStream_t s, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *flag);
 void launch_rech_list2(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, uint32_t *rech,
                        uint32_t *n_rech);
 void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                        const uint32_t *lq_start, const uint32_t *lq_end, uint32_t ksize, uint32_t *headflag);
 void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
-                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, uint32_t M,
+                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, const uint32_t *M_p,
                         const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize, void *groups,
                         uint32_t *njobs, uint32_t *n_groups, uint32_t *err);
 size_t rech_group_bytes();

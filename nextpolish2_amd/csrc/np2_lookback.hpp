@@ -1,0 +1,123 @@
+// Single-pass device-wide exclusive scan of per-block aggregates ("decoupled look-back"), used to fuse
+// flag -> scan -> scatter sequences into one multi-block kernel.
+//
+// Every block takes a ticket (its logical index in the scan order), publishes its aggregate, and wave 0 walks back
+// over the predecessors' status words, 64 at a time, until it meets one that already carries an inclusive prefix.
+// Status word: epoch (30 bits) | state (2 bits: 1 = aggregate, 2 = inclusive prefix) | value (32 bits); a launch
+// uses a fresh epoch, so the status arrays never need clearing.  Predecessors hold lower tickets, i.e. they are
+// already running, which guarantees progress; a spin limit turns a would-be hang into an error flag.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace np2 {
+
+struct Lookback {
+    uint64_t *status_a; // one word per block and scanned quantity
+    uint64_t *status_b;
+    uint32_t *ticket;   // monotonically increasing block counter (never reset)
+    uint32_t ticket_base;
+    uint32_t epoch;     // 1 .. 2^30-1
+};
+
+static constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
+static constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
+static constexpr uint32_t LB_ERR = 0x400u; // or-ed into the error word on a spin timeout
+
+__device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint32_t state, uint32_t value) {
+    return ((uint64_t)epoch << 34) | ((uint64_t)state << 32) | value;
+}
+__device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch, bool &timeout) {
+    uint64_t w;
+    uint32_t spins = 0;
+    for (;;) {
+        w = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 34) == epoch && ((uint32_t)(w >> 32) & 3u) != 0) break;
+        if (++spins > LB_SPIN_LIMIT) {
+            timeout = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return w;
+}
+
+// logical block index of this block in the scan order (uniform across the block); sh: 1 word of LDS
+__device__ __forceinline__ uint32_t lb_block_id(const Lookback &lb, uint32_t *sh) {
+    if (threadIdx.x == 0) sh[0] = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+    __syncthreads();
+    const uint32_t id = sh[0];
+    __syncthreads();
+    return id;
+}
+
+// Exclusive prefixes over the blocks of two block aggregates (agg_a, agg_b: uniform across the block).
+// Called by every thread of the block; returns the prefixes in pre_a / pre_b.  sh: 2 words of LDS.
+__device__ __forceinline__ void lb_exclusive2(const Lookback &lb, uint32_t bid, uint32_t agg_a, uint32_t agg_b,
+                                              uint32_t *sh, uint32_t *err, uint32_t &pre_a, uint32_t &pre_b) {
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        if (lane == 0) {
+            const uint32_t st = bid == 0 ? LB_PREFIX : LB_AGG;
+            __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, st, agg_a), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, st, agg_b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t ea = 0, eb = 0;
+        if (bid > 0) {
+            int64_t j0 = (int64_t)bid - 1;
+            bool timeout = false;
+            for (;;) {
+                const int64_t j = j0 - lane;
+                uint64_t wa = 0, wb = 0;
+                if (j >= 0) {
+                    wa = lb_wait(&lb.status_a[j], lb.epoch, timeout);
+                    wb = lb_wait(&lb.status_b[j], lb.epoch, timeout);
+                }
+                if (__ballot(timeout)) {
+                    if (lane == 0) atomicOr(err, LB_ERR);
+                    break;
+                }
+                // both words of a block are published together, but read one after the other: a block counts as
+                // "prefix" only if both words say so; otherwise use its aggregates... which are only valid if both
+                // words are aggregates.  Re-read until the pair is consistent.
+                while (j >= 0 && (((uint32_t)(wa >> 32) ^ (uint32_t)(wb >> 32)) & 3u)) {
+                    wa = lb_wait(&lb.status_a[j], lb.epoch, timeout);
+                    wb = lb_wait(&lb.status_b[j], lb.epoch, timeout);
+                    if (timeout) break;
+                }
+                const bool is_prefix = j >= 0 && ((uint32_t)(wa >> 32) & 3u) == LB_PREFIX;
+                const uint64_t pm = __ballot(is_prefix);
+                uint32_t va = j >= 0 ? (uint32_t)wa : 0u, vb = j >= 0 ? (uint32_t)wb : 0u;
+                if (pm) {
+                    const uint32_t first = (uint32_t)__builtin_ctzll(pm); // nearest predecessor with a prefix
+                    if (lane > first) va = 0, vb = 0;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    va += __shfl_xor(va, o);
+                    vb += __shfl_xor(vb, o);
+                }
+                ea += va;
+                eb += vb;
+                if (pm) break;
+                j0 -= 64;
+                if (j0 < 0) break;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, LB_PREFIX, ea + agg_a), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, LB_PREFIX, eb + agg_b), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lane == 0) {
+            sh[0] = ea;
+            sh[1] = eb;
+        }
+    }
+    __syncthreads();
+    pre_a = sh[0];
+    pre_b = sh[1];
+    __syncthreads();
+}
+
+} // namespace np2

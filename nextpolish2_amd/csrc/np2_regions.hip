@@ -5,6 +5,8 @@
 //   update_consensus_with_lqseqs (1027-1058) and reupdate_consensus_with_lqseqs (1060-1420).
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_blockscan.hpp"
+#include "np2_lookback.hpp"
 
 namespace np2 {
 
@@ -352,48 +354,70 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t 
 
 // per labelled region: [idx_s, idx_e) to delete; the cursor gets stuck at the leftmost (highest index)
 // labelled region whose start position no longer exists in the consensus
-__global__ void k_splice_find(const uint32_t *__restrict__ cns_pos, uint32_t M, const uint32_t *__restrict__ lq_start,
+__global__ void k_splice_find(const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
+                              const uint32_t *__restrict__ lq_start,
                               const uint32_t *__restrict__ lq_end, const uint8_t *__restrict__ reg_lable,
                               uint8_t lable, uint32_t n_reg, uint32_t *__restrict__ idx_s, uint32_t *__restrict__ idx_e,
                               uint32_t *__restrict__ stuck) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_reg || !(reg_lable[g] & lable)) return;
+    const uint32_t M = *M_p;
     const uint32_t s = lower_bound_u32(cns_pos, M, lq_start[g]);
     const bool found = s < M && cns_pos[s] == lq_start[g];
     idx_s[g] = s;
     idx_e[g] = found ? max(s, upper_bound_u32(cns_pos, M, lq_end[g])) : s;
     if (!found) atomicMax(stuck, g + 1);
 }
-// applied regions in left -> right order (reverse region index): flag + per-slot payload
-__global__ void k_splice_flag(const uint8_t *__restrict__ reg_lable, uint8_t lable, uint32_t n_reg,
-                              const uint32_t *__restrict__ stuck, uint32_t *__restrict__ flag) {
-    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr >= n_reg) return;
-    const uint32_t g = n_reg - 1 - rr;
-    flag[rr] = ((reg_lable[g] & lable) && g + 1 > *stuck) ? 1u : 0u;
-}
-__global__ void k_splice_slots(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot, uint32_t n_reg,
-                               const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ idx_e,
-                               const uint32_t *__restrict__ seed_cand, const uint32_t *__restrict__ seq_off,
-                               uint32_t *__restrict__ ap_g, uint32_t *__restrict__ ap_s, uint32_t *__restrict__ ap_e,
-                               int32_t *__restrict__ ap_delta, uint32_t *__restrict__ n_ap) {
-    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr >= n_reg) return;
-    if (flag[rr]) {
-        const uint32_t g = n_reg - 1 - rr, o = slot[rr];
-        const uint32_t c = seed_cand[g];
-        const uint32_t len = seq_off[c + 1] - seq_off[c];
-        ap_g[o] = g;
-        ap_s[o] = idx_s[g];
-        ap_e[o] = idx_e[g];
-        ap_delta[o] = (int32_t)len - (int32_t)(idx_e[g] - idx_s[g]);
+// Applied regions in left -> right order (reverse region index): flag each region, compact the applied ones into
+// slots with their payload and prefix-sum the length changes -- one pass with a decoupled look-back across blocks.
+// The consensus length is chained on the device (*M_out = *M_in + total shift), so the host does not have to read
+// anything back between splice rounds.
+__global__ __launch_bounds__(256) void k_splice_plan(Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
+                                                     uint8_t lable, uint32_t n_reg, const uint32_t *__restrict__ stuck,
+                                                     const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ idx_e,
+                                                     const uint32_t *__restrict__ seed_cand,
+                                                     const uint32_t *__restrict__ seq_off, uint32_t *__restrict__ ap_g,
+                                                     uint32_t *__restrict__ ap_s, uint32_t *__restrict__ ap_e,
+                                                     int32_t *__restrict__ ap_delta, int32_t *__restrict__ ap_shift_incl,
+                                                     uint32_t *__restrict__ n_ap, const uint32_t *__restrict__ M_in,
+                                                     uint32_t *__restrict__ M_out, uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t rr = bid * 256 + threadIdx.x;
+    uint32_t flag = 0, g = 0, s = 0, e = 0;
+    int32_t delta = 0;
+    if (rr < n_reg) {
+        g = n_reg - 1 - rr;
+        flag = ((reg_lable[g] & lable) && g + 1 > *stuck) ? 1u : 0u;
+        if (flag) {
+            const uint32_t c = seed_cand[g];
+            s = idx_s[g], e = idx_e[g];
+            delta = (int32_t)(seq_off[c + 1] - seq_off[c]) - (int32_t)(e - s);
+        }
     }
-    if (rr == n_reg - 1) *n_ap = slot[rr] + flag[rr];
+    uint32_t cnt, dsum;
+    const uint32_t lo = block_excl_scan<OpAdd, 4>(flag, sh, cnt);
+    const uint32_t ld = block_excl_scan<OpAdd, 4>((uint32_t)delta, sh, dsum);
+    uint32_t pre_c, pre_d;
+    lb_exclusive2(lb, bid, cnt, dsum, sh, err, pre_c, pre_d);
+    if (flag) {
+        const uint32_t o = pre_c + lo;
+        ap_g[o] = g;
+        ap_s[o] = s;
+        ap_e[o] = e;
+        ap_delta[o] = delta;
+        ap_shift_incl[o] = (int32_t)(pre_d + ld) + delta;
+    }
+    if (bid == n_blocks - 1 && threadIdx.x == 0) {
+        *n_ap = pre_c + cnt;
+        *M_out = *M_in + pre_d + dsum;
+    }
 }
 // copy the bases outside the applied regions to their shifted places.  The slot search is done once per block for
 // the block's first and last index; threads only search the (usually empty) slot range in between.
 __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict__ in_pos,
-                                                      const uint8_t *__restrict__ in_base, uint32_t M,
+                                                      const uint8_t *__restrict__ in_base,
+                                                      const uint32_t *__restrict__ M_p,
                                                       const uint32_t *__restrict__ ap_s, const uint32_t *__restrict__ ap_e,
                                                       const int32_t *__restrict__ ap_shift_incl,
                                                       const uint32_t *__restrict__ n_ap_p, uint32_t *__restrict__ out_pos,
@@ -401,7 +425,8 @@ __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict
     __shared__ uint32_t s_lo[2];
     const uint32_t i0 = blockIdx.x * blockDim.x;
     const uint32_t i = i0 + threadIdx.x;
-    const uint32_t n_ap = *n_ap_p;
+    const uint32_t n_ap = *n_ap_p, M = *M_p;
+    if (i0 >= M) return;
     if (threadIdx.x < 2) { // number of slots with ap_s <= first / last index of the block
         const uint32_t key = threadIdx.x == 0 ? i0 : min(M - 1, i0 + blockDim.x - 1);
         uint32_t lo = 0, hi = n_ap;
@@ -481,12 +506,12 @@ struct RechGroup { // one recheck group = 1..6 chained RECH regions
 
 __global__ void k_rech_groups(const uint32_t *__restrict__ headflag, const uint32_t *__restrict__ gslot,
                               const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
-                              const uint32_t *__restrict__ cns_pos, uint32_t M, const uint32_t *__restrict__ lq_start,
-                              const uint32_t *__restrict__ lq_end, const uint32_t *__restrict__ keep_n, uint32_t ksize,
-                              RechGroup *__restrict__ groups, uint32_t *__restrict__ njobs,
-                              uint32_t *__restrict__ n_groups, uint32_t *__restrict__ err) {
+                              const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
+                              const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end,
+                              const uint32_t *__restrict__ keep_n, uint32_t ksize, RechGroup *__restrict__ groups,
+                              uint32_t *__restrict__ njobs, uint32_t *__restrict__ n_groups, uint32_t *__restrict__ err) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_rech = *n_rech_p;
+    const uint32_t n_rech = *n_rech_p, M = *M_p;
     if (e >= n_rech) return;
     if (e == n_rech - 1) *n_groups = gslot[e] + headflag[e];
     if (!headflag[e]) return;
@@ -690,26 +715,26 @@ void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, u
         hipLaunchKernelGGL(k_seed, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, max_indel_len, reg_lable, seed_cand,
                            keep_n, keep_list, keep_ks, err);
 }
-void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, uint32_t M, const uint32_t *lq_start,
+void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
                         const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
-                        uint32_t *idx_s, uint32_t *idx_e, uint32_t *stuck, uint32_t *flag) {
-    hipLaunchKernelGGL(k_splice_find, g1(n_reg), dim3(256), 0, s, cns_pos, M, lq_start, lq_end, reg_lable, lable, n_reg,
+                        uint32_t *idx_s, uint32_t *idx_e, uint32_t *stuck) {
+    hipLaunchKernelGGL(k_splice_find, g1(n_reg), dim3(256), 0, s, cns_pos, M_p, lq_start, lq_end, reg_lable, lable, n_reg,
                        idx_s, idx_e, stuck);
-    hipLaunchKernelGGL(k_splice_flag, g1(n_reg), dim3(256), 0, s, reg_lable, lable, n_reg, stuck, flag);
 }
-void launch_splice_slots(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg,
-                         const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
-                         const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
-                         uint32_t *n_ap) {
-    hipLaunchKernelGGL(k_splice_slots, g1(n_reg), dim3(256), 0, s, flag, slot, n_reg, idx_s, idx_e, seed_cand, seq_off,
-                       ap_g, ap_s, ap_e, ap_delta, n_ap);
+void launch_splice_plan(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
+                        const uint32_t *stuck, const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
+                        const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
+                        int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t *err) {
+    const uint32_t nb = (n_reg + 255) / 256;
+    hipLaunchKernelGGL(k_splice_plan, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e,
+                       seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, err);
 }
-void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, uint32_t M,
+void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, const uint32_t *M_p, uint32_t M_cap,
                          const uint32_t *ap_g, const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta,
                          const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base) {
-    hipLaunchKernelGGL(k_splice_bases, g1(M), dim3(256), 0, s, in_pos, in_base, M, ap_s, ap_e, ap_shift_incl, n_ap,
+    hipLaunchKernelGGL(k_splice_bases, g1(M_cap), dim3(256), 0, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap,
                        out_pos, out_base);
     if (max_ap)
         hipLaunchKernelGGL(k_splice_seeds, g1(max_ap, 64), dim3(64), 0, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap,
@@ -729,11 +754,11 @@ void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_re
                            headflag);
 }
 void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
-                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, uint32_t M,
+                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, const uint32_t *M_p,
                         const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize,
                         void *groups, uint32_t *njobs, uint32_t *n_groups, uint32_t *err) {
     if (max_rech)
-        hipLaunchKernelGGL(k_rech_groups, g1(max_rech, 64), dim3(64), 0, s, headflag, gslot, rech, n_rech_p, cns_pos, M,
+        hipLaunchKernelGGL(k_rech_groups, g1(max_rech, 64), dim3(64), 0, s, headflag, gslot, rech, n_rech_p, cns_pos, M_p,
                            lq_start, lq_end, keep_n, ksize, (RechGroup *)groups, njobs, n_groups, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
