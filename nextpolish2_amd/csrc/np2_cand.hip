@@ -208,14 +208,16 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
-                                                        uint32_t *__restrict__ reg_maxlen) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_reg) return;
-    const uint32_t start = cx.lq_start[g], end = cx.lq_end[g];
+                                                        uint32_t *__restrict__ blk_sum) {
+    // blk_sum: per block of 4 regions, three arrays of gridDim.x entries: candidates, bytes, longest kept strings
+    __shared__ uint32_t s_w[3][4];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * 4 + wv;
+    const bool live = g < n_reg;
+    const uint32_t start = live ? cx.lq_start[g] : 0u, end = live ? cx.lq_end[g] : 0u;
     uint32_t mx = 0;
     const uint32_t tile = min(end >> TILE_SHIFT, cx.n_tiles - 1);
-    const uint32_t la = cx.tile_rd_off[tile], lb = cx.tile_rd_off[tile + 1];
+    const uint32_t la = live ? cx.tile_rd_off[tile] : 0u, lb = live ? cx.tile_rd_off[tile + 1] : 0u;
     uint32_t kept = 0, bytes = 0;
     for (uint32_t c0 = la; c0 < lb && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
         const uint32_t i = c0 + lane;
@@ -245,26 +247,34 @@ __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_r
     }
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
     if (lane == 0) {
-        reg_ncand[g] = kept;
-        reg_bytes[g] = bytes;
-        reg_maxlen[g] = mx; // the longest string a splice can put in place of this region
+        if (live) {
+            reg_ncand[g] = kept;
+            reg_bytes[g] = bytes;
+        }
+        s_w[0][wv] = kept;
+        s_w[1][wv] = bytes;
+        s_w[2][wv] = mx; // the longest string a splice can put in place of this region
     }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        blk_sum[threadIdx.x * gridDim.x + blockIdx.x] =
+            s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
 }
 
 // candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
-__global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restrict__ reg_ncand,
-                                                       const uint32_t *__restrict__ reg_bytes, uint32_t n_reg,
-                                                       const uint32_t *__restrict__ reg_maxlen,
-                                                       uint32_t *__restrict__ cand_off, uint32_t *__restrict__ reg_soff,
-                                                       uint32_t *__restrict__ n_cand, uint32_t *__restrict__ n_bytes,
-                                                       uint32_t *__restrict__ grow) {
+__global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restrict__ blk_sum, uint32_t n_blk,
+                                                       uint32_t n_reg, uint32_t *__restrict__ blk_coff,
+                                                       uint32_t *__restrict__ blk_soff, uint32_t *__restrict__ cand_off,
+                                                       uint32_t *__restrict__ reg_soff, uint32_t *__restrict__ n_cand,
+                                                       uint32_t *__restrict__ n_bytes, uint32_t *__restrict__ grow) {
     __shared__ uint32_t sh[16];
     const uint32_t ta = block_scan_array<OpAdd>(
-        n_reg, sh, [&](uint32_t i) { return reg_ncand[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { cand_off[i] = pre; });
+        n_blk, sh, [&](uint32_t i) { return blk_sum[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { blk_coff[i] = pre; });
     const uint32_t tb = block_scan_array<OpAdd>(
-        n_reg, sh, [&](uint32_t i) { return reg_bytes[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { reg_soff[i] = pre; });
+        n_blk, sh, [&](uint32_t i) { return blk_sum[n_blk + i]; },
+        [&](uint32_t i, uint32_t pre, uint32_t) { blk_soff[i] = pre; });
     const uint32_t tc = block_scan_array<OpAdd>(
-        n_reg, sh, [&](uint32_t i) { return reg_maxlen[i]; }, [&](uint32_t, uint32_t, uint32_t) {});
+        n_blk, sh, [&](uint32_t i) { return blk_sum[2 * n_blk + i]; }, [&](uint32_t, uint32_t, uint32_t) {});
     if (threadIdx.x == 0) {
         cand_off[n_reg] = ta;
         reg_soff[n_reg] = tb;
@@ -279,8 +289,11 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
                                                       const uint32_t *__restrict__ kept_len,
                                                       const uint32_t *__restrict__ kept_col,
                                                       const uint32_t *__restrict__ reg_ncand,
-                                                      const uint32_t *__restrict__ cand_off,
-                                                      const uint32_t *__restrict__ reg_soff, uint32_t cand_cap,
+                                                      const uint32_t *__restrict__ reg_bytes,
+                                                      const uint32_t *__restrict__ blk_coff,
+                                                      const uint32_t *__restrict__ blk_soff,
+                                                      uint32_t *__restrict__ cand_off, uint32_t *__restrict__ reg_soff,
+                                                      uint32_t cand_cap,
                                                       uint32_t seq_cap, uint32_t *__restrict__ cand_order,
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
@@ -288,12 +301,22 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_reg) return;
     if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
+    // offsets of this region: its block's prefix + the regions before it inside the block of 4
+    uint32_t oc = blk_coff[blockIdx.x], ob = blk_soff[blockIdx.x];
+    for (uint32_t w = blockIdx.x * 4; w < g; ++w) {
+        oc += reg_ncand[w];
+        ob += reg_bytes[w];
+    }
+    if (lane == 0) {
+        cand_off[g] = oc;
+        reg_soff[g] = ob;
+    }
     const uint32_t n = reg_ncand[g];
     const bool act = lane < n;
     const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + lane;
     const uint32_t len = act ? kept_len[slot] : 0u;
-    const uint32_t so = reg_soff[g] + wave_excl(len);
-    const uint32_t ci = cand_off[g] + lane;
+    const uint32_t so = ob + wave_excl(len);
+    const uint32_t ci = oc + lane;
     if (!act || ci >= cand_cap || (uint64_t)so + len > seq_cap) return;
     const uint32_t r = kept_read[slot];
     const np2_read_t rd = cx.reads[r];
@@ -322,25 +345,25 @@ static CandCtx mk_cand(const CandPtrs &c) {
                    c.pcount, c.alive, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
 }
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen) {
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *blk_sum) {
     if (n_reg)
         hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, reg_bytes, reg_maxlen);
+                           kept_col, reg_ncand, reg_bytes, blk_sum);
 }
-void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, const uint32_t *reg_maxlen,
-                         uint32_t n_reg, uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes,
-                         uint32_t *grow) {
-    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, reg_ncand, reg_bytes, n_reg, reg_maxlen, cand_off, reg_soff,
-                       n_cand, n_bytes, grow);
+void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff,
+                       cand_off, reg_soff, n_cand, n_bytes, grow);
 }
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
-                         const uint32_t *cand_off, const uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap,
-                         uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq) {
+                         const uint32_t *reg_bytes, const uint32_t *blk_coff, const uint32_t *blk_soff, uint32_t *cand_off,
+                         uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap, uint32_t *cand_order, uint64_t *cand_kmer,
+                         uint32_t *cand_seq_off, uint8_t *cand_seq) {
     if (n_reg)
         hipLaunchKernelGGL(k_region_write, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off,
-                           cand_seq);
+                           kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap,
+                           cand_order, cand_kmer, cand_seq_off, cand_seq);
 }
 
 } // namespace np2

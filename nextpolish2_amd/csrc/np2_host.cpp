@@ -292,30 +292,18 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
     const uint32_t n_reg = pc.n_reg, ksize = cx->yaks[yak_idx].k;
     uint32_t n_rech = 0, n_groups = 0, n_jobs = 0;
     {
-        // everything up to the job count runs on the n_reg bound with zero-padded flag arrays: one read-back
+        // RECH region list, chain groups and job offsets: two look-back passes, then one read-back
         EventTimer t(cx, "recheck");
-        cx->sp_flag.ensure(n_reg + 2);
-        cx->sp_slot.ensure(n_reg + 2);
         cx->rech.ensure(n_reg + 2);
-        cx->rech_head.ensure(n_reg + 2);
-        cx->rech_gslot.ensure(n_reg + 2);
         cx->rech_groups.ensure((size_t)(n_reg + 2) * rech_group_bytes());
-        cx->rech_njobs.ensure(n_reg + 2);
         cx->rech_joboff.ensure(n_reg + 2);
-        zero32(cx, cx->scal.p + S_NRECH, 2);
-        zero32(cx, cx->rech_head.p, n_reg + 2);
-        zero32(cx, cx->rech_njobs.p, n_reg + 2);
-        launch_rech_list(s, cx->reg_lable.p, n_reg, cx->sp_flag.p);
-        exclusive_total(cx, cx->sp_flag.p, cx->sp_slot.p, n_reg);
-        launch_rech_list2(s, cx->sp_flag.p, cx->sp_slot.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH);
-        launch_rech_heads(s, cx->rech.p, cx->scal.p + S_NRECH, n_reg, cx->lq_start.p, cx->lq_end.p, ksize,
-                          cx->rech_head.p);
-        exclusive_total(cx, cx->rech_head.p, cx->rech_gslot.p, n_reg);
-        launch_rech_groups(s, cx->rech_head.p, cx->rech_gslot.p, cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
-                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_njobs.p,
-                           cx->scal.p + S_NGROUPS, cx->scal.p + S_ERR);
-        exclusive_total(cx, cx->rech_njobs.p, cx->rech_joboff.p, (size_t)n_reg + 1);
-        std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->rech_joboff.p + n_reg);
+        const uint32_t nb = (n_reg + 255) / 256;
+        launch_rech_list(s, next_lookback(cx, nb), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
+                         cx->scal.p + S_ERR);
+        launch_rech_groups(s, next_lookback(cx, nb), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
+                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_joboff.p,
+                           cx->scal.p + S_NGROUPS, cx->scal.p + S_M0, cx->scal.p + S_ERR);
+        std::vector<uint32_t> sc = fetch_scal(cx);
         check_region_err(cx, sc[S_ERR]);
         n_rech = sc[S_NRECH];
         n_groups = sc[S_NGROUPS];
@@ -570,6 +558,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
     }
     std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + L);
+    check_region_err(cx, sc[S_ERR]);
     if (sc[S_BEST] == 0xFFFFFFFFu)
         throw Np2Error(NP2_E_UNSUPPORTED,
                        "best path score is negative at the contig end (reference would emit its default node)");
@@ -633,7 +622,9 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->reg_ncand.ensure(n_reg + 2);
     cx->reg_bytes.ensure(n_reg + 2);
     cx->reg_soff.ensure(n_reg + 2);
-    cx->reg_maxlen.ensure(n_reg + 2);
+    cx->blk_sum.ensure(3 * ((size_t)n_reg / 4 + 2));
+    cx->blk_coff.ensure((size_t)n_reg / 4 + 2);
+    cx->blk_soff.ensure((size_t)n_reg / 4 + 2);
     cx->cand_off.ensure(n_reg + 2);
     cx->kept_read.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
     cx->kept_len.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
@@ -649,8 +640,8 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
                           cx->pcount.p);
         // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
-                              cx->reg_bytes.p, cx->reg_maxlen.p);
-        launch_cand_offsets(s, cx->reg_ncand.p, cx->reg_bytes.p, cx->reg_maxlen.p, n_reg, cx->cand_off.p, cx->reg_soff.p,
+                              cx->reg_bytes.p, cx->blk_sum.p);
+        launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
                             cx->scal.p + S_M1, cx->scal.p + S_M2, cx->scal.p + S_M3);
         std::vector<uint32_t> m2 = fetch_scal(cx);
         NC = m2[S_M1];
@@ -665,8 +656,8 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     {
         EventTimer t(cx, "candidates");
         launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
-                            cx->cand_off.p, cx->reg_soff.p, NC + 1, SB, cx->cand_order.p, cx->cand_kmer.p,
-                            cx->cand_seq_off.p, cx->cand_seq.p);
+                            cx->reg_bytes.p, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p, NC + 1, SB,
+                            cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
     }
     {
         EventTimer t(cx, "kmer_score");

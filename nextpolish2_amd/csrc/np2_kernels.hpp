@@ -117,14 +117,16 @@ void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, ui
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen);
-void launch_cand_offsets(hipStream_t s, const uint32_t *reg_ncand, const uint32_t *reg_bytes, const uint32_t *reg_maxlen,
-                         uint32_t n_reg, uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes,
-                         uint32_t *grow);
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *blk_sum);
+// blk_sum: 3 x ceil(n_reg / 4) sums per block of 4 regions (candidates, bytes, longest kept string)
+void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow);
+// also fills cand_off[g] / reg_soff[g] (block prefix + the regions before g inside its block)
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
-                         const uint32_t *cand_off, const uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap,
-                         uint32_t *cand_order, uint64_t *cand_kmer, uint32_t *cand_seq_off, uint8_t *cand_seq);
+                         const uint32_t *reg_bytes, const uint32_t *blk_coff, const uint32_t *blk_soff, uint32_t *cand_off,
+                         uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap, uint32_t *cand_order, uint64_t *cand_kmer,
+                         uint32_t *cand_seq_off, uint8_t *cand_seq);
 
 // ---- np2_graph.hip: tile-bucketed exception sort and per-pass graph construction ---------------------
 void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
@@ -192,15 +194,13 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                          const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base);
-void launch_rech_list(hipStream_t s, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *flag);
-void launch_rech_list2(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, uint32_t *rech,
-                       uint32_t *n_rech);
-void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
-                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t ksize, uint32_t *headflag);
-void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
-                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, const uint32_t *M_p,
-                        const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize, void *groups,
-                        uint32_t *njobs, uint32_t *n_groups, uint32_t *err);
+void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
+                      uint32_t *n_rech, uint32_t *err);
+// groups of chained RECH regions + per-group job offsets (job_off[n_groups] = *n_jobs); max_rech = launch bound
+void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                        const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
+                        const uint32_t *keep_n, uint32_t ksize, void *groups, uint32_t *job_off, uint32_t *n_groups,
+                        uint32_t *n_jobs, uint32_t *err);
 size_t rech_group_bytes();
 void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len);
 void launch_rech_job_build(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, const uint32_t *soff32, uint64_t *soff64,

@@ -471,29 +471,19 @@ __global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t
 }
 
 // ---- recheck (reupdate_consensus_with_lqseqs, main.rs:1060-1420) ------------------------------------
-__global__ void k_rech_flag(const uint8_t *__restrict__ reg_lable, uint32_t n_reg, uint32_t *__restrict__ flag) {
-    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr < n_reg) flag[rr] = (reg_lable[n_reg - 1 - rr] & LB_RECH) ? 1u : 0u;
-}
-__global__ void k_rech_list(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot, uint32_t n_reg,
-                            uint32_t *__restrict__ rech, uint32_t *__restrict__ n_rech) {
-    uint32_t rr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rr >= n_reg) return;
-    if (flag[rr]) rech[slot[rr]] = n_reg - 1 - rr;
-    if (rr == n_reg - 1) *n_rech = slot[rr] + flag[rr];
-}
-// chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions
-__global__ void k_rech_heads(const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
-                             const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end, uint32_t ksize,
-                             uint32_t *__restrict__ headflag) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *n_rech_p) return;
-    uint32_t back = 0, x = e;
-    while (x > 0 && lq_start[rech[x]] < lq_end[rech[x - 1]] + ksize) {
-        --x;
-        ++back;
-    }
-    headflag[e] = (back % 6 == 0) ? 1u : 0u;
+// RECH regions in left -> right order (reverse region index), compacted with a look-back across blocks
+__global__ __launch_bounds__(256) void k_rech_list(Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
+                                                   uint32_t n_reg, uint32_t *__restrict__ rech, uint32_t *__restrict__ n_rech,
+                                                   uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t rr = bid * 256 + threadIdx.x;
+    const uint32_t flag = (rr < n_reg && (reg_lable[n_reg - 1 - rr] & LB_RECH)) ? 1u : 0u;
+    uint32_t cnt, pre, dummy;
+    const uint32_t lo = block_excl_scan<OpAdd, 4>(flag, sh, cnt);
+    lb_exclusive2(lb, bid, cnt, 0u, sh, err, pre, dummy);
+    if (flag) rech[pre + lo] = n_reg - 1 - rr;
+    if (bid == n_blocks - 1 && threadIdx.x == 0) *n_rech = pre + cnt;
 }
 
 struct RechGroup { // one recheck group = 1..6 chained RECH regions
@@ -504,58 +494,89 @@ struct RechGroup { // one recheck group = 1..6 chained RECH regions
     uint32_t njobs;
 };
 
-__global__ void k_rech_groups(const uint32_t *__restrict__ headflag, const uint32_t *__restrict__ gslot,
-                              const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
-                              const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
-                              const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end,
-                              const uint32_t *__restrict__ keep_n, uint32_t ksize, RechGroup *__restrict__ groups,
-                              uint32_t *__restrict__ njobs, uint32_t *__restrict__ n_groups, uint32_t *__restrict__ err) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+// chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions.  One thread per
+// RECH region; a thread whose region heads a group builds it.  Group slots and job offsets (exclusive sums of the
+// group / job counts) come from a look-back across blocks; the last block leaves the totals.
+__global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ rech,
+                                                     const uint32_t *__restrict__ n_rech_p,
+                                                     const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
+                                                     const uint32_t *__restrict__ lq_start,
+                                                     const uint32_t *__restrict__ lq_end,
+                                                     const uint32_t *__restrict__ keep_n, uint32_t ksize,
+                                                     RechGroup *__restrict__ groups, uint32_t *__restrict__ job_off,
+                                                     uint32_t *__restrict__ n_groups, uint32_t *__restrict__ n_jobs,
+                                                     uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t e = bid * 256 + threadIdx.x;
     const uint32_t n_rech = *n_rech_p, M = *M_p;
-    if (e >= n_rech) return;
-    if (e == n_rech - 1) *n_groups = gslot[e] + headflag[e];
-    if (!headflag[e]) return;
+    auto chained = [&](uint32_t x) { return lq_start[rech[x]] < lq_end[rech[x - 1]] + ksize; };
+    bool head = false;
     RechGroup G;
-    G.first = e;
-    uint32_t n = 1;
-    while (e + n < n_rech && !headflag[e + n]) ++n;
-    G.n = n;
-    const uint32_t l = ksize - 1;
-    // iter_consensus_extend(toleft): first index with pos >= start; the reference indexes [i-1]
-    const uint32_t p0 = lq_start[rech[e]];
-    const uint32_t i0 = lower_bound_u32(cns_pos, M, p0);
-    if (i0 == 0 || i0 >= M) atomicOr(err, 64u);
-    G.el = i0;
-    G.sl = i0 > l ? i0 - l : 0;
-    // iter_consensus_extend(right): last index with pos <= end; the reference indexes [i+1]
-    const uint32_t p1 = lq_end[rech[e + n - 1]];
-    const uint32_t i1u = upper_bound_u32(cns_pos, M, p1);
-    if (i1u == 0 || i1u >= M) atomicOr(err, 64u);
-    const uint32_t i1 = i1u ? i1u - 1 : 0;
-    G.sr = i1 + 1;
-    G.er = (i1 + l < M) ? i1 + l + 1 : M;
-    uint64_t jobs = 1;
-    for (uint32_t x = 0; x < n; ++x) {
-        G.lens[x] = keep_n[rech[e + x]];
-        jobs *= G.lens[x];
-        if (jobs > 0x7FFFFFFFull) {
-            atomicOr(err, 128u);
-            jobs = 0;
+    uint32_t jobs32 = 0;
+    if (e < n_rech) {
+        uint32_t back = 0, x = e;
+        while (x > 0 && chained(x)) {
+            --x;
+            ++back;
         }
-        if (x + 1 < n) { // iter_consensus_region(s, e): indices with s < pos < e
-            const uint32_t s = lq_end[rech[e + x]], en = lq_start[rech[e + x + 1]];
-            if (s + 1 == en) {
-                G.bs[x] = G.be[x] = 0;
-            } else {
-                G.bs[x] = upper_bound_u32(cns_pos, M, s);
-                G.be[x] = lower_bound_u32(cns_pos, M, en);
-                if (G.be[x] < G.bs[x]) G.be[x] = G.bs[x];
+        head = back % 6 == 0;
+    }
+    if (head) {
+        G.first = e;
+        uint32_t n = 1;
+        while (n < 6 && e + n < n_rech && chained(e + n)) ++n;
+        G.n = n;
+        const uint32_t l = ksize - 1;
+        // iter_consensus_extend(toleft): first index with pos >= start; the reference indexes [i-1]
+        const uint32_t p0 = lq_start[rech[e]];
+        const uint32_t i0 = lower_bound_u32(cns_pos, M, p0);
+        if (i0 == 0 || i0 >= M) atomicOr(err, 64u);
+        G.el = i0;
+        G.sl = i0 > l ? i0 - l : 0;
+        // iter_consensus_extend(right): last index with pos <= end; the reference indexes [i+1]
+        const uint32_t p1 = lq_end[rech[e + n - 1]];
+        const uint32_t i1u = upper_bound_u32(cns_pos, M, p1);
+        if (i1u == 0 || i1u >= M) atomicOr(err, 64u);
+        const uint32_t i1 = i1u ? i1u - 1 : 0;
+        G.sr = i1 + 1;
+        G.er = (i1 + l < M) ? i1 + l + 1 : M;
+        uint64_t jobs = 1;
+        for (uint32_t x = 0; x < n; ++x) {
+            G.lens[x] = keep_n[rech[e + x]];
+            jobs *= G.lens[x];
+            if (jobs > 0x7FFFFFFFull) {
+                atomicOr(err, 128u);
+                jobs = 0;
+            }
+            if (x + 1 < n) { // iter_consensus_region(s, e): indices with s < pos < e
+                const uint32_t s = lq_end[rech[e + x]], en = lq_start[rech[e + x + 1]];
+                if (s + 1 == en) {
+                    G.bs[x] = G.be[x] = 0;
+                } else {
+                    G.bs[x] = upper_bound_u32(cns_pos, M, s);
+                    G.be[x] = lower_bound_u32(cns_pos, M, en);
+                    if (G.be[x] < G.bs[x]) G.be[x] = G.bs[x];
+                }
             }
         }
+        jobs32 = (uint32_t)jobs;
+        G.njobs = jobs32;
     }
-    G.njobs = (uint32_t)jobs;
-    groups[gslot[e]] = G;
-    njobs[gslot[e]] = (uint32_t)jobs;
+    uint32_t nh, nj, pre_h, pre_j;
+    const uint32_t lh = block_excl_scan<OpAdd, 4>(head ? 1u : 0u, sh, nh);
+    const uint32_t lj = block_excl_scan<OpAdd, 4>(jobs32, sh, nj);
+    lb_exclusive2(lb, bid, nh, nj, sh, err, pre_h, pre_j);
+    if (pre_j + nj < pre_j) atomicOr(err, 128u); // total job count overflows 32 bits
+    if (head) {
+        groups[pre_h + lh] = G;
+        job_off[pre_h + lh] = pre_j + lj;
+    }
+    if (bid == n_blocks - 1 && threadIdx.x == 0) {
+        *n_groups = pre_h + nh;
+        *n_jobs = pre_j + nj;
+        job_off[pre_h + nh] = pre_j + nj;
+    }
 }
 
 struct RechCtx {
@@ -740,26 +761,18 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
         hipLaunchKernelGGL(k_splice_seeds, g1(max_ap, 64), dim3(64), 0, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap,
                            lq_start, seed_cand, seq_off, seq, out_pos, out_base);
 }
-void launch_rech_list(hipStream_t s, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *flag) {
-    hipLaunchKernelGGL(k_rech_flag, g1(n_reg), dim3(256), 0, s, reg_lable, n_reg, flag);
+void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
+                      uint32_t *n_rech, uint32_t *err) {
+    const uint32_t nb = (n_reg + 255) / 256;
+    hipLaunchKernelGGL(k_rech_list, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, n_reg, rech, n_rech, err);
 }
-void launch_rech_list2(hipStream_t s, const uint32_t *flag, const uint32_t *slot, uint32_t n_reg, uint32_t *rech,
-                       uint32_t *n_rech) {
-    hipLaunchKernelGGL(k_rech_list, g1(n_reg), dim3(256), 0, s, flag, slot, n_reg, rech, n_rech);
-}
-void launch_rech_heads(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
-                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t ksize, uint32_t *headflag) {
-    if (max_rech)
-        hipLaunchKernelGGL(k_rech_heads, g1(max_rech), dim3(256), 0, s, rech, n_rech_p, lq_start, lq_end, ksize,
-                           headflag);
-}
-void launch_rech_groups(hipStream_t s, const uint32_t *headflag, const uint32_t *gslot, const uint32_t *rech,
-                        const uint32_t *n_rech_p, uint32_t max_rech, const uint32_t *cns_pos, const uint32_t *M_p,
-                        const uint32_t *lq_start, const uint32_t *lq_end, const uint32_t *keep_n, uint32_t ksize,
-                        void *groups, uint32_t *njobs, uint32_t *n_groups, uint32_t *err) {
-    if (max_rech)
-        hipLaunchKernelGGL(k_rech_groups, g1(max_rech, 64), dim3(64), 0, s, headflag, gslot, rech, n_rech_p, cns_pos, M_p,
-                           lq_start, lq_end, keep_n, ksize, (RechGroup *)groups, njobs, n_groups, err);
+void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
+                        const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
+                        const uint32_t *keep_n, uint32_t ksize, void *groups, uint32_t *job_off, uint32_t *n_groups,
+                        uint32_t *n_jobs, uint32_t *err) {
+    const uint32_t nb = (max_rech + 255) / 256;
+    hipLaunchKernelGGL(k_rech_groups, dim3(nb), dim3(256), 0, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end,
+                       keep_n, ksize, (RechGroup *)groups, job_off, n_groups, n_jobs, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
 static RechCtx mk_rech(const RechPtrs &p) {
