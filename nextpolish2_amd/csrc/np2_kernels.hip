@@ -11,6 +11,7 @@
 // so the whole-contig DP (main.rs:1645-1687) decomposes into independent "dirty runs".
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_blockscan.hpp"
 #include "../../include/np2.h"
 
 namespace np2 {
@@ -18,15 +19,6 @@ namespace np2 {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o);
-        if (lane >= (uint32_t)o) v += t;
-    }
-    return v;
-}
 __device__ __forceinline__ uint32_t swap_nib(uint32_t w) {
     return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu);
 }
@@ -138,168 +130,249 @@ __global__ void k_fill_carry(ChunkDesc *__restrict__ descs, const uint32_t *__re
     if (ch < n_chunks) descs[ch].carryN = chunk_pre[ch] - chunk_pre[descs[ch].first_chunk];
 }
 
-// Dense pass: one wavefront per 2048-column chunk.  The kernel is VALU-issue bound (not latency bound), so it does
-// the minimum per column: classify columns as exceptions and emit raw (read, column, t_pos) records; the 3-column
-// node keys are built afterwards by the tile sort (np2_graph.hip).  Records go straight into the fixed-capacity
-// bucket of their contig tile (TILE positions); a full bucket spills to a shared overflow area (rare).
+// ---- 128-bit nibble vectors: column j of a lane lives in nibble j (bits 4j..4j+3; lo = columns 0-15) ----------
+struct N128 {
+    uint64_t lo, hi;
+};
+static constexpr uint64_t NF3 = 0x8888888888888888ULL; // bit 3 of every nibble: the flag position of all column masks
+__device__ __forceinline__ N128 n_below(uint32_t p) { // all bits of nibbles [0, p)
+    N128 m;
+    m.lo = p >= 16 ? ~0ULL : ((1ULL << (4 * p)) - 1ULL);
+    m.hi = p <= 16 ? 0ULL : (p >= 32 ? ~0ULL : ((1ULL << (4 * (p - 16))) - 1ULL));
+    return m;
+}
+__device__ __forceinline__ uint32_t n_ctz(const N128 &x) { // index of the first set bit, 128 if none
+    return x.lo ? (uint32_t)__builtin_ctzll(x.lo) : (x.hi ? 64u + (uint32_t)__builtin_ctzll(x.hi) : 128u);
+}
+__device__ __forceinline__ uint32_t n_popc(const N128 &x) {
+    return (uint32_t)__builtin_popcountll(x.lo) + (uint32_t)__builtin_popcountll(x.hi);
+}
+__device__ __forceinline__ N128 n_shl(const N128 &x, uint32_t s) { // 0 < s < 128
+    N128 r;
+    if (s < 64) {
+        r.hi = (x.hi << s) | (x.lo >> (64 - s));
+        r.lo = x.lo << s;
+    } else {
+        r.hi = x.lo << (s - 64);
+        r.lo = 0;
+    }
+    return r;
+}
+
+// Dense pass: one wavefront per pair of consecutive 2048-column chunks, each lane owning 32 columns (16 B) of a chunk.
+// The kernel is VALU-issue bound, so everything stays in the nibble domain (no per-column loops, no bit gathers):
+//  * the lane's 32 contig codes come from one unaligned 20-byte window of the nibble-packed contig;
+//  * insertion runs shift the tail of that window (one iteration per run, usually none or one);
+//  * mismatch / insertion / "one of the two previous columns is bad" masks are nibble-flag words (bit 3);
+//  * wave scans and neighbour exchange are DPP operations.
+// It emits raw exception records (read, column, t_pos) straight into the fixed-capacity bucket of their contig tile
+// (TILE positions; a full bucket spills to a shared overflow area) and the per-read checkpoints; the 3-column node keys
+// are built afterwards by the tile sort (np2_graph.hip).
 __global__ __launch_bounds__(256) void k_diff_reads(
     const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
-    const uint64_t *__restrict__ refw, const uint8_t *__restrict__ refnib, uint32_t L,
+    const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
     uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
     uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
     uint32_t *__restrict__ ckpt, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (ch >= n_chunks) return;
-    const ChunkDesc d = descs[ch];
-    const uint8_t *base = nib + d.nib_off; // start of the READ's stream
-    const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0, carryN = d.carryN;
-    const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
-    const uint32_t lc0 = c0 + lane * 32;
-
-    const LaneCols c = load_lane(base, lc0, ncols);
-    uint32_t pbad = 0; // bad bits of the two columns before the chunk: bit 31 = column c0-1, bit 30 = column c0-2
-    if (lane == 0 && c0 > 0) {
-        const uint8_t byte = base[(c0 - 2) >> 1];
-        const uint8_t n2 = byte >> 4, n1 = byte & 15;
-        const uint32_t t1 = ts + carryN - 1;
-        const uint32_t t2 = t1 - ((n1 & 8) ? 0u : 1u);
-        const bool b1 = (n1 & 8) || t1 >= L || (n1 & 7) != ref_code(refnib, t1);
-        const bool b2 = (n2 & 8) || t2 >= L || (n2 & 7) != ref_code(refnib, t2);
-        pbad = (b1 ? 0x80000000u : 0u) | (b2 ? 0x40000000u : 0u);
-    }
-    const uint64_t lo = c.lo, hi = c.hi;
-    const uint32_t nv = c.nv, n_ins = c.n_ins;
-    const uint32_t nonins = nv - n_ins;
-    const uint32_t incl = wave_incl_scan(nonins);
-    const uint32_t total = __shfl(incl, 63);
-    const uint32_t Nb = carryN + (incl - nonins); // non-insertion columns before this lane
-    const uint32_t t0 = ts + Nb;                  // t_pos of the lane's first non-insertion column
-    uint32_t bad = 0, im = 0;
-    if (nv) {
-        if (n_ins == 0) {
-            uint64_t rlo, rhi;
-            load_ref128(refw, t0, rlo, rhi);
-            const uint64_t x = (lo ^ rlo) & c.mlo, y = (hi ^ rhi) & c.mhi;
-            if (x | y) bad = gather16(nz_nib(x)) | (gather16(nz_nib(y)) << 16);
-        } else {
-            im = gather16(c.ilo >> 3) | (gather16(c.ihi >> 3) << 16);
-            const uint32_t runs = __builtin_popcount(im & ~(im << 1));
-            const uint32_t i1 = __builtin_ctz(im);
-            const uint32_t vmask = nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-            if (runs == 1 && t0 >= n_ins) {
-                // one insertion run [i1, i1+m): columns before it sit at t0+j, after it at t0+j-m
-                uint64_t rlo, rhi;
-                load_ref128(refw, t0, rlo, rhi);
-                const uint32_t badA = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
-                load_ref128(refw, t0 - n_ins, rlo, rhi);
-                const uint32_t badB = gather16(nz_nib(lo ^ rlo)) | (gather16(nz_nib(hi ^ rhi)) << 16);
-                const uint32_t below = (1u << i1) - 1u;
-                const uint32_t e2 = i1 + n_ins;
-                const uint32_t above = e2 >= 32 ? 0u : ~((1u << e2) - 1u);
-                bad = ((badA & below) | (badB & above) | im) & vmask;
-            } else {
-                uint32_t tcur = t0 - 1;
-                for (uint32_t j = 0; j < nv; ++j) {
-                    if ((im >> j) & 1u) {
-                        bad |= 1u << j;
-                    } else {
-                        ++tcur;
-                        if (tcur >= L || reg_nib(lo, hi, j) != ref_code(refnib, tcur)) bad |= 1u << j;
-                    }
+    const uint32_t pw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    uint32_t prev_read = 0xFFFFFFFFu, prev_b3 = 0; // for the second chunk: does it continue the first one?
+    for (uint32_t it = 0; it < 2; ++it) {
+        const uint32_t ch = 2 * pw + it;
+        if (ch >= n_chunks) break;
+        const ChunkDesc d = descs[ch];
+        const uint8_t *base = nib + d.nib_off; // start of the READ's stream
+        const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0, carryN = d.carryN;
+        const uint32_t lc0 = c0 + lane * 32;
+        const bool full = ncols - c0 >= 2048; // every lane of the wave holds 32 columns
+        const uint32_t nv = full ? 32u : (lc0 < ncols ? min(32u, ncols - lc0) : 0u);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
+        N128 w;
+        w.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
+        w.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
+        N128 V{NF3, NF3}; // flags of the valid columns
+        if (!full) {
+            const N128 m = n_below(nv);
+            V.lo &= m.lo;
+            V.hi &= m.hi;
+        }
+        N128 I{w.lo & V.lo, w.hi & V.hi}; // insertion columns
+        if (c0 == 0 && lane == 0) I.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
+        const N128 codes{w.lo & ~NF3, w.hi & ~NF3};
+        const uint32_t n_ins = n_popc(I);
+        const uint32_t nonins = nv - n_ins;
+        const uint32_t incl = wave_incl_scan<OpAdd>(nonins);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t t0 = ts + carryN + (incl - nonins); // t_pos of the lane's first non-insertion column
+        // ---- the 32 contig codes starting at t0 ------------------------------------------------------------------
+        N128 R;
+        {
+            // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer;
+            // such a read is reported by the descriptor check at the end of its last chunk)
+            const uint32_t q = min(t0 >> 3, (L >> 3) + 8), sh = (t0 & 7) * 4;
+            const uint32_t r0 = refw32[q], r1 = refw32[q + 1], r2 = refw32[q + 2], r3 = refw32[q + 3], r4 = refw32[q + 4];
+            const uint32_t a0 = __builtin_amdgcn_alignbit(r1, r0, sh), a1 = __builtin_amdgcn_alignbit(r2, r1, sh);
+            const uint32_t a2 = __builtin_amdgcn_alignbit(r3, r2, sh), a3 = __builtin_amdgcn_alignbit(r4, r3, sh);
+            R.lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+            R.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
+        }
+        // ---- insertion runs push the rest of the window up by their length (one iteration per run) -----------------
+        if (__ballot(n_ins != 0)) {
+            N128 J = I;
+            while (__ballot((J.lo | J.hi) != 0)) {
+                if (J.lo | J.hi) {
+                    const uint32_t p = n_ctz(J) >> 2; // first column of the run
+                    const N128 bp = n_below(p);
+                    const N128 K{~J.lo & NF3 & ~bp.lo, ~J.hi & NF3 & ~bp.hi}; // non-insertion flags at / above p
+                    const uint32_t qn = min(n_ctz(K) >> 2, 32u);               // first column past the run
+                    const N128 up = n_shl(N128{R.lo & ~bp.lo, R.hi & ~bp.hi}, 4 * (qn - p));
+                    R.lo = (R.lo & bp.lo) | up.lo;
+                    R.hi = (R.hi & bp.hi) | up.hi;
+                    const N128 bq = n_below(qn);
+                    J.lo &= ~bq.lo;
+                    J.hi &= ~bq.hi;
                 }
             }
         }
-        // checkpoint: column of the reference column at the next multiple of CKPT
-        if (nonins) {
+        // ---- bad columns: insertion, or code differs from the contig ------------------------------------------------
+        N128 B;
+        B.lo = ((((codes.lo ^ R.lo) & ~NF3) + ~NF3) | I.lo) & V.lo; // nibble != 0  ->  + 7 carries into bit 3
+        B.hi = ((((codes.hi ^ R.hi) & ~NF3) + ~NF3) | I.hi) & V.hi;
+        // ---- checkpoint: column of the reference column at the next multiple of CKPT ----------------------------------
+        {
             const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
-            uint32_t nth = tstar - t0;
+            const uint32_t nth = tstar - t0; // 0-based index among the lane's non-insertion columns
             if (nth < nonins) {
-                uint32_t j = nth;
-                if (n_ins) {
-                    j = 0;
-                    for (;; ++j) {
-                        if (!((im >> j) & 1u)) {
-                            if (nth == 0) break;
-                            --nth;
-                        }
+                const N128 NI{~I.lo & V.lo, ~I.hi & V.hi};
+                uint32_t k = nth + 1, col = 0;
+                uint32_t m8;
+                const uint32_t cA = __builtin_popcount((uint32_t)NI.lo), cB = __builtin_popcount((uint32_t)(NI.lo >> 32));
+                const uint32_t cC = __builtin_popcount((uint32_t)NI.hi);
+                if (k <= cA) {
+                    m8 = (uint32_t)NI.lo;
+                } else if (k <= cA + cB) {
+                    k -= cA, col = 8, m8 = (uint32_t)(NI.lo >> 32);
+                } else if (k <= cA + cB + cC) {
+                    k -= cA + cB, col = 16, m8 = (uint32_t)NI.hi;
+                } else {
+                    k -= cA + cB + cC, col = 24, m8 = (uint32_t)(NI.hi >> 32);
+                }
+                uint32_t c = __builtin_popcount(m8 & 0xFFFFu); // k-th flag inside the dword: binary descent
+                if (k > c) k -= c, col += 4, m8 >>= 16;
+                c = __builtin_popcount(m8 & 0xFFu);
+                if (k > c) k -= c, col += 2, m8 >>= 8;
+                c = __builtin_popcount(m8 & 0xFu);
+                if (k > c) col += 1;
+                const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
+                const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
+                if (idx < d.nck) ckpt[d.ckbase + idx] = lc0 + col;
+            }
+        }
+        // ---- exception columns: a bad column marks itself and the two columns after it (3-column-mers) -------------
+        uint32_t pb; // B flags of the 8 columns before the lane (only the top two matter)
+        {
+            const bool cont = it == 1 && d.read == prev_read && c0 != 0;
+            uint32_t first = cont ? prev_b3 : 0u;
+            if (!cont && c0 > 0 && lane == 0) { // the two columns before the chunk (rare: reads with an odd chunk count)
+                const uint8_t byte = base[(c0 - 2) >> 1];
+                const uint8_t n2 = byte >> 4, n1 = byte & 15;
+                const uint32_t t1 = ts + carryN - 1;
+                const uint32_t t2 = t1 - ((n1 & 8) ? 0u : 1u);
+                const bool b1 = (n1 & 8) || t1 >= L || (n1 & 7) != ref_code(refnib, t1);
+                const bool b2 = (n2 & 8) || t2 >= L || (n2 & 7) != ref_code(refnib, t2);
+                first = (b1 ? 0x80000000u : 0u) | (b2 ? 0x08000000u : 0u);
+            }
+            pb = wave_prev_lane(0u, (uint32_t)(B.hi >> 32));
+            if (lane == 0) pb = first;
+        }
+        N128 E;
+        {
+            const uint32_t b0 = (uint32_t)B.lo, b1 = (uint32_t)(B.lo >> 32), b2 = (uint32_t)B.hi, b3 = (uint32_t)(B.hi >> 32);
+            // x | x << 1 column | x << 2 columns, carrying across dwords (alignbit(hi, lo, s) = {hi, lo} >> s)
+            const uint32_t e0 = b0 | __builtin_amdgcn_alignbit(b0, pb, 28) | __builtin_amdgcn_alignbit(b0, pb, 24);
+            const uint32_t e1 = b1 | __builtin_amdgcn_alignbit(b1, b0, 28) | __builtin_amdgcn_alignbit(b1, b0, 24);
+            const uint32_t e2 = b2 | __builtin_amdgcn_alignbit(b2, b1, 28) | __builtin_amdgcn_alignbit(b2, b1, 24);
+            const uint32_t e3 = b3 | __builtin_amdgcn_alignbit(b3, b2, 28) | __builtin_amdgcn_alignbit(b3, b2, 24);
+            E.lo = (uint64_t)e0 | ((uint64_t)e1 << 32);
+            E.hi = (uint64_t)e2 | ((uint64_t)e3 << 32);
+            if (lc0 == 0 && ts != 0) E.lo |= 0x88ULL; // head sentinels differ from the contig's own (main.rs:579-580)
+            E.lo &= V.lo;
+            E.hi &= V.hi;
+        }
+        prev_read = d.read;
+        prev_b3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(B.hi >> 32), 63);
+        if (__ballot((E.lo | E.hi) != 0)) {
+            // The chunk's columns sit at contig positions [ts + carryN - 1, ts + carryN + 2047]: at most three contig
+            // tiles.  Records are position-ordered across the wave, so the tile boundaries split them into three
+            // consecutive groups; each group reserves its place in its tile's bucket with one wave-level atomic.
+            const N128 NI{~I.lo & V.lo, ~I.hi & V.hi};
+            auto t_of = [&](uint32_t j) -> uint32_t { // t_pos of column j: non-insertion columns up to and including j
+                const N128 m = n_below(j + 1);
+                return t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1;
+            };
+            const uint32_t cnt = n_popc(E);
+            const uint32_t inc2 = wave_incl_scan<OpAdd>(cnt);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
+            const uint32_t s0 = ts + carryN;
+            const uint32_t tA = (s0 ? s0 - 1 : 0u) >> TILE_SHIFT;
+            const uint32_t P1 = (tA + 1) << TILE_SHIFT, P2 = (tA + 2) << TILE_SHIFT;
+            const uint32_t t_last = t0 + nonins - 1;                // t_pos of the lane's last column
+            const uint32_t t_first = t0 - ((I.lo & 8ULL) ? 1u : 0u); // a leading insertion column belongs to t0 - 1
+            auto below = [&](uint32_t P) -> uint32_t { // records of the wave with t_pos < P
+                const uint32_t nb = __builtin_popcountll(__ballot(nv != 0 && t_last < P)); // lanes entirely below: a prefix
+                uint32_t c = nb ? __shfl(inc2, nb - 1) : 0u;
+                uint32_t part = 0;
+                if (lane == nb && cnt && t_first < P) { // the one lane straddling the boundary
+                    N128 e = E;
+                    while (e.lo | e.hi) {
+                        const uint32_t j = n_ctz(e) >> 2;
+                        const N128 m = n_below(j + 1);
+                        e.lo &= ~m.lo;
+                        e.hi &= ~m.hi;
+                        if (t_of(j) < P) ++part; else break;
                     }
                 }
-                const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                if (idx < d.nck) ckpt[d.ckbase + idx] = lc0 + j;
-            }
-        }
-    }
-    uint32_t pb = __shfl_up(bad, 1);
-    if (lane == 0) pb = pbad;
-    uint32_t E = bad | (bad << 1) | (bad << 2) | (((pb >> 31) & 1u) * 3u) | ((pb >> 30) & 1u);
-    if (lc0 == 0 && ts != 0) E |= 3u; // head sentinels differ from the contig's own (main.rs:579-580)
-    E &= nv == 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
-    if (__ballot(E != 0)) {
-        // The chunk's columns sit at contig positions [ts + carryN - 1, ts + carryN + 2047]: at most three contig
-        // tiles.  Records are position-ordered across the wave, so the tile boundaries split them into three
-        // consecutive groups; each group reserves its place in its tile's bucket with one wave-level atomic.
-        const uint32_t cnt = __builtin_popcount(E);
-        const uint32_t inc2 = wave_incl_scan(cnt);
-        const uint32_t tot = __shfl(inc2, 63);
-        const uint32_t s0 = ts + carryN;
-        const uint32_t tA = (s0 ? s0 - 1 : 0u) >> TILE_SHIFT;
-        const uint32_t P1 = (tA + 1) << TILE_SHIFT, P2 = (tA + 2) << TILE_SHIFT;
-        const uint32_t t_last = t0 + nonins - 1;              // t_pos of the lane's last column
-        const uint32_t t_first = t0 - ((im & 1u) ? 1u : 0u);  // a leading insertion column belongs to t0 - 1
-        auto below = [&](uint32_t P) -> uint32_t { // records of the wave with t_pos < P
-            const uint32_t nb = __builtin_popcountll(__ballot(nv != 0 && t_last < P)); // lanes entirely below: a prefix
-            uint32_t c = nb ? __shfl(inc2, nb - 1) : 0u;
-            uint32_t part = 0;
-            if (lane == nb && cnt && t_first < P) { // the one lane straddling the boundary
-                uint32_t e = E;
-                while (e) {
-                    const uint32_t j = __builtin_ctz(e);
-                    e &= e - 1;
-                    const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
-                    if (t0 + __builtin_popcount(~im & low) - 1 < P) ++part; else break;
+                if (nb < 64) c += __shfl(part, nb);
+                return c;
+            };
+            const uint32_t nb1 = below(P1), nb2 = below(P2);
+            uint32_t rb = 0; // lane j < 3: reservation of group j in bucket tA + j
+            if (lane < 3) {
+                const uint32_t cj = lane == 0 ? nb1 : (lane == 1 ? nb2 - nb1 : tot - nb2);
+                if (cj) {
+                    if (tA + lane < n_tiles) rb = atomicAdd(&tile_cur[tA + lane], cj);
+                    else rb = 0xFFFFFFFFu - cj; // position >= L: the descriptor check below reports the read
                 }
             }
-            if (nb < 64) c += __shfl(part, nb);
-            return c;
-        };
-        const uint32_t nb1 = below(P1), nb2 = below(P2);
-        uint32_t rb = 0; // lane j < 3: reservation of group j in bucket tA + j
-        if (lane < 3) {
-            const uint32_t cj = lane == 0 ? nb1 : (lane == 1 ? nb2 - nb1 : tot - nb2);
-            if (cj) {
-                if (tA + lane < n_tiles) rb = atomicAdd(&tile_cur[tA + lane], cj);
-                else rb = 0xFFFFFFFFu - cj; // position >= L: the descriptor check below reports the read
+            const uint32_t g0 = __shfl(rb, 0), g1 = __shfl(rb, 1), g2 = __shfl(rb, 2);
+            uint32_t o = inc2 - cnt; // rank of the lane's first record within the wave
+            N128 e = E;
+            while (e.lo | e.hi) { // raw record: t_pos << 32 | column, read
+                const uint32_t j = n_ctz(e) >> 2;
+                const N128 m = n_below(j + 1);
+                e.lo &= ~m.lo;
+                e.hi &= ~m.hi;
+                const uint32_t t = t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1;
+                const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
+                const uint32_t slot = (g == 0 ? g0 + o : (g == 1 ? g1 + (o - nb1) : g2 + (o - nb2)));
+                uint64_t dst;
+                bool ok = tA + g < n_tiles;
+                if (slot < bucket_cap) {
+                    dst = (uint64_t)(tA + g) * bucket_cap + slot;
+                } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
+                    const uint32_t x = atomicAdd(ovf_cnt, 1u);
+                    dst = ovf_base + x;
+                    ok = ok && x < ovf_cap;
+                }
+                if (ok) {
+                    out_keys[dst] = ((uint64_t)t << 32) | (lc0 + j);
+                    out_vals[dst] = d.read;
+                }
+                ++o;
             }
         }
-        const uint32_t b0 = __shfl(rb, 0), b1 = __shfl(rb, 1), b2 = __shfl(rb, 2);
-        uint32_t o = inc2 - cnt; // rank of the lane's first record within the wave
-        uint32_t e = E;
-        while (e) { // raw record: t_pos << 32 | column, read
-            const uint32_t j = __builtin_ctz(e);
-            e &= e - 1;
-            const uint32_t low = j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u);
-            const uint32_t t = t0 + __builtin_popcount(~im & low) - 1;
-            const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
-            const uint32_t slot = (g == 0 ? b0 + o : (g == 1 ? b1 + (o - nb1) : b2 + (o - nb2)));
-            uint64_t dst;
-            bool ok = tA + g < n_tiles;
-            if (slot < bucket_cap) {
-                dst = (uint64_t)(tA + g) * bucket_cap + slot;
-            } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
-                const uint32_t x = atomicAdd(ovf_cnt, 1u);
-                dst = ovf_base + x;
-                ok = ok && x < ovf_cap;
-            }
-            if (ok) {
-                out_keys[dst] = ((uint64_t)t << 32) | (lc0 + j);
-                out_vals[dst] = d.read;
-            }
-            ++o;
-        }
-    }
-    if (lane == 0) {
-        if (c0 + 2048 >= ncols) {
+        if (lane == 0 && c0 + 2048 >= ncols) {
             // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
             if (ncols == 0 || ts + carryN + total - 1 != d.aln_t_e || d.aln_t_e >= L) atomicOr(err, 2u);
             if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
@@ -1012,8 +1085,9 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
                        uint32_t *ovf_cnt, uint32_t *ckpt, uint32_t *err) {
     if (n_chunks)
-        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 3) / 4), dim3(256), 0, s, descs, n_chunks, nib, refw, refnib, L,
-                           keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, err);
+        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 7) / 8), dim3(256), 0, s, descs, n_chunks, nib,
+                           (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap,
+                           ovf_cnt, ckpt, err);
 }
 void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n) {
     if (n_chunks)
