@@ -147,6 +147,29 @@ __device__ __forceinline__ uint32_t n_ctz(const N128 &x) { // index of the first
 __device__ __forceinline__ uint32_t n_popc(const N128 &x) {
     return (uint32_t)__builtin_popcountll(x.lo) + (uint32_t)__builtin_popcountll(x.hi);
 }
+// x holds nibble flags (bit 3) and is not zero: all bits below the nibble of its lowest flag / up to and including it
+__device__ __forceinline__ N128 n_mask_before_first(const N128 &x) {
+    N128 m;
+    if (x.lo) {
+        m.lo = ((x.lo & (0ULL - x.lo)) >> 3) - 1ULL;
+        m.hi = 0;
+    } else {
+        m.lo = ~0ULL;
+        m.hi = ((x.hi & (0ULL - x.hi)) >> 3) - 1ULL;
+    }
+    return m;
+}
+__device__ __forceinline__ N128 n_mask_through_first(const N128 &x) {
+    N128 m;
+    if (x.lo) {
+        m.lo = x.lo ^ (x.lo - 1ULL);
+        m.hi = 0;
+    } else {
+        m.lo = ~0ULL;
+        m.hi = x.hi ^ (x.hi - 1ULL);
+    }
+    return m;
+}
 __device__ __forceinline__ N128 n_shl(const N128 &x, uint32_t s) { // 0 < s < 128
     N128 r;
     if (s < 64) {
@@ -222,16 +245,20 @@ __global__ __launch_bounds__(256) void k_diff_reads(
             N128 J = I;
             while (__ballot((J.lo | J.hi) != 0)) {
                 if (J.lo | J.hi) {
-                    const uint32_t p = n_ctz(J) >> 2; // first column of the run
-                    const N128 bp = n_below(p);
-                    const N128 K{~J.lo & NF3 & ~bp.lo, ~J.hi & NF3 & ~bp.hi}; // non-insertion flags at / above p
-                    const uint32_t qn = min(n_ctz(K) >> 2, 32u);               // first column past the run
-                    const N128 up = n_shl(N128{R.lo & ~bp.lo, R.hi & ~bp.hi}, 4 * (qn - p));
-                    R.lo = (R.lo & bp.lo) | up.lo;
-                    R.hi = (R.hi & bp.hi) | up.hi;
-                    const N128 bq = n_below(qn);
-                    J.lo &= ~bq.lo;
-                    J.hi &= ~bq.hi;
+                    const N128 bp = n_mask_before_first(J);                    // columns before the run
+                    const N128 K{~J.lo & NF3 & ~bp.lo, ~J.hi & NF3 & ~bp.hi}; // non-insertion flags at / above it
+                    if (K.lo | K.hi) {
+                        const N128 up = n_shl(N128{R.lo & ~bp.lo, R.hi & ~bp.hi}, n_ctz(K) - n_ctz(J)); // 4 * run length
+                        R.lo = (R.lo & bp.lo) | up.lo;
+                        R.hi = (R.hi & bp.hi) | up.hi;
+                        const N128 bq = n_mask_before_first(K); // columns before the first one past the run
+                        J.lo &= ~bq.lo;
+                        J.hi &= ~bq.hi;
+                    } else { // the run reaches the lane's last column
+                        R.lo &= bp.lo;
+                        R.hi &= bp.hi;
+                        J.lo = J.hi = 0;
+                    }
                 }
             }
         }
@@ -307,10 +334,6 @@ __global__ __launch_bounds__(256) void k_diff_reads(
             // tiles.  Records are position-ordered across the wave, so the tile boundaries split them into three
             // consecutive groups; each group reserves its place in its tile's bucket with one wave-level atomic.
             const N128 NI{~I.lo & V.lo, ~I.hi & V.hi};
-            auto t_of = [&](uint32_t j) -> uint32_t { // t_pos of column j: non-insertion columns up to and including j
-                const N128 m = n_below(j + 1);
-                return t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1;
-            };
             const uint32_t cnt = n_popc(E);
             const uint32_t inc2 = wave_incl_scan<OpAdd>(cnt);
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
@@ -321,19 +344,18 @@ __global__ __launch_bounds__(256) void k_diff_reads(
             const uint32_t t_first = t0 - ((I.lo & 8ULL) ? 1u : 0u); // a leading insertion column belongs to t0 - 1
             auto below = [&](uint32_t P) -> uint32_t { // records of the wave with t_pos < P
                 const uint32_t nb = __builtin_popcountll(__ballot(nv != 0 && t_last < P)); // lanes entirely below: a prefix
-                uint32_t c = nb ? __shfl(inc2, nb - 1) : 0u;
+                uint32_t c = nb ? (uint32_t)__builtin_amdgcn_readlane((int)inc2, (int)nb - 1) : 0u;
                 uint32_t part = 0;
                 if (lane == nb && cnt && t_first < P) { // the one lane straddling the boundary
                     N128 e = E;
                     while (e.lo | e.hi) {
-                        const uint32_t j = n_ctz(e) >> 2;
-                        const N128 m = n_below(j + 1);
+                        const N128 m = n_mask_through_first(e);
                         e.lo &= ~m.lo;
                         e.hi &= ~m.hi;
-                        if (t_of(j) < P) ++part; else break;
+                        if (t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1 < P) ++part; else break;
                     }
                 }
-                if (nb < 64) c += __shfl(part, nb);
+                if (nb < 64) c += (uint32_t)__builtin_amdgcn_readlane((int)part, (int)nb);
                 return c;
             };
             const uint32_t nb1 = below(P1), nb2 = below(P2);
@@ -345,15 +367,16 @@ __global__ __launch_bounds__(256) void k_diff_reads(
                     else rb = 0xFFFFFFFFu - cj; // position >= L: the descriptor check below reports the read
                 }
             }
-            const uint32_t g0 = __shfl(rb, 0), g1 = __shfl(rb, 1), g2 = __shfl(rb, 2);
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 1);
+            const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 2);
             uint32_t o = inc2 - cnt; // rank of the lane's first record within the wave
             N128 e = E;
             while (e.lo | e.hi) { // raw record: t_pos << 32 | column, read
                 const uint32_t j = n_ctz(e) >> 2;
-                const N128 m = n_below(j + 1);
+                const N128 m = n_mask_through_first(e); // columns 0 .. j
                 e.lo &= ~m.lo;
                 e.hi &= ~m.hi;
-                const uint32_t t = t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1;
+                const uint32_t t = t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1; // non-insertion columns up to j
                 const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
                 const uint32_t slot = (g == 0 ? g0 + o : (g == 1 ? g1 + (o - nb1) : g2 + (o - nb2)));
                 uint64_t dst;
