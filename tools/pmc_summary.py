@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 --pmc passes (counter_collection.csv), e.g.
+   python tools/pmc_summary.py gpurun_out/pmc_f/*/*_counter_collection.csv gpurun_out/pmc_w/*/*_counter_collection.csv
+Prints JSON: {kernel: {counter_avg_per_launch: value}}.  FETCH_SIZE / WRITE_SIZE are reported in KB."""
+import csv, json, re, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for path in sys.argv[1:]:
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"np2::(\w+)", r["Kernel_Name"])
+        name = "np2::" + m.group(1) if m else r["Kernel_Name"][:48]
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c + "_KB_avg_per_launch": round(sum(v) / len(v), 1) for c, v in cs.items()} for k, cs in acc.items()}
+print(json.dumps(out, indent=1))
