@@ -203,7 +203,9 @@ struct np2_ctx {
     DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
-    DevBuf<uint32_t> long_list, chunk_n, chunk_pre;
+    DevBuf<uint32_t> long_list;
+    DevBuf<uint64_t> chunk_st; // per chunk: launch epoch | non-insertion columns (k_diff_reads)
+    uint32_t chunk_epoch = 0;
     DevBuf<uint32_t> tile_cur, tile_n, tile_scan, tile_scanb, tile_nn, tile_nr, tile_noff, tile_roff;
     uint32_t tile_cap = TILE_CAP; // records per tile bucket (tests lower it to force the spill path)
     uint32_t bucket_cap = 0;      // layout of the sorted records of the current contig (0 = compact)

@@ -381,8 +381,6 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     const uint32_t bcap = cx->tile_cap;
     const uint64_t buckets = (uint64_t)n_tiles * bcap;
     uint64_t ovf_cap = std::max<uint64_t>(c->n_cols / 256 + 65536, 1u << 18); // spill area of full buckets
-    cx->chunk_n.ensure(NCH + 2);
-    cx->chunk_pre.ensure(NCH + 2);
     cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)NCH + 2, (size_t)L + 2)));
     cx->tile_n.ensure(n_tiles + 2);
     cx->tile_scan.ensure(n_tiles + 2);
@@ -396,23 +394,21 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         cx->tile_cur.ensure(n_tiles + 2);
         zero32(cx, cx->tile_cur.p, cx->tile_cur.cap);
     }
-    {
-        EventTimer t(cx, "chunk_prefix");
-        launch_chunk_count(s, c->descs.p, c->nib.p, NCH, cx->chunk_n.p);
-        zero32(cx, cx->chunk_n.p + NCH, 1);
-        exclusive_total(cx, cx->chunk_n.p, cx->chunk_pre.p, (size_t)NCH + 1);
-        launch_fill_carry(s, c->descs.p, cx->chunk_pre.p, NCH);
+    if (cx->chunk_st.cap < (size_t)NCH + 2) { // status words carry a launch epoch: cleared once, never again
+        cx->chunk_st.ensure(NCH + 2);
+        zero32(cx, cx->chunk_st.p, cx->chunk_st.cap, 8);
     }
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (ovf_cap >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
         cx->keys_raw.ensure(buckets + ovf_cap + 1);
         cx->vals_raw.ensure(buckets + ovf_cap + 1);
         zero32(cx, cx->scal.p, S_COUNT);
+        if (++cx->chunk_epoch == 0) ++cx->chunk_epoch; // 0 = never written
         {
             EventTimer t(cx, "diff_reads", true);
             launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
                               cx->keys_raw.p, cx->vals_raw.p, cx->tile_cur.p, n_tiles, bcap, buckets, (uint32_t)ovf_cap,
-                              cx->scal.p + S_M3, c->ckpt.p, cx->scal.p + S_ERR);
+                              cx->scal.p + S_M3, c->ckpt.p, cx->chunk_st.p, cx->chunk_epoch, cx->scal.p + S_ERR);
         }
         {
             EventTimer t(cx, "sort_exceptions");

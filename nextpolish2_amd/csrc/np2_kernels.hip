@@ -22,34 +22,6 @@ namespace np2 {
 __device__ __forceinline__ uint32_t swap_nib(uint32_t w) {
     return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu);
 }
-// gather bit 0 of each of the 16 nibbles of x into 16 contiguous bits
-__device__ __forceinline__ uint32_t gather16(uint64_t x) {
-    x &= 0x1111111111111111ULL;
-    x = (x | (x >> 3)) & 0x0303030303030303ULL;
-    x = (x | (x >> 6)) & 0x000F000F000F000FULL;
-    x = (x | (x >> 12)) & 0x000000FF000000FFULL;
-    x = (x | (x >> 24)) & 0xFFFFULL;
-    return (uint32_t)x;
-}
-// nonzero-nibble mask (bit 0 of each nibble)
-__device__ __forceinline__ uint64_t nz_nib(uint64_t x) {
-    x |= x >> 1;
-    x |= x >> 2;
-    return x & 0x1111111111111111ULL;
-}
-// nibble-packed contig: code of position p at bits 4*(p&15) of 64-bit word p>>4
-__device__ __forceinline__ void load_ref128(const uint64_t *__restrict__ refw, uint32_t t, uint64_t &lo,
-                                            uint64_t &hi) {
-    uint32_t wi = t >> 4, sh = (t & 15) * 4;
-    uint64_t w0 = refw[wi], w1 = refw[wi + 1], w2 = refw[wi + 2];
-    if (sh) {
-        lo = (w0 >> sh) | (w1 << (64 - sh));
-        hi = (w1 >> sh) | (w2 << (64 - sh));
-    } else {
-        lo = w0;
-        hi = w1;
-    }
-}
 __device__ __forceinline__ uint8_t ref_code(const uint8_t *__restrict__ refnib, uint32_t p) {
     return (refnib[p >> 1] >> (4 * (p & 1))) & 7;
 }
@@ -75,61 +47,6 @@ __global__ void k_encode_ref(const uint8_t *__restrict__ read0, uint32_t L, uint
 //     per-read checkpoints.  One wavefront per 2048-column chunk; each lane owns 32 columns
 //     (16 B), i.e. a coalesced 1 KiB per wave-instruction.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint8_t reg_nib(uint64_t lo, uint64_t hi, uint32_t j) {
-    return (uint8_t)(((j < 16 ? lo >> (4 * j) : hi >> (4 * (j - 16)))) & 7);
-}
-
-// decode the lane's 16 bytes into codes (lo, hi), the compact insertion mask and the valid count
-struct LaneCols {
-    uint64_t lo, hi, mlo, mhi;
-    uint64_t ilo, ihi;
-    uint32_t nv, n_ins;
-};
-__device__ __forceinline__ LaneCols load_lane(const uint8_t *__restrict__ base, uint32_t lc0, uint32_t ncols) {
-    LaneCols c;
-    c.nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (c.nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
-    c.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
-    c.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
-    c.mlo = ~0ULL, c.mhi = ~0ULL;
-    if (c.nv < 32) {
-        if (c.nv <= 16) {
-            c.mhi = 0;
-            c.mlo = c.nv == 16 ? ~0ULL : ((1ULL << (4 * c.nv)) - 1);
-        } else {
-            c.mhi = (1ULL << (4 * (c.nv - 16))) - 1;
-        }
-    }
-    c.lo &= c.mlo;
-    c.hi &= c.mhi;
-    c.ilo = c.lo & 0x8888888888888888ULL, c.ihi = c.hi & 0x8888888888888888ULL;
-    if (lc0 == 0) c.ilo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-    c.lo &= 0x7777777777777777ULL;
-    c.hi &= 0x7777777777777777ULL;
-    c.n_ins = __builtin_popcountll(c.ilo) + __builtin_popcountll(c.ihi);
-    return c;
-}
-
-// pre-pass: non-insertion columns per 2048-column chunk (one wavefront per chunk)
-__global__ __launch_bounds__(256) void k_chunk_count(const ChunkDesc *__restrict__ descs,
-                                                     const uint8_t *__restrict__ nib, uint32_t n_chunks,
-                                                     uint32_t *__restrict__ chunk_n) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (ch >= n_chunks) return;
-    const ChunkDesc d = descs[ch];
-    const LaneCols c = load_lane(nib + d.nib_off, d.c0 + lane * 32, d.ncols);
-    uint32_t v = c.nv - c.n_ins;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) chunk_n[ch] = v;
-}
-// fold the scan into the descriptors: non-insertion columns of the read before this chunk
-__global__ void k_fill_carry(ChunkDesc *__restrict__ descs, const uint32_t *__restrict__ chunk_pre, uint32_t n_chunks) {
-    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch < n_chunks) descs[ch].carryN = chunk_pre[ch] - chunk_pre[descs[ch].first_chunk];
-}
-
 // ---- 128-bit nibble vectors: column j of a lane lives in nibble j (bits 4j..4j+3; lo = columns 0-15) ----------
 struct N128 {
     uint64_t lo, hi;
@@ -196,21 +113,29 @@ __global__ __launch_bounds__(256) void k_diff_reads(
     const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
     uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
     uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
-    uint32_t *__restrict__ ckpt, uint32_t *__restrict__ err) {
+    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t pw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    uint32_t prev_read = 0xFFFFFFFFu, prev_b3 = 0; // for the second chunk: does it continue the first one?
+    // ---- phase A: load both chunks, count their non-insertion columns and publish the counts at once.  A chunk needs
+    //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
+    //      already running waves, which publish within a microsecond of starting ---------------------------------------
+    __shared__ uint32_t s_total[8]; // counts of the block's 8 chunks (4 waves x 2): most of a read's chunks are in here
+    const uint32_t blk_first = blockIdx.x * 8;
+    N128 w_[2], V_[2], I_[2];
+    uint32_t nv_[2], nonins_[2], incl_[2], total_[2];
+#pragma unroll
     for (uint32_t it = 0; it < 2; ++it) {
         const uint32_t ch = 2 * pw + it;
+        w_[it] = V_[it] = I_[it] = N128{0, 0};
+        nv_[it] = nonins_[it] = incl_[it] = total_[it] = 0;
         if (ch >= n_chunks) break;
         const ChunkDesc d = descs[ch];
-        const uint8_t *base = nib + d.nib_off; // start of the READ's stream
-        const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0, carryN = d.carryN;
+        const uint32_t ncols = d.ncols, c0 = d.c0;
         const uint32_t lc0 = c0 + lane * 32;
         const bool full = ncols - c0 >= 2048; // every lane of the wave holds 32 columns
         const uint32_t nv = full ? 32u : (lc0 < ncols ? min(32u, ncols - lc0) : 0u);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (nv) v = *reinterpret_cast<const uint4 *>(base + (lc0 >> 1));
+        if (nv) v = *reinterpret_cast<const uint4 *>(nib + d.nib_off + (lc0 >> 1));
         N128 w;
         w.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
         w.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
@@ -222,11 +147,65 @@ __global__ __launch_bounds__(256) void k_diff_reads(
         }
         N128 I{w.lo & V.lo, w.hi & V.hi}; // insertion columns
         if (c0 == 0 && lane == 0) I.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-        const N128 codes{w.lo & ~NF3, w.hi & ~NF3};
-        const uint32_t n_ins = n_popc(I);
-        const uint32_t nonins = nv - n_ins;
+        const uint32_t nonins = nv - n_popc(I);
         const uint32_t incl = wave_incl_scan<OpAdd>(nonins);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 0) {
+            __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_total[ch - blk_first] = total;
+        }
+        w_[it] = w, V_[it] = V, I_[it] = I;
+        nv_[it] = nv, nonins_[it] = nonins, incl_[it] = incl, total_[it] = total;
+    }
+    __syncthreads();
+    // ---- phase B: the chunks, one after the other ----------------------------------------------------------------------
+    uint32_t prev_read = 0xFFFFFFFFu, prev_b3 = 0; // for the second chunk: does it continue the first one?
+    uint32_t prev_carry = 0, prev_total = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < 2; ++it) {
+        const uint32_t ch = 2 * pw + it;
+        if (ch >= n_chunks) break;
+        const ChunkDesc d = descs[ch];
+        const uint8_t *base = nib + d.nib_off; // start of the READ's stream
+        const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0;
+        const uint32_t lc0 = c0 + lane * 32;
+        const N128 w = w_[it], V = V_[it], I = I_[it];
+        const uint32_t nv = nv_[it], nonins = nonins_[it], incl = incl_[it], total = total_[it];
+        const N128 codes{w.lo & ~NF3, w.hi & ~NF3};
+        const uint32_t n_ins = nv - nonins;
+        uint32_t carryN = 0; // non-insertion columns of the read before this chunk
+        if (it == 1 && d.read == prev_read && c0 != 0) {
+            carryN = prev_carry + prev_total;
+        } else {
+            bool timeout = false;
+            // earlier chunks of the read inside this block: from LDS; the ones in earlier blocks: from their status words
+            for (uint32_t j = max(d.first_chunk, blk_first); j < ch; ++j) carryN += s_total[j - blk_first];
+            const uint32_t jend = min(ch, blk_first);
+            for (uint32_t j0 = d.first_chunk; j0 < jend; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                uint32_t v = 0;
+                if (j < jend) {
+                    uint32_t spins = 0;
+                    for (;;) {
+                        const uint64_t sw = __hip_atomic_load(&chunk_st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(sw >> 32) == epoch) {
+                            v = (uint32_t)sw;
+                            break;
+                        }
+                        if (++spins > (1u << 22)) {
+                            timeout = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                carryN += v;
+            }
+            if (__ballot(timeout) && lane == 0) atomicOr(err, LB_ERR);
+        }
+        prev_carry = carryN;
+        prev_total = total;
         const uint32_t t0 = ts + carryN + (incl - nonins); // t_pos of the lane's first non-insertion column
         // ---- the 32 contig codes starting at t0 ------------------------------------------------------------------
         N128 R;
@@ -1106,18 +1085,11 @@ void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t 
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
                        const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
-                       uint32_t *ovf_cnt, uint32_t *ckpt, uint32_t *err) {
+                       uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err) {
     if (n_chunks)
         hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 7) / 8), dim3(256), 0, s, descs, n_chunks, nib,
                            (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap,
-                           ovf_cnt, ckpt, err);
-}
-void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n) {
-    if (n_chunks)
-        hipLaunchKernelGGL(k_chunk_count, dim3((n_chunks + 3) / 4), dim3(256), 0, s, descs, nib, n_chunks, chunk_n);
-}
-void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks) {
-    if (n_chunks) hipLaunchKernelGGL(k_fill_carry, grid1(n_chunks), dim3(256), 0, s, descs, chunk_pre, n_chunks);
+                           ovf_cnt, ckpt, chunk_st, epoch, err);
 }
 void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2,
                  const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {

@@ -20,7 +20,7 @@ struct ChunkDesc { // one 2048-column chunk of a streamed read (built on the hos
     uint32_t c0, ncols;   // first column of the chunk, columns of the read
     uint32_t first_chunk; // index of the read's first chunk
     uint32_t aln_t_e, nck;
-    uint32_t carryN;      // non-insertion columns of the read before this chunk (filled on the device)
+    uint32_t pad0;
     uint32_t pad[4];
 };
 
@@ -64,9 +64,7 @@ void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t 
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, const uint64_t *refw,
                        const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *tile_cur,
                        uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *ovf_cnt,
-                       uint32_t *ckpt, uint32_t *err);
-void launch_chunk_count(hipStream_t s, const ChunkDesc *descs, const uint8_t *nib, uint32_t n_chunks, uint32_t *chunk_n);
-void launch_fill_carry(hipStream_t s, ChunkDesc *descs, const uint32_t *chunk_pre, uint32_t n_chunks);
+                       uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err);
 void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr,
                  uint32_t *d2 = nullptr, const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0 = nullptr,
