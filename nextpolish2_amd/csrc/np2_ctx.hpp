@@ -225,6 +225,8 @@ namespace np2h {
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
             S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_COUNT = 24 };
 
+static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it
+
 struct WallTimer {
     np2_ctx *cx;
     const char *name;
@@ -384,6 +386,15 @@ inline void scan_incl_sum(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n
 }
 inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
     if (n_elems) HIPCHK(hipMemsetAsync(p, 0, n_elems * elem, cx->stream));
+}
+// exclusive sums of in[0..n) into out[0..n], out[n] = total (in[n] is not read by the short path, cleared for the long one)
+inline void exclusive_total_n(np2_ctx *cx, uint32_t *in, uint32_t *out, size_t n) {
+    if (n + 1 <= SCAN_SMALL_MAX) {
+        launch_scan_small_excl(cx->stream, in, out, (uint32_t)n, nullptr, nullptr, true);
+        return;
+    }
+    zero32(cx, in + n, 1);
+    exclusive_total(cx, in, out, n + 1);
 }
 
 // validate the read descriptors, build checkpoint offsets / chunk tables / contig codes for a contig whose

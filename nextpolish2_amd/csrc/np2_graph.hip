@@ -284,8 +284,10 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__
 __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restrict__ tile_nn,
                                                        const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
                                                        uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
-                                                       uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs) {
+                                                       uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
+                                                       uint32_t *__restrict__ reset, uint32_t n_reset) {
     __shared__ uint32_t sh[16];
+    if (threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars (best, path begin, gains, ...)
     const uint32_t ta = block_scan_array<OpAdd>(
         n_tiles, sh, [&](uint32_t i) { return tile_nn[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { tile_noff[i] = pre; });
     const uint32_t tb = block_scan_array<OpAdd>(
@@ -552,9 +554,10 @@ void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        alive, tile_nn, tile_nr);
 }
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
-                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs) {
+                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
+                         uint32_t n_reset) {
     hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes,
-                       n_runs);
+                       n_runs, reset, n_reset);
 }
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,

@@ -140,11 +140,9 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
         uint8_t *v_seen = cx->votebuf.p + RP * 8, *v_bad = cx->votebuf.p + RP * 9;
         HIPCHK(hipMemsetAsync(v_first, 0xFF, RP * 4, s));
         HIPCHK(hipMemsetAsync(v_refw, 0, RP * 6, s));
-        zero32(cx, cx->scal.p + S_ERR, 1);
         launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, v_refw, v_seen, v_bad, v_first,
                           cx->scal.p + S_ERR);
-        zero32(cx, cx->ecount.p + n_reg, 1);
-        exclusive_total(cx, cx->ecount.p, cx->eoff.p, (size_t)n_reg + 1);
+        exclusive_total_n(cx, cx->ecount.p, cx->eoff.p, n_reg);
     }
     {
         std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
@@ -264,15 +262,16 @@ CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, 
     const size_t cap = (size_t)out_cap + 64;
     uint32_t *opos = to_b ? cx->cns_pos2.ensure(cap) : cx->cns_pos.ensure(cap);
     uint8_t *obase = to_b ? cx->cns_base2.ensure(cap) : cx->cns_base.ensure(cap);
-    zero32(cx, cx->scal.p + S_STUCK, 2); // stuck, n_ap
+    // per-round counters (stuck, n_ap) live behind the posted scalar block; run_diff zeroes them once per contig
+    uint32_t *const stuck_p = cx->scal.p + S_COUNT + 2 * version, *const nap_p = stuck_p + 1;
     launch_splice_find(s, in.pos, in.M_p, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
-                       cx->sp_idx_e.p, cx->scal.p + S_STUCK);
-    launch_splice_plan(s, next_lookback(cx, (n_reg + 255) / 256), cx->reg_lable.p, lable, n_reg, cx->scal.p + S_STUCK,
+                       cx->sp_idx_e.p, stuck_p);
+    launch_splice_plan(s, next_lookback(cx, (n_reg + 255) / 256), cx->reg_lable.p, lable, n_reg, stuck_p,
                        cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p,
-                       cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, cx->scal.p + S_NAP, in.M_p, cx->mlen.p + version,
+                       cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, nap_p, in.M_p, cx->mlen.p + version,
                        cx->scal.p + S_ERR);
     launch_splice_write(s, in.pos, in.base, in.M_p, in.M_cap, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p,
-                        cx->ap_shift.p, cx->scal.p + S_NAP, n_reg, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p,
+                        cx->ap_shift.p, nap_p, n_reg, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p,
                         cx->cand_seq.p, opos, obase);
     return CnsDev{opos, obase, cx->mlen.p + version, out_cap};
 }
@@ -320,8 +319,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
             cx->sscore.ensure(n_jobs + 2);
             cx->tmp.ensure(prim_temp_bytes((size_t)n_jobs + 2));
             launch_rech_job_len(s, rp, n_jobs, cx->job_len.p);
-            zero32(cx, cx->job_len.p + n_jobs, 1);
-            exclusive_total(cx, cx->job_len.p, cx->job_off32.p, (size_t)n_jobs + 1);
+            exclusive_total_n(cx, cx->job_len.p, cx->job_off32.p, n_jobs);
             const uint32_t blob_bytes = fetch_scal(cx, cx->scal.p + S_M0, cx->job_off32.p + n_jobs)[S_M0];
             cx->sstr.ensure((size_t)blob_bytes + 64);
             launch_rech_job_build(s, rp, n_jobs, cx->job_off32.p, cx->soff.p, cx->sstr.p);
@@ -402,7 +400,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         if (ovf_cap >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
         cx->keys_raw.ensure(buckets + ovf_cap + 1);
         cx->vals_raw.ensure(buckets + ovf_cap + 1);
-        zero32(cx, cx->scal.p, S_COUNT);
+        zero32(cx, cx->scal.p, SCAL_TOTAL);
         if (++cx->chunk_epoch == 0) ++cx->chunk_epoch; // 0 = never written
         {
             EventTimer t(cx, "diff_reads", true);
@@ -473,12 +471,12 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
     cx->emit.ensure(L + 2);
-    zero32(cx, cx->scal.p, S_COUNT);
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
     launch_tile_count(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, n_tiles,
                       cx->alive.p, cx->tile_nn.p, cx->tile_nr.p);
+    // (also resets the per-pass scalars S_BEST .. S_NLONG)
     launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
-                        cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS);
+                        cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS, cx->scal.p + S_BEST, S_NLONG + 1 - S_BEST);
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
                       cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
                       c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p, c->refnib.p, cx->emit.p,
@@ -575,12 +573,11 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         EventTimer t(cx, "dp_backtrack");
         launch_bt_write(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
                         cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->eoff.p, cx->cns_pos.p, cx->cns_base.p,
-                        cx->cns_cls.p);
+                        cx->cns_cls.p, cx->lq_nothead.p);
     }
     uint32_t n_raw = 0;
     {
         EventTimer t(cx, "lq_regions");
-        zero32(cx, cx->lq_nothead.p, M + 2, 1);
         launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M, cx->lq_kind.p, cx->lq_next.p,
                        cx->lq_nothead.p, cx->rflag.p, cx->rstart.p, cx->rend.p);
         exclusive_total(cx, cx->rflag.p, cx->ridx.p, M);
@@ -658,7 +655,6 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     {
         EventTimer t(cx, "kmer_score");
         cx->long_list.ensure(NC + 2);
-        zero32(cx, cx->scal.p + S_NLONG, 1);
         launch_cand_score(s, cx->yaks[0].dev(), cx->cand_seq_off.p, cx->cand_seq.p, cx->cand_kmer.p, NC,
                           min_kmer_count, cx->kscore.p, cx->long_list.p, cx->scal.p + S_NLONG);
     }
@@ -709,7 +705,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     hipStream_t s = cx->stream;
     HIPCHK(hipSetDevice(cx->device));
     cx->trace_items.clear();
-    cx->scal.ensure(S_COUNT);
+    cx->scal.ensure(SCAL_TOTAL);
     cx->alive.ensure(c->R + 2);
     uint32_t T = 0;
     {
@@ -787,7 +783,6 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             cx->keep_ks.ensure(pc.NC + 2);
             {
                 EventTimer t(cx, "seed");
-                zero32(cx, cx->scal.p + S_ERR, 1);
                 launch_seed(s, rt, o->max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
                             cx->keep_ks.p, cx->scal.p + S_ERR);
             }
@@ -923,7 +918,7 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         cx->device = device;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
-        cx->scal.ensure(S_COUNT);
+        cx->scal.ensure(SCAL_TOTAL);
         HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
         HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));

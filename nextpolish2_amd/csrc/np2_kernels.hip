@@ -692,7 +692,8 @@ template <bool WRITE>
 __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t entry_idx,
                             const uint32_t *__restrict__ nbesti, const uint32_t *__restrict__ n0_besti,
                             uint32_t *__restrict__ path_begin, uint32_t out_end, uint32_t *__restrict__ cns_pos,
-                            uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls) {
+                            uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
+                            uint8_t *__restrict__ lq_nothead) {
     // walks right -> left from node (b, entry_idx) until it leaves [a, b]; returns #emitted bases;
     // with WRITE, bases are stored at out_end-1, out_end-2, ...
     uint32_t pos = b, idx = entry_idx, n = 0;
@@ -722,6 +723,7 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
                 cns_pos[o] = k3.t_pos;
                 cns_base[o] = code_to_ascii(k3.q);
                 cns_cls[o] = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
+                lq_nothead[o] = 0; // every consensus index is written exactly once: clears the LQ chain flags
             }
             ++n;
         }
@@ -745,7 +747,7 @@ __global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], b = run_end[r];
     const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
-    emit[a] = bt_walk<false>(g, a, b, entry, nbesti, n0_besti, path_begin, 0, nullptr, nullptr, nullptr);
+    emit[a] = bt_walk<false>(g, a, b, entry, nbesti, n0_besti, path_begin, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
 // positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
@@ -771,11 +773,13 @@ __global__ void k_emit_fix(uint32_t *__restrict__ emit, const uint32_t *__restri
 __global__ void k_clean_write(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
                               const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
                               const uint32_t *__restrict__ eoff, uint32_t L, uint32_t *__restrict__ cns_pos,
-                              uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls) {
+                              uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
+                              uint8_t *__restrict__ lq_nothead) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= L) return;
     if (node_off[p + 1] > node_off[p] || emit[p] == 0) return;
     const uint32_t o = eoff[p];
+    lq_nothead[o] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
     cns_pos[o] = p;
     cns_base[o] = code_to_ascii(ref_code(refnib, p));
     cns_cls[o] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
@@ -786,13 +790,13 @@ __global__ void k_bt_write(const uint32_t *__restrict__ run_start, const uint32_
                            const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
                            const uint32_t *__restrict__ emit, const uint32_t *__restrict__ eoff,
                            uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
-                           uint8_t *__restrict__ cns_cls) {
+                           uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], b = run_end[r];
     if (emit[a] == 0) return;
     const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
-    bt_walk<true>(g, a, b, entry, nbesti, n0_besti, nullptr, eoff[a] + emit[a], cns_pos, cns_base, cns_cls);
+    bt_walk<true>(g, a, b, entry, nbesti, n0_besti, nullptr, eoff[a] + emit[a], cns_pos, cns_base, cns_cls, lq_nothead);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1137,13 +1141,13 @@ void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
-                     uint8_t *cns_base, uint8_t *cns_cls) {
+                     uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {
     Graph g = mk_graph(gp);
     hipLaunchKernelGGL(k_clean_write, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, gp.L,
-                       cns_pos, cns_base, cns_cls);
+                       cns_pos, cns_base, cns_cls, lq_nothead);
     if (max_runs)
         hipLaunchKernelGGL(k_bt_write, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
-                           n0_besti, best_idx, emit, eoff, cns_pos, cns_base, cns_cls);
+                           n0_besti, best_idx, emit, eoff, cns_pos, cns_base, cns_cls, lq_nothead);
 }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     uint32_t M, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag,

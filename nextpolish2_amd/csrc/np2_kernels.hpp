@@ -84,7 +84,7 @@ void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
-                     uint8_t *cns_base, uint8_t *cns_cls);
+                     uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls, uint32_t M,
                     uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag, uint32_t *rstart,
                     uint32_t *rend);
@@ -142,7 +142,8 @@ void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, uint32_t n_tiles, const uint8_t *alive,
                        uint32_t *tile_nn, uint32_t *tile_nr);
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
-                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs);
+                         uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
+                         uint32_t n_reset);
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
