@@ -143,11 +143,16 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
         launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, v_refw, v_seen, v_bad, v_first,
                           cx->scal.p + S_ERR);
         exclusive_total_n(cx, cx->ecount.p, cx->eoff.p, n_reg);
+        launch_vote_counts(s, v_first, v_bad, R, cx->scal.p + S_M1); // S_M1 = graph keys, S_M2 = invalid reads
     }
     {
         std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
         check_region_err(cx, sc[S_ERR]);
         NE = sc[S_M0];
+        if (!cx->trace && sc[S_M1] == 0 && sc[S_M2] == 0) { // no read votes anywhere: nobody can lose
+            if (NE) throw Np2Error(NP2_E_DEVICE, "internal: pair edges without voting reads");
+            return {};
+        }
     }
     std::vector<uint64_t> ukey;
     std::vector<int32_t> uw;
@@ -532,14 +537,36 @@ void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
 }
 
 // DP + backtrack + LQ regions; returns consensus length M and region count
-void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t &M, uint32_t &n_reg) {
+// One read-back at the end: consensus length, region count, error word.  The consensus length stays on the device
+// (eoff[L]) while the consensus and the LQ regions are built; launches and buffers are sized by M <= L + T.
+void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t T, uint32_t &M, uint32_t &n_reg) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L;
+    if ((uint64_t)L + T + 2 >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "consensus bound exceeds 32 bits");
+    const uint32_t M_cap = L + T + 2; // a path node emits at most one base; exception nodes <= T
     GraphPtrs gp = graph_ptrs(cx, c);
     cx->n0_besti.ensure(L + 2);
     cx->run_gain.ensure((size_t)n_runs + 2);
     cx->emit.ensure(L + 2);
     cx->eoff.ensure(L + 2);
+    cx->cns_pos.ensure(M_cap + 2);
+    cx->cns_base.ensure(M_cap + 2);
+    cx->cns_cls.ensure(M_cap + 2);
+    cx->lq_kind.ensure(M_cap + 2);
+    cx->lq_next.ensure(M_cap + 2);
+    cx->lq_nothead.ensure(M_cap + 2);
+    cx->rflag.ensure(M_cap + 2);
+    cx->rstart.ensure(M_cap + 2);
+    cx->rend.ensure(M_cap + 2);
+    cx->ridx.ensure(M_cap + 2);
+    cx->raw_start.ensure(M_cap + 2);
+    cx->raw_end.ensure(M_cap + 2);
+    cx->headflag.ensure(M_cap + 2);
+    cx->hidx.ensure(M_cap + 2);
+    cx->lq_start.ensure(M_cap + 2);
+    cx->lq_end.ensure(M_cap + 2);
+    cx->tmp.ensure(prim_temp_bytes((size_t)M_cap + 2));
+    const uint32_t *M_p = cx->eoff.p + L;
     {
         EventTimer t(cx, "dp_backtrack");
         // (scalars were zeroed by build_graph; S_GAIN already holds the clean-position gains)
@@ -550,55 +577,30 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
                         cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN);
         zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
+        launch_bt_write(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
+                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->eoff.p, cx->cns_pos.p, cx->cns_base.p,
+                        cx->cns_cls.p, cx->lq_nothead.p);
     }
-    std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + L);
+    {
+        EventTimer t(cx, "lq_regions");
+        launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, M_cap, cx->lq_kind.p, cx->lq_next.p,
+                       cx->lq_nothead.p, cx->rflag.p, cx->rstart.p, cx->rend.p);
+        exclusive_total(cx, cx->rflag.p, cx->ridx.p, M_cap);
+        launch_scatter_regions(s, cx->rflag.p, cx->ridx.p, cx->rstart.p, cx->rend.p, M_p, M_cap, cx->raw_start.p,
+                               cx->raw_end.p, cx->scal.p + S_NRAW);
+        launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p);
+        launch_scan_small_excl(s, cx->headflag.p, cx->hidx.p, M_cap, cx->scal.p + S_NRAW, nullptr, false);
+        launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
+                              cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
+    }
+    std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
     check_region_err(cx, sc[S_ERR]);
     if (sc[S_BEST] == 0xFFFFFFFFu)
         throw Np2Error(NP2_E_UNSUPPORTED,
                        "best path score is negative at the contig end (reference would emit its default node)");
     M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
-    cx->cns_pos.ensure(M + 2);
-    cx->cns_base.ensure(M + 2);
-    cx->cns_cls.ensure(M + 2);
-    cx->lq_kind.ensure(M + 2);
-    cx->lq_next.ensure(M + 2);
-    cx->lq_nothead.ensure(M + 2);
-    cx->rflag.ensure(M + 2);
-    cx->rstart.ensure(M + 2);
-    cx->rend.ensure(M + 2);
-    cx->ridx.ensure(M + 2);
-    cx->tmp.ensure(prim_temp_bytes((size_t)M + 2));
-    {
-        EventTimer t(cx, "dp_backtrack");
-        launch_bt_write(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
-                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->eoff.p, cx->cns_pos.p, cx->cns_base.p,
-                        cx->cns_cls.p, cx->lq_nothead.p);
-    }
-    uint32_t n_raw = 0;
-    {
-        EventTimer t(cx, "lq_regions");
-        launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M, cx->lq_kind.p, cx->lq_next.p,
-                       cx->lq_nothead.p, cx->rflag.p, cx->rstart.p, cx->rend.p);
-        exclusive_total(cx, cx->rflag.p, cx->ridx.p, M);
-        cx->raw_start.ensure(M + 2);
-        cx->raw_end.ensure(M + 2);
-        launch_scatter_regions(s, cx->rflag.p, cx->ridx.p, cx->rstart.p, cx->rend.p, M, cx->raw_start.p,
-                               cx->raw_end.p, cx->scal.p + S_NRAW);
-        n_raw = fetch_scal(cx)[S_NRAW];
-        n_reg = 0;
-        if (n_raw) {
-            cx->headflag.ensure(n_raw + 2);
-            cx->hidx.ensure(n_raw + 2);
-            cx->lq_start.ensure(n_raw + 2);
-            cx->lq_end.ensure(n_raw + 2);
-            launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, n_raw, cx->headflag.p);
-            exclusive_total(cx, cx->headflag.p, cx->hidx.p, n_raw);
-            launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, n_raw, cx->headflag.p,
-                                  cx->hidx.p, cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
-            n_reg = fetch_scal(cx)[S_NREG];
-        }
-    }
+    n_reg = sc[S_NRAW] ? sc[S_NREG] : 0;
 }
 
 // candidate extraction + first-yak scoring; fills the host RegionSet
@@ -658,7 +660,6 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
         launch_cand_score(s, cx->yaks[0].dev(), cx->cand_seq_off.p, cx->cand_seq.p, cx->cand_kmer.p, NC,
                           min_kmer_count, cx->kscore.p, cx->long_list.p, cx->scal.p + S_NLONG);
     }
-    HIPCHK(hipStreamSynchronize(s));
     pc.n_reg = n_reg;
     pc.NC = NC;
     pc.SB = SB;
@@ -730,7 +731,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             trace_graph(cx, c, (int)pass, n_nodes);
             {
                 WallTimer w(cx, "wall_cns_lq");
-                consensus_and_regions(cx, c, n_runs, M, n_reg);
+                consensus_and_regions(cx, c, n_runs, T, M, n_reg);
             }
             if (cx->trace) {
                 trace_cns(cx, (int)pass, "cns_raw", fetch_cns(cx, M));

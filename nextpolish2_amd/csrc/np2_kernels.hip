@@ -747,6 +747,10 @@ __global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], b = run_end[r];
     const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
+    if (entry == 0xFFFFFFFFu) { // negative best score at the contig end: the host reports it after its next read-back
+        emit[a] = 0;
+        return;
+    }
     emit[a] = bt_walk<false>(g, a, b, entry, nbesti, n0_besti, path_begin, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
@@ -805,10 +809,13 @@ __global__ void k_bt_write(const uint32_t *__restrict__ run_start, const uint32_
 // ------------------------------------------------------------------------------------------
 enum : uint8_t { LQK_LINK = 0, LQK_CLOSE = 1, LQK_RESET = 2, LQK_OPEN = 3 };
 
+// (the consensus length M lives on the device; launches cover the host-side bound M_cap)
 __global__ void k_lq_scan(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
-                          const uint8_t *__restrict__ cns_cls, uint32_t M, uint8_t *__restrict__ lq_kind,
-                          uint32_t *__restrict__ lq_next, uint8_t *__restrict__ lq_nothead) {
+                          const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p,
+                          uint8_t *__restrict__ lq_kind, uint32_t *__restrict__ lq_next,
+                          uint8_t *__restrict__ lq_nothead) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = *M_p;
     if (i >= M || cns_cls[i] != CLS_LQ) return;
     const uint32_t p = M - 1 - i;
     uint8_t kind = LQK_OPEN;
@@ -838,13 +845,15 @@ __global__ void k_lq_scan(const uint32_t *__restrict__ cns_pos, const uint8_t *_
 }
 
 __global__ void k_lq_region(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
-                            const uint8_t *__restrict__ cns_cls, uint32_t M, const uint8_t *__restrict__ lq_kind,
-                            const uint32_t *__restrict__ lq_next, const uint8_t *__restrict__ lq_nothead,
-                            uint32_t *__restrict__ rflag, uint32_t *__restrict__ rstart,
-                            uint32_t *__restrict__ rend) {
+                            const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p, uint32_t M_cap,
+                            const uint8_t *__restrict__ lq_kind, const uint32_t *__restrict__ lq_next,
+                            const uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ rflag,
+                            uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = *M_p;
+    if (p >= M_cap) return;
+    rflag[p] = 0; // also behind M: the flag scan runs over the bound
     if (p >= M) return;
-    rflag[p] = 0;
     if (cns_cls[M - 1 - p] != CLS_LQ || lq_nothead[p]) return;
     uint32_t q = p;
     while (lq_kind[q] == LQK_LINK) q = lq_next[q];
@@ -863,10 +872,11 @@ __global__ void k_lq_region(const uint32_t *__restrict__ cns_pos, const uint8_t 
 }
 
 __global__ void k_scatter_regions(const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ ridx,
-                                  const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ rend, uint32_t M,
-                                  uint32_t *__restrict__ raw_start, uint32_t *__restrict__ raw_end,
-                                  uint32_t *__restrict__ n_raw) {
+                                  const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ rend,
+                                  const uint32_t *__restrict__ M_p, uint32_t *__restrict__ raw_start,
+                                  uint32_t *__restrict__ raw_end, uint32_t *__restrict__ n_raw) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = *M_p;
     if (p >= M) return;
     if (rflag[p]) {
         raw_start[ridx[p]] = rstart[p];
@@ -878,24 +888,24 @@ __global__ void k_scatter_regions(const uint32_t *__restrict__ rflag, const uint
 // merge rule main.rs:1613-1615: region j merges into j-1 iff end_j >= start_{j-1}
 __global__ void k_lq_merge_flag(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
                                 const uint32_t *__restrict__ n_raw, uint32_t *__restrict__ headflag) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *n_raw) return;
-    headflag[j] = !(j >= 1 && raw_end[j] >= raw_start[j - 1]);
+    const uint32_t n = *n_raw; // on the device: grid-stride over whatever it turns out to be
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        headflag[j] = !(j >= 1 && raw_end[j] >= raw_start[j - 1]);
 }
 __global__ void k_lq_merge_write(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
                                  const uint32_t *__restrict__ n_raw, const uint32_t *__restrict__ headflag,
                                  const uint32_t *__restrict__ hidx, uint32_t *__restrict__ lq_start,
                                  uint32_t *__restrict__ lq_end, uint32_t *__restrict__ n_reg) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *n_raw;
-    if (j >= n) return;
-    if (headflag[j]) {
-        uint32_t l = j;
-        while (l + 1 < n && !headflag[l + 1]) ++l;
-        lq_end[hidx[j]] = raw_end[j];
-        lq_start[hidx[j]] = raw_start[l];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        if (headflag[j]) {
+            uint32_t l = j;
+            while (l + 1 < n && !headflag[l + 1]) ++l;
+            lq_end[hidx[j]] = raw_end[j];
+            lq_start[hidx[j]] = raw_start[l];
+        }
+        if (j == n - 1) *n_reg = hidx[j] + headflag[j];
     }
-    if (j == n - 1) *n_reg = hidx[j] + headflag[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1150,28 +1160,28 @@ void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
                            n0_besti, best_idx, emit, eoff, cns_pos, cns_base, cns_cls, lq_nothead);
 }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
-                    uint32_t M, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag,
-                    uint32_t *rstart, uint32_t *rend) {
-    hipLaunchKernelGGL(k_lq_scan, grid1(M), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M, lq_kind, lq_next,
+                    const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
+                    uint32_t *rflag, uint32_t *rstart, uint32_t *rend) {
+    hipLaunchKernelGGL(k_lq_scan, grid1(M_cap), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M_p, lq_kind, lq_next,
                        lq_nothead);
-    hipLaunchKernelGGL(k_lq_region, grid1(M), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M, lq_kind, lq_next,
+    hipLaunchKernelGGL(k_lq_region, grid1(M_cap), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M_p, M_cap, lq_kind, lq_next,
                        lq_nothead, rflag, rstart, rend);
 }
 void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
-                            const uint32_t *rend, uint32_t M, uint32_t *raw_start, uint32_t *raw_end,
-                            uint32_t *n_raw) {
-    hipLaunchKernelGGL(k_scatter_regions, grid1(M), dim3(256), 0, s, rflag, ridx, rstart, rend, M, raw_start, raw_end,
+                            const uint32_t *rend, const uint32_t *M_p, uint32_t M_cap, uint32_t *raw_start,
+                            uint32_t *raw_end, uint32_t *n_raw) {
+    hipLaunchKernelGGL(k_scatter_regions, grid1(M_cap), dim3(256), 0, s, rflag, ridx, rstart, rend, M_p, raw_start, raw_end,
                        n_raw);
 }
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
-                          uint32_t max_raw, uint32_t *headflag) {
-    hipLaunchKernelGGL(k_lq_merge_flag, grid1(max_raw), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag);
+                          uint32_t *headflag) {
+    hipLaunchKernelGGL(k_lq_merge_flag, dim3(256), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag);
 }
 void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
-                           uint32_t max_raw, const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start,
-                           uint32_t *lq_end, uint32_t *n_reg) {
-    hipLaunchKernelGGL(k_lq_merge_write, grid1(max_raw), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag, hidx,
-                       lq_start, lq_end, n_reg);
+                           const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start, uint32_t *lq_end,
+                           uint32_t *n_reg) {
+    hipLaunchKernelGGL(k_lq_merge_write, dim3(256), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag, hidx, lq_start,
+                       lq_end, n_reg);
 }
 void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                    uint32_t n_reg, int32_t *mval) {

@@ -85,16 +85,18 @@ void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
                      const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
                      uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
-void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls, uint32_t M,
-                    uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *rflag, uint32_t *rstart,
-                    uint32_t *rend);
+// LQ regions: the consensus length is read from the device (M_p); M_cap is the host-side bound the launches cover
+void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
+                    const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
+                    uint32_t *rflag, uint32_t *rstart, uint32_t *rend);
 void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
-                            const uint32_t *rend, uint32_t M, uint32_t *raw_start, uint32_t *raw_end, uint32_t *n_raw);
+                            const uint32_t *rend, const uint32_t *M_p, uint32_t M_cap, uint32_t *raw_start,
+                            uint32_t *raw_end, uint32_t *n_raw);
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
-                          uint32_t max_raw, uint32_t *headflag);
+                          uint32_t *headflag);
 void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
-                           uint32_t max_raw, const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start,
-                           uint32_t *lq_end, uint32_t *n_reg);
+                           const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start, uint32_t *lq_end,
+                           uint32_t *n_reg);
 void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                    uint32_t n_reg, int32_t *mval);
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
@@ -173,6 +175,7 @@ struct RechPtrs {
 void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, uint8_t *reg_lable, uint8_t *grp,
                        uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
                        uint32_t *err);
+void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out);
 void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval);
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, int32_t *wout);

@@ -704,6 +704,36 @@ __global__ void k_rech_relabel(uint8_t *__restrict__ reg_lable, uint32_t n_reg) 
     reg_lable[g] = (l & LB_TEMP) ? (uint8_t)(l ^ LB_TEMP) : (uint8_t)(l ^ LB_RECH);
 }
 
+// reads that vote in some HETE region (graph keys) / reads flagged invalid: when both are zero the phasing pass has
+// nothing to decide and the host skips the vote read-back altogether
+__global__ __launch_bounds__(1024) void k_vote_counts(const uint32_t *__restrict__ first_reg, const uint8_t *__restrict__ bad,
+                                                      uint32_t R, uint32_t *__restrict__ out) {
+    __shared__ uint32_t sk[16], sb[16];
+    uint32_t nk = 0, nb = 0;
+    for (uint32_t r = threadIdx.x; r < R; r += 1024) {
+        nk += first_reg[r] != 0xFFFFFFFFu ? 1u : 0u;
+        nb += bad[r] ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nk += __shfl_xor(nk, o);
+        nb += __shfl_xor(nb, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sk[threadIdx.x >> 6] = nk;
+        sb[threadIdx.x >> 6] = nb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < 16; ++i) {
+            a += sk[i];
+            b += sb[i];
+        }
+        out[0] = a;
+        out[1] = b;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -715,6 +745,9 @@ void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool u
     if (rt.n_reg)
         hipLaunchKernelGGL(k_vote_phase, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, asref ? 1u : 0u,
                            use_all ? 1u : 0u, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
+}
+void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out) {
+    hipLaunchKernelGGL(k_vote_counts, dim3(1), dim3(1024), 0, s, first_reg, bad, R, out);
 }
 void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval) {

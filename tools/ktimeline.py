@@ -11,7 +11,7 @@ def short(n):
     m = re.search(r"wrapped_(\w+?)_config", n)
     if m: return "prim:" + m.group(1)
     return n[:28]
-marks = [i for i, r in enumerate(rows) if "k_chunk_count" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_diff_reads" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) // 2
 a, b = marks[k], marks[k + 1]
 t0 = int(rows[a]["Start_Timestamp"])
