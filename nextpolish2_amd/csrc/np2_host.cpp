@@ -295,6 +295,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
     hipStream_t s = cx->stream;
     const uint32_t n_reg = pc.n_reg, ksize = cx->yaks[yak_idx].k;
     uint32_t n_rech = 0, n_groups = 0, n_jobs = 0;
+    uint64_t blob_bound = 0; // upper bound of the recheck strings' bytes (sizes their buffer without a read-back)
     {
         // RECH region list, chain groups and job offsets: two look-back passes, then one read-back
         EventTimer t(cx, "recheck");
@@ -303,11 +304,13 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         cx->rech_joboff.ensure(n_reg + 2);
         const uint32_t nb = (n_reg + 255) / 256;
         launch_rech_list(s, next_lookback(cx, nb), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
-                         cx->scal.p + S_ERR);
+                         (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         launch_rech_groups(s, next_lookback(cx, nb), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
-                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->rech_groups.p, cx->rech_joboff.p,
-                           cx->scal.p + S_NGROUPS, cx->scal.p + S_M0, cx->scal.p + S_ERR);
+                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->cand_off.p, cx->keep_list.p,
+                           cx->cand_seq_off.p, cx->rech_groups.p, cx->rech_joboff.p, cx->scal.p + S_NGROUPS,
+                           cx->scal.p + S_M0, (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         std::vector<uint32_t> sc = fetch_scal(cx);
+        blob_bound = (uint64_t)sc[S_M1] | ((uint64_t)sc[S_M2] << 32);
         check_region_err(cx, sc[S_ERR]);
         n_rech = sc[S_NRECH];
         n_groups = sc[S_NGROUPS];
@@ -325,8 +328,9 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
             cx->tmp.ensure(prim_temp_bytes((size_t)n_jobs + 2));
             launch_rech_job_len(s, rp, n_jobs, cx->job_len.p);
             exclusive_total_n(cx, cx->job_len.p, cx->job_off32.p, n_jobs);
-            const uint32_t blob_bytes = fetch_scal(cx, cx->scal.p + S_M0, cx->job_off32.p + n_jobs)[S_M0];
-            cx->sstr.ensure((size_t)blob_bytes + 64);
+            if (blob_bound >= 0xFFFFFFF0ull) // 32-bit string offsets: let the exact total decide
+                blob_bound = fetch_scal(cx, cx->scal.p + S_M0, cx->job_off32.p + n_jobs)[S_M0];
+            cx->sstr.ensure((size_t)blob_bound + 64);
             launch_rech_job_build(s, rp, n_jobs, cx->job_off32.p, cx->soff.p, cx->sstr.p);
             launch_score_strings(s, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n_jobs, min_kmer_count,
                                  cx->sscore.p);

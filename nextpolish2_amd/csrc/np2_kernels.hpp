@@ -197,12 +197,13 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base);
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
-                      uint32_t *n_rech, uint32_t *err);
+                      uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err);
 // groups of chained RECH regions + per-group job offsets (job_off[n_groups] = *n_jobs); max_rech = launch bound
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, void *groups, uint32_t *job_off, uint32_t *n_groups,
-                        uint32_t *n_jobs, uint32_t *err);
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *cand_off, const uint32_t *keep_list,
+                        const uint32_t *seq_off, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
+                        unsigned long long *blob_bound, uint32_t *err);
 size_t rech_group_bytes();
 void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len);
 void launch_rech_job_build(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, const uint32_t *soff32, uint64_t *soff64,

@@ -474,8 +474,9 @@ __global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t
 // RECH regions in left -> right order (reverse region index), compacted with a look-back across blocks
 __global__ __launch_bounds__(256) void k_rech_list(Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
                                                    uint32_t n_reg, uint32_t *__restrict__ rech, uint32_t *__restrict__ n_rech,
-                                                   uint32_t *__restrict__ err) {
+                                                   unsigned long long *__restrict__ blob_bound, uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *blob_bound = 0; // accumulated by k_rech_groups, the next kernel
     const uint32_t bid = lb_block_id(lb, sh);
     const uint32_t rr = bid * 256 + threadIdx.x;
     const uint32_t flag = (rr < n_reg && (reg_lable[n_reg - 1 - rr] & LB_RECH)) ? 1u : 0u;
@@ -503,10 +504,16 @@ __global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blo
                                                      const uint32_t *__restrict__ lq_start,
                                                      const uint32_t *__restrict__ lq_end,
                                                      const uint32_t *__restrict__ keep_n, uint32_t ksize,
+                                                     const uint32_t *__restrict__ cand_off,
+                                                     const uint32_t *__restrict__ keep_list,
+                                                     const uint32_t *__restrict__ seq_off,
                                                      RechGroup *__restrict__ groups, uint32_t *__restrict__ job_off,
                                                      uint32_t *__restrict__ n_groups, uint32_t *__restrict__ n_jobs,
+                                                     unsigned long long *__restrict__ blob_bound,
                                                      uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
+    __shared__ unsigned long long s_bound[4];
+    unsigned long long bound = 0; // upper bound of the bytes of this group's recheck strings
     const uint32_t bid = lb_block_id(lb, sh);
     const uint32_t e = bid * 256 + threadIdx.x;
     const uint32_t n_rech = *n_rech_p, M = *M_p;
@@ -562,7 +569,22 @@ __global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blo
         }
         jobs32 = (uint32_t)jobs;
         G.njobs = jobs32;
+        // every string of the group: both flanks + per region its longest kept candidate + the stretches in between
+        uint64_t len = (uint64_t)(G.el - G.sl) + (G.er - G.sr);
+        for (uint32_t x = 0; x < n; ++x) {
+            const uint32_t g = rech[e + x], c0 = cand_off[g];
+            uint32_t mx = 0;
+            for (uint32_t t = 0; t < G.lens[x]; ++t) {
+                const uint32_t c = keep_list[c0 + t];
+                mx = max(mx, seq_off[c + 1] - seq_off[c]);
+            }
+            len += mx;
+            if (x + 1 < n) len += G.be[x] - G.bs[x];
+        }
+        bound = (unsigned long long)jobs32 * len;
     }
+    for (int o = 32; o > 0; o >>= 1) bound += __shfl_xor(bound, o);
+    if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = bound;
     uint32_t nh, nj, pre_h, pre_j;
     const uint32_t lh = block_excl_scan<OpAdd, 4>(head ? 1u : 0u, sh, nh);
     const uint32_t lj = block_excl_scan<OpAdd, 4>(jobs32, sh, nj);
@@ -571,6 +593,10 @@ __global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blo
     if (head) {
         groups[pre_h + lh] = G;
         job_off[pre_h + lh] = pre_j + lj;
+    }
+    if (threadIdx.x == 0) { // (the block scans above contain barriers: s_bound is complete)
+        const unsigned long long b = s_bound[0] + s_bound[1] + s_bound[2] + s_bound[3];
+        if (b) atomicAdd(blob_bound, b);
     }
     if (bid == n_blocks - 1 && threadIdx.x == 0) {
         *n_groups = pre_h + nh;
@@ -795,17 +821,19 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                            lq_start, seed_cand, seq_off, seq, out_pos, out_base);
 }
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
-                      uint32_t *n_rech, uint32_t *err) {
+                      uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err) {
     const uint32_t nb = (n_reg + 255) / 256;
-    hipLaunchKernelGGL(k_rech_list, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, n_reg, rech, n_rech, err);
+    hipLaunchKernelGGL(k_rech_list, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, n_reg, rech, n_rech, blob_bound, err);
 }
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, void *groups, uint32_t *job_off, uint32_t *n_groups,
-                        uint32_t *n_jobs, uint32_t *err) {
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *cand_off, const uint32_t *keep_list,
+                        const uint32_t *seq_off, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
+                        unsigned long long *blob_bound, uint32_t *err) {
     const uint32_t nb = (max_rech + 255) / 256;
     hipLaunchKernelGGL(k_rech_groups, dim3(nb), dim3(256), 0, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end,
-                       keep_n, ksize, (RechGroup *)groups, job_off, n_groups, n_jobs, err);
+                       keep_n, ksize, cand_off, keep_list, seq_off, (RechGroup *)groups, job_off, n_groups, n_jobs,
+                       blob_bound, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
 static RechCtx mk_rech(const RechPtrs &p) {
