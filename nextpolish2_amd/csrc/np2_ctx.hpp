@@ -223,7 +223,7 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_COUNT = 24 };
+            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 24 };
 
 static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it
 

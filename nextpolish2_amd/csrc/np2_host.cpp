@@ -44,6 +44,15 @@ void trace_cns(np2_ctx *cx, int pass, const std::string &tag, const Cns &c) {
 struct PassCounts {
     uint32_t n_reg = 0, NC = 0, SB = 0, M = 0;
     uint32_t grow = 0; // upper bound of the consensus growth of one splice round (sum of the longest kept candidates)
+    // NC / SB / grow are produced on the device (scal S_NC / S_SB / S_GROW) and picked up by the next read-back that
+    // happens anyway; until then buffers and launches use the bounds below
+    bool known = false;
+    uint32_t NC_cap = 0; // 60 candidates per region
+    uint32_t SB_cap = 0; // candidate strings are disjoint pieces of the reads: at most the pileup's columns
+    void resolve(const std::vector<uint32_t> &sc) {
+        NC = sc[S_NC], SB = sc[S_SB], grow = sc[S_GROW];
+        known = true;
+    }
 };
 
 RegionTables region_tables(np2_ctx *cx, uint32_t n_reg) {
@@ -120,7 +129,7 @@ void check_region_err(np2_ctx *cx, uint32_t e) {
 }
 
 // phasing pass on the GPU tables: mark_hete (main.rs:916-946), pair edges (948-1002); Louvain on the host
-std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCounts &pc, bool asref, bool use_all,
+std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool use_all,
                                        int pass) {
     hipStream_t s = cx->stream;
     const uint32_t R = c->R, n_reg = pc.n_reg;
@@ -129,7 +138,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
     {
         EventTimer t(cx, "vote_phase");
         cx->reg_lable.ensure(n_reg + 2);
-        cx->grp.ensure(pc.NC + 2);
+        cx->grp.ensure((size_t)pc.NC_cap + 2);
         cx->ecount.ensure(n_reg + 2);
         cx->eoff.ensure(std::max<size_t>(n_reg + 2, (size_t)c->L + 2));
         // per-read vote outputs live in one buffer: [first_reg u32 x RP][ref_w i32 x RP][ref_seen u8 x RP][bad u8 x RP]
@@ -148,6 +157,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, const PassCou
     {
         std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
         check_region_err(cx, sc[S_ERR]);
+        pc.resolve(sc);
         NE = sc[S_M0];
         if (!cx->trace && sc[S_M1] == 0 && sc[S_M2] == 0) { // no read votes anywhere: nobody can lose
             if (NE) throw Np2Error(NP2_E_DEVICE, "internal: pair edges without voting reads");
@@ -613,7 +623,9 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     hipStream_t s = cx->stream;
     const uint32_t R = c->R;
     REFPANIC_IF(cx->yaks.empty(), "index out of bounds: opt.yak[0]");
-    uint32_t NC = 0, SB = 0;
+    if ((uint64_t)n_reg * LQSEQ_MAX_CAN_COUNT >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many LQ regions");
+    const uint32_t NC_cap = n_reg * LQSEQ_MAX_CAN_COUNT;
+    const uint32_t SB_cap = (uint32_t)std::min<uint64_t>(c->n_cols + 64, 0xFFFFFFF0ull);
     cx->mval.ensure(R + 2);
     cx->smin.ensure(R + 2);
     cx->pj.ensure(R + 2);
@@ -625,9 +637,15 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->blk_coff.ensure((size_t)n_reg / 4 + 2);
     cx->blk_soff.ensure((size_t)n_reg / 4 + 2);
     cx->cand_off.ensure(n_reg + 2);
-    cx->kept_read.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
-    cx->kept_len.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
-    cx->kept_col.ensure((size_t)n_reg * LQSEQ_MAX_CAN_COUNT + 2);
+    cx->kept_read.ensure((size_t)NC_cap + 2);
+    cx->kept_len.ensure((size_t)NC_cap + 2);
+    cx->kept_col.ensure((size_t)NC_cap + 2);
+    cx->cand_order.ensure((size_t)NC_cap + 2);
+    cx->cand_kmer.ensure((size_t)NC_cap + 2);
+    cx->cand_seq_off.ensure((size_t)NC_cap + 2);
+    cx->cand_seq.ensure((size_t)SB_cap + 64);
+    cx->kscore.ensure((size_t)NC_cap + 2);
+    cx->long_list.ensure((size_t)NC_cap + 2);
     CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
                 cx->pcount.p, cx->alive.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles,     cx->yaks[0].k};
     {
@@ -641,32 +659,21 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                               cx->reg_bytes.p, cx->blk_sum.p);
         launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
-                            cx->scal.p + S_M1, cx->scal.p + S_M2, cx->scal.p + S_M3);
-        std::vector<uint32_t> m2 = fetch_scal(cx);
-        NC = m2[S_M1];
-        SB = m2[S_M2];
-        pc.grow = m2[S_M3];
-    }
-    cx->cand_order.ensure(NC + 2);
-    cx->cand_kmer.ensure(NC + 2);
-    cx->cand_seq_off.ensure(NC + 2);
-    cx->cand_seq.ensure((size_t)SB + 64);
-    cx->kscore.ensure(NC + 2);
-    {
-        EventTimer t(cx, "candidates");
+                            cx->scal.p + S_NC, cx->scal.p + S_SB, cx->scal.p + S_GROW);
         launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
-                            cx->reg_bytes.p, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p, NC + 1, SB,
-                            cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
+                            cx->reg_bytes.p, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p, NC_cap + 1,
+                            SB_cap, cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
     }
     {
         EventTimer t(cx, "kmer_score");
-        cx->long_list.ensure(NC + 2);
-        launch_cand_score(s, cx->yaks[0].dev(), cx->cand_seq_off.p, cx->cand_seq.p, cx->cand_kmer.p, NC,
-                          min_kmer_count, cx->kscore.p, cx->long_list.p, cx->scal.p + S_NLONG);
+        launch_cand_score(s, cx->yaks[0].dev(), cx->cand_seq_off.p, cx->cand_seq.p, cx->cand_kmer.p, cx->scal.p + S_NC,
+                          NC_cap, min_kmer_count, cx->kscore.p, cx->long_list.p, cx->scal.p + S_NLONG);
     }
     pc.n_reg = n_reg;
-    pc.NC = NC;
-    pc.SB = SB;
+    pc.NC_cap = NC_cap;
+    pc.SB_cap = SB_cap;
+    pc.known = false;
+    if (cx->trace) pc.resolve(fetch_scal(cx));
     trace_region_tables(cx, pass, "cand", pc, false);
 }
 
@@ -756,16 +763,18 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             pc.M = M;
             WallTimer w(cx, "wall_extract");
             extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
-        } else if (pc.NC) { // undo mark_hete's kscore edits of the previous (identical) pass
-            HIPCHK(hipMemcpyAsync(cx->kscore.p, cx->kscore_saved.p, (size_t)pc.NC * 2, hipMemcpyDeviceToDevice, s));
+        } else if (pc.NC_cap) { // undo mark_hete's kscore edits of the previous (identical) pass
+            HIPCHK(hipMemcpyAsync(cx->kscore.p, cx->kscore_saved.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2,
+                                  hipMemcpyDeviceToDevice, s));
         }
         reuse = false;
         if (!out_cns) {
             WallTimer w(cx, "wall_vote");
             const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
-            if (may_reuse && pc.NC) {
-                cx->kscore_saved.ensure(pc.NC + 2);
-                HIPCHK(hipMemcpyAsync(cx->kscore_saved.p, cx->kscore.p, (size_t)pc.NC * 2, hipMemcpyDeviceToDevice, s));
+            if (may_reuse && pc.NC_cap) {
+                cx->kscore_saved.ensure((size_t)pc.NC_cap + 2);
+                HIPCHK(hipMemcpyAsync(cx->kscore_saved.p, cx->kscore.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2,
+                                      hipMemcpyDeviceToDevice, s));
             }
             std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
             trace_put(cx, (int)pass, "invalid_ids", losers);
@@ -784,8 +793,9 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             cx->reg_lable.ensure(n_reg + 2);
             cx->seed_cand.ensure(n_reg + 2);
             cx->keep_n.ensure(n_reg + 2);
-            cx->keep_list.ensure(pc.NC + 2);
-            cx->keep_ks.ensure(pc.NC + 2);
+            if (!pc.known) pc.resolve(fetch_scal(cx)); // the splice rounds need the growth bound
+            cx->keep_list.ensure((size_t)pc.NC_cap + 2);
+            cx->keep_ks.ensure((size_t)pc.NC_cap + 2);
             {
                 EventTimer t(cx, "seed");
                 launch_seed(s, rt, o->max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,

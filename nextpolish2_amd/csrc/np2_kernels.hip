@@ -1057,10 +1057,11 @@ __global__ void k_score_strings(YakDev y, const uint8_t *__restrict__ strs, cons
 // retrieve_kmer_count (main.rs:740-778): len > k -> min over the candidate's own k-mers (rare: one wave
 // each, second kernel), else the pre-hashed first k-mer (one lookup, thread per candidate), else 0
 __global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint64_t *__restrict__ cand_kmer,
-                             uint32_t n_cand, uint16_t min_count, uint16_t *__restrict__ kscore,
-                             uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long) {
+                             const uint32_t *__restrict__ n_cand_p, uint16_t min_count,
+                             uint16_t *__restrict__ kscore, uint32_t *__restrict__ long_list,
+                             uint32_t *__restrict__ n_long) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
+    if (c >= *n_cand_p) return; // the candidate count lives on the device; the launch covers its bound
     const uint32_t len = cand_seq_off[c + 1] - cand_seq_off[c];
     uint16_t sc = 0;
     if (len > y.k) {
@@ -1210,10 +1211,10 @@ void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, c
     if (n) hipLaunchKernelGGL(k_score_strings, grid1(n * 64), dim3(256), 0, s, y, strs, off, n, min_count, out);
 }
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
-                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
-                       uint32_t *long_list, uint32_t *n_long) {
-    if (!n_cand) return;
-    hipLaunchKernelGGL(k_cand_score, grid1(n_cand), dim3(256), 0, s, y, cand_seq_off, cand_kmer, n_cand, min_count,
+                       const uint64_t *cand_kmer, const uint32_t *n_cand_p, uint32_t cand_cap, uint16_t min_count,
+                       uint16_t *kscore, uint32_t *long_list, uint32_t *n_long) {
+    if (!cand_cap) return;
+    hipLaunchKernelGGL(k_cand_score, grid1(cand_cap), dim3(256), 0, s, y, cand_seq_off, cand_kmer, n_cand_p, min_count,
                        kscore, long_list, n_long);
     hipLaunchKernelGGL(k_cand_score_long, dim3(1024), dim3(256), 0, s, y, cand_seq_off, cand_seq, long_list, n_long,
                        min_count, kscore);

@@ -105,8 +105,8 @@ void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint6
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
                           uint16_t min_count, uint16_t *out);
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
-                       const uint64_t *cand_kmer, uint32_t n_cand, uint16_t min_count, uint16_t *kscore,
-                       uint32_t *long_list, uint32_t *n_long);
+                       const uint64_t *cand_kmer, const uint32_t *n_cand_p, uint32_t cand_cap, uint16_t min_count,
+                       uint16_t *kscore, uint32_t *long_list, uint32_t *n_long);
 
 
 // ---- np2_cand.hip: region-major candidate extraction, single-block scans -----------------------------
