@@ -618,7 +618,9 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
                     s_slo[i][t] = (uint32_t)(uint64_t)score;
                     s_shi[i][t] = (uint32_t)((uint64_t)score >> 32);
                 }
-                nscore[o] = score;
+                // scores are only read back from memory past the LDS cache and, at the contig's last position, by
+                // k_pick_best: skip the scattered 8-byte store otherwise
+                if (i >= DP_NR || p + 1 == L) nscore[o] = score;
                 nbesti[o] = besti;
             } else {
                 s0_cur = score;
