@@ -153,34 +153,71 @@ struct NibReader {
     }
 };
 
-// Write the candidate string (its length is known) and the hashed first k-mer (main.rs:1478-1521), starting at the
-// candidate's first column `col` whose t_pos is `t`.
+// Write the candidate string and the hashed first k-mer (main.rs:1478-1521), starting at the candidate's first
+// column `col` whose t_pos is `t`.  The string is the first `len` non-gap columns from `col` (cand_measure counted
+// exactly those), so emission needs no t_pos tracking and goes 8 columns per step: nibbles -> byte selectors ->
+// ASCII through v_perm_b32 with the 8-entry code table in two registers, dword stores.  Only words holding a gap code
+// or the string's end take the per-column path.  The k-mer needs the first k non-gap codes and the decode limit.
 __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t g, uint32_t col, uint32_t t,
-                           uint8_t *__restrict__ seq_out, uint64_t *kmer_out) {
-    NibReader nr{cx.nib + rd.nib_off, 0, 0xFFFFFFFFu};
-    const uint32_t end = cx.lq_end[g];
-    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
-    const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
-    uint64_t fw = 0, rv = 0, l = 0;
-    uint32_t len = 0;
-    for (uint32_t c = col; c < rd.n_cols; ++c) {
-        const uint8_t nb = nr.get(c);
-        if (c != col && !(nb & 8)) ++t;
-        const uint8_t q = nb & 7;
-        if (q != 4) {
-            if (t <= end) seq_out[len++] = code_to_ascii(q);
-            if (l < ksize) { // N/M codes are not filtered here (main.rs:1488-1492)
+                           uint32_t len, uint8_t *__restrict__ seq_out, uint64_t *kmer_out) {
+    const uint8_t *base = cx.nib + rd.nib_off;
+    // ---- first k-mer -------------------------------------------------------------------------------------------------
+    {
+        NibReader nr{base, 0, 0xFFFFFFFFu};
+        const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
+        const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
+        uint64_t fw = 0, rv = 0, l = 0;
+        for (uint32_t c = col; c < rd.n_cols && l < ksize; ++c) {
+            const uint8_t nb = nr.get(c);
+            if (c != col && !(nb & 8)) ++t;
+            const uint8_t q = nb & 7;
+            if (q != 4) { // N/M codes are not filtered here (main.rs:1488-1492)
                 fw = ((fw << 2) | (uint64_t)q) & mask;
                 rv = (rv >> 2) | ((3ULL ^ (uint64_t)q) << shift);
                 ++l;
             }
-            if (t > end && l >= ksize) break;
+            if (t > limit) break; // this column was the last one decoded
         }
-        if (t > limit) break; // this column was the last one decoded
+        uint64_t km = INVALID_KMER;
+        if (l >= ksize) km = yak_hash64(fw < rv ? fw : rv, mask);
+        *kmer_out = km;
     }
-    uint64_t km = INVALID_KMER;
-    if (l >= ksize) km = yak_hash64(fw < rv ? fw : rv, mask);
-    *kmer_out = km;
+    // ---- the string ----------------------------------------------------------------------------------------------------
+    const uint32_t LUT_LO = 0x54474341u, LUT_HI = 0x004D4E2Du; // code_to_ascii: A C G T | - N M
+    uint32_t o = 0;
+    for (uint32_t wi = col >> 3; o < len; ++wi) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t *>(base + ((size_t)wi << 2));
+        uint32_t w = (((raw & 0x0F0F0F0Fu) << 4) | ((raw >> 4) & 0x0F0F0F0Fu)) & 0x77777777u; // column j at bits 4j
+        uint32_t nc = 8;
+        if (wi == (col >> 3)) { // drop the columns before the start
+            const uint32_t skip = col & 7;
+            w >>= 4 * skip;
+            nc = 8 - skip;
+        }
+        const uint32_t x = w ^ 0x44444444u;
+        const uint32_t nongap = (x | (x >> 1) | (x >> 2)) & 0x11111111u;
+        const uint32_t full = nc == 8 ? 0x11111111u : ((1u << (4 * nc)) - 1u) & 0x11111111u;
+        if ((nongap & full) == full && len - o >= nc) { // no gap code among the nc columns, all of them wanted
+            const uint32_t lo4 = w & 0xFFFFu, hi4 = w >> 16;
+            uint32_t s0 = (lo4 | (lo4 << 8)) & 0x00FF00FFu, s1 = (hi4 | (hi4 << 8)) & 0x00FF00FFu;
+            s0 = (s0 | (s0 << 4)) & 0x0F0F0F0Fu;
+            s1 = (s1 | (s1 << 4)) & 0x0F0F0F0Fu;
+            const uint32_t a0 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s0), a1 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s1);
+            if (nc == 8) {
+                __builtin_memcpy(seq_out + o, &a0, 4);
+                __builtin_memcpy(seq_out + o + 4, &a1, 4);
+            } else {
+                const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32);
+                for (uint32_t k = 0; k < nc; ++k) seq_out[o + k] = (uint8_t)(a >> (8 * k));
+            }
+            o += nc;
+        } else {
+            for (uint32_t k = 0; k < nc && o < len; ++k) {
+                const uint32_t q = (w >> (4 * k)) & 7u;
+                if (q != 4) seq_out[o++] = code_to_ascii((uint8_t)q);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -208,7 +245,7 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
-                                                        uint32_t *__restrict__ blk_sum) {
+                                                        uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
     // blk_sum: per block of 4 regions, three arrays of gridDim.x entries: candidates, bytes, longest kept strings
     __shared__ uint32_t s_w[3][4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -250,6 +287,7 @@ __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_r
         if (live) {
             reg_ncand[g] = kept;
             reg_bytes[g] = bytes;
+            reg_maxlen[g] = mx;
         }
         s_w[0][wv] = kept;
         s_w[1][wv] = bytes;
@@ -322,7 +360,7 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
     const np2_read_t rd = cx.reads[r];
     cand_order[ci] = r;
     cand_seq_off[ci] = so;
-    cand_write(cx, r, rd, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), cand_seq + so, &cand_kmer[ci]);
+    cand_write(cx, r, rd, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -345,10 +383,11 @@ static CandCtx mk_cand(const CandPtrs &c) {
                    c.pcount, c.alive, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
 }
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *blk_sum) {
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
+                           uint32_t *blk_sum) {
     if (n_reg)
         hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, reg_bytes, blk_sum);
+                           kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
                          uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow) {

@@ -184,7 +184,7 @@ struct np2_ctx {
     DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
         lq_end;
     DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
-        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, blk_sum, blk_coff, blk_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
+        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, reg_maxlen, blk_sum, blk_coff, blk_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
     DevBuf<uint64_t> cand_kmer;
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;

@@ -316,8 +316,8 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         launch_rech_list(s, next_lookback(cx, nb), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
                          (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         launch_rech_groups(s, next_lookback(cx, nb), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
-                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->cand_off.p, cx->keep_list.p,
-                           cx->cand_seq_off.p, cx->rech_groups.p, cx->rech_joboff.p, cx->scal.p + S_NGROUPS,
+                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->reg_maxlen.p, cx->rech_groups.p,
+                           cx->rech_joboff.p, cx->scal.p + S_NGROUPS,
                            cx->scal.p + S_M0, (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         std::vector<uint32_t> sc = fetch_scal(cx);
         blob_bound = (uint64_t)sc[S_M1] | ((uint64_t)sc[S_M2] << 32);
@@ -633,6 +633,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->reg_ncand.ensure(n_reg + 2);
     cx->reg_bytes.ensure(n_reg + 2);
     cx->reg_soff.ensure(n_reg + 2);
+    cx->reg_maxlen.ensure(n_reg + 2);
     cx->blk_sum.ensure(3 * ((size_t)n_reg / 4 + 2));
     cx->blk_coff.ensure((size_t)n_reg / 4 + 2);
     cx->blk_soff.ensure((size_t)n_reg / 4 + 2);
@@ -657,7 +658,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
                           cx->pcount.p);
         // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
-                              cx->reg_bytes.p, cx->blk_sum.p);
+                              cx->reg_bytes.p, cx->reg_maxlen.p, cx->blk_sum.p);
         launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
                             cx->scal.p + S_NC, cx->scal.p + S_SB, cx->scal.p + S_GROW);
         launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,

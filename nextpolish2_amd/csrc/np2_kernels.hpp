@@ -117,7 +117,8 @@ void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, ui
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
-                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *blk_sum);
+                           uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
+                           uint32_t *blk_sum);
 // blk_sum: 3 x ceil(n_reg / 4) sums per block of 4 regions (candidates, bytes, longest kept string)
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
                          uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow);
@@ -201,8 +202,7 @@ void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_labl
 // groups of chained RECH regions + per-group job offsets (job_off[n_groups] = *n_jobs); max_rech = launch bound
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *cand_off, const uint32_t *keep_list,
-                        const uint32_t *seq_off, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
                         unsigned long long *blob_bound, uint32_t *err);
 size_t rech_group_bytes();
 void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len);

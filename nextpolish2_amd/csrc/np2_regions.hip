@@ -46,10 +46,14 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
     WaveStats w;
     // classes by (length, 64-bit hash); every lane then verifies byte-wise against its class head.  A hash
     // collision (never observed) falls back to the exact O(n^2) comparison, so the result is always exact.
+    // (8 bytes per step through unaligned 64-bit loads; the candidate pool is padded, the tail is masked)
     uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
     if (lane < n)
-        for (uint32_t t = 0; t < len; ++t) {
-            h ^= seq[so + t];
+        for (uint32_t t = 0; t < len; t += 8) {
+            uint64_t x;
+            __builtin_memcpy(&x, seq + so + t, 8);
+            if (len - t < 8) x &= (1ull << (8 * (len - t))) - 1ull;
+            h ^= x;
             h *= 0x100000001B3ull;
             h ^= h >> 29;
         }
@@ -65,11 +69,17 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
         const uint32_t sh = __shfl(so, head), lh = __shfl(len, head);
         ok = lh == len;
         if (ok && head != lane)
-            for (uint32_t t = 0; t < len; ++t)
-                if (seq[so + t] != seq[sh + t]) {
+            for (uint32_t t = 0; t < len; t += 8) {
+                uint64_t x, y;
+                __builtin_memcpy(&x, seq + so + t, 8);
+                __builtin_memcpy(&y, seq + sh + t, 8);
+                x ^= y;
+                if (len - t < 8) x &= (1ull << (8 * (len - t))) - 1ull;
+                if (x) {
                     ok = false;
                     break;
                 }
+            }
     } else {
         (void)__shfl(so, 0);
         (void)__shfl(len, 0);
@@ -504,9 +514,7 @@ __global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blo
                                                      const uint32_t *__restrict__ lq_start,
                                                      const uint32_t *__restrict__ lq_end,
                                                      const uint32_t *__restrict__ keep_n, uint32_t ksize,
-                                                     const uint32_t *__restrict__ cand_off,
-                                                     const uint32_t *__restrict__ keep_list,
-                                                     const uint32_t *__restrict__ seq_off,
+                                                     const uint32_t *__restrict__ reg_maxlen,
                                                      RechGroup *__restrict__ groups, uint32_t *__restrict__ job_off,
                                                      uint32_t *__restrict__ n_groups, uint32_t *__restrict__ n_jobs,
                                                      unsigned long long *__restrict__ blob_bound,
@@ -572,13 +580,7 @@ __global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blo
         // every string of the group: both flanks + per region its longest kept candidate + the stretches in between
         uint64_t len = (uint64_t)(G.el - G.sl) + (G.er - G.sr);
         for (uint32_t x = 0; x < n; ++x) {
-            const uint32_t g = rech[e + x], c0 = cand_off[g];
-            uint32_t mx = 0;
-            for (uint32_t t = 0; t < G.lens[x]; ++t) {
-                const uint32_t c = keep_list[c0 + t];
-                mx = max(mx, seq_off[c + 1] - seq_off[c]);
-            }
-            len += mx;
+            len += reg_maxlen[rech[e + x]]; // longest candidate of the region (the kept ones are a subset)
             if (x + 1 < n) len += G.be[x] - G.bs[x];
         }
         bound = (unsigned long long)jobs32 * len;
@@ -827,13 +829,11 @@ void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_labl
 }
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *cand_off, const uint32_t *keep_list,
-                        const uint32_t *seq_off, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
-                        unsigned long long *blob_bound, uint32_t *err) {
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *groups, uint32_t *job_off,
+                        uint32_t *n_groups, uint32_t *n_jobs, unsigned long long *blob_bound, uint32_t *err) {
     const uint32_t nb = (max_rech + 255) / 256;
     hipLaunchKernelGGL(k_rech_groups, dim3(nb), dim3(256), 0, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end,
-                       keep_n, ksize, cand_off, keep_list, seq_off, (RechGroup *)groups, job_off, n_groups, n_jobs,
-                       blob_bound, err);
+                       keep_n, ksize, reg_maxlen, (RechGroup *)groups, job_off, n_groups, n_jobs, blob_bound, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
 static RechCtx mk_rech(const RechPtrs &p) {
