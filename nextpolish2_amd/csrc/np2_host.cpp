@@ -208,18 +208,17 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
     phase::Graph data;
     data.reserve_ids(R);
     for (auto &k : keys) data.add_key(k.second);
-    for (uint32_t i = 0; i < NU; ++i) {
-        const uint32_t a = (uint32_t)(ukey[i] >> 32), b = (uint32_t)ukey[i];
-        const float w = (float)uw[i];
-        if (!data.keys.has(a) || !data.keys.has(b)) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
-        data.adj[a].emplace_back(b, w);
-        data.adj[b].emplace_back(a, w);
-    }
+    if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(ukey[i] >> 32); }, [&](uint64_t i) { return (uint32_t)ukey[i]; },
+                        [&](uint64_t i) { return (float)uw[i]; }))
+        throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
         if (badv[r]) bad.push_back(r);
     if (!use_all) { // data.retain(..) + per-row retain (main.rs:1004-1010): erase order = bucket order
-        data.keys.keep_if([&](uint32_t k, phase::Nil &) { return !badv[k]; });
+        data.keys.keep_if([&](uint32_t k, phase::Nil &) {
+            if (badv[k]) data.is_key[k] = 0;
+            return !badv[k];
+        });
         for (uint32_t r = 0; r < R; ++r) {
             auto &row = data.adj[r];
             if (badv[r]) {
@@ -1130,11 +1129,9 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
     phase::Graph g;
     g.reserve_ids(mx + 1);
     for (uint32_t i = 0; i < n_keys; ++i) g.add_key(keys[i]);
-    for (uint64_t i = 0; i < n_pairs; ++i) {
-        if (!g.keys.has(pa[i]) || !g.keys.has(pb[i])) return NP2_E_ARG;
-        g.adj[pa[i]].emplace_back(pb[i], pw[i]);
-        g.adj[pb[i]].emplace_back(pa[i], pw[i]);
-    }
+    if (!g.add_edges(n_pairs, [&](uint64_t i) { return pa[i]; }, [&](uint64_t i) { return pb[i]; },
+                     [&](uint64_t i) { return pw[i]; }))
+        return NP2_E_ARG;
     std::vector<float> rw(mx + 1, 0.f);
     std::vector<uint8_t> rs(mx + 1, 0);
     for (uint32_t i = 0; i < n_ref; ++i) {

@@ -8,6 +8,9 @@
 // 16, fxhash 0.2.1): SwissOrderMap below reproduces that *order* (insert / entry-insert /
 // erase / retain / grow / in-place rehash), not the container's performance.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
@@ -248,12 +251,40 @@ typedef SwissOrderMap<Nil> OrderSet;
 struct Graph {
     OrderSet keys;
     std::vector<std::vector<std::pair<uint32_t, float>>> adj; // indexed by node id; symmetric
+    std::vector<uint8_t> is_key; // dense mirror of `keys` (membership tests without hashing)
     void reserve_ids(uint32_t n) {
-        if (n > adj.size()) adj.resize(n);
+        if (n > adj.size()) {
+            adj.resize(n);
+            is_key.resize(n, 0);
+        }
     }
     void add_key(uint32_t k) { // Entry::or_insert_with on a vacant key
         reserve_ids(k + 1);
-        if (!keys.has(k)) keys.put_vacant(k, Nil{});
+        if (!is_key[k]) {
+            keys.put_vacant(k, Nil{});
+            is_key[k] = 1;
+        }
+    }
+    bool has_key(uint32_t k) const { return k < is_key.size() && is_key[k]; }
+    // undirected weighted edges in bulk: exact row sizes first, then one fill (no vector regrowth).
+    // Returns false if an endpoint is not a key.
+    template <class GetA, class GetB, class GetW> bool add_edges(uint64_t n, GetA ga, GetB gb, GetW gw) {
+        std::vector<uint32_t> deg(adj.size(), 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t a = ga(i), b = gb(i);
+            if (!has_key(a) || !has_key(b)) return false;
+            ++deg[a];
+            ++deg[b];
+        }
+        for (size_t v = 0; v < adj.size(); ++v)
+            if (deg[v]) adj[v].reserve(adj[v].size() + deg[v]);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t a = ga(i), b = gb(i);
+            const float w = gw(i);
+            adj[a].emplace_back(b, w);
+            adj[b].emplace_back(a, w);
+        }
+        return true;
     }
 };
 
@@ -274,24 +305,48 @@ class SignedLouvain {
         node_id_.resize(n);
         node_w_.assign(n, 0.f);
         members_.resize(n);
+        cnt_.assign(n, 0);
+        oplog_.assign(n, {});
         for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68
-            comm_.put(v, OrderSet::single(v, Nil{}));
+            comm_keys_.put(v, Nil{});
             node_id_[v] = v;
             members_[v] = {v};
+            cnt_[v] = 1;
         }
     }
     // returns false if the reference's weight<0 assertion (louvain.rs:234-237) would fire
     bool run(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts, std::vector<Community> &out) {
-        while (local_moving()) aggregate();
-        return collect(conflicts, out);
+        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            double t0 = now();
+            const bool moved = local_moving();
+            double t1 = now();
+            if (prof) fprintf(stderr, "  local_moving %.2f ms (nodes %zu)\n", t1 - t0, g_.keys.size());
+            if (!moved) break;
+            aggregate();
+            if (prof) fprintf(stderr, "  aggregate %.2f ms\n", now() - t1);
+        }
+        double t2 = now();
+        const bool ok = collect(conflicts, out);
+        if (prof) fprintf(stderr, "  collect %.2f ms\n", now() - t2);
+        return ok;
     }
 
   private:
+    // The reference keeps communities as HashMap<u32, HashSet<u32>>.  Only two things about those containers are
+    // observable: the iteration order of the outer map (fixed by the order its keys were inserted in: no key is
+    // inserted or removed while nodes move) and, for a community that is declustered, the iteration order of its
+    // member set (fixed by the sequence of inserts / removes it saw).  So the outer map is kept as a key-only order
+    // set, membership as node_id_ + counters, and every community logs its member operations; a member set is only
+    // rebuilt (by replaying the log into the emulated hash set) when a community has to be declustered.
     Graph g_;
-    SwissOrderMap<OrderSet> comm_;
+    OrderSet comm_keys_;
     std::vector<uint32_t> node_id_; // community of each (possibly aggregated) node
     std::vector<float> node_w_;     // weight carried by an aggregated node
     std::vector<std::vector<uint32_t>> members_;
+    std::vector<uint32_t> cnt_;                 // members per community
+    std::vector<std::vector<int64_t>> oplog_;   // per community: +(v + 1) insert, -(v + 1) remove, in order
 
     bool local_moving() { // first_stage, louvain.rs:72-117
         // The reference re-evaluates every node in every sweep until a sweep moves nothing.  A node's decision is a
@@ -327,9 +382,12 @@ class SignedLouvain {
                         (gains[i].second == gains[best].second && gains[i].first < gains[best].first))
                         best = i;
                 if (gains[best].second > 0.f && gains[best].first != cur) {
-                    node_id_[v] = gains[best].first;
-                    comm_.get(gains[best].first)->put(v, Nil{});
-                    comm_.get(cur)->take(v, nullptr);
+                    const uint32_t to = gains[best].first;
+                    node_id_[v] = to;
+                    ++cnt_[to];
+                    --cnt_[cur];
+                    oplog_[to].push_back((int64_t)v + 1);
+                    oplog_[cur].push_back(-((int64_t)v + 1));
                     for (const auto &e : g_.adj[v]) dirty[e.first] = 1; // their gains changed
                     again = true;
                     moved_any = true;
@@ -339,50 +397,70 @@ class SignedLouvain {
         return moved_any;
     }
 
+    // member lists of all communities (CSR over the current nodes; order inside a community is not observable)
+    void member_lists(std::vector<uint32_t> &off, std::vector<uint32_t> &list) const {
+        const size_t n = node_id_.size();
+        off.assign(n + 1, 0);
+        const std::vector<uint32_t> keys = g_.keys.key_list();
+        for (uint32_t v : keys) ++off[node_id_[v] + 1];
+        for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
+        list.resize(keys.size());
+        std::vector<uint32_t> cur(off.begin(), off.end() - 1);
+        for (uint32_t v : keys) list[cur[node_id_[v]]++] = v;
+    }
     // weight of a community = carried weights + half of every directed internal edge (louvain.rs:124-134)
-    float internal_weight(uint32_t cid, const OrderSet &set, std::vector<uint32_t> &mem) const {
+    float internal_weight(uint32_t cid, const uint32_t *mb, const uint32_t *me, std::vector<uint32_t> &mem) const {
         float w = 0.f;
-        set.each([&](uint32_t v, const Nil &) {
+        for (const uint32_t *p = mb; p != me; ++p) {
+            const uint32_t v = *p;
             mem.insert(mem.end(), members_[v].begin(), members_[v].end());
             w += node_w_[v];
             for (const auto &e : g_.adj[v])
                 if (node_id_[e.first] == cid) w += e.second / 2.0f;
-        });
+        }
         return w;
+    }
+    // iteration order of a community's member set: replay its history into the emulated hash set
+    std::vector<uint32_t> member_order(uint32_t id) const {
+        OrderSet set = OrderSet::single(id, Nil{}); // every community starts as {its own node}
+        for (int64_t op : oplog_[id]) {
+            if (op > 0) set.put((uint32_t)(op - 1), Nil{});
+            else set.take((uint32_t)(-op - 1), nullptr);
+        }
+        return set.key_list();
     }
 
     void aggregate() { // second_stage, louvain.rs:119-195
-        SwissOrderMap<OrderSet> ncomm;
+        OrderSet ncomm;
         std::unordered_map<uint32_t, Community> nnode;
         std::vector<uint32_t> split;
-        comm_.each([&](uint32_t id, const OrderSet &set) {
-            if (set.empty()) return;
+        std::vector<uint32_t> moff, mlist;
+        member_lists(moff, mlist);
+        // new community key of every current node (members of split communities get their own key)
+        std::vector<uint32_t> key_of(node_id_.size(), 0xFFFFFFFFu);
+        comm_keys_.each([&](uint32_t id, const Nil &) {
+            if (cnt_[id] == 0) return;
             Community c;
             c.id = id;
-            c.weight = internal_weight(id, set, c.members);
+            c.weight = internal_weight(id, mlist.data() + moff[id], mlist.data() + moff[id + 1], c.members);
+            for (uint32_t i = moff[id]; i < moff[id + 1]; ++i) key_of[mlist[i]] = id;
             if (c.weight < 0.f) {
                 split.push_back(id);
             } else {
-                ncomm.put(id, OrderSet::single(id, Nil{}));
+                ncomm.put(id, Nil{});
                 nnode[id] = std::move(c);
             }
         });
-        // new community key of every current node (members of split communities get their own key)
-        std::vector<uint32_t> key_of(node_id_.size(), 0xFFFFFFFFu);
-        comm_.each([&](uint32_t id, const OrderSet &set) { set.each([&](uint32_t v, const Nil &) { key_of[v] = id; }); });
         for (uint32_t id : split) { // decluster negative communities, louvain.rs:145-165
-            OrderSet set;
-            comm_.take(id, &set);
-            for (uint32_t v : set.key_list()) {
+            for (uint32_t v : member_order(id)) {
                 uint32_t nid = v;
                 while (ncomm.has(nid) || nnode.count(nid)) ++nid;
-                ncomm.put(nid, OrderSet::single(nid, Nil{}));
+                ncomm.put(nid, Nil{});
                 Community c;
                 c.id = nid;
                 c.weight = node_w_[v];
                 c.members = members_[v];
                 nnode[nid] = std::move(c);
-                comm_.put(nid, OrderSet::single(v, Nil{}));
                 key_of[v] = nid;
             }
         }
@@ -392,15 +470,22 @@ class SignedLouvain {
         for (const auto &kv : nnode) max_id = std::max(max_id, kv.first);
         Graph ng;
         ng.reserve_ids(max_id + 1);
-        std::vector<std::vector<uint32_t>> of_key(max_id + 1);
+        std::vector<uint32_t> koff((size_t)max_id + 2, 0), klist;
         for (uint32_t v = 0; v < key_of.size(); ++v)
-            if (key_of[v] != 0xFFFFFFFFu) of_key[key_of[v]].push_back(v);
+            if (key_of[v] != 0xFFFFFFFFu) ++koff[key_of[v] + 1];
+        for (size_t i = 0; i + 1 < koff.size(); ++i) koff[i + 1] += koff[i];
+        klist.resize(koff.back());
+        {
+            std::vector<uint32_t> cur(koff.begin(), koff.end() - 1);
+            for (uint32_t v = 0; v < key_of.size(); ++v)
+                if (key_of[v] != 0xFFFFFFFFu) klist[cur[key_of[v]]++] = v;
+        }
         std::vector<std::pair<uint32_t, float>> local;
         for (uint32_t a = 0; a <= max_id; ++a) {
-            if (of_key[a].empty()) continue;
+            if (koff[a] == koff[a + 1]) continue;
             local.clear();
-            for (uint32_t v : of_key[a])
-                for (const auto &e : g_.adj[v]) {
+            for (uint32_t i = koff[a]; i < koff[a + 1]; ++i)
+                for (const auto &e : g_.adj[klist[i]]) {
                     const uint32_t b = key_of[e.first];
                     if (b == a) continue;
                     bool hit = false;
@@ -419,14 +504,17 @@ class SignedLouvain {
                 }
         }
         g_ = std::move(ng);
-        comm_ = std::move(ncomm);
+        comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);
         node_w_.assign(max_id + 1, 0.f);
         members_.assign(max_id + 1, {});
+        cnt_.assign(max_id + 1, 0);
+        oplog_.assign(max_id + 1, {});
         for (auto &kv : nnode) {
             node_id_[kv.first] = kv.first;
             node_w_[kv.first] = kv.second.weight;
             members_[kv.first] = std::move(kv.second.members);
+            cnt_[kv.first] = 1;
         }
         g_.reserve_ids(max_id + 1);
     }
@@ -434,11 +522,13 @@ class SignedLouvain {
     bool collect(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts,
                  std::vector<Community> &out) { // get_communities, louvain.rs:197-245
         out.clear();
-        comm_.each([&](uint32_t id, const OrderSet &set) {
-            if (set.empty()) return;
+        std::vector<uint32_t> moff, mlist;
+        member_lists(moff, mlist);
+        comm_keys_.each([&](uint32_t id, const Nil &) {
+            if (cnt_[id] == 0) return;
             Community c;
             c.id = id;
-            c.weight = internal_weight(id, set, c.members);
+            c.weight = internal_weight(id, mlist.data() + moff[id], mlist.data() + moff[id + 1], c.members);
             out.push_back(std::move(c));
         });
         // conflicts between final communities: sum of the weights between their members (must be < 0)
