@@ -205,12 +205,22 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
         if (first_reg[r] != 0xFFFFFFFFu) keys.emplace_back(first_reg[r], r);
     std::sort(keys.begin(), keys.end());
     const double t_host0 = now_ms();
+    const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+    double t_mark = t_host0;
+    auto mark = [&](const char *what) {
+        if (prof) {
+            const double t = now_ms();
+            fprintf(stderr, "  vote host: %s %.2f ms\n", what, t - t_mark);
+            t_mark = t;
+        }
+    };
     phase::Graph data;
     data.reserve_ids(R);
     for (auto &k : keys) data.add_key(k.second);
     if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(ukey[i] >> 32); }, [&](uint64_t i) { return (uint32_t)ukey[i]; },
                         [&](uint64_t i) { return (float)uw[i]; }))
         throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
+    mark("keys + edges");
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
         if (badv[r]) bad.push_back(r);
@@ -219,16 +229,9 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
             if (badv[k]) data.is_key[k] = 0;
             return !badv[k];
         });
-        for (uint32_t r = 0; r < R; ++r) {
-            auto &row = data.adj[r];
-            if (badv[r]) {
-                row.clear();
-                continue;
-            }
-            row.erase(std::remove_if(row.begin(), row.end(), [&](const std::pair<uint32_t, float> &e) { return badv[e.first] != 0; }),
-                      row.end());
-        }
+        data.drop_nodes(badv);
     }
+    mark("retain");
     std::vector<float> ref_row(R, 0.f);
     std::vector<uint8_t> ref_have(R, 0);
     bool have_ref = false;
@@ -242,6 +245,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
     if (!phase::losing_reads(std::move(data), have_ref, ref_row, ref_have, losers))
         throw Np2Error(NP2_E_REFPANIC,
                        "reference would panic: the weight of two conflicting community is not less than 0");
+    mark("louvain + ranking");
     cx->timing.host.push_back({"wall_louvain", (float)(now_ms() - t_host0)});
     for (uint32_t b : bad) losers.push_back(b);
     std::sort(losers.begin(), losers.end());

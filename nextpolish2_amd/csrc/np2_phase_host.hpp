@@ -246,16 +246,27 @@ struct Nil {};
 typedef SwissOrderMap<Nil> OrderSet;
 
 // Signed weighted read graph.  `keys` reproduces the creation order of the outer keys of the reference's
-// HashMap<u32, HashMap<u32, f32>> (only that order is observable); the rows are plain adjacency vectors
+// HashMap<u32, HashMap<u32, f32>> (only that order is observable); the rows are CSR adjacency lists
 // (row iteration order only feeds exact small-integer f32 sums, so it is free).
 struct Graph {
+    typedef std::pair<uint32_t, float> Edge;
+    // row iteration helper
+    struct Row {
+        const Edge *b, *e;
+        const Edge *begin() const { return b; }
+        const Edge *end() const { return e; }
+        bool empty() const { return b == e; }
+    };
     OrderSet keys;
-    std::vector<std::vector<std::pair<uint32_t, float>>> adj; // indexed by node id; symmetric
     std::vector<uint8_t> is_key; // dense mirror of `keys` (membership tests without hashing)
+    std::vector<uint32_t> off;   // CSR row offsets, n_ids() + 1 entries
+    std::vector<Edge> edges;     // directed copies of the undirected edges, grouped by source node
+
+    uint32_t n_ids() const { return (uint32_t)is_key.size(); }
     void reserve_ids(uint32_t n) {
-        if (n > adj.size()) {
-            adj.resize(n);
+        if (n > is_key.size()) {
             is_key.resize(n, 0);
+            off.resize((size_t)n + 1, (uint32_t)edges.size());
         }
     }
     void add_key(uint32_t k) { // Entry::or_insert_with on a vacant key
@@ -266,26 +277,63 @@ struct Graph {
         }
     }
     bool has_key(uint32_t k) const { return k < is_key.size() && is_key[k]; }
-    // undirected weighted edges in bulk: exact row sizes first, then one fill (no vector regrowth).
-    // Returns false if an endpoint is not a key.
+    Row adj(uint32_t v) const { return Row{edges.data() + off[v], edges.data() + off[v + 1]}; }
+    // (Re)build the rows from a list of undirected weighted edges: count, prefix, fill.  Returns false if an
+    // endpoint is not a key.
     template <class GetA, class GetB, class GetW> bool add_edges(uint64_t n, GetA ga, GetB gb, GetW gw) {
-        std::vector<uint32_t> deg(adj.size(), 0);
+        const uint32_t N = n_ids();
+        std::vector<uint32_t> deg((size_t)N + 1, 0);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t a = ga(i), b = gb(i);
             if (!has_key(a) || !has_key(b)) return false;
-            ++deg[a];
-            ++deg[b];
+            ++deg[a + 1];
+            ++deg[b + 1];
         }
-        for (size_t v = 0; v < adj.size(); ++v)
-            if (deg[v]) adj[v].reserve(adj[v].size() + deg[v]);
+        for (uint32_t v = 0; v < N; ++v) deg[v + 1] += deg[v];
+        off = deg;
+        edges.resize(off[N]);
+        std::vector<uint32_t> cur(off.begin(), off.end() - 1);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t a = ga(i), b = gb(i);
             const float w = gw(i);
-            adj[a].emplace_back(b, w);
-            adj[b].emplace_back(a, w);
+            edges[cur[a]++] = Edge(b, w);
+            edges[cur[b]++] = Edge(a, w);
         }
         return true;
     }
+    // drop the rows of the flagged nodes and every edge pointing at one (row order is preserved)
+    void drop_nodes(const uint8_t *bad) {
+        const uint32_t N = n_ids();
+        size_t w = 0;
+        uint32_t row_begin = 0;
+        for (uint32_t v = 0; v < N; ++v) {
+            const uint32_t rb = off[v], re = off[v + 1];
+            off[v] = row_begin;
+            if (!bad[v])
+                for (uint32_t i = rb; i < re; ++i)
+                    if (!bad[edges[i].first]) edges[w++] = edges[i];
+            row_begin = (uint32_t)w;
+        }
+        off[N] = (uint32_t)w;
+        edges.resize(w);
+    }
+    // rows appended in increasing node order (used when the aggregated graph is built)
+    void begin_rows(uint32_t n) {
+        is_key.assign(n, 0);
+        off.assign((size_t)n + 1, 0);
+        edges.clear();
+        next_row_ = 0;
+    }
+    void append_row(uint32_t a, const std::vector<Edge> &row) { // a >= every earlier a
+        for (; next_row_ <= a; ++next_row_) off[next_row_] = (uint32_t)edges.size();
+        edges.insert(edges.end(), row.begin(), row.end());
+    }
+    void end_rows() {
+        for (; next_row_ < off.size(); ++next_row_) off[next_row_] = (uint32_t)edges.size();
+    }
+
+  private:
+    uint32_t next_row_ = 0;
 };
 
 struct Community {
@@ -301,7 +349,7 @@ struct Community {
 class SignedLouvain {
   public:
     explicit SignedLouvain(Graph g) : g_(std::move(g)) {
-        const uint32_t n = (uint32_t)g_.adj.size();
+        const uint32_t n = g_.n_ids();
         node_id_.resize(n);
         node_w_.assign(n, 0.f);
         members_.resize(n);
@@ -355,7 +403,7 @@ class SignedLouvain {
         bool moved_any = false;
         std::vector<uint32_t> visit = g_.keys.key_list();
         std::sort(visit.begin(), visit.end());
-        std::vector<uint8_t> dirty(g_.adj.size(), 1);
+        std::vector<uint8_t> dirty(g_.n_ids(), 1);
         std::vector<std::pair<uint32_t, float>> gains;
         for (bool again = true; again;) {
             again = false;
@@ -364,7 +412,7 @@ class SignedLouvain {
                 dirty[v] = 0;
                 const uint32_t cur = node_id_[v];
                 gains.clear();
-                for (const auto &e : g_.adj[v]) {
+                for (const auto &e : g_.adj(v)) {
                     const uint32_t c = node_id_[e.first];
                     bool hit = false;
                     for (auto &gn : gains)
@@ -388,7 +436,7 @@ class SignedLouvain {
                     --cnt_[cur];
                     oplog_[to].push_back((int64_t)v + 1);
                     oplog_[cur].push_back(-((int64_t)v + 1));
-                    for (const auto &e : g_.adj[v]) dirty[e.first] = 1; // their gains changed
+                    for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
                     again = true;
                     moved_any = true;
                 }
@@ -415,7 +463,7 @@ class SignedLouvain {
             const uint32_t v = *p;
             mem.insert(mem.end(), members_[v].begin(), members_[v].end());
             w += node_w_[v];
-            for (const auto &e : g_.adj[v])
+            for (const auto &e : g_.adj(v))
                 if (node_id_[e.first] == cid) w += e.second / 2.0f;
         }
         return w;
@@ -469,7 +517,7 @@ class SignedLouvain {
         uint32_t max_id = 0;
         for (const auto &kv : nnode) max_id = std::max(max_id, kv.first);
         Graph ng;
-        ng.reserve_ids(max_id + 1);
+        ng.begin_rows(max_id + 1);
         std::vector<uint32_t> koff((size_t)max_id + 2, 0), klist;
         for (uint32_t v = 0; v < key_of.size(); ++v)
             if (key_of[v] != 0xFFFFFFFFu) ++koff[key_of[v] + 1];
@@ -485,7 +533,7 @@ class SignedLouvain {
             if (koff[a] == koff[a + 1]) continue;
             local.clear();
             for (uint32_t i = koff[a]; i < koff[a + 1]; ++i)
-                for (const auto &e : g_.adj[klist[i]]) {
+                for (const auto &e : g_.adj(klist[i])) {
                     const uint32_t b = key_of[e.first];
                     if (b == a) continue;
                     bool hit = false;
@@ -497,12 +545,15 @@ class SignedLouvain {
                         }
                     if (!hit) local.emplace_back(b, e.second);
                 }
-            for (const auto &l : local)
-                if (l.second != 0.f) {
-                    ng.add_key(a);
-                    ng.adj[a].push_back(l);
-                }
+            // a node enters the aggregated graph with its first non-zero weight (rows hold only those)
+            local.erase(std::remove_if(local.begin(), local.end(), [](const Graph::Edge &l) { return l.second == 0.f; }),
+                        local.end());
+            if (!local.empty()) {
+                ng.add_key(a);
+                ng.append_row(a, local);
+            }
         }
+        ng.end_rows();
         g_ = std::move(ng);
         comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);
@@ -516,7 +567,6 @@ class SignedLouvain {
             members_[kv.first] = std::move(kv.second.members);
             cnt_[kv.first] = 1;
         }
-        g_.reserve_ids(max_id + 1);
     }
 
     bool collect(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts,
@@ -533,8 +583,8 @@ class SignedLouvain {
         });
         // conflicts between final communities: sum of the weights between their members (must be < 0)
         std::vector<std::vector<uint32_t>> of_comm;
-        for (uint32_t v = 0; v < g_.adj.size(); ++v) {
-            if (g_.adj[v].empty()) continue;
+        for (uint32_t v = 0; v < g_.n_ids(); ++v) {
+            if (g_.adj(v).empty()) continue;
             const uint32_t a = node_id_[v];
             if (a >= of_comm.size()) of_comm.resize(a + 1);
             of_comm[a].push_back(v);
@@ -545,7 +595,7 @@ class SignedLouvain {
             if (of_comm[a].empty()) continue;
             local.clear();
             for (uint32_t v : of_comm[a])
-                for (const auto &e : g_.adj[v]) {
+                for (const auto &e : g_.adj(v)) {
                     const uint32_t b = node_id_[e.first];
                     if (b <= a) continue;
                     bool hit = false;
