@@ -1,13 +1,16 @@
 """nextPolish2 command line mirror (src/utils/option.rs:45-292, src/main.rs:1689-1856).
 
 Usage: nextPolish2 [OPTIONS] <HiFi.map.bam> <genome.fa[.gz]> <short.read.yak>...
-Same positionals, flags, defaults and output format as the reference; contigs are polished on the GPU
-(one np2 context per process) and written in input order."""
+Same positionals, flags, defaults and output format as the reference; contigs are polished on the GPU and written in
+input order.  `-t N` runs up to N contigs concurrently (N np2 contexts on the same GPU, one host thread each, capped at
+4): the host-side phases of one contig (BAM parsing, the phasing vote's Louvain) overlap the GPU phases of another."""
 import argparse
 import os
 import resource
 import sys
+import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 from . import io as np2io
 from ._types import Opts
@@ -37,7 +40,7 @@ def build_parser():
     p.add_argument("-u", "--uppercase", action="store_true", help="output in uppercase sequences")
     p.add_argument("--out_pos", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("-k", "--min_kmer_count", type=int, default=5)
-    p.add_argument("-t", "--thread", type=int, default=1, help="accepted for compatibility (contigs run on the GPU)")
+    p.add_argument("-t", "--thread", type=int, default=1, help="contigs in flight on the GPU (1-4 np2 contexts)")
     p.add_argument("-i", "--iter_count", type=int, default=2)
     p.add_argument("-m", "--model", default="ref", type=str, help="ref|len (case-insensitive)")
     p.add_argument("-l", "--min_read_len", type=int, default=1000)
@@ -81,33 +84,48 @@ def main(argv=None):
                             min_map_fra=a.min_map_len - int(a.min_map_len), min_map_qual=a.min_map_qual,
                             max_clip_len=a.max_clip_len, use_supplementary=a.use_supplementary,
                             use_secondary=a.use_secondary)
-    pol = bam = None
+    n_workers = max(1, min(4, a.thread))
+    tls = threading.local()
+
+    def polish(name, seq):
+        """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
+        if getattr(tls, "pol", None) is None:
+            tls.pol = Polisher(yaks, device=a.device)
+            tls.bam = np2io.Bam(a.bam)
+        contig = np2io.contig_from_bam(tls.pol, tls.bam, name, seq, fopts)
+        try:
+            bases, pos = tls.pol.polish_resident(contig, opts, want_pos=a.out_pos)
+        finally:
+            contig.free()
+        b = bases.tobytes()
+        if a.uppercase:
+            b = b.upper()
+        if a.out_pos:
+            return b"".join(b"%s\t%c\t%d\n" % (name.encode(), b[i:i + 1], int(pos[i])) for i in range(len(b)))
+        return b">%s start:%d end:%d\n%s\n" % (name.encode(), pos[0], pos[1], b)
+
     try:
-        for name, seq in np2io.read_fasta(a.fa):
-            if len(seq) >= 0xFFFFFFFF:
-                raise SystemExit(f"{name} is too long!")
-            if len(seq) < a.min_ctg_len:  # pass-through (main.rs:1727-1730)
-                s = seq.upper() if a.uppercase else seq
-                if a.out_pos:
-                    out.write(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
+        with ThreadPoolExecutor(max_workers=n_workers) as pool:
+            pending = []  # records in input order: bytes or futures
+
+            def drain(keep):
+                while len(pending) > keep:
+                    rec = pending.pop(0)
+                    out.write(rec if isinstance(rec, bytes) else rec.result())
+
+            for name, seq in np2io.read_fasta(a.fa):
+                if len(seq) >= 0xFFFFFFFF:
+                    raise SystemExit(f"{name} is too long!")
+                if len(seq) < a.min_ctg_len:  # pass-through (main.rs:1727-1730)
+                    s = seq.upper() if a.uppercase else seq
+                    if a.out_pos:
+                        pending.append(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
+                    else:
+                        pending.append(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
                 else:
-                    out.write(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
-                continue
-            if pol is None:
-                pol = Polisher(yaks, device=a.device)
-                bam = np2io.Bam(a.bam)
-            contig = np2io.contig_from_bam(pol, bam, name, seq, fopts)
-            try:
-                bases, pos = pol.polish_resident(contig, opts, want_pos=a.out_pos)
-            finally:
-                contig.free()
-            b = bases.tobytes()
-            if a.uppercase:
-                b = b.upper()
-            if a.out_pos:
-                out.write(b"".join(b"%s\t%c\t%d\n" % (name.encode(), b[i:i + 1], int(pos[i])) for i in range(len(b))))
-            else:
-                out.write(b">%s start:%d end:%d\n%s\n" % (name.encode(), pos[0], pos[1], b))
+                    pending.append(pool.submit(polish, name, seq))
+                drain(2 * n_workers)  # bounded look-ahead: at most 2 x workers contigs held in memory
+            drain(0)
         out.flush()
     finally:
         if a.out is not None:

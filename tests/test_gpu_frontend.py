@@ -92,6 +92,13 @@ def test_contig_from_bam_and_cli_end_to_end(tmp_path):
                        capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr.decode()
     assert out.read_bytes() == exp
+    # -t 3: three np2 contexts on the same GPU, contigs in flight concurrently, output still in input order
+    out3 = tmp_path / "out3.fa"
+    r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-t", "3", "-L", "10000", "-o", str(out3),
+                        str(tmp_path / "m.bam"), str(tmp_path / "g.fa.gz"), str(tmp_path / "k31.yak"),
+                        str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    assert out3.read_bytes() == exp
     # API path
     pol = Polisher([y21, y31])
     bam = np2io.Bam(str(tmp_path / "m.bam"))

@@ -174,6 +174,15 @@ def test_long_insertion_overflows_a_tile():
     check_all_stages(pu, [yak_from_seqs([truth], 21, count=30)], Opts())
 
 
+def test_very_long_reads_span_many_chunks_and_blocks():
+    # reads of > 64 chunks (131 k columns): the dense pass sums the counts of a read's earlier chunks across several
+    # 64-wide windows of status words and across thread blocks
+    s = Synth(400000, depth=6, seed=91, read_len_mean=180000.0, read_len_sd=20000.0)
+    assert int(s.pileup.reads["n_cols"][1:].max()) > 70 * 2048
+    gb, _ = check_all_stages(s.pileup, [s.yak(21)], Opts())
+    assert gb.tobytes() == s.hap1
+
+
 def test_scaffold_gap_uncovered_stretch_and_soft_masking():
     # a contig with an N gap (reads stop before it and resume after it), an uncovered stretch (coverage 1: only the
     # contig's own row, main.rs:1586-1588 resets the LQ state there) and lower-case (soft-masked) letters
