@@ -485,7 +485,7 @@ __device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q,
 // One thread per dirty run.  A position costs two dependent memory rounds: {node_off, cov, contig codes} then the
 // packed node records; the nodes and scores of the current and the previous position live in LDS (element-major,
 // one 4-byte bank per thread: conflict free), nodes beyond DP_CACHE per position fall back to global memory.
-static constexpr uint32_t DP_NR = 16;    // node records of a run cached in LDS (per thread)
+static constexpr uint32_t DP_NR = 8;     // node records of a run cached in LDS (per thread)
 static constexpr uint32_t DP_BLOCK = 64;
 
 __device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1, uint8_t c0, uint16_t &bases,
