@@ -204,6 +204,7 @@ struct np2_ctx {
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list;
+    DevBuf<uint64_t> bt_path;  // recorded backtrack paths of the dirty runs (t_pos << 32 | base << 8 | class)
     DevBuf<uint64_t> chunk_st; // per chunk: launch epoch | non-insertion columns (k_diff_reads)
     uint32_t chunk_epoch = 0;
     DevBuf<uint32_t> tile_cur, tile_n, tile_scan, tile_scanb, tile_nn, tile_nr, tile_noff, tile_roff;

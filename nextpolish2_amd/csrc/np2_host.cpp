@@ -566,6 +566,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     cx->run_gain.ensure((size_t)n_runs + 2);
     cx->emit.ensure(L + 2);
     cx->eoff.ensure(L + 2);
+    cx->bt_path.ensure((size_t)M_cap + 2);
     cx->cns_pos.ensure(M_cap + 2);
     cx->cns_base.ensure(M_cap + 2);
     cx->cns_cls.ensure(M_cap + 2);
@@ -591,12 +592,11 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
                   cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
                   cx->scal.p + S_BEST, cx->run_gain.p, (const long long *)cx->tile_gain.p, (c->L + TILE - 1) >> TILE_SHIFT);
         launch_bt_count(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
-                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN);
+                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
         zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
-        launch_bt_write(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
-                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->eoff.p, cx->cns_pos.p, cx->cns_base.p,
-                        cx->cns_cls.p, cx->lq_nothead.p);
+        launch_bt_write(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p,
+                        cx->lq_nothead.p);
     }
     {
         EventTimer t(cx, "lq_regions");

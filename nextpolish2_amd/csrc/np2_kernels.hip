@@ -690,14 +690,13 @@ __global__ void k_pick_best(Graph g, const int64_t *__restrict__ nscore, const i
 // ------------------------------------------------------------------------------------------
 // K7: backtrack + consensus emission (generate_cns_from_best_score_lq, main.rs:1555-1637)
 // ------------------------------------------------------------------------------------------
-template <bool WRITE>
+// Walks right -> left from node (b, entry_idx) until it leaves [a, b]; returns the number of emitted bases and records
+// them, in walk order, as t_pos << 32 | base << 8 | class at path[0..n).  The run's slice of the path buffer starts at
+// a + node_off[a]: runs are disjoint in positions and in nodes, and a run emits at most one base per position plus one
+// per exception node, so the slices never overlap.
 __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t entry_idx,
                             const uint32_t *__restrict__ nbesti, const uint32_t *__restrict__ n0_besti,
-                            uint32_t *__restrict__ path_begin, uint32_t out_end, uint32_t *__restrict__ cns_pos,
-                            uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
-                            uint8_t *__restrict__ lq_nothead) {
-    // walks right -> left from node (b, entry_idx) until it leaves [a, b]; returns #emitted bases;
-    // with WRITE, bases are stored at out_end-1, out_end-2, ...
+                            uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
     uint32_t pos = b, idx = entry_idx, n = 0;
     for (;;) {
         uint16_t kb, kd;
@@ -717,20 +716,15 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
         AlignBase k1, k2, k3;
         node_decode(kb, kd, pos, k1, k2, k3);
         if (k3.q != 4) {
-            if (WRITE) {
-                const int64_t cov = g.cov[k3.t_pos];
-                // qv = count * 100 / coverage (integer division); qv < 95 <=> count * 100 < 95 * coverage
-                const bool lq = (int64_t)cnt * 100 < 95 * cov;
-                const uint32_t o = out_end - 1 - n;
-                cns_pos[o] = k3.t_pos;
-                cns_base[o] = code_to_ascii(k3.q);
-                cns_cls[o] = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
-                lq_nothead[o] = 0; // every consensus index is written exactly once: clears the LQ chain flags
-            }
+            const int64_t cov = g.cov[k3.t_pos];
+            // qv = count * 100 / coverage (integer division); qv < 95 <=> count * 100 < 95 * coverage
+            const bool lq = (int64_t)cnt * 100 < 95 * cov;
+            const uint32_t cls = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
+            path[n] = ((uint64_t)k3.t_pos << 32) | ((uint32_t)code_to_ascii(k3.q) << 8) | cls;
             ++n;
         }
         if (k2.is_head()) {
-            if (!WRITE && k3.t_pos > 0) atomicMax(path_begin, k3.t_pos);
+            if (k3.t_pos > 0) atomicMax(path_begin, k3.t_pos);
             break;
         }
         const uint32_t np_ = k2.t_pos;
@@ -744,7 +738,8 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
 __global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
                            const uint32_t *__restrict__ n_runs, Graph g, const uint32_t *__restrict__ nbesti,
                            const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
-                           uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin) {
+                           uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
+                           uint64_t *__restrict__ path) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], b = run_end[r];
@@ -753,7 +748,7 @@ __global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_
         emit[a] = 0;
         return;
     }
-    emit[a] = bt_walk<false>(g, a, b, entry, nbesti, n0_besti, path_begin, 0, nullptr, nullptr, nullptr, nullptr);
+    emit[a] = bt_walk(g, a, b, entry, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
 }
 
 // positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
@@ -776,33 +771,36 @@ __global__ void k_emit_fix(uint32_t *__restrict__ emit, const uint32_t *__restri
     }
 }
 
-__global__ void k_clean_write(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
-                              const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
-                              const uint32_t *__restrict__ eoff, uint32_t L, uint32_t *__restrict__ cns_pos,
-                              uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
-                              uint8_t *__restrict__ lq_nothead) {
+// Consensus write-out, one thread per contig position: a clean position emits the contig base; the first position of a
+// dirty run copies the run's recorded path (the walk went right -> left).  Output offsets grow with the position, so
+// neighbouring threads write neighbouring consensus indices.
+__global__ void k_cns_write(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
+                            const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
+                            const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
+                            uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
+                            uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= L) return;
-    if (node_off[p + 1] > node_off[p] || emit[p] == 0) return;
-    const uint32_t o = eoff[p];
-    lq_nothead[o] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
-    cns_pos[o] = p;
-    cns_base[o] = code_to_ascii(ref_code(refnib, p));
-    cns_cls[o] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
-}
-
-__global__ void k_bt_write(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
-                           const uint32_t *__restrict__ n_runs, Graph g, const uint32_t *__restrict__ nbesti,
-                           const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
-                           const uint32_t *__restrict__ emit, const uint32_t *__restrict__ eoff,
-                           uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
-                           uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *n_runs) return;
-    const uint32_t a = run_start[r], b = run_end[r];
-    if (emit[a] == 0) return;
-    const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
-    bt_walk<true>(g, a, b, entry, nbesti, n0_besti, nullptr, eoff[a] + emit[a], cns_pos, cns_base, cns_cls, lq_nothead);
+    const uint32_t e = emit[p];
+    if (e == 0) return;
+    const uint32_t o0 = eoff[p];
+    const uint32_t no = node_off[p];
+    if (node_off[p + 1] == no) { // clean position
+        lq_nothead[o0] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
+        cns_pos[o0] = p;
+        cns_base[o0] = code_to_ascii(ref_code(refnib, p));
+        cns_cls[o0] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
+        return;
+    }
+    const uint64_t *src = path + (size_t)p + no; // first position of a dirty run (only those carry a count)
+    for (uint32_t n = 0; n < e; ++n) {
+        const uint64_t w = src[n];
+        const uint32_t o = o0 + e - 1 - n;
+        cns_pos[o] = (uint32_t)(w >> 32);
+        cns_base[o] = (uint8_t)(w >> 8);
+        cns_cls[o] = (uint8_t)w;
+        lq_nothead[o] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1144,23 +1142,17 @@ void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, co
 }
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin) {
+                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
     Graph g = mk_graph(gp);
     if (max_runs)
         hipLaunchKernelGGL(k_bt_count, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
-                           n0_besti, best_idx, emit, path_begin);
+                           n0_besti, best_idx, emit, path_begin, path);
     hipLaunchKernelGGL(k_emit_fix, dim3(1), dim3(64), 0, s, emit, path_begin, gp.node_off, gp.L);
 }
-void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
-                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
-                     uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {
-    Graph g = mk_graph(gp);
-    hipLaunchKernelGGL(k_clean_write, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, gp.L,
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {
+    hipLaunchKernelGGL(k_cns_write, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L,
                        cns_pos, cns_base, cns_cls, lq_nothead);
-    if (max_runs)
-        hipLaunchKernelGGL(k_bt_write, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
-                           n0_besti, best_idx, emit, eoff, cns_pos, cns_base, cns_cls, lq_nothead);
 }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,

@@ -78,13 +78,13 @@ void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, co
                const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
                unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain, const long long *tile_gain,
                uint32_t n_tiles);
+// backtrack of every dirty run: emitted-base counts + the bases themselves, recorded in `path` (L + T entries)
 void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
                      const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin);
-void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
-                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, const uint32_t *emit, const uint32_t *eoff, uint32_t *cns_pos,
-                     uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
+                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
+// consensus write-out: clean positions + the recorded run paths, one thread per contig position
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
 // LQ regions: the consensus length is read from the device (M_p); M_cap is the host-side bound the launches cover
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
