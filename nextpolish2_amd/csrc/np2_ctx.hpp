@@ -179,12 +179,11 @@ struct np2_ctx {
     DevBuf<uint32_t> npos, ncount, nminr, nbesti, node_off, run_start, run_end, n0_besti, emit, eoff;
     DevBuf<uint16_t> nbases, ndelta;
     DevBuf<int64_t> nscore;
-    DevBuf<int32_t> covd, cov, mval, smin;
+    DevBuf<int32_t> cov, mval, smin;
     DevBuf<uint8_t> alive, cns_base, cns_cls, lq_kind, lq_nothead;
     DevBuf<uint32_t> cns_pos, lq_next, rflag, rstart, rend, ridx, raw_start, raw_end, headflag, hidx, lq_start,
         lq_end;
-    DevBuf<uint32_t> pj, pcount, poff, pair_region, pair_read, pair_region_s, pair_read_s, reg_npairs, reg_poff,
-        pair_len, pair_keep, keepflag, cand_idx, seq_off, reg_ncand, reg_bytes, reg_soff, reg_maxlen, blk_sum, blk_coff, blk_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
+    DevBuf<uint32_t> pj, pcount, reg_ncand, reg_bytes, reg_soff, reg_maxlen, blk_sum, blk_coff, blk_soff, kept_read, kept_len, kept_col, cand_off, cand_order, cand_seq_off, kill_ids;
     DevBuf<uint64_t> cand_kmer;
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;
@@ -196,11 +195,11 @@ struct np2_ctx {
     static constexpr size_t LB_MAX_BLOCKS = 1u << 20;
     DevBuf<uint32_t> mlen; // consensus length after each splice round of the final pass (device-side chain)
     // region logic
-    DevBuf<uint8_t> reg_lable, grp, ref_seen, bad, cns_base2, rech_groups;
-    DevBuf<uint32_t> ecount, first_reg, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
-        sp_idx_e, sp_flag, sp_slot, ap_g, ap_s, ap_e, rech, rech_head, rech_gslot, rech_njobs, rech_joboff, job_len,
+    DevBuf<uint8_t> reg_lable, grp, cns_base2, rech_groups;
+    DevBuf<uint32_t> ecount, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
+        sp_idx_e, ap_g, ap_s, ap_e, rech, rech_joboff, job_len,
         job_off32;
-    DevBuf<int32_t> ref_w, ew, ap_delta, ap_shift;
+    DevBuf<int32_t> ew, ap_delta, ap_shift;
     DevBuf<uint64_t> ekey, ekey_s;
     DevBuf<uint16_t> keep_ks;
     DevBuf<uint32_t> long_list;

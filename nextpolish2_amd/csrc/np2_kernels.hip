@@ -382,32 +382,8 @@ __global__ __launch_bounds__(256) void k_diff_reads(
     }
 }
 
-__global__ void k_flag_nonzero(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ flag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = in[i] != 0;
-}
-
-// coverage(p) = number of live reads spanning p (Msa::coverage, main.rs:232-241)
-__global__ void k_cov_delta(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
-                            int32_t *__restrict__ covd) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R || !alive[r]) return;
-    atomicAdd(&covd[reads[r].aln_t_s], 1);
-    atomicAdd(&covd[reads[r].aln_t_e + 1], -1);
-}
-
-// gather up to four device-resident counters into the scalar mailbox (so one D2H read serves a whole stage)
-__global__ void k_mail(uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
-                       const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
-                       uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3) {
-    if (threadIdx.x || blockIdx.x) return;
-    if (dst0) *dst0 = *src0;
-    if (dst1) *dst1 = *src1;
-    if (dst2) *dst2 = *src2;
-    if (dst3) *dst3 = *src3;
-}
-// the same gather, then the whole scalar block is posted to host-mapped memory followed by a sequence number the
-// host spins on (no copy command, no stream synchronisation)
+// gather up to four device-resident counters into scalar slots, then post the whole scalar block to host-mapped memory
+// followed by a sequence number the host spins on (no copy command, no stream synchronisation)
 __global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *__restrict__ mbox, uint32_t seq,
                        uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
                        const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
@@ -1106,10 +1082,6 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
                            (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap,
                            ovf_cnt, ckpt, chunk_st, epoch, err);
 }
-void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2,
-                 const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
-    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, d0, s0, d1, s1, d2, s2, d3, s3);
-}
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
                  const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,
                  const uint32_t *s3) {
@@ -1120,12 +1092,6 @@ void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8
 }
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) hipLaunchKernelGGL(k_kill_reads, grid1(n), dim3(256), 0, s, ids, n, alive);
-}
-void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag) {
-    if (n) hipLaunchKernelGGL(k_flag_nonzero, grid1(n), dim3(256), 0, s, in, n, flag);
-}
-void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd) {
-    hipLaunchKernelGGL(k_cov_delta, grid1(R), dim3(256), 0, s, reads, R, alive, covd);
 }
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec}; }
 

@@ -65,15 +65,11 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
                        const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *tile_cur,
                        uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *ovf_cnt,
                        uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err);
-void launch_mail(hipStream_t s, uint32_t *d0, const uint32_t *s0, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr,
-                 uint32_t *d2 = nullptr, const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0 = nullptr,
                  const uint32_t *s0 = nullptr, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
                  const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
-void launch_flag_nonzero(hipStream_t s, const uint32_t *in, uint32_t n, uint32_t *flag);
-void launch_cov_delta(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, int32_t *covd);
 void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
                const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
                unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain, const long long *tile_gain,
@@ -238,8 +234,6 @@ void launch_pack_ref(hipStream_t s, const uint8_t *ref, uint32_t L, uint8_t *dst
 // All take a caller-provided temp buffer; *_temp_bytes report the requirement for n elements.
 size_t prim_temp_bytes(size_t n);
 int prim_sort_pairs_u64_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
-                            const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
-int prim_sort_pairs_u32_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout,
                             const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
 int prim_exclusive_sum_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
 int prim_inclusive_sum_i32(hipStream_t s, void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, size_t n);

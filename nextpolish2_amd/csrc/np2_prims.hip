@@ -12,9 +12,6 @@ size_t prim_temp_bytes(size_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, n, 0, 64, (hipStream_t)0);
     best = b > best ? b : best;
-    (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                              (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0);
-    best = b > best ? b : best;
     (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n,
                             rocprim::plus<uint32_t>(), (hipStream_t)0);
     best = b > best ? b : best;
@@ -24,11 +21,6 @@ size_t prim_temp_bytes(size_t n) {
     return best + 256;
 }
 int prim_sort_pairs_u64_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
-                            const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
-    if (n == 0) return 0;
-    return (int)rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
-}
-int prim_sort_pairs_u32_u32(hipStream_t s, void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout,
                             const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
     if (n == 0) return 0;
     return (int)rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
