@@ -12,7 +12,7 @@ import numpy as np
 from ._types import Opts, Pileup, np2_opts_t, np2_read_t, np2_yak_t, yaks_array
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnp2_hip.so")
+LIB_PATH = os.environ.get("NP2_LIB_PATH") or os.path.join(_HERE, "libnp2_hip.so")  # override: A/B builds
 _LIB = None
 
 # every symbol include/np2.h declares
