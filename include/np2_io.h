@@ -25,7 +25,9 @@ typedef struct np2_front_opts {
     int16_t min_map_qual;      /* -q 1 */
     uint32_t max_clip_len;     /* -c 100 */
     uint8_t use_supplementary; /* -s */
-    uint8_t use_secondary;     /* -S (needs SEQ recovery, secondary.rs: not supported -> NP2_E_UNSUPPORTED) */
+    uint8_t use_secondary;     /* -S: np2_contig_from_bam recovers the SEQ of secondary records from the primary record
+                                * of the same read (secondary.rs; two passes over the BAM on first use);
+                                * np2_contig_from_records expects the caller to pass the recovered SEQ */
 } np2_front_opts_t;
 
 /* one alignment record, fields as in the BAM record (what rust-htslib's Record exposes, main.rs:1751-1797) */

@@ -6,6 +6,8 @@
 #include <zlib.h>
 
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 
 namespace {
 
@@ -42,9 +44,16 @@ struct Bgzf {
     FILE *f = nullptr;
     std::vector<uint8_t> block, cdata;
     size_t bpos = 0;
+    uint64_t block_off = 0; // file offset of the current block
+    // virtual offset of the next byte to be read
+    uint64_t tell() {
+        if (bpos >= block.size()) return (uint64_t)ftello(f) << 16;
+        return (block_off << 16) | bpos;
+    }
     bool read_block() { // returns false at EOF
         block.clear();
         bpos = 0;
+        block_off = (uint64_t)ftello(f);
         uint8_t hd[18];
         size_t n = fread(hd, 1, 18, f);
         if (n == 0) return false;
@@ -233,11 +242,19 @@ uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p +
 struct np2_fasta {
     Fasta f;
 };
+struct SecSeq { // SEQ of a primary alignment in read orientation (4-bit BAM codes, high nibble first)
+    std::vector<uint8_t> seq4;
+    uint32_t len = 0;
+};
 struct np2_bam {
     Bgzf z;
     std::vector<std::string> ref_names;
     std::vector<uint32_t> ref_lens;
     std::vector<uint64_t> ref_start; // virtual offset of the first record of each reference (~0 = none)
+    uint64_t first_rec = 0;          // virtual offset of the first alignment record
+    // -S: secondary alignments carry no SEQ; recovered from the primary record of the same read (secondary.rs:82-148)
+    bool sec_loaded = false;
+    std::unordered_map<std::string, SecSeq> sec;
 };
 
 namespace {
@@ -248,6 +265,57 @@ struct Admitted {
     bool is_clip;
     uint32_t n_cols;  // untrimmed columns
 };
+
+// 4-bit SEQ nibble i (BAM: high nibble first)
+inline uint8_t seq4_at(const uint8_t *s, uint32_t i) { return (i & 1) ? (s[i >> 1] & 15) : (s[i >> 1] >> 4); }
+// reverse complement in the 4-bit domain: A(1)<->T(8), C(2)<->G(4), every other code unchanged
+// (reverse_complement_seq_u8, secondary.rs:66-80, over the decoded letters "=ACMGRSVTWYHKDBN")
+void append_seq4(std::vector<uint8_t> &dst, const uint8_t *src, uint32_t len, bool revcomp) {
+    const size_t base = dst.size();
+    dst.resize(base + (len + 1) / 2, 0);
+    for (uint32_t i = 0; i < len; ++i) {
+        uint8_t c = seq4_at(src, revcomp ? len - 1 - i : i);
+        if (revcomp) c = c == 1 ? 8 : (c == 8 ? 1 : (c == 2 ? 4 : (c == 4 ? 2 : c)));
+        dst[base + (i >> 1)] |= (i & 1) ? c : (uint8_t)(c << 4);
+    }
+}
+
+// retrieve_secondary_seq_from_bam (secondary.rs:8-148): pass 1 collects the names of all secondary records, pass 2
+// the SEQ (read orientation) of the primary record (neither secondary nor supplementary) of each of those reads.
+// Two sequential passes over the whole file, once per BAM handle.
+void load_secondary_seqs(np2_bam *bam) {
+    if (bam->sec_loaded) return;
+    std::unordered_set<std::string> ids;
+    for (int pass = 0; pass < 2; ++pass) {
+        BgzfBatch z;
+        z.f = bam->z.f;
+        z.seek(bam->first_rec);
+        for (;;) {
+            const uint8_t *h4 = z.take(4);
+            if (!h4) break;
+            const uint32_t bs = le32(h4);
+            const uint8_t *rec = z.take(bs);
+            if (!rec || bs < 32) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+            const uint32_t l_read_name = rec[8];
+            const uint32_t n_cigar = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8);
+            const uint32_t l_seq = le32(rec + 16);
+            const uint8_t *ps = rec + 32 + l_read_name + (size_t)n_cigar * 4;
+            if ((size_t)(ps - rec) + (l_seq + 1) / 2 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+            const std::string name((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0); // qname without the NUL
+            if (pass == 0) {
+                if (flag & 0x100) ids.insert(name);
+            } else if (!(flag & 0x900) && ids.count(name)) {
+                SecSeq sq;
+                sq.len = l_seq;
+                append_seq4(sq.seq4, ps, l_seq, (flag & 0x10) != 0);
+                if (!bam->sec.emplace(name, std::move(sq)).second) // assert!(seqs.insert(..).is_none()), secondary.rs:130
+                    throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: two primary records for one read name");
+            }
+        }
+        if (ids.empty()) break;
+    }
+    bam->sec_loaded = true;
+}
 
 void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs, uint32_t n_recs,
                          const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes,
@@ -276,7 +344,8 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
         if ((r.flag & 0x404) != 0 || (int16_t)r.mapq <= o->min_map_qual || rlen <= o->min_read_len ||
             (secondary && !o->use_secondary) || (supplementary && !o->use_supplementary) || span < need)
             continue;
-        if (secondary) throw np2h::Np2Error(NP2_E_UNSUPPORTED, "-S (secondary alignments) needs SEQ recovery (secondary.rs)");
+        // (-S: the record's SEQ must already be the one recovered from the read's primary alignment, main.rs:1775-1789;
+        // np2_contig_from_bam does that, a caller of np2_contig_from_records passes it in)
         if (r.pos < 0 || (uint32_t)r.pos > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: record start outside the contig");
         // fill_with_cigar bookkeeping (main.rs:390-439): query clipping, op prefix sums
         uint32_t qs = 0, ts = 0, col = 0, aln_q_s = 0, aln_q_e = 0;
@@ -312,7 +381,9 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
             is_first = false;
         }
         if (aln_q_e == 0) aln_q_e = qs;
-        if (qs > r.l_seq) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: SEQ shorter than CIGAR");
+        if (qs > r.l_seq)
+            throw np2h::Np2Error(NP2_E_REFPANIC, secondary ? "reference would panic: no (or too short a) primary SEQ for a secondary alignment"
+                                                           : "reference would panic: SEQ shorter than CIGAR");
         if ((uint64_t)r.pos + ts > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end");
         if (r.seq_off + ((uint64_t)r.l_seq + 1) / 2 > seq4_bytes) throw np2h::Np2Error(NP2_E_ARG, "SEQ outside the buffer");
         fr.n_ops = (uint32_t)(fops.size() - fr.op_off);
@@ -556,6 +627,7 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
             b->ref_lens.push_back(le32(h4));
         }
         b->ref_start.assign(n_ref, ~0ull);
+        b->first_rec = b->z.tell();
         // index: <path>.bai or <stem>.bai
         std::string p1 = std::string(path) + ".bai", p2 = path;
         if (p2.size() > 4 && p2.substr(p2.size() - 4) == ".bam") p2 = p2.substr(0, p2.size() - 4) + ".bai";
@@ -654,6 +726,7 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         std::vector<np2_bamrec_t> recs;
         std::vector<uint32_t> cigar;
         std::vector<uint8_t> seq4;
+        if (opts->use_secondary) load_secondary_seqs(bam);
         if (bam->ref_start[tid] != ~0ull) {
             BgzfBatch z;
             z.f = bam->z.f;
@@ -687,7 +760,20 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
                 r.l_seq = l_seq;
                 r.seq_off = seq4.size();
                 for (uint32_t k = 0; k < n_cigar; ++k) cigar.push_back(le32(pc + 4 * k));
-                seq4.insert(seq4.end(), ps, ps + (l_seq + 1) / 2);
+                if (opts->use_secondary && (flag & 0x100)) {
+                    // SEQ of the read's primary alignment, reverse-complemented again if this record is on the reverse
+                    // strand (main.rs:1775-1784).  A missing name leaves l_seq = 0: the reference would only panic
+                    // if the record passes the admission filters, and so do we (contig_from_records).
+                    const std::string name((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0);
+                    const auto it = bam->sec.find(name);
+                    r.l_seq = 0;
+                    if (it != bam->sec.end()) {
+                        r.l_seq = it->second.len;
+                        append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
+                    }
+                } else {
+                    seq4.insert(seq4.end(), ps, ps + (l_seq + 1) / 2);
+                }
                 recs.push_back(r);
             }
         }

@@ -200,3 +200,37 @@ def front_end(ref, recs, cigar, ascii_seq, ascii_off, fopts):
     L_.np2o_front_free(pr)
     L_.np2o_front_free(pn)
     return Pileup(np.frombuffer(ref, dtype=np.uint8), reads, nib)
+
+
+_RC = {"A": "T", "a": "T", "T": "A", "t": "A", "G": "C", "g": "C", "C": "G", "c": "G"}
+
+
+def reverse_complement(seq):
+    """reverse_complement_seq_u8 (secondary.rs:66-80): A<->T, C<->G (either case -> upper), anything else unchanged."""
+    return "".join(_RC.get(ch, ch) for ch in reversed(seq))
+
+
+def secondary_seqs(all_records):
+    """retrieve_secondary_seq_from_bam (secondary.rs:8-148) over every record of the BAM (dicts with name, flag, seq):
+    {read name: SEQ of its primary record in read orientation} for the reads that have a secondary record."""
+    ids = {r["name"] for r in all_records if r["flag"] & 0x100}
+    out = {}
+    for r in all_records:
+        if r["name"] in ids and not (r["flag"] & 0x900):
+            assert r["name"] not in out, "reference would panic: two primary records for one read name"
+            out[r["name"]] = reverse_complement(r["seq"]) if r["flag"] & 0x10 else r["seq"]
+    return out
+
+
+def with_secondary_seq(records, sec):
+    """Records of one contig with the SEQ of every secondary record replaced as main.rs:1775-1784 does before
+    fill_with_cigar: the primary's SEQ, reverse-complemented if the secondary record is on the reverse strand.
+    A read without a primary record gets an empty SEQ (the reference would panic if the record is admitted)."""
+    out = []
+    for r in records:
+        if r["flag"] & 0x100:
+            q = sec.get(r["name"], "")
+            r = dict(r, seq=reverse_complement(q) if r["flag"] & 0x10 else q)
+        out.append(r)
+    return out
+

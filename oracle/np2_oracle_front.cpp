@@ -244,7 +244,8 @@ int np2o_front_end(const char *tseq, uint32_t L, const np2o_bamrec_t *recs, uint
         if ((r.flag & 0x404) != 0 || (int16_t)r.mapq <= o->min_map_qual || rlen <= o->min_read_len ||
             (secondary && !o->use_secondary) || (supplementary && !o->use_supplementary) || span < need)
             continue;
-        if (secondary && o->use_secondary) return NP2_E_UNSUPPORTED; // -S path (secondary.rs) is out of scope
+        // -S (main.rs:1775-1789): the caller passes, for a secondary record, the SEQ recovered from the read's primary
+        // alignment (oracle/np2_oracle.py: secondary_seqs restates secondary.rs:82-148 and the strand rule)
         Alignment aln;
         aln.aln_t_s = (uint32_t)r.pos;
         if ((uint32_t)r.pos > L) return NP2_E_REFPANIC;

@@ -117,3 +117,24 @@ def test_cli_pass_through_known_answer(tmp_path):
     r3 = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-u", str(tmp_path / "x.bam"), fa,
                          str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=120)
     assert r3.stdout.decode().split("\n")[1] == seq.upper()
+
+
+def test_oracle_secondary_seq_recovery_rules():
+    """secondary.rs:82-148 + main.rs:1775-1784 on a hand-made record list."""
+    recs = [
+        dict(name=b"a", flag=0x000, seq="AACGTN"),   # primary, forward, has a secondary
+        dict(name=b"a", flag=0x100, seq=""),         # secondary forward  -> AACGTN
+        dict(name=b"a", flag=0x110, seq=""),         # secondary reverse  -> revcomp = NACGTT
+        dict(name=b"b", flag=0x010, seq="GGCAm"),    # primary on the reverse strand: stored in read orientation
+        dict(name=b"b", flag=0x900, seq=""),         # secondary + supplementary counts as secondary for the id set
+        dict(name=b"b", flag=0x800, seq="TTTT"),     # supplementary: never a source
+        dict(name=b"c", flag=0x000, seq="ACGT"),     # no secondary: not collected
+        dict(name=b"d", flag=0x100, seq=""),         # secondary without any primary
+    ]
+    sec = orc.secondary_seqs(recs)
+    assert sec == {b"a": "AACGTN", b"b": "mTGCC"}
+    out = orc.with_secondary_seq(recs, sec)
+    assert [r["seq"] for r in out] == ["AACGTN", "AACGTN", "NACGTT", "GGCAm", "mTGCC", "TTTT", "ACGT", ""]
+    with pytest.raises(AssertionError):
+        orc.secondary_seqs(recs + [dict(name=b"a", flag=0, seq="AC")])
+

@@ -9,6 +9,7 @@ import pytest
 
 from nextpolish2_amd import Opts, Polisher
 from nextpolish2_amd import io as np2io
+from nextpolish2_amd.api import Np2Error
 from nextpolish2_amd.bamio import pileup_to_records, records_to_arrays, write_bam
 from nextpolish2_amd.synth import Synth
 from oracle import np2_oracle as orc
@@ -106,3 +107,81 @@ def test_contig_from_bam_and_cli_end_to_end(tmp_path):
     rr = [r for r in recs if r["tid"] == 1]
     arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
     assert same_pileup(np2io.export_contig(pol, c, s2.pileup.ref), orc.front_end(s2.pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts()))
+
+
+def test_secondary_alignments_recover_seq_from_the_primary(tmp_path):
+    """-S: secondary records carry no SEQ; it comes from the read's primary record (possibly on another contig and
+    on the other strand), secondary.rs:82-148 + main.rs:1775-1789."""
+    s1 = Synth(40000, depth=12, seed=71, read_len_mean=5000.0, read_len_sd=600.0, name="ctgA")
+    s2 = Synth(30000, depth=10, seed=72, read_len_mean=4000.0, read_len_sd=500.0, name="ctgB")
+    rng = np.random.default_rng(9)
+    recs = []
+    for tid, s in ((0, s1), (1, s2)):
+        rr = pileup_to_records(s.pileup, tid=tid, rng=np.random.default_rng(5 + tid), decorate=False)
+        for i, r in enumerate(rr):
+            r["name"] = b"t%d_r%d" % (tid, i)
+        recs += rr
+    prim = list(recs)
+    # secondaries: (a) a copy of a ctgA read's alignment flagged secondary (same strand or flipped), SEQ "*";
+    # (b) ctgB reads whose *primary* lives on ctgA-style extra records: make the ctgB record secondary and add a primary
+    #     elsewhere with the read sequence in the other orientation; (c) one secondary whose primary is missing but which
+    #     fails the admission filters (mapq 0), so nobody may panic
+    extra = []
+    for r in prim[::5]:
+        if r["tid"] != 0:
+            continue
+        sec = dict(r, flag=(r["flag"] & 0x10) | 0x100, seq="", name=r["name"])
+        if rng.random() < 0.5:  # secondary on the opposite strand of its primary: SEQ must be reverse-complemented
+            # the alignment columns describe the read as given, so flip the primary to keep the secondary sensible
+            r["flag"] ^= 0x10
+            r["seq"] = orc.reverse_complement(r["seq"])  # primary stored reverse-complemented, as an aligner would
+            # (its own alignment to ctgA is now nonsense and gets trimmed / filtered like any bad read)
+        extra.append(sec)
+    for r in prim[3::7]:
+        if r["tid"] != 1:
+            continue
+        # primary on ctgA at an arbitrary place (soft-clipped whole read would be filtered; use a short match), secondary on ctgB
+        full = r["seq"]
+        primary = dict(tid=0, pos=int(rng.integers(0, 30000)), mapq=60, flag=0x10, name=r["name"],
+                       cigar=[("S", len(full) - 600), ("M", 600)], seq=orc.reverse_complement(full))
+        extra.append(primary)
+        r["flag"] = 0x100 | 0x0  # forward secondary: needs RC(RC(full)) == full
+        r["seq"] = ""
+    orphan = dict(prim[1], flag=0x100, mapq=0, seq="", name=b"orphan")
+    extra.append(orphan)
+    recs += extra
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    write_bam(str(tmp_path / "s.bam"), [("ctgA", s1.pileup.L), ("ctgB", s2.pileup.L)], recs)
+    from test_oracle import yak_from_seqs
+    y21 = yak_from_seqs([s1.hap1.decode(), s2.hap1.decode()], 21)
+    sec = orc.secondary_seqs(recs)
+    assert len(sec) >= 10
+    fo = np2io.FrontOpts(use_secondary=True)
+    pol = Polisher([y21])
+    bam = np2io.Bam(str(tmp_path / "s.bam"))
+    o = orc.Oracle([y21])
+    for nm, s, tid in (("ctgA", s1, 0), ("ctgB", s2, 1)):
+        rr = orc.with_secondary_seq([r for r in recs if r["tid"] == tid], sec)
+        arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
+        want = orc.front_end(s.pileup.ref.tobytes(), arr, cig, asc, asc_off, fo)
+        c = np2io.contig_from_bam(pol, bam, nm, s.pileup.ref.tobytes(), fo)
+        assert same_pileup(np2io.export_contig(pol, c, s.pileup.ref), want), nm
+        # the secondaries really made it into the pileup (more reads than without -S)
+        c0 = np2io.contig_from_bam(pol, bam, nm, s.pileup.ref.tobytes(), np2io.FrontOpts())
+        assert np2io.export_contig(pol, c, s.pileup.ref).n_reads > np2io.export_contig(pol, c0, s.pileup.ref).n_reads, nm
+        gb, gp = pol.polish_resident(c, Opts())
+        ob, op = o.polish(want, Opts())
+        assert np.array_equal(gb, ob) and np.array_equal(gp, op)
+    # np2_contig_from_records: the caller passes the recovered SEQ
+    rr = orc.with_secondary_seq([r for r in recs if r["tid"] == 1], sec)
+    arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
+    c = np2io.contig_from_records(pol, s2.pileup.ref.tobytes(), arr, cig, seq4, fo)
+    assert same_pileup(np2io.export_contig(pol, c, s2.pileup.ref), orc.front_end(s2.pileup.ref.tobytes(), arr, cig, asc, asc_off, fo))
+    # a secondary without a primary that passes the filters: the reference panics on the map lookup
+    bad = [dict(r) for r in recs if r["tid"] == 1] + [dict(prim[-1], flag=0x100, seq="", name=b"nobody", tid=1)]
+    bad.sort(key=lambda r: r["pos"])
+    write_bam(str(tmp_path / "b.bam"), [("ctgA", s1.pileup.L), ("ctgB", s2.pileup.L)],
+              [r for r in recs if r["tid"] == 0] + bad)
+    with pytest.raises(Np2Error):
+        np2io.contig_from_bam(pol, np2io.Bam(str(tmp_path / "b.bam")), "ctgB", s2.pileup.ref.tobytes(), fo)
+

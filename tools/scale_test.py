@@ -11,6 +11,7 @@ t = time.time(); s = Synth(L, depth=30, seed=5, diploid=dip); print(f"gen {time.
 t = time.time(); yaks = [s.yak(21)] + ([s.yak(31)] if dip else []); print(f"yak {time.time()-t:.1f}s words {[len(y.words) for y in yaks]}", flush=True)
 t = time.time(); p = Polisher(yaks); print(f"ctx {time.time()-t:.1f}s", flush=True)
 t = time.time(); c = p.upload(s.pileup); print(f"upload {time.time()-t:.2f}s", flush=True)
+p.set_timing(True)  # per-stage HIP-event timers (adds event packets: the wall time below is a few % pessimistic)
 for i in range(3):
     t = time.time(); b, span = p.polish_resident(c, Opts(), want_pos=False); dt = time.time() - t
     print(f"polish {dt*1e3:.1f} ms -> {L/dt/1e6:.0f} Mbp/s span {span} timings {dict((k, round(v,2)) for k,v in p.timings().items())}", flush=True)
