@@ -135,6 +135,44 @@ def write_bam(path, refs, records):
         f.write(out)
 
 
+def read_bam(path):
+    """-> (refs [(name, length)], records) of a BAM file, records as the dicts write_bam takes.  A plain sequential
+    reader for tests (BGZF blocks are concatenated gzip members); the product reads BAM through csrc/np2_io.cpp."""
+    import gzip
+    with gzip.open(path, "rb") as f:
+        data = f.read()
+    assert data[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<I", data, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<I", data, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<I", data, o)
+        name = data[o + 4:o + 4 + l_name - 1].decode()
+        l_ref, = struct.unpack_from("<I", data, o + 4 + l_name)
+        refs.append((name, l_ref))
+        o += 8 + l_name
+    recs = []
+    lut = np.frombuffer(SEQ4.encode(), dtype=np.uint8)
+    while o < len(data):
+        bs, = struct.unpack_from("<I", data, o)
+        tid, pos, l_name, mapq, _bin, ncig, flag, l_seq = struct.unpack_from("<iiBBHHHI", data, o + 4)
+        q = o + 36
+        name = data[q:q + l_name - 1]
+        q += l_name
+        cw = struct.unpack_from("<%dI" % ncig, data, q)
+        q += 4 * ncig
+        nib = np.frombuffer(data, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q)
+        codes = np.empty(2 * nib.shape[0], np.uint8)
+        codes[0::2] = nib >> 4
+        codes[1::2] = nib & 15
+        recs.append(dict(tid=tid, pos=pos, mapq=mapq, flag=flag, name=name,
+                         cigar=[(CIGAR_OPS[w & 15], w >> 4) for w in cw], seq=lut[codes[:l_seq]].tobytes().decode()))
+        o += 4 + bs
+    return refs, recs
+
+
 def pileup_to_records(pileup, tid=0, rng=None, decorate=False):
     """Turn the packed reads (index >= 1) of a Pileup back into BAM-style records (CIGAR + SEQ).
 
