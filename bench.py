@@ -47,7 +47,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -57,17 +58,19 @@ def main():
     pol = Polisher(yaks, device=local_rank)
     contig = pol.upload(syn.pileup)  # pileup resident in HBM before the timed region
     opts = Opts()
-    gatherer = SequenceGatherer(a.length + a.length // 16 + 4096, dev) if world > 1 else None
+    gatherer = SequenceGatherer(a.length + a.length // 16 + 4096, dev) if distributed else None
 
     def step():
         # FASTA output needs the sequence and the first/last position only (main.rs:627-632)
         bases, pos = pol.polish_resident(contig, opts, want_pos=False)
-        if world > 1:
-            gatherer.gather(bases)  # RCCL all-gather of the polished contigs, stays on the GPUs
+        if distributed:
+            # RCCL all-gather of the polished contigs straight from the context's result buffer in HBM; it runs on
+            # torch's stream and overlaps the next contig's kernels (waited for by sync() at the end of the timed region)
+            gatherer.gather_device(*pol.last_result_device())
         return bases, pos
 
     def sync():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -90,7 +93,7 @@ def main():
         for k, v in pol.timings().items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / 3
     pol.set_timing(False)
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -141,7 +144,12 @@ def main():
             out["fasta_identical_to_oracle"] = bool(np.array_equal(ob, gb) and np.array_equal(op, gp))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
+        if rank == 0:
+            # the gathered sequences really are the polished contigs (checked outside the timed region)
+            got = gatherer.to_host()
+            assert got[0] == bases.tobytes(), "all-gathered sequence differs from the polished contig"
+            assert all(len(got[r]) > 0 for r in range(world))
         dist.destroy_process_group()
 
 

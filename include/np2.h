@@ -92,6 +92,11 @@ int np2_polish_resident(np2_ctx_t *ctx, np2_contig_t *c, const np2_opts_t *opts,
  * only the sequence and this span are needed (FASTA output), which skips a 4 B/bp device-to-host copy. */
 int np2_last_span(np2_ctx_t *ctx, uint32_t *first_pos, uint32_t *last_pos);
 
+/* Device-resident copy of the last polished sequence (`len` ASCII bases in HBM on the context's device), valid until
+ * the next call on this context.  Multi-GPU drivers hand it to RCCL directly (all-gather of the per-contig polished
+ * sequences over xGMI) instead of sending the host copy back up. */
+int np2_last_result_device(np2_ctx_t *ctx, const uint8_t **dev_bases, uint64_t *len);
+
 /* Convenience: upload + polish + free (PCIe-inclusive). */
 int np2_polish_contig(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads,
                       uint32_t n_reads, const uint8_t *nibbles, uint64_t nib_bytes,

@@ -19,7 +19,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
-    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_phase_vote",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_phase_vote",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -61,6 +61,7 @@ def lib():
         L.np2_trace_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
         L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.np2_last_span.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+        L.np2_last_result_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.np2_phase_vote.argtypes = [vp, u32, vp, vp, vp, u64, vp, vp, u32, C.c_int, vp, C.POINTER(u32)]
         _LIB = L
     return _LIB
@@ -170,6 +171,12 @@ class Polisher:
         a, b = C.c_uint32(), C.c_uint32()
         self._check(lib().np2_last_span(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_result_device(self):
+        """(device address, length) of the last polished sequence in HBM; valid until the next call on this context."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(lib().np2_last_result_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def polish(self, pileup: Pileup, opts: Opts = None):
         c = self.upload(pileup)

@@ -170,6 +170,8 @@ struct np2_ctx {
     uint32_t *mbox_host = nullptr, *mbox_dev = nullptr; // host-mapped scalar mailbox: [0] = sequence, [1..] = scal
     uint32_t mbox_seq = 0;
     uint32_t last_first_pos = 0, last_last_pos = 0;
+    const uint8_t *last_dbase = nullptr; // device copy of the last polished sequence (valid until the next call)
+    uint64_t last_len = 0;
     bool reuse_identical_pass = true;
     bool stage_timing = false; // arm every stage timer (np2_ctx_set_timing)
     // scratch (reused across contigs)

@@ -713,6 +713,8 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     HIPCHK(hipStreamSynchronize(cx->stream));
     cx->last_first_pos = span[0];
     cx->last_last_pos = span[1];
+    cx->last_dbase = dbase;
+    cx->last_len = M;
     if (cx->stage_timing) cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
 }
 
@@ -721,6 +723,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     hipStream_t s = cx->stream;
     HIPCHK(hipSetDevice(cx->device));
     cx->trace_items.clear();
+    cx->last_dbase = nullptr;
     cx->scal.ensure(SCAL_TOTAL);
     cx->alive.ensure(c->R + 2);
     uint32_t T = 0;
@@ -1119,6 +1122,14 @@ int np2_last_span(np2_ctx_t *cx, uint32_t *first_pos, uint32_t *last_pos) {
     if (!cx || !first_pos || !last_pos) return NP2_E_ARG;
     *first_pos = cx->last_first_pos;
     *last_pos = cx->last_last_pos;
+    return NP2_OK;
+}
+
+int np2_last_result_device(np2_ctx_t *cx, const uint8_t **dev_bases, uint64_t *len) {
+    if (!cx || !dev_bases || !len) return NP2_E_ARG;
+    if (!cx->last_dbase) return NP2_E_ARG;
+    *dev_bases = cx->last_dbase;
+    *len = cx->last_len;
     return NP2_OK;
 }
 

@@ -68,36 +68,68 @@ def all_gather_sequences(local, device=None, group=None):
     return out
 
 
+class _DeviceBytes:
+    """Zero-copy view of `n` bytes at device address `ptr` for torch.as_tensor (array-interface protocol)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
 class SequenceGatherer:
     """Per-step all-gather of one polished contig per rank, kept on the device.
 
-    Buffers are allocated once; a step costs one tiny all-gather (lengths) and one padded uint8 all-gather
-    (the polished bytes) — on GPUs that is RCCL over xGMI with no host round trip."""
+    Buffers are allocated once; a step costs one padded uint8 all-gather (length word + the polished bytes) — on GPUs that is RCCL over xGMI with no host round trip.  The collectives are enqueued on torch's
+    current stream and not waited for: they overlap the next contig's kernels, which run on the np2 context's own
+    stream.  `gather_device` returns as soon as the context's result buffer has been copied out (device to device), so
+    the context is free to start its next contig."""
+
+    HDR = 8  # every rank's slot starts with its sequence length (int64), so one collective moves both
 
     def __init__(self, capacity, device, group=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
-        self.device = device
-        self.cap = int(capacity)
-        self.local = torch.zeros(self.cap, dtype=torch.uint8, device=device)
-        self.len_local = torch.zeros(1, dtype=torch.int64, device=device)
-        self.bufs = [torch.zeros(self.cap, dtype=torch.uint8, device=device) for _ in range(self.world)]
-        self.lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)]
+        self.device = torch.device(device)
+        self.cap = (int(capacity) + 7) & ~7
+        stride = self.HDR + self.cap
+        self.local = torch.zeros(stride, dtype=torch.uint8, device=self.device)
+        self.flat = torch.zeros(self.world * stride, dtype=torch.uint8, device=self.device)
+        self.bufs = [self.flat[r * stride + self.HDR:(r + 1) * stride] for r in range(self.world)]
+        self.lens = [self.flat[r * stride:r * stride + self.HDR].view(torch.int64) for r in range(self.world)]
+        self._len_host = torch.zeros(1, dtype=torch.int64)
+        if self.device.type == "cuda":
+            self._len_host = self._len_host.pin_memory()
+            self._copied = torch.cuda.Event()
 
-    def gather(self, bases):
-        """bases: 1-D uint8 numpy array (this rank's polished contig). Returns (list of device tensors, lengths)."""
-        n = int(bases.shape[0])
+    def _exchange(self):
+        if not dist.is_initialized():
+            self.flat.copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.flat, self.local, group=self.group)
+        return self.bufs, self.lens
+
+    def gather_tensor(self, src):
+        """src: 1-D uint8 tensor on this gatherer's device (this rank's polished contig)."""
+        n = int(src.shape[0])
         if n > self.cap:
             raise ValueError("polished contig longer than the gather capacity")
-        self.local[:n].copy_(torch.from_numpy(np.asarray(bases)))
-        self.len_local[0] = n
-        if self.world == 1:
-            self.bufs[0].copy_(self.local)
-            self.lens[0].copy_(self.len_local)
-        else:
-            dist.all_gather(self.lens, self.len_local, group=self.group)
-            dist.all_gather(self.bufs, self.local, group=self.group)
-        return self.bufs, self.lens
+        self._len_host[0] = n
+        self.local[:self.HDR].view(torch.int64).copy_(self._len_host, non_blocking=True)
+        self.local[self.HDR:self.HDR + n].copy_(src, non_blocking=True)
+        if self.device.type == "cuda":
+            self._copied.record()
+        out = self._exchange()
+        if self.device.type == "cuda":
+            self._copied.synchronize()  # src (and the pinned length word) may be reused from here on
+        return out
+
+    def gather_device(self, ptr, n):
+        """Gather straight from a device buffer (np2_last_result_device): no host round trip."""
+        with torch.cuda.device(self.device):
+            return self.gather_tensor(torch.as_tensor(_DeviceBytes(ptr, n), device=self.device))
+
+    def gather(self, bases):
+        """bases: 1-D uint8 numpy array on the host. Returns (list of device tensors, lengths)."""
+        return self.gather_tensor(torch.from_numpy(np.ascontiguousarray(bases)).to(self.device))
 
     def to_host(self):
         """{rank: bytes} of the last gather (only for verification / output, not part of the hot loop)."""

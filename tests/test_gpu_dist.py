@@ -1,0 +1,51 @@
+"""GPU tests of the multi-GPU plumbing that can run on one device: the device-resident result buffer handed to the
+gatherer, and bench.py under torch.distributed.run with a single rank (RCCL process group, same code path as N > 1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from nextpolish2_amd import Opts, Polisher
+from nextpolish2_amd.dist import SequenceGatherer
+from nextpolish2_amd.synth import Synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gather_from_the_device_result_buffer():
+    import torch
+    s = Synth(80000, depth=20, seed=71, read_len_mean=6000.0, read_len_sd=900.0)
+    pol = Polisher([s.yak(21)])
+    c = pol.upload(s.pileup)
+    g = SequenceGatherer(s.pileup.L + 8192, torch.device("cuda", 0))
+    for _ in range(3):  # back to back: the gather of one step overlaps the next polish
+        bases, span = pol.polish_resident(c, Opts(), want_pos=False)
+        ptr, n = pol.last_result_device()
+        assert n == bases.shape[0]
+        g.gather_device(ptr, n)
+    torch.cuda.synchronize()
+    assert g.to_host() == {0: bases.tobytes()}
+    with pytest.raises(ValueError):
+        SequenceGatherer(100, torch.device("cuda", 0)).gather_device(ptr, n)
+
+
+def test_bench_under_torchrun_with_one_rank():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "4", "--warmup", "1", "--length", "300000", "--cpu-sample", "100000"],
+                       capture_output=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["fasta_identical_to_oracle"] is True
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
