@@ -159,6 +159,8 @@ struct np2_ctx {
     }
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream for kernels that can overlap the main one (fork / join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<YakTable> yaks;
     std::string err;
     bool trace = false;

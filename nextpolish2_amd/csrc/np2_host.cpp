@@ -487,9 +487,9 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->nminr.ensure(T + 1);
     cx->nscore.ensure(T + 1);
     cx->nbesti.ensure(T + 1);
-    cx->nrec.ensure((size_t)T + 32); // k_dp_runs prefetches a fixed number of records per run
-    cx->node_off.ensure(L + 2);
-    cx->cov.ensure(L + 2);
+    cx->nrec.ensure((size_t)T + 32); // the DP kernels prefetch a fixed number of records per position
+    cx->node_off.ensure(L + 16); // k_dp_bt_short reads fixed windows past a run's start
+    cx->cov.ensure(L + 16);
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
     cx->emit.ensure(L + 2);
@@ -588,11 +588,22 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     {
         EventTimer t(cx, "dp_backtrack");
         // (scalars were zeroed by build_graph; S_GAIN already holds the clean-position gains)
-        launch_dp(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
-                  cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
-                  cx->scal.p + S_BEST, cx->run_gain.p, (const long long *)cx->tile_gain.p, (c->L + TILE - 1) >> TILE_SHIFT);
-        launch_bt_count(s, gp, cx->run_start.p, cx->run_end.p, cx->scal.p + S_NRUNS, n_runs, cx->nbesti.p,
-                        cx->n0_besti.p, cx->scal.p + S_BEST, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
+        // long runs on the second stream, short runs on the main one: the kernels touch disjoint runs and the long
+        // kernel is a latency chain (a few lanes walking runs of dozens of positions) that would otherwise sit alone
+        // on the device for as long as the short kernel takes
+        HIPCHK(hipEventRecord(cx->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(cx->stream2, cx->ev_fork, 0));
+        launch_dp_long(cx->stream2, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
+                       cx->nbesti.p, cx->n0_besti.p, cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), cx->run_gain.p,
+                       cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
+        HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
+        launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p, cx->run_gain.p,
+                        cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
+        HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
+        launch_dp_finish(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
+                         (const int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
+                         cx->scal.p + S_BEST, cx->run_gain.p, (const long long *)cx->tile_gain.p,
+                         (c->L + TILE - 1) >> TILE_SHIFT, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
         zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
         launch_bt_write(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p,
@@ -928,6 +939,15 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
+static void destroy_streams(np2_ctx *cx) {
+    if (cx->ev_fork) (void)hipEventDestroy(cx->ev_fork);
+    if (cx->ev_join) (void)hipEventDestroy(cx->ev_join);
+    if (cx->stream2) (void)hipStreamDestroy(cx->stream2);
+    if (cx->stream) (void)hipStreamDestroy(cx->stream);
+    cx->ev_fork = cx->ev_join = nullptr;
+    cx->stream2 = cx->stream = nullptr;
+}
+
 int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak) {
     if (!out) return NP2_E_ARG;
     *out = nullptr;
@@ -940,6 +960,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         cx->device = device;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
         cx->scal.ensure(SCAL_TOTAL);
         HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
         memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
@@ -976,13 +999,13 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
     } catch (const Np2Error &e) {
         fprintf(stderr, "np2_ctx_create: %s\n", e.what());
         int code = e.code;
-        if (cx->stream) (void)hipStreamDestroy(cx->stream);
+        destroy_streams(cx);
         delete cx;
         return code;
     } catch (const std::exception &ex) {
         fprintf(stderr, "np2_ctx_create: %s\n", ex.what());
         int code = NP2_E_NOMEM;
-        if (cx->stream) (void)hipStreamDestroy(cx->stream);
+        destroy_streams(cx);
         delete cx;
         return code;
     }
@@ -993,10 +1016,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
 void np2_ctx_destroy(np2_ctx_t *cx) {
     if (!cx) return;
     (void)hipSetDevice(cx->device);
-    if (cx->stream) {
-        (void)hipStreamSynchronize(cx->stream);
-        (void)hipStreamDestroy(cx->stream);
-    }
+    if (cx->stream) (void)hipStreamSynchronize(cx->stream);
+    if (cx->stream2) (void)hipStreamSynchronize(cx->stream2);
+    destroy_streams(cx);
     delete cx;
 }
 const char *np2_last_error(np2_ctx_t *cx) { return cx ? cx->err.c_str() : "null context"; }

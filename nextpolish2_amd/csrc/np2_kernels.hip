@@ -447,21 +447,47 @@ __device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
 // ------------------------------------------------------------------------------------------
 // K5/K6: dirty runs and the per-run DP (get_cns_from_align_tags, main.rs:1645-1687)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool pred_match(uint16_t vb, uint16_t vd, uint32_t q, const AlignBase &kb1,
-                                           const AlignBase &kb2, AlignBase &pb1) {
-    // Msa::get(base2 = K.b1, base3 = K.b2) (main.rs:209-225)
-    const uint8_t base23 = (uint8_t)((kb1.q << 4) | kb2.q);
-    const uint16_t delta23 = kb1.t_pos == kb2.t_pos ? 1 : 0;
-    if ((uint8_t)vb != base23 || ((vb >> 12) & 1) != delta23) return false;
-    AlignBase pb2, pb3;
-    node_decode(vb, vd, q, pb1, pb2, pb3);
-    return pb2.eq(kb1) && pb3.eq(kb2);
+// ---- run classes ---------------------------------------------------------------------------------------------------------
+// A "short" run (99.9 % of them at HiFi error rates) has at most RW_P - 1 dirty positions followed by a clean one (inside the contig) and at most RW_N
+// exception nodes: k_dp_bt_short scores and backtracks it entirely on chip.  Everything else (long runs, the run that
+// reaches the contig end) goes to k_dp_bt_long.  Both kernels classify for themselves from the node offsets, so they
+// need no hand-over and can run side by side on two streams.
+static constexpr uint32_t RW_P = 13; // positions of a short run kept on chip: up to 12 dirty ones + the closing clean one
+static constexpr uint32_t RW_N = 16; // exception nodes of a short run kept on chip
+struct __attribute__((packed, aligned(4))) U32x4 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(4))) U32x2 {
+    uint32_t x, y;
+};
+// off[i] = node_off[a + i], i = 0 .. RW_P (the array is padded past L); returns the number of dirty positions, RW_P if
+// the run does not close inside the window
+__device__ __forceinline__ uint32_t short_run_len(const uint32_t (&off)[RW_P + 1], uint32_t a, uint32_t L) {
+    const uint32_t lim = min(RW_P, L - a); // the closing clean position must exist (< L)
+    uint32_t len = RW_P;
+#pragma unroll
+    for (uint32_t i = RW_P; i-- > 0;)
+        if (i < lim && off[i + 1] == off[i]) len = i;
+    return len;
+}
+__device__ __forceinline__ void load_run_offsets(const uint32_t *__restrict__ node_off, uint32_t a, uint32_t (&off)[RW_P + 1]) {
+    static_assert(RW_P + 1 == 14, "three 4-dword loads + one 2-dword load");
+    const U32x4 v0 = *reinterpret_cast<const U32x4 *>(node_off + a);
+    const U32x4 v1 = *reinterpret_cast<const U32x4 *>(node_off + a + 4);
+    const U32x4 v2 = *reinterpret_cast<const U32x4 *>(node_off + a + 8);
+    const U32x2 v3 = *reinterpret_cast<const U32x2 *>(node_off + a + 12);
+    off[0] = v0.x, off[1] = v0.y, off[2] = v0.z, off[3] = v0.w, off[4] = v1.x, off[5] = v1.y, off[6] = v1.z, off[7] = v1.w;
+    off[8] = v2.x, off[9] = v2.y, off[10] = v2.z, off[11] = v2.w, off[12] = v3.x, off[13] = v3.y;
 }
 
-// One thread per dirty run.  A position costs two dependent memory rounds: {node_off, cov, contig codes} then the
-// packed node records; the nodes and scores of the current and the previous position live in LDS (element-major,
-// one 4-byte bank per thread: conflict free), nodes beyond DP_CACHE per position fall back to global memory.
-static constexpr uint32_t DP_NR = 8;     // node records of a run cached in LDS (per thread)
+__device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t entry_idx, const uint32_t *__restrict__ nbesti,
+                            const uint32_t *__restrict__ n0_besti, uint32_t *__restrict__ path_begin,
+                            uint64_t *__restrict__ path);
+
+// One thread per long dirty run.  LDS holds the node records and scores of two positions per thread — the current one and
+// its predecessor, in two banks selected by the position's parity (element-major, one 4-byte bank per thread: conflict
+// free); a position with more than DP_NR exception nodes falls back to global memory for the excess.
+static constexpr uint32_t DP_NR = 8; // exception nodes of one position cached in LDS (per thread)
 static constexpr uint32_t DP_BLOCK = 64;
 
 __device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1, uint8_t c0, uint16_t &bases,
@@ -478,44 +504,55 @@ __device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1
     }
 }
 
-// One thread per dirty run.  The run's first DP_NR node records are fetched into LDS up front (one round trip) and
-// the per-position scalars (node_off, coverage, contig code) are requested one position ahead, so the serial DP over
-// the run's positions does not wait on HBM for every position.
-__global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict__ run_start,
+// The serial DP over a run's positions never waits on memory inside a position: while position p is scored, the
+// scalars of p + 1 (node_off, coverage, contig code) and the DP_NR node records that follow p's are in flight; they
+// are consumed / parked in the other LDS bank at the end of the step.
+__global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restrict__ run_start,
                                                       const uint32_t *__restrict__ n_runs, Graph g,
                                                       const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
                                                       uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
                                                       uint32_t *__restrict__ run_end,
                                                       int64_t *__restrict__ last_n0_score,
-                                                      int64_t *__restrict__ run_gain) {
-    __shared__ uint32_t s_key[DP_NR][DP_BLOCK];
-    __shared__ uint32_t s_cnt[DP_NR][DP_BLOCK];
-    __shared__ uint32_t s_slo[DP_NR][DP_BLOCK];
-    __shared__ uint32_t s_shi[DP_NR][DP_BLOCK];
+                                                      int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
+                                                      uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+    // one 16-byte LDS word per cached node: {key, count, score lo, score hi} (a node is read as a whole: the DP chain
+    // is bound by LDS round trips, not by bytes)
+    __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
     const uint32_t t = threadIdx.x;
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *n_runs) return;
     const uint32_t a = run_start[r], L = g.L;
-    const uint32_t o_base = g.node_off[a];
-    uint32_t o0 = o_base, o1 = g.node_off[a + 1];
+    uint32_t o0, o1;
+    {
+        uint32_t off[RW_P + 1];
+        load_run_offsets(g.node_off, a, off);
+        const uint32_t len = short_run_len(off, a, L);
+        if (len < RW_P && off[len] - off[0] <= RW_N) return; // a short run: k_dp_bt_short's
+        o0 = off[0], o1 = off[1];
+    }
+    const uint32_t o_first = o0;
     int64_t cov = g.cov[a];
     uint8_t c2 = a >= 2 ? ref_code(g.refnib, a - 2) : 0, c1 = a >= 1 ? ref_code(g.refnib, a - 1) : 0;
     uint8_t c0 = ref_code(g.refnib, a);
     const uint8_t c3 = a >= 3 ? ref_code(g.refnib, a - 3) : 0;
 #pragma unroll
     for (uint32_t k = 0; k < DP_NR; ++k) { // the node arrays are padded by DP_NR entries
-        const uint2 rc = nrec[o_base + k];
-        s_key[k][t] = rc.x;
-        s_cnt[k][t] = rc.y;
+        const uint2 rc = nrec[o0 + k];
+        s_node[(a & 1) * DP_NR + k][t] = make_uint4(rc.x, rc.y, 0u, 0u);
     }
-    // node records / scores by absolute node index
-    auto rec_of = [&](uint32_t o) -> uint2 {
-        const uint32_t i = o - o_base;
-        return i < DP_NR ? make_uint2(s_key[i][t], s_cnt[i][t]) : nrec[o];
+    // k-th exception node of a position whose nodes start at `base` and live in LDS bank `bank`
+    auto node_at = [&](uint32_t bank, uint32_t base, uint32_t k) -> uint4 { // {key, count, score lo, score hi}
+        if (k < DP_NR) return s_node[bank * DP_NR + k][t];
+        const uint2 rc = nrec[base + k];
+        const uint64_t sc = (uint64_t)nscore[base + k];
+        return make_uint4(rc.x, rc.y, (uint32_t)sc, (uint32_t)(sc >> 32));
     };
-    auto score_of = [&](uint32_t o) -> int64_t {
-        const uint32_t i = o - o_base;
-        return i < DP_NR ? (int64_t)(((uint64_t)s_shi[i][t] << 32) | s_slo[i][t]) : nscore[o];
+    auto rec_at = [&](uint32_t bank, uint32_t base, uint32_t k) -> uint2 {
+        if (k < DP_NR) {
+            const uint4 v = s_node[bank * DP_NR + k][t];
+            return make_uint2(v.x, v.y);
+        }
+        return nrec[base + k];
     };
     // previous position (starts as the clean position a-1: only N0, score 0 by convention)
     uint32_t pv_o0 = 0, pv_n = 0; // exception nodes of the previous position
@@ -524,22 +561,28 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
     bool pv_valid = a > 0;
     if (pv_valid) n0_from_codes(a - 1, c3, c2, c1, pv_b0, pv_d0);
     for (uint32_t p = a; p < L; ++p) {
-        // request the next position's scalars now; they are consumed at the end of this iteration
+        const uint32_t bank = p & 1;
+        // request the next position's scalars and node records now; they are consumed at the end of this iteration
         uint32_t nx_o1 = o1;
         int64_t nx_cov = 0;
         uint8_t nx_c = 0;
+        uint2 nx_rec[DP_NR];
         if (p + 1 < L) {
             nx_o1 = g.node_off[p + 2];
             nx_cov = g.cov[p + 1];
             nx_c = ref_code(g.refnib, p + 1);
         }
+        const bool in_run = o1 > o0;
+        if (in_run) {
+#pragma unroll
+            for (uint32_t k = 0; k < DP_NR; ++k) nx_rec[k] = nrec[o1 + k];
+        }
         uint16_t b0, d0;
         n0_from_codes(p, c2, c1, c0, b0, d0);
-        const bool in_run = o1 > o0;
         const uint32_t n = o1 - o0;
         uint32_t e0 = 0;
         for (uint32_t k = 0; k < n; ++k) {
-            const uint2 rc = rec_of(o0 + k);
+            const uint2 rc = rec_at(bank, o0, k);
             if (node_delta3((uint16_t)rc.x, (uint16_t)(rc.x >> 16)) == 0) e0 += rc.y;
         }
         const int64_t cn0 = cov - (int64_t)e0;
@@ -548,40 +591,48 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
             uint16_t kb = b0, kd = d0;
             int64_t cnt = cn0;
             if (idx) {
-                const uint2 rc = rec_of(o0 + idx - 1);
+                const uint2 rc = rec_at(bank, o0, idx - 1);
                 kb = (uint16_t)rc.x, kd = (uint16_t)(rc.x >> 16), cnt = rc.y;
             }
-            AlignBase k1, k2, k3;
-            node_decode(kb, kd, p, k1, k2, k3);
+            // Predecessor test without decoding the nodes (Msa::get, main.rs:209-225 + the eq checks of main.rs:1664):
+            // V = (v1, v2, v3) precedes K = (b1, b2, b3) iff (v2, v3) == (b1, b2).  V is looked up at t_pos(b2), so the
+            // positions agree as soon as "v2, v3 share a position" (V bit 12) equals "b1, b2 share one" (K bit 14); the
+            // base codes are the low byte of V against bits 4..11 of K; of the deltas only v2's has to be compared
+            // with b1's (= kd): the third column's follows from the shared-position flag (node_decode).
             int64_t score;
             uint32_t besti = 0;
-            if (k2.is_head()) {
+            if (((kb >> 4) & 0xF) == 15) { // b2 is a head sentinel: the path starts here
                 score = 10 * cnt - 4 * cov;
             } else {
                 score = SCORE_NEG;
-                const uint32_t q = k2.t_pos;
-                uint32_t qo0 = 0, qn = 0;
+                const bool same_pos = (kb & 0x1000) != 0; // b2 sits at p, else at p - 1
+                const uint32_t q = same_pos ? p : p - 1;
+                const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
+                uint32_t qo0 = 0, qn = 0, qbank = bank;
                 uint16_t qb0 = 0, qd0 = 0;
                 int64_t qs0 = 0;
                 bool ok = false;
-                if (q == p) { // same position: only nodes before K can match (their b3.delta = K.b2.delta)
+                if (same_pos) { // same position: only nodes before K can match (their b3.delta = K.b2.delta)
                     qo0 = o0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
-                } else if (q + 1 == p && pv_valid) {
-                    qo0 = pv_o0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
+                } else if (pv_valid) {
+                    qo0 = pv_o0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, qbank = bank ^ 1, ok = true;
                 }
                 if (ok) {
                     for (uint32_t pi = 0; pi < qn; ++pi) {
                         uint16_t vb = qb0, vd = qd0;
+                        int64_t ps = qs0;
                         if (pi) {
-                            const uint2 rc = rec_of(qo0 + pi - 1);
-                            vb = (uint16_t)rc.x, vd = (uint16_t)(rc.x >> 16);
+                            const uint4 v = node_at(qbank, qo0, pi - 1);
+                            vb = (uint16_t)v.x, vd = (uint16_t)(v.x >> 16);
+                            ps = (int64_t)(((uint64_t)v.w << 32) | v.z);
                         }
-                        AlignBase pb1;
-                        if (!pred_match(vb, vd, q, k1, k2, pb1)) continue;
-                        if (q >= 3 && pb1.is_head()) continue; // main.rs:1666-1668
-                        const int64_t ps = pi ? score_of(qo0 + pi - 1) : qs0;
+                        if ((vb & 0x10FFu) != want) continue;
+                        const uint16_t v2d = (vb & 0x4000) ? (uint16_t)(vd + 1) : (uint16_t)0;
+                        if (v2d != kd) continue;
+                        const uint32_t v1q = (vb >> 8) & 0xFu;
+                        if (q >= 3 && v1q == 15) continue; // main.rs:1666-1668
                         const int64_t sc = ps + 10 * cnt - 4 * cov;
-                        if (sc > score || (sc == score && pb1.q != 4)) { // main.rs:1670
+                        if (sc > score || (sc == score && v1q != 4)) { // main.rs:1670
                             score = sc;
                             besti = pi;
                         }
@@ -589,15 +640,15 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
                 }
             }
             if (idx) {
-                const uint32_t o = o0 + idx - 1, i = o - o_base;
-                if (i < DP_NR) {
-                    s_slo[i][t] = (uint32_t)(uint64_t)score;
-                    s_shi[i][t] = (uint32_t)((uint64_t)score >> 32);
+                const uint32_t k = idx - 1;
+                if (k < DP_NR) {
+                    s_node[bank * DP_NR + k][t].z = (uint32_t)(uint64_t)score;
+                    s_node[bank * DP_NR + k][t].w = (uint32_t)((uint64_t)score >> 32);
                 }
                 // scores are only read back from memory past the LDS cache and, at the contig's last position, by
                 // k_pick_best: skip the scattered 8-byte store otherwise
-                if (i >= DP_NR || p + 1 == L) nscore[o] = score;
-                nbesti[o] = besti;
+                if (k >= DP_NR || p + 1 == L) nscore[o0 + k] = score;
+                nbesti[o0 + k] = besti;
             } else {
                 s0_cur = score;
                 n0_besti[p] = besti;
@@ -605,8 +656,15 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
         }
         if (!in_run) { // p == b+1: the clean position closing the run; its N0 is scored above
             run_end[r] = p - 1;
-            run_gain[r] = s0_cur; // summed by k_clean_gain (one same-address atomic per run would serialise at L2)
+            run_gain[r] = s0_cur; // summed by k_sum_gains (one same-address atomic per run would serialise at L2)
+            // backtrack from this closing position's best predecessor (the thread's own stores, read back in order)
+            emit[a] = bt_walk(g, a, p - 1, n0_besti[p], nbesti, n0_besti, path_begin, path + (size_t)a + o_first);
             return;
+        }
+        // park the next position's records in the other bank (its previous content, position p - 1, is dead now)
+#pragma unroll
+        for (uint32_t k = 0; k < DP_NR; ++k) {
+            s_node[(bank ^ 1) * DP_NR + k][t] = make_uint4(nx_rec[k].x, nx_rec[k].y, 0u, 0u);
         }
         pv_o0 = o0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
         o0 = o1, o1 = nx_o1, cov = nx_cov;
@@ -616,6 +674,200 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_runs(const uint32_t *__restrict
     run_end[r] = L - 1;
     run_gain[r] = 0;
     *last_n0_score = pv_s0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Short runs: DP and backtrack of a run in one go, entirely out of LDS.
+//
+// The per-run kernels are latency chains (one lane walks a run position by position; measured ~2.5 us per position with
+// everything in LDS, VALU utilisation ~20 %), so what counts is how much of a run's work needs no memory round trip
+// at all.  A short run is fetched once with a handful of wide per-lane loads (node offsets, coverage, contig codes,
+// node records), scored, walked back and written out as its path slice; scores and best predecessors never leave
+// the chip.  Long runs and the run that reaches the contig end belong to k_dp_bt_long.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__ run_start,
+                                                    const uint32_t *__restrict__ n_runs, Graph g,
+                                                    const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
+                                                    int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
+                                                    uint64_t *__restrict__ path) {
+    __shared__ uint8_t s_off[RW_P + 1][64]; // node offsets relative to the run's first node (<= RW_N)
+    __shared__ int32_t s_cov[RW_P][64];
+    __shared__ uint4 s_node[RW_N][64]; // {key, count, score lo, score hi}: one LDS round trip per node
+    __shared__ uint8_t s_bi[RW_N][64];
+    __shared__ uint8_t s_n0bi[RW_P][64];
+    const uint32_t t = threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_runs) return;
+    const uint32_t a = run_start[r], L = g.L;
+    // ---- node offsets of positions a .. a + RW_P, run class -----------------------------------------------------------
+    uint32_t len, nn, o_base;
+    {
+        uint32_t off[RW_P + 1];
+        load_run_offsets(g.node_off, a, off);
+        len = short_run_len(off, a, L);
+        o_base = off[0];
+        nn = len < RW_P ? off[len] - o_base : 0xFFFFFFFFu;
+        if (len >= RW_P || nn > RW_N) return; // k_dp_bt_long's
+#pragma unroll
+        for (uint32_t i = 0; i <= RW_P; ++i) s_off[i][t] = (uint8_t)min(off[i] - o_base, 255u); // (only [0, len] are used)
+    }
+    // ---- coverage of positions a .. a + len, contig codes of a - 3 .. a + len, the run's node records -------------------
+    {
+        const U32x4 v0 = *reinterpret_cast<const U32x4 *>(g.cov + a);
+        s_cov[0][t] = (int32_t)v0.x, s_cov[1][t] = (int32_t)v0.y, s_cov[2][t] = (int32_t)v0.z, s_cov[3][t] = (int32_t)v0.w;
+        if (len >= 4) {
+            const U32x4 v1 = *reinterpret_cast<const U32x4 *>(g.cov + a + 4);
+            s_cov[4][t] = (int32_t)v1.x, s_cov[5][t] = (int32_t)v1.y, s_cov[6][t] = (int32_t)v1.z, s_cov[7][t] = (int32_t)v1.w;
+        }
+        if (len >= 8) {
+            const U32x4 v2 = *reinterpret_cast<const U32x4 *>(g.cov + a + 8);
+            s_cov[8][t] = (int32_t)v2.x, s_cov[9][t] = (int32_t)v2.y, s_cov[10][t] = (int32_t)v2.z, s_cov[11][t] = (int32_t)v2.w;
+            if (len >= 12) s_cov[12][t] = g.cov[a + 12];
+        }
+    }
+    // contig codes of positions a - 3 .. a + 12 as one 64-bit word (nibble i = position a - 3 + i): three dwords of the
+    // nibble-packed contig, shifted into place (plain shifts: a selected-by-index temporary would live in scratch)
+    uint64_t cpk;
+    {
+        const uint32_t cbase = a >= 3 ? ((a - 3) >> 3) : 0;
+        const uint64_t lo = (uint64_t)refw32[cbase] | ((uint64_t)refw32[cbase + 1] << 32);
+        const uint64_t hi = refw32[cbase + 2];
+        if (a >= 3) {
+            const uint32_t sh = ((a - 3) & 7) * 4;
+            cpk = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        } else {
+            cpk = lo << ((3 - a) * 4);
+        }
+    }
+    auto code_at = [&](uint32_t p) -> uint8_t { return (uint8_t)((cpk >> ((p + 3 - a) * 4)) & 7); }; // a - 3 <= p <= a + 12
+    for (uint32_t k = 0; k < nn; k += 2) { // two 8-byte records per load (the node array is padded)
+        const U32x4 v = *reinterpret_cast<const U32x4 *>(g.nrec + o_base + k);
+        s_node[k][t] = make_uint4(v.x, v.y, 0u, 0u);
+        if (k + 1 < RW_N) s_node[k + 1][t] = make_uint4(v.z, v.w, 0u, 0u);
+    }
+    auto n0_key_at = [&](uint32_t p, uint16_t &b, uint16_t &d) {
+        n0_from_codes(p, p >= 2 ? code_at(p - 2) : 0, p >= 1 ? code_at(p - 1) : 0, code_at(p), b, d);
+    };
+    // ---- DP over positions a .. a + len (the last one is clean: only its N0) ----------------------------------------------
+    uint16_t pv_b0 = 0, pv_d0 = 0;
+    int64_t pv_s0 = 0;
+    bool pv_valid = a > 0;
+    if (pv_valid) n0_key_at(a - 1, pv_b0, pv_d0);
+    uint32_t pv_k0 = 0, pv_n = 0;
+    int64_t s0_cur = 0;
+    for (uint32_t st = 0; st <= len; ++st) {
+        const uint32_t p = a + st;
+        const uint32_t k0 = s_off[st][t], n = s_off[st + 1][t] - k0;
+        const int64_t cov = s_cov[st][t];
+        uint16_t b0, d0;
+        n0_key_at(p, b0, d0);
+        uint32_t e0 = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint4 v = s_node[k0 + k][t];
+            if (node_delta3((uint16_t)v.x, (uint16_t)(v.x >> 16)) == 0) e0 += v.y;
+        }
+        const int64_t cn0 = cov - (int64_t)e0;
+        for (uint32_t idx = 0; idx <= n; ++idx) {
+            uint16_t kb = b0, kd = d0;
+            int64_t cnt = cn0;
+            if (idx) {
+                const uint4 v = s_node[k0 + idx - 1][t];
+                kb = (uint16_t)v.x, kd = (uint16_t)(v.x >> 16), cnt = v.y;
+            }
+            int64_t score;
+            uint32_t besti = 0;
+            if (((kb >> 4) & 0xF) == 15) { // (see k_dp_bt_long for the predecessor test)
+                score = 10 * cnt - 4 * cov;
+            } else {
+                score = SCORE_NEG;
+                const bool same_pos = (kb & 0x1000) != 0;
+                const uint32_t q = same_pos ? p : p - 1;
+                const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
+                uint32_t qk0 = 0, qn = 0;
+                uint16_t qb0 = 0, qd0 = 0;
+                int64_t qs0 = 0;
+                bool ok = false;
+                if (same_pos) {
+                    qk0 = k0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
+                } else if (pv_valid) {
+                    qk0 = pv_k0, qn = 1 + pv_n, qb0 = pv_b0, qd0 = pv_d0, qs0 = pv_s0, ok = true;
+                }
+                if (ok) {
+                    for (uint32_t pi = 0; pi < qn; ++pi) {
+                        uint16_t vb = qb0, vd = qd0;
+                        int64_t ps = qs0;
+                        if (pi) {
+                            const uint4 v = s_node[qk0 + pi - 1][t];
+                            vb = (uint16_t)v.x, vd = (uint16_t)(v.x >> 16);
+                            ps = (int64_t)(((uint64_t)v.w << 32) | v.z);
+                        }
+                        if ((vb & 0x10FFu) != want) continue;
+                        const uint16_t v2d = (vb & 0x4000) ? (uint16_t)(vd + 1) : (uint16_t)0;
+                        if (v2d != kd) continue;
+                        const uint32_t v1q = (vb >> 8) & 0xFu;
+                        if (q >= 3 && v1q == 15) continue; // main.rs:1666-1668
+                        const int64_t sc = ps + 10 * cnt - 4 * cov;
+                        if (sc > score || (sc == score && v1q != 4)) { // main.rs:1670
+                            score = sc;
+                            besti = pi;
+                        }
+                    }
+                }
+            }
+            if (idx) {
+                s_node[k0 + idx - 1][t].z = (uint32_t)(uint64_t)score;
+                s_node[k0 + idx - 1][t].w = (uint32_t)((uint64_t)score >> 32);
+                s_bi[k0 + idx - 1][t] = (uint8_t)besti;
+            } else {
+                s0_cur = score;
+                s_n0bi[st][t] = (uint8_t)besti;
+            }
+        }
+        pv_k0 = k0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
+    }
+    run_end[r] = a + len - 1;
+    run_gain[r] = s0_cur; // N0 of the closing clean position
+    // ---- backtrack from the closing position's best predecessor (bt_walk) --------------------------------------------------
+    uint64_t *out = path + (size_t)a + o_base;
+    uint32_t st = len - 1, idx = s_n0bi[len][t], n_out = 0;
+    for (;;) {
+        const uint32_t p = a + st;
+        const uint32_t k0 = s_off[st][t];
+        uint16_t kb, kd;
+        uint32_t cnt, bi;
+        if (idx == 0) {
+            n0_key_at(p, kb, kd);
+            uint32_t e0 = 0; // count of the contig's own node: coverage minus the exception nodes ending like it
+            for (uint32_t k = k0; k < s_off[st + 1][t]; ++k) {
+                const uint4 v = s_node[k][t];
+                if (node_delta3((uint16_t)v.x, (uint16_t)(v.x >> 16)) == 0) e0 += v.y;
+            }
+            cnt = (uint32_t)s_cov[st][t] - e0;
+            bi = s_n0bi[st][t];
+        } else {
+            const uint4 v = s_node[k0 + idx - 1][t];
+            kb = (uint16_t)v.x, kd = (uint16_t)(v.x >> 16);
+            cnt = v.y;
+            bi = s_bi[k0 + idx - 1][t];
+        }
+        const uint8_t k3q = kb & 0xF;
+        if (k3q != 4) {
+            const int64_t cov = s_cov[st][t];
+            const bool lq = (int64_t)cnt * 100 < 95 * cov;
+            const uint32_t cls = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
+            out[n_out++] = ((uint64_t)p << 32) | ((uint32_t)code_to_ascii(k3q) << 8) | cls;
+        }
+        if (((kb >> 4) & 0xF) == 15) {
+            if (p > 0) atomicMax(path_begin, p);
+            break;
+        }
+        if (!(kb & 0x1000)) { // second column at p - 1
+            if (st == 0) break; // left the run: N0(a - 1)
+            --st;
+        }
+        idx = bi;
+    }
+    emit[a] = n_out;
 }
 
 // absolute best-path score = clean-position gains (one partial per contig tile, from the graph build) + the gains
@@ -689,21 +941,21 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
             cnt = rc.y;
             bi = nbesti[o0 + idx - 1];
         }
-        AlignBase k1, k2, k3;
-        node_decode(kb, kd, pos, k1, k2, k3);
-        if (k3.q != 4) {
-            const int64_t cov = g.cov[k3.t_pos];
+        // third column: always at `pos`; second column: at `pos` iff bit 12 (node_decode)
+        const uint8_t k3q = kb & 0xF;
+        if (k3q != 4) {
+            const int64_t cov = g.cov[pos];
             // qv = count * 100 / coverage (integer division); qv < 95 <=> count * 100 < 95 * coverage
             const bool lq = (int64_t)cnt * 100 < 95 * cov;
             const uint32_t cls = cov < 2 ? CLS_RESET : (lq ? CLS_LQ : CLS_HQ);
-            path[n] = ((uint64_t)k3.t_pos << 32) | ((uint32_t)code_to_ascii(k3.q) << 8) | cls;
+            path[n] = ((uint64_t)pos << 32) | ((uint32_t)code_to_ascii(k3q) << 8) | cls;
             ++n;
         }
-        if (k2.is_head()) {
-            if (k3.t_pos > 0) atomicMax(path_begin, k3.t_pos);
+        if (((kb >> 4) & 0xF) == 15) { // second column is a head sentinel: the path starts here
+            if (pos > 0) atomicMax(path_begin, pos);
             break;
         }
-        const uint32_t np_ = k2.t_pos;
+        const uint32_t np_ = (kb & 0x1000) ? pos : pos - 1;
         if (np_ < a || np_ > pos) break; // left the run (np_ == a-1 -> N0(a-1)); np_ > pos: wrapped
         pos = np_;
         idx = bi;
@@ -711,20 +963,22 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
     return n;
 }
 
-__global__ void k_bt_count(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_end,
-                           const uint32_t *__restrict__ n_runs, Graph g, const uint32_t *__restrict__ nbesti,
-                           const uint32_t *__restrict__ n0_besti, const uint32_t *__restrict__ best_idx,
-                           uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
-                           uint64_t *__restrict__ path) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *n_runs) return;
-    const uint32_t a = run_start[r], b = run_end[r];
-    const uint32_t entry = (b + 1 < g.L) ? n0_besti[b + 1] : *best_idx;
+// The run that reaches the contig end is entered at the globally best node of the last position (k_pick_best), which
+// needs the gains of all runs: it is walked here, after them.  It exists iff the last position is dirty, and is the last run.
+__global__ void k_bt_end_run(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ n_runs, Graph g,
+                             const uint32_t *__restrict__ nbesti, const uint32_t *__restrict__ n0_besti,
+                             const uint32_t *__restrict__ best_idx, uint32_t *__restrict__ emit,
+                             uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t L = g.L, nr = *n_runs;
+    if (nr == 0 || g.node_off[L] == g.node_off[L - 1]) return;
+    const uint32_t a = run_start[nr - 1];
+    const uint32_t entry = *best_idx;
     if (entry == 0xFFFFFFFFu) { // negative best score at the contig end: the host reports it after its next read-back
         emit[a] = 0;
         return;
     }
-    emit[a] = bt_walk(g, a, b, entry, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
+    emit[a] = bt_walk(g, a, L - 1, entry, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
 }
 
 // positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
@@ -1095,24 +1349,30 @@ void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *
 }
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec}; }
 
-void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
-               uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end,
-               int64_t *last_n0_score, unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain,
-               const long long *tile_gain, uint32_t n_tiles) {
-    Graph g = mk_graph(gp);
+void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
+                     const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
+                     uint32_t *path_begin, uint64_t *path) {
     if (max_runs)
-        hipLaunchKernelGGL(k_dp_runs, grid1(max_runs, DP_BLOCK), dim3(DP_BLOCK), 0, s, run_start, n_runs, g, nrec, nscore,
-                           nbesti, n0_besti, run_end, last_n0_score, run_gain);
+        hipLaunchKernelGGL(k_dp_bt_short, grid1(max_runs, 64), dim3(64), 0, s, run_start, n_runs, mk_graph(gp),
+                           (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path);
+}
+void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                    uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
+                    uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
+                    uint64_t *path) {
+    if (max_runs)
+        hipLaunchKernelGGL(k_dp_bt_long, grid1(max_runs, DP_BLOCK), dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp),
+                           nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path);
+}
+void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                      const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
+                      unsigned long long *total_gain, uint32_t *best_idx, const int64_t *run_gain, const long long *tile_gain,
+                      uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
+    Graph g = mk_graph(gp);
     hipLaunchKernelGGL(k_sum_gains, dim3(64), dim3(256), 0, s, run_gain, n_runs, tile_gain, n_tiles, total_gain);
     hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
-}
-void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
-                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
-    Graph g = mk_graph(gp);
-    if (max_runs)
-        hipLaunchKernelGGL(k_bt_count, grid1(max_runs, 64), dim3(64), 0, s, run_start, run_end, n_runs, g, nbesti,
-                           n0_besti, best_idx, emit, path_begin, path);
+    hipLaunchKernelGGL(k_bt_end_run, dim3(1), dim3(64), 0, s, run_start, n_runs, g, nbesti, n0_besti, best_idx, emit,
+                       path_begin, path);
     hipLaunchKernelGGL(k_emit_fix, dim3(1), dim3(64), 0, s, emit, path_begin, gp.node_off, gp.L);
 }
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,

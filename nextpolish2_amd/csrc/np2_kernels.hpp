@@ -70,14 +70,20 @@ void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox,
                  const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
-void launch_dp(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs, uint32_t max_runs,
-               const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti, uint32_t *run_end, int64_t *last_n0_score,
-               unsigned long long *total_gain, uint32_t *best_idx, int64_t *run_gain, const long long *tile_gain,
-               uint32_t n_tiles);
-// backtrack of every dirty run: emitted-base counts + the bases themselves, recorded in `path` (L + T entries)
-void launch_bt_count(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *run_end,
-                     const uint32_t *n_runs, uint32_t max_runs, const uint32_t *nbesti, const uint32_t *n0_besti,
-                     const uint32_t *best_idx, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
+// DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
+// the generic kernel (independent of the first: the two may run on different streams); finish: score total, best end
+// node, backtrack of the contig-end run, emission fix-up left of the path start.
+void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
+                     const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
+                     uint32_t *path_begin, uint64_t *path);
+void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                    uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
+                    uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
+                    uint64_t *path);
+void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                      const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
+                      unsigned long long *total_gain, uint32_t *best_idx, const int64_t *run_gain, const long long *tile_gain,
+                      uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
 // consensus write-out: clean positions + the recorded run paths, one thread per contig position
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                      uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
