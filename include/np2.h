@@ -97,6 +97,14 @@ int np2_last_span(np2_ctx_t *ctx, uint32_t *first_pos, uint32_t *last_pos);
  * sequences over xGMI) instead of sending the host copy back up. */
 int np2_last_result_device(np2_ctx_t *ctx, const uint8_t **dev_bases, uint64_t *len);
 
+/* Deferred output for back-to-back contigs: call np2_polish_resident with out_bases == NULL (the sequence then stays
+ * on the device), then np2_result_fetch_begin: it snapshots the sequence and starts its device-to-host copy on a
+ * stream of its own, so the copy overlaps the next contig's kernels instead of ending this one's.
+ * np2_result_fetch_end waits for the copy and returns the host bytes: pinned memory owned by the context, valid
+ * until the second-next np2_result_fetch_begin.  One fetch may be in flight per context. */
+int np2_result_fetch_begin(np2_ctx_t *ctx);
+int np2_result_fetch_end(np2_ctx_t *ctx, const uint8_t **bases, uint64_t *len);
+
 /* Convenience: upload + polish + free (PCIe-inclusive). */
 int np2_polish_contig(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads,
                       uint32_t n_reads, const uint8_t *nibbles, uint64_t nib_bytes,

@@ -19,7 +19,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
-    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_phase_vote",
+    "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_result_fetch_begin", "np2_result_fetch_end", "np2_phase_vote",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -62,6 +62,8 @@ def lib():
         L.np2_last_timings.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.np2_last_span.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.np2_last_result_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.np2_result_fetch_begin.argtypes = [vp]
+        L.np2_result_fetch_end.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.np2_phase_vote.argtypes = [vp, u32, vp, vp, vp, u64, vp, vp, u32, C.c_int, vp, C.POINTER(u32)]
         _LIB = L
     return _LIB
@@ -156,10 +158,15 @@ class Polisher:
                                             C.byref(h)))
         return ResidentContig(self, h, pileup)
 
-    def polish_resident(self, contig: ResidentContig, opts: Opts = None, want_pos=True):
-        """np2_polish_resident.  want_pos=False returns (bases, (first_pos, last_pos)) — all a FASTA record needs."""
+    def polish_resident(self, contig: ResidentContig, opts: Opts = None, want_pos=True, defer_output=False):
+        """np2_polish_resident.  want_pos=False returns (bases, (first_pos, last_pos)) — all a FASTA record needs.
+        defer_output=True leaves the sequence on the device and returns (None, span): fetch it with fetch_begin() /
+        fetch_end() so that its host copy overlaps the next contig."""
         o = (opts or Opts()).c()
         ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        if defer_output:
+            self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), None, None, C.byref(on)))
+            return None, self.last_span()
         self._check(lib().np2_polish_resident(self._h, contig._h, C.byref(o), C.byref(ob),
                                               C.byref(op) if want_pos else None, C.byref(on)))
         n = on.value
@@ -171,6 +178,17 @@ class Polisher:
         a, b = C.c_uint32(), C.c_uint32()
         self._check(lib().np2_last_span(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def fetch_begin(self):
+        """np2_result_fetch_begin: start the host copy of the last (deferred) result on the output stream."""
+        self._check(lib().np2_result_fetch_begin(self._h))
+
+    def fetch_end(self):
+        """np2_result_fetch_end: wait for the copy; zero-copy view of the context's pinned buffer (valid until the
+        second-next fetch_begin)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(lib().np2_result_fetch_end(self._h, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value]
 
     def last_result_device(self):
         """(device address, length) of the last polished sequence in HBM; valid until the next call on this context."""

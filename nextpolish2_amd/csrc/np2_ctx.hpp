@@ -161,6 +161,14 @@ struct np2_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream for kernels that can overlap the main one (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // deferred output (np2_result_fetch_begin / _end): device snapshot, two pinned host buffers, their own stream
+    hipStream_t stream_out = nullptr;
+    hipEvent_t ev_out = nullptr;
+    uint8_t *out_host[2] = {nullptr, nullptr};
+    size_t out_host_cap[2] = {0, 0};
+    int out_slot = 0;
+    bool out_pending = false;
+    uint64_t out_len = 0;
     std::vector<YakTable> yaks;
     std::string err;
     bool trace = false;
@@ -216,6 +224,7 @@ struct np2_ctx {
     DevBuf<uint2> nrec;
     DevBuf<uint8_t> votebuf;
     DevBuf<int64_t> run_gain, tile_gain;
+    DevBuf<uint8_t> out_snap;
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;

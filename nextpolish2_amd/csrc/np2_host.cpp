@@ -704,6 +704,7 @@ struct ResultOut {
     uint32_t *pos = nullptr;
     uint64_t len = 0;
     bool want_pos = true;
+    bool want_bases = true; // false: the sequence stays on the device (np2_last_result_device / np2_result_fetch_begin)
 };
 void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, ResultOut &r) {
     const double t0 = now_ms();
@@ -713,10 +714,10 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     const uint32_t M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
     r.len = M;
-    r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
+    if (r.want_bases) r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
     if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
-    if (!r.bases || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
-    HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
+    if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+    if (r.want_bases) HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
     if (r.want_pos) HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
     uint32_t *span = (uint32_t *)cx->pin_d2h.ensure(16);
     HIPCHK(hipMemcpyAsync(span, dpos, 4, hipMemcpyDeviceToHost, cx->stream));
@@ -940,6 +941,13 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
 extern "C" {
 
 static void destroy_streams(np2_ctx *cx) {
+    if (cx->ev_out) (void)hipEventDestroy(cx->ev_out);
+    if (cx->stream_out) (void)hipStreamDestroy(cx->stream_out);
+    for (int i = 0; i < 2; ++i)
+        if (cx->out_host[i]) (void)hipHostFree(cx->out_host[i]);
+    cx->out_host[0] = cx->out_host[1] = nullptr;
+    cx->ev_out = nullptr;
+    cx->stream_out = nullptr;
     if (cx->ev_fork) (void)hipEventDestroy(cx->ev_fork);
     if (cx->ev_join) (void)hipEventDestroy(cx->ev_join);
     if (cx->stream2) (void)hipStreamDestroy(cx->stream2);
@@ -961,6 +969,8 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&cx->stream_out, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
         cx->scal.ensure(SCAL_TOTAL);
@@ -1018,6 +1028,7 @@ void np2_ctx_destroy(np2_ctx_t *cx) {
     (void)hipSetDevice(cx->device);
     if (cx->stream) (void)hipStreamSynchronize(cx->stream);
     if (cx->stream2) (void)hipStreamSynchronize(cx->stream2);
+    if (cx->stream_out) (void)hipStreamSynchronize(cx->stream_out);
     destroy_streams(cx);
     delete cx;
 }
@@ -1059,9 +1070,10 @@ void np2_contig_free(np2_ctx_t *cx, np2_contig_t *c) {
 
 int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, uint8_t **out_bases,
                         uint32_t **out_pos, uint64_t *out_len) {
-    if (!cx || !c || !opts || !out_bases || !out_len) return NP2_E_ARG;
+    if (!cx || !c || !opts || !out_len) return NP2_E_ARG;
     ResultOut r;
     r.want_pos = out_pos != nullptr;
+    r.want_bases = out_bases != nullptr;
     const double t_wall0 = now_ms();
     try {
         polish_impl(cx, c, opts, r);
@@ -1081,8 +1093,51 @@ int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, 
         return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     *out_len = r.len;
-    *out_bases = r.bases;
+    if (out_bases) *out_bases = r.bases;
     if (out_pos) *out_pos = r.pos;
+    return NP2_OK;
+}
+
+int np2_result_fetch_begin(np2_ctx_t *cx) {
+    if (!cx || !cx->last_dbase || cx->out_pending) return NP2_E_ARG;
+    try {
+        HIPCHK(hipSetDevice(cx->device));
+        const size_t n = cx->last_len;
+        cx->out_snap.ensure(n + 1);
+        uint8_t *&host = cx->out_host[cx->out_slot];
+        if (cx->out_host_cap[cx->out_slot] < n + 1) {
+            if (host) (void)hipHostFree(host);
+            host = nullptr;
+            const size_t cap = n + n / 8 + 4096;
+            if (hipHostMalloc((void **)&host, cap, hipHostMallocDefault) != hipSuccess)
+                throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+            cx->out_host_cap[cx->out_slot] = cap;
+        }
+        // snapshot on the main stream (in order before the next contig overwrites the consensus buffers), host copy on
+        // the output stream behind it
+        HIPCHK(hipMemcpyAsync(cx->out_snap.p, cx->last_dbase, n, hipMemcpyDeviceToDevice, cx->stream));
+        HIPCHK(hipEventRecord(cx->ev_out, cx->stream));
+        HIPCHK(hipStreamWaitEvent(cx->stream_out, cx->ev_out, 0));
+        HIPCHK(hipMemcpyAsync(host, cx->out_snap.p, n, hipMemcpyDeviceToHost, cx->stream_out));
+        cx->out_len = n;
+        cx->out_pending = true;
+    } catch (const Np2Error &e) {
+        return fail(cx, e);
+    }
+    return NP2_OK;
+}
+
+int np2_result_fetch_end(np2_ctx_t *cx, const uint8_t **bases, uint64_t *len) {
+    if (!cx || !bases || !len || !cx->out_pending) return NP2_E_ARG;
+    try {
+        HIPCHK(hipStreamSynchronize(cx->stream_out));
+    } catch (const Np2Error &e) {
+        return fail(cx, e);
+    }
+    *bases = cx->out_host[cx->out_slot];
+    *len = cx->out_len;
+    cx->out_slot ^= 1;
+    cx->out_pending = false;
     return NP2_OK;
 }
 

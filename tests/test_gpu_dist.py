@@ -49,3 +49,35 @@ def test_bench_under_torchrun_with_one_rank():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["fasta_identical_to_oracle"] is True
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+
+
+def test_deferred_output_fetch_overlaps_the_next_contig():
+    """np2_result_fetch_begin / _end: the host copy of contig i is started after contig i and collected after contig
+    i + 1; results equal the synchronous path."""
+    sa = Synth(60000, depth=20, seed=72, read_len_mean=6000.0, read_len_sd=900.0)
+    sb = Synth(90000, depth=20, seed=73, diploid=True, read_len_mean=6000.0, read_len_sd=900.0)
+    ya, yb = sa.yak(21), sb.yak(21)
+    pol = Polisher([ya])
+    polb = Polisher([yb])
+    ca, cb = pol.upload(sa.pileup), polb.upload(sb.pileup)
+    exp_a, span_a = pol.polish_resident(ca, Opts(), want_pos=False)
+    exp_a = exp_a.copy()
+    # same context, back to back: A deferred, A again (different options) deferred, collect in order
+    none, span = pol.polish_resident(ca, Opts(), want_pos=False, defer_output=True)
+    assert none is None and span == span_a
+    pol.fetch_begin()
+    with pytest.raises(Exception):
+        pol.fetch_begin()  # one fetch in flight per context
+    exp2, span2 = Polisher([ya]).polish(sa.pileup, Opts(iter_count=1))
+    _, s2 = pol.polish_resident(ca, Opts(iter_count=1), want_pos=False, defer_output=True)
+    got1 = pol.fetch_end().copy()
+    pol.fetch_begin()
+    got2 = pol.fetch_end().copy()
+    assert np.array_equal(got1, exp_a) and np.array_equal(got2, exp2) and s2 == (int(span2[0]), int(span2[-1]))
+    with pytest.raises(Exception):
+        pol.fetch_end()  # nothing in flight
+    # and on another context with another contig
+    eb, _ = polb.polish_resident(cb, Opts(), want_pos=False)
+    polb.polish_resident(cb, Opts(), want_pos=False, defer_output=True)
+    polb.fetch_begin()
+    assert np.array_equal(polb.fetch_end(), eb)
