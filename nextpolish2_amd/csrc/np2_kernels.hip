@@ -447,6 +447,18 @@ __device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
 // ------------------------------------------------------------------------------------------
 // K5/K6: dirty runs and the per-run DP (get_cns_from_align_tags, main.rs:1645-1687)
 // ------------------------------------------------------------------------------------------
+// Scores inside a run are relative to its left neighbour N0(a - 1), whose own score (the gains of everything before
+// the run) is added back by k_sum_gains.  That is exact as long as every path through the run comes from N0(a - 1) —
+// not so for a run starting at position 1 or 2: there a read's head-sentinel start node is a live alternative
+// (main.rs:1666-1668 only rejects them from t_pos 3 on) and carries an absolute score, so the run has to know the
+// absolute score of N0(a - 1) as well.  N0(1)'s only possible predecessor is N0(0), a path start itself.
+__device__ __forceinline__ int64_t early_run_base(const Graph &g, uint32_t a) {
+    if (a != 1 && a != 2) return 0;
+    int64_t s = 10 * (int64_t)(int32_t)n0_count(g, 0) - 4 * (int64_t)g.cov[0]; // N0(0): a path start
+    if (a == 2) s += 6 * (int64_t)g.cov[1]; // position 1 is clean: count == coverage
+    return s;
+}
+
 // ---- run classes ---------------------------------------------------------------------------------------------------------
 // A "short" run (99.9 % of them at HiFi error rates) has at most RW_P - 1 dirty positions followed by a clean one (inside the contig) and at most RW_N
 // exception nodes: k_dp_bt_short scores and backtracks it entirely on chip.  Everything else (long runs, the run that
@@ -557,7 +569,8 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
     // previous position (starts as the clean position a-1: only N0, score 0 by convention)
     uint32_t pv_o0 = 0, pv_n = 0; // exception nodes of the previous position
     uint16_t pv_b0 = 0, pv_d0 = 0;
-    int64_t pv_s0 = 0;
+    const int64_t base = early_run_base(g, a);
+    int64_t pv_s0 = base;
     bool pv_valid = a > 0;
     if (pv_valid) n0_from_codes(a - 1, c3, c2, c1, pv_b0, pv_d0);
     for (uint32_t p = a; p < L; ++p) {
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
         }
         if (!in_run) { // p == b+1: the clean position closing the run; its N0 is scored above
             run_end[r] = p - 1;
-            run_gain[r] = s0_cur; // summed by k_sum_gains (one same-address atomic per run would serialise at L2)
+            run_gain[r] = s0_cur - base; // summed by k_sum_gains (one same-address atomic per run would serialise at L2)
             // backtrack from this closing position's best predecessor (the thread's own stores, read back in order)
             emit[a] = bt_walk(g, a, p - 1, n0_besti[p], nbesti, n0_besti, path_begin, path + (size_t)a + o_first);
             return;
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
     }
     // the run reaches the contig end
     run_end[r] = L - 1;
-    run_gain[r] = 0;
+    run_gain[r] = -base; // (k_pick_best adds the total of all gains to this run's scores, which already contain `base`)
     *last_n0_score = pv_s0;
 }
 
@@ -750,7 +763,8 @@ __global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__
     };
     // ---- DP over positions a .. a + len (the last one is clean: only its N0) ----------------------------------------------
     uint16_t pv_b0 = 0, pv_d0 = 0;
-    int64_t pv_s0 = 0;
+    const int64_t base = early_run_base(g, a);
+    int64_t pv_s0 = base;
     bool pv_valid = a > 0;
     if (pv_valid) n0_key_at(a - 1, pv_b0, pv_d0);
     uint32_t pv_k0 = 0, pv_n = 0;
@@ -826,7 +840,7 @@ __global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__
         pv_k0 = k0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
     }
     run_end[r] = a + len - 1;
-    run_gain[r] = s0_cur; // N0 of the closing clean position
+    run_gain[r] = s0_cur - base; // N0 of the closing clean position
     // ---- backtrack from the closing position's best predecessor (bt_walk) --------------------------------------------------
     uint64_t *out = path + (size_t)a + o_base;
     uint32_t st = len - 1, idx = s_n0bi[len][t], n_out = 0;
