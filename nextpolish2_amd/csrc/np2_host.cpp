@@ -602,9 +602,9 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
         launch_dp_finish(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
                          (const int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
-                         cx->scal.p + S_BEST, cx->run_gain.p, (const long long *)cx->tile_gain.p,
+                         cx->scal.p + S_DUP /* block counter: reset with the per-pass scalars */, cx->scal.p + S_BEST,
+                         cx->run_gain.p, (const long long *)cx->tile_gain.p,
                          (c->L + TILE - 1) >> TILE_SHIFT, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
-        zero32(cx, cx->emit.p + L, 1);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
         launch_bt_write(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p,
                         cx->lq_nothead.p);

@@ -448,7 +448,7 @@ __device__ __forceinline__ uint32_t n0_count(const Graph &g, uint32_t p) {
 // K5/K6: dirty runs and the per-run DP (get_cns_from_align_tags, main.rs:1645-1687)
 // ------------------------------------------------------------------------------------------
 // Scores inside a run are relative to its left neighbour N0(a - 1), whose own score (the gains of everything before
-// the run) is added back by k_sum_gains.  That is exact as long as every path through the run comes from N0(a - 1) —
+// the run) is added back by k_dp_finish.  That is exact as long as every path through the run comes from N0(a - 1) —
 // not so for a run starting at position 1 or 2: there a read's head-sentinel start node is a live alternative
 // (main.rs:1666-1668 only rejects them from t_pos 3 on) and carries an absolute score, so the run has to know the
 // absolute score of N0(a - 1) as well.  N0(1)'s only possible predecessor is N0(0), a path start itself.
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
                     s_node[bank * DP_NR + k][t].w = (uint32_t)((uint64_t)score >> 32);
                 }
                 // scores are only read back from memory past the LDS cache and, at the contig's last position, by
-                // k_pick_best: skip the scattered 8-byte store otherwise
+                // k_dp_finish: skip the scattered 8-byte store otherwise
                 if (k >= DP_NR || p + 1 == L) nscore[o0 + k] = score;
                 nbesti[o0 + k] = besti;
             } else {
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
         }
         if (!in_run) { // p == b+1: the clean position closing the run; its N0 is scored above
             run_end[r] = p - 1;
-            run_gain[r] = s0_cur - base; // summed by k_sum_gains (one same-address atomic per run would serialise at L2)
+            run_gain[r] = s0_cur - base; // summed by k_dp_finish (one same-address atomic per run would serialise at L2)
             // backtrack from this closing position's best predecessor (the thread's own stores, read back in order)
             emit[a] = bt_walk(g, a, p - 1, n0_besti[p], nbesti, n0_besti, path_begin, path + (size_t)a + o_first);
             return;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
     }
     // the run reaches the contig end
     run_end[r] = L - 1;
-    run_gain[r] = -base; // (k_pick_best adds the total of all gains to this run's scores, which already contain `base`)
+    run_gain[r] = -base; // (k_dp_finish adds the total of all gains to this run's scores, which already contain `base`)
     *last_n0_score = pv_s0;
 }
 
@@ -884,49 +884,22 @@ __global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__
     emit[a] = n_out;
 }
 
-// absolute best-path score = clean-position gains (one partial per contig tile, from the graph build) + the gains
-// of all dirty runs: grid-stride partial sums, one atomic per block
-__global__ __launch_bounds__(256) void k_sum_gains(const int64_t *__restrict__ run_gain,
-                                                   const uint32_t *__restrict__ n_runs,
-                                                   const long long *__restrict__ tile_gain, uint32_t n_tiles,
-                                                   unsigned long long *__restrict__ total_gain) {
-    long long v = 0;
-    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nr = *n_runs;
-    for (uint32_t r = t0; r < nr; r += stride) v += run_gain[r];
-    for (uint32_t t = t0; t < n_tiles; t += stride) v += tile_gain[t];
-    __shared__ long long sm[4];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const long long s = sm[0] + sm[1] + sm[2] + sm[3];
-        if (s) atomicAdd(total_gain, (unsigned long long)s);
-    }
-}
-
 // global best node at L-1 (main.rs:1651,1680): later node wins ties, must reach score >= 0
-__global__ void k_pick_best(Graph g, const int64_t *__restrict__ nscore, const int64_t *__restrict__ last_n0_score,
-                            const unsigned long long *__restrict__ total_gain, uint32_t *__restrict__ best_idx) {
-    if (blockIdx.x || threadIdx.x) return;
+__device__ uint32_t pick_best(const Graph &g, const int64_t *__restrict__ nscore, int64_t last_n0_score, int64_t total) {
     const uint32_t p = g.L - 1;
     const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
-    const int64_t total = (int64_t)*total_gain;
-    if (o1 == o0) {
-        *best_idx = total >= 0 ? 0u : 0xFFFFFFFFu;
-        return;
-    }
+    if (o1 == o0) return total >= 0 ? 0u : 0xFFFFFFFFu;
     int64_t best = 0;
     uint32_t bi = 0xFFFFFFFFu;
     for (uint32_t idx = 0; idx < 1 + (o1 - o0); ++idx) {
-        const int64_t rel = idx ? nscore[o0 + idx - 1] : *last_n0_score;
+        const int64_t rel = idx ? nscore[o0 + idx - 1] : last_n0_score;
         const int64_t s = rel <= (SCORE_NEG / 2) ? rel : total + rel;
         if (s >= best) {
             best = s;
             bi = idx;
         }
     }
-    *best_idx = bi;
+    return bi;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -977,42 +950,64 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
     return n;
 }
 
-// The run that reaches the contig end is entered at the globally best node of the last position (k_pick_best), which
-// needs the gains of all runs: it is walked here, after them.  It exists iff the last position is dirty, and is the last run.
-__global__ void k_bt_end_run(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ n_runs, Graph g,
-                             const uint32_t *__restrict__ nbesti, const uint32_t *__restrict__ n0_besti,
-                             const uint32_t *__restrict__ best_idx, uint32_t *__restrict__ emit,
-                             uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
-    if (blockIdx.x || threadIdx.x) return;
-    const uint32_t L = g.L, nr = *n_runs;
-    if (nr == 0 || g.node_off[L] == g.node_off[L - 1]) return;
-    const uint32_t a = run_start[nr - 1];
-    const uint32_t entry = *best_idx;
-    if (entry == 0xFFFFFFFFu) { // negative best score at the contig end: the host reports it after its next read-back
-        emit[a] = 0;
-        return;
+// End of the DP stage in one launch.  Every block adds its share of the gains (clean-position partials per contig tile
+// from the graph build + the dirty runs') to the absolute best-path score; the last block to finish then does the three
+// things that need that total, in order, on one thread:
+//  * the best end node at the last position;
+//  * the backtrack of the run that reaches the contig end (it exists iff the last position is dirty, and is the last
+//    run): it is entered at that best node, so it could not be walked with the others;
+//  * positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
+//    main.rs:1666-1668, so at most positions 0..1 are affected); emit[L] = 0 terminates the offset scan.
+__global__ __launch_bounds__(256) void k_dp_finish(const int64_t *__restrict__ run_gain, const uint32_t *__restrict__ n_runs,
+                                                   const long long *__restrict__ tile_gain, uint32_t n_tiles,
+                                                   unsigned long long *__restrict__ total_gain,
+                                                   uint32_t *__restrict__ blocks_done, Graph g,
+                                                   const int64_t *__restrict__ nscore,
+                                                   const int64_t *__restrict__ last_n0_score,
+                                                   const uint32_t *__restrict__ run_start,
+                                                   const uint32_t *__restrict__ nbesti,
+                                                   const uint32_t *__restrict__ n0_besti, uint32_t *__restrict__ best_idx,
+                                                   uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
+                                                   uint64_t *__restrict__ path) {
+    long long v = 0;
+    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nr = *n_runs;
+    for (uint32_t r = t0; r < nr; r += stride) v += run_gain[r];
+    for (uint32_t t = t0; t < n_tiles; t += stride) v += tile_gain[t];
+    __shared__ long long sm[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x) return;
+    const long long sum = sm[0] + sm[1] + sm[2] + sm[3];
+    if (sum) atomicAdd(total_gain, (unsigned long long)sum);
+    __threadfence();
+    if (atomicAdd(blocks_done, 1u) != gridDim.x - 1) return;
+    __threadfence();
+    const int64_t total = (int64_t)atomicAdd(total_gain, 0ULL); // (the device-coherent value)
+    const uint32_t L = g.L;
+    const uint32_t best = pick_best(g, nscore, *last_n0_score, total);
+    *best_idx = best;
+    if (nr != 0 && g.node_off[L] != g.node_off[L - 1]) {
+        const uint32_t a = run_start[nr - 1];
+        // (a negative best score at the contig end is reported by the host after its next read-back)
+        emit[a] = best == 0xFFFFFFFFu ? 0u
+                                      : bt_walk(g, a, L - 1, best, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
     }
-    emit[a] = bt_walk(g, a, L - 1, entry, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
-}
-
-// positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
-// main.rs:1666-1668, so at most positions 0..1 are affected)
-__global__ void k_emit_fix(uint32_t *__restrict__ emit, const uint32_t *__restrict__ path_begin,
-                           const uint32_t *__restrict__ node_off, uint32_t L) {
-    if (blockIdx.x || threadIdx.x) return;
-    const uint32_t pb = *path_begin;
+    const uint32_t pb = atomicMax(path_begin, 0u);
     uint32_t p = 0;
     while (p < pb && p < L) {
-        if (!(node_off[p + 1] > node_off[p])) {
+        if (!(g.node_off[p + 1] > g.node_off[p])) {
             emit[p] = 0; // clean position before the path start
             ++p;
         } else {
             uint32_t e = p;
-            while (e + 1 < L && node_off[e + 2] > node_off[e + 1]) ++e;
+            while (e + 1 < L && g.node_off[e + 2] > g.node_off[e + 1]) ++e;
             if (e < pb) emit[p] = 0; // whole dirty run lies before the path start
             p = e + 1;
         }
     }
+    emit[L] = 0;
 }
 
 // Consensus write-out, one thread per contig position: a clean position emits the contig base; the first position of a
@@ -1380,14 +1375,11 @@ void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
 }
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
-                      unsigned long long *total_gain, uint32_t *best_idx, const int64_t *run_gain, const long long *tile_gain,
-                      uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
-    Graph g = mk_graph(gp);
-    hipLaunchKernelGGL(k_sum_gains, dim3(64), dim3(256), 0, s, run_gain, n_runs, tile_gain, n_tiles, total_gain);
-    hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(64), 0, s, g, nscore, last_n0_score, total_gain, best_idx);
-    hipLaunchKernelGGL(k_bt_end_run, dim3(1), dim3(64), 0, s, run_start, n_runs, g, nbesti, n0_besti, best_idx, emit,
+                      unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
+                      const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
+    hipLaunchKernelGGL(k_dp_finish, dim3(64), dim3(256), 0, s, run_gain, n_runs, tile_gain, n_tiles, total_gain,
+                       blocks_done, mk_graph(gp), nscore, last_n0_score, run_start, nbesti, n0_besti, best_idx, emit,
                        path_begin, path);
-    hipLaunchKernelGGL(k_emit_fix, dim3(1), dim3(64), 0, s, emit, path_begin, gp.node_off, gp.L);
 }
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                      uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {

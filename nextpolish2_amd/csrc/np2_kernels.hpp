@@ -82,8 +82,8 @@ void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
                     uint64_t *path);
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
-                      unsigned long long *total_gain, uint32_t *best_idx, const int64_t *run_gain, const long long *tile_gain,
-                      uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
+                      unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
+                      const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
 // consensus write-out: clean positions + the recorded run paths, one thread per contig position
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                      uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
