@@ -316,7 +316,8 @@ template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
 inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0 = nullptr, const uint32_t *s0 = nullptr,
                                         uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
                                         const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr,
-                                        const uint32_t *s3 = nullptr);
+                                        const uint32_t *s3 = nullptr, const uint32_t *ends_of = nullptr,
+                                        uint32_t *ends_dst = nullptr);
 
 // host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
 inline void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
@@ -334,9 +335,10 @@ template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name
 }
 
 inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_t *s0, uint32_t *d1, const uint32_t *s1,
-                                        uint32_t *d2, const uint32_t *s2, uint32_t *d3, const uint32_t *s3) {
+                                        uint32_t *d2, const uint32_t *s2, uint32_t *d3, const uint32_t *s3,
+                                        const uint32_t *ends_of, uint32_t *ends_dst) {
     const uint32_t seq = ++cx->mbox_seq;
-    launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, d0, s0, d1, s1, d2, s2, d3, s3);
+    launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, d0, s0, d1, s1, d2, s2, d3, s3, ends_of, ends_dst);
     uint64_t spins = 0;
     while (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0xFFFF) == 0) { // a failed launch / device fault would never post: surface it

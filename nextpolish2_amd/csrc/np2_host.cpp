@@ -709,7 +709,9 @@ struct ResultOut {
 void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, ResultOut &r) {
     const double t0 = now_ms();
     // final length + the error word of everything that ran without a read-back since the last one
-    const std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
+    // (the same post carries the first and the last consensus position: the FASTA header span)
+    const std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                nullptr, dpos, cx->scal.p + S_M1);
     check_region_err(cx, sc[S_ERR]);
     const uint32_t M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
@@ -719,12 +721,9 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
     if (r.want_bases) HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
     if (r.want_pos) HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
-    uint32_t *span = (uint32_t *)cx->pin_d2h.ensure(16);
-    HIPCHK(hipMemcpyAsync(span, dpos, 4, hipMemcpyDeviceToHost, cx->stream));
-    HIPCHK(hipMemcpyAsync(span + 1, dpos + (M - 1), 4, hipMemcpyDeviceToHost, cx->stream));
-    HIPCHK(hipStreamSynchronize(cx->stream));
-    cx->last_first_pos = span[0];
-    cx->last_last_pos = span[1];
+    if (r.want_bases || r.want_pos) HIPCHK(hipStreamSynchronize(cx->stream));
+    cx->last_first_pos = sc[S_M1];
+    cx->last_last_pos = sc[S_M2];
     cx->last_dbase = dbase;
     cx->last_len = M;
     if (cx->stage_timing) cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});

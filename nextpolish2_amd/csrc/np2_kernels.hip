@@ -387,12 +387,18 @@ __global__ __launch_bounds__(256) void k_diff_reads(
 __global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *__restrict__ mbox, uint32_t seq,
                        uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
                        const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
-                       uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3) {
+                       uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3,
+                       const uint32_t *__restrict__ ends_of, uint32_t *__restrict__ ends_dst) {
     if (threadIdx.x == 0) {
         if (dst0) *dst0 = *src0;
         if (dst1) *dst1 = *src1;
         if (dst2) *dst2 = *src2;
         if (dst3) *dst3 = *src3;
+        if (ends_of) { // first and last element of an array whose device-side length was just gathered into *dst0
+            const uint32_t n = *dst0;
+            ends_dst[0] = n ? ends_of[0] : 0u;
+            ends_dst[1] = n ? ends_of[n - 1] : 0u;
+        }
     }
     __threadfence();
     if (threadIdx.x < n_scal) // one wavefront: a single store instruction posts the whole block
@@ -1347,8 +1353,9 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
 }
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
                  const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,
-                 const uint32_t *s3) {
-    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, s, scal, n_scal, mbox, seq, d0, s0, d1, s1, d2, s2, d3, s3);
+                 const uint32_t *s3, const uint32_t *ends_of, uint32_t *ends_dst) {
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, s, scal, n_scal, mbox, seq, d0, s0, d1, s1, d2, s2, d3, s3, ends_of,
+                       ends_dst);
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
     hipLaunchKernelGGL(k_init_alive, grid1(R), dim3(256), 0, s, reads, R, alive);

@@ -67,7 +67,8 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
                        uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err);
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0 = nullptr,
                  const uint32_t *s0 = nullptr, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
-                 const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr);
+                 const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr,
+                 const uint32_t *ends_of = nullptr, uint32_t *ends_dst = nullptr);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 // DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
