@@ -96,6 +96,8 @@ class SequenceGatherer:
         self.bufs = [self.flat[r * stride + self.HDR:(r + 1) * stride] for r in range(self.world)]
         self.lens = [self.flat[r * stride:r * stride + self.HDR].view(torch.int64) for r in range(self.world)]
         self._len_host = torch.zeros(1, dtype=torch.int64)
+        self._hdr = self.local[:self.HDR].view(torch.int64)
+        self._views = {}  # (device address, length) -> zero-copy tensor (the np2 result buffers are few and stable)
         if self.device.type == "cuda":
             self._len_host = self._len_host.pin_memory()
             self._copied = torch.cuda.Event()
@@ -113,7 +115,7 @@ class SequenceGatherer:
         if n > self.cap:
             raise ValueError("polished contig longer than the gather capacity")
         self._len_host[0] = n
-        self.local[:self.HDR].view(torch.int64).copy_(self._len_host, non_blocking=True)
+        self._hdr.copy_(self._len_host, non_blocking=True)
         self.local[self.HDR:self.HDR + n].copy_(src, non_blocking=True)
         if self.device.type == "cuda":
             self._copied.record()
@@ -124,8 +126,15 @@ class SequenceGatherer:
 
     def gather_device(self, ptr, n):
         """Gather straight from a device buffer (np2_last_result_device): no host round trip."""
-        with torch.cuda.device(self.device):
-            return self.gather_tensor(torch.as_tensor(_DeviceBytes(ptr, n), device=self.device))
+        if n > self.cap:
+            raise ValueError("polished contig longer than the gather capacity")
+        view = self._views.get((ptr, n))
+        if view is None:
+            if len(self._views) > 16:
+                self._views.clear()
+            with torch.cuda.device(self.device):
+                view = self._views[(ptr, n)] = torch.as_tensor(_DeviceBytes(ptr, n), device=self.device)
+        return self.gather_tensor(view)
 
     def gather(self, bases):
         """bases: 1-D uint8 numpy array on the host. Returns (list of device tensors, lengths)."""
