@@ -433,8 +433,11 @@ __global__ __launch_bounds__(256) void k_splice_plan(Lookback lb, uint32_t n_blo
         *M_out = *M_in + pre_d + dsum;
     }
 }
-// copy the bases outside the applied regions to their shifted places.  The slot search is done once per block for
-// the block's first and last index; threads only search the (usually empty) slot range in between.
+// copy the bases outside the applied regions to their shifted places.  A block covers SPLICE_SPAN consecutive consensus
+// indices (coalesced, several per thread): the slot search — a latency chain over the applied-region starts — is done once
+// per block for its first and last index with 16 probes in flight per round, threads only search the (usually empty)
+// slot range in between.
+static constexpr uint32_t SPLICE_SPAN = 2048;
 __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict__ in_pos,
                                                       const uint8_t *__restrict__ in_base,
                                                       const uint32_t *__restrict__ M_p,
@@ -443,34 +446,31 @@ __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ n_ap_p, uint32_t *__restrict__ out_pos,
                                                       uint8_t *__restrict__ out_base) {
     __shared__ uint32_t s_lo[2];
-    const uint32_t i0 = blockIdx.x * blockDim.x;
-    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t i0 = blockIdx.x * SPLICE_SPAN;
     const uint32_t n_ap = *n_ap_p, M = *M_p;
     if (i0 >= M) return;
-    if (threadIdx.x < 2) { // number of slots with ap_s <= first / last index of the block
-        const uint32_t key = threadIdx.x == 0 ? i0 : min(M - 1, i0 + blockDim.x - 1);
-        uint32_t lo = 0, hi = n_ap;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (ap_s[mid] <= key) lo = mid + 1; else hi = mid;
-        }
-        s_lo[threadIdx.x] = lo;
-    }
+    if (threadIdx.x < 2) // number of slots with ap_s <= first / last index of the block
+        s_lo[threadIdx.x] = upper_bound_u32(ap_s, n_ap, threadIdx.x == 0 ? i0 : min(M - 1, i0 + SPLICE_SPAN - 1));
     __syncthreads();
-    if (i >= M) return;
-    uint32_t lo = s_lo[0], hi = s_lo[1];
-    while (lo < hi) { // last slot with ap_s <= i
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
+    const uint32_t blo = s_lo[0], bhi = s_lo[1];
+#pragma unroll
+    for (uint32_t k = 0; k < SPLICE_SPAN / 256; ++k) {
+        const uint32_t i = i0 + k * 256 + threadIdx.x;
+        if (i >= M) break;
+        uint32_t lo = blo, hi = bhi;
+        while (lo < hi) { // last slot with ap_s <= i
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
+        }
+        int64_t o = i;
+        if (lo > 0) {
+            const uint32_t sl = lo - 1;
+            if (i < ap_e[sl]) continue; // replaced by the region's seed
+            o += ap_shift_incl[sl];
+        }
+        out_pos[o] = in_pos[i];
+        out_base[o] = in_base[i];
     }
-    int64_t o = i;
-    if (lo > 0) {
-        const uint32_t sl = lo - 1;
-        if (i < ap_e[sl]) return; // replaced by the region's seed
-        o += ap_shift_incl[sl];
-    }
-    out_pos[o] = in_pos[i];
-    out_base[o] = in_base[i];
 }
 __global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t *__restrict__ ap_s,
                                const int32_t *__restrict__ ap_delta, const int32_t *__restrict__ ap_shift_incl,
@@ -830,7 +830,7 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                          const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base) {
-    hipLaunchKernelGGL(k_splice_bases, g1(M_cap), dim3(256), 0, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap,
+    hipLaunchKernelGGL(k_splice_bases, dim3((M_cap + SPLICE_SPAN - 1) / SPLICE_SPAN), dim3(256), 0, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap,
                        out_pos, out_base);
     if (max_ap)
         hipLaunchKernelGGL(k_splice_seeds, g1(max_ap, 64), dim3(64), 0, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap,
