@@ -62,3 +62,16 @@ def test_random_configurations(stream):
                  o=dict(min_kmer_count=int(rng.choice([2, 5, 8])), iter_count=int(rng.choice([1, 2, 3])),
                         model=str(rng.choice(["ref", "len"])), use_all_reads=bool(rng.integers(0, 2)),
                         max_indel_len=int(rng.choice([5, 20]))))
+
+
+def test_one_context_many_contigs():
+    """tests/tools/fuzz_reuse.py: one context polishing different contigs back to back, in all three output modes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_reuse.py"), "9", "5"], capture_output=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    last = r.stdout.decode().strip().splitlines()[-1]
+    assert last.startswith("reuse polishes") and last.endswith("bad 0"), r.stdout.decode()[-2000:]
