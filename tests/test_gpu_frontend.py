@@ -185,3 +185,44 @@ def test_secondary_alignments_recover_seq_from_the_primary(tmp_path):
     with pytest.raises(Np2Error):
         np2io.contig_from_bam(pol, np2io.Bam(str(tmp_path / "b.bam")), "ctgB", s2.pileup.ref.tobytes(), fo)
 
+
+
+def test_cli_many_contigs_concurrent_contexts(tmp_path):
+    """16 contigs of mixed size and ploidy through 1 and 4 concurrent contexts: identical output, in input order."""
+    rng = np.random.default_rng(7)
+    syn, recs, refs = [], [], []
+    for i in range(16):
+        L = int(rng.choice([12000, 25000, 60000, 110000]))
+        s = Synth(L, depth=int(rng.choice([10, 25])), seed=200 + i, diploid=bool(i % 3 == 0), read_len_mean=5000.0, read_len_sd=800.0,
+                  name=f"c{i}")
+        syn.append(s)
+        refs.append((f"c{i}", s.pileup.L))
+        recs += pileup_to_records(s.pileup, tid=i, rng=np.random.default_rng(300 + i), decorate=True)
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    write_bam(str(tmp_path / "m.bam"), refs, recs)
+    with gzip.open(tmp_path / "g.fa.gz", "wt") as f:
+        for i, s in enumerate(syn):
+            f.write(f">c{i}\n{s.pileup.ref.tobytes().decode()}\n")
+    from test_oracle import yak_from_seqs
+    haps = []
+    for s in syn:
+        haps += [s.hap1.decode()] + ([s.hap2.decode()] if s.diploid else [])
+    np2io.write_yak(str(tmp_path / "k21.yak"), yak_from_seqs(haps, 21))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    outs = []
+    for t in ("1", "4", "4"):
+        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-t", t, "-L", "10000", str(tmp_path / "m.bam"),
+                            str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0].count(b">") == 16
+    # spot check against the oracle
+    y21 = np2io.load_yak(str(tmp_path / "k21.yak"))
+    o = orc.Oracle([y21])
+    for tid in (0, 5, 15):
+        rr = [r for r in recs if r["tid"] == tid]
+        arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
+        pu = orc.front_end(syn[tid].pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts())
+        b, p = o.polish(pu, Opts())
+        assert b">c%d start:%d end:%d\n%s\n" % (tid, p[0], p[-1], b.tobytes()) in outs[0]
