@@ -1080,12 +1080,14 @@ int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, 
         flush_timings(cx);
     } catch (const Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);
+        if (cx->stream2) (void)hipStreamSynchronize(cx->stream2); // (a failure between fork and join leaves work there)
         flush_timings(cx);
         if (r.bases) pinned_pool().put(r.bases);
         if (r.pos) pinned_pool().put(r.pos);
         return fail(cx, e);
     } catch (const std::exception &ex) {
         (void)hipStreamSynchronize(cx->stream);
+        if (cx->stream2) (void)hipStreamSynchronize(cx->stream2); // (a failure between fork and join leaves work there)
         flush_timings(cx);
         if (r.bases) pinned_pool().put(r.bases);
         if (r.pos) pinned_pool().put(r.pos);
