@@ -507,6 +507,7 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
 // free); a position with more than DP_NR exception nodes falls back to global memory for the excess.
 static constexpr uint32_t DP_NR = 8; // exception nodes of one position cached in LDS (per thread)
 static constexpr uint32_t DP_BLOCK = 64;
+static constexpr uint32_t DP_GRID_CAP = 8192; // workgroups of the per-run kernels (grid-stride beyond)
 
 __device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1, uint8_t c0, uint16_t &bases,
                                               uint16_t &delta) {
@@ -525,20 +526,14 @@ __device__ __forceinline__ void n0_from_codes(uint32_t p, uint8_t c2, uint8_t c1
 // The serial DP over a run's positions never waits on memory inside a position: while position p is scored, the
 // scalars of p + 1 (node_off, coverage, contig code) and the DP_NR node records that follow p's are in flight; they
 // are consumed / parked in the other LDS bank at the end of the step.
-__global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restrict__ run_start,
-                                                      const uint32_t *__restrict__ n_runs, Graph g,
-                                                      const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
-                                                      uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
-                                                      uint32_t *__restrict__ run_end,
-                                                      int64_t *__restrict__ last_n0_score,
-                                                      int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
-                                                      uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
-    // one 16-byte LDS word per cached node: {key, count, score lo, score hi} (a node is read as a whole: the DP chain
-    // is bound by LDS round trips, not by bytes)
-    __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
+__device__ __forceinline__ void dp_bt_long_run(uint32_t r, const uint32_t *__restrict__ run_start, const Graph &g,
+                                               const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
+                                               uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
+                                               uint32_t *__restrict__ run_end, int64_t *__restrict__ last_n0_score,
+                                               int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
+                                               uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
+                                               uint4 (*s_node)[DP_BLOCK]) {
     const uint32_t t = threadIdx.x;
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *n_runs) return;
     const uint32_t a = run_start[r], L = g.L;
     uint32_t o0, o1;
     {
@@ -695,6 +690,24 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
     *last_n0_score = pv_s0;
 }
 
+// (grid-stride over a capped grid, see k_dp_bt_short)
+__global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restrict__ run_start,
+                                                      const uint32_t *__restrict__ n_runs, Graph g,
+                                                      const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
+                                                      uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
+                                                      uint32_t *__restrict__ run_end,
+                                                      int64_t *__restrict__ last_n0_score,
+                                                      int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
+                                                      uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+    // one 16-byte LDS word per cached node: {key, count, score lo, score hi} (a node is read as a whole: the DP chain
+    // is bound by LDS round trips, not by bytes)
+    __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
+    const uint32_t nr = *n_runs;
+    for (uint32_t r = blockIdx.x * DP_BLOCK + threadIdx.x; r < nr; r += gridDim.x * DP_BLOCK)
+        dp_bt_long_run(r, run_start, g, nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
+                       path, s_node);
+}
+
 // ------------------------------------------------------------------------------------------
 // Short runs: DP and backtrack of a run in one go, entirely out of LDS.
 //
@@ -704,19 +717,12 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
 // node records), scored, walked back and written out as its path slice; scores and best predecessors never leave
 // the chip.  Long runs and the run that reaches the contig end belong to k_dp_bt_long.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__ run_start,
-                                                    const uint32_t *__restrict__ n_runs, Graph g,
+__device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__restrict__ run_start, const Graph &g,
                                                     const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
                                                     int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
-                                                    uint64_t *__restrict__ path) {
-    __shared__ uint8_t s_off[RW_P + 1][64]; // node offsets relative to the run's first node (<= RW_N)
-    __shared__ int32_t s_cov[RW_P][64];
-    __shared__ uint4 s_node[RW_N][64]; // {key, count, score lo, score hi}: one LDS round trip per node
-    __shared__ uint8_t s_bi[RW_N][64];
-    __shared__ uint8_t s_n0bi[RW_P][64];
+                                                    uint64_t *__restrict__ path, uint8_t (*s_off)[64], int32_t (*s_cov)[64],
+                                                    uint4 (*s_node)[64], uint8_t (*s_bi)[64], uint8_t (*s_n0bi)[64]) {
     const uint32_t t = threadIdx.x;
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *n_runs) return;
     const uint32_t a = run_start[r], L = g.L;
     // ---- node offsets of positions a .. a + RW_P, run class -----------------------------------------------------------
     uint32_t len, nn, o_base;
@@ -888,6 +894,24 @@ __global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__
         idx = bi;
     }
     emit[a] = n_out;
+}
+
+// One thread per short run, grid-stride: the launch covers a host-side bound on the number of runs (the record count)
+// that is ~4x the real number, and every workgroup — also one that finds nothing to do — costs a dispatch slot with its
+// LDS allocation, so the grid is capped and the threads loop instead.
+__global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__ run_start,
+                                                    const uint32_t *__restrict__ n_runs, Graph g,
+                                                    const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
+                                                    int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
+                                                    uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+    __shared__ uint8_t s_off[RW_P + 1][64]; // node offsets relative to the run's first node (<= RW_N)
+    __shared__ int32_t s_cov[RW_P][64];
+    __shared__ uint4 s_node[RW_N][64]; // {key, count, score lo, score hi}: one LDS round trip per node
+    __shared__ uint8_t s_bi[RW_N][64];
+    __shared__ uint8_t s_n0bi[RW_P][64];
+    const uint32_t nr = *n_runs;
+    for (uint32_t r = blockIdx.x * 64 + threadIdx.x; r < nr; r += gridDim.x * 64)
+        dp_bt_short_run(r, run_start, g, refw32, run_end, run_gain, emit, path_begin, path, s_off, s_cov, s_node, s_bi, s_n0bi);
 }
 
 // global best node at L-1 (main.rs:1651,1680): later node wins ties, must reach score >= 0
@@ -1369,7 +1393,7 @@ void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const
                      const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
                      uint32_t *path_begin, uint64_t *path) {
     if (max_runs)
-        hipLaunchKernelGGL(k_dp_bt_short, grid1(max_runs, 64), dim3(64), 0, s, run_start, n_runs, mk_graph(gp),
+        hipLaunchKernelGGL(k_dp_bt_short, dim3(std::min<uint32_t>((max_runs + 63) / 64, DP_GRID_CAP)), dim3(64), 0, s, run_start, n_runs, mk_graph(gp),
                            (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path);
 }
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
@@ -1377,7 +1401,7 @@ void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
                     uint64_t *path) {
     if (max_runs)
-        hipLaunchKernelGGL(k_dp_bt_long, grid1(max_runs, DP_BLOCK), dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp),
+        hipLaunchKernelGGL(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)), dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp),
                            nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path);
 }
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
