@@ -122,7 +122,12 @@ def main():
         dt = float(t.item())
 
     L = syn.pileup.L
-    value = world * L * a.steps / dt / 1e6
+    total_bp = L
+    if distributed:  # every rank polishes its own contig: sum their lengths
+        tb = torch.tensor([L], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bp = int(tb.item())
+    value = total_bp * a.steps / dt / 1e6
     # roofline of the dominant kernel k_diff_reads: algorithmic bytes per launch =
     # 0.5 B per pileup column (packed nibbles, read once) + 0.5 B per contig base (nibble-packed contig)
     n_cols = syn.pileup.n_columns() - L  # read 0 (the contig itself) is not streamed
@@ -185,6 +190,7 @@ def main():
             got = gatherer.to_host()
             assert got[0] == bases.tobytes(), "all-gathered sequence differs from the polished contig"
             assert all(len(got[r]) > 0 for r in range(world))
+        dist.barrier()  # (rank 0 spends a few seconds on the CPU baseline: leave together)
         dist.destroy_process_group()
 
 
