@@ -225,6 +225,7 @@ struct np2_ctx {
     DevBuf<uint8_t> votebuf;
     DevBuf<int64_t> run_gain, tile_gain;
     DevBuf<uint8_t> out_snap;
+    DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;

@@ -564,6 +564,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     GraphPtrs gp = graph_ptrs(cx, c);
     cx->n0_besti.ensure(L + 2);
     cx->run_gain.ensure((size_t)n_runs + 2);
+    cx->run_flag.ensure((size_t)n_runs + 2);
     cx->emit.ensure(L + 2);
     cx->eoff.ensure(L + 2);
     cx->bt_path.ensure((size_t)M_cap + 2);
@@ -595,7 +596,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         HIPCHK(hipStreamWaitEvent(cx->stream2, cx->ev_fork, 0));
         launch_dp_long(cx->stream2, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
                        cx->nbesti.p, cx->n0_besti.p, cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), cx->run_gain.p,
-                       cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
+                       cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, cx->run_flag.p);
         HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
         launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p, cx->run_gain.p,
                         cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);

@@ -488,6 +488,11 @@ __device__ __forceinline__ uint32_t short_run_len(const uint32_t (&off)[RW_P + 1
         if (i < lim && off[i + 1] == off[i]) len = i;
     return len;
 }
+// which kernel owns a run: the on-chip one takes runs of at most SHORT_LEN dirty positions (and RW_N nodes); its own
+// duration is set by the longest run it takes (a serial chain per lane), the eight-lane kernel's by the longest run of
+// the contig at a third of the cost per position — SHORT_LEN balances the two
+static constexpr uint32_t SHORT_LEN = RW_P - 1;
+__device__ __forceinline__ bool run_is_short(uint32_t len, uint32_t nn) { return len <= SHORT_LEN && nn <= RW_N; }
 __device__ __forceinline__ void load_run_offsets(const uint32_t *__restrict__ node_off, uint32_t a, uint32_t (&off)[RW_P + 1]) {
     static_assert(RW_P + 1 == 14, "three 4-dword loads + one 2-dword load");
     const U32x4 v0 = *reinterpret_cast<const U32x4 *>(node_off + a);
@@ -532,7 +537,7 @@ __device__ __forceinline__ void dp_bt_long_run(uint32_t r, const uint32_t *__res
                                                uint32_t *__restrict__ run_end, int64_t *__restrict__ last_n0_score,
                                                int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
                                                uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
-                                               uint4 (*s_node)[DP_BLOCK]) {
+                                               const uint8_t *__restrict__ run_flag, uint4 (*s_node)[DP_BLOCK]) {
     const uint32_t t = threadIdx.x;
     const uint32_t a = run_start[r], L = g.L;
     uint32_t o0, o1;
@@ -540,7 +545,8 @@ __device__ __forceinline__ void dp_bt_long_run(uint32_t r, const uint32_t *__res
         uint32_t off[RW_P + 1];
         load_run_offsets(g.node_off, a, off);
         const uint32_t len = short_run_len(off, a, L);
-        if (len < RW_P && off[len] - off[0] <= RW_N) return; // a short run: k_dp_bt_short's
+        if (len < RW_P && run_is_short(len, off[len] - off[0])) return; // a short run: k_dp_bt_short's
+        if (!run_flag[r]) return;                              // done by k_dp_bt_oct
         o0 = off[0], o1 = off[1];
     }
     const uint32_t o_first = o0;
@@ -690,6 +696,196 @@ __device__ __forceinline__ void dp_bt_long_run(uint32_t r, const uint32_t *__res
     *last_n0_score = pv_s0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Long runs, eight lanes per run.  A long run is a long serial chain, and the longest one in the contig sets the duration
+// of the whole DP stage, so here the chain is made as short as possible instead of as cheap as possible: lane j of the
+// octet holds exception node j of the current and of the previous position (key, count, score) in registers, the node
+// being scored is broadcast with a sub-wave shuffle, every lane tests "its" predecessor and a three-step butterfly
+// merges the candidates with the reference's tie rule.  No LDS, no memory round trip inside a position; the next
+// position's scalars and nodes are in flight meanwhile.  A position with more than 8 exception nodes hands the run to
+// the per-thread kernel (run_flag = 1).
+//
+// Candidate merge.  The reference scans predecessors in order and takes one if it scores higher, or equal with a
+// first base other than '-' (main.rs:1670).  Over any set of candidates that is: M = the best score, f = the first
+// candidate reaching M, l = the last one reaching M with the flag; the winner is l if it comes after f, else f.  The
+// scan's initial state (SCORE_NEG, index 0) is a candidate before all others (f = -1).  (M, f, l) triples of disjoint
+// sets merge by: higher M wins, equal M -> (min f, max l).
+// ------------------------------------------------------------------------------------------
+struct Cand3 {
+    int64_t m;
+    int32_t f, l;
+};
+// butterfly partners inside an octet, as DPP moves (VALU speed; a general shuffle goes through the LDS crossbar):
+// step 0: lane ^ 1 (quad_perm 1,0,3,2), step 1: lane ^ 2 (quad_perm 2,3,0,1), step 2: lane -> 7 - lane (row_half_mirror)
+template <int STEP> __device__ __forceinline__ uint32_t oct_partner(uint32_t x) {
+    constexpr int CTRL = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : 0x141);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+template <int STEP> __device__ __forceinline__ int64_t oct_partner64(int64_t x) {
+    const uint32_t lo = oct_partner<STEP>((uint32_t)(uint64_t)x), hi = oct_partner<STEP>((uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void cand_take(Cand3 &c, int64_t sc, int32_t pi, bool flag) {
+    if (sc > c.m) {
+        c.m = sc, c.f = pi, c.l = flag ? pi : -1;
+    } else if (sc == c.m) {
+        if (pi < c.f) c.f = pi;
+        if (flag && pi > c.l) c.l = pi;
+    }
+}
+__device__ __forceinline__ void cand_merge(Cand3 &a, int64_t m, int32_t f, int32_t l) {
+    if (m > a.m) {
+        a.m = m, a.f = f, a.l = l;
+    } else if (m == a.m) {
+        a.f = min(a.f, f);
+        a.l = max(a.l, l);
+    }
+}
+__device__ __forceinline__ bool pred_ok(uint16_t vb, uint16_t vd, uint32_t want, uint16_t kd, uint32_t q, bool &flag) {
+    if ((vb & 0x10FFu) != want) return false;
+    const uint16_t v2d = (vb & 0x4000) ? (uint16_t)(vd + 1) : (uint16_t)0;
+    if (v2d != kd) return false;
+    const uint32_t v1q = (vb >> 8) & 0xFu;
+    if (q >= 3 && v1q == 15) return false; // main.rs:1666-1668
+    flag = v1q != 4;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_dp_bt_oct(const uint32_t *__restrict__ run_start,
+                                                  const uint32_t *__restrict__ n_runs, Graph g,
+                                                  const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
+                                                  uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
+                                                  uint32_t *__restrict__ run_end, int64_t *__restrict__ last_n0_score,
+                                                  int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
+                                                  uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
+                                                  uint8_t *__restrict__ run_flag) {
+    const uint32_t j = threadIdx.x & 7;
+    const uint32_t nr = *n_runs, L = g.L;
+    for (uint32_t r = blockIdx.x * 8 + (threadIdx.x >> 3); r < nr; r += gridDim.x * 8) { // (uniform per octet)
+        const uint32_t a = run_start[r];
+        uint32_t o0, o1;
+        {
+            uint32_t off[RW_P + 1];
+            load_run_offsets(g.node_off, a, off);
+            const uint32_t len = short_run_len(off, a, L);
+            if (len < RW_P && run_is_short(len, off[len] - off[0])) continue; // a short run: k_dp_bt_short's
+            o0 = off[0], o1 = off[1];
+        }
+        const uint32_t o_first = o0;
+        int64_t cov = g.cov[a];
+        uint8_t c2 = a >= 2 ? ref_code(g.refnib, a - 2) : 0, c1 = a >= 1 ? ref_code(g.refnib, a - 1) : 0;
+        uint8_t c0 = ref_code(g.refnib, a);
+        const uint8_t c3 = a >= 3 ? ref_code(g.refnib, a - 3) : 0;
+        uint2 cur = nrec[o0 + j]; // node j of the current position (the array is padded: lanes past n read junk)
+        uint32_t prv_key = 0, pv_n = 0;
+        int64_t prv_score = 0, cur_score = 0;
+        uint16_t pv_b0 = 0, pv_d0 = 0;
+        const int64_t base = early_run_base(g, a);
+        int64_t pv_s0 = base;
+        bool pv_valid = a > 0;
+        if (pv_valid) n0_from_codes(a - 1, c3, c2, c1, pv_b0, pv_d0);
+        bool done = false, handed_over = false;
+        uint32_t p = a;
+        for (; p < L; ++p) {
+            const uint32_t n = o1 - o0;
+            if (n > 8) { // more nodes than lanes: the per-thread kernel redoes this run
+                handed_over = true;
+                break;
+            }
+            uint32_t nx_o1 = o1;
+            int64_t nx_cov = 0;
+            uint8_t nx_c = 0;
+            if (p + 1 < L) {
+                nx_o1 = g.node_off[p + 2];
+                nx_cov = g.cov[p + 1];
+                nx_c = ref_code(g.refnib, p + 1);
+            }
+            const uint2 nxt = nrec[o1 + j];
+            uint16_t b0, d0;
+            n0_from_codes(p, c2, c1, c0, b0, d0);
+            uint32_t e0 = (j < n && node_delta3((uint16_t)cur.x, (uint16_t)(cur.x >> 16)) == 0) ? cur.y : 0u;
+            e0 += oct_partner<0>(e0);
+            e0 += oct_partner<1>(e0);
+            e0 += oct_partner<2>(e0);
+            const int64_t cn0 = cov - (int64_t)e0;
+            int64_t s0_cur = 0;
+            for (uint32_t idx = 0; idx <= n; ++idx) {
+                uint32_t key = (uint32_t)b0 | ((uint32_t)d0 << 16);
+                int64_t cnt = cn0;
+                if (idx) {
+                    key = __shfl(cur.x, idx - 1, 8);
+                    cnt = __shfl(cur.y, idx - 1, 8);
+                }
+                const uint16_t kb = (uint16_t)key, kd = (uint16_t)(key >> 16);
+                int64_t score;
+                uint32_t besti = 0;
+                if (((kb >> 4) & 0xF) == 15) {
+                    score = 10 * cnt - 4 * cov;
+                } else {
+                    const bool same_pos = (kb & 0x1000) != 0;
+                    const uint32_t q = same_pos ? p : p - 1;
+                    const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
+                    const int64_t w = 10 * cnt - 4 * cov;
+                    Cand3 c{SCORE_NEG, -1, -1};
+                    if (same_pos || pv_valid) {
+                        bool flag;
+                        // predecessor 0: the contig's own node of that position (every lane, same result)
+                        if (pred_ok(same_pos ? b0 : pv_b0, same_pos ? d0 : pv_d0, want, kd, q, flag))
+                            cand_take(c, (same_pos ? s0_cur : pv_s0) + w, 0, flag);
+                        // predecessor j + 1: exception node j of that position
+                        const uint32_t qn = same_pos ? idx : 1 + pv_n;
+                        if (j + 1 < qn) {
+                            const uint32_t vkey = same_pos ? cur.x : prv_key;
+                            if (pred_ok((uint16_t)vkey, (uint16_t)(vkey >> 16), want, kd, q, flag))
+                                cand_take(c, (same_pos ? cur_score : prv_score) + w, (int32_t)(j + 1), flag);
+                        }
+                    }
+                    cand_merge(c, oct_partner64<0>(c.m), (int32_t)oct_partner<0>((uint32_t)c.f), (int32_t)oct_partner<0>((uint32_t)c.l));
+                    cand_merge(c, oct_partner64<1>(c.m), (int32_t)oct_partner<1>((uint32_t)c.f), (int32_t)oct_partner<1>((uint32_t)c.l));
+                    cand_merge(c, oct_partner64<2>(c.m), (int32_t)oct_partner<2>((uint32_t)c.f), (int32_t)oct_partner<2>((uint32_t)c.l));
+                    score = c.m;
+                    besti = (c.l >= 0 && c.l > c.f) ? (uint32_t)c.l : (c.f < 0 ? 0u : (uint32_t)c.f);
+                }
+                if (idx) {
+                    if (j == idx - 1) {
+                        cur_score = score;
+                        nbesti[o0 + idx - 1] = besti;
+                        if (p + 1 == L) nscore[o0 + idx - 1] = score; // read by k_dp_finish
+                    }
+                } else {
+                    s0_cur = score;
+                    if (j == 0) n0_besti[p] = besti;
+                }
+            }
+            if (n == 0) { // the clean position closing the run
+                done = true;
+                if (j == 0) {
+                    run_end[r] = p - 1;
+                    run_gain[r] = s0_cur - base;
+                }
+                break;
+            }
+            pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
+            prv_key = cur.x, prv_score = cur_score;
+            cur = nxt;
+            o0 = o1, o1 = nx_o1, cov = nx_cov;
+            c2 = c1, c1 = c0, c0 = nx_c;
+        }
+        if (j == 0) run_flag[r] = handed_over ? 1 : 0;
+        if (handed_over) continue;
+        if (!done) { // the run reaches the contig end
+            if (j == 0) {
+                run_end[r] = L - 1;
+                run_gain[r] = -base;
+                *last_n0_score = pv_s0;
+            }
+            continue;
+        }
+        __threadfence_block(); // the octet's besti stores, read back by the walk
+        if (j == 0) emit[a] = bt_walk(g, a, p - 1, n0_besti[p], nbesti, n0_besti, path_begin, path + (size_t)a + o_first);
+    }
+}
+
 // (grid-stride over a capped grid, see k_dp_bt_short)
 __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restrict__ run_start,
                                                       const uint32_t *__restrict__ n_runs, Graph g,
@@ -698,14 +894,15 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
                                                       uint32_t *__restrict__ run_end,
                                                       int64_t *__restrict__ last_n0_score,
                                                       int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
-                                                      uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+                                                      uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
+                                                      const uint8_t *__restrict__ run_flag) {
     // one 16-byte LDS word per cached node: {key, count, score lo, score hi} (a node is read as a whole: the DP chain
     // is bound by LDS round trips, not by bytes)
     __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
     const uint32_t nr = *n_runs;
     for (uint32_t r = blockIdx.x * DP_BLOCK + threadIdx.x; r < nr; r += gridDim.x * DP_BLOCK)
         dp_bt_long_run(r, run_start, g, nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
-                       path, s_node);
+                       path, run_flag, s_node);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,7 +929,7 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
         len = short_run_len(off, a, L);
         o_base = off[0];
         nn = len < RW_P ? off[len] - o_base : 0xFFFFFFFFu;
-        if (len >= RW_P || nn > RW_N) return; // k_dp_bt_long's
+        if (!run_is_short(len, nn)) return; // the long-run kernels'
 #pragma unroll
         for (uint32_t i = 0; i <= RW_P; ++i) s_off[i][t] = (uint8_t)min(off[i] - o_base, 255u); // (only [0, len] are used)
     }
@@ -1399,10 +1596,15 @@ void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
-                    uint64_t *path) {
-    if (max_runs)
-        hipLaunchKernelGGL(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)), dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp),
-                           nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path);
+                    uint64_t *path, uint8_t *run_flag) {
+    if (!max_runs) return;
+    hipLaunchKernelGGL(k_dp_bt_oct, dim3(std::min<uint32_t>((max_runs + 7) / 8, 4 * DP_GRID_CAP)), dim3(64), 0, s, run_start,
+                       n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
+                       path, run_flag);
+    // runs with a position of more than 8 exception nodes (deep pileups): the per-thread kernel
+    hipLaunchKernelGGL(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)),
+                       dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end,
+                       last_n0_score, run_gain, emit, path_begin, path, run_flag);
 }
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,

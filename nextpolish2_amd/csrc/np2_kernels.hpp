@@ -80,7 +80,7 @@ void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
-                    uint64_t *path);
+                    uint64_t *path, uint8_t *run_flag);
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
                       unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
