@@ -7,6 +7,7 @@
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
 #include "np2_blockscan.hpp"
+#include "np2_lookback.hpp"
 
 namespace np2 {
 
@@ -34,6 +35,33 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict_
         if (MODE == 0 && write_end) out[n] = total;
         if (total_out) *total_out = total;
     }
+}
+
+// Mid-sized exclusive sums (8 k .. 64 k elements, length known on the host): the single-block scan above costs ~12 us per
+// 20 k elements whatever its tuning; a few dozen light, uniform blocks are what the decoupled look-back is good at.
+static constexpr uint32_t SCAN_LB_ITEMS = 8; // elements per thread, blocked: thread t owns [8t, 8t + 8) of its block's 2048
+__global__ __launch_bounds__(256) void k_scan_lb_excl(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
+                                                      uint32_t *__restrict__ out, uint32_t n, bool write_end,
+                                                      uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t i0 = bid * (256 * SCAN_LB_ITEMS) + threadIdx.x * SCAN_LB_ITEMS;
+    uint32_t v[SCAN_LB_ITEMS], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) {
+        v[k] = i0 + k < n ? in[i0 + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total, pre, dummy;
+    uint32_t run = block_excl_scan<OpAdd, 4>(sum, sh, total);
+    lb_exclusive2(lb, bid, total, 0u, sh, err, pre, dummy);
+    run += pre;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) {
+        if (i0 + k < n) out[i0 + k] = run;
+        run += v[k];
+    }
+    if (write_end && bid == n_blocks - 1 && threadIdx.x == 255) out[n] = run; // (the last thread's running sum = total)
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -369,6 +397,11 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
 void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
                             uint32_t *total_out, bool write_end) {
     hipLaunchKernelGGL(k_scan_small<0>, dim3(1), dim3(1024), 0, s, in, out, n, n_dev, total_out, write_end);
+}
+void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
+                          uint32_t *err) {
+    const uint32_t nb = (n + 256 * SCAN_LB_ITEMS - 1) / (256 * SCAN_LB_ITEMS);
+    hipLaunchKernelGGL(k_scan_lb_excl, dim3(nb), dim3(256), 0, s, lb, nb, in, out, n, write_end, err);
 }
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev) {
     hipLaunchKernelGGL(k_scan_small<1>, dim3(1), dim3(1024), 0, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev,

@@ -405,6 +405,11 @@ inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
 }
 // exclusive sums of in[0..n) into out[0..n], out[n] = total (in[n] is not read by the short path, cleared for the long one)
 inline void exclusive_total_n(np2_ctx *cx, uint32_t *in, uint32_t *out, size_t n) {
+    if (n >= 8192 && n + 1 <= SCAN_SMALL_MAX) { // a few dozen blocks chained by a look-back
+        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n + 2047) / 2048)), in, out, (uint32_t)n, true,
+                            cx->scal.p + S_ERR);
+        return;
+    }
     if (n + 1 <= SCAN_SMALL_MAX) {
         launch_scan_small_excl(cx->stream, in, out, (uint32_t)n, nullptr, nullptr, true);
         return;

@@ -115,6 +115,8 @@ void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_
 // ---- np2_cand.hip: region-major candidate extraction, single-block scans -----------------------------
 void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                        const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
+void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
+                          uint32_t *err);
 void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
                             uint32_t *total_out, bool write_end); // write_end: also out[n] = total
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
