@@ -8,6 +8,7 @@
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
 #include "np2_blockscan.hpp"
+#include "np2_lookback.hpp"
 
 namespace np2 {
 
@@ -86,6 +87,51 @@ __global__ __launch_bounds__(1024) void k_tile_layout(uint32_t *__restrict__ til
         tile_scanb[n_tiles] = tb;
         out[0] = ta;
         out[1] = mx;
+        out[2] = *ovf_cnt;
+    }
+}
+
+// the same for contigs of more than a couple of thousand tiles: 1024 tiles per block, the two running sums chained across
+// the blocks by the look-back (a handful of light, uniform blocks), the maximum by one atomic per wave (out[1] is zero
+// before: the scalar block is cleared ahead of the dense pass)
+static constexpr uint32_t TLB_ITEMS = 4;
+__global__ __launch_bounds__(256) void k_tile_layout_lb(Lookback lb, uint32_t n_blocks, uint32_t *__restrict__ tile_cur,
+                                                        uint32_t n_tiles, uint32_t bucket_cap, uint32_t *__restrict__ tile_n,
+                                                        uint32_t *__restrict__ tile_scan, uint32_t *__restrict__ tile_scanb,
+                                                        const uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ out,
+                                                        uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t i0 = (bid * 256 + threadIdx.x) * TLB_ITEMS;
+    uint32_t v[TLB_ITEMS], sa = 0, sb = 0, mx = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TLB_ITEMS; ++k) {
+        v[k] = i0 + k < n_tiles ? tile_cur[i0 + k] : 0u;
+        sa += v[k];
+        sb += min(v[k], bucket_cap);
+        mx = max(mx, v[k]);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&out[1], mx);
+    uint32_t ta, tb, pa, pb;
+    uint32_t ra = block_excl_scan<OpAdd, 4>(sa, sh, ta);
+    uint32_t rb = block_excl_scan<OpAdd, 4>(sb, sh, tb);
+    lb_exclusive2(lb, bid, ta, tb, sh, err, pa, pb);
+    ra += pa, rb += pb;
+#pragma unroll
+    for (uint32_t k = 0; k < TLB_ITEMS; ++k)
+        if (i0 + k < n_tiles) {
+            tile_scan[i0 + k] = ra;
+            tile_scanb[i0 + k] = rb;
+            tile_n[i0 + k] = v[k];
+            tile_cur[i0 + k] = 0;
+            ra += v[k];
+            rb += min(v[k], bucket_cap);
+        }
+    if (bid == n_blocks - 1 && threadIdx.x == 255) { // (the last thread's running sums are the totals)
+        tile_scan[n_tiles] = ra;
+        tile_scanb[n_tiles] = rb;
+        out[0] = ra;
         out[2] = *ovf_cnt;
     }
 }
@@ -295,6 +341,43 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
     if (threadIdx.x == 0) {
         *n_nodes = ta;
         *n_runs = tb;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_offsets_lb(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ tile_nn,
+                                                         const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
+                                                         uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
+                                                         uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
+                                                         uint32_t *__restrict__ reset, uint32_t n_reset,
+                                                         uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    if (blockIdx.x == 0 && threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t i0 = (bid * 256 + threadIdx.x) * TLB_ITEMS;
+    uint32_t a[TLB_ITEMS], b[TLB_ITEMS], sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TLB_ITEMS; ++k) {
+        a[k] = i0 + k < n_tiles ? tile_nn[i0 + k] : 0u;
+        b[k] = i0 + k < n_tiles ? tile_nr[i0 + k] : 0u;
+        sa += a[k];
+        sb += b[k];
+    }
+    uint32_t ta, tb, pa, pb;
+    uint32_t ra = block_excl_scan<OpAdd, 4>(sa, sh, ta);
+    uint32_t rb = block_excl_scan<OpAdd, 4>(sb, sh, tb);
+    lb_exclusive2(lb, bid, ta, tb, sh, err, pa, pb);
+    ra += pa, rb += pb;
+#pragma unroll
+    for (uint32_t k = 0; k < TLB_ITEMS; ++k)
+        if (i0 + k < n_tiles) {
+            tile_noff[i0 + k] = ra;
+            tile_roff[i0 + k] = rb;
+            ra += a[k];
+            rb += b[k];
+        }
+    if (bid == n_blocks - 1 && threadIdx.x == 255) {
+        *n_nodes = ra;
+        *n_runs = rb;
     }
 }
 
@@ -522,10 +605,16 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
+uint32_t tile_scan_blocks(uint32_t n_tiles) { return (n_tiles + 256 * TLB_ITEMS - 1) / (256 * TLB_ITEMS); }
 void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
-                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out) {
-    hipLaunchKernelGGL(k_tile_layout, dim3(1), dim3(1024), 0, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan,
-                       tile_scanb, ovf_cnt, out);
+                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out,
+                        const Lookback *lb, uint32_t *err) {
+    if (lb)
+        hipLaunchKernelGGL(k_tile_layout_lb, dim3(tile_scan_blocks(n_tiles)), dim3(256), 0, s, *lb, tile_scan_blocks(n_tiles),
+                           tile_cur, n_tiles, bucket_cap, tile_n, tile_scan, tile_scanb, ovf_cnt, out, err);
+    else
+        hipLaunchKernelGGL(k_tile_layout, dim3(1), dim3(1024), 0, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan,
+                           tile_scanb, ovf_cnt, out);
 }
 void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
@@ -555,9 +644,14 @@ void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals
 }
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
                          uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
-                         uint32_t n_reset) {
-    hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes,
-                       n_runs, reset, n_reset);
+                         uint32_t n_reset, const Lookback *lb, uint32_t *err) {
+    if (lb)
+        hipLaunchKernelGGL(k_tile_offsets_lb, dim3(tile_scan_blocks(n_tiles)), dim3(256), 0, s, *lb,
+                           tile_scan_blocks(n_tiles), tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset,
+                           n_reset, err);
+    else
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff,
+                           n_nodes, n_runs, reset, n_reset);
 }
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,

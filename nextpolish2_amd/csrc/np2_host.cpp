@@ -434,8 +434,12 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
             EventTimer t(cx, "sort_exceptions");
             // per-tile counts / layouts + the counters the host needs, all in the mailbox: S_M0 = T, S_M1 = largest
             // tile, S_M2 = records spilled from full buckets
+            // (contigs of a few thousand tiles and more: a handful of blocks chained by the look-back)
+            const bool wide = n_tiles >= 2048;
+            Lookback lb{};
+            if (wide) lb = next_lookback(cx, tile_scan_blocks(n_tiles));
             launch_tile_layout(s, cx->tile_cur.p, n_tiles, bcap, cx->tile_n.p, cx->tile_scan.p, cx->tile_scanb.p,
-                               cx->scal.p + S_M3, cx->scal.p + S_M0);
+                               cx->scal.p + S_M3, cx->scal.p + S_M0, wide ? &lb : nullptr, cx->scal.p + S_ERR);
         }
         std::vector<uint32_t> sc = fetch_scal(cx);
         if (sc[S_ERR] & 2u)
@@ -497,8 +501,14 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     launch_tile_count(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, n_tiles,
                       cx->alive.p, cx->tile_nn.p, cx->tile_nr.p);
     // (also resets the per-pass scalars S_BEST .. S_NLONG)
-    launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
-                        cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS, cx->scal.p + S_BEST, S_NLONG + 1 - S_BEST);
+    {
+        const bool wide = n_tiles >= 2048;
+        Lookback lb{};
+        if (wide) lb = next_lookback(cx, tile_scan_blocks(n_tiles));
+        launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
+                            cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS, cx->scal.p + S_BEST, S_NLONG + 1 - S_BEST,
+                            wide ? &lb : nullptr, cx->scal.p + S_ERR);
+    }
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
                       cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
                       c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p, c->refnib.p, cx->emit.p,

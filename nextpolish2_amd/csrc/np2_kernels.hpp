@@ -135,8 +135,10 @@ void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const
                          uint32_t *cand_seq_off, uint8_t *cand_seq);
 
 // ---- np2_graph.hip: tile-bucketed exception sort and per-pass graph construction ---------------------
+uint32_t tile_scan_blocks(uint32_t n_tiles); // blocks of the look-back variants of the two per-tile scans below
 void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
-                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out);
+                        uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out,
+                        const Lookback *lb = nullptr, uint32_t *err = nullptr);
 void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
                       uint32_t *err);
@@ -151,7 +153,7 @@ void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        uint32_t *tile_nn, uint32_t *tile_nr);
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
                          uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
-                         uint32_t n_reset);
+                         uint32_t n_reset, const Lookback *lb = nullptr, uint32_t *err = nullptr);
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
