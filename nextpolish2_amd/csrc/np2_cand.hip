@@ -350,6 +350,51 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restric
     }
 }
 
+// the same with a few blocks chained by the look-back (1024 region blocks each); block 0 also adds up the growth bound
+__global__ __launch_bounds__(256) void k_cand_offsets_lb(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ blk_sum,
+                                                         uint32_t n_blk, uint32_t n_reg, uint32_t *__restrict__ blk_coff,
+                                                         uint32_t *__restrict__ blk_soff, uint32_t *__restrict__ cand_off,
+                                                         uint32_t *__restrict__ reg_soff, uint32_t *__restrict__ n_cand,
+                                                         uint32_t *__restrict__ n_bytes, uint32_t *__restrict__ grow,
+                                                         uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t i0 = (bid * 256 + threadIdx.x) * 4;
+    uint32_t a[4], b[4], sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        a[k] = i0 + k < n_blk ? blk_sum[i0 + k] : 0u;
+        b[k] = i0 + k < n_blk ? blk_sum[n_blk + i0 + k] : 0u;
+        sa += a[k];
+        sb += b[k];
+    }
+    uint32_t ta, tb, pa, pb;
+    uint32_t ra = block_excl_scan<OpAdd, 4>(sa, sh, ta);
+    uint32_t rb = block_excl_scan<OpAdd, 4>(sb, sh, tb);
+    lb_exclusive2(lb, bid, ta, tb, sh, err, pa, pb);
+    ra += pa, rb += pb;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (i0 + k < n_blk) {
+            blk_coff[i0 + k] = ra;
+            blk_soff[i0 + k] = rb;
+            ra += a[k];
+            rb += b[k];
+        }
+    if (bid == n_blocks - 1 && threadIdx.x == 255) {
+        cand_off[n_reg] = ra;
+        reg_soff[n_reg] = rb;
+        *n_cand = ra;
+        *n_bytes = rb;
+    }
+    if (bid == 0) { // upper bound of the consensus growth of one splice round
+        uint32_t c = 0, tc;
+        for (uint32_t i = threadIdx.x; i < n_blk; i += 256) c += blk_sum[2 * n_blk + i];
+        (void)block_excl_scan<OpAdd, 4>(c, sh, tc);
+        if (threadIdx.x == 0) *grow = tc;
+    }
+}
+
 // one lane per kept candidate (at most 60 per region = one pass of the wave)
 __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
                                                       const uint32_t *__restrict__ kept_len,
@@ -422,10 +467,17 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
         hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
                            kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
+uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
-                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow) {
-    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff,
-                       cand_off, reg_soff, n_cand, n_bytes, grow);
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow,
+                         const Lookback *lb, uint32_t *err) {
+    if (lb)
+        hipLaunchKernelGGL(k_cand_offsets_lb, dim3(cand_offsets_blocks(n_reg)), dim3(256), 0, s, *lb,
+                           cand_offsets_blocks(n_reg), blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff, cand_off, reg_soff,
+                           n_cand, n_bytes, grow, err);
+    else
+        hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff,
+                           cand_off, reg_soff, n_cand, n_bytes, grow);
 }
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,

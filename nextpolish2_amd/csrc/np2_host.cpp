@@ -684,8 +684,14 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
         // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                               cx->reg_bytes.p, cx->reg_maxlen.p, cx->blk_sum.p);
-        launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
-                            cx->scal.p + S_NC, cx->scal.p + S_SB, cx->scal.p + S_GROW);
+        {
+            const bool wide = n_reg >= 8192; // 2048+ region blocks: chained blocks instead of one
+            Lookback lb{};
+            if (wide) lb = next_lookback(cx, cand_offsets_blocks(n_reg));
+            launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
+                                cx->scal.p + S_NC, cx->scal.p + S_SB, cx->scal.p + S_GROW, wide ? &lb : nullptr,
+                                cx->scal.p + S_ERR);
+        }
         launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                             cx->reg_bytes.p, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p, NC_cap + 1,
                             SB_cap, cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);

@@ -125,8 +125,10 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum);
 // blk_sum: 3 x ceil(n_reg / 4) sums per block of 4 regions (candidates, bytes, longest kept string)
+uint32_t cand_offsets_blocks(uint32_t n_reg); // blocks of the look-back variant
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
-                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow);
+                         uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow,
+                         const Lookback *lb = nullptr, uint32_t *err = nullptr);
 // also fills cand_off[g] / reg_soff[g] (block prefix + the regions before g inside its block)
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
