@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # HBM traffic of one k_diff_reads launch on the default workload, from rocprofv3 PMC passes
-# (profiles/r01i_pmc_fetch_write.json: 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE)
-PMC_TRAFFIC_DEFAULT_WORKLOAD = int((2 * 48683.8 + 31188.6) * 1024)
+# (profiles/r01j_pmc_fetch_write.json: 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE)
+PMC_TRAFFIC_DEFAULT_WORKLOAD = int((2 * 48559.0 + 31205.3) * 1024)
 
 
 def main():
