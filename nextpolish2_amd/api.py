@@ -218,11 +218,12 @@ class Polisher:
         lib().np2_last_timings(self._h, C.byref(names), C.byref(ms), C.byref(n))
         out = {}
         if n.value:
-            raw = C.string_at(names.value, 4096)
-            parts = raw.split(b"\0")
             vals = np.ctypeslib.as_array(C.cast(ms, C.POINTER(C.c_float)), shape=(n.value,))
-            for i in range(n.value):
-                out[parts[i].decode()] = float(vals[i])
+            addr = names.value
+            for i in range(n.value):  # NUL-separated names: walk them one C string at a time
+                nm = C.string_at(addr)
+                addr += len(nm) + 1
+                out[nm.decode()] = float(vals[i])
         return out
 
     def score_strings(self, yak_idx, strings, min_kmer_count=5):

@@ -12,6 +12,8 @@ import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
+
 from . import io as np2io
 from ._types import Opts
 from .api import Polisher, fasta_record
@@ -27,8 +29,15 @@ def _existing(path):
 
 
 def _map_len(v):
-    f = float(v)  # -a INT.FLOAT: integer part = min length, fractional part = min fraction (option.rs:232,258-259)
-    return f
+    """-a INT.FLOAT parsed as f32 like the reference (option.rs:232 remove_one::<f32>)."""
+    return np.float32(v)
+
+
+def split_map_len(v):
+    """(min_map_len, min_map_fra) = (f32 as usize, f32::fract()) (option.rs:258-259): both in single precision, so
+    `-a 500.3` gives fra = 0.29998779 (not 0.3) and (rlen as f32 * fra) as i64 matches the reference to the unit."""
+    f = np.float32(v)
+    return int(f), float(np.float32(f - np.trunc(f)))
 
 
 def build_parser():
@@ -71,7 +80,7 @@ def main(argv=None):
     if a.model.lower() not in ("ref", "len"):
         raise SystemExit("error: invalid value for --model (ref|len)")
     out = sys.stdout.buffer
-    if a.out is not None:
+    if a.out is not None and a.out != "stdout":  # option.rs:76-79: the literal default "stdout" means stdout
         path = os.path.abspath(a.out)
         if os.path.exists(path):  # option.rs:312-316: refuse to overwrite
             raise SystemExit(f"Error: {path!r} already exists!")
@@ -80,8 +89,9 @@ def main(argv=None):
     # main.rs:1547 compares the raw option with "ref" (case-sensitive)
     opts = Opts(min_kmer_count=a.min_kmer_count, max_indel_len=a.max_indel_len, iter_count=a.iter_count,
                 model=a.model, use_all_reads=a.use_all_reads)
-    fopts = np2io.FrontOpts(min_read_len=a.min_read_len, min_map_len=int(a.min_map_len),
-                            min_map_fra=a.min_map_len - int(a.min_map_len), min_map_qual=a.min_map_qual,
+    map_len, map_fra = split_map_len(a.min_map_len)
+    fopts = np2io.FrontOpts(min_read_len=a.min_read_len, min_map_len=map_len,
+                            min_map_fra=map_fra, min_map_qual=a.min_map_qual,
                             max_clip_len=a.max_clip_len, use_supplementary=a.use_supplementary,
                             use_secondary=a.use_secondary)
     n_workers = max(1, min(4, a.thread))
@@ -128,7 +138,7 @@ def main(argv=None):
             drain(0)
         out.flush()
     finally:
-        if a.out is not None:
+        if out is not sys.stdout.buffer:
             out.close()
     print(resource_str(t0, ["nextPolish2"] + argv), file=sys.stderr)
     return 0

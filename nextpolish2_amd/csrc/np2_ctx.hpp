@@ -239,6 +239,7 @@ namespace np2h {
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
             S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 24 };
 
+static constexpr int NP2_MAX_YAK = 15; // splice rounds 0 .. n_yak index mlen[16] and the counters behind S_COUNT
 static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it
 
 struct WallTimer {
@@ -371,7 +372,7 @@ inline Lookback next_lookback(np2_ctx *cx, uint32_t n_blocks) {
         cx->lb_epoch = 1;
     }
     Lookback lb{cx->lb_status.p, cx->lb_status.p + np2_ctx::LB_MAX_BLOCKS, cx->lb_ticket.p, cx->lb_ticket_total,
-                cx->lb_epoch};
+                cx->lb_epoch, n_blocks, cx->scal.p + S_ERR};
     cx->lb_ticket_total += n_blocks;
     return lb;
 }

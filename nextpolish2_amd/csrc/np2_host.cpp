@@ -444,6 +444,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         std::vector<uint32_t> sc = fetch_scal(cx);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
+        check_region_err(cx, sc[S_ERR]); // (a look-back timeout in k_tile_layout would leave T / S_M1 / S_M2 undefined)
         if (sc[S_M2] > ovf_cap) { // the spill area itself overflowed: grow and redo the dense pass
             ovf_cap = (uint64_t)sc[S_M2] * 5 / 4 + 65536;
             continue;
@@ -995,6 +996,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
         HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
         if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
             cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
+        // the final pass runs one splice round + one per yak table; their per-round device counters live in fixed slots
+        if (n_yak < 0 || n_yak > NP2_MAX_YAK || (n_yak && !yaks))
+            throw Np2Error(NP2_E_ARG, "n_yak must be in [0, 15]");
         cx->yaks.resize(n_yak);
         for (int i = 0; i < n_yak; ++i) {
             const np2_yak_t &y = yaks[i];

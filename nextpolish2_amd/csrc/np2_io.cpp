@@ -327,10 +327,8 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
     std::vector<FrontOp> fops;
     std::vector<Admitted> adm;
     uint64_t out_off = ((((uint64_t)L + 1) >> 1) + 1 + 15) & ~15ull; // slot 0 = the contig itself
-    int32_t pre_pos = 0;
     for (uint32_t i = 0; i < n_recs; ++i) {
         const np2_bamrec_t &r = recs[i];
-        if (r.pos < pre_pos) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: Unsorted input file!");
         const uint32_t *cg = cigar + r.cigar_off;
         uint64_t rlen = 0;
         int64_t span = 0;
@@ -394,7 +392,6 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
         const bool is_clip = aln_q_e - aln_q_s + o->max_clip_len < (uint32_t)rlen; // main.rs:1796-1797
         adm.push_back(Admitted{i, is_clip, col});
         frec.push_back(fr);
-        pre_pos = r.pos;
     }
     const uint32_t n = (uint32_t)frec.size();
     const uint64_t nib_bytes = out_off + 64;
@@ -434,9 +431,11 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
         r0.aln_t_s = 0, r0.aln_t_e = L - 1, r0.nib_off = 0, r0.n_cols = L;
         reads.push_back(r0);
         lable.push_back(0);
+        std::vector<uint8_t> pushed(n_recs, 0);
         for (uint32_t i = 0; i < n; ++i) {
             if (fout[i].n_cols <= o->min_map_len) continue; // aln_len() <= min_map_len
             if (adm[i].is_clip && L < 500000) continue;
+            pushed[adm[i].rec] = 1;
             np2_read_t rd;
             memset(&rd, 0, sizeof rd);
             rd.aln_t_s = fout[i].aln_t_s;
@@ -445,6 +444,15 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
             rd.nib_off = frec[i].out_off;
             reads.push_back(rd);
             lable.push_back(adm[i].is_clip ? 1 : 0);
+        }
+        {
+            // the sortedness assertion compares every record with the start of the last record that was *pushed*
+            // (pre_pos only advances at main.rs:1814-1815, after the trim-length and short-contig clip skips)
+            int64_t pre_pos = 0;
+            for (uint32_t i = 0; i < n_recs; ++i) {
+                if (recs[i].pos < pre_pos) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: Unsorted input file!");
+                if (pushed[i]) pre_pos = recs[i].pos;
+            }
         }
         {
             const uint32_t offset = 50;

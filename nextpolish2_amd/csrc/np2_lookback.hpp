@@ -22,6 +22,8 @@ struct Lookback {
     uint32_t *ticket;   // monotonically increasing block counter (never reset)
     uint32_t ticket_base;
     uint32_t epoch;     // 1 .. 2^30-1
+    uint32_t n_blocks;  // grid size this descriptor was issued for
+    uint32_t *err;      // device error word (LB_ERR is or-ed in on a ticket outside the grid)
 };
 
 static constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
@@ -48,7 +50,14 @@ __device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch, b
 
 // logical block index of this block in the scan order (uniform across the block); sh: 1 word of LDS
 __device__ __forceinline__ uint32_t lb_block_id(const Lookback &lb, uint32_t *sh) {
-    if (threadIdx.x == 0) sh[0] = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+    if (threadIdx.x == 0) {
+        uint32_t id = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+        if (id >= lb.n_blocks) { // host-side ticket accounting out of step with the launches: never index past the grid
+            atomicOr(lb.err, LB_ERR);
+            id = lb.n_blocks - 1;
+        }
+        sh[0] = id;
+    }
     __syncthreads();
     const uint32_t id = sh[0];
     __syncthreads();
@@ -59,6 +68,9 @@ __device__ __forceinline__ uint32_t lb_block_id(const Lookback &lb, uint32_t *sh
 // Called by every thread of the block; returns the prefixes in pre_a / pre_b.  sh: 2 words of LDS.
 __device__ __forceinline__ void lb_exclusive2(const Lookback &lb, uint32_t bid, uint32_t agg_a, uint32_t agg_b,
                                               uint32_t *sh, uint32_t *err, uint32_t &pre_a, uint32_t &pre_b) {
+    // callers hand over the LDS words of the block scan that produced agg_a / agg_b: its last step has every wave read
+    // them, so nobody may overwrite sh[0..1] (wave 0 below, at once when bid == 0) before all waves are through
+    __syncthreads();
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         if (lane == 0) {
