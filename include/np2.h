@@ -69,6 +69,10 @@ typedef struct np2_contig np2_contig_t;
  * tables from `yaks` (ascending k, option.rs:238).  Replaces KmerInfo::new +
  * retrieve_kmers file re-streaming (kmer.rs:72-170). */
 int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak);
+/* A further context on the device of `parent` that shares its HBM k-mer tables (reference-counted: the tables are freed
+ * with the last context that uses them).  Mirrors the reference's worker threads, which clone the option set but read
+ * the same yak files (main.rs:1724). */
+int np2_ctx_create_shared(np2_ctx_t **out, np2_ctx_t *parent);
 void np2_ctx_destroy(np2_ctx_t *ctx);
 const char *np2_last_error(np2_ctx_t *ctx);
 /* The HIP stream every kernel of this context is launched on (hipStream_t as void*). */
@@ -136,6 +140,30 @@ int np2_trace_get(np2_ctx_t *ctx, int pass, const char *name, const void **data,
 int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, const uint32_t *pb, const float *pw,
                    uint64_t n_pairs, const uint32_t *ref_ids, const float *ref_w, uint32_t n_ref, int has_ref,
                    uint32_t *out_ids, uint32_t *n_out);
+
+/* ---- batch of contigs (the reference's N worker threads, main.rs:1717-1843, as ONE launch stream) -------------------
+ * np2_batch_polish runs np2_polish_resident for up to `n_slots` resident contigs at a time: every contig keeps its own
+ * pipeline, scratch context and host thread (so the host side of the phasing vote runs concurrently), but their
+ * kernels are issued as one grid per pipeline step for the whole batch.  Results per contig are exactly those of
+ * np2_polish_resident: out_bases[i] / out_pos[i] (either array may be NULL; release entries with np2_free),
+ * out_len[i], out_span[2i], out_span[2i+1] (np2_last_span), rcs[i].  With out_bases == NULL the sequences stay on the device: slot context i % n_slots
+ * (np2_batch_slot_ctx) then serves np2_last_span / np2_last_result_device / np2_result_fetch_begin for contig i of
+ * the last wave.  Returns 0 or the code of the last failing contig (np2_batch_last_error). */
+typedef struct np2_batch np2_batch_t;
+int np2_batch_create(np2_batch_t **out, np2_ctx_t *parent, int n_slots);
+void np2_batch_destroy(np2_batch_t *b);
+int np2_batch_slots(np2_batch_t *b);
+np2_ctx_t *np2_batch_slot_ctx(np2_batch_t *b, int slot);
+const char *np2_batch_last_error(np2_batch_t *b);
+int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const np2_opts_t *opts, uint8_t **out_bases,
+                     uint32_t **out_pos, uint64_t *out_len, uint32_t *out_span /* first / last position per contig, or NULL */,
+                     int *rcs);
+/* HIP-event timing of the batched dense kernel (k_diff_reads) on the batch's stream: total ms and launches of the last
+ * np2_batch_polish (roofline bookkeeping of bench.py). */
+void np2_batch_set_timing(np2_batch_t *b, int enable);
+int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches);
+/* cumulative counters: kernel launches issued, commands recorded by the pipelines, device flushes */
+int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes);
 
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
  * names: NUL-separated list terminated by an empty string; ms[i] matches names[i].

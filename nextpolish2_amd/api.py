@@ -20,6 +20,8 @@ ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
     "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_result_fetch_begin", "np2_result_fetch_end", "np2_phase_vote",
+    "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
+    "np2_batch_last_error", "np2_batch_polish", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -65,6 +67,20 @@ def lib():
         L.np2_result_fetch_begin.argtypes = [vp]
         L.np2_result_fetch_end.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.np2_phase_vote.argtypes = [vp, u32, vp, vp, vp, u64, vp, vp, u32, C.c_int, vp, C.POINTER(u32)]
+        L.np2_ctx_create_shared.argtypes = [C.POINTER(vp), vp]
+        L.np2_batch_create.argtypes = [C.POINTER(vp), vp, C.c_int]
+        L.np2_batch_destroy.argtypes = [vp]
+        L.np2_batch_destroy.restype = None
+        L.np2_batch_slots.argtypes = [vp]
+        L.np2_batch_slot_ctx.argtypes = [vp, C.c_int]
+        L.np2_batch_slot_ctx.restype = vp
+        L.np2_batch_last_error.argtypes = [vp]
+        L.np2_batch_last_error.restype = C.c_char_p
+        L.np2_batch_polish.argtypes = [vp, vp, C.c_int, C.POINTER(np2_opts_t), vp, vp, vp, vp, vp]
+        L.np2_batch_set_timing.argtypes = [vp, C.c_int]
+        L.np2_batch_set_timing.restype = None
+        L.np2_batch_last_diff_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.np2_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -242,6 +258,85 @@ class Polisher:
         self._check(lib().np2_lookup_hashes(self._h, yak_idx, h.ctypes.data, h.shape[0], min_kmer_count,
                                             out.ctypes.data))
         return out
+
+
+class BatchPolisher:
+    """np2_batch_t: up to `n_slots` contigs polished at once with one launch per pipeline step for all of them.
+
+    Mirrors the reference's pool of worker threads (src/main.rs:1717-1843); results per contig are exactly those of
+    Polisher.polish_resident."""
+
+    def __init__(self, polisher: Polisher, n_slots):
+        self._pol = polisher  # keeps the parent context (and its yak tables) alive
+        h = C.c_void_p()
+        rc = lib().np2_batch_create(C.byref(h), polisher._h, n_slots)
+        if rc != 0:
+            raise Np2Error(rc, lib().np2_last_error(polisher._h).decode())
+        self._h = h
+        self.n_slots = n_slots
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().np2_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on=True):
+        lib().np2_batch_set_timing(self._h, 1 if on else 0)
+
+    def last_diff_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        lib().np2_batch_last_diff_ms(self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().np2_batch_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"launches": a.value, "commands": b.value, "flushes": c.value}
+
+    def polish(self, contigs, opts: Opts = None, want_pos=False, keep_on_device=False):
+        """[(bases, pos-or-span)] per contig, like Polisher.polish_resident(want_pos=...).  keep_on_device=True returns
+        [(None, span)]: fetch the sequences of the last wave from the slot contexts (slot_fetch_begin / _end)."""
+        n = len(contigs)
+        o = (opts or Opts()).c()
+        hs = (C.c_void_p * n)(*[c._h for c in contigs])
+        ob = (C.c_void_p * n)()
+        op = (C.c_void_p * n)()
+        on = (C.c_uint64 * n)()
+        rcs = (C.c_int * n)()
+        span = (C.c_uint32 * (2 * n))()
+        rc = lib().np2_batch_polish(self._h, hs, n, C.byref(o), None if keep_on_device else ob,
+                                    op if (want_pos and not keep_on_device) else None, on, span, rcs)
+        if rc != 0:
+            raise Np2Error(rc, lib().np2_batch_last_error(self._h).decode())
+        out = []
+        for i in range(n):
+            if keep_on_device:
+                out.append((None, (span[2 * i], span[2 * i + 1])))
+                continue
+            b = _owned(C.c_void_p(ob[i]), on[i], C.c_uint8)
+            if want_pos:
+                out.append((b, _owned(C.c_void_p(op[i]), on[i], C.c_uint32)))
+            else:
+                out.append((b, (span[2 * i], span[2 * i + 1])))
+        return out
+
+    def slot_fetch_begin(self, slot):
+        rc = lib().np2_result_fetch_begin(lib().np2_batch_slot_ctx(self._h, slot))
+        if rc != 0:
+            raise Np2Error(rc, "np2_result_fetch_begin")
+
+    def slot_fetch_end(self, slot):
+        p, n = C.c_void_p(), C.c_uint64()
+        rc = lib().np2_result_fetch_end(lib().np2_batch_slot_ctx(self._h, slot), C.byref(p), C.byref(n))
+        if rc != 0:
+            raise Np2Error(rc, "np2_result_fetch_end")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value]
 
 
 def fasta_record(name, bases, pos):

@@ -1,0 +1,380 @@
+// Batch driver: polishes several contigs of one assembly at once on one GPU, with one kernel launch per pipeline step
+// for the whole batch instead of one per contig.
+//
+// The reference hands one contig to each worker thread (src/main.rs:1717-1843) and the per-contig loop
+// (main.rs:1819-1836) shares nothing between contigs.  On the GPU a contig of a few hundred kb is a few microseconds
+// of work per kernel, so a many-contig assembly is bound by the number of launches.  Here every contig of a batch runs
+// the unchanged per-contig host pipeline (np2_polish_resident) on its own host thread and its own scratch context,
+// but the threads *record* their device commands (np2_launch.hpp).  Whenever every pipeline of the batch waits for the
+// device (a read-back of counters, a result copy), the last thread to arrive merges the recorded queues: commands
+// keep their per-contig order, and launches of the same kernel at the heads of several queues go out as ONE grid
+// (k_np2_batched).  Host-side phases — the Louvain phasing vote above all — run concurrently on the contigs' threads.
+#include "../../include/np2.h"
+#include "np2_ctx.hpp"
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+using namespace np2;
+
+namespace {
+
+struct Job {
+    np2_contig *contig = nullptr;
+    const np2_opts_t *opts = nullptr;
+    uint8_t **out_bases = nullptr;
+    uint32_t **out_pos = nullptr;
+    uint64_t *out_len = nullptr;
+    uint32_t *out_span = nullptr;
+    int *rc = nullptr;
+};
+
+} // namespace
+
+struct np2_batch {
+    np2_ctx *parent = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<np2_ctx *> slots;
+    std::vector<Recorder> recs;
+    std::vector<std::thread> workers;
+    std::string err;
+
+    // job hand-off (one generation = one wave of at most slots.size() contigs)
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    uint64_t job_gen = 0;
+    std::vector<Job> jobs; // jobs[slot]
+    int n_running = 0;
+    bool quit = false;
+
+    // device synchronisation of the wave: counts are guarded by `sync_mu`, waiters spin on `flush_gen`
+    std::mutex sync_mu;
+    int n_active = 0, n_waiting = 0;
+    std::atomic<uint64_t> flush_gen{0};
+    std::atomic<bool> failed{false};
+    std::string fail_msg;
+
+    // completion word of a flush: host-mapped, written by the last kernel of the flush
+    uint32_t *done_host = nullptr, *done_dev = nullptr;
+    uint32_t done_seq = 0;
+
+    // HIP-event timing of the batched dense kernel (bench roofline): pairs recorded around its launches
+    bool time_diff = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> diff_events;
+    float last_diff_ms = 0;
+    int last_diff_launches = 0;
+    uint64_t stat_launches = 0, stat_cmds = 0, stat_flushes = 0;
+};
+
+namespace {
+
+// one-thread kernel that marks the end of a flush in host-mapped memory
+__device__ __forceinline__ void k_flush_done(const uint32_t np2_bid, const uint32_t np2_nb, uint32_t *__restrict__ word, uint32_t seq) {
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Issue every recorded command of the active slots on the batch stream, merging equal kernels at the queue heads, then
+// wait for the device.  Called with sync_mu held by the last thread that arrived.
+void flush(np2_batch *b) {
+    const int n = (int)b->recs.size();
+    std::vector<size_t> idx(n, 0);
+    hipStream_t s = b->stream;
+    Recorder *saved = tl_recorder();
+    tl_recorder() = nullptr; // the launches below are real
+    try {
+        for (;;) {
+            // generic operations go out as soon as they reach the head of their queue
+            bool any = false;
+            for (int i = 0; i < n; ++i) {
+                auto &q = b->recs[i].q;
+                while (idx[i] < q.size() && !q[idx[i]].kd) {
+                    q[idx[i]].fn(s);
+                    ++idx[i];
+                    ++b->stat_cmds;
+                }
+                any |= idx[i] < q.size();
+            }
+            if (!any) break;
+            // the kernel most queues are waiting to launch (ties: the one of the lowest slot)
+            const KernelDesc *best = nullptr;
+            int best_n = 0;
+            for (int i = 0; i < n; ++i) {
+                auto &q = b->recs[i].q;
+                if (idx[i] >= q.size()) continue;
+                const KernelDesc *kd = q[idx[i]].kd;
+                int c = 0;
+                for (int j = i; j < n; ++j)
+                    if (idx[j] < b->recs[j].q.size() && b->recs[j].q[idx[j]].kd == kd) ++c;
+                if (c > best_n) best = kd, best_n = c;
+            }
+            uint32_t grids[MAXB];
+            const void *args[MAXB];
+            int m = 0;
+            const bool timed = b->time_diff && strcmp(best->name, "k_diff_reads") == 0;
+            auto issue = [&]() {
+                if (!m) return;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timed) {
+                    HIPCHK(hipEventCreate(&e0));
+                    HIPCHK(hipEventCreate(&e1));
+                    HIPCHK(hipEventRecord(e0, s));
+                }
+                best->launch(s, m, grids, args);
+                if (timed) {
+                    HIPCHK(hipEventRecord(e1, s));
+                    b->diff_events.push_back({e0, e1});
+                }
+                ++b->stat_launches;
+                m = 0;
+            };
+            for (int i = 0; i < n; ++i) {
+                auto &r = b->recs[i];
+                if (idx[i] >= r.q.size() || r.q[idx[i]].kd != best) continue;
+                grids[m] = r.q[idx[i]].grid;
+                args[m] = r.arena.data() + r.q[idx[i]].arg_off;
+                ++m;
+                ++idx[i];
+                ++b->stat_cmds;
+                if (m == best->max_batch) issue();
+            }
+            issue();
+        }
+        HIPCHK(hipGetLastError());
+        // completion: a last one-thread kernel posts a sequence number the host spins on (a stream synchronisation
+        // costs a few tens of microseconds more per flush)
+        const uint32_t seq = ++b->done_seq;
+        NP2_LAUNCH(k_flush_done, 1, 64, s, b->done_dev, seq);
+        uint64_t spins = 0;
+        while (__atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFF) == 0) {
+                hipError_t e = hipStreamQuery(s);
+                if (e != hipSuccess && e != hipErrorNotReady)
+                    throw Np2Error(NP2_E_DEVICE, std::string("device error during a batch flush: ") + hipGetErrorString(e));
+                if (e == hipSuccess && __atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) != seq)
+                    throw Np2Error(NP2_E_DEVICE, "batch flush completed without posting");
+            }
+        }
+    } catch (const std::exception &ex) {
+        b->fail_msg = ex.what();
+        b->failed.store(true);
+        (void)hipStreamSynchronize(s);
+    }
+    tl_recorder() = saved;
+    for (auto &r : b->recs) r.clear();
+    ++b->stat_flushes;
+}
+
+// Recorder::sync_fn: wait until every running pipeline of the wave has reached a synchronisation point; the last one
+// to arrive flushes for all.
+void group_sync(Recorder *r) {
+    np2_batch *b = (np2_batch *)r->group;
+    uint64_t my_gen;
+    {
+        std::lock_guard<std::mutex> l(b->sync_mu);
+        my_gen = b->flush_gen.load(std::memory_order_relaxed);
+        if (++b->n_waiting == b->n_active) {
+            flush(b);
+            b->n_waiting = 0;
+            b->flush_gen.store(my_gen + 1, std::memory_order_release);
+            if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
+            return;
+        }
+    }
+    uint32_t spins = 0;
+    while (b->flush_gen.load(std::memory_order_acquire) == my_gen) {
+        if (++spins > 2000) std::this_thread::yield(); // (a flush takes tens of microseconds; host phases a millisecond)
+    }
+    if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
+}
+
+// a pipeline left the wave (finished or failed): the others must not wait for it
+void leave_wave(np2_batch *b, Recorder *r) {
+    std::lock_guard<std::mutex> l(b->sync_mu);
+    r->clear(); // (commands recorded after the last synchronisation of a failed pipeline are dropped)
+    --b->n_active;
+    if (b->n_active > 0 && b->n_waiting == b->n_active) {
+        const uint64_t g = b->flush_gen.load(std::memory_order_relaxed);
+        flush(b);
+        b->n_waiting = 0;
+        b->flush_gen.store(g + 1, std::memory_order_release);
+    }
+}
+
+void worker_main(np2_batch *b, int slot) {
+    (void)hipSetDevice(b->device);
+    uint64_t seen = 0;
+    for (;;) {
+        Job job;
+        {
+            std::unique_lock<std::mutex> l(b->mu);
+            b->cv_start.wait(l, [&] { return b->quit || b->job_gen != seen; });
+            if (b->quit) return;
+            seen = b->job_gen;
+            job = b->jobs[slot];
+        }
+        if (!job.contig) continue; // this slot has no contig in this wave
+        Recorder *r = &b->recs[slot];
+        tl_recorder() = r;
+        int rc = np2_polish_resident(b->slots[slot], job.contig, job.opts, job.out_bases, job.out_pos, job.out_len);
+        tl_recorder() = nullptr;
+        for (void *p : r->graveyard) (void)hipFree(p);
+        r->graveyard.clear();
+        leave_wave(b, r);
+        if (rc == NP2_OK && job.out_span) (void)np2_last_span(b->slots[slot], &job.out_span[0], &job.out_span[1]);
+        *job.rc = rc;
+        {
+            std::lock_guard<std::mutex> l(b->mu);
+            if (--b->n_running == 0) b->cv_done.notify_all();
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int np2_batch_create(np2_batch_t **out, np2_ctx_t *parent, int n_slots) {
+    if (!out || !parent || n_slots < 1 || n_slots > 256) return NP2_E_ARG;
+    *out = nullptr;
+    np2_batch *b = new np2_batch();
+    b->parent = parent;
+    b->device = parent->device;
+    try {
+        HIPCHK(hipSetDevice(b->device));
+        HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        HIPCHK(hipHostMalloc((void **)&b->done_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *b->done_host = 0;
+        HIPCHK(hipHostGetDevicePointer((void **)&b->done_dev, b->done_host, 0));
+        b->recs.resize(n_slots);
+        b->jobs.resize(n_slots);
+        for (int i = 0; i < n_slots; ++i) {
+            np2_ctx *cx = nullptr;
+            int rc = np2_ctx_create_shared(&cx, parent);
+            if (rc) throw Np2Error(rc, "np2_ctx_create_shared failed");
+            b->slots.push_back(cx);
+            b->recs[i].group = b;
+            b->recs[i].slot = i;
+            b->recs[i].sync_fn = &group_sync;
+        }
+        for (int i = 0; i < n_slots; ++i) b->workers.emplace_back(worker_main, b, i);
+    } catch (const Np2Error &e) {
+        parent->err = e.what();
+        int code = e.code;
+        np2_batch_destroy(b);
+        return code;
+    }
+    *out = b;
+    return NP2_OK;
+}
+
+void np2_batch_destroy(np2_batch_t *b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> l(b->mu);
+        b->quit = true;
+    }
+    b->cv_start.notify_all();
+    for (auto &t : b->workers) t.join();
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (np2_ctx *cx : b->slots) np2_ctx_destroy(cx);
+    for (auto &e : b->diff_events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (b->done_host) (void)hipHostFree(b->done_host);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int np2_batch_slots(np2_batch_t *b) { return b ? (int)b->slots.size() : 0; }
+np2_ctx_t *np2_batch_slot_ctx(np2_batch_t *b, int slot) {
+    return (b && slot >= 0 && slot < (int)b->slots.size()) ? b->slots[slot] : nullptr;
+}
+const char *np2_batch_last_error(np2_batch_t *b) { return b ? b->err.c_str() : "null batch"; }
+
+int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const np2_opts_t *opts, uint8_t **out_bases,
+                     uint32_t **out_pos, uint64_t *out_len, uint32_t *out_span, int *rcs) {
+    if (!b || !contigs || n < 0 || !opts || !out_len || !rcs) return NP2_E_ARG;
+    const int S = (int)b->slots.size();
+    int worst = NP2_OK;
+    if (b->time_diff) {
+        for (auto &e : b->diff_events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        b->diff_events.clear();
+    }
+    for (int w0 = 0; w0 < n; w0 += S) { // waves of at most S contigs; contig w0 + i runs on slot i
+        const int m = std::min(S, n - w0);
+        {
+            std::lock_guard<std::mutex> l(b->mu);
+            for (int i = 0; i < S; ++i) {
+                Job j;
+                if (i < m) {
+                    j.contig = contigs[w0 + i];
+                    j.opts = opts;
+                    j.out_bases = out_bases ? &out_bases[w0 + i] : nullptr;
+                    j.out_pos = out_pos ? &out_pos[w0 + i] : nullptr;
+                    j.out_len = &out_len[w0 + i];
+                    j.out_span = out_span ? &out_span[2 * (w0 + i)] : nullptr;
+                    j.rc = &rcs[w0 + i];
+                }
+                b->jobs[i] = j;
+            }
+            b->n_running = m;
+            {
+                std::lock_guard<std::mutex> l2(b->sync_mu);
+                b->n_active = m;
+                b->n_waiting = 0;
+                b->failed.store(false);
+            }
+            ++b->job_gen;
+        }
+        b->cv_start.notify_all();
+        {
+            std::unique_lock<std::mutex> l(b->mu);
+            b->cv_done.wait(l, [&] { return b->n_running == 0; });
+        }
+        for (int i = 0; i < m; ++i)
+            if (rcs[w0 + i] != NP2_OK) {
+                worst = rcs[w0 + i];
+                b->err = std::string("contig ") + std::to_string(w0 + i) + ": " + np2_last_error(b->slots[i]);
+            }
+    }
+    if (b->time_diff) {
+        b->last_diff_ms = 0;
+        b->last_diff_launches = (int)b->diff_events.size();
+        for (auto &e : b->diff_events) {
+            float ms = 0;
+            (void)hipEventSynchronize(e.second);
+            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            b->last_diff_ms += ms;
+        }
+    }
+    return worst;
+}
+
+void np2_batch_set_timing(np2_batch_t *b, int enable) {
+    if (b) b->time_diff = enable != 0;
+}
+int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches) {
+    if (!b || !ms || !launches) return NP2_E_ARG;
+    *ms = b->last_diff_ms;
+    *launches = b->last_diff_launches;
+    return NP2_OK;
+}
+int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes) {
+    if (!b || !launches || !commands || !flushes) return NP2_E_ARG;
+    *launches = b->stat_launches;
+    *commands = b->stat_cmds;
+    *flushes = b->stat_flushes;
+    return NP2_OK;
+}
+}

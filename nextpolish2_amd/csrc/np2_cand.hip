@@ -16,7 +16,7 @@ namespace np2 {
 // element count may live on the device
 // ------------------------------------------------------------------------------------------------------
 template <int MODE> // 0: exclusive sum (optionally out[n] = total), 1: inclusive sum, 2: inclusive min (signed)
-__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+__device__ __forceinline__ void k_scan_small(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                      uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                      uint32_t *__restrict__ total_out, bool write_end) {
     __shared__ uint32_t sh[16];
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *__restrict_
 // Mid-sized exclusive sums (8 k .. 64 k elements, length known on the host): the single-block scan above costs ~12 us per
 // 20 k elements whatever its tuning; a few dozen light, uniform blocks are what the decoupled look-back is good at.
 static constexpr uint32_t SCAN_LB_ITEMS = 8; // elements per thread, blocked: thread t owns [8t, 8t + 8) of its block's 2048
-__global__ __launch_bounds__(256) void k_scan_lb_excl(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
+__device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint32_t n, bool write_end,
                                                       uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
@@ -62,6 +62,67 @@ __global__ __launch_bounds__(256) void k_scan_lb_excl(Lookback lb, uint32_t n_bl
         run += v[k];
     }
     if (write_end && bid == n_blocks - 1 && threadIdx.x == 255) out[n] = run; // (the last thread's running sum = total)
+}
+
+// Long exclusive sums (one element per contig position / consensus base / band slot): reduce-then-scan.  Tiles of 4096
+// elements: (1) tile sums, (2) a single-block scan of the tile sums (k_scan_small), (3) tile-local scans seeded with
+// the tile offsets.  12 B of traffic per element, three launches whatever the number of contigs in the batch, no
+// inter-block waiting (a chained look-back over thousands of tiles measured 100x slower here).
+static constexpr uint32_t SCAN3_ITEMS = 16;
+static constexpr uint32_t SCAN3_TILE = 256 * SCAN3_ITEMS;
+__device__ __forceinline__ void scan3_load(const uint32_t *__restrict__ in, uint32_t i0, uint32_t n, uint32_t (&v)[SCAN3_ITEMS]) {
+    if (i0 + SCAN3_ITEMS <= n) {
+#pragma unroll
+        for (uint32_t q = 0; q < SCAN3_ITEMS / 4; ++q) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(in + i0 + 4 * q);
+            v[4 * q] = w.x, v[4 * q + 1] = w.y, v[4 * q + 2] = w.z, v[4 * q + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN3_ITEMS; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
+    }
+}
+__device__ __forceinline__ void k_scan3_part(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in, uint32_t n,
+                                             uint32_t *__restrict__ part) {
+    __shared__ uint32_t sh[4];
+    uint32_t v[SCAN3_ITEMS], sum = 0;
+    scan3_load(in, np2_bid * SCAN3_TILE + threadIdx.x * SCAN3_ITEMS, n, v);
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN3_ITEMS; ++k) sum += v[k];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[np2_bid] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ void k_scan3_apply(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                              uint32_t n, const uint32_t *__restrict__ part_off, bool write_end) {
+    __shared__ uint32_t sh[4];
+    const uint32_t i0 = np2_bid * SCAN3_TILE + threadIdx.x * SCAN3_ITEMS;
+    uint32_t v[SCAN3_ITEMS], sum = 0;
+    scan3_load(in, i0, n, v);
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN3_ITEMS; ++k) sum += v[k];
+    uint32_t total;
+    uint32_t run = part_off[np2_bid] + block_excl_scan<OpAdd, 4>(sum, sh, total);
+    if (i0 + SCAN3_ITEMS <= n) {
+#pragma unroll
+        for (uint32_t q = 0; q < SCAN3_ITEMS / 4; ++q) {
+            uint4 w;
+            w.x = run, run += v[4 * q];
+            w.y = run, run += v[4 * q + 1];
+            w.z = run, run += v[4 * q + 2];
+            w.w = run, run += v[4 * q + 3];
+            *reinterpret_cast<uint4 *>(out + i0 + 4 * q) = w;
+        }
+        if (write_end && i0 + SCAN3_ITEMS == n) out[n] = run;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN3_ITEMS; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+            if (write_end && i0 + k + 1 == n) out[n] = run;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -270,14 +331,14 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 // yields a non-empty string has lq_end[g] inside the read, so the reads overlapping that position's contig tile are
 // the only ones to test; the list is ascending in read index = the order the reference visits alignseqs in.
 // Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col.
-__global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
+__device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
                                                         uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
-    // blk_sum: per block of 4 regions, three arrays of gridDim.x entries: candidates, bytes, longest kept strings
+    // blk_sum: per block of 4 regions, three arrays of np2_nb entries: candidates, bytes, longest kept strings
     __shared__ uint32_t s_w[3][4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t g = blockIdx.x * 4 + wv;
+    const uint32_t g = np2_bid * 4 + wv;
     const bool live = g < n_reg;
     const uint32_t start = live ? cx.lq_start[g] : 0u, end = live ? cx.lq_end[g] : 0u;
     uint32_t mx = 0;
@@ -323,12 +384,12 @@ __global__ __launch_bounds__(256) void k_region_measure(CandCtx cx, uint32_t n_r
     }
     __syncthreads();
     if (threadIdx.x < 3)
-        blk_sum[threadIdx.x * gridDim.x + blockIdx.x] =
+        blk_sum[threadIdx.x * np2_nb + np2_bid] =
             s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
 }
 
 // candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
-__global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restrict__ blk_sum, uint32_t n_blk,
+__device__ __forceinline__ void k_cand_offsets(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ blk_sum, uint32_t n_blk,
                                                        uint32_t n_reg, uint32_t *__restrict__ blk_coff,
                                                        uint32_t *__restrict__ blk_soff, uint32_t *__restrict__ cand_off,
                                                        uint32_t *__restrict__ reg_soff, uint32_t *__restrict__ n_cand,
@@ -351,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(const uint32_t *__restric
 }
 
 // the same with a few blocks chained by the look-back (1024 region blocks each); block 0 also adds up the growth bound
-__global__ __launch_bounds__(256) void k_cand_offsets_lb(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ blk_sum,
+__device__ __forceinline__ void k_cand_offsets_lb(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ blk_sum,
                                                          uint32_t n_blk, uint32_t n_reg, uint32_t *__restrict__ blk_coff,
                                                          uint32_t *__restrict__ blk_soff, uint32_t *__restrict__ cand_off,
                                                          uint32_t *__restrict__ reg_soff, uint32_t *__restrict__ n_cand,
@@ -396,7 +457,7 @@ __global__ __launch_bounds__(256) void k_cand_offsets_lb(Lookback lb, uint32_t n
 }
 
 // one lane per kept candidate (at most 60 per region = one pass of the wave)
-__global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
+__device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
                                                       const uint32_t *__restrict__ kept_len,
                                                       const uint32_t *__restrict__ kept_col,
                                                       const uint32_t *__restrict__ reg_ncand,
@@ -409,12 +470,12 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t g = np2_bid * 4 + (threadIdx.x >> 6);
     if (g >= n_reg) return;
     if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
     // offsets of this region: its block's prefix + the regions before it inside the block of 4
-    uint32_t oc = blk_coff[blockIdx.x], ob = blk_soff[blockIdx.x];
-    for (uint32_t w = blockIdx.x * 4; w < g; ++w) {
+    uint32_t oc = blk_coff[np2_bid], ob = blk_soff[np2_bid];
+    for (uint32_t w = np2_bid * 4; w < g; ++w) {
         oc += reg_ncand[w];
         ob += reg_bytes[w];
     }
@@ -441,20 +502,27 @@ __global__ __launch_bounds__(256) void k_region_write(CandCtx cx, uint32_t n_reg
 // ------------------------------------------------------------------------------------------------------
 void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
                             uint32_t *total_out, bool write_end) {
-    hipLaunchKernelGGL(k_scan_small<0>, dim3(1), dim3(1024), 0, s, in, out, n, n_dev, total_out, write_end);
+    NP2_LAUNCH(k_scan_small<0>, dim3(1), 1024, s, in, out, n, n_dev, total_out, write_end);
 }
 void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
                           uint32_t *err) {
     const uint32_t nb = (n + 256 * SCAN_LB_ITEMS - 1) / (256 * SCAN_LB_ITEMS);
-    hipLaunchKernelGGL(k_scan_lb_excl, dim3(nb), dim3(256), 0, s, lb, nb, in, out, n, write_end, err);
+    NP2_LAUNCH(k_scan_lb_excl, dim3(nb), 256, s, lb, nb, in, out, n, write_end, err);
+}
+uint32_t scan3_tiles(uint32_t n) { return (n + SCAN3_TILE - 1) / SCAN3_TILE; }
+void launch_scan3_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part, uint32_t *part_off,
+                       bool write_end) {
+    if (!n) return;
+    const uint32_t nt = scan3_tiles(n);
+    NP2_LAUNCH(k_scan3_part, nt, 256, s, in, n, part);
+    NP2_LAUNCH(k_scan_small<0>, 1, 1024, s, (const uint32_t *)part, part_off, nt, (const uint32_t *)nullptr, (uint32_t *)nullptr, false);
+    NP2_LAUNCH(k_scan3_apply, nt, 256, s, in, out, n, (const uint32_t *)part_off, write_end);
 }
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev) {
-    hipLaunchKernelGGL(k_scan_small<1>, dim3(1), dim3(1024), 0, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev,
-                       (uint32_t *)nullptr, false);
+    NP2_LAUNCH(k_scan_small<1>, dim3(1), 1024, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev, (uint32_t *)nullptr, false);
 }
 void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev) {
-    hipLaunchKernelGGL(k_scan_small<2>, dim3(1), dim3(1024), 0, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev,
-                       (uint32_t *)nullptr, false);
+    NP2_LAUNCH(k_scan_small<2>, dim3(1), 1024, s, (const uint32_t *)in, (uint32_t *)out, n, n_dev, (uint32_t *)nullptr, false);
 }
 static CandCtx mk_cand(const CandPtrs &c) {
     return CandCtx{c.reads, c.nib,    c.ck_off, c.ckpt,        c.lq_start, c.lq_end, c.pj,
@@ -464,20 +532,16 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum) {
     if (n_reg)
-        hipLaunchKernelGGL(k_region_measure, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
+        NP2_LAUNCH(k_region_measure, dim3((n_reg + 3) / 4), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
                          uint32_t *cand_off, uint32_t *reg_soff, uint32_t *n_cand, uint32_t *n_bytes, uint32_t *grow,
                          const Lookback *lb, uint32_t *err) {
     if (lb)
-        hipLaunchKernelGGL(k_cand_offsets_lb, dim3(cand_offsets_blocks(n_reg)), dim3(256), 0, s, *lb,
-                           cand_offsets_blocks(n_reg), blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff, cand_off, reg_soff,
-                           n_cand, n_bytes, grow, err);
+        NP2_LAUNCH(k_cand_offsets_lb, dim3(cand_offsets_blocks(n_reg)), 256, s, *lb, cand_offsets_blocks(n_reg), blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff, cand_off, reg_soff, n_cand, n_bytes, grow, err);
     else
-        hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff,
-                           cand_off, reg_soff, n_cand, n_bytes, grow);
+        NP2_LAUNCH(k_cand_offsets, dim3(1), 1024, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff, cand_off, reg_soff, n_cand, n_bytes, grow);
 }
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
@@ -485,9 +549,7 @@ void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const
                          uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap, uint32_t *cand_order, uint64_t *cand_kmer,
                          uint32_t *cand_seq_off, uint8_t *cand_seq) {
     if (n_reg)
-        hipLaunchKernelGGL(k_region_write, dim3((n_reg + 3) / 4), dim3(256), 0, s, mk_cand(c), n_reg, kept_read, kept_len,
-                           kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap,
-                           cand_order, cand_kmer, cand_seq_off, cand_seq);
+        NP2_LAUNCH(k_region_write, dim3((n_reg + 3) / 4), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off, cand_seq);
 }
 
 } // namespace np2

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -39,7 +40,12 @@ template <class T> struct DevBuf {
     size_t cap = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (Recorder *r = tl_recorder())
+                r->graveyard.push_back(p); // recorded, not yet issued commands may name it: freed after the next flush
+            else
+                (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
@@ -118,8 +124,8 @@ struct PinnedBuf {
 
 struct YakTable {
     uint32_t k = 0, cap_log2 = 0;
-    DevBuf<uint64_t> table;
-    YakDev dev() const { return YakDev{table.p, cap_log2, k}; }
+    std::shared_ptr<DevBuf<uint64_t>> table; // shared by the contexts of one device (np2_ctx_create_shared)
+    YakDev dev() const { return YakDev{table->p, cap_log2, k}; }
 };
 
 struct Timing {
@@ -183,6 +189,7 @@ struct np2_ctx {
     const uint8_t *last_dbase = nullptr; // device copy of the last polished sequence (valid until the next call)
     uint64_t last_len = 0;
     bool reuse_identical_pass = true;
+    bool h2d_inflight = false; // pin_h2d holds data of a copy that may not have completed yet
     bool stage_timing = false; // arm every stage timer (np2_ctx_set_timing)
     // scratch (reused across contigs)
     DevBuf<uint8_t> tmp;
@@ -200,6 +207,7 @@ struct np2_ctx {
     DevBuf<uint8_t> cand_seq;
     DevBuf<uint16_t> kscore;
     DevBuf<uint32_t> scal; // device scalars: see enum below
+    DevBuf<uint32_t> scan_part, scan_poff; // tile sums / offsets of the long scans
     // decoupled look-back state (np2_lookback.hpp): status words per block, ticket counter, launch epoch
     DevBuf<uint64_t> lb_status;
     DevBuf<uint32_t> lb_ticket;
@@ -223,6 +231,7 @@ struct np2_ctx {
     uint32_t bucket_cap = 0;      // layout of the sorted records of the current contig (0 = compact)
     DevBuf<uint2> nrec;
     DevBuf<uint8_t> votebuf;
+    DevBuf<uint32_t> band, band_n, band_off; // banded read-pair accumulator of the phasing vote
     DevBuf<int64_t> run_gain, tile_gain;
     DevBuf<uint8_t> out_snap;
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
@@ -256,7 +265,8 @@ struct EventTimer {
     np2_ctx *cx;
     hipEvent_t a = nullptr, b = nullptr;
     bool on;
-    EventTimer(np2_ctx *c, const char *name, bool always = false) : cx(c), on(always || c->stage_timing) {
+    EventTimer(np2_ctx *c, const char *name, bool always = false)
+        : cx(c), on((always || c->stage_timing) && !tl_recorder()) { // (batched launches are timed by the batch driver)
         if (!on) return;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
@@ -302,12 +312,49 @@ inline void flush_timings(np2_ctx *cx) {
     cx->timing.joined.push_back('\0');
 }
 
+// ---- stream operations of the per-contig pipeline ------------------------------------------------------------------
+// Issued on the context's stream, or recorded when this thread runs under the batch driver (np2_launch.hpp): fills and
+// device-to-device copies are kernels (so that they batch across contigs), host transfers are generic recorded
+// operations, a synchronisation flushes the whole group.
+inline void recorder_sync(Recorder *r) {
+    r->sync_fn(r);
+    for (void *p : r->graveyard) (void)hipFree(p);
+    r->graveyard.clear();
+}
+inline void op_sync(np2_ctx *cx) {
+    if (Recorder *r = tl_recorder())
+        recorder_sync(r);
+    else
+        HIPCHK(hipStreamSynchronize(cx->stream));
+    cx->h2d_inflight = false;
+}
+inline void op_fill(np2_ctx *cx, void *p, uint8_t byte, size_t bytes) {
+    if (bytes) launch_fill(cx->stream, (uint8_t *)p, bytes, byte);
+}
+inline void op_copy_d2d(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
+    if (bytes) launch_copy(cx->stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+}
+inline void op_d2h(np2_ctx *cx, void *pinned_dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (Recorder *r = tl_recorder())
+        r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, s)); });
+    else
+        HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, cx->stream));
+}
+inline void op_h2d(np2_ctx *cx, void *dst, const void *pinned_src, size_t bytes) {
+    if (!bytes) return;
+    if (Recorder *r = tl_recorder())
+        r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, s)); });
+    else
+        HIPCHK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, cx->stream));
+}
+
 template <class T> std::vector<T> d2h(np2_ctx *cx, const T *d, size_t n) {
     std::vector<T> v(n);
     if (n) {
         void *pin = cx->pin_d2h.ensure(n * sizeof(T));
-        HIPCHK(hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, cx->stream));
-        HIPCHK(hipStreamSynchronize(cx->stream));
+        op_d2h(cx, pin, d, n * sizeof(T));
+        op_sync(cx);
         memcpy(v.data(), pin, n * sizeof(T));
     }
     return v;
@@ -324,10 +371,11 @@ inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0 = nullptr, con
 // host -> device through the pinned staging buffer (valid until the next h2d_staged or an explicit sync)
 inline void h2d_staged(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
-    HIPCHK(hipStreamSynchronize(cx->stream)); // the staging buffer may still be in flight
+    if (cx->h2d_inflight) op_sync(cx); // the staging buffer may still be in flight (cleared by every synchronisation)
     void *pin = cx->pin_h2d.ensure(bytes);
     memcpy(pin, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, cx->stream));
+    op_h2d(cx, dst, pin, bytes);
+    cx->h2d_inflight = true;
 }
 template <class T> void trace_put(np2_ctx *cx, int pass, const std::string &name, const std::vector<T> &v) {
     if (!cx->trace) return;
@@ -341,6 +389,13 @@ inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_
                                         const uint32_t *ends_of, uint32_t *ends_dst) {
     const uint32_t seq = ++cx->mbox_seq;
     launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, d0, s0, d1, s1, d2, s2, d3, s3, ends_of, ends_dst);
+    cx->h2d_inflight = false;
+    if (Recorder *r = tl_recorder()) { // batch driver: flush the group's queues and wait for the device
+        recorder_sync(r);
+        if (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
+            throw Np2Error(NP2_E_DEVICE, "mailbox not posted after a batch flush");
+        return std::vector<uint32_t>(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
+    }
     uint64_t spins = 0;
     while (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0xFFFF) == 0) { // a failed launch / device fault would never post: surface it
@@ -362,13 +417,13 @@ inline Lookback next_lookback(np2_ctx *cx, uint32_t n_blocks) {
     if (!cx->lb_status.p) {
         cx->lb_status.ensure(2 * np2_ctx::LB_MAX_BLOCKS);
         cx->lb_ticket.ensure(4);
-        HIPCHK(hipMemsetAsync(cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t), cx->stream));
-        HIPCHK(hipMemsetAsync(cx->lb_ticket.p, 0, 16, cx->stream));
+        op_fill(cx, cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t));
+        op_fill(cx, cx->lb_ticket.p, 0, 16);
         cx->lb_ticket_total = 0;
         cx->lb_epoch = 0;
     }
     if (++cx->lb_epoch >= (1u << 30)) { // epochs exhausted: start over with cleared status words
-        HIPCHK(hipMemsetAsync(cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t), cx->stream));
+        op_fill(cx, cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t));
         cx->lb_epoch = 1;
     }
     Lookback lb{cx->lb_status.p, cx->lb_status.p + np2_ctx::LB_MAX_BLOCKS, cx->lb_ticket.p, cx->lb_ticket_total,
@@ -377,32 +432,52 @@ inline Lookback next_lookback(np2_ctx *cx, uint32_t n_blocks) {
     return lb;
 }
 
+// a rocPRIM call (device-wide sort / long signed scans): runs on the context's stream, or is recorded as one
+// un-batched operation of this contig's queue
+template <class F> inline void prim_op(np2_ctx *cx, F f) {
+    if (Recorder *r = tl_recorder())
+        r->push_fn(f);
+    else
+        f(cx->stream);
+}
+// exclusive sum of any length: reduce-then-scan over 4096-element tiles (np2_cand.hip)
+inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n, bool write_end = false) {
+    if (n >= 0xFFFFF000ull) throw Np2Error(NP2_E_NOMEM, "scan over more than 2^32 elements");
+    const uint32_t nt = scan3_tiles((uint32_t)n);
+    cx->scan_part.ensure((size_t)nt + 2);
+    cx->scan_poff.ensure((size_t)nt + 2);
+    launch_scan3_excl(cx->stream, in, out, (uint32_t)n, cx->scan_part.p, cx->scan_poff.p, write_end);
+}
+
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
     // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
     if (n_plus1 <= SCAN_SMALL_MAX) {
         launch_scan_small_excl(cx->stream, in, out, (uint32_t)n_plus1, nullptr, nullptr, false);
         return 0;
     }
-    int rc = prim_exclusive_sum_u32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n_plus1);
-    if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim exclusive_scan failed");
+    scan_large_excl(cx, in, out, n_plus1);
     return 0;
 }
 inline void scan_incl_min(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n) {
     if (n <= SCAN_SMALL_MAX) {
         launch_scan_small_min(cx->stream, in, out, (uint32_t)n, nullptr);
-    } else if (prim_inclusive_min_i32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n)) {
-        throw Np2Error(NP2_E_DEVICE, "rocprim min-scan failed");
+    } else {
+        prim_op(cx, [=](hipStream_t s) {
+            if (prim_inclusive_min_i32(s, cx->tmp.p, cx->tmp.cap, in, out, n)) throw Np2Error(NP2_E_DEVICE, "rocprim min-scan failed");
+        });
     }
 }
 inline void scan_incl_sum(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n) {
     if (n <= SCAN_SMALL_MAX) {
         launch_scan_small_incl(cx->stream, in, out, (uint32_t)n, nullptr);
-    } else if (prim_inclusive_sum_i32(cx->stream, cx->tmp.p, cx->tmp.cap, in, out, n)) {
-        throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+    } else {
+        prim_op(cx, [=](hipStream_t s) {
+            if (prim_inclusive_sum_i32(s, cx->tmp.p, cx->tmp.cap, in, out, n)) throw Np2Error(NP2_E_DEVICE, "rocprim inclusive_scan failed");
+        });
     }
 }
 inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
-    if (n_elems) HIPCHK(hipMemsetAsync(p, 0, n_elems * elem, cx->stream));
+    op_fill(cx, p, 0, n_elems * elem);
 }
 // exclusive sums of in[0..n) into out[0..n], out[n] = total (in[n] is not read by the short path, cleared for the long one)
 inline void exclusive_total_n(np2_ctx *cx, uint32_t *in, uint32_t *out, size_t n) {

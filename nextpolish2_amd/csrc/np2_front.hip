@@ -92,12 +92,12 @@ __device__ __forceinline__ uint32_t run8_ends(uint32_t m, uint32_t prev_m) {
     return (uint32_t)y;
 }
 
-__global__ __launch_bounds__(256) void k_columnarise(const FrontRec *__restrict__ recs, uint32_t n_recs,
+__device__ __forceinline__ void k_columnarise(const uint32_t np2_bid, const uint32_t np2_nb, const FrontRec *__restrict__ recs, uint32_t n_recs,
                                                      const FrontOp *__restrict__ ops, const uint8_t *__restrict__ ref,
                                                      const uint8_t *__restrict__ seq4, uint8_t *__restrict__ nib,
                                                      FrontOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t r = (np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (r >= n_recs) return;
     const FrontRec rc = recs[r];
     const uint32_t N = rc.n_cols;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void k_columnarise(const FrontRec *__restrict_
 }
 
 // reads[0]: the contig aligned to itself (main.rs:1732-1739), packed like any other AlignSeq
-__global__ void k_pack_ref(const uint8_t *__restrict__ ref, uint32_t L, uint8_t *__restrict__ dst) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; // output byte
+__device__ __forceinline__ void k_pack_ref(const uint32_t np2_bid, const uint32_t np2_nb, const uint8_t *__restrict__ ref, uint32_t L, uint8_t *__restrict__ dst) {
+    const uint32_t b = np2_bid * blockDim.x + threadIdx.x; // output byte
     const uint32_t nbytes = ((L + 1) >> 1) + 1;
     if (b >= nbytes) return;
     const uint32_t c0 = 2 * b, c1 = 2 * b + 1;
@@ -198,12 +198,11 @@ __global__ void k_pack_ref(const uint8_t *__restrict__ ref, uint32_t L, uint8_t 
 void launch_columnarise(hipStream_t s, const FrontRec *recs, uint32_t n_recs, const FrontOp *ops, const uint8_t *ref,
                         const uint8_t *seq4, uint8_t *nib, FrontOut *out) {
     if (n_recs)
-        hipLaunchKernelGGL(k_columnarise, dim3((n_recs + 3) / 4), dim3(256), 0, s, recs, n_recs, ops, ref, seq4, nib,
-                           out);
+        NP2_LAUNCH(k_columnarise, dim3((n_recs + 3) / 4), 256, s, recs, n_recs, ops, ref, seq4, nib, out);
 }
 void launch_pack_ref(hipStream_t s, const uint8_t *ref, uint32_t L, uint8_t *dst) {
     const uint32_t nbytes = ((L + 1) >> 1) + 1;
-    hipLaunchKernelGGL(k_pack_ref, dim3((nbytes + 255) / 256), dim3(256), 0, s, ref, L, dst);
+    NP2_LAUNCH(k_pack_ref, dim3((nbytes + 255) / 256), 256, s, ref, L, dst);
 }
 
 } // namespace np2

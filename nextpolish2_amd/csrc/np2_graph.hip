@@ -66,7 +66,7 @@ __device__ uint64_t make_node_key(const np2_read_t *__restrict__ reads, const ui
 // single block: per-tile record counts -> tile_n (the cursors are reset for the next contig), exclusive scans of
 // the true counts (tile_scan: compact layout) and of the bucket-resident counts (tile_scanb), and the mailbox:
 // out[0] = T, out[1] = largest tile, out[2] = records spilled to the overflow area
-__global__ __launch_bounds__(1024) void k_tile_layout(uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
+__device__ __forceinline__ void k_tile_layout(const uint32_t np2_bid, const uint32_t np2_nb, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
                                                       uint32_t bucket_cap, uint32_t *__restrict__ tile_n,
                                                       uint32_t *__restrict__ tile_scan, uint32_t *__restrict__ tile_scanb,
                                                       const uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ out) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_tile_layout(uint32_t *__restrict__ til
 // the blocks by the look-back (a handful of light, uniform blocks), the maximum by one atomic per wave (out[1] is zero
 // before: the scalar block is cleared ahead of the dense pass)
 static constexpr uint32_t TLB_ITEMS = 4;
-__global__ __launch_bounds__(256) void k_tile_layout_lb(Lookback lb, uint32_t n_blocks, uint32_t *__restrict__ tile_cur,
+__device__ __forceinline__ void k_tile_layout_lb(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, uint32_t *__restrict__ tile_cur,
                                                         uint32_t n_tiles, uint32_t bucket_cap, uint32_t *__restrict__ tile_n,
                                                         uint32_t *__restrict__ tile_scan, uint32_t *__restrict__ tile_scanb,
                                                         const uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ out,
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(256) void k_tile_layout_lb(Lookback lb, uint32_t n_
 // one block per tile: raw records of the tile's bucket -> node keys, bitonic sort of the (key, read) pairs in LDS,
 // written back in place.  Pairs are unique, so the result does not depend on the order the bucket was filled in.
 template <uint32_t CAP>
-__global__ __launch_bounds__(256) void k_tile_sort(const np2_read_t *__restrict__ reads,
+__device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads,
                                                    const uint8_t *__restrict__ nib, const uint32_t *__restrict__ tile_n,
                                                    uint32_t bucket_cap, uint64_t *__restrict__ keys,
                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ err) {
     __shared__ uint64_t sk[CAP];
     __shared__ uint32_t sv[CAP];
-    const uint32_t n = tile_n[blockIdx.x];
-    const uint64_t a = (uint64_t)blockIdx.x * bucket_cap;
+    const uint32_t n = tile_n[np2_bid];
+    const uint64_t a = (uint64_t)np2_bid * bucket_cap;
     if (n == 0) return;
     if (n > CAP) {
         if (threadIdx.x == 0) atomicOr(err, 8u);
@@ -193,26 +193,26 @@ __global__ __launch_bounds__(256) void k_tile_sort(const np2_read_t *__restrict_
 
 // oversized tiles: gather bucket-resident and spilled raw records into one compact array of node keys
 // (sorted device-wide afterwards)
-__global__ __launch_bounds__(256) void k_gather_buckets(const np2_read_t *__restrict__ reads,
+__device__ __forceinline__ void k_gather_buckets(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads,
                                                         const uint8_t *__restrict__ nib,
                                                         const uint32_t *__restrict__ tile_n,
                                                         const uint32_t *__restrict__ tile_scanb, uint32_t bucket_cap,
                                                         const uint64_t *__restrict__ bkeys,
                                                         const uint32_t *__restrict__ bvals, uint64_t *__restrict__ keys,
                                                         uint32_t *__restrict__ vals) {
-    const uint32_t n = min(tile_n[blockIdx.x], bucket_cap);
-    const uint64_t a = (uint64_t)blockIdx.x * bucket_cap;
-    const uint32_t dst = tile_scanb[blockIdx.x];
+    const uint32_t n = min(tile_n[np2_bid], bucket_cap);
+    const uint64_t a = (uint64_t)np2_bid * bucket_cap;
+    const uint32_t dst = tile_scanb[np2_bid];
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t r = bvals[a + i];
         keys[dst + i] = make_node_key(reads, nib, bkeys[a + i], r);
         vals[dst + i] = r;
     }
 }
-__global__ void k_gather_spill(const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib,
+__device__ __forceinline__ void k_gather_spill(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, const uint8_t *__restrict__ nib,
                                const uint64_t *__restrict__ okeys, const uint32_t *__restrict__ ovals, uint32_t n,
                                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = ovals[i];
     keys[i] = make_node_key(reads, nib, okeys[i], r);
@@ -261,7 +261,7 @@ struct TileLayout {
 
 static constexpr uint32_t TC_CAP = 2048; // records of a tile staged in LDS by k_tile_count
 
-__global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ keys,
+__device__ __forceinline__ void k_tile_count(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
                                                     const uint8_t *__restrict__ alive,
                                                     uint32_t *__restrict__ tile_nn, uint32_t *__restrict__ tile_nr) {
@@ -271,18 +271,18 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__
     __shared__ uint64_t s_k[TC_CAP];
     __shared__ uint8_t s_live[TC_CAP];
     const uint32_t tid = threadIdx.x;
-    const uint64_t a = tl.begin(blockIdx.x);
-    const uint32_t n = tl.tile_n[blockIdx.x];
+    const uint64_t a = tl.begin(np2_bid);
+    const uint32_t n = tl.tile_n[np2_bid];
     const uint64_t b = a + n;
-    const uint32_t start = blockIdx.x << TILE_SHIFT;
+    const uint32_t start = np2_bid << TILE_SHIFT;
     const bool fast = n <= TC_CAP;
     if (tid < TILE / 32) dirty[tid] = 0;
     if (tid < 2) acc[tid] = 0;
     if (tid == 0) {
         prevd = 0;
         if (start && n) {
-            const uint64_t pa = tl.begin(blockIdx.x - 1);
-            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
+            const uint64_t pa = tl.begin(np2_bid - 1);
+            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[np2_bid - 1], start - 1) ? 1u : 0u;
         }
     }
     if (fast) {
@@ -321,13 +321,13 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__
     }
     __syncthreads();
     if (tid == 0) {
-        tile_nn[blockIdx.x] = acc[0];
-        tile_nr[blockIdx.x] = acc[1];
+        tile_nn[np2_bid] = acc[0];
+        tile_nr[np2_bid] = acc[1];
     }
 }
 
 // single block: exclusive scans of the per-tile node and run counts; totals -> n_nodes / n_runs
-__global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restrict__ tile_nn,
+__device__ __forceinline__ void k_tile_offsets(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ tile_nn,
                                                        const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
                                                        uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
                                                        uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
@@ -344,14 +344,14 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_offsets_lb(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ tile_nn,
+__device__ __forceinline__ void k_tile_offsets_lb(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ tile_nn,
                                                          const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
                                                          uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
                                                          uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
                                                          uint32_t *__restrict__ reset, uint32_t n_reset,
                                                          uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
-    if (blockIdx.x == 0 && threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars
+    if (np2_bid == 0 && threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars
     const uint32_t bid = lb_block_id(lb, sh);
     const uint32_t i0 = (bid * 256 + threadIdx.x) * TLB_ITEMS;
     uint32_t a[TLB_ITEMS], b[TLB_ITEMS], sa = 0, sb = 0;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_tile_offsets_lb(Lookback lb, uint32_t n
 // ordering never touch global memory.  Larger tiles take the same steps on the global arrays.
 static constexpr uint32_t TW_CAP = 1024;
 
-__global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__ keys,
+__device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
                                                     const uint32_t *__restrict__ tile_noff,
                                                     const uint32_t *__restrict__ tile_roff,
@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     __shared__ uint32_t s_ncnt[TW_CAP];
     __shared__ uint32_t s_nmin[TW_CAP];
     const uint32_t tid = threadIdx.x;
-    const uint64_t a = tl.begin(blockIdx.x);
-    const uint32_t n = tl.tile_n[blockIdx.x];
+    const uint64_t a = tl.begin(np2_bid);
+    const uint32_t n = tl.tile_n[np2_bid];
     const uint64_t b = a + n;
-    const uint32_t start = blockIdx.x << TILE_SHIFT;
+    const uint32_t start = np2_bid << TILE_SHIFT;
     const uint32_t npos = min((uint32_t)TILE, L - start);
-    const uint32_t nbase = tile_noff[blockIdx.x];
+    const uint32_t nbase = tile_noff[np2_bid];
     const bool fast = n <= TW_CAP;
     for (uint32_t i = tid; i < TILE; i += 256) {
         cnt[i] = 0;
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
         dcov[TILE] = 0;
         prevd = 0;
         if (start) {
-            const uint64_t pa = tl.begin(blockIdx.x - 1);
-            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[blockIdx.x - 1], start - 1) ? 1u : 0u;
+            const uint64_t pa = tl.begin(np2_bid - 1);
+            prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[np2_bid - 1], start - 1) ? 1u : 0u;
         }
     }
     if (fast) {
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     __syncthreads();
     // ---- coverage of the tile's positions (Msa::coverage, main.rs:232-241): difference array over the live reads
     //      overlapping the tile, then a block-wide inclusive scan ----------------------------------------------
-    for (uint32_t i = tile_rd_off[blockIdx.x] + tid; i < tile_rd_off[blockIdx.x + 1]; i += 256) {
+    for (uint32_t i = tile_rd_off[np2_bid] + tid; i < tile_rd_off[np2_bid + 1]; i += 256) {
         const uint32_t r = tile_rd[i];
         if (!alive[r]) continue;
         const uint32_t ts = reads[r].aln_t_s, te = reads[r].aln_t_e;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
     const uint32_t off[5] = {l0, l0 + c0, l0 + c0 + c1, l0 + c0 + c1 + c2, l0 + c0 + c1 + c2 + c3};
     for (uint32_t j = 0; j < 4; ++j)
         if (q0 + j < npos) node_off[start + q0 + j] = nbase + off[j];
-    if (blockIdx.x == n_tiles - 1 && tid == 255) node_off[L] = nbase + off[4];
+    if (np2_bid == n_tiles - 1 && tid == 255) node_off[L] = nbase + off[4];
     // ---- order the nodes of each position, emit the packed records ---------------------------------------
     const uint32_t cj[4] = {c0, c1, c2, c3};
     if (fast) {
@@ -590,11 +590,11 @@ __global__ __launch_bounds__(256) void k_tile_write(const uint64_t *__restrict__
         if ((tid & 63) == 0) s_gain[tid >> 6] = gain;
         __syncthreads();
         // one value per tile, summed later (same-address atomics from every tile would serialise at L2)
-        if (tid == 0) tile_gain[blockIdx.x] = s_gain[0] + s_gain[1] + s_gain[2] + s_gain[3];
+        if (tid == 0) tile_gain[np2_bid] = s_gain[0] + s_gain[1] + s_gain[2] + s_gain[3];
     }
     // ---- dirty-run starts ----------------------------------------------------------------------------------
     const bool s0 = c0 && !pd0, s1 = c1 && !c0, s2 = c2 && !c1, s3 = c3 && !c2;
-    uint32_t r = tile_roff[blockIdx.x] +
+    uint32_t r = tile_roff[np2_bid] +
                  block_excl_scan_256((uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3, sh, tot);
     if (s0) run_start[r++] = start + q0;
     if (s1) run_start[r++] = start + q0 + 1;
@@ -610,57 +610,46 @@ void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uin
                         uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out,
                         const Lookback *lb, uint32_t *err) {
     if (lb)
-        hipLaunchKernelGGL(k_tile_layout_lb, dim3(tile_scan_blocks(n_tiles)), dim3(256), 0, s, *lb, tile_scan_blocks(n_tiles),
-                           tile_cur, n_tiles, bucket_cap, tile_n, tile_scan, tile_scanb, ovf_cnt, out, err);
+        NP2_LAUNCH(k_tile_layout_lb, dim3(tile_scan_blocks(n_tiles)), 256, s, *lb, tile_scan_blocks(n_tiles), tile_cur, n_tiles, bucket_cap, tile_n, tile_scan, tile_scanb, ovf_cnt, out, err);
     else
-        hipLaunchKernelGGL(k_tile_layout, dim3(1), dim3(1024), 0, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan,
-                           tile_scanb, ovf_cnt, out);
+        NP2_LAUNCH(k_tile_layout, dim3(1), 1024, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan, tile_scanb, ovf_cnt, out);
 }
 void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
                       uint32_t *err) {
     if (max_tile <= 1024)
-        hipLaunchKernelGGL(k_tile_sort<1024>, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, bucket_cap, keys, vals,
-                           err);
+        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
     else
-        hipLaunchKernelGGL(k_tile_sort<TILE_CAP>, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, bucket_cap, keys,
-                           vals, err);
+        NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
 }
 void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                            const uint32_t *tile_scanb, uint32_t n_tiles, uint32_t bucket_cap, const uint64_t *bkeys,
                            const uint32_t *bvals, uint64_t *keys, uint32_t *vals) {
-    hipLaunchKernelGGL(k_gather_buckets, dim3(n_tiles), dim3(256), 0, s, reads, nib, tile_n, tile_scanb, bucket_cap, bkeys,
-                       bvals, keys, vals);
+    NP2_LAUNCH(k_gather_buckets, dim3(n_tiles), 256, s, reads, nib, tile_n, tile_scanb, bucket_cap, bkeys, bvals, keys, vals);
 }
 void launch_gather_spill(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint64_t *okeys,
                          const uint32_t *ovals, uint32_t n, uint64_t *keys, uint32_t *vals) {
-    if (n) hipLaunchKernelGGL(k_gather_spill, dim3((n + 255) / 256), dim3(256), 0, s, reads, nib, okeys, ovals, n, keys, vals);
+    if (n) NP2_LAUNCH(k_gather_spill, dim3((n + 255) / 256), 256, s, reads, nib, okeys, ovals, n, keys, vals);
 }
 void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, uint32_t n_tiles, const uint8_t *alive,
                        uint32_t *tile_nn, uint32_t *tile_nr) {
-    hipLaunchKernelGGL(k_tile_count, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
-                       alive, tile_nn, tile_nr);
+    NP2_LAUNCH(k_tile_count, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, alive, tile_nn, tile_nr);
 }
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
                          uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
                          uint32_t n_reset, const Lookback *lb, uint32_t *err) {
     if (lb)
-        hipLaunchKernelGGL(k_tile_offsets_lb, dim3(tile_scan_blocks(n_tiles)), dim3(256), 0, s, *lb,
-                           tile_scan_blocks(n_tiles), tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset,
-                           n_reset, err);
+        NP2_LAUNCH(k_tile_offsets_lb, dim3(tile_scan_blocks(n_tiles)), 256, s, *lb, tile_scan_blocks(n_tiles), tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset, err);
     else
-        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff,
-                           n_nodes, n_runs, reset, n_reset);
+        NP2_LAUNCH(k_tile_offsets, dim3(1), 1024, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset);
 }
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
                        int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain) {
-    hipLaunchKernelGGL(k_tile_write, dim3(n_tiles), dim3(256), 0, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap},
-                       tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd,
-                       cov, refnib, emit, tile_gain);
+    NP2_LAUNCH(k_tile_write, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd, cov, refnib, emit, tile_gain);
 }
 
 } // namespace np2

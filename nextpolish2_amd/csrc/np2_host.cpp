@@ -23,6 +23,13 @@
 
 using namespace np2;
 
+namespace np2 {
+Recorder *&tl_recorder() {
+    static thread_local Recorder *r = nullptr;
+    return r;
+}
+} // namespace np2
+
 
 namespace {
 
@@ -147,8 +154,8 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
         uint32_t *v_first = (uint32_t *)cx->votebuf.p;
         int32_t *v_refw = (int32_t *)(cx->votebuf.p + RP * 4);
         uint8_t *v_seen = cx->votebuf.p + RP * 8, *v_bad = cx->votebuf.p + RP * 9;
-        HIPCHK(hipMemsetAsync(v_first, 0xFF, RP * 4, s));
-        HIPCHK(hipMemsetAsync(v_refw, 0, RP * 6, s));
+        op_fill(cx, v_first, 0xFF, RP * 4);
+        op_fill(cx, v_refw, 0, RP * 6);
         launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, v_refw, v_seen, v_bad, v_first,
                           cx->scal.p + S_ERR);
         exclusive_total_n(cx, cx->ecount.p, cx->eoff.p, n_reg);
@@ -167,29 +174,72 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
     std::vector<uint64_t> ukey;
     std::vector<int32_t> uw;
     if (NE) {
-        EventTimer t(cx, "vote_phase");
-        cx->ekey.ensure(NE + 2);
-        cx->ekey_s.ensure(NE + 2);
-        cx->eval.ensure(NE + 2);
-        cx->eval_s.ensure(NE + 2);
-        cx->eflag.ensure(NE + 2);
-        cx->eidx.ensure(NE + 2);
-        cx->ew.ensure(NE + 2);
-        cx->tmp.ensure(prim_temp_bytes((size_t)NE + 2));
-        launch_edges_write(s, rt, cx->reg_lable.p, cx->grp.p, cx->ecount.p, cx->eoff.p, cx->ekey.p, cx->eval.p);
-        if (prim_sort_pairs_u64_u32(s, cx->tmp.p, cx->tmp.cap, cx->ekey.p, cx->ekey_s.p, cx->eval.p, cx->eval_s.p, NE, 64))
-            throw Np2Error(NP2_E_DEVICE, "rocprim edge sort failed");
-        launch_edge_reduce(s, cx->ekey_s.p, cx->eval_s.p, NE, cx->eflag.p, cx->ew.p);
-        exclusive_total(cx, cx->eflag.p, cx->eidx.p, NE);
-        // compact into ekey / eval (reused as int32 weights)
-        launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, cx->ew.p, NE, cx->ekey.p, (int32_t *)cx->eval.p,
-                            cx->scal.p + S_NRAW);
-        NU = fetch_scal(cx)[S_NRAW];
-        ukey = d2h(cx, cx->ekey.p, NU);
-        uw = d2h(cx, (const int32_t *)cx->eval.p, NU);
+        // distinct read pairs + weights.  Normal case: accumulate the raw pair votes in the banded matrix (reads are
+        // numbered in start order, partners are close), rows read in order = the sorted unique list.
+        bool far = false;
+        {
+            EventTimer t(cx, "vote_phase");
+            const size_t band_words = (size_t)R * EDGE_BAND;
+            cx->band.ensure(band_words + 4);
+            cx->band_n.ensure((size_t)R + 2);
+            cx->band_off.ensure((size_t)R + 2);
+            op_fill(cx, cx->band.p, 0, band_words * 4);
+            op_fill(cx, cx->scal.p + S_M3, 0, 4);
+            launch_edges_band(s, rt, cx->grp.p, cx->ecount.p, cx->band.p, cx->scal.p + S_M3);
+            launch_band_count(s, cx->band.p, R, cx->band_n.p);
+            exclusive_total_n(cx, cx->band_n.p, cx->band_off.p, R);
+            // (at most one distinct pair per raw vote: NE bounds the output)
+            cx->ekey.ensure((size_t)NE + 2);
+            cx->eval.ensure((size_t)NE + 2);
+            launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, (int32_t *)cx->eval.p, cx->scal.p + S_NRAW);
+            const std::vector<uint32_t> sc = fetch_scal(cx);
+            NU = sc[S_NRAW];
+            far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
+        }
+        if (far) { // some pair lies outside the band (deep pileup): sort the raw votes instead
+            EventTimer t(cx, "vote_phase");
+            cx->ekey.ensure(NE + 2);
+            cx->ekey_s.ensure(NE + 2);
+            cx->eval.ensure(NE + 2);
+            cx->eval_s.ensure(NE + 2);
+            cx->eflag.ensure(NE + 2);
+            cx->eidx.ensure(NE + 2);
+            cx->ew.ensure(NE + 2);
+            cx->tmp.ensure(prim_temp_bytes((size_t)NE + 2));
+            launch_edges_write(s, rt, cx->reg_lable.p, cx->grp.p, cx->ecount.p, cx->eoff.p, cx->ekey.p, cx->eval.p);
+            unsigned rbits = 1;
+            while ((1ull << rbits) < (uint64_t)R + 1) ++rbits;
+            prim_op(cx, [=](hipStream_t st) {
+                if (prim_sort_pairs_u64_u32(st, cx->tmp.p, cx->tmp.cap, cx->ekey.p, cx->ekey_s.p, cx->eval.p, cx->eval_s.p, NE,
+                                            32 + rbits))
+                    throw Np2Error(NP2_E_DEVICE, "rocprim edge sort failed");
+            });
+            launch_edge_reduce(s, cx->ekey_s.p, cx->eval_s.p, NE, cx->eflag.p, cx->ew.p);
+            exclusive_total(cx, cx->eflag.p, cx->eidx.p, NE);
+            // compact into ekey / eval (reused as int32 weights)
+            launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, cx->ew.p, NE, cx->ekey.p, (int32_t *)cx->eval.p,
+                                cx->scal.p + S_NRAW);
+            NU = fetch_scal(cx)[S_NRAW];
+        }
     }
+    // one wait for everything the host side of the vote needs: unique pairs, their weights, the per-read vote arrays
     const size_t RP = ((size_t)R + 63) & ~(size_t)63;
-    std::vector<uint8_t> vb = d2h(cx, cx->votebuf.p, RP * 10);
+    const size_t b_key = (size_t)NU * 8, b_w = ((size_t)NU * 4 + 7) & ~(size_t)7, b_v = RP * 10;
+    std::vector<uint8_t> vb(b_v);
+    {
+        uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_v + 64);
+        op_d2h(cx, pin, cx->ekey.p, b_key);
+        op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
+        op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
+        op_sync(cx);
+        ukey.resize(NU);
+        uw.resize(NU);
+        if (NU) {
+            memcpy(ukey.data(), pin, b_key);
+            memcpy(uw.data(), pin + b_key, (size_t)NU * 4);
+        }
+        memcpy(vb.data(), pin + b_key + b_w, b_v);
+    }
     const uint32_t *first_reg = (const uint32_t *)vb.data();
     const int32_t *ref_w = (const int32_t *)(vb.data() + RP * 4);
     const uint8_t *ref_seen = vb.data() + RP * 8, *badv = vb.data() + RP * 9;
@@ -367,13 +417,14 @@ void gpu_score_strings(np2_ctx *cx, int yak_idx, const std::vector<uint8_t> &blo
     cx->soff.ensure(off.size());
     cx->sscore.ensure(n);
     {
-        HIPCHK(hipStreamSynchronize(cx->stream));
+        op_sync(cx);
         uint8_t *pin = (uint8_t *)cx->pin_h2d.ensure(blob.size() + off.size() * 8 + 16);
         const size_t o2 = (blob.size() + 7) & ~(size_t)7;
         memcpy(pin, blob.data(), blob.size());
         memcpy(pin + o2, off.data(), off.size() * 8);
-        HIPCHK(hipMemcpyAsync(cx->sstr.p, pin, blob.size(), hipMemcpyHostToDevice, cx->stream));
-        HIPCHK(hipMemcpyAsync(cx->soff.p, pin + o2, off.size() * 8, hipMemcpyHostToDevice, cx->stream));
+        op_h2d(cx, cx->sstr.p, pin, blob.size());
+        op_h2d(cx, cx->soff.p, pin + o2, off.size() * 8);
+        cx->h2d_inflight = true;
     }
     {
         EventTimer t(cx, "score_strings");
@@ -470,9 +521,11 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
                                 cx->keys.p + nb, cx->vals.p + nb);
             unsigned pos_bits = 1;
             while ((1ull << pos_bits) < (uint64_t)L + 1) ++pos_bits;
-            int rc = prim_sort_pairs_u64_u32(s, cx->tmp.p, cx->tmp.cap, cx->keys.p, cx->keys_raw.p, cx->vals.p,
-                                             cx->vals_raw.p, T, 32 + pos_bits);
-            if (rc) throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
+            prim_op(cx, [=](hipStream_t st) {
+                if (prim_sort_pairs_u64_u32(st, cx->tmp.p, cx->tmp.cap, cx->keys.p, cx->keys_raw.p, cx->vals.p, cx->vals_raw.p,
+                                            T, 32 + pos_bits))
+                    throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
+            });
             cx->bucket_cap = 0;
         }
         return;
@@ -603,15 +656,18 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         // long runs on the second stream, short runs on the main one: the kernels touch disjoint runs and the long
         // kernel is a latency chain (a few lanes walking runs of dozens of positions) that would otherwise sit alone
         // on the device for as long as the short kernel takes
-        HIPCHK(hipEventRecord(cx->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(cx->stream2, cx->ev_fork, 0));
+        const bool forked = tl_recorder() == nullptr; // (recorded launches all go to the group's one stream)
+        if (forked) {
+            HIPCHK(hipEventRecord(cx->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(cx->stream2, cx->ev_fork, 0));
+        }
         launch_dp_long(cx->stream2, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
                        cx->nbesti.p, cx->n0_besti.p, cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), cx->run_gain.p,
                        cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, cx->run_flag.p);
-        HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
+        if (forked) HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
         launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p, cx->run_gain.p,
                         cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
-        HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
+        if (forked) HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
         launch_dp_finish(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
                          (const int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
                          cx->scal.p + S_DUP /* block counter: reset with the per-pass scalars */, cx->scal.p + S_BEST,
@@ -737,9 +793,9 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     if (r.want_bases) r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
     if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
     if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
-    if (r.want_bases) HIPCHK(hipMemcpyAsync(r.bases, dbase, M, hipMemcpyDeviceToHost, cx->stream));
-    if (r.want_pos) HIPCHK(hipMemcpyAsync(r.pos, dpos, (size_t)M * 4, hipMemcpyDeviceToHost, cx->stream));
-    if (r.want_bases || r.want_pos) HIPCHK(hipStreamSynchronize(cx->stream));
+    if (r.want_bases) op_d2h(cx, r.bases, dbase, M);
+    if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)M * 4);
+    if (r.want_bases || r.want_pos) op_sync(cx);
     cx->last_first_pos = sc[S_M1];
     cx->last_last_pos = sc[S_M2];
     cx->last_dbase = dbase;
@@ -800,8 +856,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             WallTimer w(cx, "wall_extract");
             extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
         } else if (pc.NC_cap) { // undo mark_hete's kscore edits of the previous (identical) pass
-            HIPCHK(hipMemcpyAsync(cx->kscore.p, cx->kscore_saved.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2,
-                                  hipMemcpyDeviceToDevice, s));
+            op_copy_d2d(cx, cx->kscore.p, cx->kscore_saved.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2);
         }
         reuse = false;
         if (!out_cns) {
@@ -809,8 +864,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
             if (may_reuse && pc.NC_cap) {
                 cx->kscore_saved.ensure((size_t)pc.NC_cap + 2);
-                HIPCHK(hipMemcpyAsync(cx->kscore_saved.p, cx->kscore.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2,
-                                      hipMemcpyDeviceToDevice, s));
+                op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2);
             }
             std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
             trace_put(cx, (int)pass, "invalid_ids", losers);
@@ -819,7 +873,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
                 cx->kill_ids.ensure(losers.size());
                 h2d_staged(cx, cx->kill_ids.p, losers.data(), losers.size() * 4);
                 launch_kill_reads(s, cx->kill_ids.p, (uint32_t)losers.size(), cx->alive.p);
-                HIPCHK(hipStreamSynchronize(s));
+                // (no wait: the ids sit in the pinned staging buffer, guarded by h2d_inflight)
             } else if (may_reuse) {
                 reuse = true;
             }
@@ -973,29 +1027,34 @@ static void destroy_streams(np2_ctx *cx) {
     cx->stream2 = cx->stream = nullptr;
 }
 
+// streams, events, mailbox: everything of a context but its k-mer tables
+static void init_ctx_device(np2_ctx *cx, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Np2Error(NP2_E_DEVICE, "no HIP device available (the np2 hot path has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw Np2Error(NP2_E_ARG, "bad device index");
+    cx->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&cx->stream_out, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
+    cx->scal.ensure(SCAL_TOTAL);
+    HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
+    HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
+    if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
+        cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
+}
+
 int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak) {
     if (!out) return NP2_E_ARG;
     *out = nullptr;
     np2_ctx *cx = new np2_ctx();
     try {
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-            throw Np2Error(NP2_E_DEVICE, "no HIP device available (the np2 hot path has no CPU fallback)");
-        if (device < 0 || device >= ndev) throw Np2Error(NP2_E_ARG, "bad device index");
-        cx->device = device;
-        HIPCHK(hipSetDevice(device));
-        HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&cx->stream_out, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
-        cx->scal.ensure(SCAL_TOTAL);
-        HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
-        HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
-        if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
-            cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
+        init_ctx_device(cx, device);
         // the final pass runs one splice round + one per yak table; their per-round device counters live in fixed slots
         if (n_yak < 0 || n_yak > NP2_MAX_YAK || (n_yak && !yaks))
             throw Np2Error(NP2_E_ARG, "n_yak must be in [0, 15]");
@@ -1013,8 +1072,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
             t.k = y.k;
             t.cap_log2 = cl;
             const size_t slots = (size_t)1024 << cl;
-            t.table.ensure(slots);
-            HIPCHK(hipMemsetAsync(t.table.p, 0xFF, slots * 8, cx->stream));
+            t.table = std::make_shared<DevBuf<uint64_t>>();
+            t.table->ensure(slots);
+            HIPCHK(hipMemsetAsync(t.table->p, 0xFF, slots * 8, cx->stream));
             HIPCHK(hipStreamSynchronize(cx->stream)); // large fill + pageable H2D below: do not rely on their ordering
             DevBuf<uint64_t> dw, doff;
             dw.ensure(y.n_words + 1);
@@ -1022,7 +1082,7 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
             HIPCHK(hipMemcpyAsync(dw.p, y.words, y.n_words * 8, hipMemcpyHostToDevice, cx->stream));
             HIPCHK(hipMemcpyAsync(doff.p, y.bucket_off, 1025 * 8, hipMemcpyHostToDevice, cx->stream));
             zero32(cx, cx->scal.p, S_COUNT);
-            launch_yak_insert(cx->stream, dw.p, doff.p, 1024, mx, t.table.p, cl, cx->scal.p + S_DUP);
+            launch_yak_insert(cx->stream, dw.p, doff.p, 1024, mx, t.table->p, cl, cx->scal.p + S_DUP);
             auto sc = d2h(cx, cx->scal.p, S_COUNT);
             if (sc[S_DUP]) throw Np2Error(NP2_E_UNSUPPORTED, "duplicate k-mer key inside one yak bucket");
         }
@@ -1035,6 +1095,25 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
     } catch (const std::exception &ex) {
         fprintf(stderr, "np2_ctx_create: %s\n", ex.what());
         int code = NP2_E_NOMEM;
+        destroy_streams(cx);
+        delete cx;
+        return code;
+    }
+    *out = cx;
+    return NP2_OK;
+}
+
+int np2_ctx_create_shared(np2_ctx_t **out, np2_ctx_t *parent) {
+    if (!out || !parent) return NP2_E_ARG;
+    *out = nullptr;
+    np2_ctx *cx = new np2_ctx();
+    try {
+        init_ctx_device(cx, parent->device);
+        cx->yaks = parent->yaks; // the HBM tables are reference-counted: freed with the last context using them
+        cx->tile_cap = parent->tile_cap;
+    } catch (const Np2Error &e) {
+        fprintf(stderr, "np2_ctx_create_shared: %s\n", e.what());
+        int code = e.code;
         destroy_streams(cx);
         delete cx;
         return code;

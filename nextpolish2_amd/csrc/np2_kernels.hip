@@ -29,9 +29,9 @@ __device__ __forceinline__ uint8_t ref_code(const uint8_t *__restrict__ refnib, 
 // ------------------------------------------------------------------------------------------
 // K0: contig codes from read 0 (the contig aligned to itself, main.rs:1732-1739)
 // ------------------------------------------------------------------------------------------
-__global__ void k_encode_ref(const uint8_t *__restrict__ read0, uint32_t L, uint8_t *__restrict__ refnib,
+__device__ __forceinline__ void k_encode_ref(const uint32_t np2_bid, const uint32_t np2_nb, const uint8_t *__restrict__ read0, uint32_t L, uint8_t *__restrict__ refnib,
                              uint32_t nbytes_total, uint32_t *__restrict__ err) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= nbytes_total) return;
     uint32_t c0 = 2 * i, c1 = 2 * i + 1;
     uint8_t b = c0 < L ? read0[i] : 0;
@@ -108,19 +108,18 @@ __device__ __forceinline__ N128 n_shl(const N128 &x, uint32_t s) { // 0 < s < 12
 // It emits raw exception records (read, column, t_pos) straight into the fixed-capacity bucket of their contig tile
 // (TILE positions; a full bucket spills to a shared overflow area) and the per-read checkpoints; the 3-column node keys
 // are built afterwards by the tile sort (np2_graph.hip).
-__global__ __launch_bounds__(256) void k_diff_reads(
-    const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
+__device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint32_t np2_nb, const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
     const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
     uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
     uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
     uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t pw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
     // ---- phase A: load both chunks, count their non-insertion columns and publish the counts at once.  A chunk needs
     //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
     //      already running waves, which publish within a microsecond of starting ---------------------------------------
     __shared__ uint32_t s_total[8]; // counts of the block's 8 chunks (4 waves x 2): most of a read's chunks are in here
-    const uint32_t blk_first = blockIdx.x * 8;
+    const uint32_t blk_first = np2_bid * 8;
     N128 w_[2], V_[2], I_[2];
     uint32_t nv_[2], nonins_[2], incl_[2], total_[2];
 #pragma unroll
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(256) void k_diff_reads(
 
 // gather up to four device-resident counters into scalar slots, then post the whole scalar block to host-mapped memory
 // followed by a sequence number the host spins on (no copy command, no stream synchronisation)
-__global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *__restrict__ mbox, uint32_t seq,
+__device__ __forceinline__ void k_post(const uint32_t np2_bid, const uint32_t np2_nb, uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *__restrict__ mbox, uint32_t seq,
                        uint32_t *__restrict__ dst0, const uint32_t *__restrict__ src0, uint32_t *__restrict__ dst1,
                        const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst2, const uint32_t *__restrict__ src2,
                        uint32_t *__restrict__ dst3, const uint32_t *__restrict__ src3,
@@ -406,12 +405,32 @@ __global__ void k_post(uint32_t *__restrict__ scal, uint32_t n_scal, uint32_t *_
     __threadfence_system();
     if (threadIdx.x == 0) __hip_atomic_store(&mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_init_alive(const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+// fills / device-to-device copies as kernels: unlike hipMemsetAsync / hipMemcpyAsync they batch across contigs.
+// 16 bytes per thread where the pointers allow it, byte-wise at unaligned ends.
+__device__ __forceinline__ void k_fill(const uint32_t np2_bid, const uint32_t np2_nb, uint8_t *__restrict__ p, uint64_t n, uint32_t v4) {
+    const uint64_t o = ((uint64_t)np2_bid * 256 + threadIdx.x) * 16;
+    if (o >= n) return;
+    if ((((uintptr_t)p) & 15) == 0 && o + 16 <= n) {
+        *reinterpret_cast<uint4 *>(p + o) = make_uint4(v4, v4, v4, v4);
+    } else {
+        for (uint64_t i = o; i < min(o + 16, n); ++i) p[i] = (uint8_t)v4;
+    }
+}
+__device__ __forceinline__ void k_copy(const uint32_t np2_bid, const uint32_t np2_nb, uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
+    const uint64_t o = ((uint64_t)np2_bid * 256 + threadIdx.x) * 16;
+    if (o >= n) return;
+    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0 && o + 16 <= n) {
+        *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+    } else {
+        for (uint64_t i = o; i < min(o + 16, n); ++i) dst[i] = src[i];
+    }
+}
+__device__ __forceinline__ void k_init_alive(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
+    uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
 }
-__global__ void k_kill_reads(const uint32_t *__restrict__ ids, uint32_t n, uint8_t *__restrict__ alive) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_kill_reads(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ ids, uint32_t n, uint8_t *__restrict__ alive) {
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i < n) alive[ids[i]] = 0;
 }
 
@@ -751,7 +770,7 @@ __device__ __forceinline__ bool pred_ok(uint16_t vb, uint16_t vd, uint32_t want,
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_dp_bt_oct(const uint32_t *__restrict__ run_start,
+__device__ __forceinline__ void k_dp_bt_oct(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ run_start,
                                                   const uint32_t *__restrict__ n_runs, Graph g,
                                                   const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
                                                   uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
@@ -761,7 +780,7 @@ __global__ __launch_bounds__(64) void k_dp_bt_oct(const uint32_t *__restrict__ r
                                                   uint8_t *__restrict__ run_flag) {
     const uint32_t j = threadIdx.x & 7;
     const uint32_t nr = *n_runs, L = g.L;
-    for (uint32_t r = blockIdx.x * 8 + (threadIdx.x >> 3); r < nr; r += gridDim.x * 8) { // (uniform per octet)
+    for (uint32_t r = np2_bid * 8 + (threadIdx.x >> 3); r < nr; r += np2_nb * 8) { // (uniform per octet)
         const uint32_t a = run_start[r];
         uint32_t o0, o1;
         {
@@ -887,7 +906,7 @@ __global__ __launch_bounds__(64) void k_dp_bt_oct(const uint32_t *__restrict__ r
 }
 
 // (grid-stride over a capped grid, see k_dp_bt_short)
-__global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restrict__ run_start,
+__device__ __forceinline__ void k_dp_bt_long(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ run_start,
                                                       const uint32_t *__restrict__ n_runs, Graph g,
                                                       const uint2 *__restrict__ nrec, int64_t *__restrict__ nscore,
                                                       uint32_t *__restrict__ nbesti, uint32_t *__restrict__ n0_besti,
@@ -900,7 +919,7 @@ __global__ __launch_bounds__(DP_BLOCK) void k_dp_bt_long(const uint32_t *__restr
     // is bound by LDS round trips, not by bytes)
     __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
     const uint32_t nr = *n_runs;
-    for (uint32_t r = blockIdx.x * DP_BLOCK + threadIdx.x; r < nr; r += gridDim.x * DP_BLOCK)
+    for (uint32_t r = np2_bid * DP_BLOCK + threadIdx.x; r < nr; r += np2_nb * DP_BLOCK)
         dp_bt_long_run(r, run_start, g, nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
                        path, run_flag, s_node);
 }
@@ -1096,7 +1115,7 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
 // One thread per short run, grid-stride: the launch covers a host-side bound on the number of runs (the record count)
 // that is ~4x the real number, and every workgroup — also one that finds nothing to do — costs a dispatch slot with its
 // LDS allocation, so the grid is capped and the threads loop instead.
-__global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__ run_start,
+__device__ __forceinline__ void k_dp_bt_short(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ run_start,
                                                     const uint32_t *__restrict__ n_runs, Graph g,
                                                     const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
                                                     int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
@@ -1107,7 +1126,7 @@ __global__ __launch_bounds__(64) void k_dp_bt_short(const uint32_t *__restrict__
     __shared__ uint8_t s_bi[RW_N][64];
     __shared__ uint8_t s_n0bi[RW_P][64];
     const uint32_t nr = *n_runs;
-    for (uint32_t r = blockIdx.x * 64 + threadIdx.x; r < nr; r += gridDim.x * 64)
+    for (uint32_t r = np2_bid * 64 + threadIdx.x; r < nr; r += np2_nb * 64)
         dp_bt_short_run(r, run_start, g, refw32, run_end, run_gain, emit, path_begin, path, s_off, s_cov, s_node, s_bi, s_n0bi);
 }
 
@@ -1185,7 +1204,7 @@ __device__ uint32_t bt_walk(const Graph &g, uint32_t a, uint32_t b, uint32_t ent
 //    run): it is entered at that best node, so it could not be walked with the others;
 //  * positions left of the path's first node emit nothing (start nodes are only accepted at t_pos < 3,
 //    main.rs:1666-1668, so at most positions 0..1 are affected); emit[L] = 0 terminates the offset scan.
-__global__ __launch_bounds__(256) void k_dp_finish(const int64_t *__restrict__ run_gain, const uint32_t *__restrict__ n_runs,
+__device__ __forceinline__ void k_dp_finish(const uint32_t np2_bid, const uint32_t np2_nb, const int64_t *__restrict__ run_gain, const uint32_t *__restrict__ n_runs,
                                                    const long long *__restrict__ tile_gain, uint32_t n_tiles,
                                                    unsigned long long *__restrict__ total_gain,
                                                    uint32_t *__restrict__ blocks_done, Graph g,
@@ -1197,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_dp_finish(const int64_t *__restrict__ r
                                                    uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
                                                    uint64_t *__restrict__ path) {
     long long v = 0;
-    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = np2_nb * blockDim.x, t0 = np2_bid * blockDim.x + threadIdx.x;
     const uint32_t nr = *n_runs;
     for (uint32_t r = t0; r < nr; r += stride) v += run_gain[r];
     for (uint32_t t = t0; t < n_tiles; t += stride) v += tile_gain[t];
@@ -1209,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_dp_finish(const int64_t *__restrict__ r
     const long long sum = sm[0] + sm[1] + sm[2] + sm[3];
     if (sum) atomicAdd(total_gain, (unsigned long long)sum);
     __threadfence();
-    if (atomicAdd(blocks_done, 1u) != gridDim.x - 1) return;
+    if (atomicAdd(blocks_done, 1u) != np2_nb - 1) return;
     __threadfence();
     const int64_t total = (int64_t)atomicAdd(total_gain, 0ULL); // (the device-coherent value)
     const uint32_t L = g.L;
@@ -1240,12 +1259,12 @@ __global__ __launch_bounds__(256) void k_dp_finish(const int64_t *__restrict__ r
 // Consensus write-out, one thread per contig position: a clean position emits the contig base; the first position of a
 // dirty run copies the run's recorded path (the walk went right -> left).  Output offsets grow with the position, so
 // neighbouring threads write neighbouring consensus indices.
-__global__ void k_cns_write(const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
+__device__ __forceinline__ void k_cns_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
                             const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
                             const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
                             uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
                             uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
     if (p >= L) return;
     const uint32_t e = emit[p];
     if (e == 0) return;
@@ -1276,11 +1295,11 @@ __global__ void k_cns_write(const uint32_t *__restrict__ node_off, const uint8_t
 enum : uint8_t { LQK_LINK = 0, LQK_CLOSE = 1, LQK_RESET = 2, LQK_OPEN = 3 };
 
 // (the consensus length M lives on the device; launches cover the host-side bound M_cap)
-__global__ void k_lq_scan(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
+__device__ __forceinline__ void k_lq_scan(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
                           const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p,
                           uint8_t *__restrict__ lq_kind, uint32_t *__restrict__ lq_next,
                           uint8_t *__restrict__ lq_nothead) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     const uint32_t M = *M_p;
     if (i >= M || cns_cls[i] != CLS_LQ) return;
     const uint32_t p = M - 1 - i;
@@ -1310,12 +1329,12 @@ __global__ void k_lq_scan(const uint32_t *__restrict__ cns_pos, const uint8_t *_
     if (kind == LQK_LINK) lq_nothead[pp] = 1;
 }
 
-__global__ void k_lq_region(const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
+__device__ __forceinline__ void k_lq_region(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
                             const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p, uint32_t M_cap,
                             const uint8_t *__restrict__ lq_kind, const uint32_t *__restrict__ lq_next,
                             const uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ rflag,
                             uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
     const uint32_t M = *M_p;
     if (p >= M_cap) return;
     rflag[p] = 0; // also behind M: the flag scan runs over the bound
@@ -1337,11 +1356,11 @@ __global__ void k_lq_region(const uint32_t *__restrict__ cns_pos, const uint8_t 
 #undef CB
 }
 
-__global__ void k_scatter_regions(const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ ridx,
+__device__ __forceinline__ void k_scatter_regions(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ ridx,
                                   const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ rend,
                                   const uint32_t *__restrict__ M_p, uint32_t *__restrict__ raw_start,
                                   uint32_t *__restrict__ raw_end, uint32_t *__restrict__ n_raw) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
     const uint32_t M = *M_p;
     if (p >= M) return;
     if (rflag[p]) {
@@ -1352,18 +1371,18 @@ __global__ void k_scatter_regions(const uint32_t *__restrict__ rflag, const uint
 }
 
 // merge rule main.rs:1613-1615: region j merges into j-1 iff end_j >= start_{j-1}
-__global__ void k_lq_merge_flag(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
+__device__ __forceinline__ void k_lq_merge_flag(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
                                 const uint32_t *__restrict__ n_raw, uint32_t *__restrict__ headflag) {
     const uint32_t n = *n_raw; // on the device: grid-stride over whatever it turns out to be
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n; j += np2_nb * blockDim.x)
         headflag[j] = !(j >= 1 && raw_end[j] >= raw_start[j - 1]);
 }
-__global__ void k_lq_merge_write(const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
+__device__ __forceinline__ void k_lq_merge_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
                                  const uint32_t *__restrict__ n_raw, const uint32_t *__restrict__ headflag,
                                  const uint32_t *__restrict__ hidx, uint32_t *__restrict__ lq_start,
                                  uint32_t *__restrict__ lq_end, uint32_t *__restrict__ n_reg) {
     const uint32_t n = *n_raw;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n; j += np2_nb * blockDim.x) {
         if (headflag[j]) {
             uint32_t l = j;
             while (l + 1 < n && !headflag[l + 1]) ++l;
@@ -1398,9 +1417,9 @@ __device__ __forceinline__ uint32_t count_gt_desc(const uint32_t *a, uint32_t n,
 
 // the cursor `s` of main.rs:1446-1448 is a running minimum over live reads of
 // m(r) = max(0, #regions with start >= aln_t_s - 1)
-__global__ void k_read_m(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
+__device__ __forceinline__ void k_read_m(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
                          const uint32_t *__restrict__ lq_start, uint32_t n_reg, int32_t *__restrict__ mval) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r >= R) return;
     if (!alive[r]) {
         mval[r] = 0x7FFFFFFF;
@@ -1410,11 +1429,11 @@ __global__ void k_read_m(const np2_read_t *__restrict__ reads, uint32_t R, const
     mval[r] = c ? (int32_t)(c - 1) : 0;
 }
 
-__global__ void k_pair_count(const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
+__device__ __forceinline__ void k_pair_count(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
                              const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end,
                              uint32_t n_reg, const int32_t *__restrict__ smin, uint32_t *__restrict__ pj,
                              uint32_t *__restrict__ pcount) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r >= R) return;
     uint32_t cnt = 0, j = 0;
     if (alive[r]) {
@@ -1478,9 +1497,9 @@ __device__ __forceinline__ uint16_t yak_get(const YakDev &y, uint64_t x, uint16_
     }
 }
 
-__global__ void k_lookup(YakDev y, const uint64_t *__restrict__ hashes, uint64_t n, uint16_t min_count,
+__device__ __forceinline__ void k_lookup(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint64_t *__restrict__ hashes, uint64_t n, uint16_t min_count,
                          uint16_t *__restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = (uint64_t)np2_bid * blockDim.x + threadIdx.x;
     if (i < n) out[i] = yak_get(y, hashes[i], min_count);
 }
 
@@ -1512,9 +1531,9 @@ __device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uin
     return mn == 0xFFFFFFFFu ? (uint16_t)0 : (uint16_t)mn;
 }
 
-__global__ void k_score_strings(YakDev y, const uint8_t *__restrict__ strs, const uint64_t *__restrict__ off,
+__device__ __forceinline__ void k_score_strings(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint8_t *__restrict__ strs, const uint64_t *__restrict__ off,
                                 uint64_t n, uint16_t min_count, uint16_t *__restrict__ out) {
-    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t w = ((uint64_t)np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (w >= n) return;
     const uint16_t sc = wave_score_string(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count);
     if ((threadIdx.x & 63) == 0) out[w] = sc;
@@ -1522,11 +1541,11 @@ __global__ void k_score_strings(YakDev y, const uint8_t *__restrict__ strs, cons
 
 // retrieve_kmer_count (main.rs:740-778): len > k -> min over the candidate's own k-mers (rare: one wave
 // each, second kernel), else the pre-hashed first k-mer (one lookup, thread per candidate), else 0
-__global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint64_t *__restrict__ cand_kmer,
+__device__ __forceinline__ void k_cand_score(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint32_t *__restrict__ cand_seq_off, const uint64_t *__restrict__ cand_kmer,
                              const uint32_t *__restrict__ n_cand_p, uint16_t min_count,
                              uint16_t *__restrict__ kscore, uint32_t *__restrict__ long_list,
                              uint32_t *__restrict__ n_long) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = np2_bid * blockDim.x + threadIdx.x;
     if (c >= *n_cand_p) return; // the candidate count lives on the device; the launch covers its bound
     const uint32_t len = cand_seq_off[c + 1] - cand_seq_off[c];
     uint16_t sc = 0;
@@ -1538,12 +1557,12 @@ __global__ void k_cand_score(YakDev y, const uint32_t *__restrict__ cand_seq_off
     }
     kscore[c] = sc;
 }
-__global__ void k_cand_score_long(YakDev y, const uint32_t *__restrict__ cand_seq_off,
+__device__ __forceinline__ void k_cand_score_long(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint32_t *__restrict__ cand_seq_off,
                                   const uint8_t *__restrict__ cand_seq, const uint32_t *__restrict__ long_list,
                                   const uint32_t *__restrict__ n_long, uint16_t min_count,
                                   uint16_t *__restrict__ kscore) {
     const uint32_t nl = *n_long;
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nl; w += (gridDim.x * blockDim.x) >> 6) {
+    for (uint32_t w = (np2_bid * blockDim.x + threadIdx.x) >> 6; w < nl; w += (np2_nb * blockDim.x) >> 6) {
         const uint32_t c = long_list[w];
         const uint16_t sc = wave_score_string(y, cand_seq + cand_seq_off[c], cand_seq_off[c + 1] - cand_seq_off[c],
                                               min_count);
@@ -1561,28 +1580,31 @@ static inline dim3 grid1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)
 
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes,
                        uint32_t *err) {
-    hipLaunchKernelGGL(k_encode_ref, grid1(nbytes), dim3(256), 0, s, read0, L, refnib, nbytes, err);
+    NP2_LAUNCH(k_encode_ref, grid1(nbytes), 256, s, read0, L, refnib, nbytes, err);
 }
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
                        const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
                        uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err) {
     if (n_chunks)
-        hipLaunchKernelGGL(k_diff_reads, dim3((n_chunks + 7) / 8), dim3(256), 0, s, descs, n_chunks, nib,
-                           (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap,
-                           ovf_cnt, ckpt, chunk_st, epoch, err);
+        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + 7) / 8), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err);
 }
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
                  const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,
                  const uint32_t *s3, const uint32_t *ends_of, uint32_t *ends_dst) {
-    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, s, scal, n_scal, mbox, seq, d0, s0, d1, s1, d2, s2, d3, s3, ends_of,
-                       ends_dst);
+    NP2_LAUNCH(k_post, dim3(1), 64, s, scal, n_scal, mbox, seq, d0, s0, d1, s1, d2, s2, d3, s3, ends_of, ends_dst);
+}
+void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte) {
+    if (bytes) NP2_LAUNCH(k_fill, grid1((bytes + 15) / 16), 256, s, p, bytes, 0x01010101u * byte);
+}
+void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes) {
+    if (bytes) NP2_LAUNCH(k_copy, grid1((bytes + 15) / 16), 256, s, dst, src, bytes);
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
-    hipLaunchKernelGGL(k_init_alive, grid1(R), dim3(256), 0, s, reads, R, alive);
+    NP2_LAUNCH(k_init_alive, grid1(R), 256, s, reads, R, alive);
 }
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
-    if (n) hipLaunchKernelGGL(k_kill_reads, grid1(n), dim3(256), 0, s, ids, n, alive);
+    if (n) NP2_LAUNCH(k_kill_reads, grid1(n), 256, s, ids, n, alive);
 }
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec}; }
 
@@ -1590,68 +1612,55 @@ void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const
                      const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
                      uint32_t *path_begin, uint64_t *path) {
     if (max_runs)
-        hipLaunchKernelGGL(k_dp_bt_short, dim3(std::min<uint32_t>((max_runs + 63) / 64, DP_GRID_CAP)), dim3(64), 0, s, run_start, n_runs, mk_graph(gp),
-                           (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path);
+        NP2_LAUNCH(k_dp_bt_short, dim3(std::min<uint32_t>((max_runs + 63) / 64, DP_GRID_CAP)), 64, s, run_start, n_runs, mk_graph(gp), (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path);
 }
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
                     uint64_t *path, uint8_t *run_flag) {
     if (!max_runs) return;
-    hipLaunchKernelGGL(k_dp_bt_oct, dim3(std::min<uint32_t>((max_runs + 7) / 8, 4 * DP_GRID_CAP)), dim3(64), 0, s, run_start,
-                       n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
-                       path, run_flag);
+    NP2_LAUNCH(k_dp_bt_oct, dim3(std::min<uint32_t>((max_runs + 7) / 8, 4 * DP_GRID_CAP)), 64, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag);
     // runs with a position of more than 8 exception nodes (deep pileups): the per-thread kernel
-    hipLaunchKernelGGL(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)),
-                       dim3(DP_BLOCK), 0, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end,
-                       last_n0_score, run_gain, emit, path_begin, path, run_flag);
+    NP2_LAUNCH(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)), DP_BLOCK, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag);
 }
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
                       unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
                       const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
-    hipLaunchKernelGGL(k_dp_finish, dim3(64), dim3(256), 0, s, run_gain, n_runs, tile_gain, n_tiles, total_gain,
-                       blocks_done, mk_graph(gp), nscore, last_n0_score, run_start, nbesti, n0_besti, best_idx, emit,
-                       path_begin, path);
+    NP2_LAUNCH(k_dp_finish, dim3(64), 256, s, run_gain, n_runs, tile_gain, n_tiles, total_gain, blocks_done, mk_graph(gp), nscore, last_n0_score, run_start, nbesti, n0_besti, best_idx, emit, path_begin, path);
 }
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                      uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {
-    hipLaunchKernelGGL(k_cns_write, grid1(gp.L), dim3(256), 0, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L,
-                       cns_pos, cns_base, cns_cls, lq_nothead);
+    NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L, cns_pos, cns_base, cns_cls, lq_nothead);
 }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
                     uint32_t *rflag, uint32_t *rstart, uint32_t *rend) {
-    hipLaunchKernelGGL(k_lq_scan, grid1(M_cap), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M_p, lq_kind, lq_next,
-                       lq_nothead);
-    hipLaunchKernelGGL(k_lq_region, grid1(M_cap), dim3(256), 0, s, cns_pos, cns_base, cns_cls, M_p, M_cap, lq_kind, lq_next,
-                       lq_nothead, rflag, rstart, rend);
+    NP2_LAUNCH(k_lq_scan, grid1(M_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, lq_kind, lq_next, lq_nothead);
+    NP2_LAUNCH(k_lq_region, grid1(M_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, M_cap, lq_kind, lq_next, lq_nothead, rflag, rstart, rend);
 }
 void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
                             const uint32_t *rend, const uint32_t *M_p, uint32_t M_cap, uint32_t *raw_start,
                             uint32_t *raw_end, uint32_t *n_raw) {
-    hipLaunchKernelGGL(k_scatter_regions, grid1(M_cap), dim3(256), 0, s, rflag, ridx, rstart, rend, M_p, raw_start, raw_end,
-                       n_raw);
+    NP2_LAUNCH(k_scatter_regions, grid1(M_cap), 256, s, rflag, ridx, rstart, rend, M_p, raw_start, raw_end, n_raw);
 }
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                           uint32_t *headflag) {
-    hipLaunchKernelGGL(k_lq_merge_flag, dim3(256), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag);
+    NP2_LAUNCH(k_lq_merge_flag, dim3(256), 256, s, raw_start, raw_end, n_raw, headflag);
 }
 void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                            const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start, uint32_t *lq_end,
                            uint32_t *n_reg) {
-    hipLaunchKernelGGL(k_lq_merge_write, dim3(256), dim3(256), 0, s, raw_start, raw_end, n_raw, headflag, hidx, lq_start,
-                       lq_end, n_reg);
+    NP2_LAUNCH(k_lq_merge_write, dim3(256), 256, s, raw_start, raw_end, n_raw, headflag, hidx, lq_start, lq_end, n_reg);
 }
 void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                    uint32_t n_reg, int32_t *mval) {
-    hipLaunchKernelGGL(k_read_m, grid1(R), dim3(256), 0, s, reads, R, alive, lq_start, n_reg, mval);
+    NP2_LAUNCH(k_read_m, grid1(R), 256, s, reads, R, alive, lq_start, n_reg, mval);
 }
 void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive,
                        const uint32_t *lq_start, const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin,
                        uint32_t *pj, uint32_t *pcount) {
-    hipLaunchKernelGGL(k_pair_count, grid1(R), dim3(256), 0, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj,
-                       pcount);
+    NP2_LAUNCH(k_pair_count, grid1(R), 256, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj, pcount);
 }
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag) {
@@ -1663,19 +1672,17 @@ void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *buc
 }
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count,
                    uint16_t *out) {
-    if (n) hipLaunchKernelGGL(k_lookup, grid1(n), dim3(256), 0, s, y, hashes, n, min_count, out);
+    if (n) NP2_LAUNCH(k_lookup, grid1(n), 256, s, y, hashes, n, min_count, out);
 }
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
                           uint16_t min_count, uint16_t *out) {
-    if (n) hipLaunchKernelGGL(k_score_strings, grid1(n * 64), dim3(256), 0, s, y, strs, off, n, min_count, out);
+    if (n) NP2_LAUNCH(k_score_strings, grid1(n * 64), 256, s, y, strs, off, n, min_count, out);
 }
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
                        const uint64_t *cand_kmer, const uint32_t *n_cand_p, uint32_t cand_cap, uint16_t min_count,
                        uint16_t *kscore, uint32_t *long_list, uint32_t *n_long) {
     if (!cand_cap) return;
-    hipLaunchKernelGGL(k_cand_score, grid1(cand_cap), dim3(256), 0, s, y, cand_seq_off, cand_kmer, n_cand_p, min_count,
-                       kscore, long_list, n_long);
-    hipLaunchKernelGGL(k_cand_score_long, dim3(1024), dim3(256), 0, s, y, cand_seq_off, cand_seq, long_list, n_long,
-                       min_count, kscore);
+    NP2_LAUNCH(k_cand_score, grid1(cand_cap), 256, s, y, cand_seq_off, cand_kmer, n_cand_p, min_count, kscore, long_list, n_long);
+    NP2_LAUNCH(k_cand_score_long, dim3(1024), 256, s, y, cand_seq_off, cand_seq, long_list, n_long, min_count, kscore);
 }
 } // namespace np2

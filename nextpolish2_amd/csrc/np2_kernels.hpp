@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/np2.h"
 #include "np2_lookback.hpp"
+#include "np2_launch.hpp"
 
 namespace np2 {
 
@@ -69,6 +70,8 @@ void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox,
                  const uint32_t *s0 = nullptr, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
                  const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr,
                  const uint32_t *ends_of = nullptr, uint32_t *ends_dst = nullptr);
+void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte);
+void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 // DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
@@ -117,6 +120,10 @@ void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const
                        const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
 void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
                           uint32_t *err);
+// exclusive sums of any length (reduce-then-scan over 4096-element tiles); part / part_off: scan3_tiles(n) + 1 words each
+uint32_t scan3_tiles(uint32_t n);
+void launch_scan3_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part, uint32_t *part_off,
+                       bool write_end);
 void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,
                             uint32_t *total_out, bool write_end); // write_end: also out[n] = total
 void launch_scan_small_incl(hipStream_t s, const int32_t *in, int32_t *out, uint32_t n, const uint32_t *n_dev);
@@ -188,6 +195,13 @@ void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool u
 void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out);
 void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval);
+// banded pair accumulator (np2_regions.hip): EDGE_BAND partners per read, 256 = one uint4 per lane of a wavefront
+static constexpr uint32_t EDGE_BAND = 256;
+void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, uint32_t *band,
+                       uint32_t *ovf);
+void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n);
+void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, int32_t *uw,
+                      uint32_t *n_out);
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, int32_t *wout);
 void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx, const int32_t *wout,
                          uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out);

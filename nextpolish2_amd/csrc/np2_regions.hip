@@ -124,13 +124,13 @@ __device__ bool hp_differs(const uint8_t *a, uint32_t na, const uint8_t *b, uint
 }
 
 // ---- phasing pass -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vote_phase(RegionTables rt, uint32_t asref, uint32_t use_all,
+__device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, uint32_t asref, uint32_t use_all,
                                                     uint8_t *__restrict__ reg_lable, uint8_t *__restrict__ grp,
                                                     uint32_t *__restrict__ ecount, int32_t *__restrict__ ref_w,
                                                     uint8_t *__restrict__ ref_seen, uint8_t *__restrict__ bad,
                                                     uint32_t *__restrict__ first_reg, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (g >= rt.n_reg) return;
     const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
     uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
@@ -187,13 +187,13 @@ __global__ __launch_bounds__(256) void k_vote_phase(RegionTables rt, uint32_t as
 }
 
 // edges among the valid non-ref candidates of HETE regions: key = order_i << 32 | order_j (i < j), val = +1 / -1
-__global__ __launch_bounds__(256) void k_edges_write(RegionTables rt, const uint8_t *__restrict__ reg_lable,
+__device__ __forceinline__ void k_edges_write(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ reg_lable,
                                                      const uint8_t *__restrict__ grp,
                                                      const uint32_t *__restrict__ ecount,
                                                      const uint32_t *__restrict__ eoff, uint64_t *__restrict__ ekey,
                                                      uint32_t *__restrict__ eval) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (g >= rt.n_reg || ecount[g] == 0) return;
     const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
     uint32_t order = 0xFFFFFFFFu, gi = 0;
@@ -224,10 +224,86 @@ __global__ __launch_bounds__(256) void k_edges_write(RegionTables rt, const uint
     }
 }
 
+// ---- banded pair accumulator --------------------------------------------------------------------------------
+// Reads are numbered in alignment-start order, so the partners b > a of read a (reads sharing a HETE region with it)
+// lie within a short index distance.  band[a * EDGE_BAND + (b - a - 1)] counts the regions in which the pair agrees
+// (low half-word) and disagrees (high half-word): a diploid yeast contig produces ~3 M raw pair votes per Mb but only
+// ~0.1 M distinct pairs, so accumulating in place replaces a 64-bit radix sort of the raw votes; the rows, read in
+// order, ARE the sorted unique pair list.  Pairs further apart than the band bump *ovf: the host then takes the
+// sort-based path below for the whole contig (deep pileups).
+__device__ __forceinline__ void k_edges_band(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ grp,
+                                             const uint32_t *__restrict__ ecount, uint32_t *__restrict__ band,
+                                             uint32_t *__restrict__ ovf) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    if (g >= rt.n_reg || ecount[g] == 0) return;
+    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+    uint32_t order = 0xFFFFFFFFu, gi = 0;
+    bool v = false;
+    if (lane < n) {
+        order = rt.order[c0 + lane];
+        gi = grp[c0 + lane];
+        v = rt.kscore[c0 + lane] > 0;
+    }
+    uint64_t V = __ballot(v);
+    if ((V & 1ull) && __shfl(order, 0) == 0) V &= ~1ull;
+    const bool mine = (V >> lane) & 1ull;
+    uint32_t far = 0;
+    for (uint32_t j = 1; j < n; ++j) { // (shuffles must be wave-uniform)
+        const uint32_t oj = __shfl(order, j), gj = __shfl(gi, j);
+        if (mine && j > lane && ((V >> j) & 1ull)) {
+            const uint32_t d = oj - order - 1;
+            if (d < EDGE_BAND)
+                atomicAdd(&band[(uint64_t)order * EDGE_BAND + d], gj == gi ? 1u : 0x10000u);
+            else
+                ++far;
+        }
+    }
+    if (far) atomicAdd(ovf, far);
+}
+// one wavefront per read: distinct partners in its band row
+__device__ __forceinline__ void k_band_count(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
+                                             uint32_t *__restrict__ row_n) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    if (a >= R) return;
+    const uint4 w = *reinterpret_cast<const uint4 *>(band + (uint64_t)a * EDGE_BAND + lane * 4);
+    uint32_t c = (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) row_n[a] = c;
+}
+// ... and their emission in (a, b) order: ukey = a << 32 | b, uw = sum(w) unless #(-1) >= 3 then -(#-1) (main.rs:996-1002)
+__device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
+                                            const uint32_t *__restrict__ row_off, uint64_t *__restrict__ ukey,
+                                            int32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    if (a >= R) return;
+    if (a == R - 1 && lane == 0) *n_out = row_off[R];
+    if (row_off[a + 1] == row_off[a]) return;
+    const uint4 w = *reinterpret_cast<const uint4 *>(band + (uint64_t)a * EDGE_BAND + lane * 4);
+    const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t c = (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    uint32_t o = row_off[a] + inc - c;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (v[k]) {
+            const int32_t same = (int32_t)(v[k] & 0xFFFFu), neg = (int32_t)(v[k] >> 16);
+            ukey[o] = ((uint64_t)a << 32) | (a + 1 + lane * 4 + k);
+            uw[o] = neg >= 3 ? -neg : same - neg;
+            ++o;
+        }
+}
+
 // reduce sorted edges: data weight = sum(w), unless #(-1) >= 3 then -(#-1) (main.rs:996-1002)
-__global__ void k_edge_reduce(const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ eval, uint32_t n,
+__device__ __forceinline__ void k_edge_reduce(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ eval, uint32_t n,
                               uint32_t *__restrict__ flag, int32_t *__restrict__ wout) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = ekey[i];
     if (i > 0 && ekey[i - 1] == k) {
@@ -243,10 +319,10 @@ __global__ void k_edge_reduce(const uint64_t *__restrict__ ekey, const uint32_t 
     flag[i] = 1;
     wout[i] = neg >= 3 ? -neg : sum;
 }
-__global__ void k_edge_compact(const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ flag,
+__device__ __forceinline__ void k_edge_compact(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ flag,
                                const uint32_t *__restrict__ idx, const int32_t *__restrict__ wout, uint32_t n,
                                uint64_t *__restrict__ ukey, int32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flag[i]) {
         ukey[idx[i]] = ekey[i];
@@ -256,12 +332,12 @@ __global__ void k_edge_compact(const uint64_t *__restrict__ ekey, const uint32_t
 }
 
 // ---- final pass: seeds -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_seed(RegionTables rt, int32_t max_indel_len,
+__device__ __forceinline__ void k_seed(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, int32_t max_indel_len,
                                               uint8_t *__restrict__ reg_lable, uint32_t *__restrict__ seed_cand,
                                               uint32_t *__restrict__ keep_n, uint32_t *__restrict__ keep_list,
                                               uint16_t *__restrict__ keep_ks, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (g >= rt.n_reg) return;
     const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
     if (n == 0) { // lqseq.seqs[max1_p] would be out of bounds
@@ -374,12 +450,12 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t 
 
 // per labelled region: [idx_s, idx_e) to delete; the cursor gets stuck at the leftmost (highest index)
 // labelled region whose start position no longer exists in the consensus
-__global__ void k_splice_find(const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
+__device__ __forceinline__ void k_splice_find(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
                               const uint32_t *__restrict__ lq_start,
                               const uint32_t *__restrict__ lq_end, const uint8_t *__restrict__ reg_lable,
                               uint8_t lable, uint32_t n_reg, uint32_t *__restrict__ idx_s, uint32_t *__restrict__ idx_e,
                               uint32_t *__restrict__ stuck) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g = np2_bid * blockDim.x + threadIdx.x;
     if (g >= n_reg || !(reg_lable[g] & lable)) return;
     const uint32_t M = *M_p;
     const uint32_t s = lower_bound_u32(cns_pos, M, lq_start[g]);
@@ -392,7 +468,7 @@ __global__ void k_splice_find(const uint32_t *__restrict__ cns_pos, const uint32
 // slots with their payload and prefix-sum the length changes -- one pass with a decoupled look-back across blocks.
 // The consensus length is chained on the device (*M_out = *M_in + total shift), so the host does not have to read
 // anything back between splice rounds.
-__global__ __launch_bounds__(256) void k_splice_plan(Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
+__device__ __forceinline__ void k_splice_plan(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
                                                      uint8_t lable, uint32_t n_reg, const uint32_t *__restrict__ stuck,
                                                      const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ idx_e,
                                                      const uint32_t *__restrict__ seed_cand,
@@ -438,7 +514,7 @@ __global__ __launch_bounds__(256) void k_splice_plan(Lookback lb, uint32_t n_blo
 // per block for its first and last index with 16 probes in flight per round, threads only search the (usually empty)
 // slot range in between.
 static constexpr uint32_t SPLICE_SPAN = 2048;
-__global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict__ in_pos,
+__device__ __forceinline__ void k_splice_bases(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in_pos,
                                                       const uint8_t *__restrict__ in_base,
                                                       const uint32_t *__restrict__ M_p,
                                                       const uint32_t *__restrict__ ap_s, const uint32_t *__restrict__ ap_e,
@@ -446,7 +522,7 @@ __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ n_ap_p, uint32_t *__restrict__ out_pos,
                                                       uint8_t *__restrict__ out_base) {
     __shared__ uint32_t s_lo[2];
-    const uint32_t i0 = blockIdx.x * SPLICE_SPAN;
+    const uint32_t i0 = np2_bid * SPLICE_SPAN;
     const uint32_t n_ap = *n_ap_p, M = *M_p;
     if (i0 >= M) return;
     if (threadIdx.x < 2) // number of slots with ap_s <= first / last index of the block
@@ -472,13 +548,13 @@ __global__ __launch_bounds__(256) void k_splice_bases(const uint32_t *__restrict
         out_base[o] = in_base[i];
     }
 }
-__global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t *__restrict__ ap_s,
+__device__ __forceinline__ void k_splice_seeds(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ ap_g, const uint32_t *__restrict__ ap_s,
                                const int32_t *__restrict__ ap_delta, const int32_t *__restrict__ ap_shift_incl,
                                const uint32_t *__restrict__ n_ap_p, const uint32_t *__restrict__ lq_start,
                                const uint32_t *__restrict__ seed_cand, const uint32_t *__restrict__ seq_off,
                                const uint8_t *__restrict__ seq, uint32_t *__restrict__ out_pos,
                                uint8_t *__restrict__ out_base) {
-    uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t sl = np2_bid * blockDim.x + threadIdx.x;
     if (sl >= *n_ap_p) return;
     const uint32_t g = ap_g[sl], c = seed_cand[g];
     const uint32_t so = seq_off[c], len = seq_off[c + 1] - so;
@@ -492,11 +568,11 @@ __global__ void k_splice_seeds(const uint32_t *__restrict__ ap_g, const uint32_t
 
 // ---- recheck (reupdate_consensus_with_lqseqs, main.rs:1060-1420) ------------------------------------
 // RECH regions in left -> right order (reverse region index), compacted with a look-back across blocks
-__global__ __launch_bounds__(256) void k_rech_list(Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
+__device__ __forceinline__ void k_rech_list(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
                                                    uint32_t n_reg, uint32_t *__restrict__ rech, uint32_t *__restrict__ n_rech,
                                                    unsigned long long *__restrict__ blob_bound, uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *blob_bound = 0; // accumulated by k_rech_groups, the next kernel
+    if (np2_bid == 0 && threadIdx.x == 0) *blob_bound = 0; // accumulated by k_rech_groups, the next kernel
     const uint32_t bid = lb_block_id(lb, sh);
     const uint32_t rr = bid * 256 + threadIdx.x;
     const uint32_t flag = (rr < n_reg && (reg_lable[n_reg - 1 - rr] & LB_RECH)) ? 1u : 0u;
@@ -518,7 +594,7 @@ struct RechGroup { // one recheck group = 1..6 chained RECH regions
 // chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions.  One thread per
 // RECH region; a thread whose region heads a group builds it.  Group slots and job offsets (exclusive sums of the
 // group / job counts) come from a look-back across blocks; the last block leaves the totals.
-__global__ __launch_bounds__(256) void k_rech_groups(Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ rech,
+__device__ __forceinline__ void k_rech_groups(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ rech,
                                                      const uint32_t *__restrict__ n_rech_p,
                                                      const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
                                                      const uint32_t *__restrict__ lq_start,
@@ -668,24 +744,24 @@ template <bool WRITE> __device__ uint32_t rech_string(const RechCtx &cx, uint32_
         if (WRITE) out[o] = cx.cns_base[i];
     return o;
 }
-__global__ void k_rech_job_len(RechCtx cx, uint32_t n_jobs, uint32_t *__restrict__ len) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_rech_job_len(const uint32_t np2_bid, const uint32_t np2_nb, RechCtx cx, uint32_t n_jobs, uint32_t *__restrict__ len) {
+    uint32_t j = np2_bid * blockDim.x + threadIdx.x;
     if (j < n_jobs) len[j] = rech_string<false>(cx, j, nullptr);
 }
-__global__ void k_rech_job_build(RechCtx cx, uint32_t n_jobs, const uint64_t *__restrict__ soff,
+__device__ __forceinline__ void k_rech_job_build(const uint32_t np2_bid, const uint32_t np2_nb, RechCtx cx, uint32_t n_jobs, const uint64_t *__restrict__ soff,
                                  uint8_t *__restrict__ blob) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = np2_bid * blockDim.x + threadIdx.x;
     if (j < n_jobs) rech_string<true>(cx, j, blob + soff[j]);
 }
-__global__ void k_u32_to_u64_off(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_u32_to_u64_off(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i];
 }
 
 // apply the scores: single regions take their job's score; chains zero everything, then every product with
 // score > 0 stamps its members, later products overwriting earlier ones (main.rs:1358-1366)
-__global__ void k_rech_apply(RechCtx cx, const uint16_t *__restrict__ score, uint16_t *__restrict__ keep_ks) {
-    uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_rech_apply(const uint32_t np2_bid, const uint32_t np2_nb, RechCtx cx, const uint16_t *__restrict__ score, uint16_t *__restrict__ keep_ks) {
+    uint32_t gi = np2_bid * blockDim.x + threadIdx.x;
     if (gi >= cx.n_groups) return;
     const RechGroup &G = cx.groups[gi];
     const uint32_t j0 = cx.job_off[gi];
@@ -711,12 +787,12 @@ __global__ void k_rech_apply(RechCtx cx, const uint16_t *__restrict__ score, uin
 }
 
 // selection per RECH region (main.rs:1371-1406)
-__global__ void k_rech_select(const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
+__device__ __forceinline__ void k_rech_select(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ rech, const uint32_t *__restrict__ n_rech_p,
                               const uint32_t *__restrict__ cand_off, const uint32_t *__restrict__ keep_n,
                               const uint32_t *__restrict__ keep_list, const uint16_t *__restrict__ keep_ks,
                               const uint32_t *__restrict__ order, uint32_t first_yak, uint8_t *__restrict__ reg_lable,
                               uint32_t *__restrict__ seed_cand) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t e = np2_bid * blockDim.x + threadIdx.x;
     if (e >= *n_rech_p) return;
     const uint32_t g = rech[e], c0 = cand_off[g], n = keep_n[g];
     uint32_t c = 0, valid = 0;
@@ -738,8 +814,8 @@ __global__ void k_rech_select(const uint32_t *__restrict__ rech, const uint32_t 
         seed_cand[g] = keep_list[c0 + i];
     }
 }
-__global__ void k_rech_relabel(uint8_t *__restrict__ reg_lable, uint32_t n_reg) { // main.rs:1411-1417
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_rech_relabel(const uint32_t np2_bid, const uint32_t np2_nb, uint8_t *__restrict__ reg_lable, uint32_t n_reg) { // main.rs:1411-1417
+    uint32_t g = np2_bid * blockDim.x + threadIdx.x;
     if (g >= n_reg) return;
     const uint8_t l = reg_lable[g];
     if (!(l & LB_RECH)) return;
@@ -748,7 +824,7 @@ __global__ void k_rech_relabel(uint8_t *__restrict__ reg_lable, uint32_t n_reg) 
 
 // reads that vote in some HETE region (graph keys) / reads flagged invalid: when both are zero the phasing pass has
 // nothing to decide and the host skips the vote read-back altogether
-__global__ __launch_bounds__(1024) void k_vote_counts(const uint32_t *__restrict__ first_reg, const uint8_t *__restrict__ bad,
+__device__ __forceinline__ void k_vote_counts(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ first_reg, const uint8_t *__restrict__ bad,
                                                       uint32_t R, uint32_t *__restrict__ out) {
     __shared__ uint32_t sk[16], sb[16];
     uint32_t nk = 0, nb = 0;
@@ -785,69 +861,72 @@ void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool u
                        uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
                        uint32_t *err) {
     if (rt.n_reg)
-        hipLaunchKernelGGL(k_vote_phase, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, asref ? 1u : 0u,
-                           use_all ? 1u : 0u, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
+        NP2_LAUNCH(k_vote_phase, g1((uint64_t)rt.n_reg * 64), 256, s, rt, asref ? 1u : 0u, use_all ? 1u : 0u, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
 }
 void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out) {
-    hipLaunchKernelGGL(k_vote_counts, dim3(1), dim3(1024), 0, s, first_reg, bad, R, out);
+    NP2_LAUNCH(k_vote_counts, dim3(1), 1024, s, first_reg, bad, R, out);
 }
 void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval) {
     if (rt.n_reg)
-        hipLaunchKernelGGL(k_edges_write, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, reg_lable, grp, ecount, eoff,
-                           ekey, eval);
+        NP2_LAUNCH(k_edges_write, g1((uint64_t)rt.n_reg * 64), 256, s, rt, reg_lable, grp, ecount, eoff, ekey, eval);
+}
+void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, uint32_t *band,
+                       uint32_t *ovf) {
+    if (rt.n_reg) NP2_LAUNCH(k_edges_band, g1((uint64_t)rt.n_reg * 64), 256, s, rt, grp, ecount, band, ovf);
+}
+void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n) {
+    if (R) NP2_LAUNCH(k_band_count, g1((uint64_t)R * 64), 256, s, band, R, row_n);
+}
+void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, int32_t *uw,
+                      uint32_t *n_out) {
+    if (R) NP2_LAUNCH(k_band_emit, g1((uint64_t)R * 64), 256, s, band, R, row_off, ukey, uw, n_out);
 }
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag,
                         int32_t *wout) {
-    if (n) hipLaunchKernelGGL(k_edge_reduce, g1(n), dim3(256), 0, s, ekey, eval, n, flag, wout);
+    if (n) NP2_LAUNCH(k_edge_reduce, g1(n), 256, s, ekey, eval, n, flag, wout);
 }
 void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx,
                          const int32_t *wout, uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out) {
-    if (n) hipLaunchKernelGGL(k_edge_compact, g1(n), dim3(256), 0, s, ekey, flag, idx, wout, n, ukey, uw, n_out);
+    if (n) NP2_LAUNCH(k_edge_compact, g1(n), 256, s, ekey, flag, idx, wout, n, ukey, uw, n_out);
 }
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
                  uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err) {
     if (rt.n_reg)
-        hipLaunchKernelGGL(k_seed, g1((uint64_t)rt.n_reg * 64), dim3(256), 0, s, rt, max_indel_len, reg_lable, seed_cand,
-                           keep_n, keep_list, keep_ks, err);
+        NP2_LAUNCH(k_seed, g1((uint64_t)rt.n_reg * 64), 256, s, rt, max_indel_len, reg_lable, seed_cand, keep_n, keep_list, keep_ks, err);
 }
 void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
                         const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
                         uint32_t *idx_s, uint32_t *idx_e, uint32_t *stuck) {
-    hipLaunchKernelGGL(k_splice_find, g1(n_reg), dim3(256), 0, s, cns_pos, M_p, lq_start, lq_end, reg_lable, lable, n_reg,
-                       idx_s, idx_e, stuck);
+    NP2_LAUNCH(k_splice_find, g1(n_reg), 256, s, cns_pos, M_p, lq_start, lq_end, reg_lable, lable, n_reg, idx_s, idx_e, stuck);
 }
 void launch_splice_plan(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
                         const uint32_t *stuck, const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
                         const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
                         int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t *err) {
     const uint32_t nb = (n_reg + 255) / 256;
-    hipLaunchKernelGGL(k_splice_plan, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e,
-                       seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, err);
+    NP2_LAUNCH(k_splice_plan, dim3(nb), 256, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e, seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, err);
 }
 void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, const uint32_t *M_p, uint32_t M_cap,
                          const uint32_t *ap_g, const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta,
                          const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base) {
-    hipLaunchKernelGGL(k_splice_bases, dim3((M_cap + SPLICE_SPAN - 1) / SPLICE_SPAN), dim3(256), 0, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap,
-                       out_pos, out_base);
+    NP2_LAUNCH(k_splice_bases, dim3((M_cap + SPLICE_SPAN - 1) / SPLICE_SPAN), 256, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap, out_pos, out_base);
     if (max_ap)
-        hipLaunchKernelGGL(k_splice_seeds, g1(max_ap, 64), dim3(64), 0, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap,
-                           lq_start, seed_cand, seq_off, seq, out_pos, out_base);
+        NP2_LAUNCH(k_splice_seeds, g1(max_ap, 64), 64, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap, lq_start, seed_cand, seq_off, seq, out_pos, out_base);
 }
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
                       uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err) {
     const uint32_t nb = (n_reg + 255) / 256;
-    hipLaunchKernelGGL(k_rech_list, dim3(nb), dim3(256), 0, s, lb, nb, reg_lable, n_reg, rech, n_rech, blob_bound, err);
+    NP2_LAUNCH(k_rech_list, dim3(nb), 256, s, lb, nb, reg_lable, n_reg, rech, n_rech, blob_bound, err);
 }
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
                         const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *groups, uint32_t *job_off,
                         uint32_t *n_groups, uint32_t *n_jobs, unsigned long long *blob_bound, uint32_t *err) {
     const uint32_t nb = (max_rech + 255) / 256;
-    hipLaunchKernelGGL(k_rech_groups, dim3(nb), dim3(256), 0, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end,
-                       keep_n, ksize, reg_maxlen, (RechGroup *)groups, job_off, n_groups, n_jobs, blob_bound, err);
+    NP2_LAUNCH(k_rech_groups, dim3(nb), 256, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end, keep_n, ksize, reg_maxlen, (RechGroup *)groups, job_off, n_groups, n_jobs, blob_bound, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
 static RechCtx mk_rech(const RechPtrs &p) {
@@ -855,27 +934,26 @@ static RechCtx mk_rech(const RechPtrs &p) {
                    p.cns_base, p.n_groups};
 }
 void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len) {
-    if (n_jobs) hipLaunchKernelGGL(k_rech_job_len, g1(n_jobs, 64), dim3(64), 0, s, mk_rech(p), n_jobs, len);
+    if (n_jobs) NP2_LAUNCH(k_rech_job_len, g1(n_jobs, 64), 64, s, mk_rech(p), n_jobs, len);
 }
 void launch_rech_job_build(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, const uint32_t *soff32, uint64_t *soff64,
                            uint8_t *blob) {
     if (!n_jobs) return;
-    hipLaunchKernelGGL(k_u32_to_u64_off, g1(n_jobs + 1), dim3(256), 0, s, soff32, n_jobs + 1, soff64);
-    hipLaunchKernelGGL(k_rech_job_build, g1(n_jobs, 64), dim3(64), 0, s, mk_rech(p), n_jobs, soff64, blob);
+    NP2_LAUNCH(k_u32_to_u64_off, g1(n_jobs + 1), 256, s, soff32, n_jobs + 1, soff64);
+    NP2_LAUNCH(k_rech_job_build, g1(n_jobs, 64), 64, s, mk_rech(p), n_jobs, soff64, blob);
 }
 void launch_rech_apply(hipStream_t s, const RechPtrs &p, const uint16_t *score, uint16_t *keep_ks) {
-    if (p.n_groups) hipLaunchKernelGGL(k_rech_apply, g1(p.n_groups, 64), dim3(64), 0, s, mk_rech(p), score, keep_ks);
+    if (p.n_groups) NP2_LAUNCH(k_rech_apply, g1(p.n_groups, 64), 64, s, mk_rech(p), score, keep_ks);
 }
 void launch_rech_select(hipStream_t s, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cand_off, const uint32_t *keep_n, const uint32_t *keep_list,
                         const uint16_t *keep_ks, const uint32_t *order, bool first_yak, uint8_t *reg_lable,
                         uint32_t *seed_cand) {
     if (max_rech)
-        hipLaunchKernelGGL(k_rech_select, g1(max_rech, 64), dim3(64), 0, s, rech, n_rech_p, cand_off, keep_n, keep_list,
-                           keep_ks, order, first_yak ? 1u : 0u, reg_lable, seed_cand);
+        NP2_LAUNCH(k_rech_select, g1(max_rech, 64), 64, s, rech, n_rech_p, cand_off, keep_n, keep_list, keep_ks, order, first_yak ? 1u : 0u, reg_lable, seed_cand);
 }
 void launch_rech_relabel(hipStream_t s, uint8_t *reg_lable, uint32_t n_reg) {
-    hipLaunchKernelGGL(k_rech_relabel, g1(n_reg), dim3(256), 0, s, reg_lable, n_reg);
+    NP2_LAUNCH(k_rech_relabel, g1(n_reg), 256, s, reg_lable, n_reg);
 }
 
 } // namespace np2

@@ -50,6 +50,8 @@ def lib():
         L.np2s_nibbles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.np2s_yak_build.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_uint64, C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        L.np2s_yak_build_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_double, C.c_uint64,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
         L.np2s_pack_alignment.restype = C.c_uint64
         L.np2s_pack_alignment.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
         _LIB = L
@@ -96,6 +98,17 @@ class Synth:
         words = _copy(w.value, n.value * 8, np.uint64)
         off = _copy(o.value, 1025 * 8, np.uint64)
         return Yak(k, words, off)
+
+    @staticmethod
+    def yak_assembly(synths, k, coverage=60.0, read_len=150, seed=7):
+        """One yak table over every contig of a synthetic assembly (what `yak count` on the short reads gives)."""
+        dip = synths[0].diploid
+        lam = coverage * (read_len - k + 1) / read_len / (2 if dip else 1)
+        hs = (C.c_void_p * len(synths))(*[s._h for s in synths])
+        w, n, o = C.c_void_p(), C.c_uint64(), C.c_void_p()
+        if lib().np2s_yak_build_multi(hs, len(synths), k, lam, seed, C.byref(w), C.byref(n), C.byref(o)) != 0:
+            raise ValueError("k must be in [2, 32)")
+        return Yak(k, _copy(w.value, n.value * 8, np.uint64), _copy(o.value, 1025 * 8, np.uint64))
 
     def close(self):
         if self._h:

@@ -475,13 +475,16 @@ const uint8_t *np2s_nibbles(void *h, uint64_t *nbytes) {
 
 // Build a yak v2 table (pre = 10) from the true haplotypes: count = min(1023, Poisson(lambda * m))
 // where m is the canonical k-mer's multiplicity over the haplotype(s).  Zero counts are dropped.
-int np2s_yak_build(void *h, uint32_t k, double lambda, uint64_t seed, const uint64_t **words,
-                   uint64_t *n_words, const uint64_t **bucket_off) {
-    Synth *S = (Synth *)h;
-    if (k < 2 || k >= 32) return -1;
+int np2s_yak_build_multi(void **hs_in, uint32_t n_h, uint32_t k, double lambda, uint64_t seed, const uint64_t **words,
+                         uint64_t *n_words, const uint64_t **bucket_off) {
+    if (k < 2 || k >= 32 || n_h == 0) return -1;
+    Synth *S = (Synth *)hs_in[0]; // the table is owned by the first generator
     std::vector<uint64_t> hs;
-    collect_kmers(S->hap_seq[0], k, hs);
-    if (S->P.diploid) collect_kmers(S->hap_seq[1], k, hs);
+    for (uint32_t g = 0; g < n_h; ++g) { // one table over every contig of the assembly (what `yak count` produces)
+        Synth *G = (Synth *)hs_in[g];
+        collect_kmers(G->hap_seq[0], k, hs);
+        if (G->P.diploid) collect_kmers(G->hap_seq[1], k, hs);
+    }
     std::sort(hs.begin(), hs.end());
     Rng rng(seed ^ (0xabcdULL * k));
     std::vector<std::vector<uint64_t>> buckets(1024);
@@ -506,6 +509,10 @@ int np2s_yak_build(void *h, uint32_t k, double lambda, uint64_t seed, const uint
     *n_words = S->yak_words.size();
     *bucket_off = S->yak_off.data();
     return 0;
+}
+int np2s_yak_build(void *h, uint32_t k, double lambda, uint64_t seed, const uint64_t **words,
+                   uint64_t *n_words, const uint64_t **bucket_off) {
+    return np2s_yak_build_multi(&h, 1, k, lambda, seed, words, n_words, bucket_off);
 }
 
 // Pack explicit (target, query) gapped strings into the boundary format — the literal

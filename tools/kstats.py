@@ -8,7 +8,14 @@ out = []
 for r in rows:
     n = r["Name"]
     m = re.search(r"np2::(\w+)", n)
-    if m:
+    mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:\d+\w+?)*?(\d+)(k_[a-z_0-9]+)", n)
+    if mb and not m:  # generic batched kernel template (np2_launch.hpp): the body's name is mangled inside
+        ln = int(mb.group(2))
+        nm = mb.group(3)[:ln]
+        mt = re.search(re.escape(nm) + r"IL[jim](\d+)E", n)
+        if mt:
+            nm += f"<{mt.group(1)}>"
+    elif m:
         nm = m.group(1)
     elif "init_lookback" in n:
         nm = "prim:init_lookback"
