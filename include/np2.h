@@ -163,6 +163,8 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
 void np2_batch_set_timing(np2_batch_t *b, int enable);
 int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches);
 /* cumulative counters: kernel launches issued, commands recorded by the pipelines, device flushes */
+/* per flush of the last np2_batch_polish: (host phase before it, command issue, device wait) in ms; returns the count */
+int np2_batch_flush_log(np2_batch_t *b, const double **log);
 int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes);
 
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
     "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_result_fetch_begin", "np2_result_fetch_end", "np2_phase_vote",
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
-    "np2_batch_last_error", "np2_batch_polish", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
+    "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -80,6 +80,7 @@ def lib():
         L.np2_batch_set_timing.argtypes = [vp, C.c_int]
         L.np2_batch_set_timing.restype = None
         L.np2_batch_last_diff_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.np2_batch_flush_log.argtypes = [vp, C.POINTER(vp)]
         L.np2_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         _LIB = L
     return _LIB
@@ -293,6 +294,15 @@ class BatchPolisher:
         ms, n = C.c_float(), C.c_int()
         lib().np2_batch_last_diff_ms(self._h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def flush_log(self):
+        """[(host ms, issue ms, device-wait ms)] per flush of the last polish call."""
+        p = C.c_void_p()
+        n = lib().np2_batch_flush_log(self._h, C.byref(p))
+        if not n:
+            return []
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(3 * n,)).copy()
+        return [tuple(round(float(x), 3) for x in a[3 * i:3 * i + 3]) for i in range(n)]
 
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -67,6 +67,9 @@ struct np2_batch {
     float last_diff_ms = 0;
     int last_diff_launches = 0;
     uint64_t stat_launches = 0, stat_cmds = 0, stat_flushes = 0;
+    // where a wave's wall time goes (ms, cumulative): host phases between flushes, issuing commands, waiting for the GPU
+    double t_last_end = 0, ms_host = 0, ms_issue = 0, ms_wait = 0;
+    std::vector<double> flush_log; // per flush of the last polish call: host, issue, wait (ms)
 };
 
 namespace {
@@ -83,6 +86,8 @@ __device__ __forceinline__ void k_flush_done(const uint32_t np2_bid, const uint3
 // wait for the device.  Called with sync_mu held by the last thread that arrived.
 void flush(np2_batch *b) {
     const int n = (int)b->recs.size();
+    const double t_begin = now_ms();
+    double t_issued = t_begin;
     std::vector<size_t> idx(n, 0);
     hipStream_t s = b->stream;
     Recorder *saved = tl_recorder();
@@ -150,6 +155,7 @@ void flush(np2_batch *b) {
         // costs a few tens of microseconds more per flush)
         const uint32_t seq = ++b->done_seq;
         NP2_LAUNCH(k_flush_done, 1, 64, s, b->done_dev, seq);
+        t_issued = now_ms();
         uint64_t spins = 0;
         while (__atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) != seq) {
             if ((++spins & 0xFFFF) == 0) {
@@ -168,6 +174,14 @@ void flush(np2_batch *b) {
     tl_recorder() = saved;
     for (auto &r : b->recs) r.clear();
     ++b->stat_flushes;
+    const double t_end = now_ms();
+    b->ms_host += t_begin - b->t_last_end;
+    b->ms_issue += t_issued - t_begin;
+    b->ms_wait += t_end - t_issued;
+    b->flush_log.push_back(t_begin - b->t_last_end);
+    b->flush_log.push_back(t_issued - t_begin);
+    b->flush_log.push_back(t_end - t_issued);
+    b->t_last_end = t_end;
 }
 
 // Recorder::sync_fn: wait until every running pipeline of the wave has reached a synchronisation point; the last one
@@ -311,6 +325,8 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
         }
         b->diff_events.clear();
     }
+    b->flush_log.clear();
+    b->t_last_end = now_ms();
     for (int w0 = 0; w0 < n; w0 += S) { // waves of at most S contigs; contig w0 + i runs on slot i
         const int m = std::min(S, n - w0);
         {
@@ -369,6 +385,12 @@ int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches) {
     *ms = b->last_diff_ms;
     *launches = b->last_diff_launches;
     return NP2_OK;
+}
+// per flush of the last np2_batch_polish: (host phase before it, command issue, device wait) in ms; returns the count
+int np2_batch_flush_log(np2_batch_t *b, const double **log) {
+    if (!b || !log) return 0;
+    *log = b->flush_log.data();
+    return (int)(b->flush_log.size() / 3);
 }
 int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes) {
     if (!b || !launches || !commands || !flushes) return NP2_E_ARG;

@@ -90,7 +90,12 @@ struct PinnedPool {
         if (it == live.end()) return false;
         free_.emplace_back(it->second, p);
         live.erase(it);
-        while (free_.size() > 8) { // keep the pool small
+        // keep what a batch of contigs hands back between two steps (a pinned allocation costs ~1 ms), but bound the
+        // idle memory: beyond 64 blocks or 1 GiB the oldest go
+        size_t held = 0;
+        for (auto &f : free_) held += f.first;
+        while (free_.size() > 64 || (held > (1ull << 30) && free_.size() > 8)) {
+            held -= free_.front().first;
             (void)hipHostFree(free_.front().second);
             free_.erase(free_.begin());
         }

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -214,9 +215,12 @@ struct KmerInfo {
     uint32_t ksize = 0, pre = 0;
     uint64_t kmask = 0, pmask = 0;
     // per bucket: (key = w>>10, index in file order) sorted by key then index; counts[]
-    std::vector<std::vector<std::pair<uint64_t, uint16_t>>> sets; // (w>>10, count) file order kept
+    typedef std::vector<std::vector<std::pair<uint64_t, uint16_t>>> Buckets;
+    std::shared_ptr<Buckets> sets_p = std::make_shared<Buckets>(); // (w>>10, count) file order kept
     uint16_t built_min = 0xFFFF;
-    std::vector<std::vector<std::pair<uint64_t, uint16_t>>> sorted; // filtered by built_min, last wins
+    // filtered by built_min, last wins.  Shared (read-only) by the clones of a context (np2o_ctx_clone): the CPU
+    // baseline runs one oracle per host thread on ONE copy of the tables, like the reference's workers read one file
+    std::shared_ptr<Buckets> sorted_p = std::make_shared<Buckets>();
 
     void load(const np2_yak_t &y) {
         ksize = y.k;
@@ -224,6 +228,7 @@ struct KmerInfo {
         kmask = (1ULL << (2 * (uint64_t)ksize)) - 1;
         pmask = (1ULL << pre) - 1;
         size_t nb = (size_t)1 << pre;
+        Buckets &sets = *sets_p;
         sets.assign(nb, {});
         for (size_t b = 0; b < nb; ++b) {
             sets[b].reserve(y.bucket_off[b + 1] - y.bucket_off[b]);
@@ -236,6 +241,9 @@ struct KmerInfo {
     }
     void prepare(uint16_t min_count) { // models retrieve_kmers(min_count) (kmer.rs:132-170)
         if (built_min == min_count) return;
+        const Buckets &sets = *sets_p;
+        sorted_p = std::make_shared<Buckets>(); // (a clone keeps the previous filter of its parent untouched)
+        Buckets &sorted = *sorted_p;
         sorted.assign(sets.size(), {});
         for (size_t b = 0; b < sets.size(); ++b) {
             auto &s = sorted[b];
@@ -255,7 +263,7 @@ struct KmerInfo {
         built_min = min_count;
     }
     uint16_t get_or0(uint64_t hash) const { // kmer.rs:123-125 + unwrap_or(0)
-        const auto &s = sorted[hash & pmask];
+        const auto &s = (*sorted_p)[hash & pmask];
         uint64_t key = hash >> 10;
         auto it = std::lower_bound(
             s.begin(), s.end(), key,
@@ -1387,6 +1395,14 @@ void *np2o_ctx_create(const np2_yak_t *yaks, int n_yak) {
         cx->opt.yak.emplace_back();
         cx->opt.yak.back().load(yaks[i]);
     }
+    return cx;
+}
+// a further context over the same (read-only) k-mer tables, filtered for `min_kmer_count` once in the parent
+void *np2o_ctx_clone(void *parent, uint16_t min_kmer_count) {
+    Ctx *p = (Ctx *)parent;
+    for (auto &ki : p->opt.yak) ki.prepare(min_kmer_count);
+    Ctx *cx = new Ctx();
+    cx->opt.yak = p->opt.yak; // shared_ptr copies
     return cx;
 }
 void np2o_ctx_destroy(void *c) { delete (Ctx *)c; }

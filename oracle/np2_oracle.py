@@ -29,6 +29,8 @@ def lib():
         L.np2o_ctx_create.restype = C.c_void_p
         L.np2o_ctx_create.argtypes = [C.POINTER(np2_yak_t), C.c_int]
         L.np2o_ctx_destroy.argtypes = [C.c_void_p]
+        L.np2o_ctx_clone.restype = C.c_void_p
+        L.np2o_ctx_clone.argtypes = [C.c_void_p, C.c_uint16]
         L.np2o_last_error.restype = C.c_char_p
         L.np2o_last_error.argtypes = [C.c_void_p]
         L.np2o_set_trace.argtypes = [C.c_void_p, C.c_int]
@@ -78,6 +80,14 @@ class Oracle:
         self._h = lib().np2o_ctx_create(arr, len(self._yaks))
         if not self._h:
             raise ValueError("oracle: unsupported yak table (k must be < 32)")
+
+    def clone(self, min_kmer_count=5):
+        """A further oracle over the SAME in-memory k-mer tables (one per host thread of the CPU baseline)."""
+        o = Oracle.__new__(Oracle)
+        o._yaks = self._yaks
+        o._parent = self
+        o._h = lib().np2o_ctx_clone(self._h, min_kmer_count)
+        return o
 
     def close(self):
         if self._h:

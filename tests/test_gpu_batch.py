@@ -1,0 +1,120 @@
+"""Batch driver (np2_batch_*, csrc/np2_batch.cpp): several contigs polished with one launch per pipeline step.
+
+Every contig keeps its own pipeline; only the launches are merged — so the results must be exactly those of
+np2_polish_resident contig by contig, and those of the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from nextpolish2_amd import BatchPolisher, Opts, Polisher
+from nextpolish2_amd.synth import Synth
+from oracle import np2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _assembly():
+    # deliberately uneven: diploid contigs of different sizes, one with very short reads (other kernels / branches),
+    # one tiny one, so that the recorded command streams of the slots diverge
+    specs = [dict(L=90000, seed=301), dict(L=30000, seed=302, read_len_mean=4000.0, read_len_sd=700.0),
+             dict(L=150000, seed=303), dict(L=20000, seed=304, depth=12), dict(L=60000, seed=305, read_err_rate=0.01)]
+    syn = [Synth(sp.pop("L"), diploid=True, **sp) for sp in specs]
+    return syn, [Synth.yak_assembly(syn, 21), Synth.yak_assembly(syn, 31)]
+
+
+@pytest.mark.parametrize("n_slots", [5, 2])
+def test_batch_equals_per_contig_and_oracle(n_slots):
+    syn, yaks = _assembly()
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in syn]
+    single = [pol.polish_resident(c, Opts()) for c in contigs]
+    bp = BatchPolisher(pol, n_slots)  # 2 slots: three waves
+    for _ in range(2):  # (second call: warm buffers, recycled pinned blocks)
+        out = bp.polish(contigs, Opts(), want_pos=True)
+        for (b, p), (sb, sp) in zip(out, single):
+            assert np.array_equal(b, sb) and np.array_equal(p, sp)
+    spans = bp.polish(contigs, Opts())
+    assert [s[1] for s in spans] == [(int(p[0]), int(p[-1])) for _, p in single]
+    o = orc.Oracle(yaks)
+    for s, (b, p) in zip(syn, out):
+        ob, op = o.polish(s.pileup, Opts())
+        assert np.array_equal(ob, b) and np.array_equal(op, p)
+    st = bp.stats()
+    assert st["launches"] < st["commands"]  # launches really were merged
+    bp.close()
+
+
+def test_batch_with_haploid_and_regionless_contigs():
+    # a contig without any LQ region leaves the wave early; the others must not wait for it
+    a = Synth(40000, seed=311, asm_err_rate=0.0, read_err_rate=0.0)
+    b = Synth(80000, seed=312, diploid=True)
+    c = Synth(50000, seed=313)
+    yaks = [Synth.yak_assembly([b, a, c], 21)]
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in (a, b, c)]
+    bp = BatchPolisher(pol, 3)
+    out = bp.polish(contigs, Opts(), want_pos=True)
+    o = orc.Oracle(yaks)
+    for s, (gb, gp) in zip((a, b, c), out):
+        ob, op = o.polish(s.pileup, Opts())
+        assert np.array_equal(ob, gb) and np.array_equal(op, gp)
+    assert out[0][0].tobytes() == a.hap1
+
+
+def test_batch_reports_a_failing_contig_and_keeps_going():
+    from nextpolish2_amd._types import Pileup
+    from nextpolish2_amd.api import Np2Error
+    good = Synth(40000, seed=321, diploid=True)
+    yaks = [good.yak(21)]
+    pol = Polisher(yaks)
+    cg = pol.upload(good.pileup)
+    bp = BatchPolisher(pol, 2)
+    with pytest.raises(Np2Error):
+        bp.polish([cg, cg], Opts(iter_count=0))  # every pipeline rejects iter_count 0
+    out = bp.polish([cg, cg], Opts())  # the batch is still usable
+    assert out[0][0].tobytes() == good.hap1 and np.array_equal(out[0][0], out[1][0])
+
+
+def test_two_batches_on_two_host_threads():
+    syn, yaks = _assembly()
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in syn]
+    ref = [pol.polish_resident(c, Opts(), want_pos=False)[0] for c in contigs]
+    halves = [[0, 2, 4], [1, 3]]
+    bps = [BatchPolisher(pol, len(h)) for h in halves]
+    outs = [None, None]
+
+    def run(k):
+        for _ in range(3):
+            outs[k] = bps[k].polish([contigs[i] for i in halves[k]], Opts())
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for k in range(2):
+        for j, i in enumerate(halves[k]):
+            assert np.array_equal(outs[k][j][0], ref[i])
+
+
+def test_pair_votes_outside_the_band_take_the_sort_path(monkeypatch):
+    # depth 400 with short reads: more than EDGE_BAND reads start inside one read's span, so some read pair lies outside
+    # the banded accumulator and the whole contig falls back to sorting the raw pair votes
+    s = Synth(12000, depth=400, seed=331, diploid=True, read_len_mean=3000.0, read_len_sd=300.0)
+    yaks = [s.yak(21)]
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    ob, op = o.polish(s.pileup, Opts())
+    g = Polisher(yaks)
+    g.set_trace(True)
+    gb, gp = g.polish(s.pileup, Opts())
+    assert np.array_equal(o.trace(0, "invalid_ids"), g.trace(0, "invalid_ids"))
+    assert np.array_equal(ob, gb) and np.array_equal(op, gp)
+    # and the sort path forced on an ordinary contig gives what the band gives
+    d = Synth(60000, seed=332, diploid=True)
+    yd = [d.yak(21)]
+    b1, p1 = Polisher(yd).polish(d.pileup, Opts())
+    monkeypatch.setenv("NP2_EDGE_SORT", "1")
+    b2, p2 = Polisher(yd).polish(d.pileup, Opts())
+    assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+    ob2, op2 = orc.Oracle(yd).polish(d.pileup, Opts())
+    assert np.array_equal(ob2, b1) and np.array_equal(op2, p1)

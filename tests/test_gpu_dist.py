@@ -42,13 +42,15 @@ def test_bench_under_torchrun_with_one_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "1", "--steps", "4", "--warmup", "1", "--length", "300000", "--cpu-sample", "100000"],
+                        "--gpus", "1", "--steps", "4", "--warmup", "1", "--scale", "0.05", "--cpu-threads", "8"],
                        capture_output=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["fasta_identical_to_oracle"] is True
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+    assert out["config"]["contigs"] == 17 and out["oracle_checked_contigs"] == 17
+    assert out["end_to_end"]["value"] > 0 and out["end_to_end"]["identical_to_resident_path"] is True
 
 
 def test_deferred_output_fetch_overlaps_the_next_contig():

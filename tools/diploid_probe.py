@@ -55,7 +55,26 @@ for nslots in [int(x) for x in os.environ.get('NSLOTS', '17').split(',')]:
         out = bp.polish(contigs, Opts())
         dt = time.time() - t
         print(f"batch slots {nslots} rep {rep}: {dt*1e3:.1f} ms -> {total/dt/1e6:.0f} Mbp/s stats {bp.stats()}", flush=True)
+    print("flush log (host, issue, wait ms):", bp.flush_log(), flush=True)
     ok = sum(bytes(out[i][0]) == res[i] for i in range(len(syn))) if res[0] is not None else -1
     okh = sum(bytes(out[i][0]) == syn[i].hap1 for i in range(len(syn)))
     print("batch == per-contig:", ok, "== hap1:", okh, "of", len(syn), flush=True)
     bp.close()
+
+# ---- two half batches, phase-shifted: one group's host phases (Louvain) overlap the other group's kernels ----
+order = sorted(range(len(syn)), key=lambda i: -lens[i])
+halves = [order[0::2], order[1::2]]
+bps = [BatchPolisher(pol, len(h)) for h in halves]
+outs = [None, None]
+def half(k):
+    outs[k] = bps[k].polish([contigs[i] for i in halves[k]], Opts())
+for rep in range(4):
+    t = time.time()
+    ths = [threading.Thread(target=half, args=(k,)) for k in range(2)]
+    [x.start() for x in ths]; [x.join() for x in ths]
+    dt = time.time() - t
+    print(f"2 half batches rep {rep}: {dt*1e3:.1f} ms -> {total/dt/1e6:.0f} Mbp/s", flush=True)
+okh = sum(bytes(outs[k][j][0]) == syn[i].hap1 for k in range(2) for j, i in enumerate(halves[k]))
+print("half batches == hap1:", okh, "of", len(syn))
+for k in range(2):
+    print("flush log", k, bps[k].flush_log())

@@ -8,8 +8,8 @@ out = []
 for r in rows:
     n = r["Name"]
     m = re.search(r"np2::(\w+)", n)
-    mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:\d+\w+?)*?(\d+)(k_[a-z_0-9]+)", n)
-    if mb and not m:  # generic batched kernel template (np2_launch.hpp): the body's name is mangled inside
+    mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
+    if mb:  # generic batched kernel template (np2_launch.hpp): the body's name is mangled inside
         ln = int(mb.group(2))
         nm = mb.group(3)[:ln]
         mt = re.search(re.escape(nm) + r"IL[jim](\d+)E", n)
