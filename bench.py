@@ -97,15 +97,25 @@ def cpu_baseline(syn, yaks, opts, max_threads, budget_s=25.0):
     results = {}
 
     def run(n):
-        jobs = [i % len(syn) for i in range(n)]
-        workers = [base.clone(opts.min_kmer_count) for _ in range(n)]
+        # n worker threads pull contigs from one queue (the reference's bounded channel, main.rs:1700-1715); the queue
+        # holds every contig of the assembly, replicated until each thread has at least one
+        jobs = [i % len(syn) for i in range(max(n, len(syn)))]
+        nxt = [0]
+        lock = threading.Lock()
         done = [0] * n
 
         def work(w):
-            r = workers[w].polish(syn[jobs[w]].pileup, opts)
-            done[w] = syn[jobs[w]].pileup.L
-            if w < len(syn):
-                results[jobs[w]] = r
+            orc = base.clone(opts.min_kmer_count)
+            while True:
+                with lock:
+                    j = nxt[0]
+                    nxt[0] += 1
+                if j >= len(jobs):
+                    return
+                r = orc.polish(syn[jobs[j]].pileup, opts)
+                done[w] += syn[jobs[j]].pileup.L
+                if j < len(syn):
+                    results[jobs[j]] = r
         ths = [threading.Thread(target=work, args=(w,)) for w in range(n)]
         t1 = time.perf_counter()
         for t in ths:

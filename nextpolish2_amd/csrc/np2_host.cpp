@@ -135,13 +135,30 @@ void check_region_err(np2_ctx *cx, uint32_t e) {
     if (e & LB_ERR) throw Np2Error(NP2_E_DEVICE, "device-wide scan timed out waiting for a predecessor block");
 }
 
-// phasing pass on the GPU tables: mark_hete (main.rs:916-946), pair edges (948-1002); Louvain on the host
-std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool use_all,
-                                       int pass) {
+// What one phasing pass hands to the host side of the vote (phase_reads_by_lqseqs, main.rs:948-1015).  Everything in
+// it is additive over the HETE regions it was collected from, so the shards of one contig (np2_shard_*) each collect
+// theirs over the regions they own and the contig's owner merges them before the Louvain.
+struct VoteData {
+    uint32_t R = 0;                   // reads of the (sub-)contig, local numbering
+    bool any = false;                 // false: no read votes anywhere, nobody can lose
+    std::vector<uint64_t> pair_key;   // a << 32 | b (a < b), ascending
+    std::vector<uint32_t> pair_cnt;   // HETE regions in which the pair agrees | disagrees << 16
+    std::vector<uint32_t> first_key;  // per read: creation rank of its key in the reference's weight map = index of the
+                                      // first HETE region it votes in (0xFFFFFFFF: none); shards: see shard_vote_export
+    std::vector<int32_t> ref_w;       // per read: summed weight against the contig's own candidate (ref_data[0])
+    std::vector<uint8_t> ref_seen, bad;
+};
+
+// GPU part of the phasing pass: mark_hete (main.rs:916-946), pair votes (948-1002) over the regions whose start lies in
+// [own_lo, own_hi)
+void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool use_all, int pass, uint32_t own_lo,
+                  uint32_t own_hi, VoteData &vd) {
     hipStream_t s = cx->stream;
     const uint32_t R = c->R, n_reg = pc.n_reg;
     RegionTables rt = region_tables(cx, n_reg);
     uint32_t NE = 0, NU = 0;
+    vd = VoteData();
+    vd.R = R;
     {
         EventTimer t(cx, "vote_phase");
         cx->reg_lable.ensure(n_reg + 2);
@@ -156,8 +173,8 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
         uint8_t *v_seen = cx->votebuf.p + RP * 8, *v_bad = cx->votebuf.p + RP * 9;
         op_fill(cx, v_first, 0xFF, RP * 4);
         op_fill(cx, v_refw, 0, RP * 6);
-        launch_vote_phase(s, rt, asref, use_all, cx->reg_lable.p, cx->grp.p, cx->ecount.p, v_refw, v_seen, v_bad, v_first,
-                          cx->scal.p + S_ERR);
+        launch_vote_phase(s, rt, asref, use_all, cx->lq_start.p, own_lo, own_hi, cx->reg_lable.p, cx->grp.p, cx->ecount.p,
+                          v_refw, v_seen, v_bad, v_first, cx->scal.p + S_ERR);
         exclusive_total_n(cx, cx->ecount.p, cx->eoff.p, n_reg);
         launch_vote_counts(s, v_first, v_bad, R, cx->scal.p + S_M1); // S_M1 = graph keys, S_M2 = invalid reads
     }
@@ -168,14 +185,13 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
         NE = sc[S_M0];
         if (!cx->trace && sc[S_M1] == 0 && sc[S_M2] == 0) { // no read votes anywhere: nobody can lose
             if (NE) throw Np2Error(NP2_E_DEVICE, "internal: pair edges without voting reads");
-            return {};
+            return;
         }
     }
-    std::vector<uint64_t> ukey;
-    std::vector<int32_t> uw;
+    vd.any = true;
     if (NE) {
-        // distinct read pairs + weights.  Normal case: accumulate the raw pair votes in the banded matrix (reads are
-        // numbered in start order, partners are close), rows read in order = the sorted unique list.
+        // distinct read pairs + their vote counts.  Normal case: accumulate the raw pair votes in the banded matrix
+        // (reads are numbered in start order, partners are close); rows read in order = the sorted unique list.
         bool far = false;
         {
             EventTimer t(cx, "vote_phase");
@@ -191,7 +207,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
             // (at most one distinct pair per raw vote: NE bounds the output)
             cx->ekey.ensure((size_t)NE + 2);
             cx->eval.ensure((size_t)NE + 2);
-            launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, (int32_t *)cx->eval.p, cx->scal.p + S_NRAW);
+            launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
             const std::vector<uint32_t> sc = fetch_scal(cx);
             NU = sc[S_NRAW];
             far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
@@ -214,45 +230,51 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
                                             32 + rbits))
                     throw Np2Error(NP2_E_DEVICE, "rocprim edge sort failed");
             });
-            launch_edge_reduce(s, cx->ekey_s.p, cx->eval_s.p, NE, cx->eflag.p, cx->ew.p);
+            launch_edge_reduce(s, cx->ekey_s.p, cx->eval_s.p, NE, cx->eflag.p, (uint32_t *)cx->ew.p);
             exclusive_total(cx, cx->eflag.p, cx->eidx.p, NE);
-            // compact into ekey / eval (reused as int32 weights)
-            launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, cx->ew.p, NE, cx->ekey.p, (int32_t *)cx->eval.p,
-                                cx->scal.p + S_NRAW);
+            // compact into ekey / eval (packed agree | disagree << 16 counts)
+            launch_edge_compact(s, cx->ekey_s.p, cx->eflag.p, cx->eidx.p, (const uint32_t *)cx->ew.p, NE, cx->ekey.p,
+                                cx->eval.p, cx->scal.p + S_NRAW);
             NU = fetch_scal(cx)[S_NRAW];
         }
     }
-    // one wait for everything the host side of the vote needs: unique pairs, their weights, the per-read vote arrays
+    // one wait for everything the host side of the vote needs: unique pairs, their counts, the per-read vote arrays
     const size_t RP = ((size_t)R + 63) & ~(size_t)63;
     const size_t b_key = (size_t)NU * 8, b_w = ((size_t)NU * 4 + 7) & ~(size_t)7, b_v = RP * 10;
-    std::vector<uint8_t> vb(b_v);
     {
         uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_v + 64);
         op_d2h(cx, pin, cx->ekey.p, b_key);
         op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
         op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
         op_sync(cx);
-        ukey.resize(NU);
-        uw.resize(NU);
+        vd.pair_key.resize(NU);
+        vd.pair_cnt.resize(NU);
         if (NU) {
-            memcpy(ukey.data(), pin, b_key);
-            memcpy(uw.data(), pin + b_key, (size_t)NU * 4);
+            memcpy(vd.pair_key.data(), pin, b_key);
+            memcpy(vd.pair_cnt.data(), pin + b_key, (size_t)NU * 4);
         }
-        memcpy(vb.data(), pin + b_key + b_w, b_v);
+        const uint8_t *vb = pin + b_key + b_w;
+        vd.first_key.assign((const uint32_t *)vb, (const uint32_t *)vb + R);
+        vd.ref_w.assign((const int32_t *)(vb + RP * 4), (const int32_t *)(vb + RP * 4) + R);
+        vd.ref_seen.assign(vb + RP * 8, vb + RP * 8 + R);
+        vd.bad.assign(vb + RP * 9, vb + RP * 9 + R);
     }
-    const uint32_t *first_reg = (const uint32_t *)vb.data();
-    const int32_t *ref_w = (const int32_t *)(vb.data() + RP * 4);
-    const uint8_t *ref_seen = vb.data() + RP * 8, *badv = vb.data() + RP * 9;
     if (cx->trace) {
         trace_put(cx, pass, "hete.lable", d2h(cx, cx->reg_lable.p, n_reg));
         trace_put(cx, pass, "hete.kscore", d2h(cx, cx->kscore.p, pc.NC));
     }
-    // ---- host: rebuild the weight maps in the reference's key-creation order, then Louvain --------
-    // outer keys of `data` are created region by region (index order), valid non-ref candidates in
-    // position (= read index) order, first occurrence wins
+}
+
+// Host part of the vote: rebuild the weight maps in the reference's key-creation order, then Louvain
+// (louvain.rs:290-356).  Outer keys of `data` are created region by region (index order), valid non-ref candidates in
+// position (= read index) order, first occurrence wins.
+std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all) {
+    if (!vd.any) return {};
+    const uint32_t R = vd.R;
+    const uint64_t NU = vd.pair_key.size();
     std::vector<std::pair<uint32_t, uint32_t>> keys;
     for (uint32_t r = 0; r < R; ++r)
-        if (first_reg[r] != 0xFFFFFFFFu) keys.emplace_back(first_reg[r], r);
+        if (vd.first_key[r] != 0xFFFFFFFFu) keys.emplace_back(vd.first_key[r], r);
     std::sort(keys.begin(), keys.end());
     const double t_host0 = now_ms();
     const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
@@ -267,27 +289,33 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
     phase::Graph data;
     data.reserve_ids(R);
     for (auto &k : keys) data.add_key(k.second);
-    if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(ukey[i] >> 32); }, [&](uint64_t i) { return (uint32_t)ukey[i]; },
-                        [&](uint64_t i) { return (float)uw[i]; }))
+    // data weight of a pair = sum(w), unless the pair disagrees in 3 or more regions: then -(#disagreements)
+    // (dif <= -3 overwrites, main.rs:996-1002)
+    auto weight = [&](uint64_t i) {
+        const int32_t same = (int32_t)(vd.pair_cnt[i] & 0xFFFFu), neg = (int32_t)(vd.pair_cnt[i] >> 16);
+        return (float)(neg >= 3 ? -neg : same - neg);
+    };
+    if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(vd.pair_key[i] >> 32); },
+                        [&](uint64_t i) { return (uint32_t)vd.pair_key[i]; }, weight))
         throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
     mark("keys + edges");
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
-        if (badv[r]) bad.push_back(r);
+        if (vd.bad[r]) bad.push_back(r);
     if (!use_all) { // data.retain(..) + per-row retain (main.rs:1004-1010): erase order = bucket order
         data.keys.keep_if([&](uint32_t k, phase::Nil &) {
-            if (badv[k]) data.is_key[k] = 0;
-            return !badv[k];
+            if (vd.bad[k]) data.is_key[k] = 0;
+            return !vd.bad[k];
         });
-        data.drop_nodes(badv);
+        data.drop_nodes(vd.bad.data());
     }
     mark("retain");
     std::vector<float> ref_row(R, 0.f);
     std::vector<uint8_t> ref_have(R, 0);
     bool have_ref = false;
     for (uint32_t r = 0; r < R; ++r)
-        if (ref_seen[r]) {
-            ref_row[r] = (float)ref_w[r];
+        if (vd.ref_seen[r]) {
+            ref_row[r] = (float)vd.ref_w[r];
             ref_have[r] = 1;
             have_ref = true;
         }
@@ -296,7 +324,7 @@ std::vector<uint32_t> phasing_vote_gpu(np2_ctx *cx, np2_contig *c, PassCounts &p
         throw Np2Error(NP2_E_REFPANIC,
                        "reference would panic: the weight of two conflicting community is not less than 0");
     mark("louvain + ranking");
-    cx->timing.host.push_back({"wall_louvain", (float)(now_ms() - t_host0)});
+    if (cx) cx->timing.host.push_back({"wall_louvain", (float)(now_ms() - t_host0)});
     for (uint32_t b : bad) losers.push_back(b);
     std::sort(losers.begin(), losers.end());
     losers.erase(std::unique(losers.begin(), losers.end()), losers.end());
@@ -803,113 +831,158 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     if (cx->stage_timing) cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
 }
 
-void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
-    if (o->iter_count < 1) throw Np2Error(NP2_E_ARG, "iter_count must be >= 1");
-    hipStream_t s = cx->stream;
+// The per-contig loop (main.rs:1819-1836) as a stepper: begin (dense pass), then for every pass either
+// vote_pass + apply_losers (a phasing pass) or final_pass.  np2_polish_resident drives it straight through; the shards
+// of one contig (np2_shard_*) stop after vote_pass, exchange their votes, and continue with the contig-wide losers.
+struct PolishRun {
+    np2_ctx *cx = nullptr;
+    np2_contig *c = nullptr;
+    np2_opts_t o{};
+    uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu; // regions this run votes over (sub-contig coordinates)
+    uint32_t T = 0, pass = 0, M = 0, n_reg = 0;
+    bool reuse = false;
+    PassCounts pc;
+    bool final_pass() const { return pass + 1 == o.iter_count; }
+};
+
+void run_begin(PolishRun &r) {
+    np2_ctx *cx = r.cx;
+    if (r.o.iter_count < 1) throw Np2Error(NP2_E_ARG, "iter_count must be >= 1");
     HIPCHK(hipSetDevice(cx->device));
     cx->trace_items.clear();
     cx->last_dbase = nullptr;
     cx->scal.ensure(SCAL_TOTAL);
-    cx->alive.ensure(c->R + 2);
-    uint32_t T = 0;
+    cx->alive.ensure(r.c->R + 2);
     {
         WallTimer w(cx, "wall_diff");
-        run_diff(cx, c, T);
+        run_diff(cx, r.c, r.T);
     }
-    launch_init_alive(s, c->reads.p, c->R, cx->alive.p);
-    // If a phasing pass votes out no read, the next pass would rebuild a byte-identical graph, consensus,
-    // region list and candidate table (they are pure functions of the pileup and the live-read set): reuse
-    // them.  The reference recomputes (main.rs:1819-1836); the result is identical by construction.
-    bool reuse = false;
-    uint32_t M = 0, n_reg = 0;
-    PassCounts pc;
-    for (uint32_t pass = 0; pass < o->iter_count; ++pass) {
-        const bool out_cns = pass + 1 == o->iter_count;
-        if (!reuse) {
-            uint32_t n_nodes = 0, n_runs = 0;
-            {
-                WallTimer w(cx, "wall_graph");
-                build_graph(cx, c, T, n_nodes, n_runs);
-            }
-            trace_graph(cx, c, (int)pass, n_nodes);
-            {
-                WallTimer w(cx, "wall_cns_lq");
-                consensus_and_regions(cx, c, n_runs, T, M, n_reg);
-            }
-            if (cx->trace) {
-                trace_cns(cx, (int)pass, "cns_raw", fetch_cns(cx, M));
-                trace_put(cx, (int)pass, "lq.start", d2h(cx, cx->lq_start.p, n_reg));
-                trace_put(cx, (int)pass, "lq.end", d2h(cx, cx->lq_end.p, n_reg));
-            }
+    launch_init_alive(cx->stream, r.c->reads.p, r.c->R, cx->alive.p);
+    r.pass = 0;
+    r.reuse = false;
+}
+
+// graph, consensus, LQ regions and candidates of pass r.pass.  If a phasing pass voted out no read, this pass would
+// rebuild a byte-identical graph, consensus, region list and candidate table (they are pure functions of the pileup and
+// the live-read set): reuse them.  The reference recomputes (main.rs:1819-1836); the result is identical by construction.
+void run_pass_front(PolishRun &r) {
+    np2_ctx *cx = r.cx;
+    np2_contig *c = r.c;
+    if (!r.reuse) {
+        uint32_t n_nodes = 0, n_runs = 0;
+        {
+            WallTimer w(cx, "wall_graph");
+            build_graph(cx, c, r.T, n_nodes, n_runs);
         }
-        if (n_reg == 0) {
-            if (out_cns) {
-                fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, result);
-                return;
-            }
-            reuse = cx->reuse_identical_pass && !cx->trace; // no region -> no read is voted out
-            continue;
+        trace_graph(cx, c, (int)r.pass, n_nodes);
+        {
+            WallTimer w(cx, "wall_cns_lq");
+            consensus_and_regions(cx, c, n_runs, r.T, r.M, r.n_reg);
         }
-        if (!reuse) {
-            pc = PassCounts();
-            pc.M = M;
-            WallTimer w(cx, "wall_extract");
-            extract_candidates(cx, c, n_reg, o->min_kmer_count, (int)pass, pc);
-        } else if (pc.NC_cap) { // undo mark_hete's kscore edits of the previous (identical) pass
-            op_copy_d2d(cx, cx->kscore.p, cx->kscore_saved.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2);
-        }
-        reuse = false;
-        if (!out_cns) {
-            WallTimer w(cx, "wall_vote");
-            const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
-            if (may_reuse && pc.NC_cap) {
-                cx->kscore_saved.ensure((size_t)pc.NC_cap + 2);
-                op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(pc.known ? pc.NC : pc.NC_cap) * 2);
-            }
-            std::vector<uint32_t> losers = phasing_vote_gpu(cx, c, pc, o->model_ref != 0, o->use_all_reads != 0, (int)pass);
-            trace_put(cx, (int)pass, "invalid_ids", losers);
-            for (uint32_t id : losers) REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
-            if (!losers.empty()) {
-                cx->kill_ids.ensure(losers.size());
-                h2d_staged(cx, cx->kill_ids.p, losers.data(), losers.size() * 4);
-                launch_kill_reads(s, cx->kill_ids.p, (uint32_t)losers.size(), cx->alive.p);
-                // (no wait: the ids sit in the pinned staging buffer, guarded by h2d_inflight)
-            } else if (may_reuse) {
-                reuse = true;
-            }
-        } else {
-            WallTimer w(cx, "wall_final");
-            RegionTables rt = region_tables(cx, n_reg);
-            cx->reg_lable.ensure(n_reg + 2);
-            cx->seed_cand.ensure(n_reg + 2);
-            cx->keep_n.ensure(n_reg + 2);
-            if (!pc.known) pc.resolve(fetch_scal(cx)); // the splice rounds need the growth bound
-            cx->keep_list.ensure((size_t)pc.NC_cap + 2);
-            cx->keep_ks.ensure((size_t)pc.NC_cap + 2);
-            {
-                EventTimer t(cx, "seed");
-                launch_seed(s, rt, o->max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
-                            cx->keep_ks.p, cx->scal.p + S_ERR);
-            }
-            if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
-            trace_region_tables(cx, (int)pass, "seed", pc, true);
-            CnsDev cur{cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, M}; // eoff[L] = length of the raw consensus
-            bool to_b = true;
-            uint32_t version = 0;
-            cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.grow, to_b, version++);
-            to_b = !to_b;
-            if (cx->trace) trace_cns(cx, (int)pass, "cns_succ", fetch_cns_dev(cx, cur));
-            for (size_t y = 0; y < cx->yaks.size(); ++y) {
-                cur = recheck_gpu(cx, cur, pc, (int)y, o->min_kmer_count, y == 0, to_b, version++);
-                to_b = !to_b;
-                trace_region_tables(cx, (int)pass, "rech" + std::to_string(y), pc, true);
-                if (cx->trace) trace_cns(cx, (int)pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
-            }
-            fetch_result(cx, cur.pos, cur.base, cur.M_p, result);
-            return;
+        if (cx->trace) {
+            trace_cns(cx, (int)r.pass, "cns_raw", fetch_cns(cx, r.M));
+            trace_put(cx, (int)r.pass, "lq.start", d2h(cx, cx->lq_start.p, r.n_reg));
+            trace_put(cx, (int)r.pass, "lq.end", d2h(cx, cx->lq_end.p, r.n_reg));
         }
     }
-    throw Np2Error(NP2_E_ARG, "unreachable: no final pass");
+    if (r.n_reg == 0) return;
+    if (!r.reuse) {
+        r.pc = PassCounts();
+        r.pc.M = r.M;
+        WallTimer w(cx, "wall_extract");
+        extract_candidates(cx, c, r.n_reg, r.o.min_kmer_count, (int)r.pass, r.pc);
+    } else if (r.pc.NC_cap) { // undo mark_hete's kscore edits of the previous (identical) pass
+        op_copy_d2d(cx, cx->kscore.p, cx->kscore_saved.p, (size_t)(r.pc.known ? r.pc.NC : r.pc.NC_cap) * 2);
+    }
+}
+
+// a phasing pass up to the votes (vd.any == false: nobody votes)
+void run_vote_pass(PolishRun &r, VoteData &vd) {
+    np2_ctx *cx = r.cx;
+    vd = VoteData();
+    vd.R = r.c->R;
+    run_pass_front(r);
+    if (r.n_reg == 0) return;
+    WallTimer w(cx, "wall_vote");
+    const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
+    if (may_reuse && r.pc.NC_cap) {
+        cx->kscore_saved.ensure((size_t)r.pc.NC_cap + 2);
+        op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(r.pc.known ? r.pc.NC : r.pc.NC_cap) * 2);
+    }
+    vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd);
+}
+
+// the reads the vote removed (align_bases = empty, main.rs:1548-1550), then on to the next pass
+void run_apply_losers(PolishRun &r, const std::vector<uint32_t> &losers) {
+    np2_ctx *cx = r.cx;
+    if (r.n_reg) trace_put(cx, (int)r.pass, "invalid_ids", losers); // (a pass without regions never reaches the vote)
+    for (uint32_t id : losers) REFPANIC_IF(id >= r.c->R, "index out of bounds: alignseqs[id]");
+    const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
+    r.reuse = false;
+    if (!losers.empty()) {
+        cx->kill_ids.ensure(losers.size());
+        h2d_staged(cx, cx->kill_ids.p, losers.data(), losers.size() * 4);
+        launch_kill_reads(cx->stream, cx->kill_ids.p, (uint32_t)losers.size(), cx->alive.p);
+        // (no wait: the ids sit in the pinned staging buffer, guarded by h2d_inflight)
+    } else if (may_reuse) {
+        r.reuse = true; // (also when the pass had no region at all: no read was voted out)
+    }
+    ++r.pass;
+}
+
+void run_final_pass(PolishRun &r, ResultOut &result) {
+    np2_ctx *cx = r.cx;
+    np2_contig *c = r.c;
+    hipStream_t s = cx->stream;
+    const uint32_t n_reg_prev = r.n_reg;
+    (void)n_reg_prev;
+    run_pass_front(r);
+    const uint32_t n_reg = r.n_reg;
+    if (n_reg == 0) {
+        fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, result);
+        return;
+    }
+    PassCounts &pc = r.pc;
+    WallTimer w(cx, "wall_final");
+    RegionTables rt = region_tables(cx, n_reg);
+    cx->reg_lable.ensure(n_reg + 2);
+    cx->seed_cand.ensure(n_reg + 2);
+    cx->keep_n.ensure(n_reg + 2);
+    if (!pc.known) pc.resolve(fetch_scal(cx)); // the splice rounds need the growth bound
+    cx->keep_list.ensure((size_t)pc.NC_cap + 2);
+    cx->keep_ks.ensure((size_t)pc.NC_cap + 2);
+    {
+        EventTimer t(cx, "seed");
+        launch_seed(s, rt, r.o.max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
+                    cx->keep_ks.p, cx->scal.p + S_ERR);
+    }
+    if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
+    trace_region_tables(cx, (int)r.pass, "seed", pc, true);
+    CnsDev cur{cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, r.M}; // eoff[L] = length of the raw consensus
+    bool to_b = true;
+    uint32_t version = 0;
+    cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.grow, to_b, version++);
+    to_b = !to_b;
+    if (cx->trace) trace_cns(cx, (int)r.pass, "cns_succ", fetch_cns_dev(cx, cur));
+    for (size_t y = 0; y < cx->yaks.size(); ++y) {
+        cur = recheck_gpu(cx, cur, pc, (int)y, r.o.min_kmer_count, y == 0, to_b, version++);
+        to_b = !to_b;
+        trace_region_tables(cx, (int)r.pass, "rech" + std::to_string(y), pc, true);
+        if (cx->trace) trace_cns(cx, (int)r.pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
+    }
+    fetch_result(cx, cur.pos, cur.base, cur.M_p, result);
+}
+
+void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
+    PolishRun r;
+    r.cx = cx, r.c = c, r.o = *o;
+    run_begin(r);
+    while (!r.final_pass()) {
+        VoteData vd;
+        run_vote_pass(r, vd);
+        run_apply_losers(r, vote_decide(cx, vd, o->use_all_reads != 0));
+    }
+    run_final_pass(r, result);
 }
 
 } // namespace

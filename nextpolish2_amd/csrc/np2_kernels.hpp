@@ -189,9 +189,10 @@ struct RechPtrs {
     const uint8_t *cns_base;
     uint32_t n_groups;
 };
-void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, uint8_t *reg_lable, uint8_t *grp,
-                       uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
-                       uint32_t *err);
+// votes are collected over the regions whose start lies in [own_lo, own_hi) (everything for a whole contig)
+void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, const uint32_t *lq_start,
+                       uint32_t own_lo, uint32_t own_hi, uint8_t *reg_lable, uint8_t *grp, uint32_t *ecount, int32_t *ref_w,
+                       uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg, uint32_t *err);
 void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out);
 void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *reg_lable, const uint8_t *grp,
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval);
@@ -200,11 +201,11 @@ static constexpr uint32_t EDGE_BAND = 256;
 void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, uint32_t *band,
                        uint32_t *ovf);
 void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n);
-void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, int32_t *uw,
+void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out);
-void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, int32_t *wout);
-void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx, const int32_t *wout,
-                         uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out);
+void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, uint32_t *wout);
+void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx, const uint32_t *wout,
+                         uint32_t n, uint64_t *ukey, uint32_t *uw, uint32_t *n_out);
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
                  uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err);
 void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,

@@ -125,6 +125,7 @@ __device__ bool hp_differs(const uint8_t *a, uint32_t na, const uint8_t *b, uint
 
 // ---- phasing pass -----------------------------------------------------------------------------
 __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, uint32_t asref, uint32_t use_all,
+                                                    const uint32_t *__restrict__ lq_start, uint32_t own_lo, uint32_t own_hi,
                                                     uint8_t *__restrict__ reg_lable, uint8_t *__restrict__ grp,
                                                     uint32_t *__restrict__ ecount, int32_t *__restrict__ ref_w,
                                                     uint8_t *__restrict__ ref_seen, uint8_t *__restrict__ bad,
@@ -164,7 +165,11 @@ __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint3
             const uint64_t valid = __ballot(lane < n && ks > 0);
             const bool ref_valid = (valid & 1ull) && __shfl(order, 0) == 0;
             if (lane < n && ks > 0 && order == 0 && lane != 0) atomicOr(err, 4u); // seq2 order == 0 assertion
-            if (ref_valid && lane >= 1 && lane < n && ks > 0) { // pairs (ref, j): main.rs:972-980
+            // a shard of a contig (np2_shard_*) votes only over the regions it owns; its neighbours see the same region
+            // in their halo and stay silent there, so every HETE region of the contig is counted exactly once
+            const uint32_t gs = lq_start[g];
+            const bool owned = gs >= own_lo && gs < own_hi;
+            if (owned && ref_valid && lane >= 1 && lane < n && ks > 0) { // pairs (ref, j): main.rs:972-980
                 const int wgt = ((w.eqmask & 1ull) != 0) ? 1 : -1;
                 if (asref) {
                     atomicAdd(&ref_w[order], wgt);
@@ -174,7 +179,7 @@ __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint3
             }
             const uint64_t V = ref_valid ? (valid & ~1ull) : valid;
             const uint32_t m = __builtin_popcountll(V);
-            if (m >= 2) {
+            if (m >= 2 && owned) {
                 ne = m * (m - 1) / 2;
                 if ((V >> lane) & 1ull) atomicMin(&first_reg[order], g);
             }
@@ -272,10 +277,11 @@ __device__ __forceinline__ void k_band_count(const uint32_t np2_bid, const uint3
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if (lane == 0) row_n[a] = c;
 }
-// ... and their emission in (a, b) order: ukey = a << 32 | b, uw = sum(w) unless #(-1) >= 3 then -(#-1) (main.rs:996-1002)
+// ... and their emission in (a, b) order: ukey = a << 32 | b, ucnt = agreeing regions | disagreeing regions << 16 (the
+// host turns the counts into the weight sum(w), or -(#-1) if #(-1) >= 3, main.rs:996-1002 — after merging shards)
 __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
                                             const uint32_t *__restrict__ row_off, uint64_t *__restrict__ ukey,
-                                            int32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
+                                            uint32_t *__restrict__ ucnt, uint32_t *__restrict__ n_out) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (a >= R) return;
@@ -293,16 +299,15 @@ __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (v[k]) {
-            const int32_t same = (int32_t)(v[k] & 0xFFFFu), neg = (int32_t)(v[k] >> 16);
             ukey[o] = ((uint64_t)a << 32) | (a + 1 + lane * 4 + k);
-            uw[o] = neg >= 3 ? -neg : same - neg;
+            ucnt[o] = v[k];
             ++o;
         }
 }
 
-// reduce sorted edges: data weight = sum(w), unless #(-1) >= 3 then -(#-1) (main.rs:996-1002)
+// reduce sorted edges to per-pair counts: agreeing regions | disagreeing regions << 16
 __device__ __forceinline__ void k_edge_reduce(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ eval, uint32_t n,
-                              uint32_t *__restrict__ flag, int32_t *__restrict__ wout) {
+                              uint32_t *__restrict__ flag, uint32_t *__restrict__ wout) {
     uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = ekey[i];
@@ -317,11 +322,11 @@ __device__ __forceinline__ void k_edge_reduce(const uint32_t np2_bid, const uint
         neg += w < 0;
     }
     flag[i] = 1;
-    wout[i] = neg >= 3 ? -neg : sum;
+    wout[i] = (uint32_t)(sum + neg) | ((uint32_t)neg << 16);
 }
 __device__ __forceinline__ void k_edge_compact(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ flag,
-                               const uint32_t *__restrict__ idx, const int32_t *__restrict__ wout, uint32_t n,
-                               uint64_t *__restrict__ ukey, int32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
+                               const uint32_t *__restrict__ idx, const uint32_t *__restrict__ wout, uint32_t n,
+                               uint64_t *__restrict__ ukey, uint32_t *__restrict__ uw, uint32_t *__restrict__ n_out) {
     uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flag[i]) {
@@ -857,11 +862,11 @@ __device__ __forceinline__ void k_vote_counts(const uint32_t np2_bid, const uint
 // ------------------------------------------------------------------------------------------
 static inline dim3 g1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, uint8_t *reg_lable, uint8_t *grp,
-                       uint32_t *ecount, int32_t *ref_w, uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg,
-                       uint32_t *err) {
+void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool use_all, const uint32_t *lq_start,
+                       uint32_t own_lo, uint32_t own_hi, uint8_t *reg_lable, uint8_t *grp, uint32_t *ecount, int32_t *ref_w,
+                       uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg, uint32_t *err) {
     if (rt.n_reg)
-        NP2_LAUNCH(k_vote_phase, g1((uint64_t)rt.n_reg * 64), 256, s, rt, asref ? 1u : 0u, use_all ? 1u : 0u, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
+        NP2_LAUNCH(k_vote_phase, g1((uint64_t)rt.n_reg * 64), 256, s, rt, asref ? 1u : 0u, use_all ? 1u : 0u, lq_start, own_lo, own_hi, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
 }
 void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out) {
     NP2_LAUNCH(k_vote_counts, dim3(1), 1024, s, first_reg, bad, R, out);
@@ -878,16 +883,16 @@ void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp
 void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n) {
     if (R) NP2_LAUNCH(k_band_count, g1((uint64_t)R * 64), 256, s, band, R, row_n);
 }
-void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, int32_t *uw,
+void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out) {
     if (R) NP2_LAUNCH(k_band_emit, g1((uint64_t)R * 64), 256, s, band, R, row_off, ukey, uw, n_out);
 }
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag,
-                        int32_t *wout) {
+                        uint32_t *wout) {
     if (n) NP2_LAUNCH(k_edge_reduce, g1(n), 256, s, ekey, eval, n, flag, wout);
 }
 void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx,
-                         const int32_t *wout, uint32_t n, uint64_t *ukey, int32_t *uw, uint32_t *n_out) {
+                         const uint32_t *wout, uint32_t n, uint64_t *ukey, uint32_t *uw, uint32_t *n_out) {
     if (n) NP2_LAUNCH(k_edge_compact, g1(n), 256, s, ekey, flag, idx, wout, n, ukey, uw, n_out);
 }
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
