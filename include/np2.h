@@ -167,6 +167,53 @@ int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches);
 int np2_batch_flush_log(np2_batch_t *b, const double **log);
 int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes);
 
+/* ---- shards of one contig: reference-interval sharding of a long contig over several GPUs ------------------------------
+ * The reference polishes a contig on one thread (main.rs:1726-1837).  Here a contig can be cut into reference intervals,
+ * one per GPU: a shard holds every read overlapping its interval widened by `halo` (whole reads, global read numbering
+ * kept), polishes that sub-contig like a contig of its own, votes only over the HETE regions it owns and emits only the
+ * consensus bases of its interval.  Per phasing pass the shards' votes are merged and decided once per contig
+ * (np2_vote_decide: the Louvain of louvain.rs:290-356 on the merged read graph), and the reads it removes are applied to
+ * every shard.  Inside [own_lo - halo, own_hi + halo) a shard sees exactly the reads of the whole contig, so the stitched
+ * result is the unsharded one; `verify` extra positions on either side are emitted too so that the stitcher can check
+ * that neighbouring shards agree there (nextpolish2_amd.dist.stitch_shards). */
+typedef struct np2_shard_plan {
+    uint32_t own_lo, own_hi;   /* contig positions [own_lo, own_hi) this shard emits and votes over */
+    uint32_t sub_lo, sub_hi;   /* sub-contig [sub_lo, sub_hi) it polishes (holds its reads entirely) */
+    uint32_t zone_lo, zone_hi; /* [own_lo - halo, own_hi + halo) clipped to the contig: reads overlapping it are held */
+    uint32_t read_lo, read_hi; /* reads [read_lo, read_hi) of the contig (read 0, the contig itself, is replaced by the
+                                * sub-contig); local read i >= 1 is contig read read_lo + i - 1 */
+} np2_shard_plan_t;
+/* host only: cut a contig (read descriptors in alignment-start order, as the BAM gives them) into n_shards intervals */
+int np2_shard_plan(const np2_read_t *reads, uint32_t n_reads, uint32_t L, uint32_t n_shards, uint32_t halo,
+                   np2_shard_plan_t *out /* [n_shards] */);
+/* upload the shard's part of a host pileup (same arguments as np2_contig_upload + the plan entry) */
+int np2_shard_upload(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, const np2_read_t *reads, uint32_t n_reads,
+                     const uint8_t *nibbles, uint64_t nib_bytes, const np2_shard_plan_t *plan, np2_contig_t **out);
+/* what one shard contributes to a phasing pass (borrowed from the run until its next call); read ids are contig-wide */
+typedef struct np2_vote {
+    uint64_t n_pairs;
+    const uint64_t *pair_key;  /* a << 32 | b, a < b */
+    const uint32_t *pair_cnt;  /* owned HETE regions in which the pair agrees | disagrees << 16 (main.rs:982-1002) */
+    uint32_t n_reads;
+    const uint32_t *read_id;
+    const uint32_t *first_pos; /* start of the rightmost owned HETE region the read votes in (0xFFFFFFFF: none) */
+    const int32_t *ref_w;      /* summed weight against the contig's own candidate (ref_data[0], main.rs:972-976) */
+    const uint8_t *flags;      /* 1: votes, 2: has a ref_data entry, 4: invalid (disagrees with the contig, main.rs:977) */
+} np2_vote_t;
+typedef struct np2_shard_run np2_shard_run_t;
+int np2_shard_begin(np2_ctx_t *ctx, np2_contig_t *shard, const np2_shard_plan_t *plan, const np2_opts_t *opts,
+                    uint32_t verify, np2_shard_run_t **out);
+int np2_shard_passes_left(np2_shard_run_t *run);          /* iter_count - passes done; 1 = only the final pass is left */
+int np2_shard_vote(np2_shard_run_t *run, np2_vote_t *out); /* a phasing pass up to its votes */
+/* host only: merge the shards' votes of one pass and decide (reads of the whole contig: n_reads_total); losers: capacity
+ * n_reads_total */
+int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total, const np2_opts_t *opts, uint32_t *losers,
+                    uint32_t *n_losers);
+int np2_shard_apply(np2_shard_run_t *run, const uint32_t *losers, uint32_t n_losers); /* contig-wide ids */
+/* the final pass; bases / positions (contig coordinates) of [own_lo - verify, own_hi + verify); release with np2_free */
+int np2_shard_final(np2_shard_run_t *run, uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
+void np2_shard_end(np2_shard_run_t *run);
+
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
  * names: NUL-separated list terminated by an empty string; ms[i] matches names[i].
  * By default only the dense pass ("diff_reads") is timed; np2_ctx_set_timing(ctx, 1) arms every stage timer

@@ -43,6 +43,18 @@ class np2_opts_t(C.Structure):
     ]
 
 
+class np2_shard_plan_t(C.Structure):
+    # include/np2.h: one reference interval of a contig cut over several GPUs
+    _fields_ = [("own_lo", C.c_uint32), ("own_hi", C.c_uint32), ("sub_lo", C.c_uint32), ("sub_hi", C.c_uint32),
+                ("zone_lo", C.c_uint32), ("zone_hi", C.c_uint32), ("read_lo", C.c_uint32), ("read_hi", C.c_uint32)]
+
+
+class np2_vote_t(C.Structure):
+    # include/np2.h: what one shard contributes to a phasing pass
+    _fields_ = [("n_pairs", C.c_uint64), ("pair_key", C.c_void_p), ("pair_cnt", C.c_void_p), ("n_reads", C.c_uint32),
+                ("read_id", C.c_void_p), ("first_pos", C.c_void_p), ("ref_w", C.c_void_p), ("flags", C.c_void_p)]
+
+
 class Opts:
     """Defaults of the reference CLI (src/utils/option.rs:267-292)."""
 

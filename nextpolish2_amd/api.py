@@ -9,7 +9,7 @@ import weakref
 
 import numpy as np
 
-from ._types import Opts, Pileup, np2_opts_t, np2_read_t, np2_yak_t, yaks_array
+from ._types import Opts, Pileup, np2_opts_t, np2_read_t, np2_shard_plan_t, np2_vote_t, np2_yak_t, yaks_array
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NP2_LIB_PATH") or os.path.join(_HERE, "libnp2_hip.so")  # override: A/B builds
@@ -21,7 +21,9 @@ ABI_SYMBOLS = [
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
     "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_result_fetch_begin", "np2_result_fetch_end", "np2_phase_vote",
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
-    "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
+    "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
+    "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
+    "np2_shard_end", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -81,6 +83,16 @@ def lib():
         L.np2_batch_set_timing.restype = None
         L.np2_batch_last_diff_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.np2_batch_flush_log.argtypes = [vp, C.POINTER(vp)]
+        L.np2_shard_plan.argtypes = [vp, u32, u32, u32, u32, C.POINTER(np2_shard_plan_t)]
+        L.np2_shard_upload.argtypes = [vp, vp, u32, vp, u32, vp, u64, C.POINTER(np2_shard_plan_t), C.POINTER(vp)]
+        L.np2_shard_begin.argtypes = [vp, vp, C.POINTER(np2_shard_plan_t), C.POINTER(np2_opts_t), u32, C.POINTER(vp)]
+        L.np2_shard_passes_left.argtypes = [vp]
+        L.np2_shard_vote.argtypes = [vp, C.POINTER(np2_vote_t)]
+        L.np2_vote_decide.argtypes = [C.POINTER(np2_vote_t), C.c_int, u32, C.POINTER(np2_opts_t), vp, C.POINTER(u32)]
+        L.np2_shard_apply.argtypes = [vp, vp, u32]
+        L.np2_shard_final.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.np2_shard_end.argtypes = [vp]
+        L.np2_shard_end.restype = None
         L.np2_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         _LIB = L
     return _LIB
@@ -145,6 +157,19 @@ class Polisher:
             raise Np2Error(rc, "np2_ctx_create failed (see stderr)")
         self._h = h
         self.device = device
+
+    def clone(self):
+        """np2_ctx_create_shared: a further context on the same device over the SAME HBM k-mer tables."""
+        p = Polisher.__new__(Polisher)
+        p._yaks = self._yaks
+        p._parent = self
+        p.device = self.device
+        h = C.c_void_p()
+        rc = lib().np2_ctx_create_shared(C.byref(h), self._h)
+        if rc != 0:
+            raise Np2Error(rc, "np2_ctx_create_shared failed (see stderr)")
+        p._h = h
+        return p
 
     def close(self):
         if getattr(self, "_h", None):
@@ -347,6 +372,119 @@ class BatchPolisher:
         if rc != 0:
             raise Np2Error(rc, "np2_result_fetch_end")
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value]
+
+
+# ---- shards of one contig (include/np2.h np2_shard_*) -------------------------------------------------------------------
+def shard_plan(pileup: Pileup, n_shards, halo=65536):
+    """np2_shard_plan: cut a contig into n_shards reference intervals -> [np2_shard_plan_t]."""
+    plans = (np2_shard_plan_t * n_shards)()
+    rc = lib().np2_shard_plan(pileup.reads.ctypes.data, pileup.n_reads, pileup.L, n_shards, halo, plans)
+    if rc != 0:
+        raise Np2Error(rc, "np2_shard_plan: contig too short for that many shards?")
+    return [plans[i] for i in range(n_shards)]
+
+
+class Vote:
+    """Host copy of one shard's np2_vote_t (numpy arrays), serialisable for the exchange between ranks."""
+
+    FIELDS = (("pair_key", np.uint64), ("pair_cnt", np.uint32), ("read_id", np.uint32), ("first_pos", np.uint32),
+              ("ref_w", np.int32), ("flags", np.uint8))
+
+    def __init__(self, **arrays):
+        for name, dt in self.FIELDS:
+            setattr(self, name, np.ascontiguousarray(arrays.get(name, np.zeros(0, dtype=dt)), dtype=dt))
+
+    @classmethod
+    def from_c(cls, v: np2_vote_t):
+        def arr(ptr, n, dt):
+            if not n:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer((C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+        return cls(pair_key=arr(v.pair_key, v.n_pairs, np.uint64), pair_cnt=arr(v.pair_cnt, v.n_pairs, np.uint32),
+                   read_id=arr(v.read_id, v.n_reads, np.uint32), first_pos=arr(v.first_pos, v.n_reads, np.uint32),
+                   ref_w=arr(v.ref_w, v.n_reads, np.int32), flags=arr(v.flags, v.n_reads, np.uint8))
+
+    def c(self):
+        return np2_vote_t(len(self.pair_key), self.pair_key.ctypes.data, self.pair_cnt.ctypes.data, len(self.read_id),
+                          self.read_id.ctypes.data, self.first_pos.ctypes.data, self.ref_w.ctypes.data, self.flags.ctypes.data)
+
+    def to_bytes(self):
+        hdr = np.array([len(self.pair_key), len(self.read_id)], dtype=np.uint64).tobytes()
+        return hdr + b"".join(getattr(self, n).tobytes() for n, _ in self.FIELDS)
+
+    @classmethod
+    def from_bytes(cls, raw):
+        n_pairs, n_reads = (int(x) for x in np.frombuffer(raw[:16], dtype=np.uint64))
+        off, out = 16, {}
+        for name, dt in cls.FIELDS:
+            n = n_pairs if name.startswith("pair") else n_reads
+            nb = n * np.dtype(dt).itemsize
+            out[name] = np.frombuffer(raw[off:off + nb], dtype=dt)
+            off += nb
+        return cls(**out)
+
+
+def vote_decide(votes, n_reads_total, opts: Opts = None):
+    """np2_vote_decide: merge the shards' votes of one phasing pass, Louvain on the merged read graph -> sorted losers
+    (contig-wide read ids).  Host only, deterministic: every rank can run it on the same gathered votes."""
+    o = (opts or Opts()).c()
+    arr = (np2_vote_t * len(votes))(*[v.c() for v in votes])
+    out = np.zeros(max(1, n_reads_total), dtype=np.uint32)
+    n = C.c_uint32()
+    rc = lib().np2_vote_decide(arr, len(votes), n_reads_total, C.byref(o), out.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise Np2Error(rc, "np2_vote_decide")
+    return out[: n.value].copy()
+
+
+class ShardRun:
+    """One shard of a contig on one context: upload, then vote() / apply() per phasing pass, final()."""
+
+    def __init__(self, polisher: Polisher, pileup: Pileup, plan: np2_shard_plan_t, opts: Opts = None, verify=1024):
+        self._pol = polisher
+        self.plan = plan
+        self.verify = verify
+        self._c = C.c_void_p()
+        polisher._check(lib().np2_shard_upload(polisher._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
+                                               pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
+                                               C.byref(plan), C.byref(self._c)))
+        self._o = (opts or Opts()).c()
+        self._r = C.c_void_p()
+        rc = lib().np2_shard_begin(polisher._h, self._c, C.byref(plan), C.byref(self._o), verify, C.byref(self._r))
+        if rc != 0:
+            self.close()
+            polisher._check(rc)
+
+    def passes_left(self):
+        return lib().np2_shard_passes_left(self._r)
+
+    def vote(self) -> Vote:
+        v = np2_vote_t()
+        self._pol._check(lib().np2_shard_vote(self._r, C.byref(v)))
+        return Vote.from_c(v)
+
+    def apply(self, losers):
+        a = np.ascontiguousarray(losers, dtype=np.uint32)
+        self._pol._check(lib().np2_shard_apply(self._r, a.ctypes.data, len(a)))
+
+    def final(self):
+        ob, op, on = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._pol._check(lib().np2_shard_final(self._r, C.byref(ob), C.byref(op), C.byref(on)))
+        return _owned(ob, on.value, C.c_uint8), _owned(op, on.value, C.c_uint32)
+
+    def close(self):
+        if getattr(self, "_r", None):
+            lib().np2_shard_end(self._r)
+            self._r = None
+        if getattr(self, "_c", None):
+            lib().np2_contig_free(self._pol._h, self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fasta_record(name, bases, pos):

@@ -985,6 +985,25 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     run_final_pass(r, result);
 }
 
+
+// ---- shards of one contig ----------------------------------------------------------------------------------------------
+// A shard polishes the sub-contig [sub_lo, sub_hi) that holds every read overlapping its owned interval widened by a halo,
+// as if it were a contig of its own; inside [own_lo - halo, own_hi + halo) every read of the whole contig is present, so
+// graph, DP (exact between clean positions), LQ regions, candidates and recheck chains there are those of
+// the whole contig.  What is not local: the phasing vote (collected per shard over the regions it owns, decided once per
+// contig on the merged votes, main.rs:948-1015) and the reads it removes (applied everywhere).
+struct ShardRun {
+    PolishRun run;
+    np2_shard_plan_t plan{};
+    uint32_t verify = 0; // positions beyond the owned interval that are emitted as well (checked by the stitcher)
+    // last exported vote (borrowed by the caller until the next call)
+    std::vector<uint64_t> v_key;
+    std::vector<uint32_t> v_cnt, v_read, v_first;
+    std::vector<int32_t> v_refw;
+    std::vector<uint8_t> v_flags;
+};
+inline uint32_t shard_global_read(const np2_shard_plan_t &pl, uint32_t local) { return local == 0 ? 0u : pl.read_lo + local - 1; }
+
 } // namespace
 
 
@@ -1430,6 +1449,284 @@ int np2_last_timings(np2_ctx_t *cx, const char **names, const float **ms, int *n
     *names = cx->timing.joined.c_str();
     *ms = cx->timing.ms.data();
     *n = (int)cx->timing.ms.size();
+    return NP2_OK;
+}
+
+// ---- shards of one contig (multi-GPU: reference intervals of a long contig) -----------------------------------------
+int np2_shard_plan(const np2_read_t *reads, uint32_t n_reads, uint32_t L, uint32_t n_shards, uint32_t halo,
+                   np2_shard_plan_t *out) {
+    if (!reads || !out || n_reads < 1 || n_shards < 1 || L < 3) return NP2_E_ARG;
+    for (uint32_t k = 0; k < n_shards; ++k) {
+        np2_shard_plan_t &p = out[k];
+        p.own_lo = (uint32_t)((uint64_t)L * k / n_shards);
+        p.own_hi = (uint32_t)((uint64_t)L * (k + 1) / n_shards);
+        if (k) p.own_lo &= ~1023u; // (cuts on tile boundaries; the last shard ends at L)
+        if (k + 1 < n_shards) p.own_hi &= ~1023u;
+        if (p.own_hi <= p.own_lo) return NP2_E_ARG; // contig too short for that many shards
+        const uint32_t zlo = p.own_lo > halo ? p.own_lo - halo : 0u;
+        const uint32_t zhi = (uint64_t)p.own_hi + halo < L ? p.own_hi + halo : L;
+        // every read overlapping the zone, whole; the sub-contig spans from the first start to the last end among them
+        uint32_t rlo = 0xFFFFFFFFu, rhi = 0, slo = zlo, shi = zhi;
+        for (uint32_t r = 1; r < n_reads; ++r) {
+            const np2_read_t &rd = reads[r];
+            if (rd.flags & NP2_READ_DROPPED) continue;
+            if (rd.aln_t_e < zlo || rd.aln_t_s >= zhi) continue;
+            rlo = std::min(rlo, r);
+            rhi = std::max(rhi, r + 1);
+            slo = std::min(slo, rd.aln_t_s);
+            shi = std::max(shi, rd.aln_t_e + 1);
+        }
+        if (rlo == 0xFFFFFFFFu) rlo = rhi = 1;
+        p.read_lo = rlo;
+        p.read_hi = rhi;
+        p.sub_lo = k == 0 ? 0u : (slo & ~63u); // (64-aligned: the packed contig slice starts on a byte / word boundary)
+        p.sub_hi = k + 1 == n_shards ? L : shi;
+        p.zone_lo = zlo;
+        p.zone_hi = zhi;
+    }
+    return NP2_OK;
+}
+
+int np2_shard_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_read_t *reads, uint32_t n_reads,
+                     const uint8_t *nibbles, uint64_t nib_bytes, const np2_shard_plan_t *pl, np2_contig_t **out) {
+    if (!cx || !ref || !reads || !nibbles || !pl || !out) return NP2_E_ARG;
+    *out = nullptr;
+    try {
+        if (pl->sub_hi > L || pl->sub_lo >= pl->sub_hi || pl->read_hi > n_reads || pl->read_lo < 1 || pl->read_lo > pl->read_hi)
+            throw Np2Error(NP2_E_ARG, "shard plan does not fit the contig");
+        const uint32_t Ls = pl->sub_hi - pl->sub_lo, n = 1 + (pl->read_hi - pl->read_lo);
+        // local read 0: the sub-contig aligned to itself, packed here (AlignSeq::new of main.rs:1732-1739 on the slice)
+        const uint64_t ref_bytes = ((((uint64_t)Ls + 1) >> 1) + 1 + 15) & ~15ull;
+        // nibble streams of the shard's reads: one contiguous piece of the contig's buffer (reads are stored in order)
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t r = pl->read_lo; r < pl->read_hi; ++r) {
+            lo = std::min<uint64_t>(lo, reads[r].nib_off);
+            hi = std::max<uint64_t>(hi, reads[r].nib_off + (((uint64_t)reads[r].n_cols + 1) >> 1) + 1);
+        }
+        if (lo == ~0ull) lo = hi = 0;
+        if (hi + 16 > nib_bytes && hi) throw Np2Error(NP2_E_ARG, "nibble stream (plus 16 B tail padding) exceeds the buffer");
+        const uint64_t piece = hi > lo ? ((hi - lo + 15) & ~15ull) : 0;
+        const uint64_t total = ref_bytes + piece + 64;
+        std::vector<uint8_t> host(total, 0);
+        for (uint32_t i = 0; i < Ls; ++i) {
+            const uint8_t code = ascii_to_code(ref[pl->sub_lo + i]);
+            host[i >> 1] |= (i & 1) ? code : (uint8_t)(code << 4);
+        }
+        host[Ls >> 1] |= (Ls & 1) ? 0x0F : 0xFF;
+        if (piece) memcpy(host.data() + ref_bytes, nibbles + lo, std::min<uint64_t>(piece, nib_bytes - lo));
+        std::vector<np2_read_t> rds(n);
+        memset(rds.data(), 0, n * sizeof(np2_read_t));
+        rds[0].aln_t_s = 0, rds[0].aln_t_e = Ls - 1, rds[0].n_cols = Ls, rds[0].nib_off = 0;
+        for (uint32_t i = 1; i < n; ++i) {
+            const np2_read_t &g = reads[pl->read_lo + i - 1];
+            np2_read_t &d = rds[i];
+            d = g;
+            const bool outside = (g.flags & NP2_READ_DROPPED) || g.aln_t_e < pl->zone_lo || g.aln_t_s >= pl->zone_hi;
+            if (outside) { // keeps its index (like a read the clip filter emptied, main.rs:571)
+                d.flags |= NP2_READ_DROPPED;
+                d.n_cols = 0;
+                d.aln_t_s = d.aln_t_e = 0;
+                d.nib_off = ref_bytes; // (any valid 16-B aligned slot: never decoded)
+                continue;
+            }
+            if (g.aln_t_s < pl->sub_lo || g.aln_t_e >= pl->sub_hi) throw Np2Error(NP2_E_ARG, "shard plan: read outside the sub-contig");
+            d.aln_t_s = g.aln_t_s - pl->sub_lo;
+            d.aln_t_e = g.aln_t_e - pl->sub_lo;
+            d.nib_off = ref_bytes + (g.nib_off - lo);
+        }
+        return np2_contig_upload(cx, ref + pl->sub_lo, Ls, rds.data(), n, host.data(), total, out);
+    } catch (const Np2Error &e) {
+        return fail(cx, e);
+    } catch (const std::exception &ex) {
+        return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
+    }
+}
+
+#define NP2_SHARD_TRY(cxp, ...)                                                                      \
+    try {                                                                                            \
+        __VA_ARGS__                                                                                  \
+    } catch (const Np2Error &e) {                                                                    \
+        (void)hipStreamSynchronize((cxp)->stream);                                                   \
+        if ((cxp)->stream2) (void)hipStreamSynchronize((cxp)->stream2);                              \
+        return fail((cxp), e);                                                                       \
+    } catch (const std::exception &ex) {                                                             \
+        (void)hipStreamSynchronize((cxp)->stream);                                                   \
+        return fail((cxp), Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what())); \
+    }
+
+int np2_shard_begin(np2_ctx_t *cx, np2_contig_t *c, const np2_shard_plan_t *pl, const np2_opts_t *opts, uint32_t verify,
+                    np2_shard_run_t **out) {
+    if (!cx || !c || !pl || !opts || !out) return NP2_E_ARG;
+    *out = nullptr;
+    ShardRun *sr = new ShardRun();
+    sr->plan = *pl;
+    sr->verify = verify;
+    sr->run.cx = cx, sr->run.c = c, sr->run.o = *opts;
+    sr->run.own_lo = pl->own_lo - pl->sub_lo;
+    sr->run.own_hi = pl->own_hi - pl->sub_lo;
+    try {
+        if (c->L != pl->sub_hi - pl->sub_lo || c->R != 1 + (pl->read_hi - pl->read_lo))
+            throw Np2Error(NP2_E_ARG, "contig is not the upload of this shard plan");
+        run_begin(sr->run);
+    } catch (const Np2Error &e) {
+        delete sr;
+        (void)hipStreamSynchronize(cx->stream);
+        return fail(cx, e);
+    }
+    *out = (np2_shard_run_t *)sr;
+    return NP2_OK;
+}
+void np2_shard_end(np2_shard_run_t *h) { delete (ShardRun *)h; }
+int np2_shard_passes_left(np2_shard_run_t *h) {
+    ShardRun *sr = (ShardRun *)h;
+    return sr ? (int)(sr->run.o.iter_count - sr->run.pass) : 0;
+}
+
+int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
+    ShardRun *sr = (ShardRun *)h;
+    if (!sr || !out || sr->run.final_pass()) return NP2_E_ARG;
+    np2_ctx *cx = sr->run.cx;
+    NP2_SHARD_TRY(cx, {
+        VoteData vd;
+        run_vote_pass(sr->run, vd);
+        sr->v_key.clear(), sr->v_cnt.clear(), sr->v_read.clear(), sr->v_first.clear(), sr->v_refw.clear(), sr->v_flags.clear();
+        if (vd.any) {
+            // region index -> contig position: the merged key order of the contig's weight map is by descending region
+            // start (regions are listed right to left, main.rs:1613-1620), read index within a region
+            std::vector<uint32_t> start = d2h(cx, cx->lq_start.p, sr->run.n_reg);
+            const np2_shard_plan_t &pl = sr->plan;
+            for (size_t i = 0; i < vd.pair_key.size(); ++i) {
+                const uint32_t a = shard_global_read(pl, (uint32_t)(vd.pair_key[i] >> 32));
+                const uint32_t b = shard_global_read(pl, (uint32_t)vd.pair_key[i]);
+                sr->v_key.push_back(((uint64_t)a << 32) | b);
+                sr->v_cnt.push_back(vd.pair_cnt[i]);
+            }
+            for (uint32_t r = 0; r < vd.R; ++r) {
+                const bool votes = vd.first_key[r] != 0xFFFFFFFFu;
+                if (!votes && !vd.ref_seen[r] && !vd.bad[r]) continue;
+                sr->v_read.push_back(shard_global_read(pl, r));
+                sr->v_first.push_back(votes ? start[vd.first_key[r]] + pl.sub_lo : 0xFFFFFFFFu);
+                sr->v_refw.push_back(vd.ref_w[r]);
+                sr->v_flags.push_back((uint8_t)((votes ? 1 : 0) | (vd.ref_seen[r] ? 2 : 0) | (vd.bad[r] ? 4 : 0)));
+            }
+        }
+        out->n_pairs = sr->v_key.size();
+        out->pair_key = sr->v_key.data();
+        out->pair_cnt = sr->v_cnt.data();
+        out->n_reads = (uint32_t)sr->v_read.size();
+        out->read_id = sr->v_read.data();
+        out->first_pos = sr->v_first.data();
+        out->ref_w = sr->v_refw.data();
+        out->flags = sr->v_flags.data();
+    })
+    return NP2_OK;
+}
+
+int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total, const np2_opts_t *opts, uint32_t *losers,
+                    uint32_t *n_losers) {
+    if (!votes || n_votes < 1 || !opts || !losers || !n_losers) return NP2_E_ARG;
+    try {
+        VoteData vd;
+        vd.R = n_reads_total;
+        vd.first_key.assign(n_reads_total, 0xFFFFFFFFu);
+        vd.ref_w.assign(n_reads_total, 0);
+        vd.ref_seen.assign(n_reads_total, 0);
+        vd.bad.assign(n_reads_total, 0);
+        std::vector<uint32_t> first_pos(n_reads_total, 0);
+        std::vector<uint8_t> votes_any(n_reads_total, 0);
+        std::vector<std::pair<uint64_t, uint32_t>> pairs;
+        for (int v = 0; v < n_votes; ++v) {
+            const np2_vote_t &x = votes[v];
+            for (uint64_t i = 0; i < x.n_pairs; ++i) pairs.emplace_back(x.pair_key[i], x.pair_cnt[i]);
+            for (uint32_t i = 0; i < x.n_reads; ++i) {
+                const uint32_t r = x.read_id[i];
+                if (r >= n_reads_total) return NP2_E_ARG;
+                vd.any = true;
+                vd.ref_w[r] += x.ref_w[i];
+                if (x.flags[i] & 2) vd.ref_seen[r] = 1;
+                if (x.flags[i] & 4) vd.bad[r] = 1;
+                if (x.flags[i] & 1) { // the read's first vote = its rightmost HETE region over all shards
+                    if (!votes_any[r] || x.first_pos[i] > first_pos[r]) first_pos[r] = x.first_pos[i];
+                    votes_any[r] = 1;
+                }
+            }
+        }
+        // the same pair may share regions of two shards: counts add up before the weight rule is applied
+        std::sort(pairs.begin(), pairs.end());
+        for (size_t i = 0; i < pairs.size();) {
+            uint32_t same = 0, neg = 0;
+            size_t j = i;
+            for (; j < pairs.size() && pairs[j].first == pairs[i].first; ++j) same += pairs[j].second & 0xFFFFu, neg += pairs[j].second >> 16;
+            if (same > 0xFFFFu || neg > 0xFFFFu) return NP2_E_UNSUPPORTED;
+            vd.pair_key.push_back(pairs[i].first);
+            vd.pair_cnt.push_back(same | (neg << 16));
+            i = j;
+        }
+        for (uint32_t r = 0; r < n_reads_total; ++r)
+            if (votes_any[r]) vd.first_key[r] = 0xFFFFFFFEu - first_pos[r]; // ascending = right to left
+        std::vector<uint32_t> ls = vote_decide(nullptr, vd, opts->use_all_reads != 0);
+        *n_losers = (uint32_t)ls.size();
+        for (size_t i = 0; i < ls.size(); ++i) losers[i] = ls[i];
+    } catch (const Np2Error &e) {
+        return e.code;
+    } catch (const std::exception &) {
+        return NP2_E_NOMEM;
+    }
+    return NP2_OK;
+}
+
+int np2_shard_apply(np2_shard_run_t *h, const uint32_t *losers, uint32_t n) {
+    ShardRun *sr = (ShardRun *)h;
+    if (!sr || (n && !losers) || sr->run.final_pass()) return NP2_E_ARG;
+    np2_ctx *cx = sr->run.cx;
+    NP2_SHARD_TRY(cx, {
+        std::vector<uint32_t> local;
+        const np2_shard_plan_t &pl = sr->plan;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (losers[i] == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: the contig itself was voted out");
+            if (losers[i] >= pl.read_lo && losers[i] < pl.read_hi) local.push_back(losers[i] - pl.read_lo + 1);
+        }
+        // (no identical-pass reuse across shards: a neighbour's removals are not visible here, the decision would
+        // differ from shard to shard only in cost, never in result — but keep it simple)
+        const uint32_t n_reg = sr->run.n_reg;
+        run_apply_losers(sr->run, local);
+        if (n) sr->run.reuse = false;
+        (void)n_reg;
+    })
+    return NP2_OK;
+}
+
+int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len) {
+    ShardRun *sr = (ShardRun *)h;
+    if (!sr || !out_bases || !out_pos || !out_len || !sr->run.final_pass()) return NP2_E_ARG;
+    np2_ctx *cx = sr->run.cx;
+    ResultOut r;
+    NP2_SHARD_TRY(cx, {
+        run_final_pass(sr->run, r);
+        const np2_shard_plan_t &pl = sr->plan;
+        // a splice cursor that got stuck (update_consensus_with_lqseqs, main.rs:1036-1056) leaves every region to its
+        // right untouched — contig-wide: a shard cannot reproduce that on its own
+        if (pl.sub_lo != 0) {
+            std::vector<uint32_t> rounds = d2h(cx, cx->scal.p + S_COUNT, 2 * (cx->yaks.size() + 1));
+            for (size_t v = 0; v < rounds.size(); v += 2)
+                if (rounds[v]) throw Np2Error(NP2_E_UNSUPPORTED, "splice cursor stuck inside a shard: polish this contig unsharded");
+        }
+        // keep the owned interval (+ the verification margin), in contig coordinates
+        const uint32_t lo = pl.own_lo > sr->verify ? pl.own_lo - sr->verify : 0u;
+        const uint64_t hi = (uint64_t)pl.own_hi + sr->verify;
+        uint64_t w = 0;
+        for (uint64_t i = 0; i < r.len; ++i) {
+            const uint64_t gp = (uint64_t)r.pos[i] + pl.sub_lo;
+            if (gp < lo || gp >= hi) continue;
+            r.bases[w] = r.bases[i];
+            r.pos[w] = (uint32_t)gp;
+            ++w;
+        }
+        r.len = w;
+    })
+    *out_bases = r.bases;
+    *out_pos = r.pos;
+    *out_len = r.len;
     return NP2_OK;
 }
 }

@@ -68,6 +68,90 @@ def all_gather_sequences(local, device=None, group=None):
     return out
 
 
+# ---- reference-interval sharding of one long contig --------------------------------------------------------------
+def stitch_shards(pieces, plans, verify):
+    """Join the shards' consensus pieces [(bases, pos)] (each covering [own_lo - verify, own_hi + verify) in contig
+    coordinates) into the contig's consensus.  Neighbouring shards computed the `verify` positions on either side of
+    their common boundary independently: they must agree base for base there, otherwise the halo was too small for this
+    pileup and the caller falls back to the unsharded path."""
+    out_b, out_p = [], []
+    for k, ((b, p), pl) in enumerate(zip(pieces, plans)):
+        b, p = np.asarray(b), np.asarray(p)
+        if k + 1 < len(pieces):
+            nb, npos = np.asarray(pieces[k + 1][0]), np.asarray(pieces[k + 1][1])
+            lo, hi = max(0, pl.own_hi - verify), pl.own_hi + verify
+            m1 = (p >= lo) & (p < hi)
+            m2 = (npos >= lo) & (npos < hi)
+            if not (np.array_equal(b[m1], nb[m2]) and np.array_equal(p[m1], npos[m2])):
+                raise ShardMismatch(f"shards {k} and {k + 1} disagree around position {pl.own_hi}")
+        own = (p >= pl.own_lo) & (p < pl.own_hi)
+        out_b.append(b[own])
+        out_p.append(p[own])
+    return np.concatenate(out_b), np.concatenate(out_p)
+
+
+class ShardMismatch(RuntimeError):
+    pass
+
+
+def polish_sharded_local(polisher, pileup, opts=None, n_shards=2, halo=65536, verify=1024):
+    """Polish one contig as n_shards reference intervals inside this process, one np2 context per shard (clones of
+    `polisher`: same device, shared k-mer tables): the single-process form of polish_sharded, used by tests and by a
+    single-GPU run that wants the shard path.  Returns (bases, pos) of the whole contig."""
+    from .api import ShardRun, shard_plan, vote_decide
+    plans = shard_plan(pileup, n_shards, halo)
+    ctxs = [polisher.clone() for _ in range(n_shards)]  # a run keeps its state in its context's scratch
+    runs = [ShardRun(ctxs[k], pileup, plans[k], opts, verify) for k in range(n_shards)]
+    try:
+        while runs[0].passes_left() > 1:
+            votes = [r.vote() for r in runs]
+            losers = vote_decide(votes, pileup.n_reads, opts)
+            for r in runs:
+                r.apply(losers)
+        pieces = [r.final() for r in runs]
+    finally:
+        for r in runs:
+            r.close()
+    return stitch_shards(pieces, plans, verify)
+
+
+def all_gather_bytes(raw, device=None, group=None):
+    """Every rank's byte string, in rank order."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    got = all_gather_sequences([(rank, raw)], device=device, group=group)
+    return [got[r] for r in range(len(got))]
+
+
+def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=None, group=None):
+    """Polish one contig cut into world_size reference intervals, one per rank (one process per GPU).
+
+    Every rank holds the contig's host pileup (or at least its own shard's reads) and uploads only its shard.  Per
+    phasing pass the ranks all-gather their votes (pair counts of the HETE regions they own, per-read vote records —
+    a few MB per Mb of diploid contig) and each runs the contig-wide decision on the merged votes (host only,
+    deterministic: no broadcast needed); the removed reads are applied to every shard.  The polished pieces are
+    all-gathered (RCCL over xGMI with backend nccl) and stitched; every rank returns the whole contig's (bases, pos)."""
+    from .api import ShardRun, Vote, shard_plan, vote_decide
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    plans = shard_plan(pileup, world, halo)
+    run = ShardRun(polisher, pileup, plans[rank], opts, verify)
+    try:
+        while run.passes_left() > 1:
+            raws = all_gather_bytes(run.vote().to_bytes(), device=device, group=group)
+            losers = vote_decide([Vote.from_bytes(x) for x in raws], pileup.n_reads, opts)
+            run.apply(losers)
+        b, p = run.final()
+    finally:
+        run.close()
+    hdr = np.array([len(b)], dtype=np.uint64).tobytes()
+    raws = all_gather_bytes(hdr + np.asarray(b).tobytes() + np.asarray(p).tobytes(), device=device, group=group)
+    pieces = []
+    for x in raws:
+        n = int(np.frombuffer(x[:8], dtype=np.uint64)[0])
+        pieces.append((np.frombuffer(x[8:8 + n], dtype=np.uint8), np.frombuffer(x[8 + n:8 + 5 * n], dtype=np.uint32)))
+    return stitch_shards(pieces, plans, verify)
+
+
 class _DeviceBytes:
     """Zero-copy view of `n` bytes at device address `ptr` for torch.as_tensor (array-interface protocol)."""
 

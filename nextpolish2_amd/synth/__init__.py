@@ -122,6 +122,42 @@ class Synth:
             pass
 
 
+def concat_pileups(parts, name="ctg"):
+    """One contig out of several generated pieces laid end to end (reads never span a joint; coverage tapers to the
+    contig's own base there).  Lets a chromosome-sized contig be generated on many host threads."""
+    L = sum(p.L for p in parts)
+    ref = np.concatenate([p.ref for p in parts])
+    # slot 0: the whole contig aligned to itself
+    codes = np.full(256, 4, dtype=np.uint8)
+    for ch, c in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"TtUu", 3), (b"Nn", 5), (b"Mm", 6)):
+        for x in ch:
+            codes[x] = c
+    cod = codes[ref]
+    if L & 1:
+        cod = np.concatenate([cod, np.array([15], dtype=np.uint8)])
+        packed = (cod[0::2] << 4) | cod[1::2]
+    else:
+        packed = np.concatenate([(cod[0::2] << 4) | cod[1::2], np.array([0xFF], dtype=np.uint8)])
+    slot0 = ((len(packed) + 1 + 15) // 16) * 16
+    chunks = [packed, np.zeros(slot0 - len(packed), dtype=np.uint8)]
+    reads = [np.array([(0, L - 1, 0, L, 0)], dtype=READ_DTYPE)]
+    off, pos0 = slot0, 0
+    for p in parts:
+        r = p.reads[1:].copy()
+        first = int(p.reads["nib_off"][1]) if len(r) else 0
+        r["aln_t_s"] += pos0
+        r["aln_t_e"] += pos0
+        r["nib_off"] = r["nib_off"] - first + off
+        reads.append(r)
+        body = p.nibbles[first:]
+        pad = (-len(body)) % 16
+        chunks += [body, np.zeros(pad, dtype=np.uint8)]
+        off += len(body) + pad
+        pos0 += p.L
+    chunks.append(np.zeros(64, dtype=np.uint8))
+    return Pileup(ref, np.concatenate(reads), np.concatenate(chunks), name=name)
+
+
 def pack_alignment(t_aln, q_aln, aln_t_s):
     """AlignSeq::new (src/main.rs:279-312) for explicit gapped strings -> (bytes, aln_t_e, n_cols)."""
     assert len(t_aln) == len(q_aln)

@@ -1,0 +1,135 @@
+"""Host-side pieces of the reference-interval sharding (no GPU): the shard plan, the merge + decision of the shards'
+votes (np2_vote_decide), and the world-size-2 exchange (gloo) replayed from a fixture recorded on a GPU box."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nextpolish2_amd import Opts
+from nextpolish2_amd._types import np2_shard_plan_t
+from nextpolish2_amd.api import Vote, phase_vote, shard_plan, vote_decide
+from nextpolish2_amd.dist import all_gather_bytes, stitch_shards
+from nextpolish2_amd.synth import Synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "golden", "shard_votes.npz")
+
+
+def test_shard_plan_covers_the_contig_and_holds_whole_reads():
+    s = Synth(300000, seed=861, read_len_mean=9000.0, read_len_sd=1500.0)
+    rd = s.pileup.reads
+    for n, halo in ((1, 1000), (2, 30000), (5, 8000)):
+        plans = shard_plan(s.pileup, n, halo)
+        assert plans[0].own_lo == 0 and plans[-1].own_hi == s.pileup.L
+        for a, b in zip(plans, plans[1:]):
+            assert a.own_hi == b.own_lo and a.own_hi % 1024 == 0
+        for pl in plans:
+            assert pl.sub_lo <= pl.zone_lo <= pl.own_lo < pl.own_hi <= pl.zone_hi <= pl.sub_hi <= s.pileup.L
+            assert pl.zone_lo == max(0, pl.own_lo - halo) and pl.zone_hi == min(s.pileup.L, pl.own_hi + halo)
+            inside = [r for r in range(1, len(rd)) if rd["aln_t_e"][r] >= pl.zone_lo and rd["aln_t_s"][r] < pl.zone_hi]
+            assert inside and pl.read_lo == min(inside) and pl.read_hi == max(inside) + 1
+            assert all(rd["aln_t_s"][r] >= pl.sub_lo and rd["aln_t_e"][r] < pl.sub_hi for r in inside)
+
+
+def _random_votes(rng, n_reads, n_pairs):
+    """One contig's votes as the unsharded pass would produce them, and the same split over two shards."""
+    reads = np.sort(rng.choice(np.arange(1, n_reads), size=min(n_reads - 1, 40), replace=False)).astype(np.uint32)
+    pairs = {}
+    while len(pairs) < n_pairs:
+        a, b = sorted(rng.choice(reads, size=2, replace=False).tolist())
+        pairs[(a, b)] = (int(rng.integers(0, 4)), int(rng.integers(0, 5)))  # agreeing / disagreeing regions
+    pairs = {k: v for k, v in pairs.items() if v != (0, 0)}
+    first = {int(r): int(rng.integers(100, 100000)) for r in reads}
+    refw = {int(r): int(rng.integers(-3, 4)) for r in reads if rng.random() < 0.5}
+    bad = {int(r) for r in reads if rng.random() < 0.1}
+    return reads, pairs, first, refw, bad
+
+
+def _vote(reads, pairs, first, refw, bad, seen):
+    keys = sorted(pairs)
+    rid = sorted(set(reads))
+    return Vote(pair_key=np.array([(a << 32) | b for a, b in keys], dtype=np.uint64),
+                pair_cnt=np.array([pairs[k][0] | (pairs[k][1] << 16) for k in keys], dtype=np.uint32),
+                read_id=np.array(rid, dtype=np.uint32),
+                first_pos=np.array([first.get(r, 0xFFFFFFFF) for r in rid], dtype=np.uint32),
+                ref_w=np.array([refw.get(r, 0) for r in rid], dtype=np.int32),
+                flags=np.array([(1 if r in first else 0) | (2 if r in seen else 0) | (4 if r in bad else 0) for r in rid], dtype=np.uint8))
+
+
+def test_vote_decide_merges_shards_and_matches_the_single_graph_vote():
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        n_reads = 60
+        reads, pairs, first, refw, bad = _random_votes(rng, n_reads, 70)
+        voters = {r for ab in pairs for r in ab}
+        first = {r: p for r, p in first.items() if r in voters}
+        whole = vote_decide([_vote(reads.tolist(), pairs, first, refw, bad, set(refw))], n_reads, Opts())
+        # the same votes split over two shards: every pair's regions are dealt out, each read's first region is the
+        # rightmost one over the shards, ref weights add up
+        pa, pb = {}, {}
+        for k, (sm, ng) in pairs.items():
+            s1, n1 = int(rng.integers(0, sm + 1)), int(rng.integers(0, ng + 1))
+            if (s1, n1) != (0, 0):
+                pa[k] = (s1, n1)
+            if (sm - s1, ng - n1) != (0, 0):
+                pb[k] = (sm - s1, ng - n1)
+        fa = {r: p for r, p in first.items() if rng.random() < 0.6}
+        fb = {r: (p if r not in fa else int(rng.integers(1, p + 1))) for r, p in first.items() if r not in fa or rng.random() < 0.5}
+        ra = {r: int(rng.integers(-2, 3)) for r in refw}
+        rb = {r: refw[r] - ra[r] for r in refw}
+        ba = {r for r in bad if rng.random() < 0.5}
+        both = vote_decide([_vote(reads.tolist(), pa, fa, ra, ba, set(ra)), _vote(reads.tolist(), pb, fb, rb, bad - ba, set(rb))],
+                           n_reads, Opts())
+        assert np.array_equal(whole, both)
+        # ... and the merged decision is the one the host-only graph vote gives on the explicit weights
+        keys = [r for _, r in sorted((-first[r], r) for r in first)]
+        w = lambda sm, ng: float(-ng if ng >= 3 else sm - ng)  # noqa: E731  (main.rs:996-1002)
+        edges = [(a, b, w(*pairs[(a, b)])) for (a, b) in sorted(pairs)]
+        keep = [k for k in keys if k not in bad]
+        edges = [(a, b, x) for a, b, x in edges if a not in bad and b not in bad]
+        ref = {r: float(x) for r, x in refw.items()}
+        exp = sorted(set(phase_vote(keep, edges, ref if ref else None)) | bad)
+        assert whole.tolist() == exp
+
+
+def _rank(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = np.load(FIX)
+        plans = [np2_shard_plan_t(*[int(x) for x in row]) for row in fx["plans"]]
+        # what this rank's shard produced on the GPU (recorded): its votes, then its piece of the consensus
+        raws = all_gather_bytes(fx[f"vote{rank}"].tobytes(), device=torch.device("cpu"))
+        losers = vote_decide([Vote.from_bytes(x) for x in raws], int(fx["n_reads"][0]), Opts())
+        ok = np.array_equal(losers, fx["losers"]) and len(losers) > 0
+        b, p = fx[f"piece{rank}_bases"], fx[f"piece{rank}_pos"]
+        raws = all_gather_bytes(np.array([len(b)], dtype=np.uint64).tobytes() + b.tobytes() + p.tobytes(), device=torch.device("cpu"))
+        pieces = []
+        for x in raws:
+            n = int(np.frombuffer(x[:8], dtype=np.uint64)[0])
+            pieces.append((np.frombuffer(x[8:8 + n], dtype=np.uint8), np.frombuffer(x[8 + n:8 + 5 * n], dtype=np.uint32)))
+        sb, sp = stitch_shards(pieces, plans, 1024)
+        ok = ok and np.array_equal(sb, fx["oracle_bases"]) and np.array_equal(sp, fx["oracle_pos"])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_of_recorded_shards_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,42 @@
+"""Helper of tests/test_gpu_shard.py: run under torchrun; every rank polishes its reference interval of one contig."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from nextpolish2_amd import Opts, Polisher  # noqa: E402
+from nextpolish2_amd.dist import polish_sharded  # noqa: E402
+from nextpolish2_amd.synth import Synth  # noqa: E402
+
+backend = os.environ.get("NP2_SHARD_BACKEND", "gloo")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+n_gpu = torch.cuda.device_count()
+dev_idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_gpu)
+if backend == "nccl":
+    torch.cuda.set_device(dev_idx)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
+    xdev = torch.device("cuda", dev_idx)
+else:
+    dist.init_process_group(backend="gloo")
+    xdev = torch.device("cpu")
+s = Synth(400000, seed=871, diploid=True)  # (same seed on every rank: every rank holds the contig's host pileup)
+yaks = [s.yak(21), s.yak(31)]
+pol = Polisher(yaks, device=dev_idx)
+b, p = polish_sharded(pol, s.pileup, Opts(), halo=40000, device=xdev)
+digest = torch.tensor([int(np.asarray(b, dtype=np.int64).sum()) + 7 * int(np.asarray(p, dtype=np.int64).sum()), len(b)], dtype=torch.int64, device=xdev)
+all_d = [torch.zeros_like(digest) for _ in range(world)]
+dist.all_gather(all_d, digest)
+if rank == 0:
+    from oracle.np2_oracle import Oracle
+    b0, p0 = pol.polish(s.pileup, Opts())
+    ob, op = Oracle(yaks).polish(s.pileup, Opts())
+    print(json.dumps({"world": world, "equal_single": bool(np.array_equal(b, b0) and np.array_equal(p, p0)),
+                      "equal_oracle": bool(np.array_equal(b, ob) and np.array_equal(p, op)),
+                      "ranks_agree": bool(all(torch.equal(d, all_d[0]) for d in all_d))}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
