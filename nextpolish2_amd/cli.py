@@ -62,7 +62,12 @@ def build_parser():
     p.add_argument("-c", "--max_clip_len", type=int, default=100)
     p.add_argument("-r", "--use_all_reads", action="store_true")
     p.add_argument("--min_base_cov", type=int, default=1, help=argparse.SUPPRESS)
-    p.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device index")
+    p.add_argument("--device", type=int, default=None, help="HIP device index [LOCAL_RANK, else 0]")
+    p.add_argument("--shard_min_len", type=int, default=32_000_000,
+                   help="under torchrun: contigs at least this long are cut into one reference interval per rank "
+                        "(shorter ones go to one rank each)")
+    p.add_argument("--shard_halo", type=int, default=65536, help="reads overlapping a rank's interval widened by this are held")
+    p.add_argument("--dist_backend", default=None, help="torch.distributed backend under torchrun [nccl]")
     p.add_argument("-V", "--version", action="version", version=VERSION)
     return p
 
@@ -73,6 +78,88 @@ def resource_str(t0, argv):
             f"CPU: {ru.ru_utime + ru.ru_stime:.3f} sec; Peak RSS: {ru.ru_maxrss / 1048576:.3f} GB")
 
 
+def _record(a, name, b, first, last, pos=None):
+    if a.uppercase:
+        b = b.upper()
+    if a.out_pos:
+        return b"".join(b"%s\t%c\t%d\n" % (name.encode(), b[i:i + 1], int(pos[i])) for i in range(len(b)))
+    return b">%s start:%d end:%d\n%s\n" % (name.encode(), first, last, b)
+
+
+def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
+    """One process per GPU (torchrun): the assembly is polished by all ranks and written by rank 0 in input order.
+
+    Contigs of at least --shard_min_len are cut into one reference interval per rank (np2_shard_*: votes all-gathered and
+    decided contig-wide per phasing pass, pieces all-gathered and stitched); the others go whole to one rank each,
+    longest first (the reference's unit of work, main.rs:1726-1837).  The only collectives are the small vote exchange
+    and the all-gather of polished sequences (RCCL over xGMI with the default backend)."""
+    import torch
+    import torch.distributed as dist
+
+    from .dist import ShardMismatch, all_gather_sequences, assign_contigs, polish_sharded
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = a.dist_backend or "nccl"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    n_gpu = torch.cuda.device_count()
+    dev_idx = a.device % max(1, n_gpu)
+    if backend == "nccl":
+        torch.cuda.set_device(dev_idx)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
+        xdev = torch.device("cuda", dev_idx)
+    else:
+        dist.init_process_group(backend=backend)
+        xdev = torch.device("cpu")
+    pol = Polisher(yaks, device=dev_idx)
+    bam = np2io.Bam(a.bam)
+    contigs = list(np2io.read_fasta(a.fa))  # every rank reads the assembly (cheap next to the BAM)
+    records = {}
+    long_ones = [i for i, (_, seq) in enumerate(contigs) if len(seq) >= max(a.min_ctg_len, a.shard_min_len)]
+    whole = [i for i, (_, seq) in enumerate(contigs) if len(seq) >= a.min_ctg_len and i not in set(long_ones)]
+    # 1. long contigs: one reference interval per rank
+    for i in long_ones:
+        name, seq = contigs[i]
+        if len(seq) >= 0xFFFFFFFF:
+            raise SystemExit(f"{name} is too long!")
+        c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+        pu = np2io.export_contig(pol, c, seq)  # (every rank builds the contig's pileup; it keeps only its shard in HBM)
+        c.free()
+        try:
+            b, p = polish_sharded(pol, pu, opts, halo=a.shard_halo, device=xdev)
+        except ShardMismatch:  # (the same on every rank: the pieces are all-gathered before the check) -> unsharded
+            b, p = pol.polish(pu, opts)
+        if rank == 0:
+            records[i] = _record(a, name, np.asarray(b).tobytes(), int(p[0]), int(p[-1]), p)
+    # 2. the other contigs: whole, one rank each, longest first
+    mine = assign_contigs([len(contigs[i][1]) for i in whole], world)[rank]
+    local = []
+    for k in mine:
+        i = whole[k]
+        name, seq = contigs[i]
+        c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+        try:
+            bases, pos = pol.polish_resident(c, opts, want_pos=a.out_pos)
+        finally:
+            c.free()
+        b = bases.tobytes()
+        local.append((i, _record(a, name, b, *( (int(pos[0]), int(pos[-1]), pos) if a.out_pos else (pos[0], pos[1], None)))))
+    got = all_gather_sequences(local, device=xdev)
+    if rank == 0:
+        records.update(got)
+        for i, (name, seq) in enumerate(contigs):
+            if i in records:
+                out.write(records[i])
+            else:  # pass-through (main.rs:1727-1730)
+                s_ = seq.upper() if a.uppercase else seq
+                out.write(_record(a, name, s_, 0, len(seq) - 1, range(len(seq))))
+        out.flush()
+        if out is not sys.stdout.buffer:
+            out.close()
+        print(resource_str(t0, ["nextPolish2"] + argv), file=sys.stderr)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     t0 = time.time()
@@ -80,7 +167,9 @@ def main(argv=None):
     if a.model.lower() not in ("ref", "len"):
         raise SystemExit("error: invalid value for --model (ref|len)")
     out = sys.stdout.buffer
-    if a.out is not None and a.out != "stdout":  # option.rs:76-79: the literal default "stdout" means stdout
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("RANK", "0") != "0":
+        out = None  # under torchrun only rank 0 writes
+    elif a.out is not None and a.out != "stdout":  # option.rs:76-79: the literal default "stdout" means stdout
         path = os.path.abspath(a.out)
         if os.path.exists(path):  # option.rs:312-316: refuse to overwrite
             raise SystemExit(f"Error: {path!r} already exists!")
@@ -96,6 +185,11 @@ def main(argv=None):
                             use_secondary=a.use_secondary)
     n_workers = max(1, min(4, a.thread))
     tls = threading.local()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.device is None:
+        a.device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if world > 1 and "RANK" in os.environ:
+        return _main_distributed(a, argv, t0, out, yaks, opts, fopts)
 
     def polish(name, seq):
         """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
@@ -138,7 +232,7 @@ def main(argv=None):
             drain(0)
         out.flush()
     finally:
-        if out is not sys.stdout.buffer:
+        if out is not None and out is not sys.stdout.buffer:
             out.close()
     print(resource_str(t0, ["nextPolish2"] + argv), file=sys.stderr)
     return 0

@@ -118,3 +118,33 @@ def test_pair_votes_outside_the_band_take_the_sort_path(monkeypatch):
     assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
     ob2, op2 = orc.Oracle(yd).polish(d.pileup, Opts())
     assert np.array_equal(ob2, b1) and np.array_equal(op2, p1)
+
+
+def test_full_size_yeast_assembly_through_the_batch_driver():
+    """BASELINE.json configs[2] at full size (17 contigs, 12.16 Mb diploid, 30x, k21 + k31, phasing on): the batch
+    driver's output per contig equals the one-contig-at-a-time path, is identical on a second run, recovers the
+    haplotype of record on (nearly) every contig, and reads really were voted out."""
+    from bench import YEAST, make_assembly
+    syn = make_assembly(YEAST, 30, 1, True)
+    yaks = [Synth.yak_assembly(syn, 21), Synth.yak_assembly(syn, 31)]
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in syn]
+    bp = BatchPolisher(pol, len(contigs))
+    out1 = bp.polish(contigs, Opts(), want_pos=True)
+    out2 = bp.polish(contigs, Opts(), want_pos=True)
+    n_truth = 0
+    for s, c, (b, p), (b2, p2) in zip(syn, contigs, out1, out2):
+        assert np.array_equal(b, b2) and np.array_equal(p, p2)
+        assert np.all(p[1:] >= p[:-1])
+        sb, sp = pol.polish_resident(c, Opts())
+        assert np.array_equal(b, sb) and np.array_equal(p, sp)
+        n_truth += b.tobytes() == s.hap1
+        assert b.tobytes() != s.pileup.ref.tobytes()
+    assert n_truth >= 15  # (polishing recovers hap1 exactly unless a contig keeps an ambiguous site)
+    # the largest contig against the oracle, with the reads the vote removed
+    big = max(range(len(syn)), key=lambda i: syn[i].pileup.L)
+    o = orc.Oracle(yaks)
+    o.set_trace(True)
+    ob, op = o.polish(syn[big].pileup, Opts())
+    assert np.array_equal(ob, out1[big][0]) and np.array_equal(op, out1[big][1])
+    assert len(o.trace(0, "invalid_ids")) > 1000

@@ -107,3 +107,66 @@ def test_two_ranks_polish_the_halves_of_one_contig():
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out == {"world": 2, "equal_single": True, "equal_oracle": True, "ranks_agree": True}
+
+
+def test_cli_under_torchrun_shards_long_contigs_and_spreads_the_others(tmp_path):
+    """nextPolish2 with two ranks (gloo, both on this box's GPU): the long contig is cut into two reference intervals, the
+    others go whole to one rank each, rank 0 writes one FASTA in input order == the one-process CLI's output."""
+    import gzip
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import pileup_to_records, write_bam
+    ss = [Synth(260000, depth=20, seed=891, diploid=True, read_len_mean=7000.0, read_len_sd=900.0, name="long1"),
+          Synth(50000, depth=20, seed=892, read_len_mean=5000.0, read_len_sd=700.0, name="ctgB"),
+          Synth(40000, depth=20, seed=893, diploid=True, read_len_mean=5000.0, read_len_sd=700.0, name="ctgC")]
+    recs = []
+    for tid, s in enumerate(ss):
+        recs += pileup_to_records(s.pileup, tid=tid, rng=np.random.default_rng(tid), decorate=True)
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    write_bam(str(tmp_path / "m.bam"), [(s.pileup.name, s.pileup.L) for s in ss] + [("tiny", 500)], recs)
+    with gzip.open(tmp_path / "g.fa.gz", "wt") as f:
+        for s in ss:
+            f.write(f">{s.pileup.name}\n{s.pileup.ref.tobytes().decode()}\n")
+        f.write(">tiny\nACGTACGTNNacgt\n")
+    for k in (21, 31):
+        np2io.write_yak(str(tmp_path / f"k{k}.yak"), Synth.yak_assembly(ss, k))
+    args = ["-L", "10000", str(tmp_path / "m.bam"), str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak"), str(tmp_path / "k31.yak")]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-o", str(tmp_path / "one.fa")] + args,
+                       capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "nextpolish2_amd.cli",
+                        "--dist_backend", "gloo", "--device", "0", "--shard_min_len", "200000", "--shard_halo", "30000",
+                        "-o", str(tmp_path / "two.fa")] + args, capture_output=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    one, two = (tmp_path / "one.fa").read_bytes(), (tmp_path / "two.fa").read_bytes()
+    assert one == two and one.count(b">") == 4
+
+
+def test_full_size_chr1_single_gpu_and_two_intervals():
+    """BASELINE.json configs[3] workload (human chr1-sized contig: 248 Mb, 30x HiFi, k21 + k31) on ONE GPU, through
+    size-independent properties: the polished sequence equals the simulated truth, positions never decrease, a second
+    call is identical, and the contig cut into two reference intervals (the 2-GPU layout, run here one after the other)
+    stitches to the byte-identical result.  The contig is generated as 16 pieces laid end to end (host threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_parts, L = 16, 248_000_000
+    with ThreadPoolExecutor(n_parts) as ex:
+        parts = list(ex.map(lambda i: Synth(L // n_parts, depth=30, seed=500 + i), range(n_parts)))
+    pu = concat_pileups([p.pileup for p in parts], "chr1")
+    yaks = [Synth.yak_assembly(parts, k) for k in (21, 31)]
+    truth = b"".join(p.hap1 for p in parts)
+    assert pu.ref.tobytes() != truth and pu.L > 247_000_000
+    pol = Polisher(yaks)
+    c = pol.upload(pu)
+    b1, p1 = pol.polish_resident(c, Opts())
+    assert b1.tobytes() == truth
+    assert np.all(p1[1:] >= p1[:-1]) and int(p1[0]) == 0 and int(p1[-1]) == pu.L - 1
+    b2, _ = pol.polish_resident(c, Opts(), want_pos=False)
+    assert np.array_equal(b1, b2)
+    c.free()
+    b3, p3 = polish_sharded_local(pol, pu, Opts(), n_shards=2)
+    assert np.array_equal(b1, b3) and np.array_equal(p1, p3)
