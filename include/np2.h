@@ -214,6 +214,10 @@ int np2_shard_apply(np2_shard_run_t *run, const uint32_t *losers, uint32_t n_los
 int np2_shard_final(np2_shard_run_t *run, uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
 void np2_shard_end(np2_shard_run_t *run);
 
+/* Host-only test hook: key iteration order of the SwissTable order model behind np2_phase_vote after a script of
+ * operations (0 insert, 1 remove, 2 entry().or_insert) — pinned by hand-traced vectors in tests/test_swiss_vectors.py. */
+int np2_swiss_order(const uint32_t *ops, const uint32_t *keys, uint32_t n, uint32_t *out, uint32_t *n_out);
+
 /* Per-stage device timings of the last np2_polish_resident (HIP events on the ctx stream).
  * names: NUL-separated list terminated by an empty string; ms[i] matches names[i].
  * By default only the dense pass ("diff_reads") is timed; np2_ctx_set_timing(ctx, 1) arms every stage timer

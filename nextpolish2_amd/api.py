@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
-    "np2_shard_end", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
+    "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
@@ -93,6 +93,7 @@ def lib():
         L.np2_shard_final.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.np2_shard_end.argtypes = [vp]
         L.np2_shard_end.restype = None
+        L.np2_swiss_order.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
         L.np2_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         _LIB = L
     return _LIB
@@ -491,6 +492,18 @@ def fasta_record(name, bases, pos):
     """display_consensusbase_vec (src/main.rs:607-645): '>{name} start:{first} end:{last}\\n{seq}\\n'."""
     return b">%s start:%d end:%d\n%s\n" % (name.encode() if isinstance(name, str) else name, int(pos[0]), int(pos[-1]),
                                            bytes(bases))
+
+
+def swiss_order(script):
+    """np2_swiss_order: iteration order of the product's SwissTable order model after [(op, key)] (0 insert, 1 remove,
+    2 entry)."""
+    ops = np.array([o for o, _ in script], dtype=np.uint32)
+    keys = np.array([k for _, k in script], dtype=np.uint32)
+    out = np.zeros(max(1, len(script)), dtype=np.uint32)
+    n = C.c_uint32()
+    if lib().np2_swiss_order(ops.ctypes.data, keys.ctypes.data, len(script), out.ctypes.data, C.byref(n)) != 0:
+        raise Np2Error(-1, "np2_swiss_order")
+    return out[: n.value].tolist()
 
 
 def phase_vote(keys, pairs, ref=None):

@@ -1435,6 +1435,25 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
     return NP2_OK;
 }
 
+// host-only test hook: iteration order of the product's SwissTable order model (np2_phase_host.hpp) after a script of
+// op 0 = insert(key), 1 = remove(key), 2 = entry(key).or_insert — checked against hand-traced vectors
+int np2_swiss_order(const uint32_t *ops, const uint32_t *keys, uint32_t n, uint32_t *out, uint32_t *n_out) {
+    if (!ops || !keys || !out || !n_out) return NP2_E_ARG;
+    phase::SwissOrderMap<int> m;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ops[i] == 0)
+            m.put(keys[i], 0);
+        else if (ops[i] == 1)
+            m.take(keys[i], nullptr);
+        else if (!m.has(keys[i]))
+            m.put_vacant(keys[i], 0);
+    }
+    uint32_t c = 0;
+    m.each([&](uint32_t k, const int &) { out[c++] = k; });
+    *n_out = c;
+    return NP2_OK;
+}
+
 int np2_trace_get(np2_ctx_t *cx, int pass, const char *name, const void **data, uint64_t *nbytes) {
     if (!cx) return NP2_E_ARG;
     auto it = cx->trace_items.find(std::to_string(pass) + ":" + name);

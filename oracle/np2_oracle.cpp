@@ -1484,6 +1484,24 @@ int np2o_lookup_hashes(void *c, int yak_idx, const uint64_t *hashes, uint64_t n,
 }
 uint64_t np2o_yak_hash64(uint64_t key, uint32_t k) { return yak_hash64(key, (1ULL << (2 * (uint64_t)k)) - 1); }
 
+// SwissTable script for the hand-traced order vectors (tests/test_swiss_vectors.py): op 0 = HashMap::insert(key),
+// 1 = remove(key), 2 = entry(key).or_insert (reserve(1) first when vacant); returns the keys in iteration order
+int np2o_swiss_order(const uint32_t *ops, const uint32_t *keys, uint32_t n, uint32_t *out, uint32_t *n_out) {
+    hb::FxMap<int> m;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ops[i] == 0)
+            m.insert(keys[i], 0);
+        else if (ops[i] == 1)
+            m.remove(keys[i]);
+        else if (!m.contains(keys[i]))
+            m.entry_insert_vacant(keys[i], 0);
+    }
+    uint32_t c = 0;
+    m.for_each([&](uint32_t k, const int &) { out[c++] = k; });
+    *n_out = c;
+    return 0;
+}
+
 // Louvain entry for unit tests: edges (a,b,w) applied with insert_data in order, optional ref row
 int np2o_phase_communities(const uint32_t *ea, const uint32_t *eb, const float *ew, uint64_t n_edges,
                            const uint32_t *ref_ids, const float *ref_w, uint64_t n_ref, int has_ref,

@@ -29,6 +29,7 @@ def lib():
         L.np2o_ctx_create.restype = C.c_void_p
         L.np2o_ctx_create.argtypes = [C.POINTER(np2_yak_t), C.c_int]
         L.np2o_ctx_destroy.argtypes = [C.c_void_p]
+        L.np2o_swiss_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
         L.np2o_ctx_clone.restype = C.c_void_p
         L.np2o_ctx_clone.argtypes = [C.c_void_p, C.c_uint16]
         L.np2o_last_error.restype = C.c_char_p
@@ -154,6 +155,16 @@ class Oracle:
         rc = lib().np2o_lookup_hashes(self._h, yak_idx, h.ctypes.data, h.shape[0], min_kmer_count, out.ctypes.data)
         assert rc == 0
         return out
+
+
+def swiss_order(script):
+    """Iteration order of the oracle's hashbrown emulation after a script [(op, key)]: 0 insert, 1 remove, 2 entry."""
+    ops = np.array([o for o, _ in script], dtype=np.uint32)
+    keys = np.array([k for _, k in script], dtype=np.uint32)
+    out = np.zeros(max(1, len(script)), dtype=np.uint32)
+    n = C.c_uint32()
+    lib().np2o_swiss_order(ops.ctypes.data, keys.ctypes.data, len(script), out.ctypes.data, C.byref(n))
+    return out[: n.value].tolist()
 
 
 def yak_hash64(kmer, k):

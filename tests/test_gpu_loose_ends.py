@@ -1,0 +1,121 @@
+"""Round-2 parity loose ends: --out_pos (main.rs:613-625), the f32 split of -a (option.rs:232,258-259), the documented
+refusal of a negative best score at the contig end (main.rs:1651,1680), and a multi-context soak."""
+import gzip
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from nextpolish2_amd import Opts, Polisher
+from nextpolish2_amd import io as np2io
+from nextpolish2_amd.api import Np2Error
+from nextpolish2_amd.bamio import pileup_to_records, records_to_arrays, write_bam
+from nextpolish2_amd.cli import split_map_len
+from nextpolish2_amd.synth import Synth, pileup_from_alignments
+from oracle import np2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bundle(tmp_path, s, name="ctgA"):
+    recs = pileup_to_records(s.pileup, tid=0, rng=np.random.default_rng(3), decorate=True)
+    write_bam(str(tmp_path / "m.bam"), [(name, s.pileup.L)], recs)
+    with gzip.open(tmp_path / "g.fa.gz", "wt") as f:
+        f.write(f">{name} some description\n{s.pileup.ref.tobytes().decode()}\n>tiny\nacgtNN\n")
+    np2io.write_yak(str(tmp_path / "k21.yak"), s.yak(21))
+    return recs
+
+
+def test_out_pos_table_matches_the_oracle(tmp_path):
+    s = Synth(40000, depth=20, seed=901, diploid=True, read_len_mean=5000.0, read_len_sd=700.0)
+    recs = _bundle(tmp_path, s)
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pu = orc.front_end(s.pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts())
+    b, p = orc.Oracle([s.yak(21)]).polish(pu, Opts())
+    exp = b"".join(b"ctgA\t%c\t%d\n" % (bytes([x]), int(q)) for x, q in zip(b, p))
+    exp += b"".join(b"tiny\t%c\t%d\n" % (bytes([x]), i) for i, x in enumerate(b"ACGTNN"))  # -u upper-cases pass-through
+    r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "--out_pos", "-u", "-L", "10000", str(tmp_path / "m.bam"),
+                        str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak")], capture_output=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT), timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == exp
+    assert len(set(p.tolist())) < len(p) or np.all(np.diff(p.astype(np.int64)) >= 0)
+
+
+def test_min_map_len_is_split_in_single_precision(tmp_path):
+    # option.rs:232 parses -a as f32: 500.3 -> (500, 0.29998779...), so (rlen as f32 * fra) as i64 = 2999 for rlen 10000
+    # where double precision would give 3000 (2999.99... vs 3000.0000001)
+    ml, fra = split_map_len("500.3")
+    assert ml == 500 and abs(fra - 0.29998779296875) < 1e-12
+    assert int(np.float32(10000) * np.float32(fra)) == 2999
+    assert split_map_len("500.5") == (500, 0.5) and split_map_len("1000") == (1000, 0.0)
+    # a read whose reference span sits exactly between the two thresholds is admitted with the f32 fraction, like the
+    # oracle front end given the same f32 value, and would be rejected with 0.3
+    s = Synth(30000, depth=12, seed=902, read_len_mean=10000.0, read_len_sd=1.0, read_len_min=9990)
+    recs = pileup_to_records(s.pileup, tid=0, rng=np.random.default_rng(1), decorate=False)
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pol = Polisher([s.yak(21)])
+    for frac in (fra, 0.3, 0.29):
+        fo = np2io.FrontOpts(min_map_len=ml, min_map_fra=frac)
+        pu = orc.front_end(s.pileup.ref.tobytes(), arr, cig, asc, asc_off, fo)
+        c = np2io.contig_from_records(pol, s.pileup.ref.tobytes(), arr, cig, seq4, fo)
+        ex = np2io.export_contig(pol, c, s.pileup.ref.tobytes())
+        assert np.array_equal(ex.reads, pu.reads)
+        c.free()
+
+
+def test_negative_best_score_at_the_contig_end_is_refused():
+    """DESIGN.md deviation: if no node at the last position reaches score >= 0 the reference backtracks from its default
+    node (main.rs:1651,1680: a spurious 'A', then node 0 of position L-2); the oracle follows it, the product returns
+    NP2_E_UNSUPPORTED instead of emitting that artefact.  Needs a pileup whose best path has < 40 % support everywhere."""
+    rng = np.random.default_rng(7)
+    L = 600
+    ref = "".join(rng.choice(list("ACGT"), L))
+    alns = []
+    for k in range(3):  # three full-length reads that disagree with the contig and with each other at every column
+        q = "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] for c in ref)
+        alns.append((0, ref, q))
+    pu = pileup_from_alignments(ref, alns)
+    y = Synth(2000, seed=3).yak(21)
+    ob, op = orc.Oracle([y]).polish(pu, Opts(iter_count=1))
+    assert len(ob) > 0 and chr(ob[-1]) == "A"  # the reference's artefact, restated by the oracle
+    with pytest.raises(Np2Error) as e:
+        Polisher([y]).polish(pu, Opts(iter_count=1))
+    assert e.value.code == -4 and "negative" in str(e.value)
+
+
+def test_soak_contexts_and_batches_share_one_gpu():
+    """Four host threads, each with its own context (k_diff_reads spins on status words of other waves of ITS launch:
+    interleaved launches of several contexts must not disturb that), plus a batch group, for a few hundred polishes."""
+    from nextpolish2_amd import BatchPolisher
+    ss = [Synth(60000 + 7000 * i, depth=25, seed=910 + i, diploid=bool(i & 1), read_len_mean=6000.0, read_len_sd=900.0)
+          for i in range(4)]
+    yaks = [Synth.yak_assembly(ss, 21)]
+    pol = Polisher(yaks)
+    ref = [pol.polish(s.pileup, Opts())[0].tobytes() for s in ss]
+    bad = []
+
+    def worker(w):
+        p = pol.clone()
+        c = p.upload(ss[w].pileup)
+        for _ in range(60):
+            if p.polish_resident(c, Opts(), want_pos=False)[0].tobytes() != ref[w]:
+                bad.append(w)
+        c.free()
+
+    def batch():
+        bp = BatchPolisher(pol, 4)
+        cs = [pol.upload(s.pileup) for s in ss]
+        for _ in range(30):
+            out = bp.polish(cs, Opts())
+            if [o[0].tobytes() for o in out] != ref:
+                bad.append("batch")
+        bp.close()
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(4)] + [threading.Thread(target=batch)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad
