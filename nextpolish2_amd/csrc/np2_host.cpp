@@ -199,10 +199,9 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
             cx->band.ensure(band_words + 4);
             cx->band_n.ensure((size_t)R + 2);
             cx->band_off.ensure((size_t)R + 2);
-            op_fill(cx, cx->band.p, 0, band_words * 4);
             op_fill(cx, cx->scal.p + S_M3, 0, 4);
-            launch_edges_band(s, rt, cx->grp.p, cx->ecount.p, cx->band.p, cx->scal.p + S_M3);
-            launch_band_count(s, cx->band.p, R, cx->band_n.p);
+            launch_edges_row(s, rt, cx->grp.p, cx->ecount.p, cx->pj.p, cx->pcount.p, cx->alive.p, R, cx->band.p, cx->band_n.p,
+                             cx->scal.p + S_M3);
             exclusive_total_n(cx, cx->band_n.p, cx->band_off.p, R);
             // (at most one distinct pair per raw vote: NE bounds the output)
             cx->ekey.ensure((size_t)NE + 2);

@@ -198,9 +198,9 @@ void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *re
                         const uint32_t *ecount, const uint32_t *eoff, uint64_t *ekey, uint32_t *eval);
 // banded pair accumulator (np2_regions.hip): EDGE_BAND partners per read, 256 = one uint4 per lane of a wavefront
 static constexpr uint32_t EDGE_BAND = 256;
-void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, uint32_t *band,
-                       uint32_t *ovf);
-void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n);
+// pj / pcount: the region interval every read spans (candidate extraction); rows of reads without partners stay unwritten
+void launch_edges_row(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, const uint32_t *pj,
+                      const uint32_t *pcount, const uint8_t *alive, uint32_t R, uint32_t *band, uint32_t *row_n, uint32_t *ovf);
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out);
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, uint32_t *wout);

@@ -236,46 +236,59 @@ __device__ __forceinline__ void k_edges_write(const uint32_t np2_bid, const uint
 // ~0.1 M distinct pairs, so accumulating in place replaces a 64-bit radix sort of the raw votes; the rows, read in
 // order, ARE the sorted unique pair list.  Pairs further apart than the band bump *ovf: the host then takes the
 // sort-based path below for the whole contig (deep pileups).
-__device__ __forceinline__ void k_edges_band(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ grp,
-                                             const uint32_t *__restrict__ ecount, uint32_t *__restrict__ band,
-                                             uint32_t *__restrict__ ovf) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
-    if (g >= rt.n_reg || ecount[g] == 0) return;
-    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
-    uint32_t order = 0xFFFFFFFFu, gi = 0;
-    bool v = false;
-    if (lane < n) {
-        order = rt.order[c0 + lane];
-        gi = grp[c0 + lane];
-        v = rt.kscore[c0 + lane] > 0;
-    }
-    uint64_t V = __ballot(v);
-    if ((V & 1ull) && __shfl(order, 0) == 0) V &= ~1ull;
-    const bool mine = (V >> lane) & 1ull;
+// One wavefront per read a: walk the HETE regions the read spans ([pj, pj + pcount) of the region list, from candidate
+// extraction), and for every region in which a is a valid candidate add one vote per valid partner b > a to an LDS row
+// (256 partners = 1 KiB; a region's partners are distinct, so a wave-wide ds_add never collides).  No global atomics:
+// the ~3 M raw pair votes per Mb of a diploid contig stay on chip, the finished row is written once, together with
+// its number of distinct partners.  Pairs further apart than the band bump *ovf (the host then sorts raw votes).
+__device__ __forceinline__ void k_edges_row(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ grp,
+                                            const uint32_t *__restrict__ ecount, const uint32_t *__restrict__ pj,
+                                            const uint32_t *__restrict__ pcount, const uint8_t *__restrict__ alive, uint32_t R,
+                                            uint32_t *__restrict__ band, uint32_t *__restrict__ row_n, uint32_t *__restrict__ ovf) {
+    __shared__ uint32_t s_row[4][EDGE_BAND];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t a = np2_bid * 4 + wv;
+    if (a >= R) return;
+    uint32_t *row = s_row[wv];
+    *reinterpret_cast<uint4 *>(row + lane * 4) = make_uint4(0, 0, 0, 0);
     uint32_t far = 0;
-    for (uint32_t j = 1; j < n; ++j) { // (shuffles must be wave-uniform)
-        const uint32_t oj = __shfl(order, j), gj = __shfl(gi, j);
-        if (mine && j > lane && ((V >> j) & 1ull)) {
-            const uint32_t d = oj - order - 1;
-            if (d < EDGE_BAND)
-                atomicAdd(&band[(uint64_t)order * EDGE_BAND + d], gj == gi ? 1u : 0x10000u);
-            else
-                ++far;
+    const uint32_t n_span = (a != 0 && alive[a]) ? pcount[a] : 0u; // (the contig itself never enters a pair: main.rs:972-980)
+    const uint32_t j0 = n_span ? pj[a] : 0u;
+    for (uint32_t base = 0; base < n_span; base += 64) {
+        const uint32_t gl = j0 + base + lane;
+        uint64_t het = __ballot(base + lane < n_span && gl < rt.n_reg && ecount[gl] != 0);
+        while (het) {
+            const uint32_t g = j0 + base + (uint32_t)__builtin_ctzll(het); // (uniform)
+            het &= het - 1;
+            const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+            uint32_t order = 0xFFFFFFFFu, gi = 0;
+            bool v = false;
+            if (lane < n) {
+                order = rt.order[c0 + lane];
+                gi = grp[c0 + lane];
+                v = rt.kscore[c0 + lane] > 0;
+            }
+            uint64_t V = __ballot(v);
+            if ((V & 1ull) && __shfl(order, 0) == 0) V &= ~1ull;
+            const uint64_t me = __ballot(order == a) & V;
+            if (!me) continue; // a is not a (valid) candidate of this region
+            const uint32_t ga = __shfl(gi, (int)__builtin_ctzll(me));
+            if (((V >> lane) & 1ull) && order > a) {
+                const uint32_t d = order - a - 1;
+                if (d < EDGE_BAND)
+                    atomicAdd(&row[d], gi == ga ? 1u : 0x10000u);
+                else
+                    ++far;
+            }
         }
     }
-    if (far) atomicAdd(ovf, far);
-}
-// one wavefront per read: distinct partners in its band row
-__device__ __forceinline__ void k_band_count(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
-                                             uint32_t *__restrict__ row_n) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
-    if (a >= R) return;
-    const uint4 w = *reinterpret_cast<const uint4 *>(band + (uint64_t)a * EDGE_BAND + lane * 4);
+    const uint4 w = *reinterpret_cast<const uint4 *>(row + lane * 4); // (same lane wrote / the wave's ds_adds are done)
     uint32_t c = (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (c) *reinterpret_cast<uint4 *>(band + (uint64_t)a * EDGE_BAND + lane * 4) = w; // (rows without partners are never read)
     if (lane == 0) row_n[a] = c;
+    for (int o = 32; o > 0; o >>= 1) far += __shfl_xor(far, o);
+    if (far && lane == 0) atomicAdd(ovf, far);
 }
 // ... and their emission in (a, b) order: ukey = a << 32 | b, ucnt = agreeing regions | disagreeing regions << 16 (the
 // host turns the counts into the weight sum(w), or -(#-1) if #(-1) >= 3, main.rs:996-1002 — after merging shards)
@@ -876,12 +889,9 @@ void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *re
     if (rt.n_reg)
         NP2_LAUNCH(k_edges_write, g1((uint64_t)rt.n_reg * 64), 256, s, rt, reg_lable, grp, ecount, eoff, ekey, eval);
 }
-void launch_edges_band(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, uint32_t *band,
-                       uint32_t *ovf) {
-    if (rt.n_reg) NP2_LAUNCH(k_edges_band, g1((uint64_t)rt.n_reg * 64), 256, s, rt, grp, ecount, band, ovf);
-}
-void launch_band_count(hipStream_t s, const uint32_t *band, uint32_t R, uint32_t *row_n) {
-    if (R) NP2_LAUNCH(k_band_count, g1((uint64_t)R * 64), 256, s, band, R, row_n);
+void launch_edges_row(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, const uint32_t *pj,
+                      const uint32_t *pcount, const uint8_t *alive, uint32_t R, uint32_t *band, uint32_t *row_n, uint32_t *ovf) {
+    if (R) NP2_LAUNCH(k_edges_row, g1((uint64_t)R * 64), 256, s, rt, grp, ecount, pj, pcount, alive, R, band, row_n, ovf);
 }
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out) {

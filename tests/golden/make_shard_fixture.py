@@ -1,4 +1,4 @@
-"""Generates tests/golden/shard_votes.npz ON A GPU BOX (gpurun): what the two shards of a small diploid contig hand to
+"""Generates tests/golden/shards/shard_votes.npz ON A GPU BOX (gpurun): what the two shards of a small diploid contig hand to
 the exchange steps of nextpolish2_amd.dist.polish_sharded — their votes of the phasing pass, their final pieces —
 plus the oracle's result for the whole contig.  tests/test_shard_cpu.py replays the exchange (gloo, world 2) from it
 without a GPU.  usage: python tests/golden/make_shard_fixture.py <out.npz>"""

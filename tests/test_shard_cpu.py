@@ -15,7 +15,7 @@ from nextpolish2_amd.dist import all_gather_bytes, stitch_shards
 from nextpolish2_amd.synth import Synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIX = os.path.join(HERE, "golden", "shard_votes.npz")
+FIX = os.path.join(HERE, "golden", "shards", "shard_votes.npz")
 
 
 def test_shard_plan_covers_the_contig_and_holds_whole_reads():
