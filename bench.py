@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--workload", choices=["yeast", "ecoli"], default="yeast")
     ap.add_argument("--depth", type=int, default=30)
     ap.add_argument("--scale", type=float, default=1.0, help="scale every contig length (tests; the metric is quoted at 1.0)")
-    ap.add_argument("--groups", type=int, default=2, help="batch groups (host threads driving one np2_batch_t each)")
+    ap.add_argument("--groups", type=int, default=1, help="batch groups (host threads driving one np2_batch_t each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all cores)")

@@ -339,18 +339,28 @@ inline void op_fill(np2_ctx *cx, void *p, uint8_t byte, size_t bytes) {
 inline void op_copy_d2d(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
     if (bytes) launch_copy(cx->stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
 }
+// host transfers.  Pinned host memory (hipHostMalloc) is mapped into the device's address space, so under the batch
+// driver a transfer is a copy KERNEL reading / writing host memory over the bus: the copies of all contigs of a batch
+// go out as one launch instead of one blit per contig.  Large transfers keep the DMA path.
+static constexpr size_t KERNEL_COPY_MAX = 1u << 20;
 inline void op_d2h(np2_ctx *cx, void *pinned_dst, const void *src, size_t bytes) {
     if (!bytes) return;
-    if (Recorder *r = tl_recorder())
-        r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, s)); });
-    else
+    if (Recorder *r = tl_recorder()) {
+        if (bytes <= KERNEL_COPY_MAX)
+            launch_copy(cx->stream, (uint8_t *)pinned_dst, (const uint8_t *)src, bytes);
+        else
+            r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, s)); });
+    } else
         HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, cx->stream));
 }
 inline void op_h2d(np2_ctx *cx, void *dst, const void *pinned_src, size_t bytes) {
     if (!bytes) return;
-    if (Recorder *r = tl_recorder())
-        r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, s)); });
-    else
+    if (Recorder *r = tl_recorder()) {
+        if (bytes <= KERNEL_COPY_MAX)
+            launch_copy(cx->stream, (uint8_t *)dst, (const uint8_t *)pinned_src, bytes);
+        else
+            r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, s)); });
+    } else
         HIPCHK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, cx->stream));
 }
 

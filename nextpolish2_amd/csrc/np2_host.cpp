@@ -239,17 +239,17 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
     }
     // one wait for everything the host side of the vote needs: unique pairs, their counts, the per-read vote arrays
     const size_t RP = ((size_t)R + 63) & ~(size_t)63;
-    const size_t b_key = (size_t)NU * 8, b_w = ((size_t)NU * 4 + 7) & ~(size_t)7, b_v = RP * 10;
+    const size_t b_key = ((size_t)NU * 8 + 15) & ~(size_t)15, b_w = ((size_t)NU * 4 + 15) & ~(size_t)15, b_v = RP * 10;
     {
         uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_v + 64);
-        op_d2h(cx, pin, cx->ekey.p, b_key);
+        op_d2h(cx, pin, cx->ekey.p, (size_t)NU * 8);
         op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
         op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
         op_sync(cx);
         vd.pair_key.resize(NU);
         vd.pair_cnt.resize(NU);
         if (NU) {
-            memcpy(vd.pair_key.data(), pin, b_key);
+            memcpy(vd.pair_key.data(), pin, (size_t)NU * 8);
             memcpy(vd.pair_cnt.data(), pin + b_key, (size_t)NU * 4);
         }
         const uint8_t *vb = pin + b_key + b_w;

@@ -419,8 +419,13 @@ __device__ __forceinline__ void k_fill(const uint32_t np2_bid, const uint32_t np
 __device__ __forceinline__ void k_copy(const uint32_t np2_bid, const uint32_t np2_nb, uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
     const uint64_t o = ((uint64_t)np2_bid * 256 + threadIdx.x) * 16;
     if (o >= n) return;
-    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0 && o + 16 <= n) {
+    const uintptr_t al = ((uintptr_t)dst) | ((uintptr_t)src);
+    if ((al & 15) == 0 && o + 16 <= n) {
         *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+    } else if ((al & 3) == 0 && o + 16 <= n) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+            *reinterpret_cast<uint32_t *>(dst + o + 4 * q) = *reinterpret_cast<const uint32_t *>(src + o + 4 * q);
     } else {
         for (uint64_t i = o; i < min(o + 16, n); ++i) dst[i] = src[i];
     }
