@@ -5,6 +5,10 @@
 
 #include <zlib.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -121,6 +125,118 @@ struct Bgzf {
     }
 };
 
+// Small persistent pool for the input side: BGZF blocks are independent deflate streams and BAM records independent
+// byte ranges, so inflate and record copy are plain parallel loops.  Work items are handed out by an atomic counter;
+// the calling thread works too.  One pool per process, sized to the host (at most 64 workers).
+class IoPool {
+  public:
+    static IoPool &get() {
+        static IoPool *p = new IoPool(); // leaked on purpose: workers outlive static destruction
+        return *p;
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // run fn(i) for i in [0, n), at most `max_threads` threads including the caller
+    template <class F> void parallel_for(size_t n, unsigned max_threads, F fn) {
+        if (n == 0) return;
+        const unsigned want = (unsigned)std::min<size_t>(std::min<size_t>(max_threads, size()), n);
+        if (want <= 1) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> call_lock(call_mu_); // one parallel loop at a time
+        std::atomic<size_t> next{0};
+        std::atomic<unsigned> left{want - 1};
+        std::function<void()> body = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n) break;
+                fn(i);
+            }
+        };
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            job_ = &body;
+            job_left_ = &left;
+            tickets_ = want - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        body();
+        while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            job_ = nullptr;
+        }
+    }
+
+  private:
+    IoPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned n = std::min<unsigned>(64, std::max<unsigned>(2, hw / 2));
+        if (const char *e = getenv("NP2_IO_THREADS")) n = (unsigned)std::max(1, atoi(e));
+        for (unsigned i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto &t : workers_) t.detach();
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void()> *job = nullptr;
+            std::atomic<unsigned> *left = nullptr;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (tickets_ == 0 || !job_) continue;
+                --tickets_;
+                job = job_;
+                left = job_left_;
+            }
+            (*job)();
+            left->fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_;
+    std::function<void()> *job_ = nullptr;
+    std::atomic<unsigned> *job_left_ = nullptr;
+    unsigned tickets_ = 0;
+    uint64_t gen_ = 0;
+};
+
+// growable byte buffer without value-initialisation (a std::vector would zero 100+ MiB per refill just to have inflate
+// overwrite it); kept by the BAM handle, so its pages are faulted in once
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    size_t size() const { return n; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    void clear() { n = 0; }
+    void resize(size_t m) {
+        if (m > cap) {
+            size_t want = std::max(m, cap + cap / 2 + (1u << 20));
+            uint8_t *q = (uint8_t *)realloc(p, want);
+            if (!q) throw std::bad_alloc();
+            p = q;
+            cap = want;
+        }
+        n = m;
+    }
+    void drop_front(size_t k) { // discard the first k bytes
+        if (k >= n) {
+            n = 0;
+            return;
+        }
+        memmove(p, p + k, n - k);
+        n -= k;
+    }
+};
+
 // Reads BGZF blocks in batches and inflates each batch with several host threads (blocks are independent).
 struct BgzfBatch {
     FILE *f = nullptr;
@@ -129,9 +245,10 @@ struct BgzfBatch {
         uint32_t isize = 0;
         size_t out_off = 0;
     };
-    std::vector<uint8_t> buf; // inflated bytes not yet consumed (+ the current batch)
+    RawBuf buf; // inflated bytes not yet consumed (+ the current batch)
     size_t pos = 0;
     bool eof = false;
+    size_t batch_blocks = 2048; // 64 KiB blocks per refill: 128 MiB of inflated BAM, all inflated in parallel
     bool read_raw(Blk &b) {
         uint8_t hd[18];
         const size_t n = fread(hd, 1, 18, f);
@@ -169,7 +286,7 @@ struct BgzfBatch {
     void fill(size_t n_blocks) {
         if (eof) return;
         if (pos) { // drop consumed bytes
-            buf.erase(buf.begin(), buf.begin() + (long)pos);
+            buf.drop_front(pos);
             pos = 0;
         }
         std::vector<Blk> blks;
@@ -186,47 +303,33 @@ struct BgzfBatch {
         }
         const size_t base = buf.size();
         buf.resize(base + total);
-        unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blks.size() / 4));
-        std::vector<int> bad(nt, 0);
-        auto work = [&](unsigned t) {
-            for (size_t i = t; i < blks.size(); i += nt) {
-                if (!blks[i].isize) continue;
-                z_stream zs;
-                memset(&zs, 0, sizeof zs);
-                if (inflateInit2(&zs, -15) != Z_OK) {
-                    bad[t] = 1;
-                    return;
-                }
-                zs.next_in = blks[i].c.data();
-                zs.avail_in = (uInt)blks[i].c.size();
-                zs.next_out = buf.data() + base + blks[i].out_off;
-                zs.avail_out = blks[i].isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END) bad[t] = 1;
+        std::atomic<int> bad{0};
+        IoPool::get().parallel_for(blks.size(), (unsigned)std::max<size_t>(1, blks.size() / 2), [&](size_t i) {
+            if (!blks[i].isize) return;
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) {
+                bad.store(1);
+                return;
             }
-        };
-        if (nt <= 1) {
-            work(0);
-        } else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
-            for (auto &x : th) x.join();
-        }
-        for (int b : bad)
-            if (b) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
+            zs.next_in = blks[i].c.data();
+            zs.avail_in = (uInt)blks[i].c.size();
+            zs.next_out = buf.data() + base + blks[i].out_off;
+            zs.avail_out = blks[i].isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) bad.store(1);
+        });
+        if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
     }
     // pointer to n contiguous bytes (nullptr on clean EOF before the first byte)
     const uint8_t *take(size_t n) {
-        size_t batch = 256;
         while (buf.size() - pos < n) {
             if (eof) {
                 if (buf.size() == pos) return nullptr;
                 throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
             }
-            fill(batch);
-            batch = 1024;
+            fill(batch_blocks);
         }
         const uint8_t *p = buf.data() + pos;
         pos += n;
@@ -238,6 +341,23 @@ uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((u
 uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
 
 } // namespace
+
+// std::vector storage in pinned host memory: the SEQ bytes gathered from the BAM go to the GPU by DMA straight from
+// here (a pageable source is staged through bounce buffers at a fraction of the bus rate)
+template <class T> struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+    template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+typedef std::vector<uint8_t, PinnedAlloc<uint8_t>> PinnedBytes;
 
 struct np2_fasta {
     Fasta f;
@@ -255,6 +375,8 @@ struct np2_bam {
     // -S: secondary alignments carry no SEQ; recovered from the primary record of the same read (secondary.rs:82-148)
     bool sec_loaded = false;
     std::unordered_map<std::string, SecSeq> sec;
+    PinnedBytes seq4; // SEQ staging of the contig being read (capacity kept across contigs)
+    BgzfBatch batch;  // batch inflater (its buffer is reused from contig to contig)
 };
 
 namespace {
@@ -270,7 +392,7 @@ struct Admitted {
 inline uint8_t seq4_at(const uint8_t *s, uint32_t i) { return (i & 1) ? (s[i >> 1] & 15) : (s[i >> 1] >> 4); }
 // reverse complement in the 4-bit domain: A(1)<->T(8), C(2)<->G(4), every other code unchanged
 // (reverse_complement_seq_u8, secondary.rs:66-80, over the decoded letters "=ACMGRSVTWYHKDBN")
-void append_seq4(std::vector<uint8_t> &dst, const uint8_t *src, uint32_t len, bool revcomp) {
+template <class V> void append_seq4(V &dst, const uint8_t *src, uint32_t len, bool revcomp) {
     const size_t base = dst.size();
     dst.resize(base + (len + 1) / 2, 0);
     for (uint32_t i = 0; i < len; ++i) {
@@ -733,60 +855,134 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         if (tid < 0) throw np2h::Np2Error(NP2_E_ARG, std::string("Faield random access BAM/SAM! (contig not in the BAM header: ") + name + ")");
         std::vector<np2_bamrec_t> recs;
         std::vector<uint32_t> cigar;
-        std::vector<uint8_t> seq4;
+        PinnedBytes &seq4 = bam->seq4;
+        seq4.clear();
+        const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
+        const double t_p0 = np2h::now_ms();
         if (opts->use_secondary) load_secondary_seqs(bam);
         if (bam->ref_start[tid] != ~0ull) {
-            BgzfBatch z;
+            BgzfBatch &z = bam->batch;
             z.f = bam->z.f;
             z.seek(bam->ref_start[tid]);
-            for (;;) {
-                const uint8_t *h4 = z.take(4);
-                if (!h4) break;
-                const uint32_t bs = le32(h4);
-                const uint8_t *rec = z.take(bs);
-                if (!rec) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
-                const int32_t refID = (int32_t)le32(rec);
-                if (refID != tid) {
-                    if (refID > tid || refID < 0) break;
-                    continue;
-                }
-                const int32_t pos = (int32_t)le32(rec + 4);
-                if ((uint32_t)pos >= L) continue; // fetch(tid, 0, len): records starting beyond the region
-                const uint32_t l_read_name = rec[8], mapq = rec[9];
-                const uint32_t n_cigar = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8);
-                const uint32_t l_seq = le32(rec + 16);
-                const uint8_t *pc = rec + 32 + l_read_name;
-                const uint8_t *ps = pc + (size_t)n_cigar * 4;
-                if ((size_t)(ps - rec) + (l_seq + 1) / 2 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-                np2_bamrec_t r;
-                memset(&r, 0, sizeof r);
-                r.pos = pos;
-                r.flag = (uint16_t)flag;
-                r.mapq = (uint8_t)mapq;
-                r.n_cigar = n_cigar;
-                r.cigar_off = cigar.size();
-                r.l_seq = l_seq;
-                r.seq_off = seq4.size();
-                for (uint32_t k = 0; k < n_cigar; ++k) cigar.push_back(le32(pc + 4 * k));
-                if (opts->use_secondary && (flag & 0x100)) {
-                    // SEQ of the read's primary alignment, reverse-complemented again if this record is on the reverse
-                    // strand (main.rs:1775-1784).  A missing name leaves l_seq = 0: the reference would only panic
-                    // if the record passes the admission filters, and so do we (contig_from_records).
-                    const std::string name((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0);
-                    const auto it = bam->sec.find(name);
-                    r.l_seq = 0;
-                    if (it != bam->sec.end()) {
-                        r.l_seq = it->second.len;
-                        append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
+            // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
+            // length fields finds this contig's records, a prefix sum places their CIGAR words and SEQ bytes, and the
+            // copies run in parallel (records are independent byte ranges).
+            struct RecRef {
+                size_t off; // first byte after the record's block_size field, inside z.buf
+                uint32_t bs, n_cigar, l_seq;
+                uint64_t cigar_off, seq_off;
+            };
+            std::vector<RecRef> rr;
+            bool stop = false;
+            while (!stop) {
+                rr.clear();
+                size_t p = z.pos;
+                uint64_t co = cigar.size(), so = seq4.size();
+                while (p + 4 <= z.buf.size()) {
+                    const uint32_t bs = le32(z.buf.data() + p);
+                    if (bs < 32) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                    if (p + 4 + (size_t)bs > z.buf.size()) break; // the record continues in the next refill
+                    const uint8_t *rec = z.buf.data() + p + 4;
+                    const int32_t refID = (int32_t)le32(rec);
+                    if (refID != tid) {
+                        if (refID > tid || refID < 0) {
+                            stop = true;
+                            break;
+                        }
+                        p += 4 + (size_t)bs;
+                        continue;
                     }
-                } else {
-                    seq4.insert(seq4.end(), ps, ps + (l_seq + 1) / 2);
+                    const int32_t pos = (int32_t)le32(rec + 4);
+                    if ((uint32_t)pos < L) { // (fetch(tid, 0, len): records starting beyond the region are skipped)
+                        RecRef r;
+                        r.off = p + 4;
+                        r.bs = bs;
+                        r.n_cigar = rec[12] | (rec[13] << 8);
+                        r.l_seq = le32(rec + 16);
+                        const uint32_t l_read_name = rec[8];
+                        if ((size_t)32 + l_read_name + (size_t)r.n_cigar * 4 + ((size_t)r.l_seq + 1) / 2 > bs)
+                            throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                        r.cigar_off = co;
+                        r.seq_off = so;
+                        co += r.n_cigar;
+                        const uint32_t flag = rec[14] | (rec[15] << 8);
+                        if (!(opts->use_secondary && (flag & 0x100))) so += ((uint64_t)r.l_seq + 1) / 2;
+                        rr.push_back(r);
+                    }
+                    p += 4 + (size_t)bs;
                 }
-                recs.push_back(r);
+                const size_t r0 = recs.size();
+                recs.resize(r0 + rr.size());
+                cigar.resize(co);
+                if (!opts->use_secondary) {
+                    seq4.resize(so);
+                    IoPool::get().parallel_for(rr.size(), 64, [&](size_t i) {
+                        const RecRef &q = rr[i];
+                        const uint8_t *rec = z.buf.data() + q.off;
+                        const uint32_t l_read_name = rec[8];
+                        const uint8_t *pc = rec + 32 + l_read_name;
+                        np2_bamrec_t r;
+                        memset(&r, 0, sizeof r);
+                        r.pos = (int32_t)le32(rec + 4);
+                        r.flag = (uint16_t)(rec[14] | (rec[15] << 8));
+                        r.mapq = rec[9];
+                        r.n_cigar = q.n_cigar;
+                        r.cigar_off = q.cigar_off;
+                        r.l_seq = q.l_seq;
+                        r.seq_off = q.seq_off;
+                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
+                        memcpy(seq4.data() + q.seq_off, pc + (size_t)q.n_cigar * 4, ((size_t)q.l_seq + 1) / 2);
+                        recs[r0 + i] = r;
+                    });
+                } else {
+                    for (size_t i = 0; i < rr.size(); ++i) { // -S: secondary records take their SEQ from the primary's
+                        const RecRef &q = rr[i];
+                        const uint8_t *rec = z.buf.data() + q.off;
+                        const uint32_t l_read_name = rec[8], flag = rec[14] | (rec[15] << 8);
+                        const uint8_t *pc = rec + 32 + l_read_name;
+                        const uint8_t *ps = pc + (size_t)q.n_cigar * 4;
+                        np2_bamrec_t r;
+                        memset(&r, 0, sizeof r);
+                        r.pos = (int32_t)le32(rec + 4);
+                        r.flag = (uint16_t)flag;
+                        r.mapq = rec[9];
+                        r.n_cigar = q.n_cigar;
+                        r.cigar_off = q.cigar_off;
+                        r.l_seq = q.l_seq;
+                        r.seq_off = seq4.size();
+                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
+                        if (flag & 0x100) {
+                            // SEQ of the read's primary alignment, reverse-complemented again if this record is on the
+                            // reverse strand (main.rs:1775-1784).  A missing name leaves l_seq = 0: the reference would only
+                            // panic if the record passes the admission filters, and so do we (contig_from_records).
+                            const std::string qname((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0);
+                            const auto it = bam->sec.find(qname);
+                            r.l_seq = 0;
+                            if (it != bam->sec.end()) {
+                                r.l_seq = it->second.len;
+                                append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
+                            }
+                        } else {
+                            seq4.insert(seq4.end(), ps, ps + ((size_t)q.l_seq + 1) / 2);
+                        }
+                        recs[r0 + i] = r;
+                    }
+                }
+                z.pos = p;
+                if (stop) break;
+                if (z.eof) {
+                    if (z.pos != z.buf.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+                    break;
+                }
+                z.fill(z.batch_blocks);
             }
         }
         seq4.resize(seq4.size() + 16, 0);
+        const double t_p1 = np2h::now_ms();
         contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
+        if (prof)
+            fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (%zu records, %zu SEQ bytes), records->pileup %.2f ms\n",
+                    name, t_p1 - t_p0, recs.size(), seq4.size(), np2h::now_ms() - t_p1);
         np2h::flush_timings(cx);
     } catch (const np2h::Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);
