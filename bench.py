@@ -26,9 +26,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # S. cerevisiae S288C: 16 chromosomes + the mitochondrial genome (bp)
 YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 439888, 745751, 666816, 1078177, 924431,
          784333, 1091291, 948066, 85779]
-# HBM traffic of the k_diff_reads launches of one step on the default workload, from rocprofv3 PMC passes
-# (profiles/r02_*_pmc_fetch_write.json; None until measured for this round's kernel)
-PMC_TRAFFIC_DEFAULT_WORKLOAD = None
+# HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+# 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
+# profiles/r02a_yeast_pmc_fetch_write.json, profiles/r02a_ecoli_pmc_fetch_write.json
+PMC_TRAFFIC = {"yeast": int((2 * 126797.0 + 131264.0) * 1024), "ecoli": int((2 * 48481.0 + 31234.0) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
@@ -301,7 +302,7 @@ def main():
                    "output": "polished sequences copied to the host inside the step"},
         "roofline": {"bound": "hbm", "kernel": "k_diff_reads", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": PMC_TRAFFIC_DEFAULT_WORKLOAD if (diploid and a.depth == 30 and a.scale == 1.0) else None,
+                     "traffic": PMC_TRAFFIC[a.workload] if (a.depth == 30 and a.scale == 1.0 and diff_launches == 1) else None,
                      "alg_bytes_per_launch": int(alg_bytes / max(1, diff_launches)), "launches_per_step": diff_launches,
                      "avg_launch_ms": round(avg_ms / max(1, diff_launches), 4),
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},

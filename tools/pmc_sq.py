@@ -5,8 +5,10 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        m = re.search(r"np2::(\w+)", r["Kernel_Name"])
-        name = m.group(1) if m else r["Kernel_Name"][:40]
+        n = r["Kernel_Name"]
+        mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
+        m = re.search(r"np2::(\w+)", n)
+        name = mb.group(3)[:int(mb.group(2))] if mb else (m.group(1) if m else n[:40])
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = sorted({c for cs in acc.values() for c in cs})
 print("kernel".ljust(28), " ".join(c[-14:].rjust(14) for c in cols))
