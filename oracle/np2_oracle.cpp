@@ -236,6 +236,56 @@ struct KmerInfo {
                 sets[b].emplace_back(y.words[i] >> 10, (uint16_t)(y.words[i] & 1023));
         }
     }
+    // Variant (i) of the CPU baseline: the reference keeps no table in memory, every scoring phase
+    // re-reads the whole .yak dump and probes its candidate set once per file word (retrieve_kmers, kmer.rs:132-170).
+    // With a dump path set, stream_pass() does exactly that work on the real file: BufReader-sized reads, the 8-byte
+    // word loop, the min_count test, one hash-set probe per surviving word, the histogram.  The counts themselves still
+    // come from the in-memory table (they are the same numbers), so results do not depend on the mode.
+    std::string path;
+    uint64_t stream_pass(const std::vector<std::unordered_set<uint64_t>> &want, uint16_t min_count) const {
+        if (path.empty()) return 0;
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) throw RefPanic("cannot open the yak dump for streaming");
+        std::vector<uint8_t> buf(8192); // BufReader's default capacity
+        setvbuf(f, nullptr, _IONBF, 0);
+        size_t have = 0, at = 0;
+        auto need = [&](size_t n) -> const uint8_t * { // read_exact over a refilled 8 KiB buffer
+            if (have - at < n) {
+                memmove(buf.data(), buf.data() + at, have - at);
+                have -= at;
+                at = 0;
+                const size_t got = fread(buf.data() + have, 1, buf.size() - have, f);
+                have += got;
+                if (have < n) return nullptr;
+            }
+            const uint8_t *p = buf.data() + at;
+            at += n;
+            return p;
+        };
+        uint64_t hits = 0;
+        std::vector<uint32_t> hist(1024, 0);
+        if (need(16)) {
+            for (size_t b = 0; b < ((size_t)1 << pre); ++b) {
+                const uint8_t *h = need(8);
+                if (!h) break;
+                uint32_t size;
+                memcpy(&size, h + 4, 4);
+                const auto &set = want[b];
+                for (uint32_t j = 0; j < size; ++j) {
+                    const uint8_t *w = need(8);
+                    if (!w) break;
+                    uint64_t hash;
+                    memcpy(&hash, w, 8);
+                    const uint16_t count = (uint16_t)(hash & 1023);
+                    hist[count] += 1;
+                    if (count < min_count) continue;
+                    if (set.count(hash >> 10)) ++hits;
+                }
+            }
+        }
+        fclose(f);
+        return hits + hist[0];
+    }
     uint64_t to_hash(uint64_t kmer) const { // kmer.rs:102-110
         return ksize < 32 ? yak_hash64(kmer, kmask) : kmer;
     }
@@ -293,7 +343,18 @@ template <class F> static void iter2kmer(const std::string &s, size_t ksize, F e
 }
 
 // min count over the k-mers of s; 0 if none  (main.rs:761-769, 1300-1315, 1342-1350)
+// set while the candidate k-mers of a scoring phase are being collected for KmerInfo::stream_pass (variant (i) of the
+// CPU baseline): min_kmer_count_of then records the hashes instead of looking them up
+static thread_local std::vector<std::unordered_set<uint64_t>> *tl_collect = nullptr;
+
 static uint16_t min_kmer_count_of(const std::string &s, const KmerInfo &ki) {
+    if (tl_collect) {
+        iter2kmer(s, ki.ksize, [&](uint64_t km) {
+            const uint64_t h = ki.to_hash(km);
+            (*tl_collect)[h & ki.pmask].insert(h >> 10);
+        });
+        return 0;
+    }
     bool any = false;
     uint16_t mn = 0xFFFF;
     iter2kmer(s, ki.ksize, [&](uint64_t km) {
@@ -630,6 +691,20 @@ static void retrieve_kmer_count(std::vector<LqSeqs> &lqseqs, KmerInfo &ki, uint1
                                 Stats &st) {
     ki.prepare(min_kmer_count);
     size_t ksize = ki.ksize;
+    if (!ki.path.empty()) { // variant (i): insert the candidates (main.rs:745-755), then stream the file (756)
+        std::vector<std::unordered_set<uint64_t>> want((size_t)1 << ki.pre);
+        for (auto &lq : lqseqs)
+            for (auto &seq : lq.seqs) {
+                if (seq.seq.size() > ksize)
+                    iter2kmer(seq.seq, ksize, [&](uint64_t km) {
+                        const uint64_t h = ki.to_hash(km);
+                        want[h & ki.pmask].insert(h >> 10);
+                    });
+                else if (seq.kmer != INVALID_KMER)
+                    want[seq.kmer & ki.pmask].insert(seq.kmer >> 10);
+            }
+        st.n_invalid += 0 * ki.stream_pass(want, min_kmer_count);
+    }
     for (auto &lq : lqseqs)
         for (auto &seq : lq.seqs) {
             if (seq.seq.size() > ksize) {
@@ -938,6 +1013,8 @@ static std::vector<ConsensusBase> reupdate_consensus_with_lqseqs(std::vector<LqS
     };
     std::vector<Ks> kscore_buf;
     std::string buf;
+    auto walk = [&]() {
+    idx = 0, sj = 0;
     while (sj < rech_idxs.size()) {
         ej = sj + 1;
         while (ej < rech_idxs.size() &&
@@ -1006,6 +1083,22 @@ static std::vector<ConsensusBase> reupdate_consensus_with_lqseqs(std::vector<LqS
         }
         sj = ej;
     }
+    };
+    if (!ki.path.empty()) { // variant (i): insert pass (main.rs:1193-1265), file stream (1267), then the score pass
+        std::vector<std::unordered_set<uint64_t>> want((size_t)1 << ki.pre);
+        Stats scratch = st;
+        tl_collect = &want;
+        try {
+            walk();
+        } catch (...) {
+            tl_collect = nullptr;
+            throw;
+        }
+        tl_collect = nullptr;
+        st = scratch; // (the insert pass does not count as probes)
+        (void)ki.stream_pass(want, min_kmer_count);
+    }
+    walk();
 
     for (auto &lq : lqseqs) {
         if (!lq.has_lable(LABLE_RECH)) continue;
@@ -1396,6 +1489,13 @@ void *np2o_ctx_create(const np2_yak_t *yaks, int n_yak) {
         cx->opt.yak.back().load(yaks[i]);
     }
     return cx;
+}
+// variant (i) of the CPU baseline: yak dump paths (one per table, same order); NULL / "" = in-memory only
+int np2o_set_yak_files(void *c, const char *const *paths, int n) {
+    Ctx *cx = (Ctx *)c;
+    if ((size_t)n != cx->opt.yak.size()) return NP2_E_ARG;
+    for (int i = 0; i < n; ++i) cx->opt.yak[i].path = paths && paths[i] ? paths[i] : "";
+    return 0;
 }
 // a further context over the same (read-only) k-mer tables, filtered for `min_kmer_count` once in the parent
 void *np2o_ctx_clone(void *parent, uint16_t min_kmer_count) {

@@ -30,6 +30,7 @@ def lib():
         L.np2o_ctx_create.argtypes = [C.POINTER(np2_yak_t), C.c_int]
         L.np2o_ctx_destroy.argtypes = [C.c_void_p]
         L.np2o_swiss_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.np2o_set_yak_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
         L.np2o_ctx_clone.restype = C.c_void_p
         L.np2o_ctx_clone.argtypes = [C.c_void_p, C.c_uint16]
         L.np2o_last_error.restype = C.c_char_p
@@ -81,6 +82,14 @@ class Oracle:
         self._h = lib().np2o_ctx_create(arr, len(self._yaks))
         if not self._h:
             raise ValueError("oracle: unsupported yak table (k must be < 32)")
+
+    def set_yak_files(self, paths):
+        """Variant (i) of the CPU baseline: every scoring phase re-streams these .yak dumps like the reference does
+        (kmer.rs:132-170); results are unchanged.  None switches back to the in-memory tables only."""
+        n = len(self._yaks)
+        arr = (C.c_char_p * n)(*[(p.encode() if p else None) for p in (paths or [None] * n)])
+        if lib().np2o_set_yak_files(self._h, arr, n) != 0:
+            raise ValueError("one path per yak table")
 
     def clone(self, min_kmer_count=5):
         """A further oracle over the SAME in-memory k-mer tables (one per host thread of the CPU baseline)."""
