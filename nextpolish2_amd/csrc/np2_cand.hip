@@ -189,6 +189,17 @@ __device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t
         if ((wi >> 2) != win_blk) {
             win_blk = wi >> 2;
             win = *reinterpret_cast<const uint4 *>(base + ((size_t)win_blk << 4));
+            // a whole 32-column block before the region's first column only needs its non-insertion count (the walk
+            // from the checkpoint covers up to 63 positions: most of its blocks)
+            if ((wi & 3) == 0 && !started && c0 >= col_ck && c0 != 0 && c0 + 32 <= n_cols) {
+                const uint32_t ins = (uint32_t)__builtin_popcount(win.x & 0x88888888u) + (uint32_t)__builtin_popcount(win.y & 0x88888888u) +
+                                     (uint32_t)__builtin_popcount(win.z & 0x88888888u) + (uint32_t)__builtin_popcount(win.w & 0x88888888u);
+                if (seen + (32 - ins) < want_s) {
+                    seen += 32 - ins;
+                    wi += 3;
+                    continue;
+                }
+            }
         }
         const uint32_t k = wi & 3;
         const uint32_t raw = k == 0 ? win.x : (k == 1 ? win.y : (k == 2 ? win.z : win.w));
@@ -251,9 +262,50 @@ __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, 
                            uint32_t len, uint8_t *__restrict__ seq_out, uint64_t *kmer_out) {
     const uint8_t *base = cx.nib + rd.nib_off;
     // ---- first k-mer -------------------------------------------------------------------------------------------------
-    {
+    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
+    bool have_kmer = false;
+    if (col + cx.ksize <= rd.n_cols) {
+        // Common case, without the per-column loop: the k columns from `col` on are k plain bases (codes 0-3: no gap code
+        // to skip, no N / M whose third bit would smear into the neighbour, main.rs:1488-1492).  48 columns as three
+        // 8-byte words -> the 32 columns from `col` -> 2-bit codes squeezed together; the forward k-mer is their
+        // pair-wise bit reversal, the reverse complement their complement in place (kmer.rs:255-287).
+        const uint32_t k = cx.ksize, W0 = col >> 4, sh = (col & 15) * 4;
+        auto ld = [&](uint32_t W) -> uint64_t {
+            const uint2 v = *reinterpret_cast<const uint2 *>(base + ((size_t)W << 3));
+            const uint32_t x = ((v.x & 0x0F0F0F0Fu) << 4) | ((v.x >> 4) & 0x0F0F0F0Fu);
+            const uint32_t y = ((v.y & 0x0F0F0F0Fu) << 4) | ((v.y >> 4) & 0x0F0F0F0Fu);
+            return (uint64_t)x | ((uint64_t)y << 32);
+        };
+        const uint64_t x0 = ld(W0), x1 = ld(W0 + 1), x2 = ld(W0 + 2);
+        const uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0, hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+        auto nmask = [](uint32_t n) -> uint64_t { return n >= 16 ? ~0ULL : ((1ULL << (4 * n)) - 1ULL); }; // nibbles [0, n)
+        const uint64_t m_lo = nmask(k), m_hi = k > 16 ? nmask(k - 16) : 0ULL;
+        if ((((lo & m_lo) | (hi & m_hi)) & 0x4444444444444444ULL) == 0) {
+            // the loop also ends once t_pos runs past `limit`: harmless iff that has not happened by the last but one column
+            const uint32_t span = k - 2; // columns 1 .. k - 2 advance t_pos unless they are insertion columns
+            const uint64_t r_lo = nmask(k - 1) & ~0xFULL, r_hi = k - 1 > 16 ? nmask(k - 1 - 16) : 0ULL;
+            const uint32_t ins = (uint32_t)__builtin_popcountll(lo & r_lo & 0x8888888888888888ULL) +
+                                 (uint32_t)__builtin_popcountll(hi & r_hi & 0x8888888888888888ULL);
+            if (t + (span - ins) <= limit) {
+                auto squeeze = [](uint64_t x) -> uint64_t { // 16 nibbles -> 16 two-bit codes in the low 32 bits
+                    uint64_t y = x & 0x3333333333333333ULL;
+                    y = (y | (y >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+                    y = (y | (y >> 4)) & 0x00FF00FF00FF00FFULL;
+                    y = (y | (y >> 8)) & 0x0000FFFF0000FFFFULL;
+                    return (y | (y >> 16)) & 0xFFFFFFFFULL;
+                };
+                const uint64_t codes = squeeze(lo) | (squeeze(hi) << 32); // code of column col + j at bits 2j
+                const uint64_t mask = (1ULL << (2 * (uint64_t)k)) - 1;
+                uint64_t rb = __builtin_bitreverse64(codes);
+                rb = ((rb >> 1) & 0x5555555555555555ULL) | ((rb & 0x5555555555555555ULL) << 1); // pairs back in bit order
+                const uint64_t fw = rb >> (64 - 2 * k), rv = ~codes & mask;
+                *kmer_out = yak_hash64(fw < rv ? fw : rv, mask);
+                have_kmer = true;
+            }
+        }
+    }
+    if (!have_kmer) {
         NibReader nr{base, 0, 0xFFFFFFFFu};
-        const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
         const uint64_t ksize = cx.ksize, shift = 2 * (ksize - 1), mask = (1ULL << (2 * ksize)) - 1;
         uint64_t fw = 0, rv = 0, l = 0;
         for (uint32_t c = col; c < rd.n_cols && l < ksize; ++c) {
