@@ -189,17 +189,6 @@ __device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t
         if ((wi >> 2) != win_blk) {
             win_blk = wi >> 2;
             win = *reinterpret_cast<const uint4 *>(base + ((size_t)win_blk << 4));
-            // a whole 32-column block before the region's first column only needs its non-insertion count (the walk
-            // from the checkpoint covers up to 63 positions: most of its blocks)
-            if ((wi & 3) == 0 && !started && c0 >= col_ck && c0 != 0 && c0 + 32 <= n_cols) {
-                const uint32_t ins = (uint32_t)__builtin_popcount(win.x & 0x88888888u) + (uint32_t)__builtin_popcount(win.y & 0x88888888u) +
-                                     (uint32_t)__builtin_popcount(win.z & 0x88888888u) + (uint32_t)__builtin_popcount(win.w & 0x88888888u);
-                if (seen + (32 - ins) < want_s) {
-                    seen += 32 - ins;
-                    wi += 3;
-                    continue;
-                }
-            }
         }
         const uint32_t k = wi & 3;
         const uint32_t raw = k == 0 ? win.x : (k == 1 ? win.y : (k == 2 ? win.z : win.w));

@@ -94,7 +94,7 @@ static constexpr int64_t SCORE_NEG = INT64_MIN >> 1; // main.rs:1661
 enum : uint8_t { CLS_HQ = 0, CLS_LQ = 1, CLS_RESET = 2 };
 
 // checkpoint grid: column index of the reference column at every CKPT-th contig position
-static constexpr uint32_t CKPT_SHIFT = 6;
+static constexpr uint32_t CKPT_SHIFT = 5;
 static constexpr uint32_t CKPT = 1u << CKPT_SHIFT;
 
 // packed read nibble access (main.rs:314-322)
