@@ -59,9 +59,15 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
         }
     const uint32_t hlo = (uint32_t)h, hhi = (uint32_t)(h >> 32);
     w.eqmask = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t jl = __shfl(hlo, j), jh = __shfl(hhi, j);
-        if (lane < n && jl == hlo && jh == hhi) w.eqmask |= 1ull << j;
+    { // one ballot per distinct hash (a region rarely holds more than a few different strings), not one per candidate
+        uint64_t todo = __ballot(lane < n);
+        while (todo) {
+            const uint32_t hd = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t jl = __shfl(hlo, hd), jh = __shfl(hhi, hd);
+            const uint64_t m = __ballot(lane < n && jl == hlo && jh == hhi);
+            if ((m >> lane) & 1ull) w.eqmask = m;
+            todo &= ~m;
+        }
     }
     bool ok = true;
     if (lane < n) {
@@ -404,12 +410,14 @@ __device__ __forceinline__ void k_seed(const uint32_t np2_bid, const uint32_t np
         if (lane == 0) key = k0;
     }
     // retain_sort_seqs: stable sort by key descending, keep key >= min_c
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t kj = __shfl(key, j);
-        if (lane < n && (kj > key || (kj == key && j < lane))) ++rank;
-    }
+    // (only kept candidates are ranked, and a candidate below min_c never outranks a kept one: walk the kept ones only)
     const bool kept = lane < n && key >= min_c;
+    uint32_t rank = 0;
+    for (uint64_t it = __ballot(kept); it; it &= it - 1) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(it);
+        const uint32_t kj = __shfl(key, j);
+        if (kept && (kj > key || (kj == key && j < lane))) ++rank;
+    }
     uint32_t kn = __builtin_popcountll(__ballot(kept));
     if (kn == 0) {
         if (lane == 0) atomicOr(err, 32u); // lqseq.seqs[0] out of bounds after retain_sort_seqs
