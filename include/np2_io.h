@@ -70,6 +70,21 @@ int np2_contig_from_records(np2_ctx_t *ctx, const uint8_t *ref, uint32_t L, cons
 /* same, reading the records of contig `name` from an indexed BAM (must be coordinate sorted) */
 int np2_contig_from_bam(np2_ctx_t *ctx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L,
                         const np2_front_opts_t *opts, np2_contig_t **out);
+/* ---- one reference interval of a contig straight from the BAM (multi-GPU: every rank parses only its part) -----------
+ * begin: fetch the records overlapping [own_lo - halo, own_hi + halo) through the .bai linear index, admit + columnarise
+ *        them; returns the BGZF virtual offsets of the pushed records that START in [own_lo, own_hi) (file order).
+ *        The ranks' own intervals must tile the contig (np2_shard_plan's cuts: L * k / n rounded down to 1024).
+ * exchange (caller): all-gather those lists in rank order -> the contig's pushed records in file order.
+ * finish: numbers the shard's reads contig-wide (1 + place in that list; the reference numbers alignseqs in file order,
+ *        main.rs:1813), applies the clip filter in contig coordinates, returns the shard's resident pileup, its plan for
+ *        np2_shard_begin and the contig's read count for np2_vote_decide.  Consumes `io` (also on error). */
+typedef struct np2_shard_io np2_shard_io_t;
+int np2_shard_bam_begin(np2_ctx_t *ctx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L, uint32_t own_lo,
+                        uint32_t own_hi, uint32_t halo, const np2_front_opts_t *opts, np2_shard_io_t **io,
+                        const uint64_t **own_voffsets, uint64_t *n_own);
+int np2_shard_bam_finish(np2_shard_io_t *io, const uint64_t *all_voffsets, uint64_t n_all, np2_shard_plan_t *plan,
+                         np2_contig_t **contig, uint32_t *n_reads_total);
+void np2_shard_bam_abort(np2_shard_io_t *io);
 /* copy a resident packed pileup back to the host (parity tests / debugging); free both with np2_free */
 int np2_contig_export(np2_ctx_t *ctx, np2_contig_t *c, np2_read_t **reads, uint32_t *n_reads,
                       uint8_t **nibbles, uint64_t *nib_bytes);

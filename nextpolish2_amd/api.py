@@ -26,6 +26,13 @@ ABI_SYMBOLS = [
     "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
+# include/np2_io.h (input side; bound by nextpolish2_amd.io)
+IO_ABI_SYMBOLS = [
+    "np2_fasta_open", "np2_fasta_next", "np2_fasta_close", "np2_yak_load", "np2_yak_free", "np2_bam_open", "np2_bam_close",
+    "np2_bam_n_refs", "np2_bam_ref_name", "np2_io_last_error", "np2_contig_from_records", "np2_contig_from_bam",
+    "np2_contig_export", "np2_shard_bam_begin", "np2_shard_bam_finish", "np2_shard_bam_abort",
+]
+
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}
 
 
@@ -439,16 +446,20 @@ def vote_decide(votes, n_reads_total, opts: Opts = None):
 
 
 class ShardRun:
-    """One shard of a contig on one context: upload, then vote() / apply() per phasing pass, final()."""
+    """One shard of a contig on one context: upload (from a host pileup, or an already resident shard built by
+    io.shard_from_bam), then vote() / apply() per phasing pass, final()."""
 
-    def __init__(self, polisher: Polisher, pileup: Pileup, plan: np2_shard_plan_t, opts: Opts = None, verify=1024):
+    def __init__(self, polisher: Polisher, pileup, plan: np2_shard_plan_t, opts: Opts = None, verify=1024, resident=None):
         self._pol = polisher
         self.plan = plan
         self.verify = verify
         self._c = C.c_void_p()
-        polisher._check(lib().np2_shard_upload(polisher._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
-                                               pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
-                                               C.byref(plan), C.byref(self._c)))
+        if resident is not None:
+            self._c = resident  # np2_contig_t* of the shard (ownership taken)
+        else:
+            polisher._check(lib().np2_shard_upload(polisher._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
+                                                   pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
+                                                   C.byref(plan), C.byref(self._c)))
         self._o = (opts or Opts()).c()
         self._r = C.c_void_p()
         rc = lib().np2_shard_begin(polisher._h, self._c, C.byref(plan), C.byref(self._o), verify, C.byref(self._r))

@@ -96,7 +96,7 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
     import torch
     import torch.distributed as dist
 
-    from .dist import ShardMismatch, all_gather_sequences, assign_contigs, polish_sharded
+    from .dist import ShardMismatch, all_gather_sequences, assign_contigs, polish_sharded_bam
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = a.dist_backend or "nccl"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -120,13 +120,14 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
         name, seq = contigs[i]
         if len(seq) >= 0xFFFFFFFF:
             raise SystemExit(f"{name} is too long!")
-        c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
-        pu = np2io.export_contig(pol, c, seq)  # (every rank builds the contig's pileup; it keeps only its shard in HBM)
-        c.free()
-        try:
-            b, p = polish_sharded(pol, pu, opts, halo=a.shard_halo, device=xdev)
-        except ShardMismatch:  # (the same on every rank: the pieces are all-gathered before the check) -> unsharded
-            b, p = pol.polish(pu, opts)
+        try:  # every rank parses only the BAM records overlapping its interval +- halo
+            b, p = polish_sharded_bam(pol, bam, name, seq, opts, fopts, halo=a.shard_halo, device=xdev)
+        except ShardMismatch:  # (raised on every rank alike: the pieces are all-gathered before the check) -> unsharded
+            c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+            try:
+                b, p = pol.polish_resident(c, opts)
+            finally:
+                c.free()
         if rank == 0:
             records[i] = _record(a, name, np.asarray(b).tobytes(), int(p[0]), int(p[-1]), p)
     # 2. the other contigs: whole, one rank each, longest first

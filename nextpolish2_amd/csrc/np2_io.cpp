@@ -244,13 +244,27 @@ struct BgzfBatch {
         std::vector<uint8_t> c; // raw deflate payload
         uint32_t isize = 0;
         size_t out_off = 0;
+        uint64_t file_off = 0; // offset of the block in the file
     };
+    // (buffer position of a block's first inflated byte, file offset of the block) for the blocks in `buf`: a record's
+    // BGZF virtual offset = file offset << 16 | offset inside the block
+    // (the front block may begin before the buffer once consumed bytes were dropped: signed positions)
+    std::vector<std::pair<int64_t, uint64_t>> blk_index;
+    uint64_t voffset_at(size_t p) const {
+        size_t lo = 0, hi = blk_index.size();
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (blk_index[mid].first <= (int64_t)p) lo = mid; else hi = mid;
+        }
+        return (blk_index[lo].second << 16) | (uint64_t)((int64_t)p - blk_index[lo].first);
+    }
     RawBuf buf; // inflated bytes not yet consumed (+ the current batch)
     size_t pos = 0;
     bool eof = false;
     size_t batch_blocks = 2048; // 64 KiB blocks per refill: 128 MiB of inflated BAM, all inflated in parallel
     bool read_raw(Blk &b) {
         uint8_t hd[18];
+        b.file_off = (uint64_t)ftello(f);
         const size_t n = fread(hd, 1, 18, f);
         if (n == 0) return false;
         if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
@@ -278,6 +292,7 @@ struct BgzfBatch {
     void seek(uint64_t voffset) {
         fseeko(f, (off_t)(voffset >> 16), SEEK_SET);
         buf.clear();
+        blk_index.clear();
         pos = 0;
         eof = false;
         fill(8);
@@ -285,7 +300,11 @@ struct BgzfBatch {
     }
     void fill(size_t n_blocks) {
         if (eof) return;
-        if (pos) { // drop consumed bytes
+        if (pos) { // drop consumed bytes (blocks that lie entirely before the new front leave the index)
+            size_t keep = 0;
+            while (keep + 1 < blk_index.size() && blk_index[keep + 1].first <= (int64_t)pos) ++keep;
+            blk_index.erase(blk_index.begin(), blk_index.begin() + (long)keep);
+            for (auto &e : blk_index) e.first -= (int64_t)pos;
             buf.drop_front(pos);
             pos = 0;
         }
@@ -303,6 +322,7 @@ struct BgzfBatch {
         }
         const size_t base = buf.size();
         buf.resize(base + total);
+        for (auto &bk : blks) blk_index.emplace_back((int64_t)(base + bk.out_off), bk.file_off);
         std::atomic<int> bad{0};
         IoPool::get().parallel_for(blks.size(), (unsigned)std::max<size_t>(1, blks.size() / 2), [&](size_t i) {
             if (!blks[i].isize) return;
@@ -371,6 +391,8 @@ struct np2_bam {
     std::vector<std::string> ref_names;
     std::vector<uint32_t> ref_lens;
     std::vector<uint64_t> ref_start; // virtual offset of the first record of each reference (~0 = none)
+    std::vector<std::vector<uint64_t>> lin; // .bai linear index per reference: smallest virtual offset of a record
+                                            // overlapping each 16 kb window (0 = none)
     uint64_t first_rec = 0;          // virtual offset of the first alignment record
     // -S: secondary alignments carry no SEQ; recovered from the primary record of the same read (secondary.rs:82-148)
     bool sec_loaded = false;
@@ -439,11 +461,35 @@ void load_secondary_seqs(np2_bam *bam) {
     bam->sec_loaded = true;
 }
 
-void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs, uint32_t n_recs,
-                         const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes,
-                         const np2_front_opts_t *o, np2_contig **out) {
+// A reference-interval shard built straight from its BAM records (np2_shard_bam_*): the pileup covers the sub-contig
+// [sub_lo, sub_hi) of a contig of L_glob positions; `renumber` turns the pushed records (local order, with the index of
+// their input record) into the shard's read list in contig-wide numbering (holes for the contig's reads the shard does
+// not hold) once the ranks have exchanged their counts.
+struct ShardSpec {
+    uint32_t sub_lo = 0, sub_hi = 0, zone_lo = 0, zone_hi = 0;
+};
+// state between the two halves of the front end: admission + GPU columnariser + keep / drop (front_begin), then the
+// clip filter and the contig bookkeeping (front_finish).  A shard renumbers `reads` in between (contig-wide numbers,
+// holes for the reads it does not hold) once the ranks have exchanged their records' file offsets.
+struct FrontWork {
+    np2_contig *c = nullptr;
+    std::vector<np2_read_t> reads; // [0] = the (sub-)contig; then the pushed records in file order
+    std::vector<uint8_t> lable;
+    std::vector<uint32_t> rec_of;  // input record of reads[i]
+    uint64_t nib_bytes = 0;
+    uint32_t L = 0, L_glob = 0, sub_lo = 0;
+    ~FrontWork() { delete c; }
+};
+
+void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_bamrec_t *recs, uint32_t n_recs,
+                 const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes, const np2_front_opts_t *o,
+                 const ShardSpec *sp, FrontWork &fw) {
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t s = cx->stream;
+    const uint32_t L_glob = L_in;                        // the contig (clip policy, contig-end checks)
+    const uint32_t sub_lo = sp ? sp->sub_lo : 0u;
+    const uint32_t L = sp ? sp->sub_hi - sp->sub_lo : L_in; // the (sub-)contig the pileup is built on
+    const uint8_t *ref = ref_glob + sub_lo;
     if (L < 3) throw np2h::Np2Error(NP2_E_ARG, "contig too short");
     std::vector<FrontRec> frec;
     std::vector<FrontOp> fops;
@@ -466,12 +512,13 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
             continue;
         // (-S: the record's SEQ must already be the one recovered from the read's primary alignment, main.rs:1775-1789;
         // np2_contig_from_bam does that, a caller of np2_contig_from_records passes it in)
-        if (r.pos < 0 || (uint32_t)r.pos > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: record start outside the contig");
+        if (r.pos < 0 || (uint32_t)r.pos > L_glob) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: record start outside the contig");
+        if (sp && (uint32_t)r.pos < sub_lo) throw np2h::Np2Error(NP2_E_ARG, "shard: record starts before the sub-contig");
         // fill_with_cigar bookkeeping (main.rs:390-439): query clipping, op prefix sums
         uint32_t qs = 0, ts = 0, col = 0, aln_q_s = 0, aln_q_e = 0;
         bool is_first = true;
         FrontRec fr;
-        fr.pos = (uint32_t)r.pos;
+        fr.pos = (uint32_t)r.pos - sub_lo;
         fr.op_off = fops.size();
         fr.seq_off = r.seq_off;
         for (uint32_t k = 0; k < r.n_cigar; ++k) {
@@ -504,7 +551,8 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
         if (qs > r.l_seq)
             throw np2h::Np2Error(NP2_E_REFPANIC, secondary ? "reference would panic: no (or too short a) primary SEQ for a secondary alignment"
                                                            : "reference would panic: SEQ shorter than CIGAR");
-        if ((uint64_t)r.pos + ts > L) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end");
+        if ((uint64_t)r.pos + ts > L_glob) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end");
+        if (sp && (uint64_t)r.pos + ts > sp->sub_hi) throw np2h::Np2Error(NP2_E_ARG, "shard: record ends behind the sub-contig");
         if (r.seq_off + ((uint64_t)r.l_seq + 1) / 2 > seq4_bytes) throw np2h::Np2Error(NP2_E_ARG, "SEQ outside the buffer");
         fr.n_ops = (uint32_t)(fops.size() - fr.op_off);
         fr.n_cols = col;
@@ -518,8 +566,8 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
     const uint32_t n = (uint32_t)frec.size();
     const uint64_t nib_bytes = out_off + 64;
 
-    np2_contig *c = new np2_contig();
-    try {
+    np2_contig *c = fw.c = new np2_contig();
+    {
         c->nib.ensure(nib_bytes + 64); // every slot is written completely by its producer kernel
         np2h::DevBuf<uint8_t> d_ref, d_seq;
         np2h::DevBuf<FrontRec> d_rec;
@@ -546,18 +594,21 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
             HIPCHK(hipStreamSynchronize(s));
         }
         // keep / drop / label (main.rs:1798-1813), then filter_alignseqs_by_clip (531-574)
-        std::vector<np2_read_t> reads;
-        std::vector<uint8_t> lable;
+        std::vector<np2_read_t> &reads = fw.reads;
+        std::vector<uint8_t> &lable = fw.lable;
         np2_read_t r0;
         memset(&r0, 0, sizeof r0);
         r0.aln_t_s = 0, r0.aln_t_e = L - 1, r0.nib_off = 0, r0.n_cols = L;
         reads.push_back(r0);
         lable.push_back(0);
         std::vector<uint8_t> pushed(n_recs, 0);
+        std::vector<uint32_t> &rec_of = fw.rec_of;
+        rec_of.assign(1, 0);
         for (uint32_t i = 0; i < n; ++i) {
             if (fout[i].n_cols <= o->min_map_len) continue; // aln_len() <= min_map_len
-            if (adm[i].is_clip && L < 500000) continue;
+            if (adm[i].is_clip && L_glob < 500000) continue;
             pushed[adm[i].rec] = 1;
+            rec_of.push_back(adm[i].rec);
             np2_read_t rd;
             memset(&rd, 0, sizeof rd);
             rd.aln_t_s = fout[i].aln_t_s;
@@ -576,13 +627,39 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
                 if (pushed[i]) pre_pos = recs[i].pos;
             }
         }
+        if (sp) {
+            // reads that do not reach the shard's zone keep their number but are not held (like np2_shard_upload)
+            for (size_t i = 1; i < reads.size(); ++i) {
+                const uint32_t gs = reads[i].aln_t_s + sub_lo, ge = reads[i].aln_t_e + sub_lo;
+                if (ge < sp->zone_lo || gs >= sp->zone_hi) {
+                    reads[i].flags |= NP2_READ_DROPPED;
+                    reads[i].n_cols = 0;
+                    lable[i] = 0;
+                }
+            }
+        }
+        fw.nib_bytes = nib_bytes;
+        fw.L = L, fw.L_glob = L_glob, fw.sub_lo = sub_lo;
+    }
+}
+
+void front_finish(np2_ctx *cx, FrontWork &fw, np2_contig **out) {
+    np2_contig *c = fw.c;
+    std::vector<np2_read_t> &reads = fw.reads;
+    std::vector<uint8_t> &lable = fw.lable;
+    const uint32_t L = fw.L, L_glob = fw.L_glob, sub_lo = fw.sub_lo;
+    const uint64_t nib_bytes = fw.nib_bytes;
+    {
         {
+            // (a shard applies the clip filter in contig coordinates: entry 0 is the whole contig there)
             const uint32_t offset = 50;
             std::vector<std::pair<uint32_t, uint32_t>> ranges;
+            std::vector<size_t> clip_dropped;
             uint32_t rs = 0, re = 0;
             for (size_t i = 0; i < reads.size(); ++i) {
-                if (lable[i]) continue;
-                const uint32_t ts = reads[i].aln_t_s + offset, te = reads[i].aln_t_e - offset;
+                if (lable[i] || (reads[i].flags & NP2_READ_DROPPED)) continue;
+                const uint32_t ts = (i == 0 ? 0u : reads[i].aln_t_s + sub_lo) + offset;
+                const uint32_t te = (i == 0 ? L_glob - 1 : reads[i].aln_t_e + sub_lo) - offset;
                 if (rs == re) {
                     rs = ts, re = te;
                 } else if (ts > re) {
@@ -595,29 +672,190 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
             if (rs != re) ranges.emplace_back(rs, re);
             for (size_t i = 0; i < reads.size(); ++i) {
                 if (!lable[i]) continue;
+                const uint32_t gs = reads[i].aln_t_s + sub_lo, ge = reads[i].aln_t_e + sub_lo;
                 for (auto &rg : ranges) {
-                    if (rg.first <= reads[i].aln_t_s && reads[i].aln_t_e <= rg.second) {
+                    if (rg.first <= gs && ge <= rg.second) {
                         reads[i].flags |= NP2_READ_DROPPED; // align_bases = Vec::new(), index retained
                         reads[i].n_cols = 0;
+                        clip_dropped.push_back(i);
                         break;
-                    } else if (reads[i].aln_t_e < rg.first) {
+                    } else if (ge < rg.first) {
                         break;
                     }
                 }
             }
-            // a dropped slot still needs a terminator in its (unused) stream
-            for (size_t i = 0; i < reads.size(); ++i)
-                if (reads[i].flags & NP2_READ_DROPPED) {
-                    const uint8_t ff = 0xFF;
-                    np2h::h2d_staged(cx, c->nib.p + reads[i].nib_off, &ff, 1);
-                }
+            // a slot emptied by the clip filter still needs a terminator in its (unused) stream
+            for (size_t i : clip_dropped) {
+                const uint8_t ff = 0xFF;
+                np2h::h2d_staged(cx, c->nib.p + reads[i].nib_off, &ff, 1);
+            }
         }
         np2h::finish_contig(cx, c, reads.data(), (uint32_t)reads.size(), L, nib_bytes);
-    } catch (...) {
-        delete c;
-        throw;
     }
+    fw.c = nullptr; // handed over
     *out = c;
+}
+
+void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_bamrec_t *recs, uint32_t n_recs,
+                         const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes,
+                         const np2_front_opts_t *o, np2_contig **out) {
+    FrontWork fw;
+    front_begin(cx, ref, L, recs, n_recs, cigar, seq4, seq4_bytes, o, nullptr, fw);
+    front_finish(cx, fw, out);
+}
+
+// The records of reference `tid` that overlap [zone_lo, zone_hi) (the whole contig: [0, L)), in file order, as
+// np2_bamrec_t + CIGAR words + SEQ bytes (pinned staging of the handle); optionally their BGZF virtual offsets.
+void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t zone_hi, const np2_front_opts_t *opts,
+                   std::vector<np2_bamrec_t> &recs, std::vector<uint32_t> &cigar, std::vector<uint64_t> *voffs) {
+        PinnedBytes &seq4 = bam->seq4;
+        seq4.clear();
+        if (opts->use_secondary) load_secondary_seqs(bam);
+        // where to start: the whole contig from its first record; a zone from the linear index (the smallest offset of a
+        // record overlapping the 16 kb window of zone_lo; an empty window takes the next one's, like htslib)
+        uint64_t start_off = bam->ref_start[tid];
+        if (start_off != ~0ull && zone_lo > 0 && !bam->lin[tid].empty()) {
+            size_t w = std::min<size_t>(zone_lo >> 14, bam->lin[tid].size() - 1);
+            while (w + 1 < bam->lin[tid].size() && bam->lin[tid][w] == 0) ++w;
+            if (bam->lin[tid][w] != 0) start_off = bam->lin[tid][w];
+        }
+        if (start_off != ~0ull) {
+            BgzfBatch &z = bam->batch;
+            z.f = bam->z.f;
+            z.seek(start_off);
+            // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
+            // length fields finds this contig's records, a prefix sum places their CIGAR words and SEQ bytes, and the
+            // copies run in parallel (records are independent byte ranges).
+            struct RecRef {
+                size_t off; // first byte after the record's block_size field, inside z.buf
+                uint32_t bs, n_cigar, l_seq;
+                uint64_t cigar_off, seq_off, voff;
+            };
+            std::vector<RecRef> rr;
+            bool stop = false;
+            while (!stop) {
+                rr.clear();
+                size_t p = z.pos;
+                uint64_t co = cigar.size(), so = seq4.size();
+                while (p + 4 <= z.buf.size()) {
+                    const uint32_t bs = le32(z.buf.data() + p);
+                    if (bs < 32) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                    if (p + 4 + (size_t)bs > z.buf.size()) break; // the record continues in the next refill
+                    const uint8_t *rec = z.buf.data() + p + 4;
+                    const int32_t refID = (int32_t)le32(rec);
+                    if (refID != tid) {
+                        if (refID > tid || refID < 0) {
+                            stop = true;
+                            break;
+                        }
+                        p += 4 + (size_t)bs;
+                        continue;
+                    }
+                    const int32_t pos = (int32_t)le32(rec + 4);
+                    if (pos >= 0 && (uint32_t)pos >= zone_hi) { // coordinate-sorted: nothing further overlaps the zone
+                        stop = true;
+                        break;
+                    }
+                    bool take = (uint32_t)pos < L; // (fetch(tid, 0, len): records starting beyond the region are skipped)
+                    if (take && zone_lo > 0) { // reference end from the CIGAR: the record must reach the zone
+                        const uint32_t nc = rec[12] | (rec[13] << 8);
+                        const uint8_t *pc0 = rec + 32 + rec[8];
+                        if ((size_t)32 + rec[8] + (size_t)nc * 4 > bs) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                        uint64_t span = 0;
+                        for (uint32_t k = 0; k < nc; ++k) {
+                            const uint32_t w = le32(pc0 + 4 * k), op = w & 15;
+                            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
+                        }
+                        take = (uint64_t)pos + span > zone_lo;
+                    }
+                    if (take) {
+                        RecRef r;
+                        r.voff = z.voffset_at(p);
+                        r.off = p + 4;
+                        r.bs = bs;
+                        r.n_cigar = rec[12] | (rec[13] << 8);
+                        r.l_seq = le32(rec + 16);
+                        const uint32_t l_read_name = rec[8];
+                        if ((size_t)32 + l_read_name + (size_t)r.n_cigar * 4 + ((size_t)r.l_seq + 1) / 2 > bs)
+                            throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+                        r.cigar_off = co;
+                        r.seq_off = so;
+                        co += r.n_cigar;
+                        const uint32_t flag = rec[14] | (rec[15] << 8);
+                        if (!(opts->use_secondary && (flag & 0x100))) so += ((uint64_t)r.l_seq + 1) / 2;
+                        rr.push_back(r);
+                    }
+                    p += 4 + (size_t)bs;
+                }
+                const size_t r0 = recs.size();
+                recs.resize(r0 + rr.size());
+                if (voffs)
+                    for (auto &q : rr) voffs->push_back(q.voff);
+                cigar.resize(co);
+                if (!opts->use_secondary) {
+                    seq4.resize(so);
+                    IoPool::get().parallel_for(rr.size(), 64, [&](size_t i) {
+                        const RecRef &q = rr[i];
+                        const uint8_t *rec = z.buf.data() + q.off;
+                        const uint32_t l_read_name = rec[8];
+                        const uint8_t *pc = rec + 32 + l_read_name;
+                        np2_bamrec_t r;
+                        memset(&r, 0, sizeof r);
+                        r.pos = (int32_t)le32(rec + 4);
+                        r.flag = (uint16_t)(rec[14] | (rec[15] << 8));
+                        r.mapq = rec[9];
+                        r.n_cigar = q.n_cigar;
+                        r.cigar_off = q.cigar_off;
+                        r.l_seq = q.l_seq;
+                        r.seq_off = q.seq_off;
+                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
+                        memcpy(seq4.data() + q.seq_off, pc + (size_t)q.n_cigar * 4, ((size_t)q.l_seq + 1) / 2);
+                        recs[r0 + i] = r;
+                    });
+                } else {
+                    for (size_t i = 0; i < rr.size(); ++i) { // -S: secondary records take their SEQ from the primary's
+                        const RecRef &q = rr[i];
+                        const uint8_t *rec = z.buf.data() + q.off;
+                        const uint32_t l_read_name = rec[8], flag = rec[14] | (rec[15] << 8);
+                        const uint8_t *pc = rec + 32 + l_read_name;
+                        const uint8_t *ps = pc + (size_t)q.n_cigar * 4;
+                        np2_bamrec_t r;
+                        memset(&r, 0, sizeof r);
+                        r.pos = (int32_t)le32(rec + 4);
+                        r.flag = (uint16_t)flag;
+                        r.mapq = rec[9];
+                        r.n_cigar = q.n_cigar;
+                        r.cigar_off = q.cigar_off;
+                        r.l_seq = q.l_seq;
+                        r.seq_off = seq4.size();
+                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
+                        if (flag & 0x100) {
+                            // SEQ of the read's primary alignment, reverse-complemented again if this record is on the
+                            // reverse strand (main.rs:1775-1784).  A missing name leaves l_seq = 0: the reference would only
+                            // panic if the record passes the admission filters, and so do we (contig_from_records).
+                            const std::string qname((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0);
+                            const auto it = bam->sec.find(qname);
+                            r.l_seq = 0;
+                            if (it != bam->sec.end()) {
+                                r.l_seq = it->second.len;
+                                append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
+                            }
+                        } else {
+                            seq4.insert(seq4.end(), ps, ps + ((size_t)q.l_seq + 1) / 2);
+                        }
+                        recs[r0 + i] = r;
+                    }
+                }
+                z.pos = p;
+                if (stop) break;
+                if (z.eof) {
+                    if (z.pos != z.buf.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+                    break;
+                }
+                z.fill(z.batch_blocks);
+            }
+        }
+    seq4.resize(seq4.size() + 16, 0);
 }
 
 } // namespace
@@ -757,6 +995,7 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
             b->ref_lens.push_back(le32(h4));
         }
         b->ref_start.assign(n_ref, ~0ull);
+        b->lin.assign(n_ref, {});
         b->first_rec = b->z.tell();
         // index: <path>.bai or <stem>.bai
         std::string p1 = std::string(path) + ".bai", p2 = path;
@@ -795,7 +1034,11 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
                 }
             }
             const uint32_t n_intv = le32(idx.data() + p);
-            p += 4 + (size_t)n_intv * 8;
+            p += 4;
+            if (p + (size_t)n_intv * 8 > idx.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated .bai");
+            b->lin[r].resize(n_intv);
+            for (uint32_t w = 0; w < n_intv; ++w) b->lin[r][w] = le64(idx.data() + p + (size_t)w * 8);
+            p += (size_t)n_intv * 8;
             b->ref_start[r] = best;
         }
     } catch (const np2h::Np2Error &e) {
@@ -856,128 +1099,9 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         std::vector<np2_bamrec_t> recs;
         std::vector<uint32_t> cigar;
         PinnedBytes &seq4 = bam->seq4;
-        seq4.clear();
         const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
         const double t_p0 = np2h::now_ms();
-        if (opts->use_secondary) load_secondary_seqs(bam);
-        if (bam->ref_start[tid] != ~0ull) {
-            BgzfBatch &z = bam->batch;
-            z.f = bam->z.f;
-            z.seek(bam->ref_start[tid]);
-            // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
-            // length fields finds this contig's records, a prefix sum places their CIGAR words and SEQ bytes, and the
-            // copies run in parallel (records are independent byte ranges).
-            struct RecRef {
-                size_t off; // first byte after the record's block_size field, inside z.buf
-                uint32_t bs, n_cigar, l_seq;
-                uint64_t cigar_off, seq_off;
-            };
-            std::vector<RecRef> rr;
-            bool stop = false;
-            while (!stop) {
-                rr.clear();
-                size_t p = z.pos;
-                uint64_t co = cigar.size(), so = seq4.size();
-                while (p + 4 <= z.buf.size()) {
-                    const uint32_t bs = le32(z.buf.data() + p);
-                    if (bs < 32) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-                    if (p + 4 + (size_t)bs > z.buf.size()) break; // the record continues in the next refill
-                    const uint8_t *rec = z.buf.data() + p + 4;
-                    const int32_t refID = (int32_t)le32(rec);
-                    if (refID != tid) {
-                        if (refID > tid || refID < 0) {
-                            stop = true;
-                            break;
-                        }
-                        p += 4 + (size_t)bs;
-                        continue;
-                    }
-                    const int32_t pos = (int32_t)le32(rec + 4);
-                    if ((uint32_t)pos < L) { // (fetch(tid, 0, len): records starting beyond the region are skipped)
-                        RecRef r;
-                        r.off = p + 4;
-                        r.bs = bs;
-                        r.n_cigar = rec[12] | (rec[13] << 8);
-                        r.l_seq = le32(rec + 16);
-                        const uint32_t l_read_name = rec[8];
-                        if ((size_t)32 + l_read_name + (size_t)r.n_cigar * 4 + ((size_t)r.l_seq + 1) / 2 > bs)
-                            throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-                        r.cigar_off = co;
-                        r.seq_off = so;
-                        co += r.n_cigar;
-                        const uint32_t flag = rec[14] | (rec[15] << 8);
-                        if (!(opts->use_secondary && (flag & 0x100))) so += ((uint64_t)r.l_seq + 1) / 2;
-                        rr.push_back(r);
-                    }
-                    p += 4 + (size_t)bs;
-                }
-                const size_t r0 = recs.size();
-                recs.resize(r0 + rr.size());
-                cigar.resize(co);
-                if (!opts->use_secondary) {
-                    seq4.resize(so);
-                    IoPool::get().parallel_for(rr.size(), 64, [&](size_t i) {
-                        const RecRef &q = rr[i];
-                        const uint8_t *rec = z.buf.data() + q.off;
-                        const uint32_t l_read_name = rec[8];
-                        const uint8_t *pc = rec + 32 + l_read_name;
-                        np2_bamrec_t r;
-                        memset(&r, 0, sizeof r);
-                        r.pos = (int32_t)le32(rec + 4);
-                        r.flag = (uint16_t)(rec[14] | (rec[15] << 8));
-                        r.mapq = rec[9];
-                        r.n_cigar = q.n_cigar;
-                        r.cigar_off = q.cigar_off;
-                        r.l_seq = q.l_seq;
-                        r.seq_off = q.seq_off;
-                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
-                        memcpy(seq4.data() + q.seq_off, pc + (size_t)q.n_cigar * 4, ((size_t)q.l_seq + 1) / 2);
-                        recs[r0 + i] = r;
-                    });
-                } else {
-                    for (size_t i = 0; i < rr.size(); ++i) { // -S: secondary records take their SEQ from the primary's
-                        const RecRef &q = rr[i];
-                        const uint8_t *rec = z.buf.data() + q.off;
-                        const uint32_t l_read_name = rec[8], flag = rec[14] | (rec[15] << 8);
-                        const uint8_t *pc = rec + 32 + l_read_name;
-                        const uint8_t *ps = pc + (size_t)q.n_cigar * 4;
-                        np2_bamrec_t r;
-                        memset(&r, 0, sizeof r);
-                        r.pos = (int32_t)le32(rec + 4);
-                        r.flag = (uint16_t)flag;
-                        r.mapq = rec[9];
-                        r.n_cigar = q.n_cigar;
-                        r.cigar_off = q.cigar_off;
-                        r.l_seq = q.l_seq;
-                        r.seq_off = seq4.size();
-                        for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
-                        if (flag & 0x100) {
-                            // SEQ of the read's primary alignment, reverse-complemented again if this record is on the
-                            // reverse strand (main.rs:1775-1784).  A missing name leaves l_seq = 0: the reference would only
-                            // panic if the record passes the admission filters, and so do we (contig_from_records).
-                            const std::string qname((const char *)rec + 32, l_read_name ? l_read_name - 1 : 0);
-                            const auto it = bam->sec.find(qname);
-                            r.l_seq = 0;
-                            if (it != bam->sec.end()) {
-                                r.l_seq = it->second.len;
-                                append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
-                            }
-                        } else {
-                            seq4.insert(seq4.end(), ps, ps + ((size_t)q.l_seq + 1) / 2);
-                        }
-                        recs[r0 + i] = r;
-                    }
-                }
-                z.pos = p;
-                if (stop) break;
-                if (z.eof) {
-                    if (z.pos != z.buf.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
-                    break;
-                }
-                z.fill(z.batch_blocks);
-            }
-        }
-        seq4.resize(seq4.size() + 16, 0);
+        fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr);
         const double t_p1 = np2h::now_ms();
         contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
         if (prof)
@@ -994,6 +1118,135 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         return np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }
     return NP2_OK;
+}
+
+// ---- a reference-interval shard straight from the BAM -----------------------------------------------------------------
+// Each rank reads only the records overlapping its zone (own interval +- halo; .bai linear index), admits and
+// columnarises them on its GPU, and learns which of them are pushed (main.rs:1798-1813).  The contig-wide read numbers
+// (the reference numbers pushed records in file order, main.rs:1813) come from one exchange: every rank publishes
+// the BGZF virtual offsets of the pushed records that START in its own interval (it sees all of those); the lists,
+// concatenated in rank order, are the contig's pushed records in file order, and a record's number is 1 + its place.
+struct np2_shard_io {
+    np2_ctx *cx = nullptr;
+    FrontWork fw;
+    np2_shard_plan_t plan{};
+    uint32_t L = 0;
+    std::vector<uint64_t> rec_voff;  // per fetched record
+    std::vector<uint64_t> own_voff;  // pushed records starting in [own_lo, own_hi), file order
+};
+
+int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L, uint32_t own_lo,
+                        uint32_t own_hi, uint32_t halo, const np2_front_opts_t *opts, np2_shard_io_t **out,
+                        const uint64_t **own_voffsets, uint64_t *n_own) {
+    if (!cx || !bam || !name || !ref || !opts || !out || !own_voffsets || !n_own || own_lo >= own_hi || own_hi > L)
+        return NP2_E_ARG;
+    *out = nullptr;
+    np2_shard_io *io = new np2_shard_io();
+    io->cx = cx;
+    io->L = L;
+    try {
+        int tid = -1;
+        for (size_t i = 0; i < bam->ref_names.size(); ++i)
+            if (bam->ref_names[i] == name) tid = (int)i;
+        if (tid < 0) throw np2h::Np2Error(NP2_E_ARG, std::string("Faield random access BAM/SAM! (contig not in the BAM header: ") + name + ")");
+        np2_shard_plan_t &pl = io->plan;
+        pl.own_lo = own_lo, pl.own_hi = own_hi;
+        pl.zone_lo = own_lo > halo ? own_lo - halo : 0u;
+        pl.zone_hi = (uint64_t)own_hi + halo < L ? own_hi + halo : L;
+        std::vector<np2_bamrec_t> recs;
+        std::vector<uint32_t> cigar;
+        fetch_records(bam, tid, L, pl.zone_lo, pl.zone_hi, opts, recs, cigar, &io->rec_voff);
+        // the sub-contig: from the first start to the last reference end among the fetched records
+        uint32_t slo = pl.zone_lo, shi = pl.zone_hi;
+        for (const np2_bamrec_t &r : recs) {
+            uint64_t span = 0;
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                const uint32_t w = cigar[r.cigar_off + k], op = w & 15;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
+            }
+            if (r.pos >= 0) slo = std::min<uint32_t>(slo, (uint32_t)r.pos);
+            shi = (uint32_t)std::min<uint64_t>(L, std::max<uint64_t>(shi, (uint64_t)r.pos + span));
+        }
+        pl.sub_lo = own_lo == 0 ? 0u : (slo & ~63u);
+        pl.sub_hi = own_hi == L ? L : shi;
+        ShardSpec sp;
+        sp.sub_lo = pl.sub_lo, sp.sub_hi = pl.sub_hi, sp.zone_lo = pl.zone_lo, sp.zone_hi = pl.zone_hi;
+        front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), bam->seq4.data(), bam->seq4.size(), opts, &sp,
+                    io->fw);
+        for (size_t i = 1; i < io->fw.reads.size(); ++i) {
+            const np2_bamrec_t &r = recs[io->fw.rec_of[i]];
+            if ((uint32_t)r.pos >= own_lo && (uint32_t)r.pos < own_hi) io->own_voff.push_back(io->rec_voff[io->fw.rec_of[i]]);
+        }
+        np2h::flush_timings(cx);
+    } catch (const np2h::Np2Error &e) {
+        (void)hipStreamSynchronize(cx->stream);
+        delete io;
+        return np2h::fail(cx, e);
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        delete io;
+        return np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
+    }
+    *own_voffsets = io->own_voff.data();
+    *n_own = io->own_voff.size();
+    *out = io;
+    return NP2_OK;
+}
+
+void np2_shard_bam_abort(np2_shard_io_t *io) { delete io; }
+
+int np2_shard_bam_finish(np2_shard_io_t *io, const uint64_t *all_voffsets, uint64_t n_all, np2_shard_plan_t *plan,
+                         np2_contig_t **contig, uint32_t *n_reads_total) {
+    if (!io || (n_all && !all_voffsets) || !plan || !contig || !n_reads_total) return NP2_E_ARG;
+    np2_ctx *cx = io->cx;
+    *contig = nullptr;
+    int rc = NP2_OK;
+    try {
+        FrontWork &fw = io->fw;
+        // contig-wide number of every pushed record this shard fetched
+        const size_t n = fw.reads.size();
+        std::vector<uint32_t> gid(n, 0);
+        for (size_t i = 1; i < n; ++i) {
+            const uint64_t v = io->rec_voff[fw.rec_of[i]];
+            const uint64_t *it = std::lower_bound(all_voffsets, all_voffsets + n_all, v);
+            if (it == all_voffsets + n_all || *it != v)
+                throw np2h::Np2Error(NP2_E_ARG, "shard: a pushed record is missing from the exchanged offsets (do the ranks' own intervals tile the contig?)");
+            gid[i] = 1 + (uint32_t)(it - all_voffsets);
+            if (i > 1 && gid[i] <= gid[i - 1]) throw np2h::Np2Error(NP2_E_ARG, "shard: exchanged offsets are not in file order");
+        }
+        np2_shard_plan_t &pl = io->plan;
+        pl.read_lo = n > 1 ? gid[1] : 1u;
+        pl.read_hi = n > 1 ? gid[n - 1] + 1 : 1u;
+        // holes: reads of the contig inside [read_lo, read_hi) this shard does not hold keep their number
+        std::vector<np2_read_t> reads(1 + (size_t)(pl.read_hi - pl.read_lo));
+        std::vector<uint8_t> lable(reads.size(), 0);
+        np2_read_t hole;
+        memset(&hole, 0, sizeof hole);
+        hole.flags = NP2_READ_DROPPED;
+        hole.nib_off = 0; // (never decoded; slot 0 is a valid aligned offset)
+        std::fill(reads.begin(), reads.end(), hole);
+        reads[0] = fw.reads[0];
+        for (size_t i = 1; i < n; ++i) {
+            reads[gid[i] - pl.read_lo + 1] = fw.reads[i];
+            lable[gid[i] - pl.read_lo + 1] = fw.lable[i];
+        }
+        fw.reads.swap(reads);
+        fw.lable.swap(lable);
+        np2_contig *c = nullptr;
+        front_finish(cx, fw, &c);
+        *contig = c;
+        *plan = pl;
+        *n_reads_total = 1 + (uint32_t)n_all;
+        np2h::flush_timings(cx);
+    } catch (const np2h::Np2Error &e) {
+        (void)hipStreamSynchronize(cx->stream);
+        rc = np2h::fail(cx, e);
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        rc = np2h::fail(cx, np2h::Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
+    }
+    delete io;
+    return rc;
 }
 
 int np2_contig_export(np2_ctx_t *cx, np2_contig_t *c, np2_read_t **reads, uint32_t *n_reads, uint8_t **nibbles,

@@ -152,6 +152,63 @@ def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=
     return stitch_shards(pieces, plans, verify)
 
 
+def polish_sharded_bam(polisher, bam, name, ref, opts=None, fopts=None, halo=65536, verify=1024, device=None, group=None):
+    """polish_sharded with the input side sharded too: every rank reads only the BAM records overlapping its interval
+    +- halo (io.ShardFromBam), the ranks all-gather the file offsets of the pushed records starting in their own
+    intervals (that list IS the contig's read numbering), then the shard protocol runs on the resident shards."""
+    from . import io as np2io
+    from .api import ShardRun, Vote, vote_decide
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cuts = np2io.shard_cuts(len(ref), world)
+    sb = np2io.ShardFromBam(polisher, bam, name, ref, cuts[rank][0], cuts[rank][1], halo, fopts)
+    raws = all_gather_bytes(sb.own_offsets.tobytes(), device=device, group=group)
+    all_off = np.concatenate([np.frombuffer(x, dtype=np.uint64) for x in raws]) if raws else np.zeros(0, dtype=np.uint64)
+    h, plan, n_reads_total = sb.finish(all_off)
+    run = ShardRun(polisher, None, plan, opts, verify, resident=h)
+    plans_raw = all_gather_bytes(bytes(plan), device=device, group=group)
+    plans = [type(plan).from_buffer_copy(x) for x in plans_raw]
+    try:
+        while run.passes_left() > 1:
+            raws = all_gather_bytes(run.vote().to_bytes(), device=device, group=group)
+            run.apply(vote_decide([Vote.from_bytes(x) for x in raws], n_reads_total, opts))
+        b, p = run.final()
+    finally:
+        run.close()
+    hdr = np.array([len(b)], dtype=np.uint64).tobytes()
+    raws = all_gather_bytes(hdr + np.asarray(b).tobytes() + np.asarray(p).tobytes(), device=device, group=group)
+    pieces = []
+    for x in raws:
+        n = int(np.frombuffer(x[:8], dtype=np.uint64)[0])
+        pieces.append((np.frombuffer(x[8:8 + n], dtype=np.uint8), np.frombuffer(x[8 + n:8 + 5 * n], dtype=np.uint32)))
+    return stitch_shards(pieces, plans, verify)
+
+
+def polish_sharded_bam_local(polisher, bam_path, name, ref, n_shards, opts=None, fopts=None, halo=65536, verify=1024):
+    """The single-process form of polish_sharded_bam (one context + one BAM handle per shard): tests, single-GPU runs."""
+    from . import io as np2io
+    from .api import ShardRun, vote_decide
+    cuts = np2io.shard_cuts(len(ref), n_shards)
+    ctxs = [polisher.clone() for _ in range(n_shards)]
+    bams = [np2io.Bam(bam_path) for _ in range(n_shards)]
+    sbs = [np2io.ShardFromBam(ctxs[k], bams[k], name, ref, cuts[k][0], cuts[k][1], halo, fopts) for k in range(n_shards)]
+    all_off = np.concatenate([sb.own_offsets for sb in sbs])
+    fin = [sb.finish(all_off) for sb in sbs]
+    plans = [f[1] for f in fin]
+    n_reads_total = fin[0][2]
+    runs = [ShardRun(ctxs[k], None, plans[k], opts, verify, resident=fin[k][0]) for k in range(n_shards)]
+    try:
+        while runs[0].passes_left() > 1:
+            losers = vote_decide([r.vote() for r in runs], n_reads_total, opts)
+            for r in runs:
+                r.apply(losers)
+        pieces = [r.final() for r in runs]
+    finally:
+        for r in runs:
+            r.close()
+    return stitch_shards(pieces, plans, verify)
+
+
 class _DeviceBytes:
     """Zero-copy view of `n` bytes at device address `ptr` for torch.as_tensor (array-interface protocol)."""
 

@@ -59,8 +59,18 @@ def _bind():
                                               C.POINTER(vp)]
         L.np2_contig_from_bam.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.POINTER(np2_front_opts_t), C.POINTER(vp)]
         L.np2_contig_export.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        _bind_shard(L)
         _BOUND = True
     return L
+
+
+def _bind_shard(L):
+    from ._types import np2_shard_plan_t
+    vp = C.c_void_p
+    L.np2_shard_bam_begin.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.np2_shard_bam_finish.argtypes = [vp, vp, C.c_uint64, C.POINTER(np2_shard_plan_t), C.POINTER(vp), C.POINTER(C.c_uint32)]
+    L.np2_shard_bam_abort.argtypes = [vp]
+    L.np2_shard_bam_abort.restype = None
 
 
 def _io_check(rc):
@@ -164,6 +174,51 @@ def contig_from_records(pol, ref, recs, cigar, seq4, opts=None, name="ctg"):
     pol._check(L.np2_contig_from_records(pol._h, ref.ctypes.data, ref.shape[0], recs.ctypes.data, recs.shape[0],
                                          cigar.ctypes.data, seq4.ctypes.data, C.byref(o), C.byref(h)))
     return _resident(pol, h, name, int(ref.shape[0]))
+
+
+def shard_cuts(L_, n_shards):
+    """The owned intervals np2_shard_plan gives a contig of L_ positions: cuts at L * k / n rounded down to 1024."""
+    cuts = [0] + [((L_ * k) // n_shards) & ~1023 for k in range(1, n_shards)] + [L_]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+class ShardFromBam:
+    """One reference interval of a contig read straight from the BAM (np2_shard_bam_*): begin() fetches, admits and
+    columnarises the records overlapping the interval +- halo and returns the file offsets this rank contributes to
+    the numbering exchange; finish(all_offsets) returns (np2_contig_t* of the shard, its plan, the contig's read count)."""
+
+    def __init__(self, pol, bam, name, ref, own_lo, own_hi, halo=65536, opts=None):
+        from ._types import np2_shard_plan_t
+        L = _bind()
+        self._pol = pol
+        ref = np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else np.ascontiguousarray(ref, dtype=np.uint8)
+        self._ref = ref
+        o = (opts or FrontOpts()).c()
+        self._io = C.c_void_p()
+        pv, n = C.c_void_p(), C.c_uint64()
+        pol._check(L.np2_shard_bam_begin(pol._h, bam._h, name.encode(), ref.ctypes.data, ref.shape[0], own_lo, own_hi, halo,
+                                         C.byref(o), C.byref(self._io), C.byref(pv), C.byref(n)))
+        self.own_offsets = (np.frombuffer((C.c_uint8 * (8 * n.value)).from_address(pv.value), dtype=np.uint64).copy()
+                            if n.value else np.zeros(0, dtype=np.uint64))
+        self._plan_t = np2_shard_plan_t
+
+    def finish(self, all_offsets):
+        L = _bind()
+        a = np.ascontiguousarray(all_offsets, dtype=np.uint64)
+        plan = self._plan_t()
+        h = C.c_void_p()
+        n_total = C.c_uint32()
+        io, self._io = self._io, None
+        self._pol._check(L.np2_shard_bam_finish(io, a.ctypes.data, len(a), C.byref(plan), C.byref(h), C.byref(n_total)))
+        return h, plan, n_total.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_io", None):
+                _bind().np2_shard_bam_abort(self._io)
+                self._io = None
+        except Exception:
+            pass
 
 
 def export_contig(pol, contig, ref):

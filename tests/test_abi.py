@@ -10,8 +10,8 @@ from nextpolish2_amd import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "np2.h")).read()
+def header_symbols(name="np2.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(np2_[a-z_0-9]+)\s*\(", txt)))
 
@@ -23,8 +23,12 @@ def test_header_declares_expected_entry_points():
 
 def test_library_exports_every_declared_symbol():
     L = api.lib()
-    for s in header_symbols():
+    for s in header_symbols() + header_symbols("np2_io.h"):
         assert hasattr(L, s), s
+
+
+def test_io_header_declares_expected_entry_points():
+    assert set(header_symbols("np2_io.h")) == set(api.IO_ABI_SYMBOLS)
 
 
 def test_struct_layouts_match_header():

@@ -170,3 +170,58 @@ def test_full_size_chr1_single_gpu_and_two_intervals():
     c.free()
     b3, p3 = polish_sharded_local(pol, pu, Opts(), n_shards=2)
     assert np.array_equal(b1, b3) and np.array_equal(p1, p3)
+
+
+def test_shards_read_straight_from_the_bam_number_their_reads_contig_wide(tmp_path):
+    """np2_shard_bam_*: every shard parses only the records overlapping its interval +- halo; the exchanged file offsets
+    give every pushed record its contig-wide number; stitched result == whole-contig BAM path == oracle front end + polish."""
+    import gzip  # noqa: F401
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import pileup_to_records, records_to_arrays, write_bam
+    from nextpolish2_amd.dist import polish_sharded_bam_local
+    s = Synth(420000, depth=25, seed=895, diploid=True, read_len_mean=8000.0, read_len_sd=1200.0, name="long1")
+    other = Synth(30000, depth=10, seed=896, name="other")
+    recs = pileup_to_records(other.pileup, tid=0, rng=np.random.default_rng(5), decorate=True) + \
+        pileup_to_records(s.pileup, tid=1, rng=np.random.default_rng(6), decorate=True)  # clips, secondaries, low mapq ...
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    bam_path = str(tmp_path / "m.bam")
+    write_bam(bam_path, [("other", other.pileup.L), ("long1", s.pileup.L)], recs)
+    yaks = [s.yak(21), s.yak(31)]
+    pol = Polisher(yaks)
+    ref = s.pileup.ref.tobytes()
+    bam = np2io.Bam(bam_path)
+    whole = np2io.contig_from_bam(pol, bam, "long1", ref)
+    b0, p0 = pol.polish_resident(whole, Opts())
+    whole_pu = np2io.export_contig(pol, whole, ref)
+    whole.free()
+    for n_shards, halo in ((2, 40000), (3, 25000)):
+        # the shards' read lists, renumbered, are slices of the whole contig's read list
+        cuts = np2io.shard_cuts(len(ref), n_shards)
+        ctxs = [pol.clone() for _ in cuts]
+        sbs = [np2io.ShardFromBam(ctxs[k], np2io.Bam(bam_path), "long1", ref, lo, hi, halo) for k, (lo, hi) in enumerate(cuts)]
+        all_off = np.concatenate([sb.own_offsets for sb in sbs])
+        assert len(all_off) == whole_pu.n_reads - 1 and np.all(np.diff(all_off.astype(np.int64)) > 0)
+        for k, sb in enumerate(sbs):
+            h, plan, n_total = sb.finish(all_off)
+            assert n_total == whole_pu.n_reads and (plan.own_lo, plan.own_hi) == cuts[k]
+            from nextpolish2_amd.io import _resident
+            rc = _resident(ctxs[k], h, "long1", plan.sub_hi - plan.sub_lo)  # (owns the shard contig; freed below)
+            sh = np2io.export_contig(ctxs[k], rc, ref[plan.sub_lo:plan.sub_hi])
+            assert sh.n_reads == 1 + plan.read_hi - plan.read_lo
+            for i in range(1, sh.n_reads):
+                g = whole_pu.reads[plan.read_lo + i - 1]
+                if sh.reads["flags"][i] & 1:
+                    continue  # a hole / a read outside the zone / one the clip filter emptied (checked below)
+                assert sh.reads["aln_t_s"][i] + plan.sub_lo == g["aln_t_s"] and sh.reads["aln_t_e"][i] + plan.sub_lo == g["aln_t_e"]
+                assert sh.reads["n_cols"][i] == g["n_cols"] and not (g["flags"] & 1)
+            held = [i for i in range(1, sh.n_reads) if not sh.reads["flags"][i] & 1]
+            must = [r for r in range(plan.read_lo, plan.read_hi) if not whole_pu.reads["flags"][r] & 1
+                    and whole_pu.reads["aln_t_e"][r] >= plan.zone_lo and whole_pu.reads["aln_t_s"][r] < plan.zone_hi]
+            assert [plan.read_lo + i - 1 for i in held] == must
+            rc.free()
+        b1, p1 = polish_sharded_bam_local(pol, bam_path, "long1", ref, n_shards, Opts(), halo=halo)
+        assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
+    arr, cig, seq4, asc, asc_off = records_to_arrays([r for r in recs if r["tid"] == 1])
+    pu = orc.front_end(ref, arr, cig, asc, asc_off, np2io.FrontOpts())
+    ob, op = orc.Oracle(yaks).polish(pu, Opts())
+    assert np.array_equal(ob, b0) and np.array_equal(op, p0)
