@@ -119,6 +119,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
     //      already running waves, which publish within a microsecond of starting ---------------------------------------
     __shared__ uint32_t s_total[8]; // counts of the block's 8 chunks (4 waves x 2): most of a read's chunks are in here
+    __shared__ uint32_t s_own[4][64]; // per wave: owner lane of each record rank (emission)
     const uint32_t blk_first = np2_bid * 8;
     N128 w_[2], V_[2], I_[2];
     uint32_t nv_[2], nonins_[2], incl_[2], total_[2];
@@ -347,30 +348,64 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             }
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 1);
             const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 2);
-            uint32_t o = inc2 - cnt; // rank of the lane's first record within the wave
-            N128 e = E;
-            while (e.lo | e.hi) { // raw record: t_pos << 32 | column, read
-                const uint32_t j = n_ctz(e) >> 2;
-                const N128 m = n_mask_through_first(e); // columns 0 .. j
-                e.lo &= ~m.lo;
-                e.hi &= ~m.hi;
-                const uint32_t t = t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1; // non-insertion columns up to j
-                const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
-                const uint32_t slot = (g == 0 ? g0 + o : (g == 1 ? g1 + (o - nb1) : g2 + (o - nb2)));
-                uint64_t dst;
-                bool ok = tA + g < n_tiles;
-                if (slot < bucket_cap) {
-                    dst = (uint64_t)(tA + g) * bucket_cap + slot;
-                } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
-                    const uint32_t x = atomicAdd(ovf_cnt, 1u);
-                    dst = ovf_base + x;
-                    ok = ok && x < ovf_cap;
+            // Raw records (t_pos << 32 | column, read), one LANE per record: the chunk's ~36 records sit in a dozen lanes, so
+            // a per-lane loop runs at the pace of the busiest lane with most of the wave idle.  Record rank R finds its
+            // owner lane through a head table in LDS (owner id at its first rank, running maximum across the wave), pulls
+            // the owner's masks with shuffles and selects its (R - first rank)-th exception column.
+            const uint32_t o_first = inc2 - cnt; // rank of the lane's first record within the wave
+            // (volatile: other lanes of the wave write the entry a lane reads back; LDS operations of one wave execute in
+            // program order, the compiler must not forward the lane's own zero)
+            volatile uint32_t *own_tab = s_own[threadIdx.x >> 6];
+            for (uint32_t rbase = 0; rbase < tot; rbase += 64) {
+                own_tab[lane] = 0;
+                if (cnt && o_first < rbase + 64 && o_first + cnt > rbase) own_tab[max(o_first, rbase) - rbase] = lane + 1;
+                const uint32_t own1 = wave_incl_scan<OpMaxU32>(own_tab[lane]);
+                const uint32_t R = rbase + lane;
+                const bool act = R < tot;
+                const uint32_t own = (act && own1) ? own1 - 1 : lane;
+                const uint32_t e0 = __shfl((uint32_t)E.lo, own), e1 = __shfl((uint32_t)(E.lo >> 32), own);
+                const uint32_t e2 = __shfl((uint32_t)E.hi, own), e3 = __shfl((uint32_t)(E.hi >> 32), own);
+                const uint32_t i0 = __shfl((uint32_t)NI.lo, own), i1 = __shfl((uint32_t)(NI.lo >> 32), own);
+                const uint32_t i2 = __shfl((uint32_t)NI.hi, own), i3 = __shfl((uint32_t)(NI.hi >> 32), own);
+                const uint32_t ot0 = __shfl(t0, own), oo = __shfl(o_first, own);
+                if (act) {
+                    // column of the (R - oo)-th flag of the owner's exception mask (flags at bit 3 of the nibbles)
+                    uint32_t k = R - oo + 1, col = 0, m8;
+                    const uint32_t cA = __builtin_popcount(e0), cB = __builtin_popcount(e1), cC = __builtin_popcount(e2);
+                    if (k <= cA) {
+                        m8 = e0;
+                    } else if (k <= cA + cB) {
+                        k -= cA, col = 8, m8 = e1;
+                    } else if (k <= cA + cB + cC) {
+                        k -= cA + cB, col = 16, m8 = e2;
+                    } else {
+                        k -= cA + cB + cC, col = 24, m8 = e3;
+                    }
+                    uint32_t c = __builtin_popcount(m8 & 0xFFFFu);
+                    if (k > c) k -= c, col += 4, m8 >>= 16;
+                    c = __builtin_popcount(m8 & 0xFFu);
+                    if (k > c) k -= c, col += 2, m8 >>= 8;
+                    c = __builtin_popcount(m8 & 0xFu);
+                    if (k > c) col += 1;
+                    const N128 thr = n_below(col + 1); // columns 0 .. col of the owner lane
+                    const N128 oNI{(uint64_t)i0 | ((uint64_t)i1 << 32), (uint64_t)i2 | ((uint64_t)i3 << 32)};
+                    const uint32_t t = ot0 + n_popc(N128{oNI.lo & thr.lo, oNI.hi & thr.hi}) - 1; // non-insertion columns up to it
+                    const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
+                    const uint32_t slot = (g == 0 ? g0 + R : (g == 1 ? g1 + (R - nb1) : g2 + (R - nb2)));
+                    uint64_t dst;
+                    bool ok = tA + g < n_tiles;
+                    if (slot < bucket_cap) {
+                        dst = (uint64_t)(tA + g) * bucket_cap + slot;
+                    } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
+                        const uint32_t x = atomicAdd(ovf_cnt, 1u);
+                        dst = ovf_base + x;
+                        ok = ok && x < ovf_cap;
+                    }
+                    if (ok) {
+                        out_keys[dst] = ((uint64_t)t << 32) | (c0 + own * 32 + col);
+                        out_vals[dst] = d.read;
+                    }
                 }
-                if (ok) {
-                    out_keys[dst] = ((uint64_t)t << 32) | (lc0 + j);
-                    out_vals[dst] = d.read;
-                }
-                ++o;
             }
         }
         if (lane == 0 && c0 + 2048 >= ncols) {
