@@ -264,7 +264,10 @@ def main():
     if single:
         drain_single(out)
     groups.set_timing(True)  # HIP events around the batched k_diff_reads launches, on the batch streams
-    diff_ms, diff_launches = [], 0
+    diff_ms, diff_launches, call_ms = [], 0, []
+    import gc
+    gc.collect()
+    gc.disable()  # (the cyclic collector's pauses over the ctypes wrappers would be charged to the steps)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -273,12 +276,14 @@ def main():
             ms, k = pol.timings().get("diff_reads", 0.0), 1
         else:
             ms, k = groups.diff_ms()
+        call_ms.append(sum(getattr(b, "last_call_ms", 0.0) for b in groups.bps))
         diff_ms.append(ms)
         diff_launches = k
     if single:
         out = drain_single(out)  # every polished sequence is on the host before the clock stops
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     groups.set_timing(False)
     bases = [np.array(o[0]) for o in out]
     spans = [o[1] for o in out]
@@ -322,7 +327,8 @@ def main():
                      "avg_launch_ms": round(avg_ms / max(1, diff_launches), 4),
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},
         "flush_ms": {"per_group_totals_host_issue_wait": [[round(sum(f[j] for f in fl), 3) for j in range(3)] for fl in flush_log],
-                     "flushes_per_step": [len(fl) for fl in flush_log]},
+                     "flushes_per_step": [len(fl) for fl in flush_log],
+                     "batch_call_ms_mean": round(float(np.mean(call_ms)), 3) if call_ms and not single else None},
     }
 
     if rank == 0 and not a.no_cpu_baseline:

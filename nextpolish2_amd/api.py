@@ -353,8 +353,11 @@ class BatchPolisher:
         on = (C.c_uint64 * n)()
         rcs = (C.c_int * n)()
         span = (C.c_uint32 * (2 * n))()
+        import time as _t
+        _t0 = _t.perf_counter()
         rc = lib().np2_batch_polish(self._h, hs, n, C.byref(o), None if keep_on_device else ob,
                                     op if (want_pos and not keep_on_device) else None, on, span, rcs)
+        self.last_call_ms = (_t.perf_counter() - _t0) * 1e3  # the C call alone (bench.py reports it next to the step time)
         if rc != 0:
             raise Np2Error(rc, lib().np2_batch_last_error(self._h).decode())
         out = []

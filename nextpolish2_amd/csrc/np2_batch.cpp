@@ -63,7 +63,8 @@ struct np2_batch {
 
     // HIP-event timing of the batched dense kernel (bench roofline): pairs recorded around its launches
     bool time_diff = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> diff_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> diff_events; // created once, reused by every call
+    size_t diff_used = 0;
     float last_diff_ms = 0;
     int last_diff_launches = 0;
     uint64_t stat_launches = 0, stat_cmds = 0, stat_flushes = 0;
@@ -124,16 +125,19 @@ void flush(np2_batch *b) {
             const bool timed = b->time_diff && strcmp(best->name, "k_diff_reads") == 0;
             auto issue = [&]() {
                 if (!m) return;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {
-                    HIPCHK(hipEventCreate(&e0));
-                    HIPCHK(hipEventCreate(&e1));
-                    HIPCHK(hipEventRecord(e0, s));
+                    if (b->diff_used == b->diff_events.size()) {
+                        hipEvent_t e0 = nullptr, e1 = nullptr;
+                        HIPCHK(hipEventCreate(&e0));
+                        HIPCHK(hipEventCreate(&e1));
+                        b->diff_events.push_back({e0, e1});
+                    }
+                    HIPCHK(hipEventRecord(b->diff_events[b->diff_used].first, s));
                 }
                 best->launch(s, m, grids, args);
                 if (timed) {
-                    HIPCHK(hipEventRecord(e1, s));
-                    b->diff_events.push_back({e0, e1});
+                    HIPCHK(hipEventRecord(b->diff_events[b->diff_used].second, s));
+                    ++b->diff_used;
                 }
                 ++b->stat_launches;
                 m = 0;
@@ -318,13 +322,7 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
     if (!b || !contigs || n < 0 || !opts || !out_len || !rcs) return NP2_E_ARG;
     const int S = (int)b->slots.size();
     int worst = NP2_OK;
-    if (b->time_diff) {
-        for (auto &e : b->diff_events) {
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
-        }
-        b->diff_events.clear();
-    }
+    b->diff_used = 0;
     b->flush_log.clear();
     b->t_last_end = now_ms();
     for (int w0 = 0; w0 < n; w0 += S) { // waves of at most S contigs; contig w0 + i runs on slot i
@@ -366,11 +364,11 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
     }
     if (b->time_diff) {
         b->last_diff_ms = 0;
-        b->last_diff_launches = (int)b->diff_events.size();
-        for (auto &e : b->diff_events) {
+        b->last_diff_launches = (int)b->diff_used;
+        for (size_t i = 0; i < b->diff_used; ++i) {
             float ms = 0;
-            (void)hipEventSynchronize(e.second);
-            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            (void)hipEventSynchronize(b->diff_events[i].second);
+            (void)hipEventElapsedTime(&ms, b->diff_events[i].first, b->diff_events[i].second);
             b->last_diff_ms += ms;
         }
     }
