@@ -186,6 +186,7 @@ def main(argv=None):
                             use_secondary=a.use_secondary)
     n_workers = max(1, min(4, a.thread))
     tls = threading.local()
+    base, base_lock = [], threading.Lock()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.device is None:
         a.device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
@@ -195,7 +196,12 @@ def main(argv=None):
     def polish(name, seq):
         """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
         if getattr(tls, "pol", None) is None:
-            tls.pol = Polisher(yaks, device=a.device)
+            with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
+                if not base:
+                    base.append(Polisher(yaks, device=a.device))
+                    tls.pol = base[0]
+                else:
+                    tls.pol = base[0].clone()
             tls.bam = np2io.Bam(a.bam)
         contig = np2io.contig_from_bam(tls.pol, tls.bam, name, seq, fopts)
         try:
