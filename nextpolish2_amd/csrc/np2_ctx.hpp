@@ -240,6 +240,8 @@ struct np2_ctx {
     DevBuf<int64_t> run_gain, tile_gain;
     DevBuf<uint8_t> out_snap;
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
+    uint32_t deep_min = 65536; // coverage from which the on-chip DP of short runs is off (NP2_TEST_DEEP_COV lowers it: tests)
+    DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
@@ -251,7 +253,7 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_STUCK, S_NAP, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 24 };
+            S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 24 };
 
 static constexpr int NP2_MAX_YAK = 15; // splice rounds 0 .. n_yak index mlen[16] and the counters behind S_COUNT
 static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it

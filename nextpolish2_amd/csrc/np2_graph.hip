@@ -398,7 +398,8 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
                                                     const uint32_t *__restrict__ tile_rd_off,
                                                     const uint32_t *__restrict__ tile_rd, int32_t *__restrict__ cov,
                                                     const uint8_t *__restrict__ refnib, uint32_t *__restrict__ emit,
-                                                    long long *__restrict__ tile_gain) {
+                                                    long long *__restrict__ tile_gain, uint32_t *__restrict__ deep_flag,
+                                                    int32_t deep_min) {
     __shared__ uint32_t cnt[TILE];
     __shared__ int32_t dcov[TILE + 1];
     __shared__ uint32_t sh[8];
@@ -455,6 +456,8 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
         cv[0] = pre + d0, cv[1] = cv[0] + d1, cv[2] = cv[1] + d2, cv[3] = cv[2] + d3;
         for (uint32_t j = 0; j < 4; ++j)
             if (q + j < npos) cov[start + q + j] = cv[j];
+        // the on-chip DP of short runs keeps coverages and counts in 16 bits: tell it when that does not hold
+        if (max(max(cv[0], cv[1]), max(cv[2], cv[3])) >= deep_min) atomicOr(deep_flag, 1u); // (65536; lower in a test)
     }
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
@@ -648,8 +651,8 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain) {
-    NP2_LAUNCH(k_tile_write, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd, cov, refnib, emit, tile_gain);
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min) {
+    NP2_LAUNCH(k_tile_write, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd, cov, refnib, emit, tile_gain, deep_flag, (int32_t)deep_min);
 }
 
 } // namespace np2

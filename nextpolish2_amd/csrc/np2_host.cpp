@@ -593,7 +593,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
                       cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
                       c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p, c->refnib.p, cx->emit.p,
-                      (long long *)cx->tile_gain.p);
+                      (long long *)cx->tile_gain.p, cx->scal.p + S_DEEP /* reset by launch_tile_offsets above */, cx->deep_min);
     // no read-back: downstream kernels are launched with the bound below and check the device-side counters
     n_runs = std::min<uint32_t>(T, L);
     n_nodes = T;
@@ -602,7 +602,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
 
 GraphPtrs graph_ptrs(np2_ctx *cx, np2_contig *c) {
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
-    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L, cx->nrec.p};
+    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L, cx->nrec.p, cx->scal.p + S_DEEP};
 }
 
 void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
@@ -683,18 +683,28 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
         // long runs on the second stream, short runs on the main one: the kernels touch disjoint runs and the long
         // kernel is a latency chain (a few lanes walking runs of dozens of positions) that would otherwise sit alone
         // on the device for as long as the short kernel takes
+        // Under the batch driver the launches of a group share one stream: the short kernel goes first and lists the
+        // runs it leaves alone, so that the long-run kernels walk that list instead of classifying every run again.
         const bool forked = tl_recorder() == nullptr; // (recorded launches all go to the group's one stream)
+        uint32_t *dp_list = nullptr, *n_dp_list = nullptr;
         if (forked) {
             HIPCHK(hipEventRecord(cx->ev_fork, s));
             HIPCHK(hipStreamWaitEvent(cx->stream2, cx->ev_fork, 0));
+        } else {
+            cx->dp_list.ensure((size_t)n_runs + 2);
+            dp_list = cx->dp_list.p, n_dp_list = cx->scal.p + S_NDPLIST; // (zeroed with the per-pass scalars)
+            launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p,
+                            cx->run_gain.p, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, dp_list, n_dp_list);
         }
         launch_dp_long(cx->stream2, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
                        cx->nbesti.p, cx->n0_besti.p, cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), cx->run_gain.p,
-                       cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, cx->run_flag.p);
-        if (forked) HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
-        launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p, cx->run_gain.p,
-                        cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
-        if (forked) HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
+                       cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, cx->run_flag.p, dp_list, n_dp_list);
+        if (forked) {
+            HIPCHK(hipEventRecord(cx->ev_join, cx->stream2));
+            launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p,
+                            cx->run_gain.p, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, nullptr, nullptr);
+            HIPCHK(hipStreamWaitEvent(s, cx->ev_join, 0));
+        }
         launch_dp_finish(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, cx->nscore.p, cx->nbesti.p, cx->n0_besti.p,
                          (const int64_t *)(cx->scal.p + S_LAST0), (unsigned long long *)(cx->scal.p + S_GAIN0),
                          cx->scal.p + S_DUP /* block counter: reset with the per-pass scalars */, cx->scal.p + S_BEST,
@@ -1138,6 +1148,8 @@ static void init_ctx_device(np2_ctx *cx, int device) {
     HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
     if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
         cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
+    if (const char *e = getenv("NP2_TEST_DEEP_COV")) // test hook: treat shallower pileups as too deep for the on-chip DP
+        cx->deep_min = (uint32_t)std::min<long>(65536, std::max<long>(1, atol(e)));
 }
 
 int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak) {

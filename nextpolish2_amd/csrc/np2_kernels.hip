@@ -485,6 +485,7 @@ struct Graph {
     const int32_t *cov;
     uint32_t L;
     const uint2 *nrec; // packed node records {bases | delta << 16, count}
+    const uint32_t *deep; // != 0: some position of this pass is covered 65536x or more (no run is "short" then)
 };
 __device__ __forceinline__ void n0_key(const Graph &g, uint32_t p, uint16_t &bases, uint16_t &delta) {
     const uint8_t c = ref_code(g.refnib, p);
@@ -525,12 +526,15 @@ __device__ __forceinline__ int64_t early_run_base(const Graph &g, uint32_t a) {
 }
 
 // ---- run classes ---------------------------------------------------------------------------------------------------------
-// A "short" run (99.9 % of them at HiFi error rates) has at most RW_P - 1 dirty positions followed by a clean one (inside the contig) and at most RW_N
-// exception nodes: k_dp_bt_short scores and backtracks it entirely on chip.  Everything else (long runs, the run that
-// reaches the contig end) goes to k_dp_bt_long.  Both kernels classify for themselves from the node offsets, so they
-// need no hand-over and can run side by side on two streams.
+// A "short" run (the great majority at HiFi error rates) has at most RW_P - 1 dirty positions followed by a clean one
+// (inside the contig) and at most RW_N exception nodes: k_dp_bt_short scores and backtracks it entirely on chip, with
+// 16-bit coverages / counts and 32-bit scores relative to the run's left neighbour — which is why a pass that has a
+// position covered 65536x or more (Graph::deep, set by k_tile_write) has no short runs at all.  Everything else (long
+// or node-rich runs, the run that reaches the contig end) goes to the eight-lane kernel.  The kernels either classify
+// for themselves from the node offsets (no hand-over: they can run side by side on two streams) or the short kernel
+// lists what it leaves alone (batch driver: one stream).
 static constexpr uint32_t RW_P = 13; // positions of a short run kept on chip: up to 12 dirty ones + the closing clean one
-static constexpr uint32_t RW_N = 16; // exception nodes of a short run kept on chip
+static constexpr uint32_t RW_N = 8;  // exception nodes of a short run kept on chip (149 bytes of LDS per run: 16 waves per CU; 12 nodes / 12 waves measured slower)
 struct __attribute__((packed, aligned(4))) U32x4 {
     uint32_t x, y, z, w;
 };
@@ -551,7 +555,7 @@ __device__ __forceinline__ uint32_t short_run_len(const uint32_t (&off)[RW_P + 1
 // duration is set by the longest run it takes (a serial chain per lane), the eight-lane kernel's by the longest run of
 // the contig at a third of the cost per position — SHORT_LEN balances the two
 static constexpr uint32_t SHORT_LEN = RW_P - 1;
-__device__ __forceinline__ bool run_is_short(uint32_t len, uint32_t nn) { return len <= SHORT_LEN && nn <= RW_N; }
+__device__ __forceinline__ bool run_is_short(uint32_t len, uint32_t nn, bool deep) { return len <= SHORT_LEN && nn <= RW_N && !deep; }
 __device__ __forceinline__ void load_run_offsets(const uint32_t *__restrict__ node_off, uint32_t a, uint32_t (&off)[RW_P + 1]) {
     static_assert(RW_P + 1 == 14, "three 4-dword loads + one 2-dword load");
     const U32x4 v0 = *reinterpret_cast<const U32x4 *>(node_off + a);
@@ -596,15 +600,19 @@ __device__ __forceinline__ void dp_bt_long_run(uint32_t r, const uint32_t *__res
                                                uint32_t *__restrict__ run_end, int64_t *__restrict__ last_n0_score,
                                                int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
                                                uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
-                                               const uint8_t *__restrict__ run_flag, uint4 (*s_node)[DP_BLOCK]) {
+                                               const uint8_t *__restrict__ run_flag, bool listed,
+                                               uint4 (*s_node)[DP_BLOCK]) {
     const uint32_t t = threadIdx.x;
     const uint32_t a = run_start[r], L = g.L;
     uint32_t o0, o1;
-    {
+    if (listed) { // the run comes from k_dp_bt_short's list of runs it left alone
+        if (!run_flag[r]) return; // done by k_dp_bt_oct
+        o0 = g.node_off[a], o1 = g.node_off[a + 1];
+    } else {
         uint32_t off[RW_P + 1];
         load_run_offsets(g.node_off, a, off);
         const uint32_t len = short_run_len(off, a, L);
-        if (len < RW_P && run_is_short(len, off[len] - off[0])) return; // a short run: k_dp_bt_short's
+        if (len < RW_P && run_is_short(len, off[len] - off[0], *g.deep != 0)) return; // a short run: k_dp_bt_short's
         if (!run_flag[r]) return;                              // done by k_dp_bt_oct
         o0 = off[0], o1 = off[1];
     }
@@ -817,17 +825,24 @@ __device__ __forceinline__ void k_dp_bt_oct(const uint32_t np2_bid, const uint32
                                                   uint32_t *__restrict__ run_end, int64_t *__restrict__ last_n0_score,
                                                   int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
                                                   uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
-                                                  uint8_t *__restrict__ run_flag) {
+                                                  uint8_t *__restrict__ run_flag,
+                                                  const uint32_t *__restrict__ dp_list,
+                                                  const uint32_t *__restrict__ n_dp_list) {
     const uint32_t j = threadIdx.x & 7;
-    const uint32_t nr = *n_runs, L = g.L;
-    for (uint32_t r = np2_bid * 8 + (threadIdx.x >> 3); r < nr; r += np2_nb * 8) { // (uniform per octet)
+    // dp_list: the runs k_dp_bt_short left alone (it ran before this kernel); without it every octet classifies its runs
+    // itself from the node offsets (the two kernels then run side by side on two streams)
+    const uint32_t nr = dp_list ? *n_dp_list : *n_runs, L = g.L;
+    for (uint32_t i = np2_bid * 8 + (threadIdx.x >> 3); i < nr; i += np2_nb * 8) { // (uniform per octet)
+        const uint32_t r = dp_list ? dp_list[i] : i;
         const uint32_t a = run_start[r];
         uint32_t o0, o1;
-        {
+        if (dp_list) {
+            o0 = g.node_off[a], o1 = g.node_off[a + 1];
+        } else {
             uint32_t off[RW_P + 1];
             load_run_offsets(g.node_off, a, off);
             const uint32_t len = short_run_len(off, a, L);
-            if (len < RW_P && run_is_short(len, off[len] - off[0])) continue; // a short run: k_dp_bt_short's
+            if (len < RW_P && run_is_short(len, off[len] - off[0], *g.deep != 0)) continue; // a short run: k_dp_bt_short's
             o0 = off[0], o1 = off[1];
         }
         const uint32_t o_first = o0;
@@ -867,55 +882,67 @@ __device__ __forceinline__ void k_dp_bt_oct(const uint32_t np2_bid, const uint32
             e0 += oct_partner<1>(e0);
             e0 += oct_partner<2>(e0);
             const int64_t cn0 = cov - (int64_t)e0;
-            int64_t s0_cur = 0;
-            for (uint32_t idx = 0; idx <= n; ++idx) {
-                uint32_t key = (uint32_t)b0 | ((uint32_t)d0 << 16);
-                int64_t cnt = cn0;
-                if (idx) {
-                    key = __shfl(cur.x, idx - 1, 8);
-                    cnt = __shfl(cur.y, idx - 1, 8);
-                }
-                const uint16_t kb = (uint16_t)key, kd = (uint16_t)(key >> 16);
-                int64_t score;
-                uint32_t besti = 0;
-                if (((kb >> 4) & 0xF) == 15) {
-                    score = 10 * cnt - 4 * cov;
-                } else {
-                    const bool same_pos = (kb & 0x1000) != 0;
-                    const uint32_t q = same_pos ? p : p - 1;
-                    const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
-                    const int64_t w = 10 * cnt - 4 * cov;
-                    Cand3 c{SCORE_NEG, -1, -1};
-                    if (same_pos || pv_valid) {
-                        bool flag;
-                        // predecessor 0: the contig's own node of that position (every lane, same result)
-                        if (pred_ok(same_pos ? b0 : pv_b0, same_pos ? d0 : pv_d0, want, kd, q, flag))
-                            cand_take(c, (same_pos ? s0_cur : pv_s0) + w, 0, flag);
-                        // predecessor j + 1: exception node j of that position
-                        const uint32_t qn = same_pos ? idx : 1 + pv_n;
-                        if (j + 1 < qn) {
-                            const uint32_t vkey = same_pos ? cur.x : prv_key;
-                            if (pred_ok((uint16_t)vkey, (uint16_t)(vkey >> 16), want, kd, q, flag))
-                                cand_take(c, (same_pos ? cur_score : prv_score) + w, (int32_t)(j + 1), flag);
-                        }
-                    }
-                    cand_merge(c, oct_partner64<0>(c.m), (int32_t)oct_partner<0>((uint32_t)c.f), (int32_t)oct_partner<0>((uint32_t)c.l));
-                    cand_merge(c, oct_partner64<1>(c.m), (int32_t)oct_partner<1>((uint32_t)c.f), (int32_t)oct_partner<1>((uint32_t)c.l));
-                    cand_merge(c, oct_partner64<2>(c.m), (int32_t)oct_partner<2>((uint32_t)c.f), (int32_t)oct_partner<2>((uint32_t)c.l));
-                    score = c.m;
-                    besti = (c.l >= 0 && c.l > c.f) ? (uint32_t)c.l : (c.f < 0 ? 0u : (uint32_t)c.f);
-                }
-                if (idx) {
-                    if (j == idx - 1) {
-                        cur_score = score;
-                        nbesti[o0 + idx - 1] = besti;
-                        if (p + 1 == L) nscore[o0 + idx - 1] = score; // read by k_dp_finish
-                    }
-                } else {
-                    s0_cur = score;
-                    if (j == 0) n0_besti[p] = besti;
+            // Every lane scores "its" exception node j and (all of them alike) the contig's node N0(p), scanning the
+            // predecessors in the reference's order (main.rs:1664-1674): N0 of the predecessor position first, then its
+            // exception nodes, fetched from their lanes one step ahead of their use.  Nodes whose second column lies at
+            // p itself (insertion columns) have their predecessors among the earlier nodes of p: they follow, in node
+            // order, once the others are done.
+            const int64_t cov4 = 4 * cov;
+            const uint16_t mkb = (uint16_t)cur.x, mkd = (uint16_t)(cur.x >> 16);
+            const bool mine = j < n;
+            const bool m_head = ((mkb >> 4) & 0xF) == 15, m_same = (mkb & 0x1000) != 0;
+            const int64_t mw = 10 * (int64_t)cur.y - cov4, w0 = 10 * cn0 - cov4;
+            const uint32_t mwant = ((mkb >> 4) & 0xFFu) | (((mkb >> 14) & 1u) << 12);
+            const uint32_t want0 = ((b0 >> 4) & 0xFFu) | (((b0 >> 14) & 1u) << 12);
+            const bool head0 = ((b0 >> 4) & 0xF) == 15; // (N0 is a path start at positions 0 and 1 only)
+            int64_t s0_cur = head0 ? w0 : SCORE_NEG, m_score = m_head ? mw : SCORE_NEG;
+            uint32_t besti0 = 0, m_besti = 0;
+            auto take = [](int64_t sc, bool flag, uint32_t pi, int64_t &score, uint32_t &besti) {
+                if (sc > score || (sc == score && flag)) score = sc, besti = pi; // main.rs:1670
+            };
+            if (pv_valid) {
+                bool flag;
+                const bool go0 = !head0, gom = mine && !m_head && !m_same;
+                if (go0 && pred_ok(pv_b0, pv_d0, want0, d0, p - 1, flag)) take(pv_s0 + w0, flag, 0, s0_cur, besti0);
+                if (gom && pred_ok(pv_b0, pv_d0, mwant, mkd, p - 1, flag)) take(pv_s0 + mw, flag, 0, m_score, m_besti);
+                uint32_t vk = __shfl(prv_key, 0, 8);
+                int64_t vs = __shfl(prv_score, 0, 8);
+                for (uint32_t k = 0; k < pv_n; ++k) { // (uniform per octet)
+                    const uint32_t nk = __shfl(prv_key, (k + 1) & 7, 8);
+                    const int64_t ns = __shfl(prv_score, (k + 1) & 7, 8);
+                    const uint16_t vb = (uint16_t)vk, vd = (uint16_t)(vk >> 16);
+                    if (go0 && pred_ok(vb, vd, want0, d0, p - 1, flag)) take(vs + w0, flag, k + 1, s0_cur, besti0);
+                    if (gom && pred_ok(vb, vd, mwant, mkd, p - 1, flag)) take(vs + mw, flag, k + 1, m_score, m_besti);
+                    vk = nk, vs = ns;
                 }
             }
+            {
+                const uint64_t bal = __ballot(mine && m_same && !m_head);
+                uint32_t sp = (uint32_t)(bal >> (threadIdx.x & 56u)) & 0xFFu; // this octet's insertion-column nodes
+                for (; sp; sp &= sp - 1) { // rare; every lane of the octet computes the same values
+                    const uint32_t i = (uint32_t)__builtin_ctz(sp);
+                    const uint32_t ikey = __shfl(cur.x, i, 8);
+                    const int64_t iw = 10 * (int64_t)__shfl(cur.y, i, 8) - cov4;
+                    const uint16_t ikb = (uint16_t)ikey, ikd = (uint16_t)(ikey >> 16);
+                    const uint32_t iwant = ((ikb >> 4) & 0xFFu) | (((ikb >> 14) & 1u) << 12);
+                    int64_t sc = SCORE_NEG;
+                    uint32_t bi = 0;
+                    bool flag;
+                    if (pred_ok(b0, d0, iwant, ikd, p, flag)) take(s0_cur + iw, flag, 0, sc, bi);
+                    for (uint32_t k = 0; k < i; ++k) {
+                        const uint32_t vk = __shfl(cur.x, k, 8);
+                        const int64_t vs = __shfl(m_score, k, 8);
+                        if (pred_ok((uint16_t)vk, (uint16_t)(vk >> 16), iwant, ikd, p, flag)) take(vs + iw, flag, k + 1, sc, bi);
+                    }
+                    if (j == i) m_score = sc, m_besti = bi;
+                }
+            }
+            cur_score = m_score;
+            if (mine) {
+                nbesti[o0 + j] = m_besti;
+                if (p + 1 == L) nscore[o0 + j] = m_score; // read by k_dp_finish
+            }
+            if (j == 0) n0_besti[p] = besti0;
             if (n == 0) { // the clean position closing the run
                 done = true;
                 if (j == 0) {
@@ -954,14 +981,16 @@ __device__ __forceinline__ void k_dp_bt_long(const uint32_t np2_bid, const uint3
                                                       int64_t *__restrict__ last_n0_score,
                                                       int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
                                                       uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
-                                                      const uint8_t *__restrict__ run_flag) {
+                                                      const uint8_t *__restrict__ run_flag,
+                                                      const uint32_t *__restrict__ dp_list,
+                                                      const uint32_t *__restrict__ n_dp_list) {
     // one 16-byte LDS word per cached node: {key, count, score lo, score hi} (a node is read as a whole: the DP chain
     // is bound by LDS round trips, not by bytes)
     __shared__ uint4 s_node[2 * DP_NR][DP_BLOCK];
-    const uint32_t nr = *n_runs;
-    for (uint32_t r = np2_bid * DP_BLOCK + threadIdx.x; r < nr; r += np2_nb * DP_BLOCK)
-        dp_bt_long_run(r, run_start, g, nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin,
-                       path, run_flag, s_node);
+    const uint32_t nr = dp_list ? *n_dp_list : *n_runs;
+    for (uint32_t i = np2_bid * DP_BLOCK + threadIdx.x; i < nr; i += np2_nb * DP_BLOCK)
+        dp_bt_long_run(dp_list ? dp_list[i] : i, run_start, g, nrec, nscore, nbesti, n0_besti, run_end, last_n0_score,
+                       run_gain, emit, path_begin, path, run_flag, dp_list != nullptr, s_node);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -973,11 +1002,12 @@ __device__ __forceinline__ void k_dp_bt_long(const uint32_t np2_bid, const uint3
 // node records), scored, walked back and written out as its path slice; scores and best predecessors never leave
 // the chip.  Long runs and the run that reaches the contig end belong to k_dp_bt_long.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__restrict__ run_start, const Graph &g,
+__device__ __forceinline__ bool dp_bt_short_run(uint32_t r, const uint32_t *__restrict__ run_start, const Graph &g,
                                                     const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
                                                     int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit, uint32_t *__restrict__ path_begin,
-                                                    uint64_t *__restrict__ path, uint8_t (*s_off)[64], int32_t (*s_cov)[64],
-                                                    uint4 (*s_node)[64], uint8_t (*s_bi)[64], uint8_t (*s_n0bi)[64]) {
+                                                    uint64_t *__restrict__ path, bool deep, uint8_t (*s_off)[64],
+                                                    uint16_t (*s_cov)[64], uint2 (*s_ks)[64], uint32_t (*s_cb)[64],
+                                                    uint8_t (*s_n0bi)[64]) {
     const uint32_t t = threadIdx.x;
     const uint32_t a = run_start[r], L = g.L;
     // ---- node offsets of positions a .. a + RW_P, run class -----------------------------------------------------------
@@ -988,22 +1018,22 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
         len = short_run_len(off, a, L);
         o_base = off[0];
         nn = len < RW_P ? off[len] - o_base : 0xFFFFFFFFu;
-        if (!run_is_short(len, nn)) return; // the long-run kernels'
+        if (!run_is_short(len, nn, deep)) return false; // the long-run kernels'
 #pragma unroll
         for (uint32_t i = 0; i <= RW_P; ++i) s_off[i][t] = (uint8_t)min(off[i] - o_base, 255u); // (only [0, len] are used)
     }
-    // ---- coverage of positions a .. a + len, contig codes of a - 3 .. a + len, the run's node records -------------------
+    // ---- coverage of positions a .. a + len (< 65536: !deep), contig codes of a - 3 .. a + len, the run's node records ---
     {
         const U32x4 v0 = *reinterpret_cast<const U32x4 *>(g.cov + a);
-        s_cov[0][t] = (int32_t)v0.x, s_cov[1][t] = (int32_t)v0.y, s_cov[2][t] = (int32_t)v0.z, s_cov[3][t] = (int32_t)v0.w;
+        s_cov[0][t] = (uint16_t)v0.x, s_cov[1][t] = (uint16_t)v0.y, s_cov[2][t] = (uint16_t)v0.z, s_cov[3][t] = (uint16_t)v0.w;
         if (len >= 4) {
             const U32x4 v1 = *reinterpret_cast<const U32x4 *>(g.cov + a + 4);
-            s_cov[4][t] = (int32_t)v1.x, s_cov[5][t] = (int32_t)v1.y, s_cov[6][t] = (int32_t)v1.z, s_cov[7][t] = (int32_t)v1.w;
+            s_cov[4][t] = (uint16_t)v1.x, s_cov[5][t] = (uint16_t)v1.y, s_cov[6][t] = (uint16_t)v1.z, s_cov[7][t] = (uint16_t)v1.w;
         }
         if (len >= 8) {
             const U32x4 v2 = *reinterpret_cast<const U32x4 *>(g.cov + a + 8);
-            s_cov[8][t] = (int32_t)v2.x, s_cov[9][t] = (int32_t)v2.y, s_cov[10][t] = (int32_t)v2.z, s_cov[11][t] = (int32_t)v2.w;
-            if (len >= 12) s_cov[12][t] = g.cov[a + 12];
+            s_cov[8][t] = (uint16_t)v2.x, s_cov[9][t] = (uint16_t)v2.y, s_cov[10][t] = (uint16_t)v2.z, s_cov[11][t] = (uint16_t)v2.w;
+            if (len >= 12) s_cov[12][t] = (uint16_t)g.cov[a + 12];
         }
     }
     // contig codes of positions a - 3 .. a + 12 as one 64-bit word (nibble i = position a - 3 + i): three dwords of the
@@ -1023,51 +1053,61 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
     auto code_at = [&](uint32_t p) -> uint8_t { return (uint8_t)((cpk >> ((p + 3 - a) * 4)) & 7); }; // a - 3 <= p <= a + 12
     for (uint32_t k = 0; k < nn; k += 2) { // two 8-byte records per load (the node array is padded)
         const U32x4 v = *reinterpret_cast<const U32x4 *>(g.nrec + o_base + k);
-        s_node[k][t] = make_uint4(v.x, v.y, 0u, 0u);
-        if (k + 1 < RW_N) s_node[k + 1][t] = make_uint4(v.z, v.w, 0u, 0u);
+        s_ks[k][t] = make_uint2(v.x, 0u);
+        s_cb[k][t] = v.y; // count (< 65536), best predecessor << 16 later
+        if (k + 1 < RW_N) {
+            s_ks[k + 1][t] = make_uint2(v.z, 0u);
+            s_cb[k + 1][t] = v.w;
+        }
     }
     auto n0_key_at = [&](uint32_t p, uint16_t &b, uint16_t &d) {
         n0_from_codes(p, p >= 2 ? code_at(p - 2) : 0, p >= 1 ? code_at(p - 1) : 0, code_at(p), b, d);
     };
     // ---- DP over positions a .. a + len (the last one is clean: only its N0) ----------------------------------------------
+    // Scores are 32-bit and relative to N0(a - 1) (+ early_run_base): the reference's i64 scores (main.rs:1661-1677)
+    // minus that node's own score for everything reachable from it, NEG32 + the same sums for what is not — an
+    // order-preserving image of the i64 values, since a path inside the run has at most RW_N + RW_P nodes of
+    // |10 * count - 4 * coverage| < 2^20 each.
+    constexpr int32_t NEG32 = -(1 << 30);
     uint16_t pv_b0 = 0, pv_d0 = 0;
-    const int64_t base = early_run_base(g, a);
-    int64_t pv_s0 = base;
+    const int32_t base = (int32_t)early_run_base(g, a); // (0 unless the run starts at position 1 or 2; coverages < 65536)
+    int32_t pv_s0 = base;
     bool pv_valid = a > 0;
     if (pv_valid) n0_key_at(a - 1, pv_b0, pv_d0);
     uint32_t pv_k0 = 0, pv_n = 0;
-    int64_t s0_cur = 0;
+    int32_t s0_cur = 0;
     for (uint32_t st = 0; st <= len; ++st) {
         const uint32_t p = a + st;
         const uint32_t k0 = s_off[st][t], n = s_off[st + 1][t] - k0;
-        const int64_t cov = s_cov[st][t];
+        const int32_t cov = s_cov[st][t];
         uint16_t b0, d0;
         n0_key_at(p, b0, d0);
         uint32_t e0 = 0;
         for (uint32_t k = 0; k < n; ++k) {
-            const uint4 v = s_node[k0 + k][t];
-            if (node_delta3((uint16_t)v.x, (uint16_t)(v.x >> 16)) == 0) e0 += v.y;
+            const uint32_t key = s_ks[k0 + k][t].x;
+            if (node_delta3((uint16_t)key, (uint16_t)(key >> 16)) == 0) e0 += s_cb[k0 + k][t] & 0xFFFFu;
         }
-        const int64_t cn0 = cov - (int64_t)e0;
+        const int32_t cn0 = cov - (int32_t)e0;
         for (uint32_t idx = 0; idx <= n; ++idx) {
             uint16_t kb = b0, kd = d0;
-            int64_t cnt = cn0;
+            int32_t cnt = cn0;
             if (idx) {
-                const uint4 v = s_node[k0 + idx - 1][t];
-                kb = (uint16_t)v.x, kd = (uint16_t)(v.x >> 16), cnt = v.y;
+                const uint32_t key = s_ks[k0 + idx - 1][t].x;
+                kb = (uint16_t)key, kd = (uint16_t)(key >> 16), cnt = (int32_t)(s_cb[k0 + idx - 1][t] & 0xFFFFu);
             }
-            int64_t score;
+            const int32_t w = 10 * cnt - 4 * cov;
+            int32_t score;
             uint32_t besti = 0;
             if (((kb >> 4) & 0xF) == 15) { // (see k_dp_bt_long for the predecessor test)
-                score = 10 * cnt - 4 * cov;
+                score = w;
             } else {
-                score = SCORE_NEG;
+                score = NEG32;
                 const bool same_pos = (kb & 0x1000) != 0;
                 const uint32_t q = same_pos ? p : p - 1;
                 const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
                 uint32_t qk0 = 0, qn = 0;
                 uint16_t qb0 = 0, qd0 = 0;
-                int64_t qs0 = 0;
+                int32_t qs0 = 0;
                 bool ok = false;
                 if (same_pos) {
                     qk0 = k0, qn = idx, qb0 = b0, qd0 = d0, qs0 = s0_cur, ok = true;
@@ -1077,18 +1117,18 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
                 if (ok) {
                     for (uint32_t pi = 0; pi < qn; ++pi) {
                         uint16_t vb = qb0, vd = qd0;
-                        int64_t ps = qs0;
+                        int32_t ps = qs0;
                         if (pi) {
-                            const uint4 v = s_node[qk0 + pi - 1][t];
+                            const uint2 v = s_ks[qk0 + pi - 1][t];
                             vb = (uint16_t)v.x, vd = (uint16_t)(v.x >> 16);
-                            ps = (int64_t)(((uint64_t)v.w << 32) | v.z);
+                            ps = (int32_t)v.y;
                         }
                         if ((vb & 0x10FFu) != want) continue;
                         const uint16_t v2d = (vb & 0x4000) ? (uint16_t)(vd + 1) : (uint16_t)0;
                         if (v2d != kd) continue;
                         const uint32_t v1q = (vb >> 8) & 0xFu;
                         if (q >= 3 && v1q == 15) continue; // main.rs:1666-1668
-                        const int64_t sc = ps + 10 * cnt - 4 * cov;
+                        const int32_t sc = ps + w;
                         if (sc > score || (sc == score && v1q != 4)) { // main.rs:1670
                             score = sc;
                             besti = pi;
@@ -1097,9 +1137,8 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
                 }
             }
             if (idx) {
-                s_node[k0 + idx - 1][t].z = (uint32_t)(uint64_t)score;
-                s_node[k0 + idx - 1][t].w = (uint32_t)((uint64_t)score >> 32);
-                s_bi[k0 + idx - 1][t] = (uint8_t)besti;
+                s_ks[k0 + idx - 1][t].y = (uint32_t)score;
+                s_cb[k0 + idx - 1][t] = (uint32_t)cnt | (besti << 16);
             } else {
                 s0_cur = score;
                 s_n0bi[st][t] = (uint8_t)besti;
@@ -1108,7 +1147,7 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
         pv_k0 = k0, pv_n = n, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
     }
     run_end[r] = a + len - 1;
-    run_gain[r] = s0_cur - base; // N0 of the closing clean position
+    run_gain[r] = (int64_t)s0_cur - base; // N0 of the closing clean position, relative to N0(a - 1)
     // ---- backtrack from the closing position's best predecessor (bt_walk) --------------------------------------------------
     uint64_t *out = path + (size_t)a + o_base;
     uint32_t st = len - 1, idx = s_n0bi[len][t], n_out = 0;
@@ -1121,16 +1160,16 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
             n0_key_at(p, kb, kd);
             uint32_t e0 = 0; // count of the contig's own node: coverage minus the exception nodes ending like it
             for (uint32_t k = k0; k < s_off[st + 1][t]; ++k) {
-                const uint4 v = s_node[k][t];
-                if (node_delta3((uint16_t)v.x, (uint16_t)(v.x >> 16)) == 0) e0 += v.y;
+                const uint32_t key = s_ks[k][t].x;
+                if (node_delta3((uint16_t)key, (uint16_t)(key >> 16)) == 0) e0 += s_cb[k][t] & 0xFFFFu;
             }
             cnt = (uint32_t)s_cov[st][t] - e0;
             bi = s_n0bi[st][t];
         } else {
-            const uint4 v = s_node[k0 + idx - 1][t];
-            kb = (uint16_t)v.x, kd = (uint16_t)(v.x >> 16);
-            cnt = v.y;
-            bi = s_bi[k0 + idx - 1][t];
+            const uint32_t key = s_ks[k0 + idx - 1][t].x, cb = s_cb[k0 + idx - 1][t];
+            kb = (uint16_t)key, kd = (uint16_t)(key >> 16);
+            cnt = cb & 0xFFFFu;
+            bi = cb >> 16;
         }
         const uint8_t k3q = kb & 0xF;
         if (k3q != 4) {
@@ -1150,6 +1189,7 @@ __device__ __forceinline__ void dp_bt_short_run(uint32_t r, const uint32_t *__re
         idx = bi;
     }
     emit[a] = n_out;
+    return true;
 }
 
 // One thread per short run, grid-stride: the launch covers a host-side bound on the number of runs (the record count)
@@ -1159,15 +1199,30 @@ __device__ __forceinline__ void k_dp_bt_short(const uint32_t np2_bid, const uint
                                                     const uint32_t *__restrict__ n_runs, Graph g,
                                                     const uint32_t *__restrict__ refw32, uint32_t *__restrict__ run_end,
                                                     int64_t *__restrict__ run_gain, uint32_t *__restrict__ emit,
-                                                    uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path) {
+                                                    uint32_t *__restrict__ path_begin, uint64_t *__restrict__ path,
+                                                    uint32_t *__restrict__ dp_list, uint32_t *__restrict__ n_dp_list) {
     __shared__ uint8_t s_off[RW_P + 1][64]; // node offsets relative to the run's first node (<= RW_N)
-    __shared__ int32_t s_cov[RW_P][64];
-    __shared__ uint4 s_node[RW_N][64]; // {key, count, score lo, score hi}: one LDS round trip per node
-    __shared__ uint8_t s_bi[RW_N][64];
+    __shared__ uint16_t s_cov[RW_P][64];
+    __shared__ uint2 s_ks[RW_N][64];    // {key, score}
+    __shared__ uint32_t s_cb[RW_N][64]; // count | best predecessor << 16
     __shared__ uint8_t s_n0bi[RW_P][64];
-    const uint32_t nr = *n_runs;
-    for (uint32_t r = np2_bid * 64 + threadIdx.x; r < nr; r += np2_nb * 64)
-        dp_bt_short_run(r, run_start, g, refw32, run_end, run_gain, emit, path_begin, path, s_off, s_cov, s_node, s_bi, s_n0bi);
+    const uint32_t nr = *n_runs, lane = threadIdx.x;
+    const bool deep = *g.deep != 0;
+    for (uint32_t r0 = np2_bid * 64; r0 < nr; r0 += np2_nb * 64) { // (uniform trip count: the ballot below)
+        const uint32_t r = r0 + lane;
+        const bool left = r < nr && !dp_bt_short_run(r, run_start, g, refw32, run_end, run_gain, emit, path_begin, path, deep,
+                                                     s_off, s_cov, s_ks, s_cb, s_n0bi);
+        if (dp_list) { // the runs left to the long-run kernels, in no particular order: one reservation per wave
+            const uint64_t m = __ballot(left);
+            if (m) {
+                const uint32_t lead = (uint32_t)__builtin_ctzll(m);
+                uint32_t base = 0;
+                if (lane == lead) base = atomicAdd(n_dp_list, (uint32_t)__builtin_popcountll(m));
+                base = __shfl(base, lead);
+                if (left) dp_list[base + (uint32_t)__builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = r;
+            }
+        }
+    }
 }
 
 // global best node at L-1 (main.rs:1651,1680): later node wins ties, must reach score >= 0
@@ -1646,22 +1701,24 @@ void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) NP2_LAUNCH(k_kill_reads, grid1(n), 256, s, ids, n, alive);
 }
-static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec}; }
+static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec, gp.deep}; }
 
 void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
                      const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
-                     uint32_t *path_begin, uint64_t *path) {
+                     uint32_t *path_begin, uint64_t *path, uint32_t *dp_list, uint32_t *n_dp_list) {
     if (max_runs)
-        NP2_LAUNCH(k_dp_bt_short, dim3(std::min<uint32_t>((max_runs + 63) / 64, DP_GRID_CAP)), 64, s, run_start, n_runs, mk_graph(gp), (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path);
+        NP2_LAUNCH(k_dp_bt_short, dim3(std::min<uint32_t>((max_runs + 63) / 64, DP_GRID_CAP)), 64, s, run_start, n_runs, mk_graph(gp), (const uint32_t *)refw, run_end, run_gain, emit, path_begin, path, dp_list, n_dp_list);
 }
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
-                    uint64_t *path, uint8_t *run_flag) {
+                    uint64_t *path, uint8_t *run_flag, const uint32_t *dp_list, const uint32_t *n_dp_list) {
     if (!max_runs) return;
-    NP2_LAUNCH(k_dp_bt_oct, dim3(std::min<uint32_t>((max_runs + 7) / 8, 4 * DP_GRID_CAP)), 64, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag);
+    // with the short kernel's list the grids only have to keep the chip busy (grid-stride over the listed runs)
+    const uint32_t oct_cap = dp_list ? 2048u : 4 * DP_GRID_CAP, long_cap = dp_list ? 512u : DP_GRID_CAP;
+    NP2_LAUNCH(k_dp_bt_oct, dim3(std::min<uint32_t>((max_runs + 7) / 8, oct_cap)), 64, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag, dp_list, n_dp_list);
     // runs with a position of more than 8 exception nodes (deep pileups): the per-thread kernel
-    NP2_LAUNCH(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, DP_GRID_CAP)), DP_BLOCK, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag);
+    NP2_LAUNCH(k_dp_bt_long, dim3(std::min<uint32_t>((max_runs + DP_BLOCK - 1) / DP_BLOCK, long_cap)), DP_BLOCK, s, run_start, n_runs, mk_graph(gp), nrec, nscore, nbesti, n0_besti, run_end, last_n0_score, run_gain, emit, path_begin, path, run_flag, dp_list, n_dp_list);
 }
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,

@@ -39,6 +39,7 @@ struct GraphPtrs {
     const int32_t *cov;
     uint32_t L;
     const uint2 *nrec; // packed node records {bases | delta << 16, count}
+    const uint32_t *deep; // per-pass flag: a position covered 65536x or more (set by the tile builder)
 };
 struct CandPtrs {
     const np2_read_t *reads;
@@ -79,11 +80,11 @@ void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *
 // node, backtrack of the contig-end run, emission fix-up left of the path start.
 void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
                      const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
-                     uint32_t *path_begin, uint64_t *path);
+                     uint32_t *path_begin, uint64_t *path, uint32_t *dp_list, uint32_t *n_dp_list);
 void launch_dp_long(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t max_runs, const uint2 *nrec, int64_t *nscore, uint32_t *nbesti, uint32_t *n0_besti,
                     uint32_t *run_end, int64_t *last_n0_score, int64_t *run_gain, uint32_t *emit, uint32_t *path_begin,
-                    uint64_t *path, uint8_t *run_flag);
+                    uint64_t *path, uint8_t *run_flag, const uint32_t *dp_list, const uint32_t *n_dp_list);
 void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                       const int64_t *nscore, const uint32_t *nbesti, const uint32_t *n0_besti, const int64_t *last_n0_score,
                       unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
@@ -167,7 +168,7 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain);
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)

@@ -120,6 +120,25 @@ def test_pair_votes_outside_the_band_take_the_sort_path(monkeypatch):
     assert np.array_equal(ob2, b1) and np.array_equal(op2, p1)
 
 
+def test_pileups_too_deep_for_the_on_chip_dp_take_the_long_run_kernels(monkeypatch):
+    # the on-chip DP of short runs keeps coverages / counts in 16 bits and scores in 32: a pass with a position covered
+    # 65536x or more hands every run to the eight-lane / per-thread kernels.  Force that at an ordinary depth — through
+    # the plain context (the kernels classify runs themselves) and through the batch driver (the short kernel's list).
+    syn, yaks = _assembly()
+    o = orc.Oracle(yaks)
+    want = [o.polish(s.pileup, Opts()) for s in syn[:3]]
+    monkeypatch.setenv("NP2_TEST_DEEP_COV", "20")  # depth 30: most tiles have such a position, depth 12 contigs none
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in syn[:3]]
+    for c, (ob, op) in zip(contigs, want):
+        b, p = pol.polish_resident(c, Opts())
+        assert np.array_equal(ob, b) and np.array_equal(op, p)
+    bp = BatchPolisher(pol, 3)
+    for (b, p), (ob, op) in zip(bp.polish(contigs, Opts(), want_pos=True), want):
+        assert np.array_equal(ob, b) and np.array_equal(op, p)
+    bp.close()
+
+
 def test_full_size_yeast_assembly_through_the_batch_driver():
     """BASELINE.json configs[2] at full size (17 contigs, 12.16 Mb diploid, 30x, k21 + k31, phasing on): the batch
     driver's output per contig equals the one-contig-at-a-time path, is identical on a second run, recovers the
