@@ -152,6 +152,10 @@ int np2_phase_vote(const uint32_t *keys, uint32_t n_keys, const uint32_t *pa, co
 typedef struct np2_batch np2_batch_t;
 int np2_batch_create(np2_batch_t **out, np2_ctx_t *parent, int n_slots);
 void np2_batch_destroy(np2_batch_t *b);
+/* Stream priority of this batch (high != 0: the device's greatest).  Several batches driven by one host thread each
+ * overlap their host phases (the phasing vote) with each other's kernels; alternate their priorities so that they do
+ * not advance in lockstep.  Call while no np2_batch_polish is in flight. */
+int np2_batch_set_priority(np2_batch_t *b, int high);
 int np2_batch_slots(np2_batch_t *b);
 np2_ctx_t *np2_batch_slot_ctx(np2_batch_t *b, int slot);
 const char *np2_batch_last_error(np2_batch_t *b);

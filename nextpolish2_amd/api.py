@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
-    "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_last_diff_ms", "np2_batch_stats",
+    "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_set_priority", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
 # include/np2_io.h (input side; bound by nextpolish2_amd.io)
@@ -88,6 +88,8 @@ def lib():
         L.np2_batch_polish.argtypes = [vp, vp, C.c_int, C.POINTER(np2_opts_t), vp, vp, vp, vp, vp]
         L.np2_batch_set_timing.argtypes = [vp, C.c_int]
         L.np2_batch_set_timing.restype = None
+        L.np2_batch_set_priority.argtypes = [vp, C.c_int]
+        L.np2_batch_set_priority.restype = C.c_int
         L.np2_batch_last_diff_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.np2_batch_flush_log.argtypes = [vp, C.POINTER(vp)]
         L.np2_shard_plan.argtypes = [vp, u32, u32, u32, u32, C.POINTER(np2_shard_plan_t)]
@@ -319,6 +321,12 @@ class BatchPolisher:
             self.close()
         except Exception:
             pass
+
+    def set_priority(self, high):
+        """np2_batch_set_priority: stream priority of this batch (alternate it over the batches of one device)."""
+        rc = lib().np2_batch_set_priority(self._h, 1 if high else 0)
+        if rc != 0:
+            raise Np2Error(rc, "np2_batch_set_priority failed")
 
     def set_timing(self, on=True):
         lib().np2_batch_set_timing(self._h, 1 if on else 0)

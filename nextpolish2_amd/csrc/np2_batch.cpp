@@ -13,6 +13,7 @@
 #include "np2_ctx.hpp"
 
 #include <atomic>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -309,6 +310,27 @@ void np2_batch_destroy(np2_batch_t *b) {
     if (b->done_host) (void)hipHostFree(b->done_host);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
+}
+
+// Several batches on one device (one host thread each) fill each other's host phases — the phasing vote of a group of
+// contigs is a millisecond of Louvain on the CPU — but equal-priority streams tend to advance in lockstep and end up
+// in their host phases together.  Alternating priorities keep the groups out of step.
+int np2_batch_set_priority(np2_batch_t *b, int high) {
+    if (!b) return NP2_E_ARG;
+    try {
+        HIPCHK(hipSetDevice(b->device));
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamSynchronize(b->stream)); // (no call in flight: the caller's contract)
+        hipStream_t s = nullptr;
+        HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
+        (void)hipStreamDestroy(b->stream);
+        b->stream = s;
+    } catch (const Np2Error &e) {
+        b->err = e.what();
+        return e.code;
+    }
+    return NP2_OK;
 }
 
 int np2_batch_slots(np2_batch_t *b) { return b ? (int)b->slots.size() : 0; }

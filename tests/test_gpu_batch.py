@@ -83,6 +83,8 @@ def test_two_batches_on_two_host_threads():
     ref = [pol.polish_resident(c, Opts(), want_pos=False)[0] for c in contigs]
     halves = [[0, 2, 4], [1, 3]]
     bps = [BatchPolisher(pol, len(h)) for h in halves]
+    bps[0].set_priority(True)  # (what bench.py does: groups on alternating-priority streams)
+    bps[1].set_priority(False)
     outs = [None, None]
 
     def run(k):

@@ -35,3 +35,7 @@ for mode in ("raw C call, results freed", "python wrapper"):
             print(mode, "last call %.2f ms; flush totals host %.2f issue %.2f wait %.2f (sum %.2f)" % (
                 ts[-1], sum(f[0] for f in fl), sum(f[1] for f in fl), sum(f[2] for f in fl), sum(sum(f) for f in fl)))
     print(mode, "median %.2f ms min %.2f max %.2f" % (np.median(ts), min(ts), max(ts)), flush=True)
+# per-flush breakdown of the last call: (host ms before the flush, issue ms, wait ms)
+fl = bp.flush_log()
+for i, f in enumerate(fl):
+    print("flush %2d  host %.3f  issue %.3f  wait %.3f" % (i, f[0], f[1], f[2]))
