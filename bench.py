@@ -43,9 +43,11 @@ def make_assembly(lengths, depth, seed0, diploid):
 class Groups:
     """The assembly's contigs split over G batch groups of about equal size in bp, longest contigs first: each group is one
     np2_batch_t driven by its own host thread, so one group's host phases (the Louvain of the phasing vote, ~1 ms for
-    the longest contig) are filled by the other groups' kernels.  Stream priorities alternate high / low over the
-    groups: equal-priority streams advance in lockstep and meet in their host phases (measured: 3 groups at equal
-    priority are slower than one, alternating they are ~20 % faster)."""
+    the longest contig) and read-back latencies are filled by the other groups' kernels.  Over the K timed steps the
+    groups run free — every group polishes its contigs K times, the groups do not wait for each other between steps
+    (a step's output is complete when the slowest group has delivered it) — the way a server works through a queue of
+    assemblies.  Stream priorities alternate high / low over the groups: equal-priority streams advance in lockstep
+    and meet in their host phases."""
 
     def __init__(self, pol, contigs, lengths, n_groups):
         from nextpolish2_amd import BatchPolisher
@@ -64,35 +66,54 @@ class Groups:
             for g, b in enumerate(self.bps):
                 b.set_priority(g % 2 == 0)
         self.contigs = contigs
-        self.out = [None] * len(contigs)
+        self.n = len(contigs)
 
     def set_timing(self, on):
         for b in self.bps:
             b.set_timing(on)
 
-    def _run(self, g, opts):
-        res = self.bps[g].polish([self.contigs[i] for i in self.members[g]], opts)
-        for i, r in zip(self.members[g], res):
-            self.out[i] = r
+    def run(self, opts, steps, after_step=None, exclusive=False):
+        """`steps` passes over the assembly.  after_step(out) runs on the calling thread once every group has delivered
+        a step (the groups may be one step ahead of it by then).  exclusive: one group at a time (the roofline kernel
+        measured without other kernels next to it).  -> (outputs of the last step, per-step sum of the k_diff_reads
+        launch durations in ms, launches per step, mean np2_batch_polish call time in ms)"""
+        G = len(self.bps)
+        outs = [[None] * self.n, [None] * self.n]
+        done, seen = [0] * G, [0]
+        acc = [[0.0, 0, 0.0] for _ in range(G)]
+        cv = threading.Condition()
+        turn = [0]
 
-    def step(self, opts):
-        if len(self.bps) == 1:
-            self._run(0, opts)
-        else:
-            ths = [threading.Thread(target=self._run, args=(g, opts)) for g in range(len(self.bps))]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        return self.out
-
-    def diff_ms(self):
-        tot, n = 0.0, 0
-        for b in self.bps:
-            ms, k = b.last_diff_ms()
-            tot += ms
-            n += k
-        return tot, n
+        def loop(g):
+            for k in range(steps):
+                with cv:
+                    cv.wait_for(lambda: (after_step is None or seen[0] >= k - 1) and (not exclusive or turn[0] % G == g))
+                res = self.bps[g].polish([self.contigs[i] for i in self.members[g]], opts)
+                for i, r in zip(self.members[g], res):
+                    outs[k & 1][i] = r
+                ms, launches = self.bps[g].last_diff_ms()
+                acc[g][0] += ms
+                acc[g][1] = launches
+                acc[g][2] += self.bps[g].last_call_ms
+                with cv:
+                    done[g] = k + 1
+                    turn[0] += 1
+                    cv.notify_all()
+        ths = [threading.Thread(target=loop, args=(g,)) for g in range(G)]
+        for t in ths:
+            t.start()
+        if after_step is not None:
+            for k in range(steps):
+                with cv:
+                    cv.wait_for(lambda: min(done) >= k + 1)
+                after_step(outs[k & 1])
+                with cv:
+                    seen[0] = k + 1
+                    cv.notify_all()
+        for t in ths:
+            t.join()
+        return (outs[(steps - 1) & 1], sum(x[0] for x in acc) / max(1, steps), sum(x[1] for x in acc),
+                sum(x[2] for x in acc) / max(1, steps * G))
 
 
 def cpu_baseline(syn, yaks, opts, max_threads, budget_s=25.0):
@@ -259,49 +280,48 @@ def main():
             pending[0] = False
         return [(np.array(last[0]), span)]
 
-    def step():
-        if single:
-            return step_single()
-        out = groups.step(opts)
-        if distributed:
-            # RCCL all-gather of this rank's polished assembly (contigs concatenated in input order)
-            gatherer.gather(np.concatenate([o[0] for o in out]))
-        return out
+    # RCCL all-gather of this rank's polished assembly (contigs concatenated in input order), one per step
+    after = (lambda o: gatherer.gather(np.concatenate([x[0] for x in o]))) if distributed else None
 
     def sync():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        out = step()
     if single:
+        for _ in range(a.warmup):
+            out = step_single()
         drain_single(out)
+    elif a.warmup:
+        groups.run(opts, a.warmup, after)
     groups.set_timing(True)  # HIP events around the batched k_diff_reads launches, on the batch streams
-    diff_ms, diff_launches, call_ms = [], 0, []
+    diff_ms, diff_launches, call_ms = [], 0, 0.0
     import gc
     gc.collect()
     gc.disable()  # (the cyclic collector's pauses over the ctypes wrappers would be charged to the steps)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-        if single:  # HIP events around k_diff_reads on the context's own stream
-            ms, k = pol.timings().get("diff_reads", 0.0), 1
-        else:
-            ms, k = groups.diff_ms()
-        call_ms.append(sum(getattr(b, "last_call_ms", 0.0) for b in groups.bps))
+    if single:
+        for _ in range(a.steps):
+            out = step_single()
+            diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+            diff_launches = 1
+    else:
+        out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after)
         diff_ms.append(ms)
-        diff_launches = k
     if single:
         out = drain_single(out)  # every polished sequence is on the host before the clock stops
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    flush_log = [] if single else [b.flush_log() for b in groups.bps]
+    excl = None
+    if not single and len(groups.bps) > 1:  # the roofline kernel without other groups' kernels next to it (untimed)
+        _, ms_x, k_x, _ = groups.run(opts, 2, None, exclusive=True)
+        excl = (ms_x, k_x)
     groups.set_timing(False)
     bases = [np.array(o[0]) for o in out]
     spans = [o[1] for o in out]
-    flush_log = [] if single else [b.flush_log() for b in groups.bps]
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,9 +362,16 @@ def main():
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},
         "flush_ms": {"per_group_totals_host_issue_wait": [[round(sum(f[j] for f in fl), 3) for j in range(3)] for fl in flush_log],
                      "flushes_per_step": [len(fl) for fl in flush_log],
-                     "batch_call_ms_mean": round(float(np.mean(call_ms)), 3) if call_ms and not single else None},
+                     "batch_call_ms_mean": round(float(call_ms), 3) if not single else None},
     }
 
+    if excl is not None and excl[0] > 0:
+        # the same kernel over 2 extra, untimed steps in which the groups take turns: its launches then have the GPU to
+        # themselves (in the timed region they share it with the other groups' kernels, which stretches them)
+        ach_x = alg_bytes / (excl[0] * 1e-3) / 1e9
+        out_line["roofline_exclusive"] = {"achieved": round(ach_x, 2), "frac": round(ach_x / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                                          "avg_launch_ms": round(excl[0] / max(1, excl[1]), 4), "launches_per_step": excl[1],
+                                          "note": "one batch group at a time, outside the timed region"}
     if rank == 0 and not a.no_end_to_end:  # (before the CPU baseline: its hundreds of threads leave the host noisy)
         import tempfile
         with tempfile.TemporaryDirectory() as td:

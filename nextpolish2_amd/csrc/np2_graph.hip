@@ -136,58 +136,74 @@ __device__ __forceinline__ void k_tile_layout_lb(const uint32_t np2_bid, const u
     }
 }
 
-// one block per tile: raw records of the tile's bucket -> node keys, bitonic sort of the (key, read) pairs in LDS,
-// written back in place.  Pairs are unique, so the result does not depend on the order the bucket was filled in.
+// one block per tile: raw records of the tile's bucket -> node keys, sorted by (key, read) and written back in place.
+// A node key leads with its contig position and a tile has only TILE of them, so the sort is a counting sort by
+// position (LDS histogram, block scan, scatter of record indices) followed by a rank inside each position's group
+// (one thread per record counts the smaller members of its group: a position holds a handful of records, a
+// heterozygous site a few dozen).  ~5x fewer LDS operations than the bitonic network this replaces, whose 66 stages
+// at 2048 records made this the longest kernel of the diploid workload.  Pairs are unique, so the result does not
+// depend on the order the bucket was filled in.
 template <uint32_t CAP>
 __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads,
                                                    const uint8_t *__restrict__ nib, const uint32_t *__restrict__ tile_n,
                                                    uint32_t bucket_cap, uint64_t *__restrict__ keys,
                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ err) {
-    __shared__ uint64_t sk[CAP];
-    __shared__ uint32_t sv[CAP];
-    const uint32_t n = tile_n[np2_bid];
+    __shared__ uint32_t s_klo[CAP];  // bases << 16 | delta1 of the node key (its position is the group)
+    __shared__ uint32_t s_v[CAP];    // read
+    __shared__ uint16_t s_q[CAP];    // position inside the tile
+    __shared__ uint16_t s_idx[CAP];  // record indices grouped by position
+    __shared__ uint32_t s_cnt[TILE]; // records per position (also the scatter cursor)
+    __shared__ uint32_t s_off[TILE];
+    __shared__ uint32_t sh[8];
+    const uint32_t n = tile_n[np2_bid], tid = threadIdx.x;
     const uint64_t a = (uint64_t)np2_bid * bucket_cap;
     if (n == 0) return;
     if (n > CAP) {
-        if (threadIdx.x == 0) atomicOr(err, 8u);
+        if (tid == 0) atomicOr(err, 8u);
         return;
     }
-    uint32_t P = 1;
-    while (P < n) P <<= 1;
-    for (uint32_t i = threadIdx.x; i < P; i += 256) {
-        uint64_t k = ~0ULL;
-        uint32_t r = ~0u;
-        if (i < n) {
-            r = vals[a + i];
-            k = make_node_key(reads, nib, keys[a + i], r);
+    const uint32_t start = np2_bid << TILE_SHIFT;
+    for (uint32_t i = tid; i < TILE; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t r = vals[a + i];
+        const uint64_t k = make_node_key(reads, nib, keys[a + i], r);
+        uint32_t q = (uint32_t)(k >> 32) - start;
+        if (q >= TILE) { // (the dense pass files a record under the tile of its position)
+            atomicOr(err, 8u);
+            q = TILE - 1;
         }
-        sk[i] = k;
-        sv[i] = r;
+        s_klo[i] = (uint32_t)k;
+        s_v[i] = r;
+        s_q[i] = (uint16_t)q;
+        atomicAdd(&s_cnt[q], 1u);
     }
     __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (P >> 1); t += 256) {
-                // t-th compare-exchange of this stage: i has bit j clear
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t x = i | j;
-                const bool asc = (i & k) == 0;
-                const uint64_t ki = sk[i], kx = sk[x];
-                const uint32_t vi = sv[i], vx = sv[x];
-                const bool gt = ki > kx || (ki == kx && vi > vx);
-                if (gt == asc) {
-                    sk[i] = kx;
-                    sk[x] = ki;
-                    sv[i] = vx;
-                    sv[x] = vi;
-                }
-            }
-            __syncthreads();
-        }
+    {
+        const uint32_t q0 = tid * 4;
+        const uint32_t c0 = s_cnt[q0], c1 = s_cnt[q0 + 1], c2 = s_cnt[q0 + 2], c3 = s_cnt[q0 + 3];
+        uint32_t tot;
+        const uint32_t l0 = block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot);
+        s_off[q0] = l0, s_off[q0 + 1] = l0 + c0, s_off[q0 + 2] = l0 + c0 + c1, s_off[q0 + 3] = l0 + c0 + c1 + c2;
+        s_cnt[q0] = 0, s_cnt[q0 + 1] = 0, s_cnt[q0 + 2] = 0, s_cnt[q0 + 3] = 0;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        keys[a + i] = sk[i];
-        vals[a + i] = sv[i];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t q = s_q[i];
+        s_idx[s_off[q] + atomicAdd(&s_cnt[q], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < n; d += 256) {
+        const uint32_t i = s_idx[d], q = s_q[i], b = s_off[q], m = s_cnt[q];
+        const uint32_t klo = s_klo[i], v = s_v[i];
+        uint32_t rank = 0;
+        for (uint32_t e = b; e < b + m; ++e) {
+            const uint32_t j = s_idx[e];
+            const uint32_t kj = s_klo[j], vj = s_v[j];
+            rank += (kj < klo || (kj == klo && vj < v)) ? 1u : 0u;
+        }
+        keys[a + b + rank] = ((uint64_t)(start + q) << 32) | klo;
+        vals[a + b + rank] = v;
     }
 }
 
@@ -622,6 +638,8 @@ void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib
                       uint32_t *err) {
     if (max_tile <= 1024)
         NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
+    else if (max_tile <= 2048 && TILE_CAP > 2048)
+        NP2_LAUNCH(k_tile_sort<2048>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
     else
         NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
 }

@@ -294,20 +294,20 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
         const int32_t same = (int32_t)(vd.pair_cnt[i] & 0xFFFFu), neg = (int32_t)(vd.pair_cnt[i] >> 16);
         return (float)(neg >= 3 ? -neg : same - neg);
     };
+    // data.retain(..) + per-row retain (main.rs:1004-1010) drop the reads flagged bad and every edge pointing at one:
+    // those edges are left out while the rows are built (the rows' relative order is all that is kept of them)
     if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(vd.pair_key[i] >> 32); },
-                        [&](uint64_t i) { return (uint32_t)vd.pair_key[i]; }, weight))
+                        [&](uint64_t i) { return (uint32_t)vd.pair_key[i]; }, weight, use_all ? nullptr : vd.bad.data()))
         throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
     mark("keys + edges");
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
         if (vd.bad[r]) bad.push_back(r);
-    if (!use_all) { // data.retain(..) + per-row retain (main.rs:1004-1010): erase order = bucket order
+    if (!use_all) // the keys themselves: erase order = bucket order
         data.keys.keep_if([&](uint32_t k, phase::Nil &) {
             if (vd.bad[k]) data.is_key[k] = 0;
             return !vd.bad[k];
         });
-        data.drop_nodes(vd.bad.data());
-    }
     mark("retain");
     std::vector<float> ref_row(R, 0.f);
     std::vector<uint8_t> ref_have(R, 0);

@@ -280,21 +280,24 @@ struct Graph {
     Row adj(uint32_t v) const { return Row{edges.data() + off[v], edges.data() + off[v + 1]}; }
     // (Re)build the rows from a list of undirected weighted edges: count, prefix, fill.  Returns false if an
     // endpoint is not a key.
-    template <class GetA, class GetB, class GetW> bool add_edges(uint64_t n, GetA ga, GetB gb, GetW gw) {
+    // `skip` (optional, per node): edges with a flagged endpoint are left out — what drop_nodes would remove afterwards.
+    template <class GetA, class GetB, class GetW>
+    bool add_edges(uint64_t n, GetA ga, GetB gb, GetW gw, const uint8_t *skip = nullptr) {
         const uint32_t N = n_ids();
-        std::vector<uint32_t> deg((size_t)N + 1, 0);
+        off.assign((size_t)N + 1, 0);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t a = ga(i), b = gb(i);
             if (!has_key(a) || !has_key(b)) return false;
-            ++deg[a + 1];
-            ++deg[b + 1];
+            if (skip && (skip[a] | skip[b])) continue;
+            ++off[a + 1];
+            ++off[b + 1];
         }
-        for (uint32_t v = 0; v < N; ++v) deg[v + 1] += deg[v];
-        off = deg;
+        for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v];
         edges.resize(off[N]);
         std::vector<uint32_t> cur(off.begin(), off.end() - 1);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t a = ga(i), b = gb(i);
+            if (skip && (skip[a] | skip[b])) continue;
             const float w = gw(i);
             edges[cur[a]++] = Edge(b, w);
             edges[cur[b]++] = Edge(a, w);
@@ -352,13 +355,10 @@ class SignedLouvain {
         const uint32_t n = g_.n_ids();
         node_id_.resize(n);
         node_w_.assign(n, 0.f);
-        members_.resize(n);
         cnt_.assign(n, 0);
-        oplog_.assign(n, {});
-        for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68
+        for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68 (members_: every node is {itself} until aggregated)
             comm_keys_.put(v, Nil{});
             node_id_[v] = v;
-            members_[v] = {v};
             cnt_[v] = 1;
         }
     }
@@ -392,9 +392,12 @@ class SignedLouvain {
     OrderSet comm_keys_;
     std::vector<uint32_t> node_id_; // community of each (possibly aggregated) node
     std::vector<float> node_w_;     // weight carried by an aggregated node
-    std::vector<std::vector<uint32_t>> members_;
+    bool level0_ = true;                        // nodes are still single reads: members of node v = {v}
+    std::vector<std::vector<uint32_t>> members_; // original read ids of an aggregated node (from the first aggregation on)
     std::vector<uint32_t> cnt_;                 // members per community
-    std::vector<std::vector<int64_t>> oplog_;   // per community: +(v + 1) insert, -(v + 1) remove, in order
+    // member operations of this level in order: (community, +(v + 1) insert / -(v + 1) remove); one flat log instead
+    // of a vector per community (thousands of small allocations per contig), filtered when a community is replayed
+    std::vector<std::pair<uint32_t, int64_t>> oplog_;
 
     bool local_moving() { // first_stage, louvain.rs:72-117
         // The reference re-evaluates every node in every sweep until a sweep moves nothing.  A node's decision is a
@@ -434,8 +437,8 @@ class SignedLouvain {
                     node_id_[v] = to;
                     ++cnt_[to];
                     --cnt_[cur];
-                    oplog_[to].push_back((int64_t)v + 1);
-                    oplog_[cur].push_back(-((int64_t)v + 1));
+                    oplog_.emplace_back(to, (int64_t)v + 1);
+                    oplog_.emplace_back(cur, -((int64_t)v + 1));
                     for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
                     again = true;
                     moved_any = true;
@@ -461,7 +464,8 @@ class SignedLouvain {
         float w = 0.f;
         for (const uint32_t *p = mb; p != me; ++p) {
             const uint32_t v = *p;
-            mem.insert(mem.end(), members_[v].begin(), members_[v].end());
+            if (level0_) mem.push_back(v);
+            else mem.insert(mem.end(), members_[v].begin(), members_[v].end());
             w += node_w_[v];
             for (const auto &e : g_.adj(v))
                 if (node_id_[e.first] == cid) w += e.second / 2.0f;
@@ -471,7 +475,9 @@ class SignedLouvain {
     // iteration order of a community's member set: replay its history into the emulated hash set
     std::vector<uint32_t> member_order(uint32_t id) const {
         OrderSet set = OrderSet::single(id, Nil{}); // every community starts as {its own node}
-        for (int64_t op : oplog_[id]) {
+        for (const auto &e : oplog_) {
+            if (e.first != id) continue;
+            const int64_t op = e.second;
             if (op > 0) set.put((uint32_t)(op - 1), Nil{});
             else set.take((uint32_t)(-op - 1), nullptr);
         }
@@ -507,7 +513,8 @@ class SignedLouvain {
                 Community c;
                 c.id = nid;
                 c.weight = node_w_[v];
-                c.members = members_[v];
+                if (level0_) c.members = {v};
+                else c.members = members_[v];
                 nnode[nid] = std::move(c);
                 key_of[v] = nid;
             }
@@ -559,8 +566,9 @@ class SignedLouvain {
         node_id_.assign(max_id + 1, 0);
         node_w_.assign(max_id + 1, 0.f);
         members_.assign(max_id + 1, {});
+        level0_ = false;
         cnt_.assign(max_id + 1, 0);
-        oplog_.assign(max_id + 1, {});
+        oplog_.clear();
         for (auto &kv : nnode) {
             node_id_[kv.first] = kv.first;
             node_w_[kv.first] = kv.second.weight;
