@@ -345,10 +345,13 @@ inline void op_copy_d2d(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
 // driver a transfer is a copy KERNEL reading / writing host memory over the bus: the copies of all contigs of a batch
 // go out as one launch instead of one blit per contig.  Large transfers keep the DMA path.
 static constexpr size_t KERNEL_COPY_MAX = 1u << 20;
+// (device -> host: a copy kernel holds CU slots while its stores trickle over the bus — with several batch groups on
+// one device those slots are another group's; beyond a few pages the DMA engine takes it)
+static constexpr size_t KERNEL_D2H_MAX = 64u << 10;
 inline void op_d2h(np2_ctx *cx, void *pinned_dst, const void *src, size_t bytes) {
     if (!bytes) return;
     if (Recorder *r = tl_recorder()) {
-        if (bytes <= KERNEL_COPY_MAX)
+        if (bytes <= KERNEL_D2H_MAX)
             launch_copy(cx->stream, (uint8_t *)pinned_dst, (const uint8_t *)src, bytes);
         else
             r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, s)); });
