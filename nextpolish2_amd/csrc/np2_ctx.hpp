@@ -241,6 +241,9 @@ struct np2_ctx {
     DevBuf<uint8_t> out_snap;
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
     uint32_t deep_min = 65536; // coverage from which the on-chip DP of short runs is off (NP2_TEST_DEEP_COV lowers it: tests)
+    DevBuf<uint32_t> lq_list, hbits; // consensus indices of the low-quality bases; bitmap of the raw regions' head indices
+    DevBuf<uint32_t> blk_lq, blk_lq_off; // low-quality bases written per block of the consensus write-out, and their scan
+    DevBuf<uint8_t> lqn;                 // ... per contig position
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
@@ -253,7 +256,8 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 24 };
+            S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_NLQ, S_PAD0, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 26 };
+static_assert(S_M1 % 2 == 0 && S_LAST0 % 2 == 0 && S_GAIN0 % 2 == 0, "64-bit device counters live in these slot pairs");
 
 static constexpr int NP2_MAX_YAK = 15; // splice rounds 0 .. n_yak index mlen[16] and the counters behind S_COUNT
 static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it

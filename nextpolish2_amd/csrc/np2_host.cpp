@@ -133,6 +133,7 @@ void check_region_err(np2_ctx *cx, uint32_t e) {
     if (e & 64u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: consensus index out of bounds in reupdate");
     if (e & 128u) throw Np2Error(NP2_E_NOMEM, "cartesian product of chained LQ regions is too large");
     if (e & LB_ERR) throw Np2Error(NP2_E_DEVICE, "device-wide scan timed out waiting for a predecessor block");
+    if (e & LQ_LIST_ERR) throw Np2Error(NP2_E_DEVICE, "internal: more low-quality bases than their list was sized for");
 }
 
 // What one phasing pass hands to the host side of the vote (phase_reads_by_lqseqs, main.rs:948-1015).  Everything in
@@ -581,13 +582,13 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
     launch_tile_count(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, n_tiles,
                       cx->alive.p, cx->tile_nn.p, cx->tile_nr.p);
-    // (also resets the per-pass scalars S_BEST .. S_NLONG)
+    // (also resets the per-pass scalars S_BEST .. S_NLQ)
     {
         const bool wide = n_tiles >= 2048;
         Lookback lb{};
         if (wide) lb = next_lookback(cx, tile_scan_blocks(n_tiles));
         launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p,
-                            cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS, cx->scal.p + S_BEST, S_NLONG + 1 - S_BEST,
+                            cx->scal.p + S_NNODES, cx->scal.p + S_NRUNS, cx->scal.p + S_BEST, S_NLQ + 1 - S_BEST,
                             wide ? &lb : nullptr, cx->scal.p + S_ERR);
     }
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
@@ -647,7 +648,8 @@ void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
 // DP + backtrack + LQ regions; returns consensus length M and region count
 // One read-back at the end: consensus length, region count, error word.  The consensus length stays on the device
 // (eoff[L]) while the consensus and the LQ regions are built; launches and buffers are sized by M <= L + T.
-void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t T, uint32_t &M, uint32_t &n_reg) {
+void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T, uint32_t &M,
+                           uint32_t &n_reg) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L;
     if ((uint64_t)L + T + 2 >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "consensus bound exceeds 32 bits");
@@ -676,6 +678,17 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
     cx->lq_start.ensure(M_cap + 2);
     cx->lq_end.ensure(M_cap + 2);
     cx->tmp.ensure(prim_temp_bytes((size_t)M_cap + 2));
+    // the low-quality bases (they only come out of dirty runs) as a list of consensus indices; a path through a run has
+    // at most one entry per dirty position and per exception node
+    const uint32_t lq_cap = (uint32_t)std::min<uint64_t>(2ull * n_nodes + n_runs + 2, M_cap);
+    const uint32_t n_words = (M_cap + 31) / 32;
+    cx->lq_list.ensure((size_t)lq_cap + 2);
+    cx->hbits.ensure((size_t)n_words + 2);
+    const uint32_t n_blk = lq_blocks(L);
+    cx->blk_lq.ensure((size_t)n_blk + 2);
+    cx->blk_lq_off.ensure((size_t)n_blk + 2);
+    cx->lqn.ensure((size_t)L + 2);
+    const uint32_t *const n_lq = cx->blk_lq_off.p + n_blk; // total of the scanned block counts
     const uint32_t *M_p = cx->eoff.p + L;
     {
         EventTimer t(cx, "dp_backtrack");
@@ -712,14 +725,21 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_runs, uint32_t
                          (c->L + TILE - 1) >> TILE_SHIFT, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
         launch_bt_write(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p,
-                        cx->lq_nothead.p);
+                        cx->lq_nothead.p, cx->lqn.p, cx->blk_lq.p);
     }
     {
         EventTimer t(cx, "lq_regions");
-        launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, M_cap, cx->lq_kind.p, cx->lq_next.p,
-                       cx->lq_nothead.p, cx->rflag.p, cx->rstart.p, cx->rend.p);
-        exclusive_total(cx, cx->rflag.p, cx->ridx.p, M_cap);
-        launch_scatter_regions(s, cx->rflag.p, cx->ridx.p, cx->rstart.p, cx->rend.p, M_p, M_cap, cx->raw_start.p,
+        // raw regions: chain heads marked in a bitmap over the emission indices, heads per word scanned, regions
+        // written out in bit order (right -> left, the reference's numbering)
+        exclusive_total_n(cx, cx->blk_lq.p, cx->blk_lq_off.p, n_blk);
+        launch_lq_list(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->lqn.p, cx->blk_lq_off.p, lq_cap, cx->lq_list.p,
+                       cx->scal.p + S_ERR);
+        zero32(cx, cx->hbits.p, n_words + 1);
+        launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, cx->lq_list.p, n_lq, lq_cap, cx->lq_kind.p,
+                       cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, cx->rstart.p, cx->rend.p);
+        launch_lq_bits_count(s, cx->hbits.p, n_words, cx->rflag.p);
+        exclusive_total(cx, cx->rflag.p, cx->ridx.p, (size_t)n_words + 1); // (rflag[n_words] = 0)
+        launch_scatter_regions(s, cx->hbits.p, n_words, cx->ridx.p, cx->rstart.p, cx->rend.p, cx->raw_start.p,
                                cx->raw_end.p, cx->scal.p + S_NRAW);
         launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p);
         launch_scan_small_excl(s, cx->headflag.p, cx->hidx.p, M_cap, cx->scal.p + S_NRAW, nullptr, false);
@@ -886,7 +906,7 @@ void run_pass_front(PolishRun &r) {
         trace_graph(cx, c, (int)r.pass, n_nodes);
         {
             WallTimer w(cx, "wall_cns_lq");
-            consensus_and_regions(cx, c, n_runs, r.T, r.M, r.n_reg);
+            consensus_and_regions(cx, c, n_nodes, n_runs, r.T, r.M, r.n_reg);
         }
         if (cx->trace) {
             trace_cns(cx, (int)r.pass, "cns_raw", fetch_cns(cx, r.M));

@@ -1353,33 +1353,80 @@ __device__ __forceinline__ void k_dp_finish(const uint32_t np2_bid, const uint32
 
 // Consensus write-out, one thread per contig position: a clean position emits the contig base; the first position of a
 // dirty run copies the run's recorded path (the walk went right -> left).  Output offsets grow with the position, so
-// neighbouring threads write neighbouring consensus indices.
+// neighbouring threads write neighbouring consensus indices.  Low-quality bases only come out of dirty runs: every
+// thread leaves the number it wrote (lqn, one byte per position, saturating) and every block their sum; k_lq_list
+// turns the scanned block sums into the list of the low-quality bases' consensus indices, which the LQ-region kernels
+// walk instead of keeping one mostly idle thread per consensus base.  (A single device counter bumped once per block
+// would serialise: 47 k same-address atomics cost more than the whole write-out.)
 __device__ __forceinline__ void k_cns_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
                             const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
                             const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
                             uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
-                            uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
-    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
-    if (p >= L) return;
-    const uint32_t e = emit[p];
-    if (e == 0) return;
-    const uint32_t o0 = eoff[p];
-    const uint32_t no = node_off[p];
-    if (node_off[p + 1] == no) { // clean position
-        lq_nothead[o0] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
-        cns_pos[o0] = p;
-        cns_base[o0] = code_to_ascii(ref_code(refnib, p));
-        cns_cls[o0] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
-        return;
+                            uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead,
+                            uint8_t *__restrict__ lqn, uint32_t *__restrict__ blk_lq) {
+    __shared__ uint32_t s_lq;
+    if (threadIdx.x == 0) s_lq = 0;
+    __syncthreads();
+    const uint32_t p = np2_bid * blockDim.x + threadIdx.x;
+    const uint32_t e = p < L ? emit[p] : 0u;
+    uint32_t n_lq = 0;
+    if (e) {
+        const uint32_t o0 = eoff[p];
+        const uint32_t no = node_off[p];
+        if (node_off[p + 1] == no) { // clean position
+            lq_nothead[o0] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
+            cns_pos[o0] = p;
+            cns_base[o0] = code_to_ascii(ref_code(refnib, p));
+            cns_cls[o0] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
+        } else {
+            const uint64_t *src = path + (size_t)p + no; // first position of a dirty run (only those carry a count)
+            for (uint32_t n = 0; n < e; ++n) {
+                const uint64_t w = src[n];
+                const uint32_t o = o0 + e - 1 - n;
+                cns_pos[o] = (uint32_t)(w >> 32);
+                cns_base[o] = (uint8_t)(w >> 8);
+                cns_cls[o] = (uint8_t)w;
+                lq_nothead[o] = 0;
+                n_lq += (uint8_t)w == CLS_LQ ? 1u : 0u;
+            }
+            if (n_lq) atomicAdd(&s_lq, n_lq);
+        }
     }
-    const uint64_t *src = path + (size_t)p + no; // first position of a dirty run (only those carry a count)
-    for (uint32_t n = 0; n < e; ++n) {
-        const uint64_t w = src[n];
-        const uint32_t o = o0 + e - 1 - n;
-        cns_pos[o] = (uint32_t)(w >> 32);
-        cns_base[o] = (uint8_t)(w >> 8);
-        cns_cls[o] = (uint8_t)w;
-        lq_nothead[o] = 0;
+    if (p < L) lqn[p] = (uint8_t)min(n_lq, 255u); // (255: "count again")
+    __syncthreads();
+    if (threadIdx.x == 0) blk_lq[np2_bid] = s_lq;
+}
+
+// The consensus indices of the low-quality bases (ascending): same thread mapping as k_cns_write, offsets from the
+// scanned block sums; only the threads that wrote some go back to their run's path.
+__device__ __forceinline__ void k_lq_list(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ emit,
+                          const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
+                          const uint8_t *__restrict__ lqn, const uint32_t *__restrict__ blk_lq_off, uint32_t cap,
+                          uint32_t *__restrict__ lq_list, uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t base = blk_lq_off[np2_bid];
+    if (blk_lq_off[np2_bid + 1] == base) return; // (uniform)
+    const uint32_t p = np2_bid * 256 + threadIdx.x;
+    uint32_t n_lq = p < L ? lqn[p] : 0u, e = 0;
+    const uint64_t *src = nullptr;
+    if (n_lq) {
+        e = emit[p];
+        src = path + (size_t)p + node_off[p];
+        if (n_lq == 255) { // saturated: count again
+            n_lq = 0;
+            for (uint32_t n = 0; n < e; ++n) n_lq += (uint8_t)src[n] == CLS_LQ ? 1u : 0u;
+        }
+    }
+    uint32_t tot;
+    uint32_t k = base + block_excl_scan<OpAdd, 4>(n_lq, sh, tot);
+    if (n_lq) {
+        if (k + n_lq > cap) {
+            atomicOr(err, LQ_LIST_ERR);
+            return;
+        }
+        const uint32_t o0 = eoff[p];
+        for (uint32_t n = e; n-- > 0;) // path entry n sits at consensus index o0 + e - 1 - n: ascending indices
+            if ((uint8_t)src[n] == CLS_LQ) lq_list[k++] = o0 + e - 1 - n;
     }
 }
 
@@ -1389,80 +1436,90 @@ __device__ __forceinline__ void k_cns_write(const uint32_t np2_bid, const uint32
 // ------------------------------------------------------------------------------------------
 enum : uint8_t { LQK_LINK = 0, LQK_CLOSE = 1, LQK_RESET = 2, LQK_OPEN = 3 };
 
-// (the consensus length M lives on the device; launches cover the host-side bound M_cap)
+// one thread per low-quality base (lq_list: their consensus indices, ascending; the count lives on the device)
 __device__ __forceinline__ void k_lq_scan(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
                           const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p,
-                          uint8_t *__restrict__ lq_kind, uint32_t *__restrict__ lq_next,
+                          const uint32_t *__restrict__ lq_list, const uint32_t *__restrict__ n_lq_p,
+                          uint32_t lq_cap, uint8_t *__restrict__ lq_kind, uint32_t *__restrict__ lq_next,
                           uint8_t *__restrict__ lq_nothead) {
-    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
-    const uint32_t M = *M_p;
-    if (i >= M || cns_cls[i] != CLS_LQ) return;
-    const uint32_t p = M - 1 - i;
-    uint8_t kind = LQK_OPEN;
-    uint32_t pp = p + 1;
-    for (; pp < M; ++pp) {
-        const uint32_t ii = M - 1 - pp;
-        const uint8_t cl = cns_cls[ii];
-        if (cl == CLS_RESET) {
-            kind = LQK_RESET;
-            break;
-        }
-        if (cl == CLS_LQ) {
-            kind = LQK_LINK;
-            break;
-        }
-        if (pp - p > 4) { // p - lq_e > 2*lq_min_length, c(pp-1) vs c(pp-2) (main.rs:1596-1598)
-            const uint32_t i1 = ii + 1, i2 = ii + 2;
-            if (cns_pos[i1] != cns_pos[i2] && cns_base[i1] != cns_base[i2]) {
-                kind = LQK_CLOSE;
+    const uint32_t M = *M_p, n_lq = min(*n_lq_p, lq_cap);
+    for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n_lq; j += np2_nb * blockDim.x) {
+        const uint32_t i = lq_list[j];
+        const uint32_t p = M - 1 - i;
+        uint8_t kind = LQK_OPEN;
+        uint32_t pp = p + 1;
+        for (; pp < M; ++pp) {
+            const uint32_t ii = M - 1 - pp;
+            const uint8_t cl = cns_cls[ii];
+            if (cl == CLS_RESET) {
+                kind = LQK_RESET;
                 break;
             }
+            if (cl == CLS_LQ) {
+                kind = LQK_LINK;
+                break;
+            }
+            if (pp - p > 4) { // p - lq_e > 2*lq_min_length, c(pp-1) vs c(pp-2) (main.rs:1596-1598)
+                const uint32_t i1 = ii + 1, i2 = ii + 2;
+                if (cns_pos[i1] != cns_pos[i2] && cns_base[i1] != cns_base[i2]) {
+                    kind = LQK_CLOSE;
+                    break;
+                }
+            }
         }
+        lq_kind[p] = kind;
+        lq_next[p] = pp;
+        if (kind == LQK_LINK) lq_nothead[pp] = 1;
     }
-    lq_kind[p] = kind;
-    lq_next[p] = pp;
-    if (kind == LQK_LINK) lq_nothead[pp] = 1;
 }
 
+// raw regions, one per chain head: bounds stored under the head's emission index p, the head marked in a bitmap over
+// the emission indices — the regions are numbered by ascending p (right -> left), i.e. by the rank of their bit
 __device__ __forceinline__ void k_lq_region(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint8_t *__restrict__ cns_base,
-                            const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p, uint32_t M_cap,
+                            const uint32_t *__restrict__ M_p, const uint32_t *__restrict__ lq_list,
+                            const uint32_t *__restrict__ n_lq_p, uint32_t lq_cap,
                             const uint8_t *__restrict__ lq_kind, const uint32_t *__restrict__ lq_next,
-                            const uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ rflag,
+                            const uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ hbits,
                             uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend) {
-    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
-    const uint32_t M = *M_p;
-    if (p >= M_cap) return;
-    rflag[p] = 0; // also behind M: the flag scan runs over the bound
-    if (p >= M) return;
-    if (cns_cls[M - 1 - p] != CLS_LQ || lq_nothead[p]) return;
-    uint32_t q = p;
-    while (lq_kind[q] == LQK_LINK) q = lq_next[q];
-    if (lq_kind[q] != LQK_CLOSE) return;
-    const uint32_t pe = lq_next[q];
-    const uint32_t lq_e = pe - 2;
-    uint32_t lq_s = p > 2 ? p - 2 : 1;
+    const uint32_t M = *M_p, n_lq = min(*n_lq_p, lq_cap);
+    for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n_lq; j += np2_nb * blockDim.x) {
+        const uint32_t p = M - 1 - lq_list[j];
+        if (lq_nothead[p]) continue;
+        uint32_t q = p;
+        while (lq_kind[q] == LQK_LINK) q = lq_next[q];
+        if (lq_kind[q] != LQK_CLOSE) continue;
+        const uint32_t pe = lq_next[q];
+        const uint32_t lq_e = pe - 2;
+        uint32_t lq_s = p > 2 ? p - 2 : 1;
 #define CP(x) cns_pos[M - 1 - (x)]
 #define CB(x) cns_base[M - 1 - (x)]
-    while (lq_s > 1 && (CP(lq_s - 1) == CP(lq_s) || CB(lq_s - 1) == CB(lq_s))) --lq_s;
-    rflag[p] = 1;
-    rend[p] = CP(lq_s);
-    rstart[p] = CP(lq_e);
+        while (lq_s > 1 && (CP(lq_s - 1) == CP(lq_s) || CB(lq_s - 1) == CB(lq_s))) --lq_s;
+        rend[p] = CP(lq_s);
+        rstart[p] = CP(lq_e);
 #undef CP
 #undef CB
-}
-
-__device__ __forceinline__ void k_scatter_regions(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ ridx,
-                                  const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ rend,
-                                  const uint32_t *__restrict__ M_p, uint32_t *__restrict__ raw_start,
-                                  uint32_t *__restrict__ raw_end, uint32_t *__restrict__ n_raw) {
-    uint32_t p = np2_bid * blockDim.x + threadIdx.x;
-    const uint32_t M = *M_p;
-    if (p >= M) return;
-    if (rflag[p]) {
-        raw_start[ridx[p]] = rstart[p];
-        raw_end[ridx[p]] = rend[p];
+        atomicOr(&hbits[p >> 5], 1u << (p & 31));
     }
-    if (p == M - 1) *n_raw = ridx[p] + rflag[p];
+}
+// heads per bitmap word (scanned next), and the regions written out in bit order
+__device__ __forceinline__ void k_lq_bits_count(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ hbits, uint32_t n_words,
+                                uint32_t *__restrict__ wcnt) {
+    const uint32_t w = np2_bid * blockDim.x + threadIdx.x;
+    if (w <= n_words) wcnt[w] = w < n_words ? (uint32_t)__builtin_popcount(hbits[w]) : 0u;
+}
+__device__ __forceinline__ void k_scatter_regions(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ hbits, uint32_t n_words,
+                                  const uint32_t *__restrict__ woff, const uint32_t *__restrict__ rstart,
+                                  const uint32_t *__restrict__ rend, uint32_t *__restrict__ raw_start,
+                                  uint32_t *__restrict__ raw_end, uint32_t *__restrict__ n_raw) {
+    const uint32_t w = np2_bid * blockDim.x + threadIdx.x;
+    if (w == 0) *n_raw = woff[n_words];
+    if (w >= n_words) return;
+    uint32_t bits = hbits[w], k = woff[w];
+    for (; bits; bits &= bits - 1, ++k) {
+        const uint32_t p = (w << 5) + (uint32_t)__builtin_ctz(bits);
+        raw_start[k] = rstart[p];
+        raw_end[k] = rend[p];
+    }
 }
 
 // merge rule main.rs:1613-1615: region j merges into j-1 iff end_j >= start_{j-1}
@@ -1727,19 +1784,29 @@ void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_st
     NP2_LAUNCH(k_dp_finish, dim3(64), 256, s, run_gain, n_runs, tile_gain, n_tiles, total_gain, blocks_done, mk_graph(gp), nscore, last_n0_score, run_start, nbesti, n0_besti, best_idx, emit, path_begin, path);
 }
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead) {
-    NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L, cns_pos, cns_base, cns_cls, lq_nothead);
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint8_t *lqn,
+                     uint32_t *blk_lq) {
+    NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L, cns_pos, cns_base, cns_cls, lq_nothead, lqn, blk_lq);
 }
+uint32_t lq_blocks(uint32_t L) { return (L + 255) / 256; } // blocks of k_cns_write / k_lq_list
+void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                    const uint8_t *lqn, const uint32_t *blk_lq_off, uint32_t cap, uint32_t *lq_list, uint32_t *err) {
+    NP2_LAUNCH(k_lq_list, grid1(gp.L), 256, s, gp.node_off, emit, eoff, path, gp.L, lqn, blk_lq_off, cap, lq_list, err);
+}
+static inline dim3 lq_grid(uint32_t cap) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 255) / 256, 2048))); }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
-                    const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
-                    uint32_t *rflag, uint32_t *rstart, uint32_t *rend) {
-    NP2_LAUNCH(k_lq_scan, grid1(M_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, lq_kind, lq_next, lq_nothead);
-    NP2_LAUNCH(k_lq_region, grid1(M_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, M_cap, lq_kind, lq_next, lq_nothead, rflag, rstart, rend);
+                    const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
+                    uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t *rstart, uint32_t *rend) {
+    NP2_LAUNCH(k_lq_scan, lq_grid(lq_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, lq_list, n_lq, lq_cap, lq_kind, lq_next, lq_nothead);
+    NP2_LAUNCH(k_lq_region, lq_grid(lq_cap), 256, s, cns_pos, cns_base, M_p, lq_list, n_lq, lq_cap, lq_kind, lq_next, lq_nothead, hbits, rstart, rend);
 }
-void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
-                            const uint32_t *rend, const uint32_t *M_p, uint32_t M_cap, uint32_t *raw_start,
-                            uint32_t *raw_end, uint32_t *n_raw) {
-    NP2_LAUNCH(k_scatter_regions, grid1(M_cap), 256, s, rflag, ridx, rstart, rend, M_p, raw_start, raw_end, n_raw);
+void launch_lq_bits_count(hipStream_t s, const uint32_t *hbits, uint32_t n_words, uint32_t *wcnt) {
+    NP2_LAUNCH(k_lq_bits_count, grid1((uint64_t)n_words + 1), 256, s, hbits, n_words, wcnt);
+}
+void launch_scatter_regions(hipStream_t s, const uint32_t *hbits, uint32_t n_words, const uint32_t *woff,
+                            const uint32_t *rstart, const uint32_t *rend, uint32_t *raw_start, uint32_t *raw_end,
+                            uint32_t *n_raw) {
+    NP2_LAUNCH(k_scatter_regions, grid1(std::max<uint32_t>(n_words, 1)), 256, s, hbits, n_words, woff, rstart, rend, raw_start, raw_end, n_raw);
 }
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                           uint32_t *headflag) {

@@ -90,15 +90,23 @@ void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_st
                       unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
                       const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
 // consensus write-out: clean positions + the recorded run paths, one thread per contig position
+// consensus write-out with per-position / per-block counts of the low-quality bases written; the scanned block counts
+// place their consensus indices in lq_list (count on the device, bounded by lq_cap) and the LQ kernels run over that
+// list.  Region heads are marked in a bitmap over the emission indices (zeroed by the caller), counted per word,
+// scanned, and written out in bit order = the reference's order.
 void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead);
-// LQ regions: the consensus length is read from the device (M_p); M_cap is the host-side bound the launches cover
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint8_t *lqn,
+                     uint32_t *blk_lq);
+uint32_t lq_blocks(uint32_t L);
+void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                    const uint8_t *lqn, const uint32_t *blk_lq_off, uint32_t cap, uint32_t *lq_list, uint32_t *err);
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
-                    const uint32_t *M_p, uint32_t M_cap, uint8_t *lq_kind, uint32_t *lq_next, uint8_t *lq_nothead,
-                    uint32_t *rflag, uint32_t *rstart, uint32_t *rend);
-void launch_scatter_regions(hipStream_t s, const uint32_t *rflag, const uint32_t *ridx, const uint32_t *rstart,
-                            const uint32_t *rend, const uint32_t *M_p, uint32_t M_cap, uint32_t *raw_start,
-                            uint32_t *raw_end, uint32_t *n_raw);
+                    const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
+                    uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t *rstart, uint32_t *rend);
+void launch_lq_bits_count(hipStream_t s, const uint32_t *hbits, uint32_t n_words, uint32_t *wcnt);
+void launch_scatter_regions(hipStream_t s, const uint32_t *hbits, uint32_t n_words, const uint32_t *woff,
+                            const uint32_t *rstart, const uint32_t *rend, uint32_t *raw_start, uint32_t *raw_end,
+                            uint32_t *n_raw);
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                           uint32_t *headflag);
 void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
