@@ -28,9 +28,9 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
          784333, 1091291, 948066, 85779]
 # HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
-# profiles/r02b_yeast_pmc_fetch_write.json, profiles/r02b_ecoli_pmc_fetch_write.json
+# profiles/r02c_yeast_pmc_fetch_write.json (average over the three launches of a step), profiles/r02c_ecoli_pmc_fetch_write.json
 PMC_LAUNCHES = {"yeast": 3, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 126780.9 + 152992.9) * 1024), "ecoli": int((2 * 48520.2 + 39684.2) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 42316.0 + 50910.7) * 1024), "ecoli": int((2 * 48519.1 + 39668.4) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--groups", type=int, default=3, help="batch groups (host threads driving one np2_batch_t each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the two untimed steps behind roofline_exclusive (profiling runs)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all cores)")
     a = ap.parse_args()
 
@@ -316,7 +317,7 @@ def main():
     gc.enable()
     flush_log = [] if single else [b.flush_log() for b in groups.bps]
     excl = None
-    if not single and len(groups.bps) > 1:  # the roofline kernel without other groups' kernels next to it (untimed)
+    if not single and len(groups.bps) > 1 and not a.no_exclusive:  # the roofline kernel without other groups' kernels next to it (untimed)
         _, ms_x, k_x, _ = groups.run(opts, 2, None, exclusive=True)
         excl = (ms_x, k_x)
     groups.set_timing(False)
