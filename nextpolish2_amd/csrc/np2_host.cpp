@@ -696,9 +696,12 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_
         // long runs on the second stream, short runs on the main one: the kernels touch disjoint runs and the long
         // kernel is a latency chain (a few lanes walking runs of dozens of positions) that would otherwise sit alone
         // on the device for as long as the short kernel takes
-        // Under the batch driver the launches of a group share one stream: the short kernel goes first and lists the
-        // runs it leaves alone, so that the long-run kernels walk that list instead of classifying every run again.
-        const bool forked = tl_recorder() == nullptr; // (recorded launches all go to the group's one stream)
+        // The short kernel goes first and lists the runs it leaves alone, so that the long-run kernels walk that list
+        // instead of classifying every run again.
+        // (NP2_DP_FORK: the earlier scheme — short and long-run kernels side by side on two streams, each classifying
+        // the runs itself; measured ~1 % slower on the E. coli-sized contig once the short kernel had become the
+        // shorter of the two; kept as a tested alternative)
+        const bool forked = tl_recorder() == nullptr && getenv("NP2_DP_FORK") != nullptr;
         uint32_t *dp_list = nullptr, *n_dp_list = nullptr;
         if (forked) {
             HIPCHK(hipEventRecord(cx->ev_fork, s));
@@ -709,7 +712,7 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_
             launch_dp_short(s, gp, c->refnib.p, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->run_end.p,
                             cx->run_gain.p, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, dp_list, n_dp_list);
         }
-        launch_dp_long(cx->stream2, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
+        launch_dp_long(forked ? cx->stream2 : s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->nrec.p, cx->nscore.p,
                        cx->nbesti.p, cx->n0_besti.p, cx->run_end.p, (int64_t *)(cx->scal.p + S_LAST0), cx->run_gain.p,
                        cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p, cx->run_flag.p, dp_list, n_dp_list);
         if (forked) {

@@ -125,11 +125,13 @@ def test_pair_votes_outside_the_band_take_the_sort_path(monkeypatch):
 def test_pileups_too_deep_for_the_on_chip_dp_take_the_long_run_kernels(monkeypatch):
     # the on-chip DP of short runs keeps coverages / counts in 16 bits and scores in 32: a pass with a position covered
     # 65536x or more hands every run to the eight-lane / per-thread kernels.  Force that at an ordinary depth — through
-    # the plain context (the kernels classify runs themselves) and through the batch driver (the short kernel's list).
+    # the plain context (two-stream variant: the kernels classify runs themselves) and through the batch driver (the
+    # short kernel's list).
     syn, yaks = _assembly()
     o = orc.Oracle(yaks)
     want = [o.polish(s.pileup, Opts()) for s in syn[:3]]
     monkeypatch.setenv("NP2_TEST_DEEP_COV", "20")  # depth 30: most tiles have such a position, depth 12 contigs none
+    monkeypatch.setenv("NP2_DP_FORK", "1")  # plain context: long-run kernels on a second stream, classifying runs themselves
     pol = Polisher(yaks)
     contigs = [pol.upload(s.pileup) for s in syn[:3]]
     for c, (ob, op) in zip(contigs, want):

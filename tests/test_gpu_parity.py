@@ -50,6 +50,14 @@ def test_stage_parity_synthetic(seed, diploid, ks):
     check_all_stages(s.pileup, [s.yak(k) for k in ks], Opts())
 
 
+def test_dp_two_stream_variant(monkeypatch):
+    # NP2_DP_FORK: short-run and long-run DP kernels side by side on two streams, each classifying the runs itself
+    # (the default lets the short kernel list what it leaves to the others)
+    monkeypatch.setenv("NP2_DP_FORK", "1")
+    s = Synth(60000, depth=30, seed=35, diploid=True, read_len_mean=8000.0, read_len_sd=1500.0, read_err_rate=0.01)
+    check_all_stages(s.pileup, [s.yak(21)], Opts())
+
+
 @pytest.mark.parametrize("opts", [Opts(iter_count=1), Opts(iter_count=3), Opts(model="len"), Opts(use_all_reads=True),
                                   Opts(min_kmer_count=60), Opts(max_indel_len=0)])
 def test_stage_parity_options(opts, small_diploid):
