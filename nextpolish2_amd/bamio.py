@@ -135,6 +135,82 @@ def write_bam(path, refs, records):
         f.write(out)
 
 
+def write_bam_raw(path, refs, contigs, level=1, threads=16):
+    """Whole-assembly BAM + .bai from already encoded alignment records (Synth.bam_records): contigs = per reference
+    sequence, in order, (blob, record offsets, positions, reference lengths).  Records are packed into BGZF blocks of
+    at most ~60 kB without splitting one; the blocks are deflated by a thread pool (zlib releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_ref = len(refs)
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (n.encode(), l) for n, l in refs)
+    hdr = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", n_ref)
+    for n, l in refs:
+        nb = n.encode() + b"\0"
+        hdr += struct.pack("<I", len(nb)) + nb + struct.pack("<I", l)
+    blocks = [hdr]            # uncompressed payload of every BGZF block
+    where = []                # per contig: (block index, offset inside the block) of every record + the end of the last
+    for blob, off, pos, rlen in contigs:
+        w, cur, fill = [], bytearray(), 0
+        n = len(pos)
+        for i in range(n):
+            a, b = int(off[i]), int(off[i + 1])
+            if fill and fill + (b - a) > 60000:
+                blocks.append(bytes(cur))
+                cur, fill = bytearray(), 0
+            w.append((len(blocks), fill))
+            cur += blob[a:b]
+            fill += b - a
+        w.append((len(blocks), fill))
+        blocks.append(bytes(cur))
+        where.append(w)
+
+    def deflate(data):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        comp = list(pool.map(deflate, blocks))
+    comp.append(deflate(b""))  # EOF marker
+    file_off, o = [], 0
+    for c in comp:
+        file_off.append(o)
+        o += len(c)
+    with open(path, "wb") as f:
+        for c in comp:
+            f.write(c)
+    voff = lambda bi, within: (file_off[bi] << 16) | within if within < 65536 else None
+    with open(path + ".bai", "wb") as f:
+        out = b"BAI\1" + struct.pack("<I", n_ref)
+        for tid in range(n_ref):
+            _, _, pos, rlen = contigs[tid]
+            w = where[tid]
+            bins, lin = {}, {}
+            for i in range(len(pos)):
+                beg = voff(*w[i])
+                nb, nw = w[i + 1]
+                end = voff(nb, nw) if nw else (file_off[nb] << 16)  # (a record ending a block: start of the next one)
+                p0, p1 = int(pos[i]), int(pos[i]) + max(int(rlen[i]), 1)
+                ch = bins.setdefault(reg2bin(p0, p1), [])
+                if ch and ch[-1][1] == beg:
+                    ch[-1][1] = end
+                else:
+                    ch.append([beg, end])
+                for win in range(p0 >> 14, ((p1 - 1) >> 14) + 1):
+                    lin.setdefault(win, beg)
+            out += struct.pack("<I", len(bins))
+            for b, ch in sorted(bins.items()):
+                out += struct.pack("<II", b, len(ch))
+                for beg, end in ch:
+                    out += struct.pack("<QQ", beg, end)
+            n_intv = (max(lin) + 1) if lin else 0
+            out += struct.pack("<I", n_intv)
+            prev = 0
+            for win in range(n_intv):
+                prev = lin.get(win, prev)
+                out += struct.pack("<Q", prev)
+        f.write(out)
+
+
 def read_bam(path):
     """-> (refs [(name, length)], records) of a BAM file, records as the dicts write_bam takes.  A plain sequential
     reader for tests (BGZF blocks are concatenated gzip members); the product reads BAM through csrc/np2_io.cpp."""

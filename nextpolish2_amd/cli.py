@@ -175,7 +175,11 @@ def main(argv=None):
         if os.path.exists(path):  # option.rs:312-316: refuse to overwrite
             raise SystemExit(f"Error: {path!r} already exists!")
         out = open(path, "wb")
+    prof = os.environ.get("NP2_CLI_PROFILE")
+    t_y = time.time()
     yaks = sorted((np2io.load_yak(y) for y in a.yak), key=lambda y: y.k)  # option.rs:238
+    if prof:
+        print(f"[np2 profile] yak files loaded {time.time() - t_y:.3f} s", file=sys.stderr)
     # main.rs:1547 compares the raw option with "ref" (case-sensitive)
     opts = Opts(min_kmer_count=a.min_kmer_count, max_indel_len=a.max_indel_len, iter_count=a.iter_count,
                 model=a.model, use_all_reads=a.use_all_reads)
@@ -198,8 +202,12 @@ def main(argv=None):
         if getattr(tls, "pol", None) is None:
             with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
                 if not base:
+                    t_b = time.time()
                     base.append(Polisher(yaks, device=a.device))
                     tls.pol = base[0]
+                    if prof:
+                        print(f"[np2 profile] first context + k-mer tables in HBM {time.time() - t_b:.3f} s "
+                              f"(at +{time.time() - t0:.3f} s)", file=sys.stderr)
                 else:
                     tls.pol = base[0].clone()
             tls.bam = np2io.Bam(a.bam)
@@ -238,6 +246,8 @@ def main(argv=None):
                 drain(2 * n_workers)  # bounded look-ahead: at most 2 x workers contigs held in memory
             drain(0)
         out.flush()
+        if prof:
+            print(f"[np2 profile] all contigs written at +{time.time() - t0:.3f} s", file=sys.stderr)
     finally:
         if out is not None and out is not sys.stdout.buffer:
             out.close()

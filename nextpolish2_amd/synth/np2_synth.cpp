@@ -473,6 +473,83 @@ const uint8_t *np2s_nibbles(void *h, uint64_t *nbytes) {
     return S->nibbles.data();
 }
 
+// The reads of the contig (index >= 1) as BAM alignment records (CIGAR from the packed columns: M / I / D runs, 4-bit
+// SEQ, missing qualities, MAPQ 60, alternating strand flag), coordinate-sorted and concatenated; rec_off[i] .. rec_off[i + 1] delimits record
+// i, pos[i] / ref_len[i] are what an index needs.  Test / bench infrastructure: whole-assembly BAM files without a
+// per-column Python loop.  Returns the number of records; buffers are malloc'ed (np2s_free_buf).
+uint32_t np2s_bam_records(void *h, int32_t tid, uint8_t **blob, uint64_t **rec_off, int32_t **pos, uint32_t **ref_len) {
+    Synth *S = (Synth *)h;
+    const uint32_t n = S->reads.size() > 1 ? (uint32_t)S->reads.size() - 1 : 0;
+    std::vector<uint8_t> out;
+    uint64_t *off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    int32_t *ps = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint32_t *rl = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    static const uint8_t enc4[8] = {1, 2, 4, 8, 0, 15, 3, 15}; // A C G T - N M
+    auto reg2bin = [](int64_t beg, int64_t end) -> uint16_t {
+        --end;
+        if (beg >> 14 == end >> 14) return (uint16_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+        if (beg >> 17 == end >> 17) return (uint16_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+        if (beg >> 20 == end >> 20) return (uint16_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+        if (beg >> 23 == end >> 23) return (uint16_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+        if (beg >> 26 == end >> 26) return (uint16_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+        return 0;
+    };
+    auto put32 = [&](std::vector<uint8_t> &v, uint32_t x) {
+        for (int k = 0; k < 4; ++k) v.push_back((uint8_t)(x >> (8 * k)));
+    };
+    std::vector<uint32_t> cig;
+    std::vector<uint8_t> seq;
+    std::vector<uint32_t> order(n); // coordinate-sorted, ties in read order
+    for (uint32_t i = 0; i < n; ++i) order[i] = i + 1;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return S->reads[a].aln_t_s < S->reads[b].aln_t_s; });
+    for (uint32_t i = 0; i < n; ++i) {
+        const np2_read_t &rd = S->reads[order[i]];
+        const uint8_t *nb = S->nibbles.data() + rd.nib_off;
+        cig.clear();
+        seq.clear();
+        uint32_t rlen = 0;
+        for (uint32_t c = 0; c < rd.n_cols; ++c) {
+            const uint8_t x = (c & 1) ? (nb[c >> 1] & 15) : (nb[c >> 1] >> 4);
+            const uint8_t q = x & 7;
+            const uint32_t op = (x & 8) ? 1u : (q == 4 ? 2u : 0u); // I, D, M
+            if (op != 2) seq.push_back(enc4[q]);
+            if (op != 1) ++rlen;
+            if (!cig.empty() && (cig.back() & 15) == op) cig.back() += 16;
+            else cig.push_back(16 | op);
+        }
+        char name[24];
+        const int ln = snprintf(name, sizeof name, "r%u", i) + 1;
+        off[i] = out.size();
+        ps[i] = (int32_t)rd.aln_t_s;
+        rl[i] = rlen;
+        const uint32_t l_seq = (uint32_t)seq.size();
+        const uint32_t body = 32 + (uint32_t)ln + 4 * (uint32_t)cig.size() + (l_seq + 1) / 2 + l_seq;
+        put32(out, body);
+        put32(out, (uint32_t)tid);
+        put32(out, rd.aln_t_s);
+        out.push_back((uint8_t)ln);
+        out.push_back(60);
+        const uint16_t bin = reg2bin(rd.aln_t_s, (int64_t)rd.aln_t_s + (rlen ? rlen : 1));
+        out.push_back((uint8_t)bin), out.push_back((uint8_t)(bin >> 8));
+        out.push_back((uint8_t)cig.size()), out.push_back((uint8_t)(cig.size() >> 8));
+        const uint16_t flag = (i & 1) ? 16 : 0;
+        out.push_back((uint8_t)flag), out.push_back((uint8_t)(flag >> 8));
+        put32(out, l_seq);
+        put32(out, 0xFFFFFFFFu), put32(out, 0xFFFFFFFFu), put32(out, 0);
+        out.insert(out.end(), name, name + ln);
+        for (uint32_t w : cig) put32(out, w);
+        for (uint32_t k = 0; k < l_seq; k += 2) out.push_back((uint8_t)((seq[k] << 4) | (k + 1 < l_seq ? seq[k + 1] : 0)));
+        out.insert(out.end(), l_seq, (uint8_t)0xFF);
+    }
+    off[n] = out.size();
+    *blob = (uint8_t *)malloc(out.size() ? out.size() : 1);
+    memcpy(*blob, out.data(), out.size());
+    *rec_off = off, *pos = ps, *ref_len = rl;
+    return n;
+}
+void np2s_free_buf(void *p) { free(p); }
+
 // Build a yak v2 table (pre = 10) from the true haplotypes: count = min(1023, Poisson(lambda * m))
 // where m is the canonical k-mer's multiplicity over the haplotype(s).  Zero counts are dropped.
 int np2s_yak_build_multi(void **hs_in, uint32_t n_h, uint32_t k, double lambda, uint64_t seed, const uint64_t **words,
