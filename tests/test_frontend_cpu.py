@@ -138,3 +138,24 @@ def test_oracle_secondary_seq_recovery_rules():
     with pytest.raises(AssertionError):
         orc.secondary_seqs(recs + [dict(name=b"a", flag=0, seq="AC")])
 
+
+
+def test_generator_bam_records_equal_the_python_writer(tmp_path):
+    # Synth.bam_records (C++) + bamio.write_bam_raw: whole-assembly BAM files for bench.py without the per-column Python
+    # loop of pileup_to_records; same records, valid BGZF, an index the C++ reader accepts
+    from nextpolish2_amd.bamio import pileup_to_records, read_bam, write_bam, write_bam_raw
+    from nextpolish2_amd.synth import Synth
+    ss = [Synth(30000, seed=5, diploid=True, name="a"), Synth(20000, seed=6, name="b")]
+    refs = [(s.pileup.name, s.pileup.L) for s in ss]
+    write_bam_raw(str(tmp_path / "x.bam"), refs, [s.bam_records(i) for i, s in enumerate(ss)], threads=2)
+    recs = []
+    for i, s in enumerate(ss):
+        recs += pileup_to_records(s.pileup, tid=i)
+    write_bam(str(tmp_path / "y.bam"), refs, recs)
+    ra, xa = read_bam(str(tmp_path / "x.bam"))
+    rb, xb = read_bam(str(tmp_path / "y.bam"))
+    assert ra == rb and len(xa) == len(xb) == sum(s.pileup.n_reads - 1 for s in ss)
+    for a, b in zip(xa, xb):
+        assert all(a[k] == b[k] for k in ("tid", "pos", "mapq", "cigar", "seq"))
+    bam = np2io.Bam(str(tmp_path / "x.bam"))  # header + .bai parse
+    assert bam.refs() == refs

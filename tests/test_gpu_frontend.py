@@ -226,3 +226,18 @@ def test_cli_many_contigs_concurrent_contexts(tmp_path):
         pu = orc.front_end(syn[tid].pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts())
         b, p = o.polish(pu, Opts())
         assert b">c%d start:%d end:%d\n%s\n" % (tid, p[0], p[-1], b.tobytes()) in outs[0]
+
+
+def test_command_line_on_a_whole_assembly_bam_equals_the_batch_driver(tmp_path):
+    # bench.py's end_to_end_assembly leg at a small scale: BAM written from the generator's records, the CLI's code
+    # path in process, output compared with the resident pileups polished through the batch driver
+    from bench import end_to_end_assembly, make_assembly
+    from nextpolish2_amd import BatchPolisher
+    syn = make_assembly([60000, 45000, 30000], 30, 7, True)
+    yaks = [Synth.yak_assembly(syn, 21), Synth.yak_assembly(syn, 31)]
+    pol = Polisher(yaks)
+    bp = BatchPolisher(pol, 3)
+    out = bp.polish([pol.upload(s.pileup) for s in syn], Opts())
+    r = end_to_end_assembly(syn, yaks, str(tmp_path), [np.array(o[0]) for o in out], [o[1] for o in out], workers=2)
+    assert r["identical_to_resident_path"], r
+    bp.close()
