@@ -28,9 +28,9 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
          784333, 1091291, 948066, 85779]
 # HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
-# profiles/r02c_yeast_pmc_fetch_write.json (average over the three launches of a step), profiles/r02c_ecoli_pmc_fetch_write.json
-PMC_LAUNCHES = {"yeast": 3, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 42316.0 + 50910.7) * 1024), "ecoli": int((2 * 48519.1 + 39668.4) * 1024)}
+# profiles/r02d_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r02c_ecoli_pmc_fetch_write.json
+PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
+PMC_TRAFFIC = {"yeast": int((2 * 31832.1 + 38129.7) * 1024), "ecoli": int((2 * 48519.1 + 39668.4) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--workload", choices=["yeast", "ecoli"], default="yeast")
     ap.add_argument("--depth", type=int, default=30)
     ap.add_argument("--scale", type=float, default=1.0, help="scale every contig length (tests; the metric is quoted at 1.0)")
-    ap.add_argument("--groups", type=int, default=3, help="batch groups (host threads driving one np2_batch_t each)")
+    ap.add_argument("--groups", type=int, default=4, help="batch groups (host threads driving one np2_batch_t each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the two untimed steps behind roofline_exclusive (profiling runs)")
