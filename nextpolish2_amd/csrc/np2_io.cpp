@@ -3,6 +3,7 @@
 #include "../../include/np2_io.h"
 #include "np2_ctx.hpp"
 
+#include <algorithm>
 #include <zlib.h>
 
 #include <atomic>
@@ -127,7 +128,9 @@ struct Bgzf {
 
 // Small persistent pool for the input side: BGZF blocks are independent deflate streams and BAM records independent
 // byte ranges, so inflate and record copy are plain parallel loops.  Work items are handed out by an atomic counter;
-// the calling thread works too.  One pool per process, sized to the host (at most 64 workers).
+// the calling thread works too.  One pool per process, sized to the host (at most 64 workers).  Several loops may be
+// in flight at once (the command line keeps a few contigs' front ends going side by side): a worker takes items from
+// whichever open loop still has some, so a single caller gets the whole pool and concurrent callers share it.
 class IoPool {
   public:
     static IoPool &get() {
@@ -143,33 +146,37 @@ class IoPool {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
-        std::lock_guard<std::mutex> call_lock(call_mu_); // one parallel loop at a time
-        std::atomic<size_t> next{0};
-        std::atomic<unsigned> left{want - 1};
-        std::function<void()> body = [&]() {
-            for (;;) {
-                const size_t i = next.fetch_add(1, std::memory_order_relaxed);
-                if (i >= n) break;
-                fn(i);
-            }
-        };
+        Job job;
+        job.n = n;
+        job.slots = want - 1; // helpers wanted besides the caller
+        std::function<void(size_t)> body = fn;
+        job.fn = &body;
         {
             std::lock_guard<std::mutex> l(mu_);
-            job_ = &body;
-            job_left_ = &left;
-            tickets_ = want - 1;
-            ++gen_;
+            jobs_.push_back(&job);
         }
         cv_.notify_all();
-        body();
-        while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            job_ = nullptr;
-        }
+        run(job);
+        std::unique_lock<std::mutex> l(mu_);
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job)); // no new helper can pick it up from here on
+        done_cv_.wait(l, [&] { return job.helpers == 0; });
     }
 
   private:
+    struct Job {
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        unsigned slots = 0;   // helpers that may still join (guarded by mu_)
+        unsigned helpers = 0; // helpers currently inside (guarded by mu_)
+        std::function<void(size_t)> *fn = nullptr;
+    };
+    static void run(Job &j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) break;
+            (*j.fn)(i);
+        }
+    }
     IoPool() {
         unsigned hw = std::thread::hardware_concurrency();
         unsigned n = std::min<unsigned>(64, std::max<unsigned>(2, hw / 2));
@@ -177,31 +184,28 @@ class IoPool {
         for (unsigned i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
         for (auto &t : workers_) t.detach();
     }
+    Job *pick() { // mu_ held: an open loop with items left and a free helper slot
+        for (Job *j : jobs_)
+            if (j->slots && j->next.load(std::memory_order_relaxed) < j->n) return j;
+        return nullptr;
+    }
     void loop() {
-        uint64_t seen = 0;
+        std::unique_lock<std::mutex> l(mu_);
         for (;;) {
-            std::function<void()> *job = nullptr;
-            std::atomic<unsigned> *left = nullptr;
-            {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (tickets_ == 0 || !job_) continue;
-                --tickets_;
-                job = job_;
-                left = job_left_;
-            }
-            (*job)();
-            left->fetch_sub(1, std::memory_order_release);
+            Job *j = nullptr;
+            cv_.wait(l, [&] { return (j = pick()) != nullptr; });
+            --j->slots;
+            ++j->helpers;
+            l.unlock();
+            run(*j);
+            l.lock();
+            if (--j->helpers == 0) done_cv_.notify_all();
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex mu_, call_mu_;
-    std::condition_variable cv_;
-    std::function<void()> *job_ = nullptr;
-    std::atomic<unsigned> *job_left_ = nullptr;
-    unsigned tickets_ = 0;
-    uint64_t gen_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<Job *> jobs_;
 };
 
 // growable byte buffer without value-initialisation (a std::vector would zero 100+ MiB per refill just to have inflate
