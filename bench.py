@@ -418,14 +418,14 @@ def main():
         out_line["roofline_exclusive"] = {"achieved": round(ach_x, 2), "frac": round(ach_x / HBM_PEAK_GBS, 5), "unit": "GB/s",
                                           "avg_launch_ms": round(excl[0] / max(1, excl[1]), 4), "launches_per_step": excl[1],
                                           "note": "one batch group at a time, outside the timed region"}
-    if rank == 0 and not a.no_end_to_end:  # (before the CPU baseline: its hundreds of threads leave the host noisy)
+    if rank == 0 and world == 1 and not a.no_end_to_end:  # (N = 1 only; before the CPU baseline: its hundreds of threads leave the host noisy)
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             mid = sorted(range(len(syn)), key=lambda i: lengths[i])[len(syn) // 2]
             out_line["end_to_end"] = end_to_end(pol, syn[mid], yaks, opts, td, bases[mid])
             if not single and a.scale == 1.0:
                 out_line["end_to_end_assembly"] = end_to_end_assembly(syn, yaks, td, bases, spans)
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # (the host-side baseline is reported at N = 1 only)
         # CPU baseline: the oracle (a port of the reference algorithm; the Rust reference cannot be built here)
         cb, oracle_out = cpu_baseline(syn, yaks, opts, a.cpu_threads)
         out_line["cpu_baseline"] = cb
