@@ -242,8 +242,8 @@ struct np2_ctx {
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
     uint32_t deep_min = 65536; // coverage from which the on-chip DP of short runs is off (NP2_TEST_DEEP_COV lowers it: tests)
     DevBuf<uint32_t> lq_list, hbits; // consensus indices of the low-quality bases; bitmap of the raw regions' head indices
-    DevBuf<uint32_t> blk_lq, blk_lq_off; // low-quality bases written per block of the consensus write-out, and their scan
-    DevBuf<uint8_t> lqn;                 // ... per contig position
+    DevBuf<uint32_t> lqc, lqoff; // low-quality bases written per dirty run, and their exclusive scan
+    DevBuf<uint8_t> pflag;               // per contig position: has exception nodes | coverage below 2
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;

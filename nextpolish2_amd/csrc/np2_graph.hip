@@ -415,7 +415,7 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
                                                     const uint32_t *__restrict__ tile_rd, int32_t *__restrict__ cov,
                                                     const uint8_t *__restrict__ refnib, uint32_t *__restrict__ emit,
                                                     long long *__restrict__ tile_gain, uint32_t *__restrict__ deep_flag,
-                                                    int32_t deep_min) {
+                                                    int32_t deep_min, uint8_t *__restrict__ pflag) {
     __shared__ uint32_t cnt[TILE];
     __shared__ int32_t dcov[TILE + 1];
     __shared__ uint32_t sh[8];
@@ -592,6 +592,14 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     }
     // ---- clean positions: consensus emission flag (the contig base, unless it is a gap code) and their share of the
     //      best-path score: a clean position after a clean one adds 10 * c0 - 4 * cov = 6 * cov -------------------
+    // per position: bit 0 = has exception nodes, bit 1 = coverage below 2 (what the consensus write-out needs to know
+    // about a position, in one byte instead of two node offsets and the coverage); four positions per store
+    if (q0 < npos) {
+        uint32_t pf = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) pf |= ((cj[j] ? 1u : 0u) | (cv[j] < 2 ? 2u : 0u)) << (8 * j);
+        *reinterpret_cast<uint32_t *>(pflag + start + q0) = pf; // (padded past L)
+    }
     const bool pd0 = q0 ? cnt[q0 - 1] != 0 : prevd != 0;
     {
         long long gain = 0;
@@ -669,8 +677,9 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min) {
-    NP2_LAUNCH(k_tile_write, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd, cov, refnib, emit, tile_gain, deep_flag, (int32_t)deep_min);
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min,
+                       uint8_t *pflag) {
+    NP2_LAUNCH(k_tile_write, dim3(n_tiles), 256, s, keys, vals, TileLayout{tile_n, tile_scan, bucket_cap}, tile_noff, tile_roff, alive, L, n_tiles, nd, nrec, node_off, run_start, reads, tile_rd_off, tile_rd, cov, refnib, emit, tile_gain, deep_flag, (int32_t)deep_min, pflag);
 }
 
 } // namespace np2

@@ -576,6 +576,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     cx->nrec.ensure((size_t)T + 32); // the DP kernels prefetch a fixed number of records per position
     cx->node_off.ensure(L + 16); // k_dp_bt_short reads fixed windows past a run's start
     cx->cov.ensure(L + 16);
+    cx->pflag.ensure((size_t)L + TILE + 16); // (k_tile_write stores four flags at a time, up to the end of the last tile)
     cx->run_start.ensure(L + 2);
     cx->run_end.ensure(L + 2);
     cx->emit.ensure(L + 2);
@@ -594,7 +595,8 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
     launch_tile_write(s, cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->bucket_cap, cx->tile_noff.p,
                       cx->tile_roff.p, n_tiles, cx->alive.p, L, nd, cx->nrec.p, cx->node_off.p, cx->run_start.p,
                       c->reads.p, c->tile_rd_off.p, c->tile_rd.p, cx->cov.p, c->refnib.p, cx->emit.p,
-                      (long long *)cx->tile_gain.p, cx->scal.p + S_DEEP /* reset by launch_tile_offsets above */, cx->deep_min);
+                      (long long *)cx->tile_gain.p, cx->scal.p + S_DEEP /* reset by launch_tile_offsets above */, cx->deep_min,
+                      cx->pflag.p);
     // no read-back: downstream kernels are launched with the bound below and check the device-side counters
     n_runs = std::min<uint32_t>(T, L);
     n_nodes = T;
@@ -603,7 +605,7 @@ void build_graph(np2_ctx *cx, np2_contig *c, uint32_t T, uint32_t &n_nodes, uint
 
 GraphPtrs graph_ptrs(np2_ctx *cx, np2_contig *c) {
     NodeArrays nd{cx->npos.p, cx->nbases.p, cx->ndelta.p, cx->ncount.p, cx->nminr.p};
-    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L, cx->nrec.p, cx->scal.p + S_DEEP};
+    return GraphPtrs{c->refnib.p, cx->node_off.p, nd, cx->cov.p, c->L, cx->nrec.p, cx->scal.p + S_DEEP, cx->pflag.p};
 }
 
 void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
@@ -684,11 +686,9 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_
     const uint32_t n_words = (M_cap + 31) / 32;
     cx->lq_list.ensure((size_t)lq_cap + 2);
     cx->hbits.ensure((size_t)n_words + 2);
-    const uint32_t n_blk = lq_blocks(L);
-    cx->blk_lq.ensure((size_t)n_blk + 2);
-    cx->blk_lq_off.ensure((size_t)n_blk + 2);
-    cx->lqn.ensure((size_t)L + 2);
-    const uint32_t *const n_lq = cx->blk_lq_off.p + n_blk; // total of the scanned block counts
+    cx->lqc.ensure((size_t)n_runs + 4);
+    cx->lqoff.ensure((size_t)n_runs + 4);
+    const uint32_t *const n_lq = cx->lqoff.p + n_runs; // total of the scanned per-run counts (n_runs: host-side bound)
     const uint32_t *M_p = cx->eoff.p + L;
     {
         EventTimer t(cx, "dp_backtrack");
@@ -727,16 +727,16 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_
                          cx->run_gain.p, (const long long *)cx->tile_gain.p,
                          (c->L + TILE - 1) >> TILE_SHIFT, cx->emit.p, cx->scal.p + S_PATHBEGIN, cx->bt_path.p);
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
-        launch_bt_write(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p,
-                        cx->lq_nothead.p, cx->lqn.p, cx->blk_lq.p);
+        launch_bt_write(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->emit.p, cx->eoff.p, cx->bt_path.p,
+                        cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, cx->lq_nothead.p, cx->lqc.p);
     }
     {
         EventTimer t(cx, "lq_regions");
         // raw regions: chain heads marked in a bitmap over the emission indices, heads per word scanned, regions
         // written out in bit order (right -> left, the reference's numbering)
-        exclusive_total_n(cx, cx->blk_lq.p, cx->blk_lq_off.p, n_blk);
-        launch_lq_list(s, gp, cx->emit.p, cx->eoff.p, cx->bt_path.p, cx->lqn.p, cx->blk_lq_off.p, lq_cap, cx->lq_list.p,
-                       cx->scal.p + S_ERR);
+        exclusive_total(cx, cx->lqc.p, cx->lqoff.p, (size_t)n_runs + 1); // (lqc[n_runs] = 0)
+        launch_lq_list(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->emit.p, cx->eoff.p, cx->bt_path.p,
+                       cx->lqoff.p, lq_cap, cx->lq_list.p, cx->scal.p + S_ERR);
         zero32(cx, cx->hbits.p, n_words + 1);
         launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, cx->lq_list.p, n_lq, lq_cap, cx->lq_kind.p,
                        cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, cx->rstart.p, cx->rend.p);

@@ -1351,80 +1351,78 @@ __device__ __forceinline__ void k_dp_finish(const uint32_t np2_bid, const uint32
     emit[L] = 0;
 }
 
-// Consensus write-out, one thread per contig position: a clean position emits the contig base; the first position of a
-// dirty run copies the run's recorded path (the walk went right -> left).  Output offsets grow with the position, so
-// neighbouring threads write neighbouring consensus indices.  Low-quality bases only come out of dirty runs: every
-// thread leaves the number it wrote (lqn, one byte per position, saturating) and every block their sum; k_lq_list
-// turns the scanned block sums into the list of the low-quality bases' consensus indices, which the LQ-region kernels
-// walk instead of keeping one mostly idle thread per consensus base.  (A single device counter bumped once per block
-// would serialise: 47 k same-address atomics cost more than the whole write-out.)
-__device__ __forceinline__ void k_cns_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ refnib,
-                            const int32_t *__restrict__ cov, const uint32_t *__restrict__ emit,
-                            const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
+// Consensus write-out in two kernels.  k_cns_write: one thread per contig position, clean positions only — each emits
+// the contig base at its scanned offset (neighbouring threads write neighbouring consensus indices: a pure stream).
+// k_cns_runs: one thread per dirty run copies the run's recorded path (the walk went right -> left) and counts the
+// low-quality bases in it (they only come out of dirty runs).  One kernel for both had nearly every wave of 64
+// positions wait for its one run-start lane's serial copy (98 us per call on the yeast-sized assembly); split it is
+// 46 + 55 us — no faster by itself (the per-run copy is a chain of dependent loads and byte stores), but the runs'
+// counts then come in run order, which halves the list kernel.  The scanned per-run counts place the consensus indices of the low-quality
+// bases in an ordered list (k_lq_list), which the LQ-region kernels walk instead of keeping one mostly idle thread
+// per consensus base.  (A single device counter bumped once per block would serialise: tried.)
+__device__ __forceinline__ void k_cns_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint8_t *__restrict__ refnib,
+                            const uint8_t *__restrict__ pflag, const uint32_t *__restrict__ emit,
+                            const uint32_t *__restrict__ eoff, uint32_t L,
                             uint32_t *__restrict__ cns_pos, uint8_t *__restrict__ cns_base,
-                            uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead,
-                            uint8_t *__restrict__ lqn, uint32_t *__restrict__ blk_lq) {
-    __shared__ uint32_t s_lq;
-    if (threadIdx.x == 0) s_lq = 0;
-    __syncthreads();
+                            uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead) {
     const uint32_t p = np2_bid * blockDim.x + threadIdx.x;
-    const uint32_t e = p < L ? emit[p] : 0u;
-    uint32_t n_lq = 0;
-    if (e) {
-        const uint32_t o0 = eoff[p];
-        const uint32_t no = node_off[p];
-        if (node_off[p + 1] == no) { // clean position
-            lq_nothead[o0] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
-            cns_pos[o0] = p;
-            cns_base[o0] = code_to_ascii(ref_code(refnib, p));
-            cns_cls[o0] = cov[p] < 2 ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
-        } else {
-            const uint64_t *src = path + (size_t)p + no; // first position of a dirty run (only those carry a count)
-            for (uint32_t n = 0; n < e; ++n) {
-                const uint64_t w = src[n];
-                const uint32_t o = o0 + e - 1 - n;
-                cns_pos[o] = (uint32_t)(w >> 32);
-                cns_base[o] = (uint8_t)(w >> 8);
-                cns_cls[o] = (uint8_t)w;
-                lq_nothead[o] = 0;
-                n_lq += (uint8_t)w == CLS_LQ ? 1u : 0u;
-            }
-            if (n_lq) atomicAdd(&s_lq, n_lq);
-        }
-    }
-    if (p < L) lqn[p] = (uint8_t)min(n_lq, 255u); // (255: "count again")
-    __syncthreads();
-    if (threadIdx.x == 0) blk_lq[np2_bid] = s_lq;
+    if (p >= L || !emit[p]) return;
+    const uint8_t pf = pflag[p];
+    if (pf & 1) return; // first position of a dirty run: k_cns_runs
+    const uint32_t o0 = eoff[p];
+    lq_nothead[o0] = 0; // every consensus index is written exactly once: clears the LQ chain flags for k_lq_scan
+    cns_pos[o0] = p;
+    cns_base[o0] = code_to_ascii(ref_code(refnib, p));
+    cns_cls[o0] = (pf & 2) ? CLS_RESET : CLS_HQ; // count == coverage -> qv = 100
 }
-
-// The consensus indices of the low-quality bases (ascending): same thread mapping as k_cns_write, offsets from the
-// scanned block sums; only the threads that wrote some go back to their run's path.
-__device__ __forceinline__ void k_lq_list(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ emit,
-                          const uint32_t *__restrict__ eoff, const uint64_t *__restrict__ path, uint32_t L,
-                          const uint8_t *__restrict__ lqn, const uint32_t *__restrict__ blk_lq_off, uint32_t cap,
-                          uint32_t *__restrict__ lq_list, uint32_t *__restrict__ err) {
-    __shared__ uint32_t sh[8];
-    const uint32_t base = blk_lq_off[np2_bid];
-    if (blk_lq_off[np2_bid + 1] == base) return; // (uniform)
-    const uint32_t p = np2_bid * 256 + threadIdx.x;
-    uint32_t n_lq = p < L ? lqn[p] : 0u, e = 0;
-    const uint64_t *src = nullptr;
-    if (n_lq) {
-        e = emit[p];
-        src = path + (size_t)p + node_off[p];
-        if (n_lq == 255) { // saturated: count again
-            n_lq = 0;
-            for (uint32_t n = 0; n < e; ++n) n_lq += (uint8_t)src[n] == CLS_LQ ? 1u : 0u;
+// (launched over the host-side bound on the number of runs; slots past the device-side count are cleared for the scan)
+__device__ __forceinline__ void k_cns_runs(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ run_start,
+                           const uint32_t *__restrict__ n_runs, uint32_t bound, const uint32_t *__restrict__ node_off,
+                           const uint32_t *__restrict__ emit, const uint32_t *__restrict__ eoff,
+                           const uint64_t *__restrict__ path, uint32_t *__restrict__ cns_pos,
+                           uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
+                           uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ lqc) {
+    const uint32_t nr = min(*n_runs, bound);
+    for (uint32_t r = np2_bid * blockDim.x + threadIdx.x; r <= bound; r += np2_nb * blockDim.x) {
+        uint32_t n_lq = 0;
+        if (r < nr) {
+            const uint32_t a = run_start[r];
+            const uint32_t e = emit[a];
+            if (e) {
+                const uint32_t o0 = eoff[a];
+                const uint64_t *src = path + (size_t)a + node_off[a];
+                for (uint32_t n = 0; n < e; ++n) {
+                    const uint64_t w = src[n];
+                    const uint32_t o = o0 + e - 1 - n;
+                    cns_pos[o] = (uint32_t)(w >> 32);
+                    cns_base[o] = (uint8_t)(w >> 8);
+                    cns_cls[o] = (uint8_t)w;
+                    lq_nothead[o] = 0;
+                    n_lq += (uint8_t)w == CLS_LQ ? 1u : 0u;
+                }
+            }
         }
+        lqc[r] = n_lq;
     }
-    uint32_t tot;
-    uint32_t k = base + block_excl_scan<OpAdd, 4>(n_lq, sh, tot);
-    if (n_lq) {
-        if (k + n_lq > cap) {
+}
+// the consensus indices of the low-quality bases, ascending (runs are in position order): one thread per run that has any
+__device__ __forceinline__ void k_lq_list(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ run_start,
+                          const uint32_t *__restrict__ n_runs, uint32_t bound, const uint32_t *__restrict__ node_off,
+                          const uint32_t *__restrict__ emit, const uint32_t *__restrict__ eoff,
+                          const uint64_t *__restrict__ path, const uint32_t *__restrict__ lqoff, uint32_t cap,
+                          uint32_t *__restrict__ lq_list, uint32_t *__restrict__ err) {
+    const uint32_t nr = min(*n_runs, bound);
+    for (uint32_t r = np2_bid * blockDim.x + threadIdx.x; r < nr; r += np2_nb * blockDim.x) {
+        uint32_t k = lqoff[r];
+        const uint32_t c = lqoff[r + 1] - k;
+        if (!c) continue;
+        if (k + c > cap) {
             atomicOr(err, LQ_LIST_ERR);
-            return;
+            continue;
         }
-        const uint32_t o0 = eoff[p];
+        const uint32_t a = run_start[r];
+        const uint32_t e = emit[a], o0 = eoff[a];
+        const uint64_t *src = path + (size_t)a + node_off[a];
         for (uint32_t n = e; n-- > 0;) // path entry n sits at consensus index o0 + e - 1 - n: ascending indices
             if ((uint8_t)src[n] == CLS_LQ) lq_list[k++] = o0 + e - 1 - n;
     }
@@ -1758,7 +1756,7 @@ void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) NP2_LAUNCH(k_kill_reads, grid1(n), 256, s, ids, n, alive);
 }
-static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec, gp.deep}; }
+static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec, gp.deep}; } // (pflag: write-out only)
 
 void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
                      const uint32_t *n_runs, uint32_t max_runs, uint32_t *run_end, int64_t *run_gain, uint32_t *emit,
@@ -1783,15 +1781,17 @@ void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_st
                       const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path) {
     NP2_LAUNCH(k_dp_finish, dim3(64), 256, s, run_gain, n_runs, tile_gain, n_tiles, total_gain, blocks_done, mk_graph(gp), nscore, last_n0_score, run_start, nbesti, n0_besti, best_idx, emit, path_begin, path);
 }
-void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint8_t *lqn,
-                     uint32_t *blk_lq) {
-    NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.node_off, gp.refnib, gp.cov, emit, eoff, path, gp.L, cns_pos, cns_base, cns_cls, lq_nothead, lqn, blk_lq);
+static inline dim3 run_grid(uint32_t bound) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((bound + 256) / 256, 4096))); }
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                     uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lqc) {
+    NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.refnib, gp.pflag, emit, eoff, gp.L, cns_pos, cns_base, cns_cls, lq_nothead);
+    NP2_LAUNCH(k_cns_runs, run_grid(run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, cns_pos, cns_base, cns_cls, lq_nothead, lqc);
 }
-uint32_t lq_blocks(uint32_t L) { return (L + 255) / 256; } // blocks of k_cns_write / k_lq_list
-void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                    const uint8_t *lqn, const uint32_t *blk_lq_off, uint32_t cap, uint32_t *lq_list, uint32_t *err) {
-    NP2_LAUNCH(k_lq_list, grid1(gp.L), 256, s, gp.node_off, emit, eoff, path, gp.L, lqn, blk_lq_off, cap, lq_list, err);
+void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                    uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                    const uint32_t *lqoff, uint32_t cap, uint32_t *lq_list, uint32_t *err) {
+    NP2_LAUNCH(k_lq_list, run_grid(run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, lqoff, cap, lq_list, err);
 }
 static inline dim3 lq_grid(uint32_t cap) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 255) / 256, 2048))); }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,

@@ -40,6 +40,7 @@ struct GraphPtrs {
     uint32_t L;
     const uint2 *nrec; // packed node records {bases | delta << 16, count}
     const uint32_t *deep; // per-pass flag: a position covered 65536x or more (set by the tile builder)
+    const uint8_t *pflag; // per position: bit 0 = has exception nodes, bit 1 = coverage below 2
 };
 struct CandPtrs {
     const np2_read_t *reads;
@@ -90,16 +91,17 @@ void launch_dp_finish(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_st
                       unsigned long long *total_gain, uint32_t *blocks_done, uint32_t *best_idx, const int64_t *run_gain,
                       const long long *tile_gain, uint32_t n_tiles, uint32_t *emit, uint32_t *path_begin, uint64_t *path);
 // consensus write-out: clean positions + the recorded run paths, one thread per contig position
-// consensus write-out with per-position / per-block counts of the low-quality bases written; the scanned block counts
-// place their consensus indices in lq_list (count on the device, bounded by lq_cap) and the LQ kernels run over that
-// list.  Region heads are marked in a bitmap over the emission indices (zeroed by the caller), counted per word,
-// scanned, and written out in bit order = the reference's order.
-void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint8_t *lqn,
-                     uint32_t *blk_lq);
-uint32_t lq_blocks(uint32_t L);
-void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
-                    const uint8_t *lqn, const uint32_t *blk_lq_off, uint32_t cap, uint32_t *lq_list, uint32_t *err);
+// consensus write-out: clean positions by position, dirty runs by run (with the number of low-quality bases each
+// wrote: lqc[0 .. run_bound], cleared past the device-side run count); the scanned counts place the consensus indices of
+// the low-quality bases in lq_list (count on the device, bounded by lq_cap) and the LQ kernels run over that list.
+// Region heads are marked in a bitmap over the emission indices (zeroed by the caller), counted per word, scanned, and
+// written out in bit order = the reference's order.
+void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                     uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                     uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lqc);
+void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
+                    uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
+                    const uint32_t *lqoff, uint32_t cap, uint32_t *lq_list, uint32_t *err);
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
                     uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t *rstart, uint32_t *rend);
@@ -176,7 +178,8 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
-                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min);
+                       int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min,
+                       uint8_t *pflag);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)
