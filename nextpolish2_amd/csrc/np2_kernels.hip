@@ -1382,8 +1382,9 @@ __device__ __forceinline__ void k_cns_runs(const uint32_t np2_bid, const uint32_
                            const uint64_t *__restrict__ path, uint32_t *__restrict__ cns_pos,
                            uint8_t *__restrict__ cns_base, uint8_t *__restrict__ cns_cls,
                            uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ lqc) {
-    const uint32_t nr = min(*n_runs, bound);
-    for (uint32_t r = np2_bid * blockDim.x + threadIdx.x; r <= bound; r += np2_nb * blockDim.x) {
+    // four lanes per run (a run's path has a handful of entries: one round of loads and stores instead of a chain)
+    const uint32_t nr = min(*n_runs, bound), q = threadIdx.x & 3;
+    for (uint32_t r = (np2_bid * blockDim.x + threadIdx.x) >> 2; r <= bound; r += (np2_nb * blockDim.x) >> 2) {
         uint32_t n_lq = 0;
         if (r < nr) {
             const uint32_t a = run_start[r];
@@ -1391,7 +1392,7 @@ __device__ __forceinline__ void k_cns_runs(const uint32_t np2_bid, const uint32_
             if (e) {
                 const uint32_t o0 = eoff[a];
                 const uint64_t *src = path + (size_t)a + node_off[a];
-                for (uint32_t n = 0; n < e; ++n) {
+                for (uint32_t n = q; n < e; n += 4) {
                     const uint64_t w = src[n];
                     const uint32_t o = o0 + e - 1 - n;
                     cns_pos[o] = (uint32_t)(w >> 32);
@@ -1402,7 +1403,9 @@ __device__ __forceinline__ void k_cns_runs(const uint32_t np2_bid, const uint32_
                 }
             }
         }
-        lqc[r] = n_lq;
+        n_lq += __shfl_xor(n_lq, 1);
+        n_lq += __shfl_xor(n_lq, 2);
+        if (q == 0) lqc[r] = n_lq;
     }
 }
 // the consensus indices of the low-quality bases, ascending (runs are in position order): one thread per run that has any
@@ -1786,7 +1789,7 @@ void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
                      uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                      uint32_t *cns_pos, uint8_t *cns_base, uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lqc) {
     NP2_LAUNCH(k_cns_write, grid1(gp.L), 256, s, gp.refnib, gp.pflag, emit, eoff, gp.L, cns_pos, cns_base, cns_cls, lq_nothead);
-    NP2_LAUNCH(k_cns_runs, run_grid(run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, cns_pos, cns_base, cns_cls, lq_nothead, lqc);
+    NP2_LAUNCH(k_cns_runs, run_grid(4 * (uint64_t)run_bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : 4 * run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, cns_pos, cns_base, cns_cls, lq_nothead, lqc);
 }
 void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
