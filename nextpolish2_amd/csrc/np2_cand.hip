@@ -138,6 +138,7 @@ struct CandCtx {
     const uint32_t *pj;
     const uint32_t *pcount;
     const uint8_t *alive;
+    const ReadInfo *rinfo;
     const uint32_t *tile_rd_off; // reads overlapping each contig tile, ascending read index (built at upload)
     const uint32_t *tile_rd;
     uint32_t n_tiles;
@@ -145,7 +146,7 @@ struct CandCtx {
 };
 
 // checkpoint lookup: a non-insertion column at or before the first column of t_pos == start, and its t_pos
-__device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t start,
+__device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint64_t ck_off, uint32_t start,
                                             uint32_t &col, uint32_t &t) {
     col = 0;
     t = rd.aln_t_s;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const
         col = start;
         t = start;
     } else if (cki >= ck_first) {
-        col = cx.ckpt[cx.ck_off[r] + (cki - ck_first)];
+        col = cx.ckpt[ck_off + (cki - ck_first)];
         t = cki << CKPT_SHIFT;
     }
 }
@@ -169,10 +170,10 @@ __device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) {
 // Length of the candidate string of (read, region) and the column it starts at, 8 columns per step
 // (the emission rule of main.rs:1478-1521: every non-gap column whose t_pos lies in [start, end], from the reference
 // column of `start` on; the early exits of that loop all sit behind t_pos > end).
-__device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t start, uint32_t end,
-                                 uint32_t &col_start) {
+__device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint64_t ck_off, uint32_t start,
+                                 uint32_t end, uint32_t &col_start) {
     uint32_t col_ck, t_ck;
-    cand_anchor(cx, r, rd, start, col_ck, t_ck);
+    cand_anchor(cx, r, rd, ck_off, start, col_ck, t_ck);
     col_start = col_ck;
     if (end < t_ck) return 0;                                   // the read begins behind the region
     const uint32_t want_s = (start > t_ck ? start - t_ck : 0u) + 1; // col_start = want_s-th non-insertion column from col_ck
@@ -247,11 +248,11 @@ struct NibReader {
 // exactly those), so emission needs no t_pos tracking and goes 8 columns per step: nibbles -> byte selectors ->
 // ASCII through v_perm_b32 with the 8-entry code table in two registers, dword stores.  Only words holding a gap code
 // or the string's end take the per-column path.  The k-mer needs the first k non-gap codes and the decode limit.
-__device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t g, uint32_t col, uint32_t t,
+__device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint32_t pj, uint32_t g, uint32_t col, uint32_t t,
                            uint32_t len, uint8_t *__restrict__ seq_out, uint64_t *kmer_out) {
     const uint8_t *base = cx.nib + rd.nib_off;
     // ---- first k-mer -------------------------------------------------------------------------------------------------
-    const uint32_t limit = cx.lq_end[cx.pj[r]] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
+    const uint32_t limit = cx.lq_end[pj] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
     bool have_kmer = false;
     if (col + cx.ksize <= rd.n_cols) {
         // Common case, without the per-column loop: the k columns from `col` on are k plain bases (codes 0-3: no gap code
@@ -392,12 +393,12 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
         bool ok = false;
         if (i < lb) {
             r = cx.tile_rd[i];
-            const uint32_t j = cx.pj[r], n = cx.pcount[r];
-            ok = cx.alive[r] && n != 0 && j <= g && g - j < n;
-        }
-        if (ok) {
-            const np2_read_t rd = cx.reads[r];
-            len = cand_measure(cx, r, rd, start, end, col);
+            const ReadInfo ri = cx.rinfo[r]; // (pcount is 0 for a dropped read)
+            ok = ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount;
+            if (ok) {
+                const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
+                len = cand_measure(cx, r, rd, ri.ck_off, start, end, col);
+            }
         }
         const uint64_t ne = __ballot(len > 0);
         const uint32_t before = kept + (uint32_t)__builtin_popcountll(ne & ((1ULL << lane) - 1ULL));
@@ -532,10 +533,11 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
     const uint32_t ci = oc + lane;
     if (!act || ci >= cand_cap || (uint64_t)so + len > seq_cap) return;
     const uint32_t r = kept_read[slot];
-    const np2_read_t rd = cx.reads[r];
+    const ReadInfo ri = cx.rinfo[r];
+    const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
     cand_order[ci] = r;
     cand_seq_off[ci] = so;
-    cand_write(cx, r, rd, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
+    cand_write(cx, r, rd, ri.pj, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -567,7 +569,7 @@ void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint3
 }
 static CandCtx mk_cand(const CandPtrs &c) {
     return CandCtx{c.reads, c.nib,    c.ck_off, c.ckpt,        c.lq_start, c.lq_end, c.pj,
-                   c.pcount, c.alive, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
+                   c.pcount, c.alive, c.rinfo, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
 }
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,

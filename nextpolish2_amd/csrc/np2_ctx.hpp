@@ -242,6 +242,7 @@ struct np2_ctx {
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
     uint32_t deep_min = 65536; // coverage from which the on-chip DP of short runs is off (NP2_TEST_DEEP_COV lowers it: tests)
     DevBuf<uint32_t> lq_list, hbits; // consensus indices of the low-quality bases; bitmap of the raw regions' head indices
+    DevBuf<ReadInfo> rinfo;      // per read and pass: descriptor + checkpoint offset + region interval in one line
     DevBuf<uint32_t> lqc, lqoff; // low-quality bases written per dirty run, and their exclusive scan
     DevBuf<uint8_t> pflag;               // per contig position: has exception nodes | coverage below 2
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)

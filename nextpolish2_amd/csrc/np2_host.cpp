@@ -772,6 +772,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->smin.ensure(R + 2);
     cx->pj.ensure(R + 2);
     cx->pcount.ensure(R + 2);
+    cx->rinfo.ensure(R + 2);
     cx->reg_ncand.ensure(n_reg + 2);
     cx->reg_bytes.ensure(n_reg + 2);
     cx->reg_soff.ensure(n_reg + 2);
@@ -790,14 +791,14 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->kscore.ensure((size_t)NC_cap + 2);
     cx->long_list.ensure((size_t)NC_cap + 2);
     CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
-                cx->pcount.p, cx->alive.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles,     cx->yaks[0].k};
+                cx->pcount.p, cx->alive.p, cx->rinfo.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles, cx->yaks[0].k};
     {
         EventTimer t(cx, "candidates");
         // every live read covers a contiguous interval [pj, pj + pcount) of the region list
         launch_read_m(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, n_reg, cx->mval.p);
         scan_incl_min(cx, cx->mval.p, cx->smin.p, R);
         launch_pair_count(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, cx->lq_end.p, n_reg, cx->smin.p, cx->pj.p,
-                          cx->pcount.p);
+                          cx->pcount.p, c->ck_off.p, cx->rinfo.p);
         // one wavefront per region: find its reads, measure the candidates, keep the first 60 non-empty ones
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                               cx->reg_bytes.p, cx->reg_maxlen.p, cx->blk_sum.p);

@@ -1585,13 +1585,15 @@ __device__ __forceinline__ void k_read_m(const uint32_t np2_bid, const uint32_t 
 __device__ __forceinline__ void k_pair_count(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, uint32_t R, const uint8_t *__restrict__ alive,
                              const uint32_t *__restrict__ lq_start, const uint32_t *__restrict__ lq_end,
                              uint32_t n_reg, const int32_t *__restrict__ smin, uint32_t *__restrict__ pj,
-                             uint32_t *__restrict__ pcount) {
+                             uint32_t *__restrict__ pcount, const uint64_t *__restrict__ ck_off,
+                             ReadInfo *__restrict__ rinfo) {
     uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r >= R) return;
     uint32_t cnt = 0, j = 0;
+    const np2_read_t rd = reads[r];
     if (alive[r]) {
         const uint32_t s = min((uint32_t)smin[r], n_reg - 1);
-        const uint32_t ts = reads[r].aln_t_s, te = reads[r].aln_t_e;
+        const uint32_t ts = rd.aln_t_s, te = rd.aln_t_e;
         if (!(lq_start[s] < ts || lq_end[s] > te)) {
             j = count_gt_desc(lq_end, n_reg, te); // main.rs:1454-1460
             cnt = s - j + 1;
@@ -1599,6 +1601,7 @@ __device__ __forceinline__ void k_pair_count(const uint32_t np2_bid, const uint3
     }
     pj[r] = j;
     pcount[r] = cnt;
+    rinfo[r] = ReadInfo{rd.aln_t_s, rd.n_cols, rd.nib_off, ck_off[r], j, cnt};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1826,8 +1829,8 @@ void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uin
 }
 void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive,
                        const uint32_t *lq_start, const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin,
-                       uint32_t *pj, uint32_t *pcount) {
-    NP2_LAUNCH(k_pair_count, grid1(R), 256, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj, pcount);
+                       uint32_t *pj, uint32_t *pcount, const uint64_t *ck_off, ReadInfo *rinfo) {
+    NP2_LAUNCH(k_pair_count, grid1(R), 256, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj, pcount, ck_off, rinfo);
 }
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag) {

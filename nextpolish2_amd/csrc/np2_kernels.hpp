@@ -42,6 +42,14 @@ struct GraphPtrs {
     const uint32_t *deep; // per-pass flag: a position covered 65536x or more (set by the tile builder)
     const uint8_t *pflag; // per position: bit 0 = has exception nodes, bit 1 = coverage below 2
 };
+// what candidate extraction needs to know about a read, in one 32-byte line (built per pass by k_pair_count: a
+// (region, read) pair then costs one memory transaction for the read instead of six scattered ones)
+struct __attribute__((aligned(16))) ReadInfo {
+    uint32_t aln_t_s, n_cols;
+    uint64_t nib_off;
+    uint64_t ck_off;       // first checkpoint of the read
+    uint32_t pj, pcount;   // the read's region interval [pj, pj + pcount); 0 regions for a dropped read
+};
 struct CandPtrs {
     const np2_read_t *reads;
     const uint8_t *nib;
@@ -52,6 +60,7 @@ struct CandPtrs {
     const uint32_t *pj;
     const uint32_t *pcount;
     const uint8_t *alive;
+    const ReadInfo *rinfo;       // per read, packed (k_pair_count)
     const uint32_t *tile_rd_off; // per contig tile: reads overlapping it, ascending read index (built at upload)
     const uint32_t *tile_rd;
     uint32_t n_tiles;
@@ -127,8 +136,9 @@ void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_
 
 
 // ---- np2_cand.hip: region-major candidate extraction, single-block scans -----------------------------
-void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
-                       const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin, uint32_t *pj, uint32_t *pcount);
+void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive,
+                       const uint32_t *lq_start, const uint32_t *lq_end, uint32_t n_reg, const int32_t *smin,
+                       uint32_t *pj, uint32_t *pcount, const uint64_t *ck_off, ReadInfo *rinfo);
 void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
                           uint32_t *err);
 // exclusive sums of any length (reduce-then-scan over 4096-element tiles); part / part_off: scan3_tiles(n) + 1 words each
