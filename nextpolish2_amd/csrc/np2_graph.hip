@@ -147,7 +147,10 @@ template <uint32_t CAP>
 __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads,
                                                    const uint8_t *__restrict__ nib, const uint32_t *__restrict__ tile_n,
                                                    uint32_t bucket_cap, uint64_t *__restrict__ keys,
-                                                   uint32_t *__restrict__ vals, uint32_t *__restrict__ err) {
+                                                   uint32_t *__restrict__ vals, uint32_t *__restrict__ err,
+                                                   uint32_t n_above, uint32_t n_upto) {
+    // (tiles with n_above < records <= n_upto are this launch's: a contig whose fullest tile needs the big variant
+    // still sorts its ordinary tiles with the small one, at more blocks per CU)
     __shared__ uint32_t s_klo[CAP];  // bases << 16 | delta1 of the node key (its position is the group)
     __shared__ uint32_t s_v[CAP];    // read
     __shared__ uint16_t s_q[CAP];    // position inside the tile
@@ -157,7 +160,7 @@ __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32
     __shared__ uint32_t sh[8];
     const uint32_t n = tile_n[np2_bid], tid = threadIdx.x;
     const uint64_t a = (uint64_t)np2_bid * bucket_cap;
-    if (n == 0) return;
+    if (n <= n_above || n > n_upto) return;
     if (n > CAP) {
         if (tid == 0) atomicOr(err, 8u);
         return;
@@ -644,12 +647,16 @@ void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uin
 void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
                       uint32_t *err) {
-    if (max_tile <= 1024)
-        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
-    else if (max_tile <= 2048 && TILE_CAP > 2048)
-        NP2_LAUNCH(k_tile_sort<2048>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
-    else
-        NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err);
+    const uint32_t ALL = 0xFFFFFFFFu;
+    if (max_tile <= 1024) {
+        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, ALL);
+    } else {
+        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, 1024u);
+        if (max_tile <= 2048 && TILE_CAP > 2048)
+            NP2_LAUNCH(k_tile_sort<2048>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
+        else
+            NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
+    }
 }
 void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                            const uint32_t *tile_scanb, uint32_t n_tiles, uint32_t bucket_cap, const uint64_t *bkeys,
