@@ -255,10 +255,12 @@ __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, 
     const uint32_t limit = cx.lq_end[pj] + cx.ksize; // decode stops after t_pos > end[j] + k (main.rs:1467)
     bool have_kmer = false;
     if (col + cx.ksize <= rd.n_cols) {
-        // Common case, without the per-column loop: the k columns from `col` on are k plain bases (codes 0-3: no gap code
-        // to skip, no N / M whose third bit would smear into the neighbour, main.rs:1488-1492).  48 columns as three
-        // 8-byte words -> the 32 columns from `col` -> 2-bit codes squeezed together; the forward k-mer is their
-        // pair-wise bit reversal, the reverse complement their complement in place (kmer.rs:255-287).
+        // Common cases without the per-column loop: the first k non-gap codes sit inside the 32 columns from `col` and
+        // none of the columns up to the k-th one holds N / M (codes 5 / 6, whose third bit would smear into the
+        // neighbour, main.rs:1488-1492).  48 columns as three 8-byte words -> the 32 columns from `col`; gap columns
+        // (code 4: the read deletes a contig base) are taken out one at a time — a candidate has none or a few —, then
+        // the 2-bit codes are squeezed together; the forward k-mer is their pair-wise bit reversal, the reverse
+        // complement their complement in place (kmer.rs:255-287).
         const uint32_t k = cx.ksize, W0 = col >> 4, sh = (col & 15) * 4;
         auto ld = [&](uint32_t W) -> uint64_t {
             const uint2 v = *reinterpret_cast<const uint2 *>(base + ((size_t)W << 3));
@@ -267,16 +269,54 @@ __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, 
             return (uint64_t)x | ((uint64_t)y << 32);
         };
         const uint64_t x0 = ld(W0), x1 = ld(W0 + 1), x2 = ld(W0 + 2);
-        const uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0, hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+        uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0, hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
         auto nmask = [](uint32_t n) -> uint64_t { return n >= 16 ? ~0ULL : ((1ULL << (4 * n)) - 1ULL); }; // nibbles [0, n)
-        const uint64_t m_lo = nmask(k), m_hi = k > 16 ? nmask(k - 16) : 0ULL;
-        if ((((lo & m_lo) | (hi & m_hi)) & 0x4444444444444444ULL) == 0) {
-            // the loop also ends once t_pos runs past `limit`: harmless iff that has not happened by the last but one column
-            const uint32_t span = k - 2; // columns 1 .. k - 2 advance t_pos unless they are insertion columns
-            const uint64_t r_lo = nmask(k - 1) & ~0xFULL, r_hi = k - 1 > 16 ? nmask(k - 1 - 16) : 0ULL;
+        const uint64_t N1 = 0x1111111111111111ULL;
+        // the columns the read still has (at most 32 of them here)
+        const uint32_t avail = min(32u, rd.n_cols - col);
+        const uint64_t a_lo = nmask(avail), a_hi = avail > 16 ? nmask(avail - 16) : 0ULL;
+        const uint64_t ng_lo = ~(lo >> 2) & N1 & a_lo, ng_hi = ~(hi >> 2) & N1 & a_hi; // non-gap-ish columns (code < 4)
+        const uint32_t c_lo = (uint32_t)__builtin_popcountll(ng_lo);
+        if (c_lo + (uint32_t)__builtin_popcountll(ng_hi) >= k) {
+            // C: column (0 .. 31) of the k-th code below 4
+            uint32_t kk = k, C = 0;
+            uint64_t m = ng_lo;
+            if (kk > c_lo) kk -= c_lo, C = 16, m = ng_hi;
+            uint32_t c = (uint32_t)__builtin_popcount((uint32_t)m);
+            if (kk > c) kk -= c, C += 8, m >>= 32;
+            uint32_t m32 = (uint32_t)m;
+            c = (uint32_t)__builtin_popcount(m32 & 0xFFFFu);
+            if (kk > c) kk -= c, C += 4, m32 >>= 16;
+            c = (uint32_t)__builtin_popcount(m32 & 0xFFu);
+            if (kk > c) kk -= c, C += 2, m32 >>= 8;
+            c = (uint32_t)__builtin_popcount(m32 & 0xFu);
+            if (kk > c) C += 1;
+            const uint64_t u_lo = nmask(C + 1), u_hi = C + 1 > 16 ? nmask(C + 1 - 16) : 0ULL; // columns 0 .. C
+            // codes >= 4 among them must all be plain gaps (4): bit 2 set, bits 0 and 1 clear
+            const uint64_t hi4_lo = (lo >> 2) & N1 & u_lo, hi4_hi = (hi >> 2) & N1 & u_hi;
+            const bool plain = (((lo | (lo >> 1)) & hi4_lo) | ((hi | (hi >> 1)) & hi4_hi)) == 0;
+            // the loop also ends once t_pos runs past `limit`: harmless iff that has not happened by column C - 1
+            // (columns 1 .. C - 1 advance t_pos unless they are insertion columns)
+            const uint64_t r_lo = nmask(C) & ~0xFULL, r_hi = C > 16 ? nmask(C - 16) : 0ULL;
             const uint32_t ins = (uint32_t)__builtin_popcountll(lo & r_lo & 0x8888888888888888ULL) +
                                  (uint32_t)__builtin_popcountll(hi & r_hi & 0x8888888888888888ULL);
-            if (t + (span - ins) <= limit) {
+            const uint32_t steps = C ? C - 1 : 0u;
+            if (plain && t + (steps - ins) <= limit) {
+                lo &= u_lo, hi &= u_hi;
+                uint64_t g_lo = hi4_lo, g_hi = hi4_hi; // gap columns still in the window (flags at bit 0)
+                while (g_lo | g_hi) { // take the lowest gap column out: everything above it moves down one column
+                    if (g_lo) {
+                        const uint64_t below = (g_lo & (0 - g_lo)) - 1; // bits under the gap's nibble
+                        lo = (lo & below) | (((lo >> 4) | (hi << 60)) & ~below);
+                        g_lo = ((g_lo >> 4) | (g_hi << 60)) & ~below; // (no flag below; the removed gap's own falls under `below`)
+                        hi >>= 4;
+                        g_hi >>= 4;
+                    } else {
+                        const uint64_t below = (g_hi & (0 - g_hi)) - 1;
+                        hi = (hi & below) | ((hi >> 4) & ~below);
+                        g_hi = (g_hi >> 4) & ~below;
+                    }
+                }
                 auto squeeze = [](uint64_t x) -> uint64_t { // 16 nibbles -> 16 two-bit codes in the low 32 bits
                     uint64_t y = x & 0x3333333333333333ULL;
                     y = (y | (y >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
@@ -284,8 +324,8 @@ __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, 
                     y = (y | (y >> 8)) & 0x0000FFFF0000FFFFULL;
                     return (y | (y >> 16)) & 0xFFFFFFFFULL;
                 };
-                const uint64_t codes = squeeze(lo) | (squeeze(hi) << 32); // code of column col + j at bits 2j
                 const uint64_t mask = (1ULL << (2 * (uint64_t)k)) - 1;
+                const uint64_t codes = (squeeze(lo) | (squeeze(hi) << 32)) & mask; // code of the j-th kept column at bits 2j
                 uint64_t rb = __builtin_bitreverse64(codes);
                 rb = ((rb >> 1) & 0x5555555555555555ULL) | ((rb & 0x5555555555555555ULL) << 1); // pairs back in bit order
                 const uint64_t fw = rb >> (64 - 2 * k), rv = ~codes & mask;
