@@ -129,6 +129,40 @@ __device__ bool hp_differs(const uint8_t *a, uint32_t na, const uint8_t *b, uint
     return false;
 }
 
+// the same across a wavefront (every lane calls it with the same arguments): lane i holds byte i of both strings, the
+// run starts are a ballot, lane t fetches the t-th run's base of either string by shuffle.  (One lane walking the two
+// strings byte by byte is a chain of ~60 dependent loads while 63 lanes wait: it was half of k_vote_phase's time.)
+__device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t k) { // position of the k-th (0-based) set bit
+    uint32_t pos = 0;
+    uint32_t c = (uint32_t)__builtin_popcount((uint32_t)m);
+    if (k >= c) k -= c, pos = 32, m >>= 32;
+    uint32_t m32 = (uint32_t)m;
+    c = (uint32_t)__builtin_popcount(m32 & 0xFFFFu);
+    if (k >= c) k -= c, pos += 16, m32 >>= 16;
+    c = (uint32_t)__builtin_popcount(m32 & 0xFFu);
+    if (k >= c) k -= c, pos += 8, m32 >>= 8;
+    c = (uint32_t)__builtin_popcount(m32 & 0xFu);
+    if (k >= c) k -= c, pos += 4, m32 >>= 4;
+    c = (uint32_t)__builtin_popcount(m32 & 0x3u);
+    if (k >= c) k -= c, pos += 2, m32 >>= 2;
+    if (k >= (m32 & 1u)) pos += 1;
+    return pos;
+}
+__device__ __forceinline__ bool hp_differs_wave(uint32_t lane, const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb) {
+    if (na > 64 || nb > 64) { // (uniform) longer than a wavefront: the serial walk
+        uint32_t d = 0;
+        if (lane == 0) d = hp_differs(a, na, b, nb) ? 1u : 0u;
+        return __shfl(d, 0) != 0;
+    }
+    const uint32_t ca = lane < na ? a[lane] : 0u, cb = lane < nb ? b[lane] : 0u;
+    const uint32_t pa = __shfl_up(ca, 1), pb = __shfl_up(cb, 1);
+    const uint64_t ma = __ballot(lane < na && (lane == 0 || ca != pa)), mb = __ballot(lane < nb && (lane == 0 || cb != pb));
+    const uint32_t runs = min((uint32_t)__builtin_popcountll(ma), (uint32_t)__builtin_popcountll(mb));
+    const bool act = lane < runs;
+    const uint32_t xa = __shfl(ca, act ? kth_set_bit(ma, lane) : 0u), xb = __shfl(cb, act ? kth_set_bit(mb, lane) : 0u);
+    return __ballot(act && xa != xb) != 0;
+}
+
 // ---- phasing pass -----------------------------------------------------------------------------
 __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, uint32_t asref, uint32_t use_all,
                                                     const uint32_t *__restrict__ lq_start, uint32_t own_lo, uint32_t own_hi,
@@ -157,11 +191,7 @@ __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint3
         const uint32_t l1 = __shfl(len, w.max1_p), l2 = __shfl(len, w.max2_p);
         const uint32_t s1 = __shfl(so, w.max1_p), s2 = __shfl(so, w.max2_p);
         bool het = (l1 == l2) || (n >= 6 && w.max2_c >= w.max1_c / 2);
-        if (het) {
-            uint32_t d = 0;
-            if (lane == 0) d = hp_differs(rt.seq + s1, l1, rt.seq + s2, l2) ? 1u : 0u;
-            het = __shfl(d, 0) != 0;
-        }
+        if (het) het = hp_differs_wave(lane, rt.seq + s1, l1, rt.seq + s2, l2); // (het is wave-uniform)
         if (het) {
             lable = LB_HETE;
             if (lane < n && ks > 0 && w.stat < min_c) { // main.rs:934-943
