@@ -365,29 +365,33 @@ __device__ void cand_write(const CandCtx &cx, uint32_t r, const np2_read_t &rd, 
             w >>= 4 * skip;
             nc = 8 - skip;
         }
+        // gap columns are taken out of the word (usually none), the rest becomes ASCII eight at a time; a full word goes
+        // out as two dword stores, a partial one (first / last word of the string, words that held gaps) byte by byte.
+        // (A per-column fallback loop here ran on nearly every iteration: some lane of the wave is always at its tail.)
+        const uint32_t vm = nc == 8 ? 0x11111111u : ((1u << (4 * nc)) - 1u) & 0x11111111u;
         const uint32_t x = w ^ 0x44444444u;
-        const uint32_t nongap = (x | (x >> 1) | (x >> 2)) & 0x11111111u;
-        const uint32_t full = nc == 8 ? 0x11111111u : ((1u << (4 * nc)) - 1u) & 0x11111111u;
-        if ((nongap & full) == full && len - o >= nc) { // no gap code among the nc columns, all of them wanted
-            const uint32_t lo4 = w & 0xFFFFu, hi4 = w >> 16;
-            uint32_t s0 = (lo4 | (lo4 << 8)) & 0x00FF00FFu, s1 = (hi4 | (hi4 << 8)) & 0x00FF00FFu;
-            s0 = (s0 | (s0 << 4)) & 0x0F0F0F0Fu;
-            s1 = (s1 | (s1 << 4)) & 0x0F0F0F0Fu;
-            const uint32_t a0 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s0), a1 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s1);
-            if (nc == 8) {
-                __builtin_memcpy(seq_out + o, &a0, 4);
-                __builtin_memcpy(seq_out + o + 4, &a1, 4);
-            } else {
-                const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32);
-                for (uint32_t k = 0; k < nc; ++k) seq_out[o + k] = (uint8_t)(a >> (8 * k));
-            }
-            o += nc;
-        } else {
-            for (uint32_t k = 0; k < nc && o < len; ++k) {
-                const uint32_t q = (w >> (4 * k)) & 7u;
-                if (q != 4) seq_out[o++] = code_to_ascii((uint8_t)q);
-            }
+        uint32_t gap = ~(x | (x >> 1) | (x >> 2)) & vm;
+        const uint32_t cnt = min(nc - (uint32_t)__builtin_popcount(gap), len - o);
+        while (gap) {
+            const uint32_t below = (gap & (0u - gap)) - 1u;
+            w = (w & below) | ((w >> 4) & ~below);
+            gap = (gap >> 4) & ~below;
         }
+        const uint32_t lo4 = w & 0xFFFFu, hi4 = w >> 16;
+        uint32_t s0 = (lo4 | (lo4 << 8)) & 0x00FF00FFu, s1 = (hi4 | (hi4 << 8)) & 0x00FF00FFu;
+        s0 = (s0 | (s0 << 4)) & 0x0F0F0F0Fu;
+        s1 = (s1 | (s1 << 4)) & 0x0F0F0F0Fu;
+        const uint32_t a0 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s0), a1 = __builtin_amdgcn_perm(LUT_HI, LUT_LO, s1);
+        if (cnt == 8) {
+            __builtin_memcpy(seq_out + o, &a0, 4);
+            __builtin_memcpy(seq_out + o + 4, &a1, 4);
+        } else {
+            const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32);
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k)
+                if (k < cnt) seq_out[o + k] = (uint8_t)(a >> (8 * k));
+        }
+        o += cnt;
     }
 }
 
