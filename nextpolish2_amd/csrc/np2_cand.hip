@@ -162,9 +162,15 @@ __device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const
 }
 
 // position (0..7) of the n-th (1-based) set bit of a nibble-spaced mask (bits 0, 4, 8, ...)
-__device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) {
-    for (uint32_t i = 1; i < n; ++i) m &= m - 1;
-    return (uint32_t)__builtin_ctz(m) >> 2;
+__device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) { // (binary descent: no data-dependent loop)
+    uint32_t col = 0;
+    uint32_t c = (uint32_t)__builtin_popcount(m & 0xFFFFu);
+    if (n > c) n -= c, col = 4, m >>= 16;
+    c = (uint32_t)__builtin_popcount(m & 0xFFu);
+    if (n > c) n -= c, col += 2, m >>= 8;
+    c = (uint32_t)__builtin_popcount(m & 0xFu);
+    if (n > c) col += 1;
+    return col;
 }
 
 // Length of the candidate string of (read, region) and the column it starts at, 8 columns per step
