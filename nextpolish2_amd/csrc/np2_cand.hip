@@ -161,11 +161,14 @@ __device__ __forceinline__ void cand_anchor(const CandCtx &cx, uint32_t r, const
     }
 }
 
-// position (0..7) of the n-th (1-based) set bit of a nibble-spaced mask (bits 0, 4, 8, ...)
-__device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) { // (binary descent: no data-dependent loop)
+// position (0..15) of the n-th (1-based) set bit of a nibble-spaced 64-bit mask (bits 0, 4, 8, ...): binary descent
+__device__ __forceinline__ uint32_t nth_col16(uint64_t m64, uint32_t n) {
     uint32_t col = 0;
-    uint32_t c = (uint32_t)__builtin_popcount(m & 0xFFFFu);
-    if (n > c) n -= c, col = 4, m >>= 16;
+    uint32_t m = (uint32_t)m64;
+    uint32_t c = (uint32_t)__builtin_popcount(m);
+    if (n > c) n -= c, col = 8, m = (uint32_t)(m64 >> 32);
+    c = (uint32_t)__builtin_popcount(m & 0xFFFFu);
+    if (n > c) n -= c, col += 4, m >>= 16;
     c = (uint32_t)__builtin_popcount(m & 0xFFu);
     if (n > c) n -= c, col += 2, m >>= 8;
     c = (uint32_t)__builtin_popcount(m & 0xFu);
@@ -173,7 +176,7 @@ __device__ __forceinline__ uint32_t nth_col(uint32_t m, uint32_t n) { // (binary
     return col;
 }
 
-// Length of the candidate string of (read, region) and the column it starts at, 8 columns per step
+// Length of the candidate string of (read, region) and the column it starts at, 16 columns per step
 // (the emission rule of main.rs:1478-1521: every non-gap column whose t_pos lies in [start, end], from the reference
 // column of `start` on; the early exits of that loop all sit behind t_pos > end).
 __device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t &rd, uint64_t ck_off, uint32_t start,
@@ -190,40 +193,41 @@ __device__ uint32_t cand_measure(const CandCtx &cx, uint32_t r, const np2_read_t
     bool started = false;
     uint4 win = make_uint4(0, 0, 0, 0);
     uint32_t win_blk = 0xFFFFFFFFu;
-    for (uint32_t wi = col_ck >> 3;; ++wi) {
-        const uint32_t c0 = wi << 3;
+    const uint64_t N1 = 0x1111111111111111ULL;
+    for (uint32_t wi = col_ck >> 4;; ++wi) { // 16 columns = 8 bytes of the read's stream per step
+        const uint32_t c0 = wi << 4;
         if (c0 >= n_cols) break;
-        if ((wi >> 2) != win_blk) {
-            win_blk = wi >> 2;
+        if ((wi >> 1) != win_blk) {
+            win_blk = wi >> 1;
             win = *reinterpret_cast<const uint4 *>(base + ((size_t)win_blk << 4));
         }
-        const uint32_t k = wi & 3;
-        const uint32_t raw = k == 0 ? win.x : (k == 1 ? win.y : (k == 2 ? win.z : win.w));
-        const uint32_t w = ((raw & 0x0F0F0F0Fu) << 4) | ((raw >> 4) & 0x0F0F0F0Fu); // column j at bits 4j
-        uint32_t valid = 0x11111111u;
-        if (c0 < col_ck) valid &= ~((1u << (4 * (col_ck - c0))) - 1u);            // columns before the anchor
-        if (n_cols - c0 < 8) valid &= (1u << (4 * (n_cols - c0))) - 1u;           // columns past the read
-        uint32_t nonins = (~(w >> 3)) & valid;
-        if (c0 == 0) nonins |= valid & 1u; // column 0 is never an insertion column (main.rs:325,332-335)
-        const uint32_t x = (w & 0x77777777u) ^ 0x44444444u;
-        const uint32_t nongap = (x | (x >> 1) | (x >> 2)) & valid;
-        const uint32_t cn = __builtin_popcount(nonins);
-        uint32_t lo = 0, hi = 8;
+        const uint32_t r0 = (wi & 1) ? win.z : win.x, r1 = (wi & 1) ? win.w : win.y;
+        const uint64_t w = (uint64_t)(((r0 & 0x0F0F0F0Fu) << 4) | ((r0 >> 4) & 0x0F0F0F0Fu)) |
+                           ((uint64_t)(((r1 & 0x0F0F0F0Fu) << 4) | ((r1 >> 4) & 0x0F0F0F0Fu)) << 32); // column j at bits 4j
+        uint64_t valid = N1;
+        if (c0 < col_ck) valid &= ~((1ULL << (4 * (col_ck - c0))) - 1ULL);          // columns before the anchor
+        if (n_cols - c0 < 16) valid &= (1ULL << (4 * (n_cols - c0))) - 1ULL;        // columns past the read
+        uint64_t nonins = (~(w >> 3)) & valid;
+        if (c0 == 0) nonins |= valid & 1ULL; // column 0 is never an insertion column (main.rs:325,332-335)
+        const uint64_t x = (w & 0x7777777777777777ULL) ^ 0x4444444444444444ULL;
+        const uint64_t nongap = (x | (x >> 1) | (x >> 2)) & valid;
+        const uint32_t cn = (uint32_t)__builtin_popcountll(nonins);
+        uint32_t lo = 0, hi = 16;
         bool done = false;
         if (!started && seen + cn >= want_s) {
-            lo = nth_col(nonins, want_s - seen);
+            lo = nth_col16(nonins, want_s - seen);
             col_start = c0 + lo;
             started = true;
         }
         if (seen + cn >= want_e) {
-            hi = nth_col(nonins, want_e - seen);
+            hi = nth_col16(nonins, want_e - seen);
             done = true;
         }
         if (started) {
-            uint32_t m = nongap;
-            if (lo) m &= ~((1u << (4 * lo)) - 1u);
-            if (hi < 8) m &= (1u << (4 * hi)) - 1u;
-            len += __builtin_popcount(m);
+            uint64_t m = nongap;
+            if (lo) m &= ~((1ULL << (4 * lo)) - 1ULL);
+            if (hi < 16) m &= (1ULL << (4 * hi)) - 1ULL;
+            len += (uint32_t)__builtin_popcountll(m);
         }
         seen += cn;
         if (done) break;
