@@ -411,6 +411,10 @@ def main():
                      "batch_call_ms_mean": round(float(call_ms), 3) if not single else None},
     }
 
+    if not single and len(groups.bps) > 1:
+        out_line["roofline"]["note"] = ("one launch per batch group and step; in the timed region it shares the GPU with the other "
+                                        "groups' kernels (roofline_exclusive: the same launches with the GPU to themselves; "
+                                        "--workload ecoli: one contig, one stream)")
     if excl is not None and excl[0] > 0:
         # the same kernel over 2 extra, untimed steps in which the groups take turns: its launches then have the GPU to
         # themselves (in the timed region they share it with the other groups' kernels, which stretches them)
