@@ -552,7 +552,19 @@ __device__ __forceinline__ void k_cand_offsets_lb(const uint32_t np2_bid, const 
     }
 }
 
-// one lane per kept candidate (at most 60 per region = one pass of the wave)
+// one lane per kept candidate (at most 60 per region).  A wavefront owns two consecutive regions: at 30x a region keeps
+// ~30 candidates, so when both have at most 32 they are written side by side in the two halves of the wave, otherwise
+// one after the other.
+__device__ __forceinline__ uint32_t half_excl(uint32_t v) { // exclusive prefix sum inside each 32-lane half
+    const uint32_t hl = threadIdx.x & 31;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o, 32);
+        if (hl >= (uint32_t)o) x += t;
+    }
+    return x - v;
+}
 __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
                                                       const uint32_t *__restrict__ kept_len,
                                                       const uint32_t *__restrict__ kept_col,
@@ -566,32 +578,42 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = np2_bid * 4 + (threadIdx.x >> 6);
-    if (g >= n_reg) return;
-    if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
-    // offsets of this region: its block's prefix + the regions before it inside the block of 4
-    uint32_t oc = blk_coff[np2_bid], ob = blk_soff[np2_bid];
-    for (uint32_t w = np2_bid * 4; w < g; ++w) {
-        oc += reg_ncand[w];
-        ob += reg_bytes[w];
+    const uint32_t g0 = 2 * (np2_bid * 4 + (threadIdx.x >> 6));
+    if (g0 >= n_reg) return;
+    const bool has1 = g0 + 1 < n_reg;
+    const bool packed = has1 && reg_ncand[g0] <= 32 && reg_ncand[g0 + 1] <= 32; // (uniform)
+    const uint32_t rounds = (has1 && !packed) ? 2u : 1u;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t g = packed ? g0 + (lane >> 5) : g0 + round; // this lane's region
+        const uint32_t li = packed ? (lane & 31) : lane;            // ... and its candidate index in it
+        if (g == n_reg - 1 && li == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
+        // offsets of the region: the prefix of its block of 4 regions (k_region_measure's blocks) + the regions before
+        // it inside that block
+        const uint32_t mb = g >> 2;
+        uint32_t oc = blk_coff[mb], ob = blk_soff[mb];
+        for (uint32_t w = mb * 4; w < g; ++w) {
+            oc += reg_ncand[w];
+            ob += reg_bytes[w];
+        }
+        if (li == 0) {
+            cand_off[g] = oc;
+            reg_soff[g] = ob;
+        }
+        const uint32_t n = reg_ncand[g];
+        const bool act = li < n;
+        const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + li;
+        const uint32_t len = act ? kept_len[slot] : 0u;
+        const uint32_t so = ob + (packed ? half_excl(len) : wave_excl(len));
+        const uint32_t ci = oc + li;
+        if (act && ci < cand_cap && (uint64_t)so + len <= seq_cap) {
+            const uint32_t r = kept_read[slot];
+            const ReadInfo ri = cx.rinfo[r];
+            const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
+            cand_order[ci] = r;
+            cand_seq_off[ci] = so;
+            cand_write(cx, r, rd, ri.pj, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
+        }
     }
-    if (lane == 0) {
-        cand_off[g] = oc;
-        reg_soff[g] = ob;
-    }
-    const uint32_t n = reg_ncand[g];
-    const bool act = lane < n;
-    const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + lane;
-    const uint32_t len = act ? kept_len[slot] : 0u;
-    const uint32_t so = ob + wave_excl(len);
-    const uint32_t ci = oc + lane;
-    if (!act || ci >= cand_cap || (uint64_t)so + len > seq_cap) return;
-    const uint32_t r = kept_read[slot];
-    const ReadInfo ri = cx.rinfo[r];
-    const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
-    cand_order[ci] = r;
-    cand_seq_off[ci] = so;
-    cand_write(cx, r, rd, ri.pj, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -646,7 +668,7 @@ void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const
                          uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap, uint32_t *cand_order, uint64_t *cand_kmer,
                          uint32_t *cand_seq_off, uint8_t *cand_seq) {
     if (n_reg)
-        NP2_LAUNCH(k_region_write, dim3((n_reg + 3) / 4), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off, cand_seq);
+        NP2_LAUNCH(k_region_write, dim3((n_reg + 7) / 8), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off, cand_seq);
 }
 
 } // namespace np2
