@@ -431,57 +431,105 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
                                                         uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
-    // blk_sum: per block of 4 regions, three arrays of np2_nb entries: candidates, bytes, longest kept strings
-    __shared__ uint32_t s_w[3][4];
+    // A wavefront owns two consecutive regions; when both have at most 32 reads to look at (the usual case at 30x) they
+    // are measured side by side in the two halves of the wave, otherwise one after the other over all 64 lanes.
+    // blk_sum: per group of 4 regions, three arrays of n_mb entries: candidates, bytes, longest kept strings
+    __shared__ uint32_t s_w[3][8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t g = np2_bid * 4 + wv;
-    const bool live = g < n_reg;
-    const uint32_t start = live ? cx.lq_start[g] : 0u, end = live ? cx.lq_end[g] : 0u;
-    uint32_t mx = 0;
-    const uint32_t tile = min(end >> TILE_SHIFT, cx.n_tiles - 1);
-    const uint32_t la = live ? cx.tile_rd_off[tile] : 0u, lb = live ? cx.tile_rd_off[tile + 1] : 0u;
-    uint32_t kept = 0, bytes = 0;
-    for (uint32_t c0 = la; c0 < lb && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
-        const uint32_t i = c0 + lane;
+    const uint32_t n_mb = (n_reg + 3) / 4;
+    const uint32_t g0 = (np2_bid * 4 + wv) * 2;
+    uint32_t st[2], en[2], la[2], lb[2];
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const bool live = g0 + h < n_reg;
+        st[h] = live ? cx.lq_start[g0 + h] : 0u, en[h] = live ? cx.lq_end[g0 + h] : 0u;
+        const uint32_t tile = min(en[h] >> TILE_SHIFT, cx.n_tiles - 1);
+        la[h] = live ? cx.tile_rd_off[tile] : 0u, lb[h] = live ? cx.tile_rd_off[tile + 1] : 0u;
+    }
+    const bool packed = g0 + 1 < n_reg && lb[0] - la[0] <= 32 && lb[1] - la[1] <= 32; // (uniform)
+    if (packed) {
+        const uint32_t h = lane >> 5, li = lane & 31, g = g0 + h;
+        const uint32_t i = (h ? la[1] : la[0]) + li, ie = h ? lb[1] : lb[0];
         uint32_t r = 0, len = 0, col = 0;
-        bool ok = false;
-        if (i < lb) {
+        if (i < ie) {
             r = cx.tile_rd[i];
             const ReadInfo ri = cx.rinfo[r]; // (pcount is 0 for a dropped read)
-            ok = ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount;
-            if (ok) {
+            if (ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount) {
                 const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
-                len = cand_measure(cx, r, rd, ri.ck_off, start, end, col);
+                len = cand_measure(cx, r, rd, ri.ck_off, h ? st[1] : st[0], h ? en[1] : en[0], col);
             }
         }
-        const uint64_t ne = __ballot(len > 0);
-        const uint32_t before = kept + (uint32_t)__builtin_popcountll(ne & ((1ULL << lane) - 1ULL));
-        const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
-        if (keep) {
+        const uint32_t ne = (uint32_t)(__ballot(len > 0) >> (lane & 32)); // this half's non-empty candidates
+        const uint32_t before = (uint32_t)__builtin_popcount(ne & ((1u << li) - 1u));
+        if (len > 0) { // (at most 32 of them: the cap of 60 cannot bite)
             const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
             kept_read[slot] = r;
             kept_len[slot] = len;
             kept_col[slot] = col;
         }
-        kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
-        bytes += wave_sum(keep ? len : 0u);
-        mx = max(mx, keep ? len : 0u);
-    }
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
-    if (lane == 0) {
-        if (live) {
+        uint32_t bytes = len, mx = len;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            bytes += __shfl_xor(bytes, o);
+            mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+        }
+        if (li == 0) {
+            const uint32_t kept = (uint32_t)__builtin_popcount(ne);
             reg_ncand[g] = kept;
             reg_bytes[g] = bytes;
             reg_maxlen[g] = mx;
+            s_w[0][2 * wv + h] = kept;
+            s_w[1][2 * wv + h] = bytes;
+            s_w[2][2 * wv + h] = mx; // the longest string a splice can put in place of this region
         }
-        s_w[0][wv] = kept;
-        s_w[1][wv] = bytes;
-        s_w[2][wv] = mx; // the longest string a splice can put in place of this region
+    } else {
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t g = g0 + h;
+            const bool live = g < n_reg;
+            uint32_t kept = 0, bytes = 0, mx = 0;
+            for (uint32_t c0 = la[h]; c0 < lb[h] && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                uint32_t r = 0, len = 0, col = 0;
+                if (i < lb[h]) {
+                    r = cx.tile_rd[i];
+                    const ReadInfo ri = cx.rinfo[r];
+                    if (ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount) {
+                        const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
+                        len = cand_measure(cx, r, rd, ri.ck_off, st[h], en[h], col);
+                    }
+                }
+                const uint64_t ne = __ballot(len > 0);
+                const uint32_t before = kept + (uint32_t)__builtin_popcountll(ne & ((1ULL << lane) - 1ULL));
+                const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
+                if (keep) {
+                    const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
+                    kept_read[slot] = r;
+                    kept_len[slot] = len;
+                    kept_col[slot] = col;
+                }
+                kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
+                bytes += wave_sum(keep ? len : 0u);
+                mx = max(mx, keep ? len : 0u);
+            }
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+            if (lane == 0) {
+                if (live) {
+                    reg_ncand[g] = kept;
+                    reg_bytes[g] = bytes;
+                    reg_maxlen[g] = mx;
+                }
+                s_w[0][2 * wv + h] = kept;
+                s_w[1][2 * wv + h] = bytes;
+                s_w[2][2 * wv + h] = mx;
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 3)
-        blk_sum[threadIdx.x * np2_nb + np2_bid] =
-            s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+    if (threadIdx.x < 6) { // two groups of 4 regions per block
+        const uint32_t k = threadIdx.x >> 1, m = threadIdx.x & 1, mb = np2_bid * 2 + m;
+        if (mb < n_mb) blk_sum[k * n_mb + mb] = s_w[k][4 * m] + s_w[k][4 * m + 1] + s_w[k][4 * m + 2] + s_w[k][4 * m + 3];
+    }
 }
 
 // candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
@@ -651,7 +699,7 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum) {
     if (n_reg)
-        NP2_LAUNCH(k_region_measure, dim3((n_reg + 3) / 4), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
+        NP2_LAUNCH(k_region_measure, dim3((n_reg + 7) / 8), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
