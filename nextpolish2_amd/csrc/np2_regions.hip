@@ -15,6 +15,18 @@ static constexpr uint8_t LB_TEMP = 0x01, LB_SUCC = 0x80, LB_HETE = 0x40, LB_RECH
 __device__ __forceinline__ uint32_t min_support(uint32_t n) { return n >= 9 ? 3u : (n >= 6 ? 2u : 1u); }
 
 // ---- per-region wave statistics ------------------------------------------------------------
+// A region's candidates occupy either a whole wavefront (base 0, width 64) or one 32-lane half of it (base 0 / 32):
+// ballots come back relative to the region's first lane, shuffles take region-relative source lanes.
+struct SubWave {
+    uint32_t base;  // first lane of the region's lanes
+    bool half;      // 32 lanes instead of 64
+    __device__ __forceinline__ uint64_t ballot(bool p) const {
+        const uint64_t b = __ballot(p);
+        return half ? (b >> base) & 0xFFFFFFFFull : b;
+    }
+    template <class T> __device__ __forceinline__ T shfl(T v, uint32_t j) const { return __shfl(v, (int)(base + j)); }
+};
+
 struct WaveStats {
     uint64_t eqmask;  // per lane: candidates with an identical sequence (bit j)
     uint32_t stat;    // per lane: stats[p] of fill_order_stat (0 = not grouped)
@@ -24,11 +36,11 @@ struct WaveStats {
 };
 
 // exact byte-wise class computation (fallback; also the definition the fast path must reproduce)
-__device__ __forceinline__ uint64_t eqmask_exact(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
+__device__ __forceinline__ uint64_t eqmask_exact(const SubWave &sw, uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
                                                   const uint8_t *__restrict__ seq) {
     uint64_t m = 0;
     for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t sj = __shfl(so, j), lj = __shfl(len, j);
+        const uint32_t sj = sw.shfl(so, j), lj = sw.shfl(len, j);
         bool eq = lane < n && lj == len;
         if (eq)
             for (uint32_t t = 0; t < len; ++t)
@@ -41,7 +53,7 @@ __device__ __forceinline__ uint64_t eqmask_exact(uint32_t lane, uint32_t n, uint
     return m;
 }
 
-__device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
+__device__ __forceinline__ WaveStats wave_group_stats(const SubWave &sw, uint32_t lane, uint32_t n, uint32_t so, uint32_t len,
                                                       const uint8_t *__restrict__ seq, bool kpos, uint32_t order) {
     WaveStats w;
     // classes by (length, 64-bit hash); every lane then verifies byte-wise against its class head.  A hash
@@ -60,11 +72,11 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
     const uint32_t hlo = (uint32_t)h, hhi = (uint32_t)(h >> 32);
     w.eqmask = 0;
     { // one ballot per distinct hash (a region rarely holds more than a few different strings), not one per candidate
-        uint64_t todo = __ballot(lane < n);
+        uint64_t todo = sw.ballot(lane < n);
         while (todo) {
             const uint32_t hd = (uint32_t)__builtin_ctzll(todo);
-            const uint32_t jl = __shfl(hlo, hd), jh = __shfl(hhi, hd);
-            const uint64_t m = __ballot(lane < n && jl == hlo && jh == hhi);
+            const uint32_t jl = sw.shfl(hlo, hd), jh = sw.shfl(hhi, hd);
+            const uint64_t m = sw.ballot(lane < n && jl == hlo && jh == hhi);
             if ((m >> lane) & 1ull) w.eqmask = m;
             todo &= ~m;
         }
@@ -72,7 +84,7 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
     bool ok = true;
     if (lane < n) {
         const uint32_t head = __builtin_ctzll(w.eqmask);
-        const uint32_t sh = __shfl(so, head), lh = __shfl(len, head);
+        const uint32_t sh = sw.shfl(so, head), lh = sw.shfl(len, head);
         ok = lh == len;
         if (ok && head != lane)
             for (uint32_t t = 0; t < len; t += 8) {
@@ -87,11 +99,11 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
                 }
             }
     } else {
-        (void)__shfl(so, 0);
-        (void)__shfl(len, 0);
+        (void)sw.shfl(so, 0);
+        (void)sw.shfl(len, 0);
     }
-    if (__ballot(!ok)) w.eqmask = eqmask_exact(lane, n, so, len, seq);
-    const uint64_t kmask = __ballot(lane < n && kpos);
+    if (sw.ballot(!ok)) w.eqmask = eqmask_exact(sw, lane, n, so, len, seq);
+    const uint64_t kmask = sw.ballot(lane < n && kpos);
     const uint64_t valid = w.eqmask & kmask;
     uint32_t p1 = 64;
     w.c = 0;
@@ -102,11 +114,11 @@ __device__ __forceinline__ WaveStats wave_group_stats(uint32_t lane, uint32_t n,
     w.stat = (p1 < 64 && lane >= p1) ? w.c : 0;
     w.head = lane < n && p1 == lane;
     w.max1_c = w.max1_p = w.max2_c = w.max2_p = 0;
-    uint64_t hm = __ballot(w.head);
+    uint64_t hm = sw.ballot(w.head);
     while (hm) {
         const uint32_t hd = __builtin_ctzll(hm);
         hm &= hm - 1;
-        const uint32_t ch = __shfl(w.c, hd), oh = __shfl(order, hd);
+        const uint32_t ch = sw.shfl(w.c, hd), oh = sw.shfl(order, hd);
         if (ch > w.max1_c || (ch == w.max1_c && oh == 0)) {
             w.max2_c = w.max1_c, w.max2_p = w.max1_p;
             w.max1_c = ch, w.max1_p = hd;
@@ -148,19 +160,21 @@ __device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t k) { // pos
     if (k >= (m32 & 1u)) pos += 1;
     return pos;
 }
-__device__ __forceinline__ bool hp_differs_wave(uint32_t lane, const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb) {
-    if (na > 64 || nb > 64) { // (uniform) longer than a wavefront: the serial walk
+__device__ __forceinline__ bool hp_differs_wave(const SubWave &sw, uint32_t lane, const uint8_t *a, uint32_t na, const uint8_t *b,
+                                                uint32_t nb) {
+    const uint32_t W = sw.half ? 32u : 64u;
+    if (na > W || nb > W) { // (uniform over the region's lanes) longer than they are many: the serial walk
         uint32_t d = 0;
         if (lane == 0) d = hp_differs(a, na, b, nb) ? 1u : 0u;
-        return __shfl(d, 0) != 0;
+        return sw.shfl(d, 0) != 0;
     }
     const uint32_t ca = lane < na ? a[lane] : 0u, cb = lane < nb ? b[lane] : 0u;
-    const uint32_t pa = __shfl_up(ca, 1), pb = __shfl_up(cb, 1);
-    const uint64_t ma = __ballot(lane < na && (lane == 0 || ca != pa)), mb = __ballot(lane < nb && (lane == 0 || cb != pb));
+    const uint32_t pa = sw.shfl(ca, lane ? lane - 1 : 0u), pb = sw.shfl(cb, lane ? lane - 1 : 0u);
+    const uint64_t ma = sw.ballot(lane < na && (lane == 0 || ca != pa)), mb = sw.ballot(lane < nb && (lane == 0 || cb != pb));
     const uint32_t runs = min((uint32_t)__builtin_popcountll(ma), (uint32_t)__builtin_popcountll(mb));
     const bool act = lane < runs;
-    const uint32_t xa = __shfl(ca, act ? kth_set_bit(ma, lane) : 0u), xb = __shfl(cb, act ? kth_set_bit(mb, lane) : 0u);
-    return __ballot(act && xa != xb) != 0;
+    const uint32_t xa = sw.shfl(ca, act ? kth_set_bit(ma, lane) : 0u), xb = sw.shfl(cb, act ? kth_set_bit(mb, lane) : 0u);
+    return sw.ballot(act && xa != xb) != 0;
 }
 
 // ---- phasing pass -----------------------------------------------------------------------------
@@ -170,60 +184,70 @@ __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint3
                                                     uint32_t *__restrict__ ecount, int32_t *__restrict__ ref_w,
                                                     uint8_t *__restrict__ ref_seen, uint8_t *__restrict__ bad,
                                                     uint32_t *__restrict__ first_reg, uint32_t *__restrict__ err) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
-    if (g >= rt.n_reg) return;
-    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
-    uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
-    uint16_t ks = 0;
-    if (lane < n) {
-        so = rt.seq_off[c0 + lane];
-        len = rt.seq_off[c0 + lane + 1] - so;
-        order = rt.order[c0 + lane];
-        ks = rt.kscore[c0 + lane];
-    }
-    WaveStats w = wave_group_stats(lane, n, so, len, rt.seq, ks > 0, order);
-    const uint32_t min_c = min_support(n);
-    uint8_t lable = 0;
-    uint32_t ne = 0;
-    if (lane < n) grp[c0 + lane] = (uint8_t)__builtin_ctzll(w.eqmask);
-    if (w.max2_c >= min_c && n > 0) {
-        const uint32_t l1 = __shfl(len, w.max1_p), l2 = __shfl(len, w.max2_p);
-        const uint32_t s1 = __shfl(so, w.max1_p), s2 = __shfl(so, w.max2_p);
-        bool het = (l1 == l2) || (n >= 6 && w.max2_c >= w.max1_c / 2);
-        if (het) het = hp_differs_wave(lane, rt.seq + s1, l1, rt.seq + s2, l2); // (het is wave-uniform)
-        if (het) {
-            lable = LB_HETE;
-            if (lane < n && ks > 0 && w.stat < min_c) { // main.rs:934-943
-                ks = 0;
-                rt.kscore[c0 + lane] = 0;
-            }
-            const uint64_t valid = __ballot(lane < n && ks > 0);
-            const bool ref_valid = (valid & 1ull) && __shfl(order, 0) == 0;
-            if (lane < n && ks > 0 && order == 0 && lane != 0) atomicOr(err, 4u); // seq2 order == 0 assertion
-            // a shard of a contig (np2_shard_*) votes only over the regions it owns; its neighbours see the same region
-            // in their halo and stay silent there, so every HETE region of the contig is counted exactly once
-            const uint32_t gs = lq_start[g];
-            const bool owned = gs >= own_lo && gs < own_hi;
-            if (owned && ref_valid && lane >= 1 && lane < n && ks > 0) { // pairs (ref, j): main.rs:972-980
-                const int wgt = ((w.eqmask & 1ull) != 0) ? 1 : -1;
-                if (asref) {
-                    atomicAdd(&ref_w[order], wgt);
-                    ref_seen[order] = 1;
+    // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
+    // (the usual case at 30x), otherwise one after the other over all 64 lanes
+    const uint32_t wl = threadIdx.x & 63;
+    const uint32_t g0 = ((np2_bid * blockDim.x + threadIdx.x) >> 6) * 2;
+    if (g0 >= rt.n_reg) return;
+    const bool has1 = g0 + 1 < rt.n_reg;
+    const bool packed = has1 && rt.cand_off[g0 + 1] - rt.cand_off[g0] <= 32 && rt.cand_off[g0 + 2] - rt.cand_off[g0 + 1] <= 32;
+    const uint32_t rounds = (has1 && !packed) ? 2u : 1u;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const SubWave sw{packed ? (wl & 32u) : 0u, packed};
+        const uint32_t lane = packed ? (wl & 31u) : wl;              // lane inside the region
+        const uint32_t g = packed ? g0 + (wl >> 5) : g0 + round;
+        const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+        uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
+        uint16_t ks = 0;
+        if (lane < n) {
+            so = rt.seq_off[c0 + lane];
+            len = rt.seq_off[c0 + lane + 1] - so;
+            order = rt.order[c0 + lane];
+            ks = rt.kscore[c0 + lane];
+        }
+        WaveStats w = wave_group_stats(sw, lane, n, so, len, rt.seq, ks > 0, order);
+        const uint32_t min_c = min_support(n);
+        uint8_t lable = 0;
+        uint32_t ne = 0;
+        if (lane < n) grp[c0 + lane] = (uint8_t)__builtin_ctzll(w.eqmask);
+        if (w.max2_c >= min_c && n > 0) {
+            const uint32_t l1 = sw.shfl(len, w.max1_p), l2 = sw.shfl(len, w.max2_p);
+            const uint32_t s1 = sw.shfl(so, w.max1_p), s2 = sw.shfl(so, w.max2_p);
+            bool het = (l1 == l2) || (n >= 6 && w.max2_c >= w.max1_c / 2);
+            if (het) het = hp_differs_wave(sw, lane, rt.seq + s1, l1, rt.seq + s2, l2); // (uniform over the region's lanes)
+            if (het) {
+                lable = LB_HETE;
+                if (lane < n && ks > 0 && w.stat < min_c) { // main.rs:934-943
+                    ks = 0;
+                    rt.kscore[c0 + lane] = 0;
                 }
-                if (wgt < 0 && !use_all) bad[order] = 1;
-            }
-            const uint64_t V = ref_valid ? (valid & ~1ull) : valid;
-            const uint32_t m = __builtin_popcountll(V);
-            if (m >= 2 && owned) {
-                ne = m * (m - 1) / 2;
-                if ((V >> lane) & 1ull) atomicMin(&first_reg[order], g);
+                const uint64_t valid = sw.ballot(lane < n && ks > 0);
+                const bool ref_valid = (valid & 1ull) && sw.shfl(order, 0) == 0;
+                if (lane < n && ks > 0 && order == 0 && lane != 0) atomicOr(err, 4u); // seq2 order == 0 assertion
+                // a shard of a contig (np2_shard_*) votes only over the regions it owns; its neighbours see the same region
+                // in their halo and stay silent there, so every HETE region of the contig is counted exactly once
+                const uint32_t gs = lq_start[g];
+                const bool owned = gs >= own_lo && gs < own_hi;
+                if (owned && ref_valid && lane >= 1 && lane < n && ks > 0) { // pairs (ref, j): main.rs:972-980
+                    const int wgt = ((w.eqmask & 1ull) != 0) ? 1 : -1;
+                    if (asref) {
+                        atomicAdd(&ref_w[order], wgt);
+                        ref_seen[order] = 1;
+                    }
+                    if (wgt < 0 && !use_all) bad[order] = 1;
+                }
+                const uint64_t V = ref_valid ? (valid & ~1ull) : valid;
+                const uint32_t m = __builtin_popcountll(V);
+                if (m >= 2 && owned) {
+                    ne = m * (m - 1) / 2;
+                    if ((V >> lane) & 1ull) atomicMin(&first_reg[order], g);
+                }
             }
         }
-    }
-    if (lane == 0) {
-        reg_lable[g] = lable;
-        ecount[g] = ne;
+        if (lane == 0) {
+            reg_lable[g] = lable;
+            ecount[g] = ne;
+        }
     }
 }
 
@@ -390,89 +414,99 @@ __device__ __forceinline__ void k_seed(const uint32_t np2_bid, const uint32_t np
                                               uint8_t *__restrict__ reg_lable, uint32_t *__restrict__ seed_cand,
                                               uint32_t *__restrict__ keep_n, uint32_t *__restrict__ keep_list,
                                               uint16_t *__restrict__ keep_ks, uint32_t *__restrict__ err) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
-    if (g >= rt.n_reg) return;
-    const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
-    if (n == 0) { // lqseq.seqs[max1_p] would be out of bounds
+    // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
+    // (the usual case at 30x), otherwise one after the other over all 64 lanes
+    const uint32_t wl = threadIdx.x & 63;
+    const uint32_t g0 = ((np2_bid * blockDim.x + threadIdx.x) >> 6) * 2;
+    if (g0 >= rt.n_reg) return;
+    const bool has1 = g0 + 1 < rt.n_reg;
+    const bool packed = has1 && rt.cand_off[g0 + 1] - rt.cand_off[g0] <= 32 && rt.cand_off[g0 + 2] - rt.cand_off[g0 + 1] <= 32;
+    const uint32_t rounds = (has1 && !packed) ? 2u : 1u;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const SubWave sw{packed ? (wl & 32u) : 0u, packed};
+        const uint32_t lane = packed ? (wl & 31u) : wl;              // lane inside the region
+        const uint32_t g = packed ? g0 + (wl >> 5) : g0 + round;
+        const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+        if (n == 0) { // lqseq.seqs[max1_p] would be out of bounds
+            if (lane == 0) {
+                atomicOr(err, 8u);
+                reg_lable[g] = 0;
+                keep_n[g] = 0;
+                seed_cand[g] = 0; // in-bounds dummy; the error flag aborts the polish at the next read-back
+            }
+            continue;
+        }
+        uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
+        uint16_t ks = 0;
+        if (lane < n) {
+            so = rt.seq_off[c0 + lane];
+            len = rt.seq_off[c0 + lane + 1] - so;
+            order = rt.order[c0 + lane];
+            ks = rt.kscore[c0 + lane];
+        }
+        WaveStats w = wave_group_stats(sw, lane, n, so, len, rt.seq, ks > 0, order);
+        const uint32_t min_c = min_support(n);
+        if (sw.shfl(order, 0) != 0) { // "the first lqseq is not ref."
+            if (lane == 0) atomicOr(err, 16u);
+        }
+        // order_stat as a per-lane key (each candidate has its own read index)
+        uint32_t key = w.head ? w.c : 0;
+        {
+            const bool has0 = sw.shfl((uint32_t)w.head, 0) != 0;
+            uint32_t k0 = sw.shfl(key, 0);
+            if (has0) {
+                if (k0 > 1 && k0 < min_c) k0 = min_c;
+            } else {
+                const uint32_t cnt0 = __builtin_popcountll(sw.shfl((uint32_t)(w.eqmask & 0xFFFFFFFFu), 0)) +
+                                      __builtin_popcountll(sw.shfl((uint32_t)(w.eqmask >> 32), 0));
+                if (cnt0 > 1) k0 = min_c;
+            }
+            // no_dupseq_lqseq (main.rs:851-860): no two equal sequences among candidates 1..
+            const bool dup = lane >= 1 && lane < n && lane < 63 && ((w.eqmask >> (lane + 1)) != 0);
+            const bool nodup = sw.ballot(dup) == 0;
+            if (w.max1_p != 0 && w.max1_c < min_c && (w.max1_c > 1 || nodup)) {
+                if (lane == w.max1_p) key = min_c;
+                k0 = min_c;
+            } else if (w.max1_c < min_c) {
+                k0 = min_c;
+            }
+            if (lane == 0) key = k0;
+        }
+        // retain_sort_seqs: stable sort by key descending, keep key >= min_c
+        // (only kept candidates are ranked, and a candidate below min_c never outranks a kept one: walk the kept ones only)
+        const bool kept = lane < n && key >= min_c;
+        uint32_t rank = 0;
+        for (uint64_t it = sw.ballot(kept); it; it &= it - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(it);
+            const uint32_t kj = sw.shfl(key, j);
+            if (kept && (kj > key || (kj == key && j < lane))) ++rank;
+        }
+        uint32_t kn = __builtin_popcountll(sw.ballot(kept));
+        if (kn == 0) {
+            if (lane == 0) atomicOr(err, 32u); // lqseq.seqs[0] out of bounds after retain_sort_seqs
+            kn = 0;
+        }
+        // candidate of rank 0
+        const uint64_t r0mask = sw.ballot(kept && rank == 0);
+        const uint32_t first = r0mask ? __builtin_ctzll(r0mask) : 0;
+        uint32_t seed = w.max1_p;
+        const int32_t d = (int32_t)sw.shfl(len, w.max1_p) - (int32_t)sw.shfl(len, first);
+        const bool too_long = (d < 0 ? -d : d) > max_indel_len;
+        uint8_t lable = LB_SUCC | LB_RECH;
+        if (kn <= 1 || too_long) {
+            seed = first;
+            lable = LB_SUCC;
+            kn = 0;
+        }
+        if (kept && kn) {
+            keep_list[c0 + rank] = c0 + lane;
+            keep_ks[c0 + rank] = ks;
+        }
         if (lane == 0) {
-            atomicOr(err, 8u);
-            reg_lable[g] = 0;
-            keep_n[g] = 0;
-            seed_cand[g] = 0; // in-bounds dummy; the error flag aborts the polish at the next read-back
+            reg_lable[g] = lable;
+            seed_cand[g] = c0 + seed;
+            keep_n[g] = kn;
         }
-        return;
-    }
-    uint32_t so = 0, len = 0, order = 0xFFFFFFFFu;
-    uint16_t ks = 0;
-    if (lane < n) {
-        so = rt.seq_off[c0 + lane];
-        len = rt.seq_off[c0 + lane + 1] - so;
-        order = rt.order[c0 + lane];
-        ks = rt.kscore[c0 + lane];
-    }
-    WaveStats w = wave_group_stats(lane, n, so, len, rt.seq, ks > 0, order);
-    const uint32_t min_c = min_support(n);
-    if (__shfl(order, 0) != 0) { // "the first lqseq is not ref."
-        if (lane == 0) atomicOr(err, 16u);
-    }
-    // order_stat as a per-lane key (each candidate has its own read index)
-    uint32_t key = w.head ? w.c : 0;
-    {
-        const bool has0 = __shfl((uint32_t)w.head, 0) != 0;
-        uint32_t k0 = __shfl(key, 0);
-        if (has0) {
-            if (k0 > 1 && k0 < min_c) k0 = min_c;
-        } else {
-            const uint32_t cnt0 = __builtin_popcountll(__shfl((uint32_t)(w.eqmask & 0xFFFFFFFFu), 0)) +
-                                  __builtin_popcountll(__shfl((uint32_t)(w.eqmask >> 32), 0));
-            if (cnt0 > 1) k0 = min_c;
-        }
-        // no_dupseq_lqseq (main.rs:851-860): no two equal sequences among candidates 1..
-        const bool dup = lane >= 1 && lane < n && lane < 63 && ((w.eqmask >> (lane + 1)) != 0);
-        const bool nodup = __ballot(dup) == 0;
-        if (w.max1_p != 0 && w.max1_c < min_c && (w.max1_c > 1 || nodup)) {
-            if (lane == w.max1_p) key = min_c;
-            k0 = min_c;
-        } else if (w.max1_c < min_c) {
-            k0 = min_c;
-        }
-        if (lane == 0) key = k0;
-    }
-    // retain_sort_seqs: stable sort by key descending, keep key >= min_c
-    // (only kept candidates are ranked, and a candidate below min_c never outranks a kept one: walk the kept ones only)
-    const bool kept = lane < n && key >= min_c;
-    uint32_t rank = 0;
-    for (uint64_t it = __ballot(kept); it; it &= it - 1) {
-        const uint32_t j = (uint32_t)__builtin_ctzll(it);
-        const uint32_t kj = __shfl(key, j);
-        if (kept && (kj > key || (kj == key && j < lane))) ++rank;
-    }
-    uint32_t kn = __builtin_popcountll(__ballot(kept));
-    if (kn == 0) {
-        if (lane == 0) atomicOr(err, 32u); // lqseq.seqs[0] out of bounds after retain_sort_seqs
-        kn = 0;
-    }
-    // candidate of rank 0
-    const uint64_t r0mask = __ballot(kept && rank == 0);
-    const uint32_t first = r0mask ? __builtin_ctzll(r0mask) : 0;
-    uint32_t seed = w.max1_p;
-    const int32_t d = (int32_t)__shfl(len, w.max1_p) - (int32_t)__shfl(len, first);
-    const bool too_long = (d < 0 ? -d : d) > max_indel_len;
-    uint8_t lable = LB_SUCC | LB_RECH;
-    if (kn <= 1 || too_long) {
-        seed = first;
-        lable = LB_SUCC;
-        kn = 0;
-    }
-    if (kept && kn) {
-        keep_list[c0 + rank] = c0 + lane;
-        keep_ks[c0 + rank] = ks;
-    }
-    if (lane == 0) {
-        reg_lable[g] = lable;
-        seed_cand[g] = c0 + seed;
-        keep_n[g] = kn;
     }
 }
 
@@ -917,7 +951,7 @@ void launch_vote_phase(hipStream_t s, const RegionTables &rt, bool asref, bool u
                        uint32_t own_lo, uint32_t own_hi, uint8_t *reg_lable, uint8_t *grp, uint32_t *ecount, int32_t *ref_w,
                        uint8_t *ref_seen, uint8_t *bad, uint32_t *first_reg, uint32_t *err) {
     if (rt.n_reg)
-        NP2_LAUNCH(k_vote_phase, g1((uint64_t)rt.n_reg * 64), 256, s, rt, asref ? 1u : 0u, use_all ? 1u : 0u, lq_start, own_lo, own_hi, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
+        NP2_LAUNCH(k_vote_phase, g1((uint64_t)((rt.n_reg + 1) / 2) * 64), 256, s, rt, asref ? 1u : 0u, use_all ? 1u : 0u, lq_start, own_lo, own_hi, reg_lable, grp, ecount, ref_w, ref_seen, bad, first_reg, err);
 }
 void launch_vote_counts(hipStream_t s, const uint32_t *first_reg, const uint8_t *bad, uint32_t R, uint32_t *out) {
     NP2_LAUNCH(k_vote_counts, dim3(1), 1024, s, first_reg, bad, R, out);
@@ -946,7 +980,7 @@ void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *fl
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
                  uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err) {
     if (rt.n_reg)
-        NP2_LAUNCH(k_seed, g1((uint64_t)rt.n_reg * 64), 256, s, rt, max_indel_len, reg_lable, seed_cand, keep_n, keep_list, keep_ks, err);
+        NP2_LAUNCH(k_seed, g1((uint64_t)((rt.n_reg + 1) / 2) * 64), 256, s, rt, max_indel_len, reg_lable, seed_cand, keep_n, keep_list, keep_ks, err);
 }
 void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
                         const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
