@@ -362,7 +362,7 @@ CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, 
     uint32_t *const stuck_p = cx->scal.p + S_COUNT + 2 * version, *const nap_p = stuck_p + 1;
     launch_splice_find(s, in.pos, in.M_p, cx->lq_start.p, cx->lq_end.p, cx->reg_lable.p, lable, n_reg, cx->sp_idx_s.p,
                        cx->sp_idx_e.p, stuck_p);
-    launch_splice_plan(s, next_lookback(cx, (n_reg + 255) / 256), cx->reg_lable.p, lable, n_reg, stuck_p,
+    launch_splice_plan(s, next_lookback(cx, region_lb_blocks(n_reg)), cx->reg_lable.p, lable, n_reg, stuck_p,
                        cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p,
                        cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, nap_p, in.M_p, cx->mlen.p + version,
                        cx->scal.p + S_ERR);
@@ -393,8 +393,8 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         cx->rech.ensure(n_reg + 2);
         cx->rech_groups.ensure((size_t)(n_reg + 2) * rech_group_bytes());
         cx->rech_joboff.ensure(n_reg + 2);
-        const uint32_t nb = (n_reg + 255) / 256;
-        launch_rech_list(s, next_lookback(cx, nb), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
+        const uint32_t nb = (n_reg + 255) / 256; // (k_rech_groups: one region per thread)
+        launch_rech_list(s, next_lookback(cx, region_lb_blocks(n_reg)), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
                          (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         launch_rech_groups(s, next_lookback(cx, nb), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
                            cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->reg_maxlen.p, cx->rech_groups.p,

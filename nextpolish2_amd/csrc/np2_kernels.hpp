@@ -230,6 +230,8 @@ void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *fl
                          uint32_t n, uint64_t *ukey, uint32_t *uw, uint32_t *n_out);
 void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, uint8_t *reg_lable, uint32_t *seed_cand,
                  uint32_t *keep_n, uint32_t *keep_list, uint16_t *keep_ks, uint32_t *err);
+// blocks of the look-back compaction kernels over regions (k_splice_plan, k_rech_list)
+uint32_t region_lb_blocks(uint32_t n_reg);
 void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
                         const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg, uint32_t *idx_s,
                         uint32_t *idx_e, uint32_t *stuck);

@@ -554,6 +554,7 @@ __device__ __forceinline__ void k_splice_find(const uint32_t np2_bid, const uint
     idx_e[g] = found ? max(s, upper_bound_u32(cns_pos, M, lq_end[g])) : s;
     if (!found) atomicMax(stuck, g + 1);
 }
+static constexpr uint32_t LB_REG_ITEMS = 4; // regions per thread of the look-back compaction kernels
 // Applied regions in left -> right order (reverse region index): flag each region, compact the applied ones into
 // slots with their payload and prefix-sum the length changes -- one pass with a decoupled look-back across blocks.
 // The consensus length is chained on the device (*M_out = *M_in + total shift), so the host does not have to read
@@ -569,30 +570,44 @@ __device__ __forceinline__ void k_splice_plan(const uint32_t np2_bid, const uint
                                                      uint32_t *__restrict__ M_out, uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
     const uint32_t bid = lb_block_id(lb, sh);
-    const uint32_t rr = bid * 256 + threadIdx.x;
-    uint32_t flag = 0, g = 0, s = 0, e = 0;
-    int32_t delta = 0;
-    if (rr < n_reg) {
-        g = n_reg - 1 - rr;
-        flag = ((reg_lable[g] & lable) && g + 1 > *stuck) ? 1u : 0u;
-        if (flag) {
-            const uint32_t c = seed_cand[g];
-            s = idx_s[g], e = idx_e[g];
-            delta = (int32_t)(seq_off[c + 1] - seq_off[c]) - (int32_t)(e - s);
+    // four consecutive regions per thread (a quarter of the blocks: the look-back is a chain over the blocks)
+    uint32_t flag[LB_REG_ITEMS], g[LB_REG_ITEMS], s[LB_REG_ITEMS], e[LB_REG_ITEMS];
+    int32_t delta[LB_REG_ITEMS];
+    uint32_t fsum = 0;
+    int32_t dsum_t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        const uint32_t rr = (bid * 256 + threadIdx.x) * LB_REG_ITEMS + k;
+        flag[k] = 0, g[k] = 0, s[k] = 0, e[k] = 0, delta[k] = 0;
+        if (rr < n_reg) {
+            g[k] = n_reg - 1 - rr;
+            flag[k] = ((reg_lable[g[k]] & lable) && g[k] + 1 > *stuck) ? 1u : 0u;
+            if (flag[k]) {
+                const uint32_t c = seed_cand[g[k]];
+                s[k] = idx_s[g[k]], e[k] = idx_e[g[k]];
+                delta[k] = (int32_t)(seq_off[c + 1] - seq_off[c]) - (int32_t)(e[k] - s[k]);
+            }
         }
+        fsum += flag[k];
+        dsum_t += delta[k];
     }
     uint32_t cnt, dsum;
-    const uint32_t lo = block_excl_scan<OpAdd, 4>(flag, sh, cnt);
-    const uint32_t ld = block_excl_scan<OpAdd, 4>((uint32_t)delta, sh, dsum);
+    uint32_t lo = block_excl_scan<OpAdd, 4>(fsum, sh, cnt);
+    uint32_t ld = block_excl_scan<OpAdd, 4>((uint32_t)dsum_t, sh, dsum);
     uint32_t pre_c, pre_d;
     lb_exclusive2(lb, bid, cnt, dsum, sh, err, pre_c, pre_d);
-    if (flag) {
-        const uint32_t o = pre_c + lo;
-        ap_g[o] = g;
-        ap_s[o] = s;
-        ap_e[o] = e;
-        ap_delta[o] = delta;
-        ap_shift_incl[o] = (int32_t)(pre_d + ld) + delta;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        if (flag[k]) {
+            const uint32_t o = pre_c + lo;
+            ap_g[o] = g[k];
+            ap_s[o] = s[k];
+            ap_e[o] = e[k];
+            ap_delta[o] = delta[k];
+            ap_shift_incl[o] = (int32_t)(pre_d + ld) + delta[k];
+        }
+        lo += flag[k];
+        ld += (uint32_t)delta[k];
     }
     if (bid == n_blocks - 1 && threadIdx.x == 0) {
         *n_ap = pre_c + cnt;
@@ -664,12 +679,21 @@ __device__ __forceinline__ void k_rech_list(const uint32_t np2_bid, const uint32
     __shared__ uint32_t sh[8];
     if (np2_bid == 0 && threadIdx.x == 0) *blob_bound = 0; // accumulated by k_rech_groups, the next kernel
     const uint32_t bid = lb_block_id(lb, sh);
-    const uint32_t rr = bid * 256 + threadIdx.x;
-    const uint32_t flag = (rr < n_reg && (reg_lable[n_reg - 1 - rr] & LB_RECH)) ? 1u : 0u;
+    uint32_t flag[LB_REG_ITEMS], fsum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        const uint32_t rr = (bid * 256 + threadIdx.x) * LB_REG_ITEMS + k;
+        flag[k] = (rr < n_reg && (reg_lable[n_reg - 1 - rr] & LB_RECH)) ? 1u : 0u;
+        fsum += flag[k];
+    }
     uint32_t cnt, pre, dummy;
-    const uint32_t lo = block_excl_scan<OpAdd, 4>(flag, sh, cnt);
+    uint32_t lo = block_excl_scan<OpAdd, 4>(fsum, sh, cnt);
     lb_exclusive2(lb, bid, cnt, 0u, sh, err, pre, dummy);
-    if (flag) rech[pre + lo] = n_reg - 1 - rr;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        if (flag[k]) rech[pre + lo] = n_reg - 1 - ((bid * 256 + threadIdx.x) * LB_REG_ITEMS + k);
+        lo += flag[k];
+    }
     if (bid == n_blocks - 1 && threadIdx.x == 0) *n_rech = pre + cnt;
 }
 
@@ -982,6 +1006,7 @@ void launch_seed(hipStream_t s, const RegionTables &rt, int32_t max_indel_len, u
     if (rt.n_reg)
         NP2_LAUNCH(k_seed, g1((uint64_t)((rt.n_reg + 1) / 2) * 64), 256, s, rt, max_indel_len, reg_lable, seed_cand, keep_n, keep_list, keep_ks, err);
 }
+uint32_t region_lb_blocks(uint32_t n_reg) { return (n_reg + 256 * LB_REG_ITEMS - 1) / (256 * LB_REG_ITEMS); }
 void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start,
                         const uint32_t *lq_end, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
                         uint32_t *idx_s, uint32_t *idx_e, uint32_t *stuck) {
@@ -991,7 +1016,7 @@ void launch_splice_plan(hipStream_t s, const Lookback &lb, const uint8_t *reg_la
                         const uint32_t *stuck, const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
                         const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
                         int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t *err) {
-    const uint32_t nb = (n_reg + 255) / 256;
+    const uint32_t nb = region_lb_blocks(n_reg);
     NP2_LAUNCH(k_splice_plan, dim3(nb), 256, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e, seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, err);
 }
 void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, const uint32_t *M_p, uint32_t M_cap,
@@ -1005,7 +1030,7 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
 }
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
                       uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err) {
-    const uint32_t nb = (n_reg + 255) / 256;
+    const uint32_t nb = region_lb_blocks(n_reg);
     NP2_LAUNCH(k_rech_list, dim3(nb), 256, s, lb, nb, reg_lable, n_reg, rech, n_rech, blob_bound, err);
 }
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
