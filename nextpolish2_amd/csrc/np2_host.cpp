@@ -393,11 +393,13 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
         cx->rech.ensure(n_reg + 2);
         cx->rech_groups.ensure((size_t)(n_reg + 2) * rech_group_bytes());
         cx->rech_joboff.ensure(n_reg + 2);
-        const uint32_t nb = (n_reg + 255) / 256; // (k_rech_groups: one region per thread)
+        cx->rech_groups_tmp.ensure((size_t)(n_reg + 2) * rech_group_bytes());
+        cx->rech_headjobs.ensure(n_reg + 2);
         launch_rech_list(s, next_lookback(cx, region_lb_blocks(n_reg)), cx->reg_lable.p, n_reg, cx->rech.p, cx->scal.p + S_NRECH,
                          (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
-        launch_rech_groups(s, next_lookback(cx, nb), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
-                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->reg_maxlen.p, cx->rech_groups.p,
+        launch_rech_groups(s, next_lookback(cx, region_lb_blocks(n_reg)), cx->rech.p, cx->scal.p + S_NRECH, n_reg, in.pos, in.M_p,
+                           cx->lq_start.p, cx->lq_end.p, cx->keep_n.p, ksize, cx->reg_maxlen.p, cx->rech_groups_tmp.p,
+                           cx->rech_headjobs.p, cx->rech_groups.p,
                            cx->rech_joboff.p, cx->scal.p + S_NGROUPS,
                            cx->scal.p + S_M0, (unsigned long long *)(cx->scal.p + S_M1), cx->scal.p + S_ERR);
         std::vector<uint32_t> sc = fetch_scal(cx);

@@ -250,7 +250,8 @@ void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_labl
 // groups of chained RECH regions + per-group job offsets (job_off[n_groups] = *n_jobs); max_rech = launch bound
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *tmp_groups,
+                        uint32_t *head_jobs, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
                         unsigned long long *blob_bound, uint32_t *err);
 size_t rech_group_bytes();
 void launch_rech_job_len(hipStream_t s, const RechPtrs &p, uint32_t n_jobs, uint32_t *len);

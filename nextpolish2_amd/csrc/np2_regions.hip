@@ -705,25 +705,25 @@ struct RechGroup { // one recheck group = 1..6 chained RECH regions
     uint32_t njobs;
 };
 
-// chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions.  One thread per
-// RECH region; a thread whose region heads a group builds it.  Group slots and job offsets (exclusive sums of the
-// group / job counts) come from a look-back across blocks; the last block leaves the totals.
-__device__ __forceinline__ void k_rech_groups(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ rech,
+// chain grouping (main.rs:1196-1206): natural chains (next.start < prev.end + k) cut every 6 regions.  Two kernels:
+// k_rech_groups builds, one thread per RECH region, the group of every region that heads one (the searches for its
+// flanks in the consensus are chains of dependent loads: no block waits for another here) into a scratch slot under
+// the region's own index; k_rech_compact then moves the groups to their slots and leaves the job offsets (exclusive
+// sums of the group / job counts) with a look-back over a few blocks of four regions per thread.  As one kernel the
+// look-back chain ran over every block of the heavy threads (120 us per call on the yeast-sized assembly).
+__device__ __forceinline__ void k_rech_groups(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ rech,
                                                      const uint32_t *__restrict__ n_rech_p,
                                                      const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
                                                      const uint32_t *__restrict__ lq_start,
                                                      const uint32_t *__restrict__ lq_end,
                                                      const uint32_t *__restrict__ keep_n, uint32_t ksize,
                                                      const uint32_t *__restrict__ reg_maxlen,
-                                                     RechGroup *__restrict__ groups, uint32_t *__restrict__ job_off,
-                                                     uint32_t *__restrict__ n_groups, uint32_t *__restrict__ n_jobs,
+                                                     RechGroup *__restrict__ tmp_groups, uint32_t *__restrict__ head_jobs,
                                                      unsigned long long *__restrict__ blob_bound,
                                                      uint32_t *__restrict__ err) {
-    __shared__ uint32_t sh[8];
     __shared__ unsigned long long s_bound[4];
     unsigned long long bound = 0; // upper bound of the bytes of this group's recheck strings
-    const uint32_t bid = lb_block_id(lb, sh);
-    const uint32_t e = bid * 256 + threadIdx.x;
+    const uint32_t e = np2_bid * 256 + threadIdx.x;
     const uint32_t n_rech = *n_rech_p, M = *M_p;
     auto chained = [&](uint32_t x) { return lq_start[rech[x]] < lq_end[rech[x - 1]] + ksize; };
     bool head = false;
@@ -788,21 +788,49 @@ __device__ __forceinline__ void k_rech_groups(const uint32_t np2_bid, const uint
             if (x + 1 < n) len += G.be[x] - G.bs[x];
         }
         bound = (unsigned long long)jobs32 * len;
+        tmp_groups[e] = G;
     }
+    // head_jobs[e]: 0 = not a group head, else 1 + the group's job count (a head may have 0 jobs)
+    if (e < n_rech) head_jobs[e] = head ? jobs32 + 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) bound += __shfl_xor(bound, o);
     if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = bound;
-    uint32_t nh, nj, pre_h, pre_j;
-    const uint32_t lh = block_excl_scan<OpAdd, 4>(head ? 1u : 0u, sh, nh);
-    const uint32_t lj = block_excl_scan<OpAdd, 4>(jobs32, sh, nj);
-    lb_exclusive2(lb, bid, nh, nj, sh, err, pre_h, pre_j);
-    if (pre_j + nj < pre_j) atomicOr(err, 128u); // total job count overflows 32 bits
-    if (head) {
-        groups[pre_h + lh] = G;
-        job_off[pre_h + lh] = pre_j + lj;
-    }
-    if (threadIdx.x == 0) { // (the block scans above contain barriers: s_bound is complete)
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const unsigned long long b = s_bound[0] + s_bound[1] + s_bound[2] + s_bound[3];
         if (b) atomicAdd(blob_bound, b);
+    }
+}
+__device__ __forceinline__ void k_rech_compact(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks,
+                                                      const uint32_t *__restrict__ n_rech_p,
+                                                      const uint32_t *__restrict__ head_jobs,
+                                                      const RechGroup *__restrict__ tmp_groups,
+                                                      RechGroup *__restrict__ groups, uint32_t *__restrict__ job_off,
+                                                      uint32_t *__restrict__ n_groups, uint32_t *__restrict__ n_jobs,
+                                                      uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[8];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t n_rech = *n_rech_p;
+    uint32_t hj[LB_REG_ITEMS], hs = 0, js = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        const uint32_t e = (bid * 256 + threadIdx.x) * LB_REG_ITEMS + k;
+        hj[k] = e < n_rech ? head_jobs[e] : 0u;
+        hs += hj[k] ? 1u : 0u;
+        js += hj[k] ? hj[k] - 1u : 0u;
+    }
+    uint32_t nh, nj, pre_h, pre_j;
+    uint32_t lh = block_excl_scan<OpAdd, 4>(hs, sh, nh);
+    uint32_t lj = block_excl_scan<OpAdd, 4>(js, sh, nj);
+    lb_exclusive2(lb, bid, nh, nj, sh, err, pre_h, pre_j);
+    if (pre_j + nj < pre_j) atomicOr(err, 128u); // total job count overflows 32 bits
+#pragma unroll
+    for (uint32_t k = 0; k < LB_REG_ITEMS; ++k) {
+        if (!hj[k]) continue;
+        const uint32_t e = (bid * 256 + threadIdx.x) * LB_REG_ITEMS + k;
+        groups[pre_h + lh] = tmp_groups[e];
+        job_off[pre_h + lh] = pre_j + lj;
+        ++lh;
+        lj += hj[k] - 1u;
     }
     if (bid == n_blocks - 1 && threadIdx.x == 0) {
         *n_groups = pre_h + nh;
@@ -1035,10 +1063,12 @@ void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_labl
 }
 void launch_rech_groups(hipStream_t s, const Lookback &lb, const uint32_t *rech, const uint32_t *n_rech_p, uint32_t max_rech,
                         const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *lq_start, const uint32_t *lq_end,
-                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *groups, uint32_t *job_off,
-                        uint32_t *n_groups, uint32_t *n_jobs, unsigned long long *blob_bound, uint32_t *err) {
-    const uint32_t nb = (max_rech + 255) / 256;
-    NP2_LAUNCH(k_rech_groups, dim3(nb), 256, s, lb, nb, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end, keep_n, ksize, reg_maxlen, (RechGroup *)groups, job_off, n_groups, n_jobs, blob_bound, err);
+                        const uint32_t *keep_n, uint32_t ksize, const uint32_t *reg_maxlen, void *tmp_groups,
+                        uint32_t *head_jobs, void *groups, uint32_t *job_off, uint32_t *n_groups, uint32_t *n_jobs,
+                        unsigned long long *blob_bound, uint32_t *err) {
+    NP2_LAUNCH(k_rech_groups, dim3((max_rech + 255) / 256), 256, s, rech, n_rech_p, cns_pos, M_p, lq_start, lq_end, keep_n, ksize, reg_maxlen, (RechGroup *)tmp_groups, head_jobs, blob_bound, err);
+    const uint32_t nb = region_lb_blocks(max_rech);
+    NP2_LAUNCH(k_rech_compact, dim3(nb), 256, s, lb, nb, n_rech_p, head_jobs, (const RechGroup *)tmp_groups, (RechGroup *)groups, job_off, n_groups, n_jobs, err);
 }
 size_t rech_group_bytes() { return sizeof(RechGroup); }
 static RechCtx mk_rech(const RechPtrs &p) {
