@@ -243,9 +243,19 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
     const size_t b_key = ((size_t)NU * 8 + 15) & ~(size_t)15, b_w = ((size_t)NU * 4 + 15) & ~(size_t)15, b_v = RP * 10;
     {
         uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_v + 64);
-        op_d2h(cx, pin, cx->ekey.p, (size_t)NU * 8);
-        op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
-        op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
+        if (tl_recorder()) {
+            // batch driver: the three pieces are gathered into one device buffer by copy kernels (one launch each for
+            // all contigs of the batch) and cross the bus as ONE DMA transfer per contig instead of three
+            cx->votepack.ensure(b_key + b_w + b_v + 64);
+            op_copy_d2d(cx, cx->votepack.p, cx->ekey.p, (size_t)NU * 8);
+            op_copy_d2d(cx, cx->votepack.p + b_key, cx->eval.p, (size_t)NU * 4);
+            op_copy_d2d(cx, cx->votepack.p + b_key + b_w, cx->votebuf.p, b_v);
+            op_d2h(cx, pin, cx->votepack.p, b_key + b_w + b_v);
+        } else {
+            op_d2h(cx, pin, cx->ekey.p, (size_t)NU * 8);
+            op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
+            op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
+        }
         op_sync(cx);
         vd.pair_key.resize(NU);
         vd.pair_cnt.resize(NU);
