@@ -436,7 +436,7 @@ CnsDev recheck_gpu(np2_ctx *cx, const CnsDev &in, const PassCounts &pc, int yak_
             cx->sstr.ensure((size_t)blob_bound + 64);
             launch_rech_job_build(s, rp, n_jobs, cx->job_off32.p, cx->soff.p, cx->sstr.p);
             launch_score_strings(s, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n_jobs, min_kmer_count,
-                                 cx->sscore.p);
+                                 cx->sscore.p, true);
             launch_rech_apply(s, rp, cx->sscore.p, cx->keep_ks.p);
         }
         EventTimer t(cx, "recheck");
@@ -469,7 +469,7 @@ void gpu_score_strings(np2_ctx *cx, int yak_idx, const std::vector<uint8_t> &blo
     {
         EventTimer t(cx, "score_strings");
         launch_score_strings(cx->stream, cx->yaks[yak_idx].dev(), cx->sstr.p, cx->soff.p, n, min_kmer_count,
-                             cx->sscore.p);
+                             cx->sscore.p, false);
     }
     scores = d2h(cx, cx->sscore.p, n);
 }

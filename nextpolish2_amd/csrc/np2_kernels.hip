@@ -1661,8 +1661,10 @@ __device__ __forceinline__ void k_lookup(const uint32_t np2_bid, const uint32_t 
 
 // one wavefront per string: lanes own k-mer start offsets; min-count over all valid k-mers
 // (iter2kmer kmer.rs:255-287: a k-mer exists where the last k characters are all ACGT)
-__device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uint8_t *__restrict__ s, uint32_t len,
-                                                      uint16_t min_count) {
+// min count over the k-mers of a string of arbitrary ASCII (np2_score_strings: the caller's bytes go through SEQ_NUM like
+// the reference's, kmer.rs:11-22), one lane per k-mer start, a k-step byte loop per lane
+__device__ __forceinline__ uint16_t wave_score_string_any(const YakDev &y, const uint8_t *__restrict__ s, uint32_t len,
+                                                          uint16_t min_count) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = y.k;
     const uint64_t mask = (1ULL << (2 * (uint64_t)k)) - 1, shift = 2 * ((uint64_t)k - 1);
@@ -1686,12 +1688,54 @@ __device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uin
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor(mn, o));
     return mn == 0xFFFFFFFFu ? (uint16_t)0 : (uint16_t)mn;
 }
+// min count over the k-mers of a string, one lane per k-mer start (iter2kmer, kmer.rs:255-314).  The strings scored here
+// are written by this library from 3-bit codes (code_to_ascii: "ACGT-NM", upper case), so a lane builds its k-mer
+// from five unaligned 8-byte loads instead of a k-step byte loop: bit 3 of a byte singles out '-', 'N' and 'M' (the
+// k-mer is skipped: code >= 4 resets the rolling k-mer), ((c >> 1) ^ (c >> 2)) & 3 is the 2-bit code of A / C / G / T.
+__device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uint8_t *__restrict__ s, uint32_t len,
+                                                      uint16_t min_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = y.k;
+    const uint64_t mask = (1ULL << (2 * (uint64_t)k)) - 1;
+    uint32_t mn = 0xFFFFFFFFu;
+    if (len >= k) {
+        for (uint32_t st = lane; st + k <= len; st += 64) {
+            uint64_t codes = 0, bad = 0; // 2-bit code of byte j at bits 2j; bit j of `bad`: byte j is not a base
+#pragma unroll
+            for (uint32_t wd = 0; wd < 4; ++wd) { // 32 bytes cover k <= 31 (the pool is padded past its end)
+                uint64_t x;
+                __builtin_memcpy(&x, s + st + 8 * wd, 8);
+                uint64_t c = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ULL;
+                c = (c | (c >> 6)) & 0x000F000F000F000FULL;
+                c = (c | (c >> 12)) & 0x000000FF000000FFULL;
+                c = (c | (c >> 24)) & 0xFFFFULL;
+                codes |= c << (16 * wd);
+                uint64_t b = (x >> 3) & 0x0101010101010101ULL;
+                b = (b | (b >> 7)) & 0x0003000300030003ULL;
+                b = (b | (b >> 14)) & 0x0000000F0000000FULL;
+                b = (b | (b >> 28)) & 0xFFULL;
+                bad |= b << (8 * wd);
+            }
+            if ((bad & ((1ULL << k) - 1ULL)) == 0) {
+                codes &= mask;
+                uint64_t rb = __builtin_bitreverse64(codes);
+                rb = ((rb >> 1) & 0x5555555555555555ULL) | ((rb & 0x5555555555555555ULL) << 1); // pairs back in bit order
+                const uint64_t fw = rb >> (64 - 2 * k), rv = ~codes & mask;
+                mn = min(mn, (uint32_t)yak_get(y, yak_hash64(fw < rv ? fw : rv, mask), min_count));
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+    return mn == 0xFFFFFFFFu ? (uint16_t)0 : (uint16_t)mn;
+}
 
 __device__ __forceinline__ void k_score_strings(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint8_t *__restrict__ strs, const uint64_t *__restrict__ off,
-                                uint64_t n, uint16_t min_count, uint16_t *__restrict__ out) {
+                                uint64_t n, uint16_t min_count, uint16_t *__restrict__ out, uint32_t own_strings) {
     const uint64_t w = ((uint64_t)np2_bid * blockDim.x + threadIdx.x) >> 6;
     if (w >= n) return;
-    const uint16_t sc = wave_score_string(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count);
+    // own_strings: built by this library from 3-bit codes (and padded by 32 bytes), not handed in by a caller
+    const uint16_t sc = own_strings ? wave_score_string(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count)
+                                    : wave_score_string_any(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count);
     if ((threadIdx.x & 63) == 0) out[w] = sc;
 }
 
@@ -1845,8 +1889,8 @@ void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint6
     if (n) NP2_LAUNCH(k_lookup, grid1(n), 256, s, y, hashes, n, min_count, out);
 }
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
-                          uint16_t min_count, uint16_t *out) {
-    if (n) NP2_LAUNCH(k_score_strings, grid1(n * 64), 256, s, y, strs, off, n, min_count, out);
+                          uint16_t min_count, uint16_t *out, bool own_strings) {
+    if (n) NP2_LAUNCH(k_score_strings, grid1(n * 64), 256, s, y, strs, off, n, min_count, out, own_strings ? 1u : 0u);
 }
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
                        const uint64_t *cand_kmer, const uint32_t *n_cand_p, uint32_t cand_cap, uint16_t min_count,

@@ -129,7 +129,7 @@ void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *buc
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag);
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count, uint16_t *out);
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
-                          uint16_t min_count, uint16_t *out);
+                          uint16_t min_count, uint16_t *out, bool own_strings);
 void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_off, const uint8_t *cand_seq,
                        const uint64_t *cand_kmer, const uint32_t *n_cand_p, uint32_t cand_cap, uint16_t min_count,
                        uint16_t *kscore, uint32_t *long_list, uint32_t *n_long);
