@@ -1746,12 +1746,21 @@ __device__ __forceinline__ void k_cand_score(const uint32_t np2_bid, const uint3
                              uint16_t *__restrict__ kscore, uint32_t *__restrict__ long_list,
                              uint32_t *__restrict__ n_long) {
     const uint32_t c = np2_bid * blockDim.x + threadIdx.x;
-    if (c >= *n_cand_p) return; // the candidate count lives on the device; the launch covers its bound
-    const uint32_t len = cand_seq_off[c + 1] - cand_seq_off[c];
+    const bool live = c < *n_cand_p; // the candidate count lives on the device; the launch covers its bound
+    const uint32_t len = live ? cand_seq_off[c + 1] - cand_seq_off[c] : 0u;
+    const bool is_long = live && len > y.k;
+    // one reservation per wave in the list of long candidates (a same-address atomic per candidate serialises at ~10 ns each)
+    const uint64_t m = __ballot(is_long);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63, lead = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == lead) base = atomicAdd(n_long, (uint32_t)__builtin_popcountll(m));
+        base = __shfl(base, lead);
+        if (is_long) long_list[base + (uint32_t)__builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = c;
+    }
+    if (!live) return;
     uint16_t sc = 0;
-    if (len > y.k) {
-        long_list[atomicAdd(n_long, 1u)] = c;
-    } else {
+    if (!is_long) {
         const uint64_t km = cand_kmer[c];
         if (km != INVALID_KMER) sc = yak_get(y, km, min_count);
     }
