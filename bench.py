@@ -47,7 +47,8 @@ def make_assembly(lengths, depth, seed0, diploid):
 
 
 class Groups:
-    """The assembly's contigs split over G batch groups of about equal size in bp, longest contigs first: each group is one
+    """The assembly's contigs split over G batch groups of about equal size in bp (longest contig first, each to the
+    least loaded group): each group is one
     np2_batch_t driven by its own host thread, so one group's host phases (the Louvain of the phasing vote, ~1 ms for
     the longest contig) and read-back latencies are filled by the other groups' kernels.  Over the K timed steps the
     groups run free — every group polishes its contigs K times, the groups do not wait for each other between steps
@@ -58,15 +59,14 @@ class Groups:
     def __init__(self, pol, contigs, lengths, n_groups):
         from nextpolish2_amd import BatchPolisher
         order = sorted(range(len(contigs)), key=lambda i: -lengths[i])
-        tot, k, self.members = sum(lengths), 0, []
-        for g in range(n_groups):
-            acc, m = 0, []
-            while k < len(order) and (g == n_groups - 1 or acc < tot / n_groups) and len(order) - k > n_groups - 1 - g:
-                acc += lengths[order[k]]
-                m.append(order[k])
-                k += 1
-            self.members.append(m)
-        self.members = [m for m in self.members if m]
+        # longest contig first, each to the group with the least bp so far: the groups run free over the steps, so the
+        # job ends with the slowest group (cut into equal shares in input order the last group got 1.3 of 12 Mb)
+        n_groups = max(1, min(n_groups, len(order)))
+        self.members, load = [[] for _ in range(n_groups)], [0] * n_groups
+        for i in order:
+            g = min(range(n_groups), key=lambda j: (load[j], j))
+            self.members[g].append(i)
+            load[g] += lengths[i]
         self.bps = [BatchPolisher(pol, len(m)) for m in self.members]
         if len(self.bps) > 1:
             for g, b in enumerate(self.bps):
