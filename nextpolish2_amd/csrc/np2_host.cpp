@@ -178,7 +178,23 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
                           v_refw, v_seen, v_bad, v_first, cx->scal.p + S_ERR);
         exclusive_total_n(cx, cx->ecount.p, cx->eoff.p, n_reg);
         launch_vote_counts(s, v_first, v_bad, R, cx->scal.p + S_M1); // S_M1 = graph keys, S_M2 = invalid reads
+        // distinct read pairs + their vote counts, queued behind the vote without waiting for its counts (one read-back
+        // less per phasing pass; with no HETE region the three kernels find nothing to do).  Normal case: the raw pair
+        // votes are accumulated in the banded matrix (reads are numbered in start order, partners are close); rows read
+        // in order = the sorted unique list, at most EDGE_BAND pairs per read.
+        const size_t band_words = (size_t)R * EDGE_BAND;
+        cx->band.ensure(band_words + 4);
+        cx->band_n.ensure((size_t)R + 2);
+        cx->band_off.ensure((size_t)R + 2);
+        op_fill(cx, cx->scal.p + S_M3, 0, 4);
+        launch_edges_row(s, rt, cx->grp.p, cx->ecount.p, cx->pj.p, cx->pcount.p, cx->alive.p, R, cx->band.p, cx->band_n.p,
+                         cx->scal.p + S_M3);
+        exclusive_total_n(cx, cx->band_n.p, cx->band_off.p, R);
+        cx->ekey.ensure(band_words + 2);
+        cx->eval.ensure(band_words + 2);
+        launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
     }
+    bool far = false;
     {
         std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
         check_region_err(cx, sc[S_ERR]);
@@ -188,30 +204,11 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
             if (NE) throw Np2Error(NP2_E_DEVICE, "internal: pair edges without voting reads");
             return;
         }
+        NU = sc[S_NRAW];
+        far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
     }
     vd.any = true;
     if (NE) {
-        // distinct read pairs + their vote counts.  Normal case: accumulate the raw pair votes in the banded matrix
-        // (reads are numbered in start order, partners are close); rows read in order = the sorted unique list.
-        bool far = false;
-        {
-            EventTimer t(cx, "vote_phase");
-            const size_t band_words = (size_t)R * EDGE_BAND;
-            cx->band.ensure(band_words + 4);
-            cx->band_n.ensure((size_t)R + 2);
-            cx->band_off.ensure((size_t)R + 2);
-            op_fill(cx, cx->scal.p + S_M3, 0, 4);
-            launch_edges_row(s, rt, cx->grp.p, cx->ecount.p, cx->pj.p, cx->pcount.p, cx->alive.p, R, cx->band.p, cx->band_n.p,
-                             cx->scal.p + S_M3);
-            exclusive_total_n(cx, cx->band_n.p, cx->band_off.p, R);
-            // (at most one distinct pair per raw vote: NE bounds the output)
-            cx->ekey.ensure((size_t)NE + 2);
-            cx->eval.ensure((size_t)NE + 2);
-            launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
-            const std::vector<uint32_t> sc = fetch_scal(cx);
-            NU = sc[S_NRAW];
-            far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
-        }
         if (far) { // some pair lies outside the band (deep pileup): sort the raw votes instead
             EventTimer t(cx, "vote_phase");
             cx->ekey.ensure(NE + 2);
