@@ -1449,7 +1449,33 @@ __device__ __forceinline__ void k_lq_scan(const uint32_t np2_bid, const uint32_t
         const uint32_t p = M - 1 - i;
         uint8_t kind = LQK_OPEN;
         uint32_t pp = p + 1;
-        for (; pp < M; ++pp) {
+        bool resolved = false;
+        if (i >= 8) {
+            // the next eight emission indices (consensus indices i-1 .. i-8) out of one round of loads: the walk below
+            // usually ends within six steps, each of which would otherwise be a dependent load or three
+            uint64_t c8, b8;
+            uint32_t ps[8];
+            __builtin_memcpy(&c8, cns_cls + i - 8, 8); // byte k <-> consensus index i - 8 + k
+            __builtin_memcpy(&b8, cns_base + i - 8, 8);
+            __builtin_memcpy(ps, cns_pos + i - 8, 32);
+#pragma unroll
+            for (uint32_t st = 1; st <= 8; ++st) {
+                if (resolved) continue;
+                const uint32_t w = 8 - st; // window slot of consensus index i - st
+                const uint8_t cl = (uint8_t)(c8 >> (8 * w));
+                if (cl == CLS_RESET) {
+                    kind = LQK_RESET, pp = p + st, resolved = true;
+                } else if (cl == CLS_LQ) {
+                    kind = LQK_LINK, pp = p + st, resolved = true;
+                } else if (st > 4) {
+                    const uint32_t w1 = w + 1 <= 7 ? w + 1 : 7, w2 = w + 2 <= 7 ? w + 2 : 7; // (st > 4: w + 2 <= 5)
+                    if (ps[w1] != ps[w2] && (uint8_t)(b8 >> (8 * w1)) != (uint8_t)(b8 >> (8 * w2)))
+                        kind = LQK_CLOSE, pp = p + st, resolved = true;
+                }
+            }
+            if (!resolved) pp = p + 9;
+        }
+        for (; !resolved && pp < M; ++pp) {
             const uint32_t ii = M - 1 - pp;
             const uint8_t cl = cns_cls[ii];
             if (cl == CLS_RESET) {
