@@ -175,6 +175,8 @@ void flush(np2_batch *b) {
         b->fail_msg = ex.what();
         b->failed.store(true);
         (void)hipStreamSynchronize(s);
+        // whatever was not issued is dropped below: the slots' host-side look-back state no longer matches the device
+        for (np2_ctx *cx : b->slots) cx->lb_dirty = true, cx->h2d_inflight = false;
     }
     tl_recorder() = saved;
     for (auto &r : b->recs) r.clear();
@@ -215,7 +217,13 @@ void group_sync(Recorder *r) {
 // a pipeline left the wave (finished or failed): the others must not wait for it
 void leave_wave(np2_batch *b, Recorder *r) {
     std::lock_guard<std::mutex> l(b->sync_mu);
-    r->clear(); // (commands recorded after the last synchronisation of a failed pipeline are dropped)
+    if (!r->q.empty()) { // commands recorded after the last synchronisation of a failed pipeline are dropped: its
+                         // context's look-back tickets / epochs advanced at record time and must start over
+        np2_ctx *cx = b->slots[r->slot];
+        cx->lb_dirty = true;
+        cx->h2d_inflight = false;
+    }
+    r->clear();
     --b->n_active;
     if (b->n_active > 0 && b->n_waiting == b->n_active) {
         const uint64_t g = b->flush_gen.load(std::memory_order_relaxed);

@@ -217,6 +217,8 @@ struct np2_ctx {
     DevBuf<uint64_t> lb_status;
     DevBuf<uint32_t> lb_ticket;
     uint32_t lb_ticket_total = 0, lb_epoch = 0;
+    bool lb_dirty = false; // recorded commands of this context were dropped (a failed batch wave): the host-side ticket
+                           // base / epoch may be ahead of the device's counters — start the look-back state over
     static constexpr size_t LB_MAX_BLOCKS = 1u << 20;
     DevBuf<uint32_t> mlen; // consensus length after each splice round of the final pass (device-side chain)
     // region logic
@@ -448,6 +450,13 @@ inline Lookback next_lookback(np2_ctx *cx, uint32_t n_blocks) {
         op_fill(cx, cx->lb_ticket.p, 0, 16);
         cx->lb_ticket_total = 0;
         cx->lb_epoch = 0;
+    }
+    if (cx->lb_dirty) { // look-back launches were recorded and never issued: device ticket counter != host ticket base
+        op_fill(cx, cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t));
+        op_fill(cx, cx->lb_ticket.p, 0, 16);
+        cx->lb_ticket_total = 0;
+        cx->lb_epoch = 0;
+        cx->lb_dirty = false;
     }
     if (++cx->lb_epoch >= (1u << 30)) { // epochs exhausted: start over with cleared status words
         op_fill(cx, cx->lb_status.p, 0, 2 * np2_ctx::LB_MAX_BLOCKS * sizeof(uint64_t));

@@ -1700,7 +1700,11 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
         std::vector<std::pair<uint64_t, uint32_t>> pairs;
         for (int v = 0; v < n_votes; ++v) {
             const np2_vote_t &x = votes[v];
-            for (uint64_t i = 0; i < x.n_pairs; ++i) pairs.emplace_back(x.pair_key[i], x.pair_cnt[i]);
+            for (uint64_t i = 0; i < x.n_pairs; ++i) {
+                // (the keys arrive from other ranks: both endpoints index per-read arrays below)
+                if ((uint32_t)(x.pair_key[i] >> 32) >= n_reads_total || (uint32_t)x.pair_key[i] >= n_reads_total) return NP2_E_ARG;
+                pairs.emplace_back(x.pair_key[i], x.pair_cnt[i]);
+            }
             for (uint32_t i = 0; i < x.n_reads; ++i) {
                 const uint32_t r = x.read_id[i];
                 if (r >= n_reads_total) return NP2_E_ARG;
@@ -1764,15 +1768,33 @@ int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos,
     if (!sr || !out_bases || !out_pos || !out_len || !sr->run.final_pass()) return NP2_E_ARG;
     np2_ctx *cx = sr->run.cx;
     ResultOut r;
+    struct PutBack { // the pinned result blocks go back to the pool unless they are handed to the caller
+        ResultOut &r;
+        bool keep = false;
+        ~PutBack() {
+            if (keep) return;
+            if (r.bases) pinned_pool().put(r.bases);
+            if (r.pos) pinned_pool().put(r.pos);
+        }
+    } guard{r};
     NP2_SHARD_TRY(cx, {
         run_final_pass(sr->run, r);
         const np2_shard_plan_t &pl = sr->plan;
         // a splice cursor that got stuck (update_consensus_with_lqseqs, main.rs:1036-1056) leaves every region to its
-        // right untouched — contig-wide: a shard cannot reproduce that on its own
-        if (pl.sub_lo != 0) {
+        // right untouched — contig-wide: a shard cannot reproduce that on its own, whichever shard sees it (the first one
+        // included: the shards to its right would go on splicing).  Only a region stuck beyond the right end of the zone
+        // is harmless: coverage is partial there (an artefact of the cut) and everything it freezes lies outside of what
+        // this shard emits.
+        if (sr->run.n_reg) {
             std::vector<uint32_t> rounds = d2h(cx, cx->scal.p + S_COUNT, 2 * (cx->yaks.size() + 1));
-            for (size_t v = 0; v < rounds.size(); v += 2)
-                if (rounds[v]) throw Np2Error(NP2_E_UNSUPPORTED, "splice cursor stuck inside a shard: polish this contig unsharded");
+            uint32_t worst = 0; // highest region index + 1 = the leftmost stuck region over all rounds
+            for (size_t v = 0; v < rounds.size(); v += 2) worst = std::max(worst, rounds[v]);
+            if (worst) {
+                if (worst > sr->run.n_reg) throw Np2Error(NP2_E_DEVICE, "internal: stuck region index out of range");
+                const uint32_t at = d2h(cx, cx->lq_start.p + (worst - 1), 1)[0];
+                if ((uint64_t)at + pl.sub_lo < pl.zone_hi)
+                    throw Np2Error(NP2_E_UNSUPPORTED, "splice cursor stuck inside a shard: polish this contig unsharded");
+            }
         }
         // keep the owned interval (+ the verification margin), in contig coordinates
         const uint32_t lo = pl.own_lo > sr->verify ? pl.own_lo - sr->verify : 0u;
@@ -1787,6 +1809,7 @@ int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos,
         }
         r.len = w;
     })
+    guard.keep = true;
     *out_bases = r.bases;
     *out_pos = r.pos;
     *out_len = r.len;
