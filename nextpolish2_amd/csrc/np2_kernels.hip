@@ -12,6 +12,7 @@
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
 #include "np2_blockscan.hpp"
+#include "np2_nib128.hpp"
 #include "../../include/np2.h"
 
 namespace np2 {
@@ -19,9 +20,6 @@ namespace np2 {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t swap_nib(uint32_t w) {
-    return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu);
-}
 __device__ __forceinline__ uint8_t ref_code(const uint8_t *__restrict__ refnib, uint32_t p) {
     return (refnib[p >> 1] >> (4 * (p & 1))) & 7;
 }
@@ -40,380 +38,6 @@ __device__ __forceinline__ void k_encode_ref(const uint32_t np2_bid, const uint3
     if (c0 < L && (hi & 7) == 7) atomicOr(err, 1u);
     if (c1 < L && (lo & 7) == 7) atomicOr(err, 1u);
     refnib[i] = (uint8_t)((hi & 7) | ((lo & 7) << 4));
-}
-
-// ------------------------------------------------------------------------------------------
-// K1: dense pass — compare every read column with the contig, emit exception records and
-//     per-read checkpoints.  One wavefront per 2048-column chunk; each lane owns 32 columns
-//     (16 B), i.e. a coalesced 1 KiB per wave-instruction.
-// ------------------------------------------------------------------------------------------
-// ---- 128-bit nibble vectors: column j of a lane lives in nibble j (bits 4j..4j+3; lo = columns 0-15) ----------
-struct N128 {
-    uint64_t lo, hi;
-};
-static constexpr uint64_t NF3 = 0x8888888888888888ULL; // bit 3 of every nibble: the flag position of all column masks
-__device__ __forceinline__ N128 n_below(uint32_t p) { // all bits of nibbles [0, p)
-    N128 m;
-    m.lo = p >= 16 ? ~0ULL : ((1ULL << (4 * p)) - 1ULL);
-    m.hi = p <= 16 ? 0ULL : (p >= 32 ? ~0ULL : ((1ULL << (4 * (p - 16))) - 1ULL));
-    return m;
-}
-__device__ __forceinline__ uint32_t n_ctz(const N128 &x) { // index of the first set bit, 128 if none
-    return x.lo ? (uint32_t)__builtin_ctzll(x.lo) : (x.hi ? 64u + (uint32_t)__builtin_ctzll(x.hi) : 128u);
-}
-__device__ __forceinline__ uint32_t n_popc(const N128 &x) {
-    return (uint32_t)__builtin_popcountll(x.lo) + (uint32_t)__builtin_popcountll(x.hi);
-}
-// x holds nibble flags (bit 3) and is not zero: all bits below the nibble of its lowest flag / up to and including it
-__device__ __forceinline__ N128 n_mask_before_first(const N128 &x) {
-    N128 m;
-    if (x.lo) {
-        m.lo = ((x.lo & (0ULL - x.lo)) >> 3) - 1ULL;
-        m.hi = 0;
-    } else {
-        m.lo = ~0ULL;
-        m.hi = ((x.hi & (0ULL - x.hi)) >> 3) - 1ULL;
-    }
-    return m;
-}
-__device__ __forceinline__ N128 n_mask_through_first(const N128 &x) {
-    N128 m;
-    if (x.lo) {
-        m.lo = x.lo ^ (x.lo - 1ULL);
-        m.hi = 0;
-    } else {
-        m.lo = ~0ULL;
-        m.hi = x.hi ^ (x.hi - 1ULL);
-    }
-    return m;
-}
-__device__ __forceinline__ N128 n_shl(const N128 &x, uint32_t s) { // 0 < s < 128
-    N128 r;
-    if (s < 64) {
-        r.hi = (x.hi << s) | (x.lo >> (64 - s));
-        r.lo = x.lo << s;
-    } else {
-        r.hi = x.lo << (s - 64);
-        r.lo = 0;
-    }
-    return r;
-}
-
-// Dense pass: one wavefront per pair of consecutive 2048-column chunks, each lane owning 32 columns (16 B) of a chunk.
-// The kernel is VALU-issue bound, so everything stays in the nibble domain (no per-column loops, no bit gathers):
-//  * the lane's 32 contig codes come from one unaligned 20-byte window of the nibble-packed contig;
-//  * insertion runs shift the tail of that window (one iteration per run, usually none or one);
-//  * mismatch / insertion / "one of the two previous columns is bad" masks are nibble-flag words (bit 3);
-//  * wave scans and neighbour exchange are DPP operations.
-// It emits raw exception records (read, column, t_pos) straight into the fixed-capacity bucket of their contig tile
-// (TILE positions; a full bucket spills to a shared overflow area) and the per-read checkpoints; the 3-column node keys
-// are built afterwards by the tile sort (np2_graph.hip).
-__device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint32_t np2_nb, const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
-    const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
-    uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
-    uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
-    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    // ---- phase A: load both chunks, count their non-insertion columns and publish the counts at once.  A chunk needs
-    //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
-    //      already running waves, which publish within a microsecond of starting ---------------------------------------
-    __shared__ uint32_t s_total[8]; // counts of the block's 8 chunks (4 waves x 2): most of a read's chunks are in here
-    __shared__ uint32_t s_own[4][64]; // per wave: owner lane of each record rank (emission)
-    const uint32_t blk_first = np2_bid * 8;
-    N128 w_[2], V_[2], I_[2];
-    uint32_t nv_[2], nonins_[2], incl_[2], total_[2];
-#pragma unroll
-    for (uint32_t it = 0; it < 2; ++it) {
-        const uint32_t ch = 2 * pw + it;
-        w_[it] = V_[it] = I_[it] = N128{0, 0};
-        nv_[it] = nonins_[it] = incl_[it] = total_[it] = 0;
-        if (ch >= n_chunks) break;
-        const ChunkDesc d = descs[ch];
-        const uint32_t ncols = d.ncols, c0 = d.c0;
-        const uint32_t lc0 = c0 + lane * 32;
-        const bool full = ncols - c0 >= 2048; // every lane of the wave holds 32 columns
-        const uint32_t nv = full ? 32u : (lc0 < ncols ? min(32u, ncols - lc0) : 0u);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (nv) v = *reinterpret_cast<const uint4 *>(nib + d.nib_off + (lc0 >> 1));
-        N128 w;
-        w.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
-        w.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
-        N128 V{NF3, NF3}; // flags of the valid columns
-        if (!full) {
-            const N128 m = n_below(nv);
-            V.lo &= m.lo;
-            V.hi &= m.hi;
-        }
-        N128 I{w.lo & V.lo, w.hi & V.hi}; // insertion columns
-        if (c0 == 0 && lane == 0) I.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-        const uint32_t nonins = nv - n_popc(I);
-        const uint32_t incl = wave_incl_scan<OpAdd>(nonins);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (lane == 0) {
-            __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_total[ch - blk_first] = total;
-        }
-        w_[it] = w, V_[it] = V, I_[it] = I;
-        nv_[it] = nv, nonins_[it] = nonins, incl_[it] = incl, total_[it] = total;
-    }
-    __syncthreads();
-    // ---- phase B: the chunks, one after the other ----------------------------------------------------------------------
-    uint32_t prev_read = 0xFFFFFFFFu, prev_b3 = 0; // for the second chunk: does it continue the first one?
-    uint32_t prev_carry = 0, prev_total = 0;
-#pragma unroll
-    for (uint32_t it = 0; it < 2; ++it) {
-        const uint32_t ch = 2 * pw + it;
-        if (ch >= n_chunks) break;
-        const ChunkDesc d = descs[ch];
-        const uint8_t *base = nib + d.nib_off; // start of the READ's stream
-        const uint32_t ncols = d.ncols, ts = d.ts, c0 = d.c0;
-        const uint32_t lc0 = c0 + lane * 32;
-        const N128 w = w_[it], V = V_[it], I = I_[it];
-        const uint32_t nv = nv_[it], nonins = nonins_[it], incl = incl_[it], total = total_[it];
-        const N128 codes{w.lo & ~NF3, w.hi & ~NF3};
-        const uint32_t n_ins = nv - nonins;
-        uint32_t carryN = 0; // non-insertion columns of the read before this chunk
-        if (it == 1 && d.read == prev_read && c0 != 0) {
-            carryN = prev_carry + prev_total;
-        } else {
-            bool timeout = false;
-            // earlier chunks of the read inside this block: from LDS; the ones in earlier blocks: from their status words
-            for (uint32_t j = max(d.first_chunk, blk_first); j < ch; ++j) carryN += s_total[j - blk_first];
-            const uint32_t jend = min(ch, blk_first);
-            for (uint32_t j0 = d.first_chunk; j0 < jend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                uint32_t v = 0;
-                if (j < jend) {
-                    uint32_t spins = 0;
-                    for (;;) {
-                        const uint64_t sw = __hip_atomic_load(&chunk_st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)(sw >> 32) == epoch) {
-                            v = (uint32_t)sw;
-                            break;
-                        }
-                        if (++spins > (1u << 22)) {
-                            timeout = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                carryN += v;
-            }
-            if (__ballot(timeout) && lane == 0) atomicOr(err, LB_ERR);
-        }
-        prev_carry = carryN;
-        prev_total = total;
-        const uint32_t t0 = ts + carryN + (incl - nonins); // t_pos of the lane's first non-insertion column
-        // ---- the 32 contig codes starting at t0 ------------------------------------------------------------------
-        N128 R;
-        {
-            // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer;
-            // such a read is reported by the descriptor check at the end of its last chunk)
-            const uint32_t q = min(t0 >> 3, (L >> 3) + 8), sh = (t0 & 7) * 4;
-            const uint32_t r0 = refw32[q], r1 = refw32[q + 1], r2 = refw32[q + 2], r3 = refw32[q + 3], r4 = refw32[q + 4];
-            const uint32_t a0 = __builtin_amdgcn_alignbit(r1, r0, sh), a1 = __builtin_amdgcn_alignbit(r2, r1, sh);
-            const uint32_t a2 = __builtin_amdgcn_alignbit(r3, r2, sh), a3 = __builtin_amdgcn_alignbit(r4, r3, sh);
-            R.lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
-            R.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
-        }
-        // ---- insertion runs push the rest of the window up by their length (one iteration per run) -----------------
-        if (__ballot(n_ins != 0)) {
-            N128 J = I;
-            while (__ballot((J.lo | J.hi) != 0)) {
-                if (J.lo | J.hi) {
-                    const N128 bp = n_mask_before_first(J);                    // columns before the run
-                    const N128 K{~J.lo & NF3 & ~bp.lo, ~J.hi & NF3 & ~bp.hi}; // non-insertion flags at / above it
-                    if (K.lo | K.hi) {
-                        const N128 up = n_shl(N128{R.lo & ~bp.lo, R.hi & ~bp.hi}, n_ctz(K) - n_ctz(J)); // 4 * run length
-                        R.lo = (R.lo & bp.lo) | up.lo;
-                        R.hi = (R.hi & bp.hi) | up.hi;
-                        const N128 bq = n_mask_before_first(K); // columns before the first one past the run
-                        J.lo &= ~bq.lo;
-                        J.hi &= ~bq.hi;
-                    } else { // the run reaches the lane's last column
-                        R.lo &= bp.lo;
-                        R.hi &= bp.hi;
-                        J.lo = J.hi = 0;
-                    }
-                }
-            }
-        }
-        // ---- bad columns: insertion, or code differs from the contig ------------------------------------------------
-        N128 B;
-        B.lo = ((((codes.lo ^ R.lo) & ~NF3) + ~NF3) | I.lo) & V.lo; // nibble != 0  ->  + 7 carries into bit 3
-        B.hi = ((((codes.hi ^ R.hi) & ~NF3) + ~NF3) | I.hi) & V.hi;
-        // ---- checkpoint: column of the reference column at the next multiple of CKPT ----------------------------------
-        {
-            const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
-            const uint32_t nth = tstar - t0; // 0-based index among the lane's non-insertion columns
-            if (nth < nonins) {
-                const N128 NI{~I.lo & V.lo, ~I.hi & V.hi};
-                uint32_t k = nth + 1, col = 0;
-                uint32_t m8;
-                const uint32_t cA = __builtin_popcount((uint32_t)NI.lo), cB = __builtin_popcount((uint32_t)(NI.lo >> 32));
-                const uint32_t cC = __builtin_popcount((uint32_t)NI.hi);
-                if (k <= cA) {
-                    m8 = (uint32_t)NI.lo;
-                } else if (k <= cA + cB) {
-                    k -= cA, col = 8, m8 = (uint32_t)(NI.lo >> 32);
-                } else if (k <= cA + cB + cC) {
-                    k -= cA + cB, col = 16, m8 = (uint32_t)NI.hi;
-                } else {
-                    k -= cA + cB + cC, col = 24, m8 = (uint32_t)(NI.hi >> 32);
-                }
-                uint32_t c = __builtin_popcount(m8 & 0xFFFFu); // k-th flag inside the dword: binary descent
-                if (k > c) k -= c, col += 4, m8 >>= 16;
-                c = __builtin_popcount(m8 & 0xFFu);
-                if (k > c) k -= c, col += 2, m8 >>= 8;
-                c = __builtin_popcount(m8 & 0xFu);
-                if (k > c) col += 1;
-                const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
-                const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                if (idx < d.nck) ckpt[d.ckbase + idx] = lc0 + col;
-            }
-        }
-        // ---- exception columns: a bad column marks itself and the two columns after it (3-column-mers) -------------
-        uint32_t pb; // B flags of the 8 columns before the lane (only the top two matter)
-        {
-            const bool cont = it == 1 && d.read == prev_read && c0 != 0;
-            uint32_t first = cont ? prev_b3 : 0u;
-            if (!cont && c0 > 0 && lane == 0) { // the two columns before the chunk (rare: reads with an odd chunk count)
-                const uint8_t byte = base[(c0 - 2) >> 1];
-                const uint8_t n2 = byte >> 4, n1 = byte & 15;
-                const uint32_t t1 = ts + carryN - 1;
-                const uint32_t t2 = t1 - ((n1 & 8) ? 0u : 1u);
-                const bool b1 = (n1 & 8) || t1 >= L || (n1 & 7) != ref_code(refnib, t1);
-                const bool b2 = (n2 & 8) || t2 >= L || (n2 & 7) != ref_code(refnib, t2);
-                first = (b1 ? 0x80000000u : 0u) | (b2 ? 0x08000000u : 0u);
-            }
-            pb = wave_prev_lane(0u, (uint32_t)(B.hi >> 32));
-            if (lane == 0) pb = first;
-        }
-        N128 E;
-        {
-            const uint32_t b0 = (uint32_t)B.lo, b1 = (uint32_t)(B.lo >> 32), b2 = (uint32_t)B.hi, b3 = (uint32_t)(B.hi >> 32);
-            // x | x << 1 column | x << 2 columns, carrying across dwords (alignbit(hi, lo, s) = {hi, lo} >> s)
-            const uint32_t e0 = b0 | __builtin_amdgcn_alignbit(b0, pb, 28) | __builtin_amdgcn_alignbit(b0, pb, 24);
-            const uint32_t e1 = b1 | __builtin_amdgcn_alignbit(b1, b0, 28) | __builtin_amdgcn_alignbit(b1, b0, 24);
-            const uint32_t e2 = b2 | __builtin_amdgcn_alignbit(b2, b1, 28) | __builtin_amdgcn_alignbit(b2, b1, 24);
-            const uint32_t e3 = b3 | __builtin_amdgcn_alignbit(b3, b2, 28) | __builtin_amdgcn_alignbit(b3, b2, 24);
-            E.lo = (uint64_t)e0 | ((uint64_t)e1 << 32);
-            E.hi = (uint64_t)e2 | ((uint64_t)e3 << 32);
-            if (lc0 == 0 && ts != 0) E.lo |= 0x88ULL; // head sentinels differ from the contig's own (main.rs:579-580)
-            E.lo &= V.lo;
-            E.hi &= V.hi;
-        }
-        prev_read = d.read;
-        prev_b3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(B.hi >> 32), 63);
-        if (__ballot((E.lo | E.hi) != 0)) {
-            // The chunk's columns sit at contig positions [ts + carryN - 1, ts + carryN + 2047]: at most three contig
-            // tiles.  Records are position-ordered across the wave, so the tile boundaries split them into three
-            // consecutive groups; each group reserves its place in its tile's bucket with one wave-level atomic.
-            const N128 NI{~I.lo & V.lo, ~I.hi & V.hi};
-            const uint32_t cnt = n_popc(E);
-            const uint32_t inc2 = wave_incl_scan<OpAdd>(cnt);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
-            const uint32_t s0 = ts + carryN;
-            const uint32_t tA = (s0 ? s0 - 1 : 0u) >> TILE_SHIFT;
-            const uint32_t P1 = (tA + 1) << TILE_SHIFT, P2 = (tA + 2) << TILE_SHIFT;
-            const uint32_t t_last = t0 + nonins - 1;                // t_pos of the lane's last column
-            const uint32_t t_first = t0 - ((I.lo & 8ULL) ? 1u : 0u); // a leading insertion column belongs to t0 - 1
-            auto below = [&](uint32_t P) -> uint32_t { // records of the wave with t_pos < P
-                const uint32_t nb = __builtin_popcountll(__ballot(nv != 0 && t_last < P)); // lanes entirely below: a prefix
-                uint32_t c = nb ? (uint32_t)__builtin_amdgcn_readlane((int)inc2, (int)nb - 1) : 0u;
-                uint32_t part = 0;
-                if (lane == nb && cnt && t_first < P) { // the one lane straddling the boundary
-                    N128 e = E;
-                    while (e.lo | e.hi) {
-                        const N128 m = n_mask_through_first(e);
-                        e.lo &= ~m.lo;
-                        e.hi &= ~m.hi;
-                        if (t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1 < P) ++part; else break;
-                    }
-                }
-                if (nb < 64) c += (uint32_t)__builtin_amdgcn_readlane((int)part, (int)nb);
-                return c;
-            };
-            const uint32_t nb1 = below(P1), nb2 = below(P2);
-            uint32_t rb = 0; // lane j < 3: reservation of group j in bucket tA + j
-            if (lane < 3) {
-                const uint32_t cj = lane == 0 ? nb1 : (lane == 1 ? nb2 - nb1 : tot - nb2);
-                if (cj) {
-                    if (tA + lane < n_tiles) rb = atomicAdd(&tile_cur[tA + lane], cj);
-                    else rb = 0xFFFFFFFFu - cj; // position >= L: the descriptor check below reports the read
-                }
-            }
-            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 1);
-            const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)rb, 2);
-            // Raw records (t_pos << 32 | column, read), one LANE per record: the chunk's ~36 records sit in a dozen lanes, so
-            // a per-lane loop runs at the pace of the busiest lane with most of the wave idle.  Record rank R finds its
-            // owner lane through a head table in LDS (owner id at its first rank, running maximum across the wave), pulls
-            // the owner's masks with shuffles and selects its (R - first rank)-th exception column.
-            const uint32_t o_first = inc2 - cnt; // rank of the lane's first record within the wave
-            // (volatile: other lanes of the wave write the entry a lane reads back; LDS operations of one wave execute in
-            // program order, the compiler must not forward the lane's own zero)
-            volatile uint32_t *own_tab = s_own[threadIdx.x >> 6];
-            for (uint32_t rbase = 0; rbase < tot; rbase += 64) {
-                own_tab[lane] = 0;
-                if (cnt && o_first < rbase + 64 && o_first + cnt > rbase) own_tab[max(o_first, rbase) - rbase] = lane + 1;
-                const uint32_t own1 = wave_incl_scan<OpMaxU32>(own_tab[lane]);
-                const uint32_t R = rbase + lane;
-                const bool act = R < tot;
-                const uint32_t own = (act && own1) ? own1 - 1 : lane;
-                const uint32_t e0 = __shfl((uint32_t)E.lo, own), e1 = __shfl((uint32_t)(E.lo >> 32), own);
-                const uint32_t e2 = __shfl((uint32_t)E.hi, own), e3 = __shfl((uint32_t)(E.hi >> 32), own);
-                const uint32_t i0 = __shfl((uint32_t)NI.lo, own), i1 = __shfl((uint32_t)(NI.lo >> 32), own);
-                const uint32_t i2 = __shfl((uint32_t)NI.hi, own), i3 = __shfl((uint32_t)(NI.hi >> 32), own);
-                const uint32_t ot0 = __shfl(t0, own), oo = __shfl(o_first, own);
-                if (act) {
-                    // column of the (R - oo)-th flag of the owner's exception mask (flags at bit 3 of the nibbles)
-                    uint32_t k = R - oo + 1, col = 0, m8;
-                    const uint32_t cA = __builtin_popcount(e0), cB = __builtin_popcount(e1), cC = __builtin_popcount(e2);
-                    if (k <= cA) {
-                        m8 = e0;
-                    } else if (k <= cA + cB) {
-                        k -= cA, col = 8, m8 = e1;
-                    } else if (k <= cA + cB + cC) {
-                        k -= cA + cB, col = 16, m8 = e2;
-                    } else {
-                        k -= cA + cB + cC, col = 24, m8 = e3;
-                    }
-                    uint32_t c = __builtin_popcount(m8 & 0xFFFFu);
-                    if (k > c) k -= c, col += 4, m8 >>= 16;
-                    c = __builtin_popcount(m8 & 0xFFu);
-                    if (k > c) k -= c, col += 2, m8 >>= 8;
-                    c = __builtin_popcount(m8 & 0xFu);
-                    if (k > c) col += 1;
-                    const N128 thr = n_below(col + 1); // columns 0 .. col of the owner lane
-                    const N128 oNI{(uint64_t)i0 | ((uint64_t)i1 << 32), (uint64_t)i2 | ((uint64_t)i3 << 32)};
-                    const uint32_t t = ot0 + n_popc(N128{oNI.lo & thr.lo, oNI.hi & thr.hi}) - 1; // non-insertion columns up to it
-                    const uint32_t g = (t >= P1 ? 1u : 0u) + (t >= P2 ? 1u : 0u);
-                    const uint32_t slot = (g == 0 ? g0 + R : (g == 1 ? g1 + (R - nb1) : g2 + (R - nb2)));
-                    uint64_t dst;
-                    bool ok = tA + g < n_tiles;
-                    if (slot < bucket_cap) {
-                        dst = (uint64_t)(tA + g) * bucket_cap + slot;
-                    } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
-                        const uint32_t x = atomicAdd(ovf_cnt, 1u);
-                        dst = ovf_base + x;
-                        ok = ok && x < ovf_cap;
-                    }
-                    if (ok) {
-                        out_keys[dst] = ((uint64_t)t << 32) | (c0 + own * 32 + col);
-                        out_vals[dst] = d.read;
-                    }
-                }
-            }
-        }
-        if (lane == 0 && c0 + 2048 >= ncols) {
-            // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
-            if (ncols == 0 || ts + carryN + total - 1 != d.aln_t_e || d.aln_t_e >= L) atomicOr(err, 2u);
-            if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
-        }
-    }
 }
 
 // gather up to four device-resident counters into scalar slots, then post the whole scalar block to host-mapped memory
@@ -1816,13 +1440,6 @@ static inline dim3 grid1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes,
                        uint32_t *err) {
     NP2_LAUNCH(k_encode_ref, grid1(nbytes), 256, s, read0, L, refnib, nbytes, err);
-}
-void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
-                       const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
-                       uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
-                       uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err) {
-    if (n_chunks)
-        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + 7) / 8), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err);
 }
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
                  const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,

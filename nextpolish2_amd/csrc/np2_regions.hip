@@ -314,26 +314,49 @@ __device__ __forceinline__ void k_edges_row(const uint32_t np2_bid, const uint32
     uint32_t far = 0;
     const uint32_t n_span = (a != 0 && alive[a]) ? pcount[a] : 0u; // (the contig itself never enters a pair: main.rs:972-980)
     const uint32_t j0 = n_span ? pj[a] : 0u;
+    // The walk over the read's HETE regions is a chain of dependent loads per region (candidate range -> read ids, groups,
+    // k-scores): the candidate ranges of 64 regions are fetched at once (one coalesced load per lane), and two regions
+    // of at most 32 candidates each (the usual case at 30x) share an iteration, one per half of the wave.
+    const uint32_t hl = lane & 31, hsel = lane >> 5;
     for (uint32_t base = 0; base < n_span; base += 64) {
         const uint32_t gl = j0 + base + lane;
-        uint64_t het = __ballot(base + lane < n_span && gl < rt.n_reg && ecount[gl] != 0);
+        const bool in = base + lane < n_span && gl < rt.n_reg;
+        const uint32_t c0l = in ? rt.cand_off[gl] : 0u, c1l = in ? rt.cand_off[gl + 1] : 0u;
+        uint64_t het = __ballot(in && ecount[gl] != 0);
         while (het) {
-            const uint32_t g = j0 + base + (uint32_t)__builtin_ctzll(het); // (uniform)
+            const uint32_t i0 = (uint32_t)__builtin_ctzll(het); // (uniform)
             het &= het - 1;
-            const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
+            const uint32_t c0a = (uint32_t)__builtin_amdgcn_readlane((int)c0l, (int)i0);
+            const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)c1l, (int)i0) - c0a;
+            uint32_t c0b = 0, nb = 0;
+            bool two = false;
+            if (het && na <= 32) {
+                const uint32_t i1 = (uint32_t)__builtin_ctzll(het);
+                c0b = (uint32_t)__builtin_amdgcn_readlane((int)c0l, (int)i1);
+                nb = (uint32_t)__builtin_amdgcn_readlane((int)c1l, (int)i1) - c0b;
+                two = nb <= 32;
+                if (two) het &= het - 1;
+            }
+            // this lane's candidate: region a over the whole wave, or region a / b in the lower / upper half
+            const uint32_t li = two ? hl : lane;
+            const uint32_t c0 = (two && hsel) ? c0b : c0a, n = (two && hsel) ? nb : na;
             uint32_t order = 0xFFFFFFFFu, gi = 0;
             bool v = false;
-            if (lane < n) {
-                order = rt.order[c0 + lane];
-                gi = grp[c0 + lane];
-                v = rt.kscore[c0 + lane] > 0;
+            if (li < n) {
+                order = rt.order[c0 + li];
+                gi = grp[c0 + li];
+                v = rt.kscore[c0 + li] > 0;
             }
             uint64_t V = __ballot(v);
+            // the contig's own candidate (read 0, always first) takes no part in the pairs (main.rs:972-980)
             if ((V & 1ull) && __shfl(order, 0) == 0) V &= ~1ull;
+            if (two && ((V >> 32) & 1ull) && __shfl(order, 32) == 0) V &= ~(1ull << 32);
             const uint64_t me = __ballot(order == a) & V;
-            if (!me) continue; // a is not a (valid) candidate of this region
-            const uint32_t ga = __shfl(gi, (int)__builtin_ctzll(me));
-            if (((V >> lane) & 1ull) && order > a) {
+            const uint64_t half_mask = two ? (hsel ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull) : ~0ull;
+            const uint64_t mine = me & half_mask;
+            if (!me) continue; // a is not a (valid) candidate of these regions
+            const uint32_t ga = __shfl(gi, mine ? (int)__builtin_ctzll(mine) : 0);
+            if (mine && ((V >> lane) & 1ull) && order > a) {
                 const uint32_t d = order - a - 1;
                 if (d < EDGE_BAND)
                     atomicAdd(&row[d], gi == ga ? 1u : 0x10000u);
