@@ -218,6 +218,28 @@ int np2_shard_apply(np2_shard_run_t *run, const uint32_t *losers, uint32_t n_los
 int np2_shard_final(np2_shard_run_t *run, uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
 void np2_shard_end(np2_shard_run_t *run);
 
+/* The same final pass with the polished sub-contig left ON THE DEVICE.  The consensus is ordered by position, so what a
+ * shard owns — the bases emitted by positions [own_lo, own_hi) — is one contiguous slice of it: nothing is filtered, a
+ * few searches find the slice, and the stitched contig is the shards' slices end to end.  Neighbours are checked against
+ * each other on two short strips only (positions within `verify` of a cut, bases + contig positions, host memory from
+ * the pinned pool: np2_free): the high strip of shard k must equal the low strip of shard k + 1 base for base.
+ * np2_shard_fetch copies the owned slice to host memory the caller provides — for multi-megabase slices memory from
+ * np2_alloc_pinned (any offset inside such a block: the shards of one process fetch straight into their places of ONE
+ * buffer) — or the slice is gathered from dev_bases by a collective (dist.py: RCCL over xGMI).  dev_bases / dev_pos stay
+ * valid until the next call on the run's context; dev_pos holds SUB-CONTIG positions (add plan.sub_lo). */
+typedef struct np2_shard_piece {
+    uint64_t own_len;            /* bases of the owned interval */
+    const uint8_t *dev_bases;    /* device address of the first of them */
+    const uint32_t *dev_pos;     /* ... and of its position (sub-contig coordinates) */
+    uint32_t first_pos, last_pos; /* contig positions of the first / last owned base (own_len > 0) */
+    uint32_t lo_len, hi_len;     /* strips: bases at positions [own_lo - verify, own_lo + verify) / [own_hi - verify, own_hi + verify) */
+    uint8_t *lo_bases, *hi_bases;
+    uint32_t *lo_pos, *hi_pos;   /* contig coordinates */
+} np2_shard_piece_t;
+int np2_shard_final_device(np2_shard_run_t *run, np2_shard_piece_t *out);
+int np2_shard_fetch(np2_shard_run_t *run, uint8_t *dst_bases, uint32_t *dst_pos /* NULL: bases only; contig coordinates */);
+void *np2_alloc_pinned(uint64_t bytes); /* page-locked host memory from the result pool; np2_free releases it */
+
 /* Host-only test hook: key iteration order of the SwissTable order model behind np2_phase_vote after a script of
  * operations (0 insert, 1 remove, 2 entry().or_insert) — pinned by hand-traced vectors in tests/test_swiss_vectors.py. */
 int np2_swiss_order(const uint32_t *ops, const uint32_t *keys, uint32_t n, uint32_t *out, uint32_t *n_out);

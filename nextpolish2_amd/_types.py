@@ -55,6 +55,13 @@ class np2_vote_t(C.Structure):
                 ("read_id", C.c_void_p), ("first_pos", C.c_void_p), ("ref_w", C.c_void_p), ("flags", C.c_void_p)]
 
 
+class np2_shard_piece_t(C.Structure):
+    # include/np2.h: the device-resident result of one shard's final pass (owned slice + the two verification strips)
+    _fields_ = [("own_len", C.c_uint64), ("dev_bases", C.c_void_p), ("dev_pos", C.c_void_p), ("first_pos", C.c_uint32),
+                ("last_pos", C.c_uint32), ("lo_len", C.c_uint32), ("hi_len", C.c_uint32), ("lo_bases", C.c_void_p),
+                ("hi_bases", C.c_void_p), ("lo_pos", C.c_void_p), ("hi_pos", C.c_void_p)]
+
+
 class Opts:
     """Defaults of the reference CLI (src/utils/option.rs:267-292)."""
 

@@ -9,7 +9,8 @@ import weakref
 
 import numpy as np
 
-from ._types import Opts, Pileup, np2_opts_t, np2_read_t, np2_shard_plan_t, np2_vote_t, np2_yak_t, yaks_array
+from ._types import (Opts, Pileup, np2_opts_t, np2_read_t, np2_shard_piece_t, np2_shard_plan_t, np2_vote_t, np2_yak_t,
+                     yaks_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NP2_LIB_PATH") or os.path.join(_HERE, "libnp2_hip.so")  # override: A/B builds
@@ -23,6 +24,7 @@ ABI_SYMBOLS = [
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
+    "np2_shard_final_device", "np2_shard_fetch", "np2_alloc_pinned",
     "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_set_priority", "np2_batch_last_diff_ms", "np2_batch_stats",
 ]
 
@@ -100,6 +102,10 @@ def lib():
         L.np2_vote_decide.argtypes = [C.POINTER(np2_vote_t), C.c_int, u32, C.POINTER(np2_opts_t), vp, C.POINTER(u32)]
         L.np2_shard_apply.argtypes = [vp, vp, u32]
         L.np2_shard_final.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.np2_shard_final_device.argtypes = [vp, C.POINTER(np2_shard_piece_t)]
+        L.np2_shard_fetch.argtypes = [vp, vp, vp]
+        L.np2_alloc_pinned.argtypes = [u64]
+        L.np2_alloc_pinned.restype = vp
         L.np2_shard_end.argtypes = [vp]
         L.np2_shard_end.restype = None
         L.np2_swiss_order.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
@@ -427,7 +433,30 @@ class Vote:
         return np2_vote_t(len(self.pair_key), self.pair_key.ctypes.data, self.pair_cnt.ctypes.data, len(self.read_id),
                           self.read_id.ctypes.data, self.first_pos.ctypes.data, self.ref_w.ctypes.data, self.flags.ctypes.data)
 
+    def pack(self):
+        """One uint8 array: [n_pairs, n_reads] + the fields, each padded to 8 bytes (the exchange between ranks)."""
+        parts = [np.array([len(self.pair_key), len(self.read_id)], dtype=np.uint64).view(np.uint8)]
+        for name, _ in self.FIELDS:
+            a = getattr(self, name).view(np.uint8)
+            parts.append(a)
+            if a.shape[0] & 7:
+                parts.append(np.zeros(8 - (a.shape[0] & 7), dtype=np.uint8))
+        return np.concatenate(parts)
+
+    @classmethod
+    def unpack(cls, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        n_pairs, n_reads = (int(x) for x in raw[:16].view(np.uint64))
+        off, out = 16, {}
+        for name, dt in cls.FIELDS:
+            n = n_pairs if name.startswith("pair") else n_reads
+            nb = n * np.dtype(dt).itemsize
+            out[name] = raw[off:off + nb].view(dt)
+            off += (nb + 7) & ~7
+        return cls(**out)
+
     def to_bytes(self):
+        """Unpadded byte-string form (the one the recorded shard fixtures under tests/golden hold)."""
         hdr = np.array([len(self.pair_key), len(self.read_id)], dtype=np.uint64).tobytes()
         return hdr + b"".join(getattr(self, n).tobytes() for n, _ in self.FIELDS)
 
@@ -495,6 +524,17 @@ class ShardRun:
         self._pol._check(lib().np2_shard_final(self._r, C.byref(ob), C.byref(op), C.byref(on)))
         return _owned(ob, on.value, C.c_uint8), _owned(op, on.value, C.c_uint32)
 
+    def final_device(self):
+        """The final pass with the polished sub-contig left on the device -> ShardPiece (owned slice: device address +
+        length; verification strips on the host)."""
+        pc = np2_shard_piece_t()
+        self._pol._check(lib().np2_shard_final_device(self._r, C.byref(pc)))
+        return ShardPiece(pc)
+
+    def fetch(self, dst_bases, dst_pos=None):
+        """Copy the owned slice of the last final_device() into host arrays (slices of a pinned_array for long ones)."""
+        self._pol._check(lib().np2_shard_fetch(self._r, dst_bases.ctypes.data, dst_pos.ctypes.data if dst_pos is not None else None))
+
     def close(self):
         if getattr(self, "_r", None):
             lib().np2_shard_end(self._r)
@@ -508,6 +548,51 @@ class ShardRun:
             self.close()
         except Exception:
             pass
+
+
+class ShardPiece:
+    """Host view of np2_shard_piece_t: the owned slice stays on the device (dev_bases / dev_pos, own_len), the two strips
+    around the cuts are numpy arrays (contig coordinates) freed with the object."""
+
+    def __init__(self, pc: np2_shard_piece_t):
+        self.own_len = int(pc.own_len)
+        self.dev_bases, self.dev_pos = pc.dev_bases, pc.dev_pos
+        self.first_pos, self.last_pos = int(pc.first_pos), int(pc.last_pos)
+
+        def take(ptr, n, ct, dt):
+            if not n or not ptr:
+                return np.zeros(0, dtype=dt)
+            return _owned(C.c_void_p(ptr), n, ct)
+        self.lo_bases, self.lo_pos = take(pc.lo_bases, pc.lo_len, C.c_uint8, np.uint8), take(pc.lo_pos, pc.lo_len, C.c_uint32, np.uint32)
+        self.hi_bases, self.hi_pos = take(pc.hi_bases, pc.hi_len, C.c_uint8, np.uint8), take(pc.hi_pos, pc.hi_len, C.c_uint32, np.uint32)
+
+    def strips(self):
+        """(lo_bases, lo_pos, hi_bases, hi_pos) as one uint8 array (exchange between ranks) — see unpack_strips."""
+        hdr = np.array([self.own_len, self.first_pos, self.last_pos, len(self.lo_bases), len(self.hi_bases)], dtype=np.uint64)
+        return np.concatenate([hdr.view(np.uint8), self.lo_pos.view(np.uint8), self.hi_pos.view(np.uint8), self.lo_bases, self.hi_bases])
+
+    @staticmethod
+    def unpack_strips(raw):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        own_len, first, last, nl, nh = (int(x) for x in raw[:40].view(np.uint64))
+        o = 40
+        lo_pos = raw[o:o + 4 * nl].view(np.uint32); o += 4 * nl
+        hi_pos = raw[o:o + 4 * nh].view(np.uint32); o += 4 * nh
+        lo_b = raw[o:o + nl]; o += nl
+        hi_b = raw[o:o + nh]
+        return {"own_len": own_len, "first_pos": first, "last_pos": last, "lo_bases": lo_b, "lo_pos": lo_pos,
+                "hi_bases": hi_b, "hi_pos": hi_pos}
+
+
+def pinned_array(n, dtype=np.uint8):
+    """A page-locked host array from the library's result pool (np2_alloc_pinned): large device-to-host copies into
+    pageable memory stall on lazy pinning."""
+    dt = np.dtype(dtype)
+    p = lib().np2_alloc_pinned(max(1, int(n)) * dt.itemsize)
+    if not p:  # (no device in this process, e.g. the CPU-only replay tests: plain memory does the same job, slower)
+        return np.empty(int(n), dtype=dt)
+    ct = {1: C.c_uint8, 4: C.c_uint32, 8: C.c_uint64}[dt.itemsize]
+    return _owned(C.c_void_p(p), int(n), ct).view(dt)
 
 
 def fasta_record(name, bases, pos):

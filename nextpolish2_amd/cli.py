@@ -86,6 +86,40 @@ def _record(a, name, b, first, last, pos=None):
     return b">%s start:%d end:%d\n%s\n" % (name.encode(), first, last, b)
 
 
+def _init_distributed(a):
+    """torch.distributed process group of a torchrun launch, then the one decision that is rank 0's alone — may the
+    output file be written (option.rs:312-316) — shared with every rank.  Returns rank 0's output stream (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    from .dist import all_gather_arrays
+    rank = int(os.environ["RANK"])
+    backend = a.dist_backend or "nccl"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dev_idx = a.device % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_idx)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
+        xdev = torch.device("cuda", dev_idx)
+    else:
+        dist.init_process_group(backend=backend)
+        xdev = torch.device("cpu")
+    out, verdict = None, b""
+    if rank == 0:
+        out = sys.stdout.buffer
+        if a.out is not None and a.out != "stdout":
+            path = os.path.abspath(a.out)
+            if os.path.exists(path):
+                verdict = f"Error: {path!r} already exists!".encode()
+            else:
+                out = open(path, "wb")
+    got = all_gather_arrays(np.frombuffer(verdict, dtype=np.uint8), device=xdev)
+    if len(got[0]):
+        dist.destroy_process_group()
+        raise SystemExit(got[0].tobytes().decode())
+    return out
+
+
 def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
     """One process per GPU (torchrun): the assembly is polished by all ranks and written by rank 0 in input order.
 
@@ -99,37 +133,38 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
     from .dist import ShardMismatch, all_gather_sequences, assign_contigs, polish_sharded_bam
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = a.dist_backend or "nccl"
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    n_gpu = torch.cuda.device_count()
-    dev_idx = a.device % max(1, n_gpu)
-    if backend == "nccl":
-        torch.cuda.set_device(dev_idx)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
-        xdev = torch.device("cuda", dev_idx)
-    else:
-        dist.init_process_group(backend=backend)
-        xdev = torch.device("cpu")
+    dev_idx = a.device % max(1, torch.cuda.device_count())
+    xdev = torch.device("cuda", dev_idx) if backend == "nccl" else torch.device("cpu")  # (group: _init_distributed)
     pol = Polisher(yaks, device=dev_idx)
     bam = np2io.Bam(a.bam)
     contigs = list(np2io.read_fasta(a.fa))  # every rank reads the assembly (cheap next to the BAM)
     records = {}
+    for name, seq in contigs:  # main.rs:1707-1711, for every contig whichever way it is polished
+        if len(seq) >= 0xFFFFFFFF:
+            raise SystemExit(f"{name} is too long!")
     long_ones = [i for i, (_, seq) in enumerate(contigs) if len(seq) >= max(a.min_ctg_len, a.shard_min_len)]
     whole = [i for i, (_, seq) in enumerate(contigs) if len(seq) >= a.min_ctg_len and i not in set(long_ones)]
     # 1. long contigs: one reference interval per rank
     for i in long_ones:
         name, seq = contigs[i]
-        if len(seq) >= 0xFFFFFFFF:
-            raise SystemExit(f"{name} is too long!")
-        try:  # every rank parses only the BAM records overlapping its interval +- halo
-            b, p = polish_sharded_bam(pol, bam, name, seq, opts, fopts, halo=a.shard_halo, device=xdev)
-        except ShardMismatch:  # (raised on every rank alike: the pieces are all-gathered before the check) -> unsharded
-            c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
-            try:
-                b, p = pol.polish_resident(c, opts)
-            finally:
-                c.free()
+        try:  # every rank parses only the BAM records overlapping its interval +- halo; the pieces meet on rank 0
+            b, p, span = polish_sharded_bam(pol, bam, name, seq, opts, fopts, halo=a.shard_halo, device=xdev,
+                                            want_pos=a.out_pos, dst=0, with_span=True)
+        except ShardMismatch as e:
+            # raised on every rank alike (every exchange carries the ranks' status; the strips around the cuts are seen by
+            # all): the shards disagree, a splice cursor got stuck inside one (NP2_E_UNSUPPORTED), or one failed for a
+            # reason of its own -> rank 0 polishes the contig unsharded (and reports a genuine error itself)
+            print(f"[WARN] {name}: {e}; polishing it unsharded", file=sys.stderr)
+            b = None
+            if rank == 0:
+                c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+                try:
+                    b, p = pol.polish_resident(c, opts, want_pos=a.out_pos)
+                    span = (int(p[0]), int(p[-1])) if a.out_pos else (p[0], p[1])
+                finally:
+                    c.free()
         if rank == 0:
-            records[i] = _record(a, name, np.asarray(b).tobytes(), int(p[0]), int(p[-1]), p)
+            records[i] = _record(a, name, np.asarray(b).tobytes(), int(span[0]), int(span[1]), p if a.out_pos else None)
     # 2. the other contigs: whole, one rank each, longest first
     mine = assign_contigs([len(contigs[i][1]) for i in whole], world)[rank]
     local = []
@@ -168,14 +203,21 @@ def main(argv=None):
     if a.model.lower() not in ("ref", "len"):
         raise SystemExit("error: invalid value for --model (ref|len)")
     out = sys.stdout.buffer
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("RANK", "0") != "0":
-        out = None  # under torchrun only rank 0 writes
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
+    if distributed:
+        # under torchrun only rank 0 writes, and whether it may is settled together (a rank that left on its own before
+        # the process group exists would leave the others waiting for it): _main_distributed opens the file
+        out = None
     elif a.out is not None and a.out != "stdout":  # option.rs:76-79: the literal default "stdout" means stdout
         path = os.path.abspath(a.out)
         if os.path.exists(path):  # option.rs:312-316: refuse to overwrite
             raise SystemExit(f"Error: {path!r} already exists!")
         out = open(path, "wb")
     prof = os.environ.get("NP2_CLI_PROFILE")
+    if a.device is None:
+        a.device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
+    if distributed:
+        out = _init_distributed(a)  # process group first; the output-file verdict is rank 0's, shared with everyone
     t_y = time.time()
     yaks = sorted((np2io.load_yak(y) for y in a.yak), key=lambda y: y.k)  # option.rs:238
     if prof:
@@ -191,10 +233,7 @@ def main(argv=None):
     n_workers = max(1, min(4, a.thread))
     tls = threading.local()
     base, base_lock = [], threading.Lock()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.device is None:
-        a.device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
-    if world > 1 and "RANK" in os.environ:
+    if distributed:
         return _main_distributed(a, argv, t0, out, yaks, opts, fopts)
 
     def polish(name, seq):

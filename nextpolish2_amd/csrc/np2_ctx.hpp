@@ -192,6 +192,8 @@ struct np2_ctx {
     uint32_t mbox_seq = 0;
     uint32_t last_first_pos = 0, last_last_pos = 0;
     const uint8_t *last_dbase = nullptr; // device copy of the last polished sequence (valid until the next call)
+    const uint32_t *last_dpos = nullptr; // ... and of its positions
+    DevBuf<uint32_t> shard_bounds;       // np2_shard_final_device: slice / strip indices
     uint64_t last_len = 0;
     bool reuse_identical_pass = true;
     bool h2d_inflight = false; // pin_h2d holds data of a copy that may not have completed yet

@@ -869,6 +869,7 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     cx->last_first_pos = sc[S_M1];
     cx->last_last_pos = sc[S_M2];
     cx->last_dbase = dbase;
+    cx->last_dpos = dpos;
     cx->last_len = M;
     if (cx->stage_timing) cx->timing.host.push_back({"wall_fetch_result", (float)(now_ms() - t0)});
 }
@@ -893,6 +894,7 @@ void run_begin(PolishRun &r) {
     HIPCHK(hipSetDevice(cx->device));
     cx->trace_items.clear();
     cx->last_dbase = nullptr;
+    cx->last_dpos = nullptr;
     cx->scal.ensure(SCAL_TOTAL);
     cx->alive.ensure(r.c->R + 2);
     {
@@ -1043,8 +1045,29 @@ struct ShardRun {
     std::vector<uint32_t> v_cnt, v_read, v_first;
     std::vector<int32_t> v_refw;
     std::vector<uint8_t> v_flags;
+    // np2_shard_final_device: the owned slice of the device-resident result
+    uint64_t own_off = 0, own_len = 0;
+    bool have_piece = false;
 };
 inline uint32_t shard_global_read(const np2_shard_plan_t &pl, uint32_t local) { return local == 0 ? 0u : pl.read_lo + local - 1; }
+
+// A splice cursor that got stuck (update_consensus_with_lqseqs, main.rs:1036-1056) leaves every region to its right
+// untouched — contig-wide: a shard cannot reproduce that on its own, whichever shard sees it (the first one included:
+// the shards to its right would go on splicing).  Only a region stuck beyond the right end of the zone is harmless:
+// coverage is partial there (an artefact of the cut) and everything it freezes lies outside of what this shard emits.
+void shard_check_stuck(ShardRun *sr) {
+    np2_ctx *cx = sr->run.cx;
+    const np2_shard_plan_t &pl = sr->plan;
+    if (!sr->run.n_reg) return;
+    std::vector<uint32_t> rounds = d2h(cx, cx->scal.p + S_COUNT, 2 * (cx->yaks.size() + 1));
+    uint32_t worst = 0; // highest region index + 1 = the leftmost stuck region over all rounds
+    for (size_t v = 0; v < rounds.size(); v += 2) worst = std::max(worst, rounds[v]);
+    if (!worst) return;
+    if (worst > sr->run.n_reg) throw Np2Error(NP2_E_DEVICE, "internal: stuck region index out of range");
+    const uint32_t at = d2h(cx, cx->lq_start.p + (worst - 1), 1)[0];
+    if ((uint64_t)at + pl.sub_lo < pl.zone_hi)
+        throw Np2Error(NP2_E_UNSUPPORTED, "splice cursor stuck inside a shard: polish this contig unsharded");
+}
 
 } // namespace
 
@@ -1780,22 +1803,7 @@ int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos,
     NP2_SHARD_TRY(cx, {
         run_final_pass(sr->run, r);
         const np2_shard_plan_t &pl = sr->plan;
-        // a splice cursor that got stuck (update_consensus_with_lqseqs, main.rs:1036-1056) leaves every region to its
-        // right untouched — contig-wide: a shard cannot reproduce that on its own, whichever shard sees it (the first one
-        // included: the shards to its right would go on splicing).  Only a region stuck beyond the right end of the zone
-        // is harmless: coverage is partial there (an artefact of the cut) and everything it freezes lies outside of what
-        // this shard emits.
-        if (sr->run.n_reg) {
-            std::vector<uint32_t> rounds = d2h(cx, cx->scal.p + S_COUNT, 2 * (cx->yaks.size() + 1));
-            uint32_t worst = 0; // highest region index + 1 = the leftmost stuck region over all rounds
-            for (size_t v = 0; v < rounds.size(); v += 2) worst = std::max(worst, rounds[v]);
-            if (worst) {
-                if (worst > sr->run.n_reg) throw Np2Error(NP2_E_DEVICE, "internal: stuck region index out of range");
-                const uint32_t at = d2h(cx, cx->lq_start.p + (worst - 1), 1)[0];
-                if ((uint64_t)at + pl.sub_lo < pl.zone_hi)
-                    throw Np2Error(NP2_E_UNSUPPORTED, "splice cursor stuck inside a shard: polish this contig unsharded");
-            }
-        }
+        shard_check_stuck(sr);
         // keep the owned interval (+ the verification margin), in contig coordinates
         const uint32_t lo = pl.own_lo > sr->verify ? pl.own_lo - sr->verify : 0u;
         const uint64_t hi = (uint64_t)pl.own_hi + sr->verify;
@@ -1813,6 +1821,94 @@ int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos,
     *out_bases = r.bases;
     *out_pos = r.pos;
     *out_len = r.len;
+    return NP2_OK;
+}
+
+void *np2_alloc_pinned(uint64_t bytes) { return pinned_pool().get((size_t)bytes + 1); }
+
+int np2_shard_final_device(np2_shard_run_t *h, np2_shard_piece_t *out) {
+    ShardRun *sr = (ShardRun *)h;
+    if (!sr || !out || !sr->run.final_pass()) return NP2_E_ARG;
+    np2_ctx *cx = sr->run.cx;
+    memset(out, 0, sizeof *out);
+    void *blocks[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct PutBack {
+        void **b;
+        bool keep = false;
+        ~PutBack() {
+            if (!keep)
+                for (int i = 0; i < 4; ++i)
+                    if (b[i]) pinned_pool().put(b[i]);
+        }
+    } guard{blocks};
+    NP2_SHARD_TRY(cx, {
+        ResultOut r;
+        r.want_bases = false, r.want_pos = false; // the polished sub-contig stays on the device
+        run_final_pass(sr->run, r);
+        shard_check_stuck(sr);
+        const np2_shard_plan_t &pl = sr->plan;
+        const uint32_t v = sr->verify;
+        // positions in sub-contig coordinates; the consensus is ordered by position
+        auto sub = [&](uint64_t p) -> uint32_t { return p <= pl.sub_lo ? 0u : (uint32_t)std::min<uint64_t>(p - pl.sub_lo, 0xFFFFFFFFull); };
+        const uint32_t t[6] = {sub(pl.own_lo > v ? pl.own_lo - v : 0u), sub(pl.own_lo), sub((uint64_t)pl.own_lo + v),
+                               sub(pl.own_hi > v ? pl.own_hi - v : 0u), sub(pl.own_hi), sub((uint64_t)pl.own_hi + v)};
+        cx->shard_bounds.ensure(8);
+        const uint32_t *M_p = cx->mlen.p; // (a device copy of the final length: any buffer holding it will do)
+        {
+            // the final length is known on the host (fetch_result read it back): stage it next to the bounds
+            const uint32_t Mh = (uint32_t)cx->last_len;
+            cx->mlen.ensure(32);
+            h2d_staged(cx, cx->mlen.p + 31, &Mh, 4);
+            M_p = cx->mlen.p + 31;
+        }
+        launch_shard_bounds(cx->stream, cx->last_dpos, M_p, t, cx->shard_bounds.p);
+        const std::vector<uint32_t> b = d2h(cx, cx->shard_bounds.p, 8);
+        sr->own_off = b[1];
+        sr->own_len = b[4] - b[1];
+        sr->have_piece = true;
+        out->own_len = sr->own_len;
+        out->dev_bases = cx->last_dbase + b[1];
+        out->dev_pos = cx->last_dpos + b[1];
+        out->first_pos = b[6] + pl.sub_lo;
+        out->last_pos = b[7] + pl.sub_lo;
+        out->lo_len = b[2] - b[0];
+        out->hi_len = b[5] - b[3];
+        auto strip = [&](uint32_t i0, uint32_t n, uint8_t *&hb, uint32_t *&hp, int slot) {
+            if (!n) return;
+            hb = (uint8_t *)(blocks[slot] = pinned_pool().get((size_t)n + 1));
+            hp = (uint32_t *)(blocks[slot + 1] = pinned_pool().get(((size_t)n + 1) * 4));
+            if (!hb || !hp) throw Np2Error(NP2_E_NOMEM, "pinned strip allocation failed");
+            op_d2h(cx, hb, cx->last_dbase + i0, n);
+            op_d2h(cx, hp, cx->last_dpos + i0, (size_t)n * 4);
+        };
+        strip(b[0], out->lo_len, out->lo_bases, out->lo_pos, 0);
+        strip(b[3], out->hi_len, out->hi_bases, out->hi_pos, 2);
+        op_sync(cx);
+        for (uint32_t i = 0; i < out->lo_len; ++i) out->lo_pos[i] += pl.sub_lo;
+        for (uint32_t i = 0; i < out->hi_len; ++i) out->hi_pos[i] += pl.sub_lo;
+    })
+    guard.keep = true;
+    return NP2_OK;
+}
+
+int np2_shard_fetch(np2_shard_run_t *h, uint8_t *dst_bases, uint32_t *dst_pos) {
+    ShardRun *sr = (ShardRun *)h;
+    if (!sr || !dst_bases || !sr->have_piece) return NP2_E_ARG;
+    np2_ctx *cx = sr->run.cx;
+    NP2_SHARD_TRY(cx, {
+        HIPCHK(hipSetDevice(cx->device));
+        if (!cx->last_dbase) throw Np2Error(NP2_E_ARG, "the shard's device result is gone (another call used its context)");
+        if (sr->own_len) {
+            op_d2h(cx, dst_bases, cx->last_dbase + sr->own_off, sr->own_len);
+            if (dst_pos) op_d2h(cx, dst_pos, cx->last_dpos + sr->own_off, sr->own_len * 4);
+            op_sync(cx);
+            if (dst_pos) {
+                const uint32_t add = sr->plan.sub_lo;
+                if (add)
+                    for (uint64_t i = 0; i < sr->own_len; ++i) dst_pos[i] += add;
+            }
+        }
+    })
     return NP2_OK;
 }
 }

@@ -245,6 +245,9 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                          const int32_t *ap_shift_incl, const uint32_t *n_ap, uint32_t max_ap, const uint32_t *lq_start,
                          const uint32_t *seed_cand, const uint32_t *seq_off, const uint8_t *seq, uint32_t *out_pos,
                          uint8_t *out_base);
+// out[0..6): index of the first consensus base at a position >= t[k]; out[6], out[7]: positions of the first / last base of
+// [out[1], out[4])
+void launch_shard_bounds(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *t, uint32_t *out);
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
                       uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err);
 // groups of chained RECH regions + per-group job offsets (job_off[n_groups] = *n_jobs); max_rech = launch bound

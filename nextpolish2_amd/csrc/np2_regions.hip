@@ -694,6 +694,30 @@ __device__ __forceinline__ void k_splice_seeds(const uint32_t np2_bid, const uin
     }
 }
 
+// shards of one contig: where the positions t[0..6) begin in the (position-ordered) consensus, and the positions of the
+// first / last base of [idx(t[1]), idx(t[4])) — the slice a shard owns
+__device__ __forceinline__ void k_shard_bounds(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ cns_pos, const uint32_t *__restrict__ M_p,
+                                               uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5,
+                                               uint32_t *__restrict__ out) {
+    __shared__ uint32_t s_i[6];
+    const uint32_t M = *M_p;
+    const uint32_t t[6] = {t0, t1, t2, t3, t4, t5};
+    if (threadIdx.x < 6) {
+        uint32_t tv = t[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 6; ++k) tv = threadIdx.x == k ? t[k] : tv;
+        const uint32_t i = lower_bound_u32(cns_pos, M, tv);
+        out[threadIdx.x] = i;
+        s_i[threadIdx.x] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = s_i[1], b = s_i[4];
+        out[6] = b > a ? cns_pos[a] : 0u;
+        out[7] = b > a ? cns_pos[b - 1] : 0u;
+    }
+}
+
 // ---- recheck (reupdate_consensus_with_lqseqs, main.rs:1060-1420) ------------------------------------
 // RECH regions in left -> right order (reverse region index), compacted with a look-back across blocks
 __device__ __forceinline__ void k_rech_list(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint8_t *__restrict__ reg_lable,
@@ -1078,6 +1102,9 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
     NP2_LAUNCH(k_splice_bases, dim3((M_cap + SPLICE_SPAN - 1) / SPLICE_SPAN), 256, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap, out_pos, out_base);
     if (max_ap)
         NP2_LAUNCH(k_splice_seeds, g1(max_ap, 64), 64, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap, lq_start, seed_cand, seq_off, seq, out_pos, out_base);
+}
+void launch_shard_bounds(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *t, uint32_t *out) {
+    NP2_LAUNCH(k_shard_bounds, dim3(1), 64, s, cns_pos, M_p, t[0], t[1], t[2], t[3], t[4], t[5], out);
 }
 void launch_rech_list(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint32_t n_reg, uint32_t *rech,
                       uint32_t *n_rech, unsigned long long *blob_bound, uint32_t *err) {

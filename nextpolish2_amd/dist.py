@@ -69,11 +69,15 @@ def all_gather_sequences(local, device=None, group=None):
 
 
 # ---- reference-interval sharding of one long contig --------------------------------------------------------------
+class ShardMismatch(RuntimeError):
+    """The sharded attempt of a contig is abandoned — on every rank alike (the exchanges carry a status word): the
+    shards disagree around a cut, or some rank's shard failed.  The caller polishes the contig unsharded."""
+
+
 def stitch_shards(pieces, plans, verify):
-    """Join the shards' consensus pieces [(bases, pos)] (each covering [own_lo - verify, own_hi + verify) in contig
-    coordinates) into the contig's consensus.  Neighbouring shards computed the `verify` positions on either side of
-    their common boundary independently: they must agree base for base there, otherwise the halo was too small for this
-    pileup and the caller falls back to the unsharded path."""
+    """Host-side stitcher for pieces from np2_shard_final [(bases, pos)], each covering [own_lo - verify, own_hi + verify)
+    in contig coordinates (the form recorded fixtures hold; the product path keeps the pieces on the devices:
+    np2_shard_final_device + check_strips + gather_slices)."""
     out_b, out_p = [], []
     for k, ((b, p), pl) in enumerate(zip(pieces, plans)):
         b, p = np.asarray(b), np.asarray(p)
@@ -90,104 +94,257 @@ def stitch_shards(pieces, plans, verify):
     return np.concatenate(out_b), np.concatenate(out_p)
 
 
-class ShardMismatch(RuntimeError):
-    pass
+def all_gather_bytes(raw, device=None, group=None):
+    """Every rank's byte string, in rank order."""
+    return [x.tobytes() for x in all_gather_arrays(np.frombuffer(raw, dtype=np.uint8), device=device, group=group)]
 
 
-def polish_sharded_local(polisher, pileup, opts=None, n_shards=2, halo=65536, verify=1024):
+def all_gather_arrays(arr, device=None, group=None):
+    """Every rank's uint8 numpy array, in rank order (variable lengths: one length exchange + one padded all-gather
+    from a device buffer with backend nccl = RCCL over xGMI; no Python byte strings on the way)."""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [arr]
+    device = device or torch.device("cpu")
+    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=device)
+    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(x.item()) for x in lens]
+    cap = max(1, max(lens))
+    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if arr.shape[0]:
+        buf[:arr.shape[0]] = torch.from_numpy(arr).to(device)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    return [bufs[r][:lens[r]].cpu().numpy() for r in range(world)]
+
+
+def _exchange(payload, failure, device, group, what):
+    """All-gather one array per rank behind a status word.  `failure` (an exception or None) is this rank's outcome of
+    the phase that produced `payload`; if ANY rank failed, every rank raises ShardMismatch — nobody is left waiting in
+    the next collective for a rank that has gone."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    head = np.zeros(8, dtype=np.uint8)
+    head[0] = 0 if failure is None else 1
+    body = np.zeros(0, dtype=np.uint8) if failure is not None else np.ascontiguousarray(payload, dtype=np.uint8)
+    got = all_gather_arrays(np.concatenate([head, body]), device=device, group=group)
+    bad = [r for r, g in enumerate(got) if g[0] != 0]
+    if bad:
+        raise ShardMismatch(f"{what} failed on rank(s) {bad}" + (f": {failure}" if rank in bad else "")) from failure
+    return [g[8:] for g in got]
+
+
+def check_strips(metas, plans):
+    """Neighbouring shards computed the `verify` positions on either side of their common cut independently: the high
+    strip of shard k must equal the low strip of shard k + 1 base for base and position for position, otherwise the halo
+    was too small for this pileup and the contig is polished unsharded."""
+    for k in range(len(metas) - 1):
+        a, b = metas[k], metas[k + 1]
+        if not (np.array_equal(a["hi_bases"], b["lo_bases"]) and np.array_equal(a["hi_pos"], b["lo_pos"])):
+            raise ShardMismatch(f"shards {k} and {k + 1} disagree around position {plans[k].own_hi}")
+
+
+def _piece_meta(pc):
+    return {"own_len": pc.own_len, "first_pos": pc.first_pos, "last_pos": pc.last_pos, "lo_bases": pc.lo_bases,
+            "lo_pos": pc.lo_pos, "hi_bases": pc.hi_bases, "hi_pos": pc.hi_pos}
+
+
+def _run_local(runs, plans, n_reads_total, opts, want_pos):
+    """Shard protocol of one process driving every shard (one context each): votes merged per phasing pass, final pass
+    with the results left on the devices, strips checked, owned slices fetched straight into their places of ONE pinned
+    host array."""
+    from .api import pinned_array, vote_decide
+    while runs[0].passes_left() > 1:
+        losers = vote_decide([r.vote() for r in runs], n_reads_total, opts)
+        for r in runs:
+            r.apply(losers)
+    pieces = [r.final_device() for r in runs]
+    check_strips([_piece_meta(pc) for pc in pieces], plans)
+    total = sum(pc.own_len for pc in pieces)
+    out_b = pinned_array(total, np.uint8)
+    out_p = pinned_array(total, np.uint32) if want_pos else None
+    off = 0
+    for r, pc in zip(runs, pieces):
+        if pc.own_len:
+            r.fetch(out_b[off:off + pc.own_len], out_p[off:off + pc.own_len] if want_pos else None)
+        off += pc.own_len
+    return out_b, out_p
+
+
+def polish_sharded_local(polisher, pileup, opts=None, n_shards=2, halo=65536, verify=1024, want_pos=True):
     """Polish one contig as n_shards reference intervals inside this process, one np2 context per shard (clones of
     `polisher`: same device, shared k-mer tables): the single-process form of polish_sharded, used by tests and by a
-    single-GPU run that wants the shard path.  Returns (bases, pos) of the whole contig."""
-    from .api import ShardRun, shard_plan, vote_decide
+    single-GPU run that wants the shard path.  Returns (bases, pos) of the whole contig (pos None unless want_pos)."""
+    from .api import ShardRun, shard_plan
     plans = shard_plan(pileup, n_shards, halo)
-    ctxs = [polisher.clone() for _ in range(n_shards)]  # a run keeps its state in its context's scratch
+    ctxs = [polisher.clone() for _ in range(n_shards)]  # a run keeps its state (and its result) in its context's scratch
     runs = [ShardRun(ctxs[k], pileup, plans[k], opts, verify) for k in range(n_shards)]
     try:
-        while runs[0].passes_left() > 1:
-            votes = [r.vote() for r in runs]
-            losers = vote_decide(votes, pileup.n_reads, opts)
-            for r in runs:
-                r.apply(losers)
-        pieces = [r.final() for r in runs]
+        return _run_local(runs, plans, pileup.n_reads, opts, want_pos)
     finally:
         for r in runs:
             r.close()
-    return stitch_shards(pieces, plans, verify)
 
 
-def all_gather_bytes(raw, device=None, group=None):
-    """Every rank's byte string, in rank order."""
+def _device_view(ptr, n, device, dtype=torch.uint8):
+    """Zero-copy tensor over `n` elements of device memory at `ptr` (a shard's owned slice)."""
+    typestr = {torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
+    iface = type("_Dev", (), {})()
+    iface.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    with torch.cuda.device(device):
+        return torch.as_tensor(iface, device=device)
+
+
+def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
+    """The shards' owned slices, end to end, on rank `dst` (None: on every rank).  With a CUDA device the slices travel
+    from the np2 result buffers on the devices (RCCL over xGMI: gather to `dst`, or all-gather), with a CPU device
+    (gloo: tests) through host memory.  Returns (bases, pos) on the receiving rank(s), (None, None) elsewhere."""
+    from .api import pinned_array
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    got = all_gather_sequences([(rank, raw)], device=device, group=group)
-    return [got[r] for r in range(len(got))]
+    total, cap = sum(lens), max(1, max(lens))
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    sub_lo = int(run.plan.sub_lo)
+
+    def one(kind):
+        dt_t, dt_n = (torch.uint8, np.uint8) if kind == "bases" else (torch.int32, np.uint32)
+        n = pc.own_len
+        if on_gpu:
+            src = torch.zeros(cap, dtype=dt_t, device=device)
+            if n:
+                v = _device_view(pc.dev_bases if kind == "bases" else pc.dev_pos, n, device, dt_t)
+                src[:n] = v if kind == "bases" else v + sub_lo  # (device positions are sub-contig coordinates)
+        else:
+            host = np.zeros(cap, dtype=dt_n)
+            if n:
+                hb = np.empty(n, dtype=np.uint8)
+                hp = np.empty(n, dtype=np.uint32) if kind == "pos" else None
+                run.fetch(hb, hp)
+                host[:n] = hb if kind == "bases" else hp
+            src = torch.from_numpy(host.view(np.int32) if kind == "pos" else host)
+        want = dst is None or rank == dst
+        if world == 1:
+            parts = [src]
+        elif dst is None:
+            parts = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(parts, src, group=group)
+        else:
+            parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+            dist.gather(src, parts, dst=dst, group=group)
+        if not want:
+            return None
+        out = pinned_array(total, dt_n)
+        off = 0
+        for r in range(world):
+            if lens[r]:
+                t = torch.from_numpy(out[off:off + lens[r]].view(np.int32) if kind == "pos" else out[off:off + lens[r]])
+                t.copy_(parts[r][:lens[r]])
+            off += lens[r]
+        return out
+    b = one("bases")
+    p = one("pos") if want_pos else None
+    return b, p
 
 
-def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=None, group=None):
+def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
+    """Shard protocol of one rank among `world` (one process per GPU): every phase's exchange carries the ranks' status."""
+    from .api import ShardPiece, Vote, vote_decide
+    while run.passes_left() > 1:
+        err, payload = None, None
+        try:
+            payload = run.vote().pack()
+        except Exception as e:  # noqa: BLE001 — any failure of this rank's shard ends the sharded attempt everywhere
+            err = e
+        raws = _exchange(payload, err, device, group, "phasing vote")
+        losers = vote_decide([Vote.unpack(x) for x in raws], n_reads_total, opts)
+        run.apply(losers)
+    err, pc = None, None
+    try:
+        pc = run.final_device()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    raws = _exchange(pc.strips() if pc is not None else None, err, device, group, "final pass")
+    metas = [ShardPiece.unpack_strips(x) for x in raws]
+    check_strips(metas, plans)  # (every rank sees the same strips: the same verdict everywhere)
+    b, p = gather_slices(run, pc, [m["own_len"] for m in metas], want_pos, device=device, group=group, dst=dst)
+    full = [m for m in metas if m["own_len"]]
+    span = (full[0]["first_pos"], full[-1]["last_pos"]) if full else (0, 0)
+    return b, p, span
+
+
+def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=None, group=None, want_pos=True, dst=None,
+                   with_span=False):
     """Polish one contig cut into world_size reference intervals, one per rank (one process per GPU).
 
     Every rank holds the contig's host pileup (or at least its own shard's reads) and uploads only its shard.  Per
     phasing pass the ranks all-gather their votes (pair counts of the HETE regions they own, per-read vote records —
     a few MB per Mb of diploid contig) and each runs the contig-wide decision on the merged votes (host only,
-    deterministic: no broadcast needed); the removed reads are applied to every shard.  The polished pieces are
-    all-gathered (RCCL over xGMI with backend nccl) and stitched; every rank returns the whole contig's (bases, pos)."""
-    from .api import ShardRun, Vote, shard_plan, vote_decide
+    deterministic: no broadcast needed); the removed reads are applied to every shard.  The final pass leaves each
+    shard's polished sub-contig on its device; the ranks exchange the short strips around the cuts (checked on every
+    rank) and the owned slices are gathered from the device buffers (RCCL over xGMI with backend nccl) onto rank `dst`
+    (None: every rank).  Returns (bases, pos) there — pos None unless want_pos — and (None, None) on the other ranks."""
+    from .api import ShardRun, shard_plan
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     plans = shard_plan(pileup, world, halo)
-    run = ShardRun(polisher, pileup, plans[rank], opts, verify)
+    run, err = None, None
     try:
-        while run.passes_left() > 1:
-            raws = all_gather_bytes(run.vote().to_bytes(), device=device, group=group)
-            losers = vote_decide([Vote.from_bytes(x) for x in raws], pileup.n_reads, opts)
-            run.apply(losers)
-        b, p = run.final()
+        run = ShardRun(polisher, pileup, plans[rank], opts, verify)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    try:
+        _exchange(np.zeros(0, dtype=np.uint8), err, device, group, "shard upload")
+        b, p, span = _run_ranked(run, plans, pileup.n_reads, opts, want_pos, device, group, dst)
+        return (b, p, span) if with_span else (b, p)
     finally:
-        run.close()
-    hdr = np.array([len(b)], dtype=np.uint64).tobytes()
-    raws = all_gather_bytes(hdr + np.asarray(b).tobytes() + np.asarray(p).tobytes(), device=device, group=group)
-    pieces = []
-    for x in raws:
-        n = int(np.frombuffer(x[:8], dtype=np.uint64)[0])
-        pieces.append((np.frombuffer(x[8:8 + n], dtype=np.uint8), np.frombuffer(x[8 + n:8 + 5 * n], dtype=np.uint32)))
-    return stitch_shards(pieces, plans, verify)
+        if run is not None:
+            run.close()
 
 
-def polish_sharded_bam(polisher, bam, name, ref, opts=None, fopts=None, halo=65536, verify=1024, device=None, group=None):
+def polish_sharded_bam(polisher, bam, name, ref, opts=None, fopts=None, halo=65536, verify=1024, device=None, group=None,
+                       want_pos=True, dst=None, with_span=False):
     """polish_sharded with the input side sharded too: every rank reads only the BAM records overlapping its interval
     +- halo (io.ShardFromBam), the ranks all-gather the file offsets of the pushed records starting in their own
     intervals (that list IS the contig's read numbering), then the shard protocol runs on the resident shards."""
     from . import io as np2io
-    from .api import ShardRun, Vote, vote_decide
+    from .api import ShardRun
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     cuts = np2io.shard_cuts(len(ref), world)
-    sb = np2io.ShardFromBam(polisher, bam, name, ref, cuts[rank][0], cuts[rank][1], halo, fopts)
-    raws = all_gather_bytes(sb.own_offsets.tobytes(), device=device, group=group)
-    all_off = np.concatenate([np.frombuffer(x, dtype=np.uint64) for x in raws]) if raws else np.zeros(0, dtype=np.uint64)
-    h, plan, n_reads_total = sb.finish(all_off)
-    run = ShardRun(polisher, None, plan, opts, verify, resident=h)
-    plans_raw = all_gather_bytes(bytes(plan), device=device, group=group)
-    plans = [type(plan).from_buffer_copy(x) for x in plans_raw]
+    sb, err = None, None
     try:
-        while run.passes_left() > 1:
-            raws = all_gather_bytes(run.vote().to_bytes(), device=device, group=group)
-            run.apply(vote_decide([Vote.from_bytes(x) for x in raws], n_reads_total, opts))
-        b, p = run.final()
+        sb = np2io.ShardFromBam(polisher, bam, name, ref, cuts[rank][0], cuts[rank][1], halo, fopts)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    try:
+        raws = _exchange(sb.own_offsets.view(np.uint8) if sb is not None else None, err, device, group, "shard input")
+    except ShardMismatch:
+        if sb is not None:
+            sb.abort()
+        raise
+    all_off = np.concatenate([np.frombuffer(x, dtype=np.uint64) for x in raws]) if raws else np.zeros(0, dtype=np.uint64)
+    run, err, plan, n_reads_total = None, None, None, 0
+    try:
+        h, plan, n_reads_total = sb.finish(all_off)
+        run = ShardRun(polisher, None, plan, opts, verify, resident=h)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    try:
+        plans_raw = _exchange(np.frombuffer(bytes(plan), dtype=np.uint8) if plan is not None else None, err, device, group, "shard setup")
+        plans = [type(plan).from_buffer_copy(x.tobytes()) for x in plans_raw]
+        b, p, span = _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst)
+        return (b, p, span) if with_span else (b, p)
     finally:
-        run.close()
-    hdr = np.array([len(b)], dtype=np.uint64).tobytes()
-    raws = all_gather_bytes(hdr + np.asarray(b).tobytes() + np.asarray(p).tobytes(), device=device, group=group)
-    pieces = []
-    for x in raws:
-        n = int(np.frombuffer(x[:8], dtype=np.uint64)[0])
-        pieces.append((np.frombuffer(x[8:8 + n], dtype=np.uint8), np.frombuffer(x[8 + n:8 + 5 * n], dtype=np.uint32)))
-    return stitch_shards(pieces, plans, verify)
+        if run is not None:
+            run.close()
 
 
-def polish_sharded_bam_local(polisher, bam_path, name, ref, n_shards, opts=None, fopts=None, halo=65536, verify=1024):
+def polish_sharded_bam_local(polisher, bam_path, name, ref, n_shards, opts=None, fopts=None, halo=65536, verify=1024,
+                             want_pos=True):
     """The single-process form of polish_sharded_bam (one context + one BAM handle per shard): tests, single-GPU runs."""
     from . import io as np2io
-    from .api import ShardRun, vote_decide
+    from .api import ShardRun
     cuts = np2io.shard_cuts(len(ref), n_shards)
     ctxs = [polisher.clone() for _ in range(n_shards)]
     bams = [np2io.Bam(bam_path) for _ in range(n_shards)]
@@ -198,15 +355,10 @@ def polish_sharded_bam_local(polisher, bam_path, name, ref, n_shards, opts=None,
     n_reads_total = fin[0][2]
     runs = [ShardRun(ctxs[k], None, plans[k], opts, verify, resident=fin[k][0]) for k in range(n_shards)]
     try:
-        while runs[0].passes_left() > 1:
-            losers = vote_decide([r.vote() for r in runs], n_reads_total, opts)
-            for r in runs:
-                r.apply(losers)
-        pieces = [r.final() for r in runs]
+        return _run_local(runs, plans, n_reads_total, opts, want_pos)
     finally:
         for r in runs:
             r.close()
-    return stitch_shards(pieces, plans, verify)
 
 
 class _DeviceBytes:

@@ -212,11 +212,15 @@ class ShardFromBam:
         self._pol._check(L.np2_shard_bam_finish(io, a.ctypes.data, len(a), C.byref(plan), C.byref(h), C.byref(n_total)))
         return h, plan, n_total.value
 
+    def abort(self):
+        """Give the half-built shard up (another rank's shard failed: the contig is polished unsharded)."""
+        if getattr(self, "_io", None):
+            _bind().np2_shard_bam_abort(self._io)
+            self._io = None
+
     def __del__(self):
         try:
-            if getattr(self, "_io", None):
-                _bind().np2_shard_bam_abort(self._io)
-                self._io = None
+            self.abort()
         except Exception:
             pass
 

@@ -133,3 +133,130 @@ def test_two_rank_exchange_of_recorded_shards_gloo():
     for p in ps:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---- the product's rank protocol (dist._run_ranked: status-carrying exchanges, strips, slices gathered to one rank) ----
+class _ReplayRun:
+    """Stands in for api.ShardRun on a box without a GPU: votes and the final piece come from the recorded fixture, in
+    the form np2_shard_vote / np2_shard_final_device / np2_shard_fetch hand them over."""
+
+    def __init__(self, fx, rank, plan, verify=1024, fail_at=None):
+        self.fx, self.rank, self.plan, self.verify, self.fail_at = fx, rank, plan, verify, fail_at
+        self.left = 2
+        self.losers = None
+
+    def passes_left(self):
+        return self.left
+
+    def vote(self):
+        if self.fail_at == "vote" and self.rank == 1:
+            raise RuntimeError("NP2_E_REFPANIC: (injected) reference would panic in this shard's fringe")
+        return Vote.from_bytes(self.fx[f"vote{self.rank}"].tobytes())
+
+    def apply(self, losers):
+        self.losers = np.asarray(losers)
+        self.left = 1
+
+    def final_device(self):
+        from nextpolish2_amd.api import ShardPiece
+        if self.fail_at == "final" and self.rank == 0:
+            raise RuntimeError("NP2_E_UNSUPPORTED: (injected) splice cursor stuck inside a shard")
+        b, p = self.fx[f"piece{self.rank}_bases"], self.fx[f"piece{self.rank}_pos"]
+        pl, v = self.plan, self.verify
+        own = (p >= pl.own_lo) & (p < pl.own_hi)
+        lo = (p >= max(0, pl.own_lo - v)) & (p < pl.own_lo + v)
+        hi = (p >= max(0, pl.own_hi - v)) & (p < pl.own_hi + v)
+        pc = ShardPiece.__new__(ShardPiece)
+        self._own = (b[own].copy(), p[own].copy())
+        pc.own_len, pc.dev_bases, pc.dev_pos = int(own.sum()), 0, 0
+        pc.first_pos, pc.last_pos = int(p[own][0]), int(p[own][-1])
+        pc.lo_bases, pc.lo_pos, pc.hi_bases, pc.hi_pos = b[lo].copy(), p[lo].copy(), b[hi].copy(), p[hi].copy()
+        return pc
+
+    def fetch(self, dst_b, dst_p=None):
+        dst_b[:] = self._own[0]
+        if dst_p is not None:
+            dst_p[:] = self._own[1]
+
+
+def _rank_protocol(rank, world, port, q, fail_at):
+    from nextpolish2_amd.dist import ShardMismatch, _run_ranked
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = np.load(FIX)
+        plans = [np2_shard_plan_t(*[int(x) for x in row]) for row in fx["plans"]]
+        run = _ReplayRun(fx, rank, plans[rank], fail_at=fail_at)
+        try:
+            b, p, span = _run_ranked(run, plans, int(fx["n_reads"][0]), Opts(), True, torch.device("cpu"), None, 0)
+        except ShardMismatch as e:
+            q.put((rank, "mismatch", fail_at in str(e) or "failed on rank" in str(e)))
+            return
+        ok = np.array_equal(run.losers, fx["losers"])
+        if rank == 0:  # the slices meet on rank 0 only
+            ok = ok and np.array_equal(b, fx["oracle_bases"]) and np.array_equal(p, fx["oracle_pos"])
+            ok = ok and span == (int(fx["oracle_pos"][0]), int(fx["oracle_pos"][-1]))
+        else:
+            ok = ok and b is None and p is None
+        q.put((rank, "ok", bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn_protocol(fail_at):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank_protocol, args=(r, 2, port, q, fail_at)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    return res
+
+
+def test_rank_protocol_on_recorded_shards_gloo():
+    """dist._run_ranked over two gloo ranks: packed votes exchanged behind status words, contig-wide decision on both
+    ranks, strips checked, owned slices gathered onto rank 0 == the oracle's consensus of the whole contig."""
+    assert _spawn_protocol(None) == [(0, "ok", True), (1, "ok", True)]
+
+
+def test_a_failing_shard_ends_the_sharded_attempt_on_every_rank():
+    """One rank's shard fails (in its phasing pass / in its final pass): every rank raises ShardMismatch out of the same
+    exchange instead of waiting for the other in the next collective — the caller then polishes the contig unsharded."""
+    for where in ("vote", "final"):
+        assert _spawn_protocol(where) == [(0, "mismatch", True), (1, "mismatch", True)]
+
+
+def test_vote_pack_round_trip_and_strip_check():
+    from nextpolish2_amd.api import ShardPiece
+    from nextpolish2_amd.dist import ShardMismatch, check_strips
+    rng = np.random.default_rng(3)
+    v = Vote(pair_key=rng.integers(0, 1 << 40, 7).astype(np.uint64), pair_cnt=rng.integers(0, 99, 7).astype(np.uint32),
+             read_id=np.arange(5, dtype=np.uint32), first_pos=rng.integers(0, 999, 5).astype(np.uint32),
+             ref_w=rng.integers(-3, 3, 5).astype(np.int32), flags=rng.integers(0, 7, 5).astype(np.uint8))
+    w = Vote.unpack(v.pack())
+    assert all(np.array_equal(getattr(v, n), getattr(w, n)) for n, _ in Vote.FIELDS)
+    assert len(v.pack()) % 8 == 0
+    pc = ShardPiece.__new__(ShardPiece)
+    pc.own_len, pc.first_pos, pc.last_pos = 12345, 1024, 99999
+    pc.lo_bases, pc.lo_pos = np.frombuffer(b"ACGTA", dtype=np.uint8), np.arange(5, dtype=np.uint32)
+    pc.hi_bases, pc.hi_pos = np.frombuffer(b"TTG", dtype=np.uint8), np.arange(7, 10, dtype=np.uint32)
+    m = ShardPiece.unpack_strips(pc.strips())
+    assert (m["own_len"], m["first_pos"], m["last_pos"]) == (12345, 1024, 99999)
+    assert m["lo_bases"].tobytes() == b"ACGTA" and m["hi_pos"].tolist() == [7, 8, 9]
+    plans = [np2_shard_plan_t(0, 2048, 0, 4096, 0, 4096, 1, 9), np2_shard_plan_t(2048, 4096, 0, 4096, 0, 4096, 1, 9)]
+    a = {"hi_bases": m["hi_bases"], "hi_pos": m["hi_pos"]}
+    check_strips([a, {"lo_bases": m["hi_bases"].copy(), "lo_pos": m["hi_pos"].copy()}], plans)
+    bad = m["hi_bases"].copy()
+    bad[1] ^= 1
+    try:
+        check_strips([a, {"lo_bases": bad, "lo_pos": m["hi_pos"]}], plans)
+        raise AssertionError("a disagreeing strip must raise")
+    except ShardMismatch:
+        pass
