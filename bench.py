@@ -260,12 +260,159 @@ def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=4):
                     "dominated by fixed costs: ~0.1-0.2 s of yak loading, cold device / pinned allocations per context)"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N ranks on
+    this node (127.0.0.1 rendezvous on a free port) and relay their output; rank 0's JSON line carries n_gpus == N."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    out = p.stdout.decode(errors="replace")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    lines = [json.loads(x) for x in out.splitlines() if x.startswith("{")]
+    if p.returncode != 0 or not lines or lines[-1].get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: the ranks did not deliver a line with n_gpus == {n} (exit code {p.returncode})")
+    return 0
+
+
+def main_strong(a):
+    """Strong scaling on BASELINE configs[3]: ONE contig (248 Mb by default), 30x simulated HiFi, k21 + k31, cut into one
+    reference interval per rank (np2_shard_*; nextpolish2_amd.dist.polish_sharded).  The shards are resident in HBM before
+    the timed region; a step = the whole hot path of the contig: every rank's dense pass, its phasing pass, the all-gather
+    of the votes (RCCL), the contig-wide decision, the final pass, the strips around the cuts exchanged and checked, the
+    owned slices gathered from the device buffers onto rank 0 (RCCL over xGMI) and landed in one host array there."""
+    import torch
+    import torch.distributed as dist
+    from nextpolish2_amd import Opts, Polisher
+    from nextpolish2_amd.api import free_shard, shard_plan, upload_shard
+    from nextpolish2_amd.dist import polish_sharded
+    from nextpolish2_amd.synth import Synth, concat_pileups
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = "RANK" in os.environ
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    L = int(a.contig_mb * 1e6 * a.scale)
+    n_parts = 16
+    # every rank generates the same contig (seeded) and keeps only its shard in HBM
+    with ThreadPoolExecutor(min(n_parts, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(lambda i: Synth(L // n_parts, depth=a.depth, seed=500 + i), range(n_parts)))
+    pu = concat_pileups([p.pileup for p in parts], "chr1")
+    ks = [21, 31]
+    yaks = [Synth.yak_assembly(parts, k) for k in ks]
+    truth = b"".join(p.hap1 for p in parts)
+    del parts
+    pol = Polisher(yaks, device=local_rank)
+    plans = shard_plan(pu, world, 65536)
+    shard = upload_shard(pol, pu, plans[rank])
+    opts = Opts()
+    last = [None]
+
+    def step():
+        b, _, span = polish_sharded(pol, pu, opts, device=dev if distributed else None, want_pos=False, dst=0, with_span=True,
+                                    plans=plans, resident=shard)
+        last[0] = (b, span)
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    diff_ms = []
+    for _ in range(a.warmup):
+        step()
+    import gc
+    gc.collect()
+    gc.disable()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+    sync()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = pu.L * a.steps / dt / 1e6
+    # roofline of this rank's k_diff_reads launch: the reads of its zone, whole (sub-contig [sub_lo, sub_hi))
+    pl = plans[rank]
+    rd = pu.reads[pl.read_lo:pl.read_hi]
+    inz = (rd["aln_t_e"] >= pl.zone_lo) & (rd["aln_t_s"] < pl.zone_hi) & ((rd["flags"] & 1) == 0)
+    cols = int(rd["n_cols"][inz].astype(np.int64).sum())
+    alg_bytes = 0.5 * cols + 0.5 * (pl.sub_hi - pl.sub_lo)
+    avg_ms = float(np.mean(diff_ms)) if diff_ms else 0.0
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out_line = {
+        "metric": "polished reference Mbp/s (whole node) at 30x HiFi + k21/k31; FASTA identical to oracle",
+        "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"one contig of {pu.L / 1e6:.1f} Mb (BASELINE configs[3]: human chr1-sized), 30x simulated HiFi, "
+                               f"k21 + k31 yak, cut into {world} reference interval(s), one per MI355X",
+                   "contig_bp": pu.L, "depth": a.depth, "reads": pu.n_reads, "pileup_columns": int(pu.n_columns()) - pu.L,
+                   "yak_k": ks, "iter_count": 2, "halo": 65536, "verify": 1024,
+                   "parallelism": f"reference-interval shards x{world}: votes all-gathered and decided contig-wide per phasing "
+                                  f"pass, owned slices gathered from the device buffers onto rank 0",
+                   "output": "the polished contig in one host array on rank 0 inside the step"},
+        "roofline": {"bound": "hbm", "kernel": "k_diff_reads", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "alg_bytes_per_launch": int(alg_bytes), "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 4),
+                     "units_per_launch_bp": int(pl.sub_hi - pl.sub_lo), "note": "rank 0's launch over its shard"},
+    }
+    if rank == 0:
+        b, span = last[0]
+        out_line["polished_equals_truth"] = bool(b.tobytes() == truth)
+        out_line["span"] = [int(span[0]), int(span[1])]
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU baseline on a bounded sample: the reference polishes one contig on ONE thread whatever -t says
+        # (main.rs:1726-1837), so the sample is a shorter contig of the same recipe on one core
+        from oracle.np2_oracle import Oracle
+        sm = Synth(8_000_000, depth=a.depth, seed=77)
+        ys = [sm.yak(k) for k in ks]
+        t1 = time.perf_counter()
+        ob, op = Oracle(ys).polish(sm.pileup, opts)
+        st = time.perf_counter() - t1
+        g = Polisher(ys, device=local_rank)
+        gb, gp = g.polish(sm.pileup, opts)
+        out_line["cpu_baseline"] = {"value": round(sm.pileup.L / st / 1e6, 4), "unit": "Mbp/s", "cores": 1, "kind": "port",
+                                    "sample": "an 8 Mb contig of the same recipe on one host thread: the reference gives a contig "
+                                              "to ONE worker thread (main.rs:1726-1837), a one-contig input runs on one core "
+                                              "whatever -t says",
+                                    "wall_s": round(st, 1)}
+        out_line["fasta_identical_to_oracle"] = bool(np.array_equal(ob, gb) and np.array_equal(op, gp))
+    if rank == 0:
+        print(json.dumps(out_line), flush=True)
+    free_shard(pol, shard)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["yeast", "ecoli"], default="yeast")
+    ap.add_argument("--workload", choices=["yeast", "ecoli", "chr1"], default="yeast")
     ap.add_argument("--depth", type=int, default=30)
     ap.add_argument("--scale", type=float, default=1.0, help="scale every contig length (tests; the metric is quoted at 1.0)")
     ap.add_argument("--groups", type=int, default=4, help="batch groups (host threads driving one np2_batch_t each)")
@@ -273,7 +420,20 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the two untimed steps behind roofline_exclusive (profiling runs)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all cores)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): one assembly per GPU (BASELINE configs[2] at N = 1); strong: ONE long contig "
+                         "(--workload chr1, BASELINE configs[3]) cut into one reference interval per GPU")
+    ap.add_argument("--contig-mb", type=float, default=248.0, help="--scaling strong: length of the contig in Mb")
     a = ap.parse_args()
+    if a.scaling == "strong":
+        a.workload = "chr1"
+    if a.workload == "chr1":
+        a.scaling = "strong"
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not launched by torch.distributed.run: start the ranks ourselves (one process per GPU) and pass their line on
+        return spawn_ranks(a.gpus)
+    if a.scaling == "strong":
+        return main_strong(a)
 
     import torch
     import torch.distributed as dist
@@ -450,4 +610,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -489,13 +489,15 @@ class ShardRun:
     """One shard of a contig on one context: upload (from a host pileup, or an already resident shard built by
     io.shard_from_bam), then vote() / apply() per phasing pass, final()."""
 
-    def __init__(self, polisher: Polisher, pileup, plan: np2_shard_plan_t, opts: Opts = None, verify=1024, resident=None):
+    def __init__(self, polisher: Polisher, pileup, plan: np2_shard_plan_t, opts: Opts = None, verify=1024, resident=None,
+                 own_contig=True):
         self._pol = polisher
         self.plan = plan
         self.verify = verify
+        self._own = own_contig
         self._c = C.c_void_p()
         if resident is not None:
-            self._c = resident  # np2_contig_t* of the shard (ownership taken)
+            self._c = resident  # np2_contig_t* of the shard (ownership taken unless own_contig=False: see upload_shard)
         else:
             polisher._check(lib().np2_shard_upload(polisher._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
                                                    pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
@@ -540,7 +542,8 @@ class ShardRun:
             lib().np2_shard_end(self._r)
             self._r = None
         if getattr(self, "_c", None):
-            lib().np2_contig_free(self._pol._h, self._c)
+            if self._own:
+                lib().np2_contig_free(self._pol._h, self._c)
             self._c = None
 
     def __del__(self):
@@ -548,6 +551,20 @@ class ShardRun:
             self.close()
         except Exception:
             pass
+
+
+def upload_shard(polisher: Polisher, pileup: Pileup, plan: np2_shard_plan_t):
+    """np2_shard_upload on its own: the resident shard (np2_contig_t*) of `plan`, to be polished any number of times by
+    ShardRun(polisher, None, plan, ..., resident=h, own_contig=False); release it with free_shard."""
+    h = C.c_void_p()
+    polisher._check(lib().np2_shard_upload(polisher._h, pileup.ref.ctypes.data, pileup.L, pileup.reads.ctypes.data,
+                                           pileup.n_reads, pileup.nibbles.ctypes.data, pileup.nibbles.shape[0],
+                                           C.byref(plan), C.byref(h)))
+    return h
+
+
+def free_shard(polisher: Polisher, h):
+    lib().np2_contig_free(polisher._h, h)
 
 
 class ShardPiece:

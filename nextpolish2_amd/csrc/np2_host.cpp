@@ -1681,12 +1681,13 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
             // start (regions are listed right to left, main.rs:1613-1620), read index within a region
             std::vector<uint32_t> start = d2h(cx, cx->lq_start.p, sr->run.n_reg);
             const np2_shard_plan_t &pl = sr->plan;
-            for (size_t i = 0; i < vd.pair_key.size(); ++i) {
-                const uint32_t a = shard_global_read(pl, (uint32_t)(vd.pair_key[i] >> 32));
-                const uint32_t b = shard_global_read(pl, (uint32_t)vd.pair_key[i]);
-                sr->v_key.push_back(((uint64_t)a << 32) | b);
-                sr->v_cnt.push_back(vd.pair_cnt[i]);
-            }
+            // (local read i >= 1 is contig read read_lo + i - 1 and read 0 never enters a pair: one 64-bit add renumbers
+            // both ends, and the keys stay sorted)
+            const size_t np = vd.pair_key.size();
+            const uint64_t shift = pl.read_lo - 1, add = (shift << 32) | shift;
+            sr->v_key.resize(np);
+            for (size_t i = 0; i < np; ++i) sr->v_key[i] = vd.pair_key[i] + add;
+            sr->v_cnt.swap(vd.pair_cnt);
             for (uint32_t r = 0; r < vd.R; ++r) {
                 const bool votes = vd.first_key[r] != 0xFFFFFFFFu;
                 if (!votes && !vd.ref_seen[r] && !vd.bad[r]) continue;
@@ -1720,14 +1721,13 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
         vd.bad.assign(n_reads_total, 0);
         std::vector<uint32_t> first_pos(n_reads_total, 0);
         std::vector<uint8_t> votes_any(n_reads_total, 0);
-        std::vector<std::pair<uint64_t, uint32_t>> pairs;
+        // every shard's pairs arrive sorted by key (a << 32 | b): the contig's list is their merge, the counts of a pair
+        // that shares regions of two shards added up before the weight rule is applied (main.rs:996-1002).  Neighbouring
+        // shards share only the reads of their halos, so a merge step is mostly two block copies.
+        std::vector<uint64_t> mk, tk;
+        std::vector<uint32_t> mc, tc;
         for (int v = 0; v < n_votes; ++v) {
             const np2_vote_t &x = votes[v];
-            for (uint64_t i = 0; i < x.n_pairs; ++i) {
-                // (the keys arrive from other ranks: both endpoints index per-read arrays below)
-                if ((uint32_t)(x.pair_key[i] >> 32) >= n_reads_total || (uint32_t)x.pair_key[i] >= n_reads_total) return NP2_E_ARG;
-                pairs.emplace_back(x.pair_key[i], x.pair_cnt[i]);
-            }
             for (uint32_t i = 0; i < x.n_reads; ++i) {
                 const uint32_t r = x.read_id[i];
                 if (r >= n_reads_total) return NP2_E_ARG;
@@ -1740,18 +1740,64 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
                     votes_any[r] = 1;
                 }
             }
+            if (!x.n_pairs) continue;
+            // (the keys arrive from other ranks: both endpoints index per-read arrays below; unsorted input is sorted here)
+            std::vector<uint64_t> sk;
+            std::vector<uint32_t> sc;
+            const uint64_t *xk = x.pair_key;
+            const uint32_t *xc = x.pair_cnt;
+            bool sorted = true;
+            for (uint64_t i = 0; i < x.n_pairs; ++i) {
+                if ((uint32_t)(xk[i] >> 32) >= n_reads_total || (uint32_t)xk[i] >= n_reads_total) return NP2_E_ARG;
+                sorted = sorted && (i == 0 || xk[i - 1] < xk[i]);
+            }
+            if (!sorted) {
+                std::vector<std::pair<uint64_t, uint32_t>> tmp(x.n_pairs);
+                for (uint64_t i = 0; i < x.n_pairs; ++i) tmp[i] = {xk[i], xc[i]};
+                std::sort(tmp.begin(), tmp.end());
+                for (auto &t : tmp) {
+                    if (!sk.empty() && sk.back() == t.first) {
+                        const uint32_t same = (sc.back() & 0xFFFFu) + (t.second & 0xFFFFu), neg = (sc.back() >> 16) + (t.second >> 16);
+                        if (same > 0xFFFFu || neg > 0xFFFFu) return NP2_E_UNSUPPORTED;
+                        sc.back() = same | (neg << 16);
+                    } else {
+                        sk.push_back(t.first);
+                        sc.push_back(t.second);
+                    }
+                }
+                xk = sk.data(), xc = sc.data();
+            }
+            const size_t nx = sorted ? (size_t)x.n_pairs : sk.size();
+            if (mk.empty()) {
+                mk.assign(xk, xk + nx);
+                mc.assign(xc, xc + nx);
+                continue;
+            }
+            // merge (mk, mc) with (xk, xc): the part of mk below xk[0] and the part of xk above mk.back() are copied en bloc
+            tk.clear(), tc.clear();
+            tk.reserve(mk.size() + nx), tc.reserve(mk.size() + nx);
+            size_t i = (size_t)(std::lower_bound(mk.begin(), mk.end(), xk[0]) - mk.begin()), j = 0;
+            tk.insert(tk.end(), mk.begin(), mk.begin() + (long)i);
+            tc.insert(tc.end(), mc.begin(), mc.begin() + (long)i);
+            while (i < mk.size() && j < nx) {
+                if (mk[i] < xk[j]) {
+                    tk.push_back(mk[i]), tc.push_back(mc[i]), ++i;
+                } else if (xk[j] < mk[i]) {
+                    tk.push_back(xk[j]), tc.push_back(xc[j]), ++j;
+                } else {
+                    const uint32_t same = (mc[i] & 0xFFFFu) + (xc[j] & 0xFFFFu), neg = (mc[i] >> 16) + (xc[j] >> 16);
+                    if (same > 0xFFFFu || neg > 0xFFFFu) return NP2_E_UNSUPPORTED;
+                    tk.push_back(mk[i]), tc.push_back(same | (neg << 16)), ++i, ++j;
+                }
+            }
+            tk.insert(tk.end(), mk.begin() + (long)i, mk.end());
+            tc.insert(tc.end(), mc.begin() + (long)i, mc.end());
+            tk.insert(tk.end(), xk + j, xk + nx);
+            tc.insert(tc.end(), xc + j, xc + nx);
+            mk.swap(tk), mc.swap(tc);
         }
-        // the same pair may share regions of two shards: counts add up before the weight rule is applied
-        std::sort(pairs.begin(), pairs.end());
-        for (size_t i = 0; i < pairs.size();) {
-            uint32_t same = 0, neg = 0;
-            size_t j = i;
-            for (; j < pairs.size() && pairs[j].first == pairs[i].first; ++j) same += pairs[j].second & 0xFFFFu, neg += pairs[j].second >> 16;
-            if (same > 0xFFFFu || neg > 0xFFFFu) return NP2_E_UNSUPPORTED;
-            vd.pair_key.push_back(pairs[i].first);
-            vd.pair_cnt.push_back(same | (neg << 16));
-            i = j;
-        }
+        vd.pair_key.swap(mk);
+        vd.pair_cnt.swap(mc);
         for (uint32_t r = 0; r < n_reads_total; ++r)
             if (votes_any[r]) vd.first_key[r] = 0xFFFFFFFEu - first_pos[r]; // ascending = right to left
         std::vector<uint32_t> ls = vote_decide(nullptr, vd, opts->use_all_reads != 0);
@@ -1886,6 +1932,7 @@ int np2_shard_final_device(np2_shard_run_t *h, np2_shard_piece_t *out) {
         op_sync(cx);
         for (uint32_t i = 0; i < out->lo_len; ++i) out->lo_pos[i] += pl.sub_lo;
         for (uint32_t i = 0; i < out->hi_len; ++i) out->hi_pos[i] += pl.sub_lo;
+        flush_timings(cx); // (np2_last_timings: the stage timers of the whole run, the dense pass of np2_shard_begin included)
     })
     guard.keep = true;
     return NP2_OK;

@@ -274,7 +274,7 @@ def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
 
 
 def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=None, group=None, want_pos=True, dst=None,
-                   with_span=False):
+                   with_span=False, plans=None, resident=None):
     """Polish one contig cut into world_size reference intervals, one per rank (one process per GPU).
 
     Every rank holds the contig's host pileup (or at least its own shard's reads) and uploads only its shard.  Per
@@ -287,10 +287,11 @@ def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=
     from .api import ShardRun, shard_plan
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    plans = shard_plan(pileup, world, halo)
+    plans = plans or shard_plan(pileup, world, halo)
     run, err = None, None
-    try:
-        run = ShardRun(polisher, pileup, plans[rank], opts, verify)
+    try:  # (resident: this rank's shard is in HBM already — api.upload_shard — and stays there)
+        run = ShardRun(polisher, pileup if resident is None else None, plans[rank], opts, verify, resident=resident,
+                       own_contig=resident is None)
     except Exception as e:  # noqa: BLE001
         err = e
     try:
