@@ -69,6 +69,10 @@ for _t in ("cns_raw", "cns_succ", "cns_rech0", "cns_rech1", "cns_rech2"):
     TRACE_DTYPES.update({f"{_t}.pos": np.uint32, f"{_t}.base": np.uint8})
 
 
+class Unsupported(RuntimeError):
+    """An input both the product and the oracle refuse (NP2_E_UNSUPPORTED)."""
+
+
 class RefPanic(RuntimeError):
     pass
 
@@ -125,6 +129,8 @@ class Oracle:
             msg = lib().np2o_last_error(self._h).decode()
             if rc == -5:
                 raise RefPanic(msg)
+            if rc == -4:
+                raise Unsupported(msg)
             raise RuntimeError(f"oracle rc={rc}: {msg}")
         n = on.value
         bases = np.ctypeslib.as_array(C.cast(ob, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()

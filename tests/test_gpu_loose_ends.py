@@ -70,8 +70,9 @@ def test_min_map_len_is_split_in_single_precision(tmp_path):
 
 def test_negative_best_score_at_the_contig_end_is_refused():
     """DESIGN.md deviation: if no node at the last position reaches score >= 0 the reference backtracks from its default
-    node (main.rs:1651,1680: a spurious 'A', then node 0 of position L-2); the oracle follows it, the product returns
-    NP2_E_UNSUPPORTED instead of emitting that artefact.  Needs a pileup whose best path has < 40 % support everywhere."""
+    node (main.rs:1651,1680: a spurious 'A', then node 0 of position L-2).  Product AND oracle refuse such a pileup with
+    NP2_E_UNSUPPORTED (the oracle restates the artefact only under NP2O_DEFAULT_NODE=1, tests/test_oracle.py): the two
+    never disagree.  Needs a pileup whose best path has < 40 % support everywhere."""
     rng = np.random.default_rng(7)
     L = 600
     ref = "".join(rng.choice(list("ACGT"), L))
@@ -81,8 +82,9 @@ def test_negative_best_score_at_the_contig_end_is_refused():
         alns.append((0, ref, q))
     pu = pileup_from_alignments(ref, alns)
     y = Synth(2000, seed=3).yak(21)
-    ob, op = orc.Oracle([y]).polish(pu, Opts(iter_count=1))
-    assert len(ob) > 0 and chr(ob[-1]) == "A"  # the reference's artefact, restated by the oracle
+    with pytest.raises(orc.Unsupported) as eo:
+        orc.Oracle([y]).polish(pu, Opts(iter_count=1))
+    assert "negative" in str(eo.value)
     with pytest.raises(Np2Error) as e:
         Polisher([y]).polish(pu, Opts(iter_count=1))
     assert e.value.code == -4 and "negative" in str(e.value)

@@ -263,3 +263,20 @@ def test_refpanic_is_reported_not_crashed():
     pu = pileup_from_alignments(ref, [(0, ref, ref)])
     with pytest.raises(RuntimeError):
         orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=0))
+
+
+def test_negative_best_score_default_node_restatement(monkeypatch):
+    """main.rs:1651,1680: no node at the last position with a score >= 0 -> the reference backtracks from its default
+    Kmer (bases 0: 'A' at L - 1 with count 0, then node 0 of position L - 2).  The oracle refuses such a pileup like the
+    product does (NP2_E_UNSUPPORTED) and restates the artefact only under NP2O_DEFAULT_NODE=1: a trailing 'A' at L - 1
+    behind the best path into node 0 of L - 2."""
+    rng = np.random.default_rng(7)
+    L = 600
+    ref = "".join(rng.choice(list("ACGT"), L))
+    alns = [(0, ref, "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] for c in ref)) for k in range(3)]
+    pu = pileup_from_alignments(ref, alns)
+    with pytest.raises(orc.Unsupported):
+        orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=1))
+    monkeypatch.setenv("NP2O_DEFAULT_NODE", "1")
+    b, p = orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=1))
+    assert chr(b[-1]) == "A" and p[-1] == L - 1
