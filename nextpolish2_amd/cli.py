@@ -72,10 +72,15 @@ def build_parser():
     return p
 
 
-def resource_str(t0, argv):
+def _cpu_seconds():
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return ru.ru_utime + ru.ru_stime
+
+
+def resource_str(t0, argv, cpu0=0.0):
     ru = resource.getrusage(resource.RUSAGE_SELF)
     return (f"[INFO] Version: {VERSION}\n[INFO] CMD: {' '.join(argv)}\n[INFO] Real time: {time.time() - t0:.3f} sec; "
-            f"CPU: {ru.ru_utime + ru.ru_stime:.3f} sec; Peak RSS: {ru.ru_maxrss / 1048576:.3f} GB")
+            f"CPU: {ru.ru_utime + ru.ru_stime - cpu0:.3f} sec; Peak RSS: {ru.ru_maxrss / 1048576:.3f} GB")
 
 
 def _record(a, name, b, first, last, pos=None):
@@ -199,6 +204,7 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     t0 = time.time()
+    cpu0 = _cpu_seconds()  # (main() may run inside a longer-lived process: report this call's CPU time, not the process's)
     a = build_parser().parse_args(argv)
     if a.model.lower() not in ("ref", "len"):
         raise SystemExit("error: invalid value for --model (ref|len)")
@@ -290,7 +296,7 @@ def main(argv=None):
     finally:
         if out is not None and out is not sys.stdout.buffer:
             out.close()
-    print(resource_str(t0, ["nextPolish2"] + argv), file=sys.stderr)
+    print(resource_str(t0, ["nextPolish2"] + argv, cpu0), file=sys.stderr)
     return 0
 
 

@@ -13,10 +13,15 @@
 #include "np2_ctx.hpp"
 
 #include <atomic>
+#include <climits>
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 using namespace np2;
 
@@ -54,7 +59,7 @@ struct np2_batch {
     // device synchronisation of the wave: counts are guarded by `sync_mu`, waiters spin on `flush_gen`
     std::mutex sync_mu;
     int n_active = 0, n_waiting = 0;
-    std::atomic<uint64_t> flush_gen{0};
+    std::atomic<uint32_t> flush_gen{0}; // (32 bits: waiters sleep on it with futex(2) after a short spin)
     std::atomic<bool> failed{false};
     std::string fail_msg;
 
@@ -193,24 +198,38 @@ void flush(np2_batch *b) {
 
 // Recorder::sync_fn: wait until every running pipeline of the wave has reached a synchronisation point; the last one
 // to arrive flushes for all.
+// A pipeline that reached its synchronisation point before the others waits for the group's flush: a short spin (the
+// common case — the pipelines of a wave arrive within microseconds of each other and a flush of a few kernels is over
+// in tens of microseconds), then it sleeps on the generation word.  (Spinning for the whole wait had every waiting
+// pipeline of every batch group hold a core: 60+ busy host threads for one GPU.)
+inline void wait_generation(std::atomic<uint32_t> &gen, uint32_t seen) {
+    for (int i = 0; i < 4000; ++i) { // ~20-40 us
+        if (gen.load(std::memory_order_acquire) != seen) return;
+        __builtin_ia32_pause();
+    }
+    while (gen.load(std::memory_order_acquire) == seen)
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+inline void publish_generation(std::atomic<uint32_t> &gen, uint32_t next) {
+    gen.store(next, std::memory_order_release);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
 void group_sync(Recorder *r) {
     np2_batch *b = (np2_batch *)r->group;
-    uint64_t my_gen;
+    uint32_t my_gen;
     {
         std::lock_guard<std::mutex> l(b->sync_mu);
         my_gen = b->flush_gen.load(std::memory_order_relaxed);
         if (++b->n_waiting == b->n_active) {
             flush(b);
             b->n_waiting = 0;
-            b->flush_gen.store(my_gen + 1, std::memory_order_release);
+            publish_generation(b->flush_gen, my_gen + 1);
             if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
             return;
         }
     }
-    uint32_t spins = 0;
-    while (b->flush_gen.load(std::memory_order_acquire) == my_gen) {
-        if (++spins > 2000) std::this_thread::yield(); // (a flush takes tens of microseconds; host phases a millisecond)
-    }
+    wait_generation(b->flush_gen, my_gen);
     if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
 }
 
@@ -226,10 +245,10 @@ void leave_wave(np2_batch *b, Recorder *r) {
     r->clear();
     --b->n_active;
     if (b->n_active > 0 && b->n_waiting == b->n_active) {
-        const uint64_t g = b->flush_gen.load(std::memory_order_relaxed);
+        const uint32_t g = b->flush_gen.load(std::memory_order_relaxed);
         flush(b);
         b->n_waiting = 0;
-        b->flush_gen.store(g + 1, std::memory_order_release);
+        publish_generation(b->flush_gen, g + 1);
     }
 }
 

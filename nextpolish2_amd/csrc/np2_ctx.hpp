@@ -35,13 +35,91 @@ struct Np2Error : std::runtime_error {
         if (c) throw Np2Error(NP2_E_REFPANIC, std::string("reference would panic: ") + (m));        \
     } while (0)
 
+// Device blocks of short-lived objects — the resident pileup of a contig, the front end's staging buffers — are cached
+// per device by size class instead of going back to the driver: hipMalloc / hipFree cost 0.1 - 1 ms each, hipFree
+// synchronises the device, and a contig of a many-contig assembly brings a dozen of each.  Only for memory whose owner
+// releases it after its last use has COMPLETED (a contig is freed by the caller after the polish calls returned, the
+// front end's temporaries after the read-back of their kernel's results): a cached block may be handed to any stream.
+struct DevCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_; // (device, bytes) -> blocks
+    size_t cached = 0;
+    static constexpr size_t LIMIT = 24ull << 30; // idle bytes kept; beyond that blocks go back to the driver
+    static size_t size_class(size_t bytes) { // four classes per octave (<= 25 % slack), at least 4 KiB
+        size_t b = std::max<size_t>(bytes, 4096);
+        unsigned lg = 63 - (unsigned)__builtin_clzll(b);
+        const size_t step = (size_t)1 << (lg > 2 ? lg - 2 : 0);
+        return (b + step - 1) & ~(step - 1);
+    }
+    void *get(size_t &bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bytes = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto it = free_.find({dev, bytes});
+            if (it != free_.end() && !it->second.empty()) {
+                void *p = it->second.back();
+                it->second.pop_back();
+                cached -= bytes;
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim(0); // (the idle blocks may be what is missing)
+            HIPCHK(hipMalloc(&p, bytes));
+        }
+        return p;
+    }
+    void put(void *p, size_t bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bool over;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            free_[{dev, bytes}].push_back(p);
+            cached += bytes;
+            over = cached > LIMIT;
+        }
+        if (over) trim(LIMIT / 2);
+    }
+    void trim(size_t keep) {
+        std::vector<std::pair<int, void *>> drop;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            for (auto it = free_.rbegin(); it != free_.rend() && cached > keep; ++it) // largest classes first
+                while (!it->second.empty() && cached > keep) {
+                    drop.emplace_back(it->first.first, it->second.back());
+                    it->second.pop_back();
+                    cached -= it->first.second;
+                }
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto &d : drop) {
+            (void)hipSetDevice(d.first);
+            (void)hipFree(d.second);
+        }
+        (void)hipSetDevice(cur);
+    }
+};
+inline DevCache &dev_cache() {
+    static DevCache *c = new DevCache(); // leaked on purpose: outlives every context
+    return *c;
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    bool cached = false;   // blocks come from / go back to dev_cache() (see there for when that is allowed)
+    size_t cache_bytes = 0;
     ~DevBuf() { release(); }
     void release() {
         if (p) {
-            if (Recorder *r = tl_recorder())
+            if (cached)
+                dev_cache().put(p, cache_bytes);
+            else if (Recorder *r = tl_recorder())
                 r->graveyard.push_back(p); // recorded, not yet issued commands may name it: freed after the next flush
             else
                 (void)hipFree(p);
@@ -53,8 +131,14 @@ template <class T> struct DevBuf {
         if (n > cap) {
             release();
             size_t want = n + n / 8 + 64;
-            HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-            cap = want;
+            if (cached) {
+                cache_bytes = want * sizeof(T);
+                p = (T *)dev_cache().get(cache_bytes);
+                cap = cache_bytes / sizeof(T);
+            } else {
+                HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+                cap = want;
+            }
         }
         return p;
     }
@@ -149,6 +233,10 @@ inline double now_ms() {
 using namespace np2h;
 
 struct np2_contig {
+    np2_contig() { // (a contig's blocks are cached: see DevCache)
+        reads.cached = nib.cached = refnib.cached = ck_off.cached = ckpt.cached = descs.cached = true;
+        tile_rd_off.cached = tile_rd.cached = true;
+    }
     uint32_t L = 0, R = 0;
     uint64_t nib_bytes = 0, n_cols = 0, n_ckpt = 0;
     DevBuf<np2_read_t> reads;
@@ -162,6 +250,10 @@ struct np2_contig {
     // reads overlapping each contig tile (ascending read index), CSR
     uint32_t n_tiles = 0;
     DevBuf<uint32_t> tile_rd_off, tile_rd;
+    // records a contig tile's bucket holds: sized by the deepest tile of this contig (a tile of 1024 positions under d
+    // reads is 1024 * d columns, of which about one per cent become exception records: room for 4 %), between 1024 and
+    // what a tile can sort inside LDS.  24 B per contig position at 30x instead of a flat 48; fuller tiles spill.
+    uint32_t tile_cap = TILE_CAP;
 };
 
 struct np2_ctx {

@@ -486,7 +486,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L, R = c->R, NCH = c->n_chunks;
     const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
-    const uint32_t bcap = cx->tile_cap;
+    const uint32_t bcap = std::min(cx->tile_cap, c->tile_cap); // (cx: the NP2_TILE_CAP test hook)
     const uint64_t buckets = (uint64_t)n_tiles * bcap;
     uint64_t ovf_cap = std::max<uint64_t>(c->n_cols / 256 + 65536, 1u << 18); // spill area of full buckets
     cx->tmp.ensure(prim_temp_bytes(std::max<size_t>((size_t)NCH + 2, (size_t)L + 2)));
@@ -1132,6 +1132,12 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         for (uint32_t r = 0; r < n_reads; ++r)
             if (!(reads[r].flags & NP2_READ_DROPPED))
                 for (uint32_t t = reads[r].aln_t_s >> TILE_SHIFT; t <= reads[r].aln_t_e >> TILE_SHIFT; ++t) trd[cur[t]++] = r;
+    }
+    {
+        uint32_t deepest = 0;
+        for (uint32_t t = 0; t < n_tiles; ++t) deepest = std::max(deepest, trd_off[t + 1] - trd_off[t]);
+        const uint64_t want = ((uint64_t)deepest * TILE / 24 + 255) & ~255ull; // ~4 % of the tile's columns
+        c->tile_cap = (uint32_t)std::min<uint64_t>(TILE_CAP, std::max<uint64_t>(1024, want));
     }
     hipStream_t s = cx->stream;
     c->L = L;

@@ -265,6 +265,7 @@ struct BgzfBatch {
     RawBuf buf; // inflated bytes not yet consumed (+ the current batch)
     size_t pos = 0;
     bool eof = false;
+    double ms_read = 0, ms_inflate = 0, ms_drop = 0; // where the refills' time goes (NP2_IO_PROFILE)
     size_t batch_blocks = 2048; // 64 KiB blocks per refill: 128 MiB of inflated BAM, all inflated in parallel
     bool read_raw(Blk &b) {
         uint8_t hd[18];
@@ -304,6 +305,7 @@ struct BgzfBatch {
     }
     void fill(size_t n_blocks) {
         if (eof) return;
+        const double t_f0 = np2h::now_ms();
         if (pos) { // drop consumed bytes (blocks that lie entirely before the new front leave the index)
             size_t keep = 0;
             while (keep + 1 < blk_index.size() && blk_index[keep + 1].first <= (int64_t)pos) ++keep;
@@ -312,6 +314,7 @@ struct BgzfBatch {
             buf.drop_front(pos);
             pos = 0;
         }
+        const double t_f1 = np2h::now_ms();
         std::vector<Blk> blks;
         size_t total = 0;
         for (size_t i = 0; i < n_blocks; ++i) {
@@ -327,6 +330,7 @@ struct BgzfBatch {
         const size_t base = buf.size();
         buf.resize(base + total);
         for (auto &bk : blks) blk_index.emplace_back((int64_t)(base + bk.out_off), bk.file_off);
+        const double t_f2 = np2h::now_ms();
         std::atomic<int> bad{0};
         IoPool::get().parallel_for(blks.size(), (unsigned)std::max<size_t>(1, blks.size() / 2), [&](size_t i) {
             if (!blks[i].isize) return;
@@ -345,6 +349,7 @@ struct BgzfBatch {
             if (rc != Z_STREAM_END) bad.store(1);
         });
         if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
+        ms_drop += t_f1 - t_f0, ms_read += t_f2 - t_f1, ms_inflate += np2h::now_ms() - t_f2;
     }
     // pointer to n contiguous bytes (nullptr on clean EOF before the first byte)
     const uint8_t *take(size_t n) {
@@ -488,6 +493,7 @@ struct FrontWork {
 void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_bamrec_t *recs, uint32_t n_recs,
                  const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes, const np2_front_opts_t *o,
                  const ShardSpec *sp, FrontWork &fw) {
+    const double t_a0 = np2h::now_ms();
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t s = cx->stream;
     const uint32_t L_glob = L_in;                        // the contig (clip policy, contig-end checks)
@@ -569,6 +575,10 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
     }
     const uint32_t n = (uint32_t)frec.size();
     const uint64_t nib_bytes = out_off + 64;
+    const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
+    const double t_b0 = np2h::now_ms();
+    double t_b1 = t_b0, t_b2 = t_b0;
+    if (prof) fprintf(stderr, "  front_begin: admission + CIGAR prefix sums %.2f ms\n", t_b0 - t_a0);
 
     np2_contig *c = fw.c = new np2_contig();
     {
@@ -577,6 +587,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
         np2h::DevBuf<FrontRec> d_rec;
         np2h::DevBuf<FrontOp> d_ops;
         np2h::DevBuf<FrontOut> d_out;
+        d_ref.cached = d_seq.cached = d_rec.cached = d_ops.cached = d_out.cached = true; // (released after the read-back below)
         d_ref.ensure(L + 16);
         HIPCHK(hipMemcpyAsync(d_ref.p, ref, L, hipMemcpyHostToDevice, s));
         launch_pack_ref(s, d_ref.p, L, c->nib.p);
@@ -586,6 +597,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
             d_rec.ensure(n);
             d_ops.ensure(fops.size() + 1);
             d_out.ensure(n);
+            t_b1 = np2h::now_ms();
             HIPCHK(hipMemcpyAsync(d_seq.p, seq4, seq4_bytes, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(d_rec.p, frec.data(), (size_t)n * sizeof(FrontRec), hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(d_ops.p, fops.data(), fops.size() * sizeof(FrontOp), hipMemcpyHostToDevice, s));
@@ -594,6 +606,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
                 launch_columnarise(s, d_rec.p, n, d_ops.p, d_ref.p, d_seq.p, c->nib.p, d_out.p);
             }
             fout = np2h::d2h(cx, d_out.p, n);
+            t_b2 = np2h::now_ms();
         } else {
             HIPCHK(hipStreamSynchronize(s));
         }
@@ -645,9 +658,13 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
         fw.nib_bytes = nib_bytes;
         fw.L = L, fw.L_glob = L_glob, fw.sub_lo = sub_lo;
     }
+    if (prof)
+        fprintf(stderr, "  front_begin: device allocations %.2f ms, H2D + columnarise + read-back %.2f ms, keep/drop + temp frees %.2f ms\n",
+                t_b1 - t_b0, t_b2 - t_b1, np2h::now_ms() - t_b2);
 }
 
 void front_finish(np2_ctx *cx, FrontWork &fw, np2_contig **out) {
+    const double t_c0 = np2h::now_ms();
     np2_contig *c = fw.c;
     std::vector<np2_read_t> &reads = fw.reads;
     std::vector<uint8_t> &lable = fw.lable;
@@ -694,7 +711,11 @@ void front_finish(np2_ctx *cx, FrontWork &fw, np2_contig **out) {
                 np2h::h2d_staged(cx, c->nib.p + reads[i].nib_off, &ff, 1);
             }
         }
+        const double t_c1 = np2h::now_ms();
         np2h::finish_contig(cx, c, reads.data(), (uint32_t)reads.size(), L, nib_bytes);
+        if (getenv("NP2_IO_PROFILE"))
+            fprintf(stderr, "  front_finish: clip filter %.2f ms, finish_contig (descriptors, tile read lists, uploads) %.2f ms\n",
+                    t_c1 - t_c0, np2h::now_ms() - t_c1);
     }
     fw.c = nullptr; // handed over
     *out = c;
@@ -1105,12 +1126,15 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         PinnedBytes &seq4 = bam->seq4;
         const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
         const double t_p0 = np2h::now_ms();
+        bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = 0;
         fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr);
         const double t_p1 = np2h::now_ms();
         contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
         if (prof)
-            fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (%zu records, %zu SEQ bytes), records->pileup %.2f ms\n",
-                    name, t_p1 - t_p0, recs.size(), seq4.size(), np2h::now_ms() - t_p1);
+            fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (block reads %.2f, inflate %.2f, buffer moves %.2f; %zu records, "
+                            "%zu SEQ bytes), records->pileup %.2f ms\n",
+                    name, t_p1 - t_p0, bam->batch.ms_read, bam->batch.ms_inflate, bam->batch.ms_drop, recs.size(), seq4.size(),
+                    np2h::now_ms() - t_p1);
         np2h::flush_timings(cx);
     } catch (const np2h::Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);
