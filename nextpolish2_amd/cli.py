@@ -224,10 +224,6 @@ def main(argv=None):
         a.device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
     if distributed:
         out = _init_distributed(a)  # process group first; the output-file verdict is rank 0's, shared with everyone
-    t_y = time.time()
-    yaks = sorted((np2io.load_yak(y) for y in a.yak), key=lambda y: y.k)  # option.rs:238
-    if prof:
-        print(f"[np2 profile] yak files loaded {time.time() - t_y:.3f} s", file=sys.stderr)
     # main.rs:1547 compares the raw option with "ref" (case-sensitive)
     opts = Opts(min_kmer_count=a.min_kmer_count, max_indel_len=a.max_indel_len, iter_count=a.iter_count,
                 model=a.model, use_all_reads=a.use_all_reads)
@@ -236,28 +232,58 @@ def main(argv=None):
                             min_map_fra=map_fra, min_map_qual=a.min_map_qual,
                             max_clip_len=a.max_clip_len, use_supplementary=a.use_supplementary,
                             use_secondary=a.use_secondary)
+
+    def load_yaks():
+        t_y = time.time()
+        with ThreadPoolExecutor(max_workers=max(1, len(a.yak))) as ex:  # (the loader runs outside the GIL: one thread per dump)
+            ys = sorted(ex.map(np2io.load_yak, a.yak), key=lambda y: y.k)  # option.rs:238
+        if prof:
+            print(f"[np2 profile] yak files loaded {time.time() - t_y:.3f} s (at +{time.time() - t0:.3f} s)", file=sys.stderr)
+        return ys
+
+    if distributed:
+        return _main_distributed(a, argv, t0, out, load_yaks(), opts, fopts)
+
+    # Three stages, each on its own threads, a contig moving through them in input order:
+    #   front end  (a.thread capped at 3 threads, each with a table-less context and its own BAM handle): BGZF inflate +
+    #              record walk on the host pool, admission, H2D, GPU columnariser -> the contig's pileup resident in HBM;
+    #   polish     (up to 4 contexts sharing ONE copy of the k-mer tables): np2_polish_resident, record formatting;
+    #   output     (this thread): records written in input order.
+    # The k-mer dumps are loaded and their HBM tables built next to the first front ends — a resident pileup does not
+    # depend on them —, so a run starts reading alignments at once instead of after the tables (main.rs:1698-1853: the
+    # reference's reader / workers / writer threads around two bounded channels).
     n_workers = max(1, min(4, a.thread))
+    n_front = max(1, min(3, a.thread))
     tls = threading.local()
     base, base_lock = [], threading.Lock()
-    if distributed:
-        return _main_distributed(a, argv, t0, out, yaks, opts, fopts)
+    yak_pool = ThreadPoolExecutor(max_workers=2)
+    yak_future = yak_pool.submit(load_yaks)  # host only; the device is not touched before a contig needs polishing
+    base_future = []
 
-    def polish(name, seq):
-        """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
-        if getattr(tls, "pol", None) is None:
-            with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
-                if not base:
-                    t_b = time.time()
-                    base.append(Polisher(yaks, device=a.device))
-                    tls.pol = base[0]
-                    if prof:
-                        print(f"[np2 profile] first context + k-mer tables in HBM {time.time() - t_b:.3f} s "
-                              f"(at +{time.time() - t0:.3f} s)", file=sys.stderr)
-                else:
-                    tls.pol = base[0].clone()
+    def build_base():
+        ys = yak_future.result()
+        t_b = time.time()
+        pol = Polisher(ys, device=a.device)
+        if prof:
+            print(f"[np2 profile] k-mer tables in HBM {time.time() - t_b:.3f} s (at +{time.time() - t0:.3f} s)", file=sys.stderr)
+        return pol
+
+    def front(name, seq):
+        """the contig's pileup, resident in HBM (np2_contig_from_bam) — on this thread's table-less context"""
+        if getattr(tls, "fpol", None) is None:
+            tls.fpol = Polisher([], device=a.device)
             tls.bam = np2io.Bam(a.bam)
-        contig = np2io.contig_from_bam(tls.pol, tls.bam, name, seq, fopts)
+        return np2io.contig_from_bam(tls.fpol, tls.bam, name, seq, fopts)
+
+    def polish(name, fut):
+        """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
+        contig = fut.result()
         try:
+            if getattr(tls, "pol", None) is None:
+                b0 = base_future[0].result()
+                with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
+                    tls.pol = b0 if not base else b0.clone()
+                    base.append(tls.pol)
             bases, pos = tls.pol.polish_resident(contig, opts, want_pos=a.out_pos)
         finally:
             contig.free()
@@ -269,7 +295,7 @@ def main(argv=None):
         return b">%s start:%d end:%d\n%s\n" % (name.encode(), pos[0], pos[1], b)
 
     try:
-        with ThreadPoolExecutor(max_workers=n_workers) as pool:
+        with ThreadPoolExecutor(max_workers=n_front) as fpool, ThreadPoolExecutor(max_workers=n_workers) as pool:
             pending = []  # records in input order: bytes or futures
 
             def drain(keep):
@@ -287,13 +313,17 @@ def main(argv=None):
                     else:
                         pending.append(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
                 else:
-                    pending.append(pool.submit(polish, name, seq))
-                drain(2 * n_workers)  # bounded look-ahead: at most 2 x workers contigs held in memory
+                    if not base_future:  # the first contig to polish: tables into HBM next to its front end
+                        base_future.append(yak_pool.submit(build_base))
+                    pending.append(pool.submit(polish, name, fpool.submit(front, name, seq)))
+                drain(2 * n_workers + n_front)  # bounded look-ahead: that many contigs held in memory at most
             drain(0)
         out.flush()
+        yak_future.result()  # (an assembly of pass-through contigs only: a broken dump must still be reported)
         if prof:
             print(f"[np2 profile] all contigs written at +{time.time() - t0:.3f} s", file=sys.stderr)
     finally:
+        yak_pool.shutdown(wait=False)
         if out is not None and out is not sys.stdout.buffer:
             out.close()
     print(resource_str(t0, ["nextPolish2"] + argv, cpu0), file=sys.stderr)

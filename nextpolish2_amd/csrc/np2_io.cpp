@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <zlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -244,9 +247,14 @@ struct RawBuf {
 // Reads BGZF blocks in batches and inflates each batch with several host threads (blocks are independent).
 struct BgzfBatch {
     FILE *f = nullptr;
+    // the file mapped read-only: a block's deflate payload is inflated straight out of the page cache (reading 35 MB of
+    // blocks with two freads each was 9 of the 19 ms the records of an E. coli-sized contig took to arrive); the pages
+    // are first touched by the inflating threads, in parallel
+    const uint8_t *map = nullptr;
+    size_t map_len = 0, fpos = 0;
     struct Blk {
-        std::vector<uint8_t> c; // raw deflate payload
-        uint32_t isize = 0;
+        const uint8_t *c = nullptr; // raw deflate payload (inside the mapping)
+        uint32_t clen = 0, isize = 0;
         size_t out_off = 0;
         uint64_t file_off = 0; // offset of the block in the file
     };
@@ -268,34 +276,33 @@ struct BgzfBatch {
     double ms_read = 0, ms_inflate = 0, ms_drop = 0; // where the refills' time goes (NP2_IO_PROFILE)
     size_t batch_blocks = 2048; // 64 KiB blocks per refill: 128 MiB of inflated BAM, all inflated in parallel
     bool read_raw(Blk &b) {
-        uint8_t hd[18];
-        b.file_off = (uint64_t)ftello(f);
-        const size_t n = fread(hd, 1, 18, f);
-        if (n == 0) return false;
-        if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
-            throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+        if (fpos >= map_len) return false;
+        if (map_len - fpos < 18) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+        const uint8_t *hd = map + fpos;
+        b.file_off = fpos;
+        if (hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
         const uint32_t xlen = hd[10] | (hd[11] << 8);
-        std::vector<uint8_t> extra(xlen);
-        memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6)
-            throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF header");
+        if (map_len - fpos < 12 + (size_t)xlen) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF header");
+        const uint8_t *extra = hd + 12;
         uint32_t bsize = 0;
         for (size_t p = 0; p + 4 <= xlen;) {
             const uint32_t slen = extra[p + 2] | (extra[p + 3] << 8);
-            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
             p += 4 + slen;
         }
         if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+        if (bsize < 12 + xlen + 8 || map_len - fpos < bsize) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
         const size_t clen = bsize - 12 - xlen - 8;
-        b.c.resize(clen + 8);
-        if (fread(b.c.data(), 1, clen + 8, f) != clen + 8) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
-        b.isize = b.c[clen + 4] | (b.c[clen + 5] << 8) | (b.c[clen + 6] << 16) | ((uint32_t)b.c[clen + 7] << 24);
-        b.c.resize(clen);
+        b.c = hd + 12 + xlen;
+        b.clen = (uint32_t)clen;
+        const uint8_t *tail = b.c + clen;
+        b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        fpos += bsize;
         return true;
     }
     // start at a virtual offset
     void seek(uint64_t voffset) {
-        fseeko(f, (off_t)(voffset >> 16), SEEK_SET);
+        fpos = (size_t)(voffset >> 16);
         buf.clear();
         blk_index.clear();
         pos = 0;
@@ -340,8 +347,8 @@ struct BgzfBatch {
                 bad.store(1);
                 return;
             }
-            zs.next_in = blks[i].c.data();
-            zs.avail_in = (uInt)blks[i].c.size();
+            zs.next_in = const_cast<Bytef *>(blks[i].c);
+            zs.avail_in = (uInt)blks[i].clen;
             zs.next_out = buf.data() + base + blks[i].out_off;
             zs.avail_out = blks[i].isize;
             const int rc = inflate(&zs, Z_FINISH);
@@ -386,7 +393,52 @@ template <class T> struct PinnedAlloc {
     template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
     template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
 };
-typedef std::vector<uint8_t, PinnedAlloc<uint8_t>> PinnedBytes;
+// growable byte buffer in pinned host memory WITHOUT value-initialisation (std::vector::resize zero-fills what the
+// record copies overwrite a moment later: 69 MB of SEQ per E. coli-sized contig)
+struct PinnedBytes {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    PinnedBytes() = default;
+    PinnedBytes(const PinnedBytes &) = delete;
+    PinnedBytes &operator=(const PinnedBytes &) = delete;
+    ~PinnedBytes() {
+        if (p) (void)hipHostFree(p);
+    }
+    size_t size() const { return n; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    void clear() { n = 0; }
+    void reserve(size_t m) {
+        if (m <= cap) return;
+        const size_t want = std::max(m, cap + cap / 2 + (1u << 20));
+        void *q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+        if (n) memcpy(q, p, n);
+        if (p) (void)hipHostFree(p);
+        p = (uint8_t *)q;
+        cap = want;
+    }
+    void resize(size_t m) { // (new bytes are NOT initialised)
+        reserve(m);
+        n = m;
+    }
+    void resize(size_t m, uint8_t fill) {
+        const size_t old = n;
+        resize(m);
+        if (m > old) memset(p + old, fill, m - old);
+    }
+    void push_back(uint8_t b) {
+        if (n == cap) reserve(n + 1);
+        p[n++] = b;
+    }
+    void append(const uint8_t *src, size_t k) {
+        reserve(n + k);
+        memcpy(p + n, src, k);
+        n += k;
+    }
+    uint8_t &back() { return p[n - 1]; }
+    uint8_t &operator[](size_t i) { return p[i]; }
+};
 
 struct np2_fasta {
     Fasta f;
@@ -408,6 +460,8 @@ struct np2_bam {
     std::unordered_map<std::string, SecSeq> sec;
     PinnedBytes seq4; // SEQ staging of the contig being read (capacity kept across contigs)
     BgzfBatch batch;  // batch inflater (its buffer is reused from contig to contig)
+    const uint8_t *map = nullptr; // the whole file, mapped read-only (BgzfBatch inflates out of it)
+    size_t map_len = 0;
 };
 
 namespace {
@@ -442,6 +496,7 @@ void load_secondary_seqs(np2_bam *bam) {
     for (int pass = 0; pass < 2; ++pass) {
         BgzfBatch z;
         z.f = bam->z.f;
+        z.map = bam->map, z.map_len = bam->map_len;
         z.seek(bam->first_rec);
         for (;;) {
             const uint8_t *h4 = z.take(4);
@@ -501,78 +556,136 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
     const uint32_t L = sp ? sp->sub_hi - sp->sub_lo : L_in; // the (sub-)contig the pileup is built on
     const uint8_t *ref = ref_glob + sub_lo;
     if (L < 3) throw np2h::Np2Error(NP2_E_ARG, "contig too short");
+    // Admission + fill_with_cigar bookkeeping, in three steps over the host pool: (1) every record on its own — the
+    // admission predicate (main.rs:1758-1771), the number of column-producing CIGAR ops, alignment columns, clipping;
+    // (2) a prefix sum over the admitted records places their ops and their nibble slots; (3) the ops are written.  (One
+    // thread walking 2 M CIGAR ops of an E. coli-sized contig was 3 of the 6.5 ms between the records and the pileup.)
+    struct Pre {
+        uint8_t admit = 0, is_clip = 0;
+        int err = 0; // first offending condition of this record (NP2_E_*), message below
+        const char *msg = nullptr;
+        uint32_t n_ops = 0, col = 0;
+    };
+    std::vector<Pre> pre(n_recs);
+    IoPool::get().parallel_for(((size_t)n_recs + 255) / 256, 64, [&](size_t blk) {
+        for (uint32_t i = (uint32_t)blk * 256; i < std::min<uint64_t>(n_recs, ((uint64_t)blk + 1) * 256); ++i) {
+            const np2_bamrec_t &r = recs[i];
+            const uint32_t *cg = cigar + r.cigar_off;
+            Pre &q = pre[i];
+            uint64_t rlen = 0;
+            int64_t span = 0;
+            for (uint32_t k = 0; k < r.n_cigar; ++k) { // seq_len_from_cigar(true) / reference_end - reference_start
+                const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8 || op == 5) rlen += l;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += l;
+            }
+            const bool secondary = r.flag & 0x100, supplementary = r.flag & 0x800;
+            const int64_t need = std::max<int64_t>((int64_t)o->min_map_len, (int64_t)((float)rlen * o->min_map_fra));
+            if ((r.flag & 0x404) != 0 || (int16_t)r.mapq <= o->min_map_qual || rlen <= o->min_read_len ||
+                (secondary && !o->use_secondary) || (supplementary && !o->use_supplementary) || span < need)
+                continue;
+            // (-S: the record's SEQ must already be the one recovered from the read's primary alignment, main.rs:1775-1789;
+            // np2_contig_from_bam does that, a caller of np2_contig_from_records passes it in)
+            auto fail = [&](int code, const char *m) { q.err = code, q.msg = m; };
+            if (r.pos < 0 || (uint32_t)r.pos > L_glob) { fail(NP2_E_REFPANIC, "reference would panic: record start outside the contig"); continue; }
+            if (sp && (uint32_t)r.pos < sub_lo) { fail(NP2_E_ARG, "shard: record starts before the sub-contig"); continue; }
+            // fill_with_cigar bookkeeping (main.rs:390-439): query clipping, columns
+            uint32_t qs = 0, ts = 0, col = 0, aln_q_s = 0, aln_q_e = 0, n_ops = 0;
+            bool is_first = true, bad_op = false;
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
+                switch (op) {
+                case 4:
+                    qs += l;
+                    if (is_first) aln_q_s = qs; else aln_q_e = qs - l;
+                    break;
+                case 0: case 7: case 8:
+                    n_ops += l ? 1u : 0u;
+                    col += l, qs += l, ts += l;
+                    break;
+                case 1:
+                    n_ops += l ? 1u : 0u;
+                    col += l, qs += l;
+                    break;
+                case 2:
+                    n_ops += l ? 1u : 0u;
+                    col += l, ts += l;
+                    break;
+                case 5:
+                    break;
+                default:
+                    bad_op = true;
+                }
+                if (bad_op) break;
+                is_first = false;
+            }
+            if (bad_op) { fail(NP2_E_REFPANIC, "reference would panic: Unknown cigar"); continue; }
+            if (aln_q_e == 0) aln_q_e = qs;
+            if (qs > r.l_seq) {
+                fail(NP2_E_REFPANIC, secondary ? "reference would panic: no (or too short a) primary SEQ for a secondary alignment"
+                                               : "reference would panic: SEQ shorter than CIGAR");
+                continue;
+            }
+            if ((uint64_t)r.pos + ts > L_glob) { fail(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end"); continue; }
+            if (sp && (uint64_t)r.pos + ts > sp->sub_hi) { fail(NP2_E_ARG, "shard: record ends behind the sub-contig"); continue; }
+            if (r.seq_off + ((uint64_t)r.l_seq + 1) / 2 > seq4_bytes) { fail(NP2_E_ARG, "SEQ outside the buffer"); continue; }
+            q.admit = 1;
+            q.n_ops = n_ops, q.col = col;
+            q.is_clip = aln_q_e - aln_q_s + o->max_clip_len < (uint32_t)rlen; // main.rs:1796-1797
+        }
+    });
     std::vector<FrontRec> frec;
-    std::vector<FrontOp> fops;
     std::vector<Admitted> adm;
     uint64_t out_off = ((((uint64_t)L + 1) >> 1) + 1 + 15) & ~15ull; // slot 0 = the contig itself
-    for (uint32_t i = 0; i < n_recs; ++i) {
-        const np2_bamrec_t &r = recs[i];
-        const uint32_t *cg = cigar + r.cigar_off;
-        uint64_t rlen = 0;
-        int64_t span = 0;
-        for (uint32_t k = 0; k < r.n_cigar; ++k) { // seq_len_from_cigar(true) / reference_end - reference_start
-            const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
-            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8 || op == 5) rlen += l;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += l;
-        }
-        const bool secondary = r.flag & 0x100, supplementary = r.flag & 0x800;
-        const int64_t need = std::max<int64_t>((int64_t)o->min_map_len, (int64_t)((float)rlen * o->min_map_fra));
-        if ((r.flag & 0x404) != 0 || (int16_t)r.mapq <= o->min_map_qual || rlen <= o->min_read_len ||
-            (secondary && !o->use_secondary) || (supplementary && !o->use_supplementary) || span < need)
-            continue;
-        // (-S: the record's SEQ must already be the one recovered from the read's primary alignment, main.rs:1775-1789;
-        // np2_contig_from_bam does that, a caller of np2_contig_from_records passes it in)
-        if (r.pos < 0 || (uint32_t)r.pos > L_glob) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: record start outside the contig");
-        if (sp && (uint32_t)r.pos < sub_lo) throw np2h::Np2Error(NP2_E_ARG, "shard: record starts before the sub-contig");
-        // fill_with_cigar bookkeeping (main.rs:390-439): query clipping, op prefix sums
-        uint32_t qs = 0, ts = 0, col = 0, aln_q_s = 0, aln_q_e = 0;
-        bool is_first = true;
+    uint64_t n_fops = 0;
+    for (uint32_t i = 0; i < n_recs; ++i) { // (the first offending record in file order speaks, as in a sequential walk)
+        const Pre &q = pre[i];
+        if (q.err) throw np2h::Np2Error(q.err, q.msg);
+        if (!q.admit) continue;
         FrontRec fr;
-        fr.pos = (uint32_t)r.pos - sub_lo;
-        fr.op_off = fops.size();
-        fr.seq_off = r.seq_off;
-        for (uint32_t k = 0; k < r.n_cigar; ++k) {
-            const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
-            switch (op) {
-            case 4:
-                qs += l;
-                if (is_first) aln_q_s = qs; else aln_q_e = qs - l;
-                break;
-            case 0: case 7: case 8:
-                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | op});
-                col += l, qs += l, ts += l;
-                break;
-            case 1:
-                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | 1u});
-                col += l, qs += l;
-                break;
-            case 2:
-                if (l) fops.push_back(FrontOp{col, qs, ts, (l << 4) | 2u});
-                col += l, ts += l;
-                break;
-            case 5:
-                break;
-            default:
-                throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: Unknown cigar");
-            }
-            is_first = false;
-        }
-        if (aln_q_e == 0) aln_q_e = qs;
-        if (qs > r.l_seq)
-            throw np2h::Np2Error(NP2_E_REFPANIC, secondary ? "reference would panic: no (or too short a) primary SEQ for a secondary alignment"
-                                                           : "reference would panic: SEQ shorter than CIGAR");
-        if ((uint64_t)r.pos + ts > L_glob) throw np2h::Np2Error(NP2_E_REFPANIC, "reference would panic: alignment runs past the contig end");
-        if (sp && (uint64_t)r.pos + ts > sp->sub_hi) throw np2h::Np2Error(NP2_E_ARG, "shard: record ends behind the sub-contig");
-        if (r.seq_off + ((uint64_t)r.l_seq + 1) / 2 > seq4_bytes) throw np2h::Np2Error(NP2_E_ARG, "SEQ outside the buffer");
-        fr.n_ops = (uint32_t)(fops.size() - fr.op_off);
-        fr.n_cols = col;
+        fr.pos = (uint32_t)recs[i].pos - sub_lo;
+        fr.op_off = n_fops;
+        fr.seq_off = recs[i].seq_off;
+        fr.n_ops = q.n_ops;
+        fr.n_cols = q.col;
         fr.pad = 0;
         fr.out_off = out_off;
-        out_off += ((((uint64_t)col + 1) >> 1) + 1 + 15) & ~15ull;
-        const bool is_clip = aln_q_e - aln_q_s + o->max_clip_len < (uint32_t)rlen; // main.rs:1796-1797
-        adm.push_back(Admitted{i, is_clip, col});
+        n_fops += q.n_ops;
+        out_off += ((((uint64_t)q.col + 1) >> 1) + 1 + 15) & ~15ull;
+        adm.push_back(Admitted{i, q.is_clip != 0, q.col});
         frec.push_back(fr);
     }
+    std::vector<FrontOp> fops(n_fops);
+    IoPool::get().parallel_for((frec.size() + 63) / 64, 64, [&](size_t blk) {
+        for (size_t a = blk * 64; a < std::min(frec.size(), (blk + 1) * 64); ++a) {
+            const np2_bamrec_t &r = recs[adm[a].rec];
+            const uint32_t *cg = cigar + r.cigar_off;
+            FrontOp *dst = fops.data() + frec[a].op_off;
+            uint32_t qs = 0, ts = 0, col = 0;
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                const uint32_t l = cg[k] >> 4, op = cg[k] & 15;
+                switch (op) {
+                case 4:
+                    qs += l;
+                    break;
+                case 0: case 7: case 8:
+                    if (l) *dst++ = FrontOp{col, qs, ts, (l << 4) | op};
+                    col += l, qs += l, ts += l;
+                    break;
+                case 1:
+                    if (l) *dst++ = FrontOp{col, qs, ts, (l << 4) | 1u};
+                    col += l, qs += l;
+                    break;
+                case 2:
+                    if (l) *dst++ = FrontOp{col, qs, ts, (l << 4) | 2u};
+                    col += l, ts += l;
+                    break;
+                default:
+                    break;
+                }
+            }
+        }
+    });
     const uint32_t n = (uint32_t)frec.size();
     const uint64_t nib_bytes = out_off + 64;
     const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
@@ -747,6 +860,7 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
         if (start_off != ~0ull) {
             BgzfBatch &z = bam->batch;
             z.f = bam->z.f;
+            z.map = bam->map, z.map_len = bam->map_len;
             z.seek(start_off);
             // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
             // length fields finds this contig's records, a prefix sum places their CIGAR words and SEQ bytes, and the
@@ -866,7 +980,7 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                                 append_seq4(seq4, it->second.seq4.data(), it->second.len, (flag & 0x10) != 0);
                             }
                         } else {
-                            seq4.insert(seq4.end(), ps, ps + ((size_t)q.l_seq + 1) / 2);
+                            seq4.append(ps, ((size_t)q.l_seq + 1) / 2);
                         }
                         recs[r0 + i] = r;
                     }
@@ -956,29 +1070,42 @@ int np2_yak_load(const char *path, np2_yak_t *out) try {
         return io_fail(NP2_E_UNSUPPORTED, "yak prefix bits too large");
     }
     const size_t nb = (size_t)1 << pre;
-    std::vector<uint64_t> words;
+    // every word of the file is read ONCE, straight into the array that is handed out (the file's size bounds it): a
+    // human-scale dump is tens of GB, and the command line loads its dumps while the first contigs are being read
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) {
+        fclose(f);
+        return io_fail(NP2_E_ARG, std::string("cannot stat ") + path);
+    }
+    const size_t max_words = (size_t)st.st_size / 8 + 1;
+    uint64_t *w = (uint64_t *)malloc(max_words * 8);
     uint64_t *off = (uint64_t *)malloc((nb + 1) * 8);
+    if (!w || !off) {
+        fclose(f);
+        free(w);
+        free(off);
+        return io_fail(NP2_E_NOMEM, "out of memory loading the k-mer dump");
+    }
     off[0] = 0;
+    size_t have = 0;
     for (size_t b = 0; b < nb; ++b) {
         uint8_t h8[8];
         if (fread(h8, 1, 8, f) != 8) {
             fclose(f);
             free(off);
+            free(w);
             return io_fail(NP2_E_ARG, "Failed to parse the dump file");
         }
         const uint32_t n = le32(h8 + 4); // first u32 (capacity bits) is ignored like the reference (kmer.rs:143-147)
-        const size_t base = words.size();
-        words.resize(base + n);
-        const size_t got = fread(words.data() + base, 8, n, f);
-        words.resize(base + got); // UnexpectedEof ends the bucket (kmer.rs:151-155)
-        off[b + 1] = words.size();
+        const size_t want = std::min<size_t>(n, max_words - have);
+        const size_t got = fread(w + have, 8, want, f);
+        have += got; // UnexpectedEof ends the bucket (kmer.rs:151-155)
+        off[b + 1] = have;
     }
     fclose(f);
-    uint64_t *w = (uint64_t *)malloc((words.size() + 1) * 8);
-    memcpy(w, words.data(), words.size() * 8);
     out->k = k;
     out->pre = pre;
-    out->n_words = words.size();
+    out->n_words = have;
     out->words = w;
     out->bucket_off = off;
     return NP2_OK;
@@ -1022,6 +1149,14 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
         b->ref_start.assign(n_ref, ~0ull);
         b->lin.assign(n_ref, {});
         b->first_rec = b->z.tell();
+        {
+            struct stat st;
+            if (fstat(fileno(b->z.f), &st) != 0) throw np2h::Np2Error(NP2_E_ARG, std::string("cannot stat ") + path);
+            b->map_len = (size_t)st.st_size;
+            void *m = b->map_len ? mmap(nullptr, b->map_len, PROT_READ, MAP_SHARED, fileno(b->z.f), 0) : nullptr;
+            if (m == MAP_FAILED) throw np2h::Np2Error(NP2_E_NOMEM, std::string("cannot map ") + path);
+            b->map = (const uint8_t *)m;
+        }
         // index: <path>.bai or <stem>.bai
         std::string p1 = std::string(path) + ".bai", p2 = path;
         if (p2.size() > 4 && p2.substr(p2.size() - 4) == ".bam") p2 = p2.substr(0, p2.size() - 4) + ".bai";
@@ -1067,10 +1202,12 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
             b->ref_start[r] = best;
         }
     } catch (const np2h::Np2Error &e) {
+        if (b->map) munmap(const_cast<uint8_t *>(b->map), b->map_len);
         if (b->z.f) fclose(b->z.f);
         delete b;
         return io_fail(e.code, e.what());
     } catch (const std::exception &ex) {
+        if (b->map) munmap(const_cast<uint8_t *>(b->map), b->map_len);
         if (b->z.f) fclose(b->z.f);
         delete b;
         return io_fail(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what());
@@ -1080,6 +1217,7 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
 }
 void np2_bam_close(np2_bam_t *b) {
     if (!b) return;
+    if (b->map) munmap(const_cast<uint8_t *>(b->map), b->map_len);
     if (b->z.f) fclose(b->z.f);
     delete b;
 }

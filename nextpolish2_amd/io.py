@@ -98,16 +98,17 @@ def read_fasta(path):
 
 def load_yak(path):
     """yak v2 dump -> Yak (src/utils/kmer.rs:72-170)."""
+    import weakref
     L = _bind()
     y = np2_yak_t()
     _io_check(L.np2_yak_load(path.encode(), C.byref(y)))
-    try:
-        nb = (1 << y.pre) + 1
-        off = np.ctypeslib.as_array(y.bucket_off, shape=(nb,)).copy()
-        words = np.ctypeslib.as_array(y.words, shape=(max(int(y.n_words), 1),))[: int(y.n_words)].copy()
-        return Yak(y.k, words, off, pre=y.pre)
-    finally:
-        L.np2_yak_free(C.byref(y))
+    nb = (1 << y.pre) + 1
+    off = np.ctypeslib.as_array(y.bucket_off, shape=(nb,)).copy()
+    # the words are used where the loader put them (no second copy of a dump of tens of GB): np2_yak_free runs when the
+    # array is collected
+    base = np.ctypeslib.as_array(y.words, shape=(max(int(y.n_words), 1),))
+    weakref.finalize(base, L.np2_yak_free, y)
+    return Yak(y.k, base[: int(y.n_words)], off, pre=y.pre)
 
 
 def write_yak(path, yak):
