@@ -44,8 +44,19 @@ class Np2Error(RuntimeError):
         self.code = code
 
 
+_LIB_LOCK = __import__("threading").Lock()
+
+
 def lib():
     """Load libnp2_hip.so; raises loudly if the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LIB_LOCK:
+        return _lib_locked()
+
+
+def _lib_locked():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):

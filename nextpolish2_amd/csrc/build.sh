@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=${NP2_ARCH:-gfx950}
-FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-omit-frame-pointer"
 SRCS="np2_dense.hip np2_kernels.hip np2_graph.hip np2_cand.hip np2_regions.hip np2_front.hip np2_prims.hip np2_host.cpp np2_io.cpp np2_batch.cpp"
 mkdir -p obj
 pids=()
@@ -25,5 +25,5 @@ done
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 [ $rc = 0 ] || { echo "build failed"; exit 1; }
-hipcc --offload-arch=$ARCH -shared -fPIC -o ../libnp2_hip.so "${objs[@]}" -lz -lpthread
+hipcc --offload-arch=$ARCH -shared -fPIC -o ../libnp2_hip.so "${objs[@]}" -lz -lpthread -rdynamic
 echo "built nextpolish2_amd/libnp2_hip.so"

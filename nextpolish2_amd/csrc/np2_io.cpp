@@ -999,6 +999,30 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
 
 } // namespace
 
+// NP2_SEGV_TRACE=1: print the native stack of a crashing thread (field debugging; off by default)
+#include <execinfo.h>
+#include <signal.h>
+namespace {
+void np2_segv_handler(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "np2: fatal signal, native stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct SegvTraceInit {
+    SegvTraceInit() {
+        if (getenv("NP2_SEGV_TRACE")) {
+            signal(SIGSEGV, np2_segv_handler);
+            signal(SIGBUS, np2_segv_handler);
+            signal(SIGABRT, np2_segv_handler);
+        }
+    }
+} g_segv_trace_init;
+} // namespace
+
 extern "C" {
 
 const char *np2_io_last_error(void) { return g_io_err.c_str(); }

@@ -39,10 +39,27 @@ class FrontOpts:
 _BOUND = False
 
 
+_BIND_LOCK = __import__("threading").Lock()
+
+
 def _bind():
+    """The library with the argument types of include/np2_io.h declared.  Under a lock: the command line's stages call in
+    from several threads at start-up, and a function called while another thread is still declaring its argtypes gets
+    its pointers truncated to C ints."""
     global _BOUND
     L = lib()
-    if not _BOUND:
+    if _BOUND:
+        return L
+    with _BIND_LOCK:
+        if _BOUND:
+            return L
+        _bind_locked(L)
+        _BOUND = True
+    return L
+
+
+def _bind_locked(L):
+    if True:
         vp = C.c_void_p
         L.np2_fasta_open.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.np2_fasta_next.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -60,8 +77,6 @@ def _bind():
         L.np2_contig_from_bam.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.POINTER(np2_front_opts_t), C.POINTER(vp)]
         L.np2_contig_export.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64)]
         _bind_shard(L)
-        _BOUND = True
-    return L
 
 
 def _bind_shard(L):
@@ -107,8 +122,11 @@ def load_yak(path):
     # the words are used where the loader put them (no second copy of a dump of tens of GB): np2_yak_free runs when the
     # array is collected
     base = np.ctypeslib.as_array(y.words, shape=(max(int(y.n_words), 1),))
-    weakref.finalize(base, L.np2_yak_free, y)
-    return Yak(y.k, base[: int(y.n_words)], off, pre=y.pre)
+    yk = Yak(y.k, base[: int(y.n_words)], off, pre=y.pre)
+    # (tied to the Yak object, not to `base`: a view's .base is the memory's owner, not the intermediate array, so `base`
+    # itself may be collected while its views live on)
+    weakref.finalize(yk, L.np2_yak_free, y)
+    return yk
 
 
 def write_yak(path, yak):
