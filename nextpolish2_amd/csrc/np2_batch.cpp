@@ -203,9 +203,14 @@ void flush(np2_batch *b) {
 // in tens of microseconds), then it sleeps on the generation word.  (Spinning for the whole wait had every waiting
 // pipeline of every batch group hold a core: 60+ busy host threads for one GPU.)
 inline void wait_generation(std::atomic<uint32_t> &gen, uint32_t seen) {
-    for (int i = 0; i < 4000; ++i) { // ~20-40 us
-        if (gen.load(std::memory_order_acquire) != seen) return;
-        __builtin_ia32_pause();
+    static const double spin_us = getenv("NP2_BATCH_SPIN_US") ? atof(getenv("NP2_BATCH_SPIN_US")) : 30.0;
+    const double t_end = now_ms() + spin_us * 1e-3;
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (gen.load(std::memory_order_acquire) != seen) return;
+            __builtin_ia32_pause();
+        }
+        if (now_ms() >= t_end) break;
     }
     while (gen.load(std::memory_order_acquire) == seen)
         (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);

@@ -17,6 +17,7 @@ syn = make_assembly(YEAST, 30, 1, True)
 yaks = [Synth.yak_assembly(syn, k) for k in (21, 31)]
 base = Oracle(yaks)
 opts = Opts()
+base.polish(syn[-1].pileup, opts)  # (the shared in-memory tables are built on first use: before the workers clone it)
 print("malloc env:", {k: v for k, v in os.environ.items() if k.startswith("MALLOC_")}, "cores", os.cpu_count(), flush=True)
 for n in threads:
     jobs = [i % len(syn) for i in range(max(n, jobs_n))]
