@@ -273,7 +273,11 @@ def main(argv=None):
         if getattr(tls, "fpol", None) is None:
             tls.fpol = Polisher([], device=a.device)
             tls.bam = np2io.Bam(a.bam)
-        return np2io.contig_from_bam(tls.fpol, tls.bam, name, seq, fopts)
+        t_f = time.time()
+        c = np2io.contig_from_bam(tls.fpol, tls.bam, name, seq, fopts)
+        if prof:
+            print(f"[np2 profile] {name}: front end {1e3 * (time.time() - t_f):.1f} ms (done at +{time.time() - t0:.3f} s)", file=sys.stderr)
+        return c
 
     def polish(name, fut):
         """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
@@ -284,7 +288,10 @@ def main(argv=None):
                 with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
                     tls.pol = b0 if not base else b0.clone()
                     base.append(tls.pol)
+            t_p = time.time()
             bases, pos = tls.pol.polish_resident(contig, opts, want_pos=a.out_pos)
+            if prof:
+                print(f"[np2 profile] {name}: polish {1e3 * (time.time() - t_p):.1f} ms (done at +{time.time() - t0:.3f} s)", file=sys.stderr)
         finally:
             contig.free()
         b = bases.tobytes()

@@ -274,7 +274,8 @@ void worker_main(np2_batch *b, int slot) {
         tl_recorder() = r;
         int rc = np2_polish_resident(b->slots[slot], job.contig, job.opts, job.out_bases, job.out_pos, job.out_len);
         tl_recorder() = nullptr;
-        for (void *p : r->graveyard) (void)hipFree(p);
+        for (auto &g : r->graveyard) // (the pipeline's last flush has completed)
+            dev_release_idle(g.first, (g.second >> 63) ? 0 : g.second, (g.second >> 63) ? (g.second & ~(1ull << 63)) : 0);
         r->graveyard.clear();
         leave_wave(b, r);
         if (rc == NP2_OK && job.out_span) (void)np2_last_span(b->slots[slot], &job.out_span[0], &job.out_span[1]);

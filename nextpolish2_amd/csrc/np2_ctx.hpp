@@ -109,23 +109,110 @@ inline DevCache &dev_cache() {
     return *c;
 }
 
+// Small scratch blocks (a context holds ~130 buffers, most of them a few KB to a few MB) are carved out of 64 MiB slabs:
+// a cold context then costs a handful of hipMalloc calls instead of one per buffer (0.1 - 0.3 ms each, serialised by
+// the driver across the contexts of a process: four fresh contexts spent ~100 ms of a 0.3 s command-line run there).
+// A released block goes to a per-size free list after the device has drained (a buffer grows while kernels that use
+// its old storage may still be queued; hipFree, which it replaces, synchronises the device as well).
+struct DevSlabs {
+    static constexpr size_t SLAB = 64ull << 20, MAX_BLOCK = 4ull << 20;
+    std::mutex mu;
+    struct Slab {
+        int dev;
+        uint8_t *base;
+        size_t used;
+    };
+    std::vector<Slab> slabs;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_;
+    static size_t round(size_t bytes) { return DevCache::size_class(std::max<size_t>(bytes, 256)); }
+    void *get(size_t &bytes) { // bytes <= MAX_BLOCK
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bytes = (std::max<size_t>(bytes, 256) <= 4096) ? ((bytes + 255) & ~(size_t)255) : round(bytes);
+        std::lock_guard<std::mutex> l(mu);
+        auto it = free_.find({dev, bytes});
+        if (it != free_.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            return p;
+        }
+        for (auto &sl : slabs)
+            if (sl.dev == dev && SLAB - sl.used >= bytes) {
+                void *p = sl.base + sl.used;
+                sl.used += bytes;
+                return p;
+            }
+        void *b = nullptr;
+        HIPCHK(hipMalloc(&b, SLAB));
+        slabs.push_back(Slab{dev, (uint8_t *)b, bytes});
+        return b;
+    }
+    bool owns(const void *p) {
+        std::lock_guard<std::mutex> l(mu);
+        for (auto &sl : slabs)
+            if ((const uint8_t *)p >= sl.base && (const uint8_t *)p < sl.base + SLAB) return true;
+        return false;
+    }
+    void put(void *p, size_t bytes) { // the caller guarantees the block is no longer in use on the device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> l(mu);
+        free_[{dev, bytes}].push_back(p);
+    }
+};
+inline DevSlabs &dev_slabs() {
+    static DevSlabs *s = new DevSlabs(); // leaked on purpose: outlives every context
+    return *s;
+}
+// Inside such a scope the device has been drained once and stays unused by the releasing object: its buffers go back
+// to the slabs / the cache without a synchronisation each (a context frees ~130 of them when it is destroyed).
+inline int &dev_sync_depth() {
+    static thread_local int d = 0;
+    return d;
+}
+struct DevSyncScope {
+    DevSyncScope() {
+        (void)hipDeviceSynchronize();
+        ++dev_sync_depth();
+    }
+    ~DevSyncScope() { --dev_sync_depth(); }
+};
+// release of a block whose last use on the device has completed: slab pieces to their free list, hipMalloc blocks to the
+// cache (handed to the next buffer of that size class — of a later context, too — instead of back to the driver)
+inline void dev_release_idle(void *p, size_t slab_bytes, size_t big_bytes) {
+    if (slab_bytes)
+        dev_slabs().put(p, slab_bytes);
+    else if (big_bytes)
+        dev_cache().put(p, big_bytes);
+    else
+        (void)hipFree(p);
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
     bool cached = false;   // blocks come from / go back to dev_cache() (see there for when that is allowed)
     size_t cache_bytes = 0;
+    size_t slab_bytes = 0; // != 0: the block is a piece of a slab (DevSlabs)
     ~DevBuf() { release(); }
     void release() {
         if (p) {
-            if (cached)
+            if (cached) {
                 dev_cache().put(p, cache_bytes);
-            else if (Recorder *r = tl_recorder())
-                r->graveyard.push_back(p); // recorded, not yet issued commands may name it: freed after the next flush
-            else
-                (void)hipFree(p);
+            } else if (Recorder *r = tl_recorder()) {
+                // recorded, not yet issued commands may name it: released after the next flush
+                r->graveyard.push_back({p, slab_bytes ? slab_bytes : (cache_bytes | (1ull << 63))});
+            } else {
+                // a buffer grows while kernels that use its old storage may still be queued: drain the device first (what
+                // hipFree, which this replaces, does implicitly) unless the owner already has
+                if (dev_sync_depth() == 0) (void)hipDeviceSynchronize();
+                dev_release_idle(p, slab_bytes, cache_bytes);
+            }
         }
         p = nullptr;
         cap = 0;
+        slab_bytes = 0;
+        cache_bytes = 0;
     }
     T *ensure(size_t n) {
         if (n > cap) {
@@ -135,9 +222,14 @@ template <class T> struct DevBuf {
                 cache_bytes = want * sizeof(T);
                 p = (T *)dev_cache().get(cache_bytes);
                 cap = cache_bytes / sizeof(T);
-            } else {
-                HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-                cap = want;
+            } else if (want * sizeof(T) <= DevSlabs::MAX_BLOCK) {
+                slab_bytes = want * sizeof(T);
+                p = (T *)dev_slabs().get(slab_bytes);
+                cap = slab_bytes / sizeof(T);
+            } else { // a block of its own, from the cache if an idle one of its size class is there
+                cache_bytes = want * sizeof(T);
+                p = (T *)dev_cache().get(cache_bytes);
+                cap = cache_bytes / sizeof(T);
             }
         }
         return p;
@@ -428,7 +520,8 @@ inline void flush_timings(np2_ctx *cx) {
 // operations, a synchronisation flushes the whole group.
 inline void recorder_sync(Recorder *r) {
     r->sync_fn(r);
-    for (void *p : r->graveyard) (void)hipFree(p);
+    for (auto &g : r->graveyard) // (the flush has waited for the device)
+        dev_release_idle(g.first, (g.second >> 63) ? 0 : g.second, (g.second >> 63) ? (g.second & ~(1ull << 63)) : 0);
     r->graveyard.clear();
 }
 inline void op_sync(np2_ctx *cx) {

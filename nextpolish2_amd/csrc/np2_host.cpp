@@ -1294,6 +1294,7 @@ void np2_ctx_destroy(np2_ctx_t *cx) {
     if (cx->stream2) (void)hipStreamSynchronize(cx->stream2);
     if (cx->stream_out) (void)hipStreamSynchronize(cx->stream_out);
     destroy_streams(cx);
+    DevSyncScope idle; // the context's ~130 buffers go back to the slabs / the cache behind ONE device synchronisation
     delete cx;
 }
 const char *np2_last_error(np2_ctx_t *cx) { return cx ? cx->err.c_str() : "null context"; }

@@ -109,7 +109,7 @@ struct Recorder {
         q.push_back(std::move(c));
     }
     // device buffers released while recorded commands may still name them: freed after the next flush
-    std::vector<void *> graveyard;
+    std::vector<std::pair<void *, size_t>> graveyard; // (block, its slab size — or, bit 63 set, its cache size class)
     void clear() {
         q.clear();
         arena.clear();
