@@ -32,15 +32,18 @@ struct DenseChunk { // what phase 2 needs to know about a chunk of the block (LD
     uint64_t nib_off, ckbase;
     uint32_t read, ts, c0, ncols, nck, pad;
 };
-static constexpr uint32_t DENSE_CPW = 4;                 // chunks per wavefront: their loads are all in flight together
+#ifndef NP2_DENSE_CPW
+#define NP2_DENSE_CPW 4
+#endif
+static constexpr uint32_t DENSE_CPW = NP2_DENSE_CPW;                 // chunks per wavefront: their loads are all in flight together
 static constexpr uint32_t DENSE_CHUNKS = 4 * DENSE_CPW;  // chunks per 256-thread block
-static constexpr uint32_t DENSE_TSLOTS = 64;             // tile table of a block (>= 3 tiles per chunk)
+static constexpr uint32_t DENSE_TSLOTS = DENSE_CPW > 4 ? 128 : 64;             // tile table of a block (>= 3 tiles per chunk)
 
 __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint32_t np2_nb, const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
     const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
     uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
     uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
-    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err, uint32_t dbg) {
+    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
     __shared__ uint32_t s_total[DENSE_CHUNKS];        // non-insertion columns of the block's chunks
@@ -119,7 +122,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         for (uint32_t it = 0; it < DENSE_CPW; ++it) {
             const uint32_t ch = DENSE_CPW * pw + it;
             carry_[it] = 0;
-            if (!dd[it].live || (dbg & 16)) continue;
+            if (!dd[it].live) continue;
             const bool cont = it != 0 && dd[it].read == dd[it ? it - 1 : 0].read && dd[it].c0 != 0;
             if (cont) {
                 carry_[it] = carry_[it ? it - 1 : 0] + total_[it ? it - 1 : 0];
@@ -162,7 +165,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         t0_[it] = dd[it].ts + carry_[it] + (incl_[it] - nonins_[it]);
         // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer;
         // such a read is reported by the descriptor check at the end of its last chunk)
-        const uint32_t q = (dbg & 4) ? 0u : min(t0_[it] >> 3, (L >> 3) + 8);
+        const uint32_t q = min(t0_[it] >> 3, (L >> 3) + 8);
 #pragma unroll
         for (uint32_t k = 0; k < 5; ++k) r_[it][k] = refw32[q + k];
     }
@@ -170,7 +173,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
         const uint32_t ch = DENSE_CPW * pw + it;
-        if (!dd[it].live || (dbg & 64)) break;
+        if (!dd[it].live) break;
         const uint8_t *base = nib + dd[it].nib_off; // start of the READ's stream
         const uint32_t ncols = dd[it].ncols, ts = dd[it].ts, c0 = dd[it].c0;
         const uint32_t lc0 = c0 + lane * 32;
@@ -200,7 +203,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         {
             const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
             const uint32_t nth = tstar - t0; // 0-based index among the lane's non-insertion columns
-            if (n_ins == 0 && nth < nonins && !(dbg & 8)) {
+            if (n_ins == 0 && nth < nonins) {
                 const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
                 const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
                 if (idx < dd[it].nck) ckpt[dd[it].ckbase + idx] = lc0 + nth;
@@ -213,7 +216,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         if (lane == 0) pb = cont ? prev_top : (c0 > 0 ? 0x88000000u : 0u); // (chunk start inside a read: phase 2 looks)
         const bool dirty = nv != 0 && ((B0.lo | B0.hi) != 0 || (pb & 0x88000000u) != 0 || (lc0 == 0 && ts != 0));
         prev_top = (uint32_t)__builtin_amdgcn_readlane((int)top, 63);
-        const uint64_t dm = (dbg & 32) ? 0ull : __ballot(dirty);
+        const uint64_t dm = __ballot(dirty);
         if (dm) {
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&s_nq, (uint32_t)__builtin_popcountll(dm));
@@ -228,7 +231,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             dc.nib_off = dd[it].nib_off, dc.ckbase = dd[it].ckbase, dc.read = dd[it].read, dc.ts = ts, dc.c0 = c0, dc.ncols = ncols;
             dc.nck = dd[it].nck, dc.pad = 0;
             s_desc[ch - blk_first] = dc;
-            if (c0 + 2048 >= ncols && !(dbg & 16)) {
+            if (c0 + 2048 >= ncols) {
                 // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
                 if (ncols == 0 || ts + carryN + total - 1 != dd[it].aln_t_e || dd[it].aln_t_e >= L) atomicOr(err, 2u);
                 if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
@@ -241,7 +244,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     // (a 32-entry tile table in LDS: the block's 8 chunks touch at most 24 tiles), so that what a block adds to a tile
     // is one contiguous piece written through one L2.  (Reserving per lane left every bucket line shared by fragments
     // of a dozen blocks on different XCDs: the scattered partial-line stores cost 5x the rest of the kernel.)
-    const uint32_t nq = (dbg & 1) ? 0u : s_nq;
+    const uint32_t nq = s_nq;
     for (uint32_t q0 = 0; q0 < nq; q0 += 256) { // (uniform; one round unless more than half of the lanes are dirty)
         if (threadIdx.x < DENSE_TSLOTS) {
             s_tile[threadIdx.x] = 0xFFFFFFFFu;
@@ -341,7 +344,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                     if (idx < dc.nck) ckpt[dc.ckbase + idx] = lc0 + n_kth_flag(NI, nth + 1);
                 }
             }
-            cnt = (dbg & 2) ? 0u : n_popc(E);
+            cnt = n_popc(E);
         }
         // t_pos of column c = t0 - 1 + the non-insertion columns up to and including c (a leading insertion column belongs
         // to t0 - 1); the lane's columns span at most 33 positions, i.e. at most two tiles
@@ -416,7 +419,7 @@ void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
                        uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err) {
     if (n_chunks)
-        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + DENSE_CHUNKS - 1) / DENSE_CHUNKS), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err, (uint32_t)(getenv("NP2_DENSE_DBG") ? atoi(getenv("NP2_DENSE_DBG")) : 0));
+        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + DENSE_CHUNKS - 1) / DENSE_CHUNKS), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err);
 }
 
 } // namespace np2
