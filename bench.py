@@ -268,7 +268,7 @@ def end_to_end(pol, syn_c, yaks, opts, tmpdir, resident_result):
             "path": "BAM (BGZF) -> np2_contig_from_bam -> np2_polish_resident -> FASTA record, one contig, one context"}
 
 
-def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=4):
+def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=2):
     """The whole assembly through the command line's own code path (nextpolish2_amd.cli.main, in process): yak dumps,
     FASTA and one coordinate-sorted indexed BAM on local disk -> polished FASTA file.  The wall time includes loading
     the yak files and building the HBM tables; `workers` contexts keep that many contigs in flight (front end of one
@@ -287,24 +287,28 @@ def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=4):
     for y in yaks:
         yk.append(os.path.join(tmpdir, f"k{y.k}.yak"))
         np2io.write_yak(yk[-1], y)
-    best = None
-    for rep in range(2):
+    walls = []
+    for rep in range(4):
         out = os.path.join(tmpdir, f"out{rep}.fa")
         t0 = time.perf_counter()
         rc = cli.main([bam, fa] + yk + ["-o", out, "-t", str(workers), "-L", "20000"])  # (default -L 1000000 passes short contigs through)
-        dt = time.perf_counter() - t0
+        walls.append(time.perf_counter() - t0)
         if rc != 0:
             raise RuntimeError("cli.main failed")
-        best = dt if best is None else min(best, dt)
+    best = min(walls)
     want = b"".join(b">%s start:%d end:%d\n%s\n" % (s.pileup.name.encode(), spans[i][0], spans[i][1], bases[i].tobytes())
                     for i, s in enumerate(syn))
     total = sum(s.pileup.L for s in syn)
     return {"value": round(total / best / 1e6, 2), "unit": "Mbp/s", "wall_s": round(best, 3), "assembly_bp": total,
-            "bam_bytes": os.path.getsize(bam), "workers": workers,
+            "first_run": {"value": round(total / walls[0] / 1e6, 2), "wall_s": round(walls[0], 3)},
+            "all_runs_wall_s": [round(w, 3) for w in walls],
+            "bam_bytes": os.path.getsize(bam), "yak_bytes": sum(os.path.getsize(p) for p in yk), "workers": workers,
             "identical_to_resident_path": open(out, "rb").read() == want,
-            "path": "k21/k31 .yak + FASTA + BAM (BGZF, .bai) files -> nextPolish2 command line (in process, yak load and "
-                    "table build included) -> FASTA file; best of 2 runs, each with fresh contexts (a 12 Mb job is "
-                    "dominated by fixed costs: ~0.1-0.2 s of yak loading, cold device / pinned allocations per context)"}
+            "path": "k21/k31 .yak + FASTA + BAM (BGZF, .bai) files -> nextPolish2 command line (in process; reading the dumps "
+                    "and building the HBM tables included: ~10-20 ms, streamed to the device while the first alignments "
+                    "are read) -> FASTA file; value = best of 4 runs, first_run = the first one: every run makes and "
+                    "releases its own contexts, tables and BAM handles, but from the second on their streams, pinned "
+                    "staging and device blocks come from the process-wide pools the first run filled"}
 
 
 def spawn_ranks(n):

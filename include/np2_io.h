@@ -53,6 +53,10 @@ void np2_fasta_close(np2_fasta_t *f);
 /* fills *out with malloc'ed arrays (release with np2_yak_free) */
 int np2_yak_load(const char *path, np2_yak_t *out);
 void np2_yak_free(np2_yak_t *y);
+/* np2_ctx_create for dumps on disk: the files go to the device in pieces as they are read and the HBM tables are built
+ * from the file images, without the host arrays of np2_yak_load (KmerInfo::new + the per-phase file reads of
+ * kmer.rs:72-170 collapsed into one load).  Tables are ordered by k (option.rs:238).  Errors: np2_io_last_error(). */
+int np2_ctx_create_from_files(np2_ctx_t **out, int device, const char *const *paths, int n_paths);
 
 /* ---- indexed BAM ---- */
 typedef struct np2_bam np2_bam_t;

@@ -245,27 +245,29 @@ def main(argv=None):
         return _main_distributed(a, argv, t0, out, load_yaks(), opts, fopts)
 
     # Three stages, each on its own threads, a contig moving through them in input order:
-    #   front end  (a.thread capped at 3 threads, each with a table-less context and its own BAM handle): BGZF inflate +
+    #   front end  (a.thread capped at 2 threads, each with a table-less context and its own BAM handle): BGZF inflate +
     #              record walk on the host pool, admission, H2D, GPU columnariser -> the contig's pileup resident in HBM;
-    #   polish     (up to 4 contexts sharing ONE copy of the k-mer tables): np2_polish_resident, record formatting;
+    #   polish     (up to 2 contexts sharing ONE copy of the k-mer tables): np2_polish_resident, record formatting;
     #   output     (this thread): records written in input order.
     # The k-mer dumps are loaded and their HBM tables built next to the first front ends — a resident pileup does not
     # depend on them —, so a run starts reading alignments at once instead of after the tables (main.rs:1698-1853: the
     # reference's reader / workers / writer threads around two bounded channels).
-    n_workers = max(1, min(4, a.thread))
-    n_front = max(1, min(3, a.thread))
+    # (two of each: a front end already spreads its inflate over the host pool, and two polish contexts keep the GPU busy
+    # through each other's host phases — measured on the 17-contig 12 Mb assembly: 84 ms with 2 + 2, 109 ms with 3 + 4)
+    n_workers = max(1, min(2, a.thread))
+    n_front = max(1, min(2, a.thread))
     tls = threading.local()
     base, base_lock = [], threading.Lock()
-    yak_pool = ThreadPoolExecutor(max_workers=2)
-    yak_future = yak_pool.submit(load_yaks)  # host only; the device is not touched before a contig needs polishing
+    yak_pool = ThreadPoolExecutor(max_workers=1)
     base_future = []
 
     def build_base():
-        ys = yak_future.result()
+        # dumps -> HBM tables in one go (np2_ctx_create_from_files: each file streamed to the device as it is read, one
+        # host thread per dump); the device is not touched before a contig needs polishing
         t_b = time.time()
-        pol = Polisher(ys, device=a.device)
+        pol = np2io.polisher_from_yak_files(a.yak, device=a.device)
         if prof:
-            print(f"[np2 profile] k-mer tables in HBM {time.time() - t_b:.3f} s (at +{time.time() - t0:.3f} s)", file=sys.stderr)
+            print(f"[np2 profile] k-mer dumps read + tables in HBM {time.time() - t_b:.3f} s (at +{time.time() - t0:.3f} s)", file=sys.stderr)
         return pol
 
     def front(name, seq):
@@ -325,10 +327,13 @@ def main(argv=None):
                     pending.append(pool.submit(polish, name, fpool.submit(front, name, seq)))
                 drain(2 * n_workers + n_front)  # bounded look-ahead: that many contigs held in memory at most
             drain(0)
-        out.flush()
-        yak_future.result()  # (an assembly of pass-through contigs only: a broken dump must still be reported)
+            out.flush()
+            if prof:
+                print(f"[np2 profile] last record written at +{time.time() - t0:.3f} s", file=sys.stderr)
+        if not base_future:
+            load_yaks()  # (an assembly of pass-through contigs only: a broken dump must still be reported)
         if prof:
-            print(f"[np2 profile] all contigs written at +{time.time() - t0:.3f} s", file=sys.stderr)
+            print(f"[np2 profile] contexts released at +{time.time() - t0:.3f} s", file=sys.stderr)
     finally:
         yak_pool.shutdown(wait=False)
         if out is not None and out is not sys.stdout.buffer:

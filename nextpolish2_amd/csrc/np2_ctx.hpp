@@ -246,7 +246,9 @@ struct PinnedPool {
         std::lock_guard<std::mutex> l(mu);
         size_t best = free_.size();
         for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].first >= bytes && (best == free_.size() || free_[i].first < free_[best].first)) best = i;
+            if (free_[i].first >= bytes && free_[i].first <= bytes * 4 + (1u << 20) && // (a fitting block, not a huge one)
+                (best == free_.size() || free_[i].first < free_[best].first))
+                best = i;
         void *p = nullptr;
         size_t cap = 0;
         if (best != free_.size()) {
@@ -283,25 +285,74 @@ inline PinnedPool &pinned_pool() {
     return *p;
 }
 
+// A context's pinned staging: blocks of the process-wide pool (pinning and unpinning cost milliseconds per block: a
+// context that comes and goes with every command-line run must not pay them each time)
 struct PinnedBuf {
     void *p = nullptr;
     size_t cap = 0;
     ~PinnedBuf() {
-        if (p) (void)hipHostFree(p);
+        if (p) pinned_pool().put(p);
     }
     void *ensure(size_t n) {
         if (n > cap) {
-            if (p) (void)hipHostFree(p);
+            if (p) pinned_pool().put(p);
             p = nullptr;
             cap = 0;
-            size_t want = n + n / 4 + 65536;
-            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
-                throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            const size_t want = n + n / 4 + 65536;
+            p = pinned_pool().get(want);
+            if (!p) throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
             cap = want;
         }
         return p;
     }
 };
+
+// Streams, events and the host-mapped mailbox of a context, kept when the context goes: creating three streams is
+// ~9 ms (more when several threads do it at once), destroying them ~6 ms, and the command line makes a handful of
+// contexts per run.  A released set has been synchronised; at most 32 idle sets are kept per device.
+struct CtxDeviceState {
+    hipStream_t stream = nullptr, stream2 = nullptr, stream_out = nullptr;
+    hipEvent_t ev_out = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    uint32_t *mbox_host = nullptr, *mbox_dev = nullptr;
+    void destroy() {
+        if (ev_out) (void)hipEventDestroy(ev_out);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream_out) (void)hipStreamDestroy(stream_out);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (mbox_host) (void)hipHostFree(mbox_host);
+        *this = CtxDeviceState();
+    }
+};
+struct CtxStatePool {
+    std::mutex mu;
+    std::map<int, std::vector<CtxDeviceState>> idle; // by device
+    bool get(int device, CtxDeviceState &out) {
+        std::lock_guard<std::mutex> l(mu);
+        auto &v = idle[device];
+        if (v.empty()) return false;
+        out = v.back();
+        v.pop_back();
+        return true;
+    }
+    void put(int device, CtxDeviceState &st) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto &v = idle[device];
+            if (v.size() < 32) {
+                v.push_back(st);
+                st = CtxDeviceState();
+                return;
+            }
+        }
+        st.destroy();
+    }
+};
+inline CtxStatePool &ctx_state_pool() {
+    static CtxStatePool *p = new CtxStatePool(); // leaked on purpose: outlives every context
+    return *p;
+}
 
 struct YakTable {
     uint32_t k = 0, cap_log2 = 0;
@@ -349,9 +400,6 @@ struct np2_contig {
 };
 
 struct np2_ctx {
-    ~np2_ctx() {
-        if (mbox_host) (void)hipHostFree(mbox_host);
-    }
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream for kernels that can overlap the main one (fork / join by events)

@@ -1174,20 +1174,29 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
+// the context's streams, events and mailbox go back to the pool (synchronised), its result staging to the pinned pool
 static void destroy_streams(np2_ctx *cx) {
-    if (cx->ev_out) (void)hipEventDestroy(cx->ev_out);
-    if (cx->stream_out) (void)hipStreamDestroy(cx->stream_out);
-    for (int i = 0; i < 2; ++i)
-        if (cx->out_host[i]) (void)hipHostFree(cx->out_host[i]);
-    cx->out_host[0] = cx->out_host[1] = nullptr;
-    cx->ev_out = nullptr;
-    cx->stream_out = nullptr;
-    if (cx->ev_fork) (void)hipEventDestroy(cx->ev_fork);
-    if (cx->ev_join) (void)hipEventDestroy(cx->ev_join);
-    if (cx->stream2) (void)hipStreamDestroy(cx->stream2);
-    if (cx->stream) (void)hipStreamDestroy(cx->stream);
-    cx->ev_fork = cx->ev_join = nullptr;
-    cx->stream2 = cx->stream = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (cx->out_host[i]) pinned_pool().put(cx->out_host[i]);
+        cx->out_host[i] = nullptr;
+        cx->out_host_cap[i] = 0;
+    }
+    CtxDeviceState st;
+    st.stream = cx->stream, st.stream2 = cx->stream2, st.stream_out = cx->stream_out;
+    st.ev_out = cx->ev_out, st.ev_fork = cx->ev_fork, st.ev_join = cx->ev_join;
+    st.mbox_host = cx->mbox_host, st.mbox_dev = cx->mbox_dev;
+    cx->stream = cx->stream2 = cx->stream_out = nullptr;
+    cx->ev_out = cx->ev_fork = cx->ev_join = nullptr;
+    cx->mbox_host = cx->mbox_dev = nullptr;
+    const bool complete = st.stream && st.stream2 && st.stream_out && st.ev_out && st.ev_fork && st.ev_join && st.mbox_host;
+    bool idle = complete;
+    if (complete) // (nothing of this context may still be running on a set the next context takes over)
+        idle = hipStreamSynchronize(st.stream) == hipSuccess && hipStreamSynchronize(st.stream2) == hipSuccess &&
+               hipStreamSynchronize(st.stream_out) == hipSuccess;
+    if (idle)
+        ctx_state_pool().put(cx->device, st);
+    else
+        st.destroy();
 }
 
 // streams, events, mailbox: everything of a context but its k-mer tables
@@ -1198,16 +1207,23 @@ static void init_ctx_device(np2_ctx *cx, int device) {
     if (device < 0 || device >= ndev) throw Np2Error(NP2_E_ARG, "bad device index");
     cx->device = device;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&cx->stream_out, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
+    CtxDeviceState st;
+    if (ctx_state_pool().get(device, st)) {
+        cx->stream = st.stream, cx->stream2 = st.stream2, cx->stream_out = st.stream_out;
+        cx->ev_out = st.ev_out, cx->ev_fork = st.ev_fork, cx->ev_join = st.ev_join;
+        cx->mbox_host = st.mbox_host, cx->mbox_dev = st.mbox_dev;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&cx->stream_out, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
+    }
     cx->scal.ensure(SCAL_TOTAL);
-    HIPCHK(hipHostMalloc((void **)&cx->mbox_host, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     memset(cx->mbox_host, 0, 64 * sizeof(uint32_t));
-    HIPCHK(hipHostGetDevicePointer((void **)&cx->mbox_dev, cx->mbox_host, 0));
     if (const char *e = getenv("NP2_TILE_CAP")) // test hook: smaller buckets force the spill / device-wide sort path
         cx->tile_cap = (uint32_t)std::min<long>(TILE_CAP, std::max<long>(1, atol(e)));
     if (const char *e = getenv("NP2_TEST_DEEP_COV")) // test hook: treat shallower pileups as too deep for the on-chip DP
@@ -1219,7 +1235,9 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
     *out = nullptr;
     np2_ctx *cx = new np2_ctx();
     try {
+        const double t_c0 = now_ms();
         init_ctx_device(cx, device);
+        if (getenv("NP2_CTX_PROFILE")) fprintf(stderr, "np2_ctx_create: streams, events, mailbox %.2f ms\n", now_ms() - t_c0);
         // the final pass runs one splice round + one per yak table; their per-round device counters live in fixed slots
         if (n_yak < 0 || n_yak > NP2_MAX_YAK || (n_yak && !yaks))
             throw Np2Error(NP2_E_ARG, "n_yak must be in [0, 15]");
@@ -1289,13 +1307,22 @@ int np2_ctx_create_shared(np2_ctx_t **out, np2_ctx_t *parent) {
 
 void np2_ctx_destroy(np2_ctx_t *cx) {
     if (!cx) return;
+    const bool prof = getenv("NP2_CTX_PROFILE") != nullptr;
+    const double t0 = now_ms();
     (void)hipSetDevice(cx->device);
     if (cx->stream) (void)hipStreamSynchronize(cx->stream);
     if (cx->stream2) (void)hipStreamSynchronize(cx->stream2);
     if (cx->stream_out) (void)hipStreamSynchronize(cx->stream_out);
+    const double t1 = now_ms();
     destroy_streams(cx);
-    DevSyncScope idle; // the context's ~130 buffers go back to the slabs / the cache behind ONE device synchronisation
-    delete cx;
+    const double t2 = now_ms();
+    {
+        DevSyncScope idle; // the context's ~130 buffers go back to the slabs / the cache behind ONE device synchronisation
+        delete cx;
+    }
+    if (prof)
+        fprintf(stderr, "np2_ctx_destroy: stream syncs %.2f ms, streams/events/result staging %.2f ms, buffers %.2f ms\n", t1 - t0,
+                t2 - t1, now_ms() - t2);
 }
 const char *np2_last_error(np2_ctx_t *cx) { return cx ? cx->err.c_str() : "null context"; }
 void *np2_ctx_stream(np2_ctx_t *cx) { return cx ? (void *)cx->stream : nullptr; }
@@ -1373,11 +1400,12 @@ int np2_result_fetch_begin(np2_ctx_t *cx) {
         cx->out_snap.ensure(n + 1);
         uint8_t *&host = cx->out_host[cx->out_slot];
         if (cx->out_host_cap[cx->out_slot] < n + 1) {
-            if (host) (void)hipHostFree(host);
+            if (host) pinned_pool().put(host);
             host = nullptr;
+            cx->out_host_cap[cx->out_slot] = 0;
             const size_t cap = n + n / 8 + 4096;
-            if (hipHostMalloc((void **)&host, cap, hipHostMallocDefault) != hipSuccess)
-                throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+            host = (uint8_t *)pinned_pool().get(cap);
+            if (!host) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
             cx->out_host_cap[cx->out_slot] = cap;
         }
         // snapshot on the main stream (in order before the next contig overwrites the consensus buffers), host copy on

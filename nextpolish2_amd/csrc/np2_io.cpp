@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <zlib.h>
+#include <dlfcn.h>
+#include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -12,13 +14,71 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
 
 namespace {
+
+// Raw-deflate decoder for BGZF blocks (each block is one complete deflate stream of known inflated size): libdeflate's
+// whole-buffer decoder when the host has its runtime library (2-3 x zlib's rate on BAM payloads; htslib makes the same
+// choice at build time), zlib otherwise or with NP2_INFLATE=zlib.  Resolved once, at run time: the image ships
+// libdeflate.so.0 without headers, and a host without it must still work.
+struct Inflater {
+    typedef void *(*alloc_fn)(void);
+    typedef int (*dec_fn)(void *, const void *, size_t, void *, size_t, size_t *);
+    typedef void (*free_fn)(void *);
+    alloc_fn alloc = nullptr;
+    dec_fn dec = nullptr;
+    free_fn fre = nullptr;
+    Inflater() {
+        const char *e = getenv("NP2_INFLATE");
+        if (e && !strcmp(e, "zlib")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
+        dec = (dec_fn)dlsym(h, "libdeflate_deflate_decompress");
+        fre = (free_fn)dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !dec || !fre) alloc = nullptr, dec = nullptr, fre = nullptr;
+    }
+    static Inflater &get() {
+        static Inflater *i = new Inflater();
+        return *i;
+    }
+    const char *name() const { return dec ? "libdeflate" : "zlib"; }
+    struct PerThread { // one decoder per thread, released with the thread
+        void *d = nullptr;
+        free_fn fre = nullptr;
+        ~PerThread() {
+            if (d && fre) fre(d);
+        }
+    };
+    // inflates `clen` bytes at `in` into exactly `isize` bytes at `out`
+    bool run(const uint8_t *in, size_t clen, uint8_t *out, size_t isize) const {
+        if (dec) {
+            static thread_local PerThread t;
+            if (!t.d) t.d = alloc(), t.fre = fre;
+            if (t.d) {
+                size_t got = 0;
+                return dec(t.d, in, clen, out, isize, &got) == 0 && got == isize;
+            }
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(in);
+        zs.avail_in = (uInt)clen;
+        zs.next_out = out;
+        zs.avail_out = (uInt)isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        return rc == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
 
 thread_local std::string g_io_err;
 int io_fail(int code, const std::string &m) {
@@ -86,18 +146,8 @@ struct Bgzf {
         if (fread(cdata.data(), 1, clen + 8, f) != clen + 8) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
         const uint32_t isize = cdata[clen + 4] | (cdata[clen + 5] << 8) | (cdata[clen + 6] << 16) | ((uint32_t)cdata[clen + 7] << 24);
         block.resize(isize);
-        if (isize) {
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) throw np2h::Np2Error(NP2_E_NOMEM, "inflateInit2 failed");
-            zs.next_in = cdata.data();
-            zs.avail_in = (uInt)clen;
-            zs.next_out = block.data();
-            zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
-        }
+        if (isize && !Inflater::get().run(cdata.data(), clen, block.data(), isize))
+            throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
         return true;
     }
     void seek(uint64_t voffset) {
@@ -164,6 +214,40 @@ class IoPool {
         std::unique_lock<std::mutex> l(mu_);
         jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job)); // no new helper can pick it up from here on
         done_cv_.wait(l, [&] { return job.helpers == 0; });
+    }
+
+    // the same loop with the CALLER doing `during()` first — work that consumes the items' results as they appear (it
+    // must only wait for items in index order: they are handed out in that order) — and joining the loop afterwards
+    template <class F, class G> void parallel_for_during(size_t n, unsigned max_threads, F fn, G during) {
+        const unsigned want = (unsigned)std::min<size_t>(std::min<size_t>(max_threads, size()), n);
+        if (want <= 1) { // nobody to wait for: items first
+            for (size_t i = 0; i < n; ++i) fn(i);
+            during();
+            return;
+        }
+        Job job;
+        job.n = n;
+        job.slots = want - 1;
+        std::function<void(size_t)> body = fn;
+        job.fn = &body;
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            jobs_.push_back(&job);
+        }
+        cv_.notify_all();
+        std::exception_ptr ep;
+        try {
+            during();
+        } catch (...) {
+            ep = std::current_exception();
+        }
+        run(job);
+        {
+            std::unique_lock<std::mutex> l(mu_);
+            jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
+            done_cv_.wait(l, [&] { return job.helpers == 0; });
+        }
+        if (ep) std::rethrow_exception(ep);
     }
 
   private:
@@ -245,24 +329,67 @@ class IoPool {
 
 // growable byte buffer without value-initialisation (a std::vector would zero 100+ MiB per refill just to have inflate
 // overwrite it); kept by the BAM handle, so its pages are faulted in once
+// Large host blocks kept across BAM handles (the command line opens one handle per front-end thread and run): a block
+// of this size goes back to the kernel when freed, and the next handle's inflate threads then fault 200 MB of fresh
+// pages in again (11-14 ms of an E. coli-sized contig's first front end).  At most 8 idle blocks / 1 GiB are kept.
+struct HostBlockPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint8_t *>> idle;
+    static HostBlockPool &get() {
+        static HostBlockPool *p = new HostBlockPool(); // leaked on purpose
+        return *p;
+    }
+    uint8_t *take(size_t want, size_t &cap) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].first >= want && (best == idle.size() || idle[i].first < idle[best].first)) best = i;
+            if (best != idle.size()) {
+                uint8_t *p = idle[best].second;
+                cap = idle[best].first;
+                idle.erase(idle.begin() + (long)best);
+                return p;
+            }
+        }
+        cap = want;
+        return (uint8_t *)malloc(want);
+    }
+    void give(uint8_t *p, size_t cap) {
+        if (!p) return;
+        if (cap >= ((size_t)4 << 20)) {
+            std::lock_guard<std::mutex> l(mu);
+            size_t held = cap;
+            for (auto &b : idle) held += b.first;
+            if (idle.size() < 8 && held <= ((size_t)1 << 30)) {
+                idle.emplace_back(cap, p);
+                return;
+            }
+        }
+        free(p);
+    }
+};
 struct RawBuf {
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    ~RawBuf() { HostBlockPool::get().give(p, cap); }
     size_t size() const { return n; }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
     void clear() { n = 0; }
     void resize(size_t m) {
         if (m > cap) {
-            size_t want = std::max(m, cap + cap / 2 + (1u << 20));
-            uint8_t *q = (uint8_t *)realloc(p, want);
+            const size_t want = std::max(m, cap + cap / 2 + (1u << 20));
+            size_t got = 0;
+            uint8_t *q = HostBlockPool::get().take(want, got);
             if (!q) throw std::bad_alloc();
+            if (n) memcpy(q, p, n);
+            HostBlockPool::get().give(p, cap);
             p = q;
-            cap = want;
+            cap = got;
         }
         n = m;
     }
@@ -303,9 +430,18 @@ struct BgzfBatch {
         return (blk_index[lo].second << 16) | (uint64_t)((int64_t)p - blk_index[lo].first);
     }
     RawBuf buf; // inflated bytes not yet consumed (+ the current batch)
-    size_t pos = 0;
+    size_t pos = 0, skip = 0; // (skip: offset inside the first block after a seek, applied by the first fill)
+    // A HINT for where the wanted records end in the file (the index's last chunk end of the reference): a refill reads
+    // blocks up to it instead of a full batch — a 0.75 Mb contig's records are 250 blocks, a batch 2048 —, and once past
+    // it only a few at a time (8, 16, ...: an index that understates the end costs time, never records).
+    size_t hint_fpos = SIZE_MAX, past_hint = 8;
+    // the batch being inflated: its blocks, a completion flag per block, the prefix of `buf` known to be inflated
+    std::vector<Blk> cur_blks;
+    std::unique_ptr<std::atomic<uint8_t>[]> blk_done;
+    size_t blk_done_cap = 0, cur_base = 0, ready_bi = 0, ready_end = 0;
     bool eof = false;
     double ms_read = 0, ms_inflate = 0, ms_drop = 0; // where the refills' time goes (NP2_IO_PROFILE)
+    double ms_walk = 0, ms_size = 0, ms_copy = 0;   // ... and the record pass over each refill
     size_t batch_blocks = 2048; // 64 KiB blocks per refill: 128 MiB of inflated BAM, all inflated in parallel
     bool read_raw(Blk &b) {
         if (fpos >= map_len) return false;
@@ -333,17 +469,40 @@ struct BgzfBatch {
         return true;
     }
     // start at a virtual offset
-    void seek(uint64_t voffset) {
+    void seek(uint64_t voffset, bool prefill = true) {
         fpos = (size_t)(voffset >> 16);
         buf.clear();
         blk_index.clear();
         pos = 0;
         eof = false;
-        fill(8);
-        pos = std::min<size_t>(voffset & 0xFFFF, buf.size());
+        skip = voffset & 0xFFFF;
+        hint_fpos = SIZE_MAX, past_hint = 8;
+        if (prefill) fill(8);
     }
-    void fill(size_t n_blocks) {
-        if (eof) return;
+    // Bytes [0, end) of `buf` inflated?  Blocks until they are while a fill is in flight (called from the fill's `during`
+    // on the filling thread: blocks are handed to the pool in buffer order, so waiting for them in order cannot starve);
+    // false when `end` lies beyond what the buffer will hold.
+    bool wait_ready(size_t end) {
+        if (end > buf.size()) return false;
+        while (ready_end < end) {
+            if (ready_bi >= cur_blks.size()) {
+                ready_end = buf.size();
+                break;
+            }
+            for (unsigned spin = 0; !blk_done[ready_bi].load(std::memory_order_acquire); ++spin)
+                if (spin > 64) sched_yield();
+            ready_end = cur_base + cur_blks[ready_bi].out_off + cur_blks[ready_bi].isize;
+            ++ready_bi;
+        }
+        return true;
+    }
+    // Appends up to n_blocks inflated blocks to `buf`.  `during` (optional) runs on this thread while the pool inflates:
+    // it may read the buffer through wait_ready() as the blocks complete.
+    void fill(size_t n_blocks, const std::function<void()> *during = nullptr) {
+        if (eof) {
+            if (during) (*during)();
+            return;
+        }
         const double t_f0 = np2h::now_ms();
         if (pos) { // drop consumed bytes (blocks that lie entirely before the new front leave the index)
             size_t keep = 0;
@@ -354,9 +513,13 @@ struct BgzfBatch {
             pos = 0;
         }
         const double t_f1 = np2h::now_ms();
-        std::vector<Blk> blks;
+        std::vector<Blk> &blks = cur_blks;
+        blks.clear();
         size_t total = 0;
+        const bool past = fpos > hint_fpos;
+        if (past) n_blocks = std::min(n_blocks, past_hint), past_hint *= 2;
         for (size_t i = 0; i < n_blocks; ++i) {
+            if (!past && fpos > hint_fpos) break;
             Blk b;
             if (!read_raw(b)) {
                 eof = true;
@@ -364,29 +527,37 @@ struct BgzfBatch {
             }
             b.out_off = total;
             total += b.isize;
-            blks.push_back(std::move(b));
+            blks.push_back(b);
         }
         const size_t base = buf.size();
         buf.resize(base + total);
         for (auto &bk : blks) blk_index.emplace_back((int64_t)(base + bk.out_off), bk.file_off);
+        if (blks.size() > blk_done_cap) {
+            blk_done_cap = blks.size() + blks.size() / 2;
+            blk_done.reset(new std::atomic<uint8_t>[blk_done_cap]);
+        }
+        for (size_t i = 0; i < blks.size(); ++i) blk_done[i].store(0, std::memory_order_relaxed);
+        cur_base = base, ready_bi = 0, ready_end = base;
+        if (skip) pos = std::min<size_t>(skip, buf.size()), skip = 0;
         const double t_f2 = np2h::now_ms();
         std::atomic<int> bad{0};
-        IoPool::get().parallel_for(blks.size(), (unsigned)std::max<size_t>(1, blks.size() / 2), [&](size_t i) {
-            if (!blks[i].isize) return;
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) {
-                bad.store(1);
-                return;
-            }
-            zs.next_in = const_cast<Bytef *>(blks[i].c);
-            zs.avail_in = (uInt)blks[i].clen;
-            zs.next_out = buf.data() + base + blks[i].out_off;
-            zs.avail_out = blks[i].isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) bad.store(1);
-        });
+        const Inflater &inf = Inflater::get();
+        auto one = [&](size_t i) {
+            if (blks[i].isize && !inf.run(blks[i].c, blks[i].clen, buf.data() + base + blks[i].out_off, blks[i].isize)) bad.store(1);
+            blk_done[i].store(1, std::memory_order_release); // (also after a failure: a reader must not wait forever)
+        };
+        const unsigned nt = (unsigned)std::max<size_t>(1, blks.size() / 2);
+        try {
+            if (during)
+                IoPool::get().parallel_for_during(blks.size(), nt, one, *during);
+            else
+                IoPool::get().parallel_for(blks.size(), nt, one);
+        } catch (...) {
+            ready_end = buf.size();
+            if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed"); // (what the reader tripped over)
+            throw;
+        }
+        ready_bi = blks.size(), ready_end = buf.size();
         if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
         ms_drop += t_f1 - t_f0, ms_read += t_f2 - t_f1, ms_inflate += np2h::now_ms() - t_f2;
     }
@@ -434,7 +605,7 @@ struct PinnedBytes {
     PinnedBytes(const PinnedBytes &) = delete;
     PinnedBytes &operator=(const PinnedBytes &) = delete;
     ~PinnedBytes() {
-        if (p) (void)hipHostFree(p);
+        if (p) np2h::pinned_pool().put(p);
     }
     size_t size() const { return n; }
     uint8_t *data() { return p; }
@@ -443,10 +614,10 @@ struct PinnedBytes {
     void reserve(size_t m) {
         if (m <= cap) return;
         const size_t want = std::max(m, cap + cap / 2 + (1u << 20));
-        void *q = nullptr;
-        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+        void *q = np2h::pinned_pool().get(want); // (blocks of the process-wide pool: pinning 69 MB costs 50 ms)
+        if (!q) throw std::bad_alloc();
         if (n) memcpy(q, p, n);
-        if (p) (void)hipHostFree(p);
+        if (p) np2h::pinned_pool().put(p);
         p = (uint8_t *)q;
         cap = want;
     }
@@ -484,6 +655,7 @@ struct np2_bam {
     std::vector<std::string> ref_names;
     std::vector<uint32_t> ref_lens;
     std::vector<uint64_t> ref_start; // virtual offset of the first record of each reference (~0 = none)
+    std::vector<uint64_t> ref_end;   // ... and of the end of its last record, as far as the index's chunks say (0 = unknown)
     std::vector<std::vector<uint64_t>> lin; // .bai linear index per reference: smallest virtual offset of a record
                                             // overlapping each 16 kb window (0 = none)
     uint64_t first_rec = 0;          // virtual offset of the first alignment record
@@ -893,10 +1065,13 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
             BgzfBatch &z = bam->batch;
             z.f = bam->z.f;
             z.map = bam->map, z.map_len = bam->map_len;
-            z.seek(start_off);
+            z.seek(start_off, false);
+            if (bam->ref_end[tid]) z.hint_fpos = (size_t)(bam->ref_end[tid] >> 16);
             // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
-            // length fields finds this contig's records, a prefix sum places their CIGAR words and SEQ bytes, and the
-            // copies run in parallel (records are independent byte ranges).
+            // length fields finds this contig's records — on this thread, WHILE the pool inflates, trailing the blocks as
+            // they complete (10 k records = 10 k cache misses into lines other cores just wrote: 1.6 ms of an E. coli-sized
+            // contig's 7.4 ms when it ran after the inflate) —, a prefix sum places their CIGAR words and SEQ bytes, and
+            // the copies run in parallel (records are independent byte ranges).
             struct RecRef {
                 size_t off; // first byte after the record's block_size field, inside z.buf
                 uint32_t bs, n_cigar, l_seq;
@@ -906,12 +1081,16 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
             bool stop = false;
             while (!stop) {
                 rr.clear();
-                size_t p = z.pos;
+                size_t p = 0;
                 uint64_t co = cigar.size(), so = seq4.size();
-                while (p + 4 <= z.buf.size()) {
+                double t_walk = 0;
+                const std::function<void()> walk = [&]() {
+                const double t_w0 = np2h::now_ms();
+                p = z.pos;
+                while (z.wait_ready(p + 4)) {
                     const uint32_t bs = le32(z.buf.data() + p);
                     if (bs < 32) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-                    if (p + 4 + (size_t)bs > z.buf.size()) break; // the record continues in the next refill
+                    if (!z.wait_ready(p + 4 + (size_t)bs)) break; // the record continues in the next refill
                     const uint8_t *rec = z.buf.data() + p + 4;
                     const int32_t refID = (int32_t)le32(rec);
                     if (refID != tid) {
@@ -958,13 +1137,19 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                     }
                     p += 4 + (size_t)bs;
                 }
+                t_walk = np2h::now_ms() - t_w0;
+                };
+                z.fill(z.batch_blocks, &walk);
+                const double t_w1 = np2h::now_ms();
                 const size_t r0 = recs.size();
                 recs.resize(r0 + rr.size());
                 if (voffs)
                     for (auto &q : rr) voffs->push_back(q.voff);
                 cigar.resize(co);
+                if (!opts->use_secondary) seq4.resize(so);
+                const double t_w2 = np2h::now_ms();
+                z.ms_walk += t_walk, z.ms_size += t_w2 - t_w1;
                 if (!opts->use_secondary) {
-                    seq4.resize(so);
                     IoPool::get().parallel_for(rr.size(), 64, [&](size_t i) {
                         const RecRef &q = rr[i];
                         const uint8_t *rec = z.buf.data() + q.off;
@@ -1017,13 +1202,13 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                         recs[r0 + i] = r;
                     }
                 }
+                z.ms_copy += np2h::now_ms() - t_w2;
                 z.pos = p;
                 if (stop) break;
                 if (z.eof) {
                     if (z.pos != z.buf.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
                     break;
                 }
-                z.fill(z.batch_blocks);
             }
         }
     seq4.resize(seq4.size() + 16, 0);
@@ -1176,6 +1361,166 @@ void np2_yak_free(np2_yak_t *y) {
     y->bucket_off = nullptr;
 }
 
+// The dumps straight into HBM tables (what np2_yak_load + np2_ctx_create do through host arrays): each file is read
+// once, in 8 MiB pieces, into pinned staging and copied to the device while the next piece is being read; the insert
+// kernel then builds the table from the file image itself (bucket headers skipped by offset).  One host thread, one
+// stream per dump.  A 12 Mb genome's two dumps (2 x 104 MB) are tables 0.1 s sooner than through pageable host
+// arrays; a human-scale dump (tens of GB) never needs its host copy at all.
+namespace {
+struct YakFile {
+    std::string path;
+    int fd = -1;
+    uint32_t k = 0, pre = 0;
+    size_t size = 0;
+    np2h::YakTable table;
+    int code = NP2_OK;
+    std::string msg;
+    ~YakFile() {
+        if (fd >= 0) close(fd);
+    }
+};
+void yak_file_to_table(YakFile &yf, int device, hipStream_t given) {
+    hipStream_t st = given; // (one of the new context's idle streams, or our own)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    uint8_t *pin[2] = {nullptr, nullptr};
+    auto fail = [&](int code, const std::string &m) { yf.code = code, yf.msg = m; };
+    const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
+    auto body = [&]() {
+        const double t0 = np2h::now_ms();
+        HIPCHK(hipSetDevice(device));
+        const size_t nb = (size_t)1 << yf.pre;
+        // bucket headers: 1024 small reads at positions that depend on one another (page cache)
+        std::vector<uint64_t> off(nb + 1);
+        uint64_t mx = 0;
+        size_t at = 16; // file offset of the next bucket header
+        const size_t body_words = (yf.size - 16) / 8; // the device image: the file from byte 16 on, whole words
+        for (size_t b = 0; b < nb; ++b) {
+            uint8_t h8[8];
+            if (at + 8 > yf.size || pread(yf.fd, h8, 8, (off_t)at) != 8) return fail(NP2_E_ARG, "Failed to parse the dump file");
+            const uint64_t n = le32(h8 + 4); // (first u32, the capacity bits, is ignored like the reference, kmer.rs:143-147)
+            const uint64_t take = std::min<uint64_t>(n, (yf.size - at - 8) / 8); // UnexpectedEof ends the bucket (kmer.rs:151-155)
+            off[b] = (at - 16) / 8 + 1;
+            mx = std::max(mx, take);
+            at += 8 + take * 8;
+            if (b + 1 == nb) off[nb] = off[b] + take + 1;
+        }
+        uint32_t cl = 4;
+        while ((1ull << cl) < mx * 2 + 2) ++cl;
+        const size_t slots = nb << cl;
+        const double t1 = np2h::now_ms();
+        if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        yf.table.k = yf.k;
+        yf.table.cap_log2 = cl;
+        yf.table.table = std::make_shared<np2h::DevBuf<uint64_t>>();
+        yf.table.table->ensure(slots);
+        HIPCHK(hipMemsetAsync(yf.table.table->p, 0xFF, slots * 8, st));
+        np2h::DevBuf<uint64_t> d_raw, d_off;
+        np2h::DevBuf<uint32_t> d_dup;
+        d_raw.ensure(body_words + 1);
+        d_off.ensure(nb + 1);
+        d_dup.ensure(1);
+        HIPCHK(hipMemsetAsync(d_dup.p, 0, 4, st));
+        const size_t PIECE = (size_t)8 << 20;
+        for (int i = 0; i < 2; ++i) {
+            pin[i] = (uint8_t *)np2h::pinned_pool().get(PIECE);
+            if (!pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        const double t2 = np2h::now_ms();
+        const size_t body = body_words * 8;
+        size_t piece = 0;
+        for (size_t o = 0; o < body; o += PIECE, ++piece) {
+            const int sl = (int)(piece & 1);
+            if (piece >= 2) HIPCHK(hipEventSynchronize(ev[sl])); // the copy that last used this staging piece
+            const size_t want = std::min(PIECE, body - o);
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t r = pread(yf.fd, pin[sl] + got, want - got, (off_t)(16 + o + got));
+                if (r <= 0) return fail(NP2_E_ARG, "Failed to parse the dump file");
+                got += (size_t)r;
+            }
+            HIPCHK(hipMemcpyAsync((uint8_t *)d_raw.p + o, pin[sl], want, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(ev[sl], st));
+        }
+        const double t3 = np2h::now_ms();
+        // (the offsets are tiny: through the first staging piece once its last copy has drained)
+        HIPCHK(hipStreamSynchronize(st));
+        memcpy(pin[0], off.data(), (nb + 1) * 8);
+        HIPCHK(hipMemcpyAsync(d_off.p, pin[0], (nb + 1) * 8, hipMemcpyHostToDevice, st));
+        np2::launch_yak_insert(st, d_raw.p, d_off.p, (uint32_t)nb, mx, yf.table.table->p, cl, d_dup.p, 1);
+        uint32_t *dup = (uint32_t *)pin[1];
+        HIPCHK(hipMemcpyAsync(dup, d_dup.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (*dup) fail(NP2_E_UNSUPPORTED, "duplicate k-mer key inside one yak bucket");
+        if (prof)
+            fprintf(stderr, "yak dump -> table (k=%u, %.0f MB): bucket headers %.2f ms, device + staging allocations %.2f ms, read + copy %.2f ms, "
+                            "insert %.2f ms\n", yf.k, yf.size / 1e6, t1 - t0, t2 - t1, t3 - t2, np2h::now_ms() - t3);
+    };
+    try {
+        body();
+    } catch (const np2h::Np2Error &e) {
+        fail(e.code, e.what());
+    } catch (const std::exception &e) {
+        fail(NP2_E_NOMEM, e.what());
+    }
+    if (st) (void)hipStreamSynchronize(st);
+    for (int i = 0; i < 2; ++i) {
+        if (pin[i]) np2h::pinned_pool().put(pin[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (st && st != given) (void)hipStreamDestroy(st);
+}
+} // namespace
+
+int np2_ctx_create_from_files(np2_ctx_t **out, int device, const char *const *paths, int n_paths) try {
+    if (!out) return NP2_E_ARG;
+    *out = nullptr;
+    if (n_paths < 0 || n_paths > NP2_MAX_YAK || (n_paths && !paths)) return io_fail(NP2_E_ARG, "n_yak must be in [0, 15]");
+    std::vector<std::unique_ptr<YakFile>> files;
+    for (int i = 0; i < n_paths; ++i) {
+        std::unique_ptr<YakFile> yf(new YakFile());
+        yf->path = paths[i];
+        yf->fd = open(paths[i], O_RDONLY);
+        if (yf->fd < 0) return io_fail(NP2_E_ARG, std::string("cannot open ") + paths[i]);
+        struct stat st;
+        uint8_t hd[16];
+        if (fstat(yf->fd, &st) != 0) return io_fail(NP2_E_ARG, std::string("cannot stat ") + paths[i]);
+        yf->size = (size_t)st.st_size;
+        if (pread(yf->fd, hd, 16, 0) != 16 || memcmp(hd, "YAK\2", 4) != 0)
+            return io_fail(NP2_E_ARG, "The input binary k-mer dump file is incompatible.");
+        yf->k = le32(hd + 4), yf->pre = le32(hd + 8);
+        if (le32(hd + 12) != 10) return io_fail(NP2_E_ARG, "different YAK_COUNTER_BITS");
+        if (yf->k >= 32 || yf->k < 2) return io_fail(NP2_E_UNSUPPORTED, "yak k must be in [2, 32) (main.rs:1433-1434)");
+        if (yf->pre != 10) return io_fail(NP2_E_UNSUPPORTED, "yak pre must be 10 (kmer.rs:52-54,123-125)");
+        files.push_back(std::move(yf));
+    }
+    std::stable_sort(files.begin(), files.end(), [](const std::unique_ptr<YakFile> &a, const std::unique_ptr<YakFile> &b) { return a->k < b->k; }); // option.rs:238
+    np2_ctx_t *cx = nullptr;
+    const int rc = np2_ctx_create(&cx, device, nullptr, 0);
+    if (rc != NP2_OK) return io_fail(rc, "np2_ctx_create failed (see stderr)");
+    {
+        std::vector<std::thread> th;
+        hipStream_t own[3] = {cx->stream, cx->stream2, cx->stream_out}; // idle until the context's first call
+        for (size_t i = 1; i < files.size(); ++i)
+            th.emplace_back([&, i] { yak_file_to_table(*files[i], device, i < 3 ? own[i] : nullptr); });
+        if (!files.empty()) yak_file_to_table(*files[0], device, own[0]);
+        for (auto &t : th) t.join();
+    }
+    for (auto &yf : files)
+        if (yf->code != NP2_OK) {
+            const int code = yf->code;
+            const std::string msg = yf->path + ": " + yf->msg;
+            files.clear(); // (tables released before the context's device state goes)
+            np2_ctx_destroy(cx);
+            return io_fail(code, msg);
+        }
+    for (auto &yf : files) cx->yaks.push_back(yf->table);
+    *out = cx;
+    return NP2_OK;
+} catch (const std::exception &ex) {
+    return io_fail(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what());
+}
+
 // ---- BAM ---------------------------------------------------------------------------------------------
 int np2_bam_open(const char *path, np2_bam_t **out) {
     np2_bam *b = new np2_bam();
@@ -1203,6 +1548,7 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
             b->ref_lens.push_back(le32(h4));
         }
         b->ref_start.assign(n_ref, ~0ull);
+        b->ref_end.assign(n_ref, 0);
         b->lin.assign(n_ref, {});
         b->first_rec = b->z.tell();
         {
@@ -1239,16 +1585,18 @@ int np2_bam_open(const char *path, np2_bam_t **out) {
             if (p + 4 > idx.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated .bai");
             const uint32_t n_bin = le32(idx.data() + p);
             p += 4;
-            uint64_t best = ~0ull;
+            uint64_t best = ~0ull, last = 0;
             for (uint32_t bi = 0; bi < n_bin; ++bi) {
                 const uint32_t bin = le32(idx.data() + p), n_chunk = le32(idx.data() + p + 4);
                 p += 8;
                 for (uint32_t ci = 0; ci < n_chunk; ++ci) {
-                    const uint64_t beg = le64(idx.data() + p);
+                    const uint64_t beg = le64(idx.data() + p), end = le64(idx.data() + p + 8);
                     p += 16;
                     if (bin != 37450 && beg < best) best = beg; // 37450 = metadata pseudo-bin
+                    if (bin != 37450 && end > last) last = end;
                 }
             }
+            b->ref_end[r] = last;
             const uint32_t n_intv = le32(idx.data() + p);
             p += 4;
             if (p + (size_t)n_intv * 8 > idx.size()) throw np2h::Np2Error(NP2_E_ARG, "truncated .bai");
@@ -1320,15 +1668,15 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         PinnedBytes &seq4 = bam->seq4;
         const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
         const double t_p0 = np2h::now_ms();
-        bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = 0;
+        bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = bam->batch.ms_walk = bam->batch.ms_size = bam->batch.ms_copy = 0;
         fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr);
         const double t_p1 = np2h::now_ms();
         contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
         if (prof)
-            fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (block reads %.2f, inflate %.2f, buffer moves %.2f; %zu records, "
-                            "%zu SEQ bytes), records->pileup %.2f ms\n",
-                    name, t_p1 - t_p0, bam->batch.ms_read, bam->batch.ms_inflate, bam->batch.ms_drop, recs.size(), seq4.size(),
-                    np2h::now_ms() - t_p1);
+            fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (block headers %.2f, inflate [%s] %.2f, buffer moves %.2f, record "
+                            "walk %.2f, array sizing %.2f, record copies %.2f; %zu records, %zu SEQ bytes), records->pileup %.2f ms\n",
+                    name, t_p1 - t_p0, bam->batch.ms_read, Inflater::get().name(), bam->batch.ms_inflate, bam->batch.ms_drop,
+                    bam->batch.ms_walk, bam->batch.ms_size, bam->batch.ms_copy, recs.size(), seq4.size(), np2h::now_ms() - t_p1);
         np2h::flush_timings(cx);
     } catch (const np2h::Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);

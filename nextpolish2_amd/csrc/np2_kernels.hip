@@ -1263,10 +1263,12 @@ static constexpr uint64_t YAK_EMPTY = ~0ULL;
 
 __global__ void k_yak_insert(const uint64_t *__restrict__ words, const uint64_t *__restrict__ bucket_off,
                              uint32_t n_buckets, uint64_t *__restrict__ table, uint32_t cap_log2,
-                             uint32_t *__restrict__ dup_flag) {
+                             uint32_t *__restrict__ dup_flag, uint32_t gap) {
+    // gap = words between the end of one bucket's words and the start of the next one's: 0 for the boundary form
+    // (np2_yak_t), 1 when `words` is the dump file itself (each bucket preceded by its 8-byte header, kmer.rs:143-147)
     const uint32_t b = blockIdx.y;
     if (b >= n_buckets) return;
-    const uint64_t n = bucket_off[b + 1] - bucket_off[b];
+    const uint64_t n = bucket_off[b + 1] - bucket_off[b] - gap;
     const uint64_t capm = (1ULL << cap_log2) - 1;
     uint64_t *tb = table + ((uint64_t)b << cap_log2);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1529,12 +1531,12 @@ void launch_pair_count(hipStream_t s, const np2_read_t *reads, uint32_t R, const
     NP2_LAUNCH(k_pair_count, grid1(R), 256, s, reads, R, alive, lq_start, lq_end, n_reg, smin, pj, pcount, ck_off, rinfo);
 }
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
-                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag) {
+                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag, uint32_t gap) {
     uint32_t gx = (uint32_t)((max_bucket + 255) / 256);
     if (gx == 0) gx = 1;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_yak_insert, dim3(gx, n_buckets), dim3(256), 0, s, words, bucket_off, n_buckets, table,
-                       cap_log2, dup_flag);
+                       cap_log2, dup_flag, gap);
 }
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count,
                    uint16_t *out) {

@@ -126,7 +126,7 @@ void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint3
 void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uint8_t *alive, const uint32_t *lq_start,
                    uint32_t n_reg, int32_t *mval);
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
-                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag);
+                       uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag, uint32_t gap = 0);
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count, uint16_t *out);
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
                           uint16_t min_count, uint16_t *out, bool own_strings);

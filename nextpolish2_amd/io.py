@@ -12,7 +12,7 @@ assert BAMREC_DTYPE.itemsize == 40
 
 IO_SYMBOLS = ["np2_fasta_open", "np2_fasta_next", "np2_fasta_close", "np2_yak_load", "np2_yak_free", "np2_bam_open",
               "np2_bam_close", "np2_bam_n_refs", "np2_bam_ref_name", "np2_io_last_error", "np2_contig_from_records",
-              "np2_contig_from_bam", "np2_contig_export"]
+              "np2_contig_from_bam", "np2_contig_export", "np2_ctx_create_from_files"]
 
 
 class np2_front_opts_t(C.Structure):
@@ -66,6 +66,7 @@ def _bind_locked(L):
         L.np2_fasta_close.argtypes = [vp]
         L.np2_yak_load.argtypes = [C.c_char_p, C.POINTER(np2_yak_t)]
         L.np2_yak_free.argtypes = [C.POINTER(np2_yak_t)]
+        L.np2_ctx_create_from_files.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_int]
         L.np2_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.np2_bam_close.argtypes = [vp]
         L.np2_bam_n_refs.argtypes = [vp]
@@ -127,6 +128,21 @@ def load_yak(path):
     # itself may be collected while its views live on)
     weakref.finalize(yk, L.np2_yak_free, y)
     return yk
+
+
+def polisher_from_yak_files(paths, device=0):
+    """np2_ctx_create_from_files: a Polisher whose HBM k-mer tables are built from the dumps as they are read (no host
+    copy of the words; tables ordered by k, option.rs:238)."""
+    from .api import Polisher
+    L = _bind()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    h = C.c_void_p()
+    _io_check(L.np2_ctx_create_from_files(C.byref(h), device, arr, len(paths)))
+    p = Polisher.__new__(Polisher)
+    p._yaks = []
+    p._h = h
+    p.device = device
+    return p
 
 
 def write_yak(path, yak):

@@ -241,3 +241,45 @@ def test_command_line_on_a_whole_assembly_bam_equals_the_batch_driver(tmp_path):
     r = end_to_end_assembly(syn, yaks, str(tmp_path), [np.array(o[0]) for o in out], [o[1] for o in out], workers=2)
     assert r["identical_to_resident_path"], r
     bp.close()
+
+
+def test_tables_streamed_from_the_dump_files_equal_the_loaded_ones(tmp_path):
+    """np2_ctx_create_from_files (dump -> device in pieces, table built from the file image) against
+    np2_yak_load + np2_ctx_create: same counts for present, absent and below-threshold k-mers, tables ordered by k
+    whatever the order of the paths; broken dumps are refused with the loader's messages."""
+    s = Synth(60000, depth=20, seed=11, diploid=True)
+    yaks = [s.yak(21), s.yak(31)]
+    paths = []
+    for y in yaks:
+        paths.append(str(tmp_path / f"k{y.k}.yak"))
+        np2io.write_yak(paths[-1], y)
+    ref = Polisher(yaks)
+    got = np2io.polisher_from_yak_files(paths[::-1])  # (k31 first: sorted by k inside)
+    rng = np.random.default_rng(5)
+    for i, y in enumerate(yaks):
+        # a file word is (x >> 10) << 10 | count of the k-mer hash x with x & 1023 == its bucket: rebuild x for present keys
+        pos = rng.integers(0, y.words.shape[0], 4000)
+        b = (np.searchsorted(y.bucket_off, pos, side="right") - 1).astype(np.uint64)
+        present = (y.words[pos] >> np.uint64(10) << np.uint64(10)) | b
+        absent = rng.integers(0, 1 << 62, 4000, dtype=np.uint64)
+        h = np.concatenate([present, absent])
+        for mk in (1, 5, 200):
+            a, c = ref.lookup_hashes(i, h, mk), got.lookup_hashes(i, h, mk)
+            assert np.array_equal(a, c)
+        assert (ref.lookup_hashes(i, present, 1) > 0).all()
+    # and a polish through the streamed tables equals the one through the loaded tables
+    c1, c2 = ref.upload(s.pileup), got.upload(s.pileup)
+    b1, p1 = ref.polish_resident(c1, Opts())
+    b2, p2 = got.polish_resident(c2, Opts())
+    assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+    with open(tmp_path / "bad.yak", "wb") as f:
+        f.write(b"YAK\x01" + bytes(12))
+    with pytest.raises(Np2Error, match="incompatible"):
+        np2io.polisher_from_yak_files([str(tmp_path / "bad.yak")])
+    raw = open(paths[0], "rb").read()
+    with open(tmp_path / "cut.yak", "wb") as f:
+        f.write(raw[: len(raw) // 2])
+    with pytest.raises(Np2Error, match="Failed to parse"):
+        np2io.polisher_from_yak_files([str(tmp_path / "cut.yak")])
+    with pytest.raises(Np2Error, match="cannot open"):
+        np2io.polisher_from_yak_files([str(tmp_path / "none.yak")])

@@ -18,7 +18,7 @@ yk = []
 for y in yaks:
     yk.append(td + f"/k{y.k}.yak")
     np2io.write_yak(yk[-1], y)
-for t in (4, 4, 1):
+for t in (4, 4, 2, 2, 1):
     t0 = time.perf_counter()
     cli.main([bam, fa] + yk + ["-o", td + f"/o{t}_{time.time()}.fa", "-t", str(t), "-L", "20000"])
     print(f"-t {t}: {time.perf_counter() - t0:.3f} s", flush=True)
