@@ -85,10 +85,12 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     N128 w_[DENSE_CPW];
     uint32_t nv_[DENSE_CPW], nonins_[DENSE_CPW], incl_[DENSE_CPW], total_[DENSE_CPW];
     uint4 v_[DENSE_CPW];
+    bool full_[DENSE_CPW];
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) { // (all loads first)
         const uint32_t lc0 = dd[it].c0 + lane * 32;
-        const bool full = dd[it].ncols - dd[it].c0 >= 2048; // every lane of the wave holds 32 columns
+        const bool full = dd[it].live && dd[it].ncols - dd[it].c0 >= 2048; // every lane of the wave holds 32 columns
+        full_[it] = full;
         nv_[it] = !dd[it].live ? 0u : (full ? 32u : (lc0 < dd[it].ncols ? min(32u, dd[it].ncols - lc0) : 0u));
         v_[it] = make_uint4(0, 0, 0, 0);
         if (nv_[it]) v_[it] = *reinterpret_cast<const uint4 *>(nib + dd[it].nib_off + (lc0 >> 1));
@@ -101,8 +103,11 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         w.lo = (uint64_t)swap_nib(v_[it].x) | ((uint64_t)swap_nib(v_[it].y) << 32);
         w.hi = (uint64_t)swap_nib(v_[it].z) | ((uint64_t)swap_nib(v_[it].w) << 32);
         if (dd[it].c0 == 0 && lane == 0) w.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-        const N128 m = n_below(nv);
-        const N128 I{w.lo & NF3 & m.lo, w.hi & NF3 & m.hi}; // insertion columns
+        N128 I{w.lo & NF3, w.hi & NF3}; // insertion columns
+        if (!full_[it]) { // (uniform: 97 % of the chunks are whole, their lanes need no column masks)
+            const N128 m = n_below(nv);
+            I.lo &= m.lo, I.hi &= m.hi;
+        }
         const uint32_t nonins = nv - n_popc(I);
         const uint32_t incl = wave_incl_scan<OpAdd>(nonins);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -130,7 +135,14 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             }
             uint32_t carryN = 0; // non-insertion columns of the read before this chunk
             // earlier chunks of the read inside this block: from LDS; the ones in earlier blocks: from their status words
-            for (uint32_t j = max(dd[it].first_chunk, blk_first); j < ch; ++j) carryN += s_total[j - blk_first];
+            {
+                const uint32_t lo = max(dd[it].first_chunk, blk_first) - blk_first, hi = ch - blk_first; // (hi <= DENSE_CHUNKS <= 64)
+                uint32_t v = lane >= lo && lane < hi ? s_total[lane] : 0u;
+                if (lo < hi) {
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    carryN += v;
+                }
+            }
             const uint32_t jend = min(ch, blk_first);
             for (uint32_t j0 = dd[it].first_chunk; j0 < jend; j0 += 64) {
                 const uint32_t j = j0 + lane;
@@ -192,10 +204,11 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         // insertion column is dirty whatever the rest says): code differs from the contig (nibble != 0 -> + 7 carries
         // into bit 3) or the insertion flag itself; columns past the read's end are cleared
         N128 B0;
-        {
+        B0.lo = ((((w.lo ^ R.lo) & ~NF3) + ~NF3) | w.lo) & NF3;
+        B0.hi = ((((w.hi ^ R.hi) & ~NF3) + ~NF3) | w.hi) & NF3;
+        if (!full_[it]) {
             const N128 m = n_below(nv);
-            B0.lo = ((((w.lo ^ R.lo) & ~NF3) + ~NF3) | w.lo) & NF3 & m.lo;
-            B0.hi = ((((w.hi ^ R.hi) & ~NF3) + ~NF3) | w.hi) & NF3 & m.hi;
+            B0.lo &= m.lo, B0.hi &= m.hi;
         }
         const uint32_t n_ins = nv - nonins;
         // checkpoint: column of the reference column at the next multiple of CKPT (lanes without insertion columns:
