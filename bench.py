@@ -28,9 +28,10 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
          784333, 1091291, 948066, 85779]
 # HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
-# profiles/r02h_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r02h_ecoli_pmc_fetch_write.json
+# profiles/r03_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r03_ecoli_pmc_fetch_write.json
+# (the round-3 kernel; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9 KB)
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 31766.7 + 38123.8) * 1024), "ecoli": int((2 * 48516.1 + 39687.9) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 37752.6 + 38287.8) * 1024), "ecoli": int((2 * 51766.6 + 38812.5) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):

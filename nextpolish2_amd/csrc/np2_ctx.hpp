@@ -714,6 +714,12 @@ template <class F> inline void prim_op(np2_ctx *cx, F f) {
 // exclusive sum of any length: reduce-then-scan over 4096-element tiles (np2_cand.hip)
 inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n, bool write_end = false) {
     if (n >= 0xFFFFF000ull) throw Np2Error(NP2_E_NOMEM, "scan over more than 2^32 elements");
+    static const bool lb_all = getenv("NP2_SCAN_LB") != nullptr; // (experiment: one chained launch instead of three)
+    if (lb_all && (n + 2047) / 2048 <= np2_ctx::LB_MAX_BLOCKS) {
+        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n + 2047) / 2048)), in, out, (uint32_t)n, write_end,
+                            cx->scal.p + S_ERR);
+        return;
+    }
     const uint32_t nt = scan3_tiles((uint32_t)n);
     cx->scan_part.ensure((size_t)nt + 2);
     cx->scan_poff.ensure((size_t)nt + 2);
