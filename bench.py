@@ -87,7 +87,7 @@ class Groups:
         G = len(self.bps)
         outs = [[None] * self.n, [None] * self.n]
         done, seen = [0] * G, [0]
-        acc = [[0.0, 0, 0.0] for _ in range(G)]
+        acc = [[0.0, 0, 0.0, 0.0, 0.0, 0.0] for _ in range(G)]
         cv = threading.Condition()
         turn = [0]
 
@@ -102,6 +102,10 @@ class Groups:
                 acc[g][0] += ms
                 acc[g][1] = launches
                 acc[g][2] += self.bps[g].last_call_ms
+                inside, tail = self.bps[g].last_call_ms_inside()
+                acc[g][3] += inside
+                acc[g][4] += tail
+                acc[g][5] += sum(sum(f) for f in self.bps[g].flush_log())
                 with cv:
                     done[g] = k + 1
                     turn[0] += 1
@@ -119,6 +123,10 @@ class Groups:
                     cv.notify_all()
         for t in ths:
             t.join()
+        self.call_breakdown = {  # per group, mean over the steps, ms: the caller's clock around the C call, the call's own
+            # clock, the flushes inside it (host phase + issue + wait) and what follows the last flush
+            "caller_clock": [round(x[2] / max(1, steps), 3) for x in acc], "inside_call": [round(x[3] / max(1, steps), 3) for x in acc],
+            "flushes": [round(x[5] / max(1, steps), 3) for x in acc], "after_last_flush": [round(x[4] / max(1, steps), 3) for x in acc]}
         return (outs[(steps - 1) & 1], sum(x[0] for x in acc) / max(1, steps), sum(x[1] for x in acc),
                 sum(x[2] for x in acc) / max(1, steps * G))
 
@@ -566,6 +574,7 @@ def main():
             diff_launches = 1
     else:
         out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after)
+        call_breakdown = groups.call_breakdown
         diff_ms.append(ms)
     if single:
         out = drain_single(out)  # every polished sequence is on the host before the clock stops
@@ -620,7 +629,8 @@ def main():
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},
         "flush_ms": {"per_group_totals_host_issue_wait": [[round(sum(f[j] for f in fl), 3) for j in range(3)] for fl in flush_log],
                      "flushes_per_step": [len(fl) for fl in flush_log],
-                     "batch_call_ms_mean": round(float(call_ms), 3) if not single else None},
+                     "batch_call_ms_mean": round(float(call_ms), 3) if not single else None,
+                     "call_breakdown_ms_per_group": None if single else call_breakdown},
     }
 
     if not single and len(groups.bps) > 1:

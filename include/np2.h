@@ -169,6 +169,9 @@ int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches);
 /* cumulative counters: kernel launches issued, commands recorded by the pipelines, device flushes */
 /* per flush of the last np2_batch_polish: (host phase before it, command issue, device wait) in ms; returns the count */
 int np2_batch_flush_log(np2_batch_t *b, const double **log);
+/* wall time of the last np2_batch_polish measured inside the call (ms), and of it the part after the last flush
+ * (results handed over, workers parked): what a caller's own clock adds on top is its language runtime's */
+int np2_batch_last_call_ms(np2_batch_t *b, double *total_ms, double *tail_ms);
 int np2_batch_stats(np2_batch_t *b, uint64_t *launches, uint64_t *commands, uint64_t *flushes);
 
 /* ---- shards of one contig: reference-interval sharding of a long contig over several GPUs ------------------------------

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
     "np2_shard_final_device", "np2_shard_fetch", "np2_alloc_pinned",
-    "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_set_priority", "np2_batch_last_diff_ms", "np2_batch_stats",
+    "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_set_priority", "np2_batch_last_diff_ms", "np2_batch_stats", "np2_batch_last_call_ms",
 ]
 
 # include/np2_io.h (input side; bound by nextpolish2_amd.io)
@@ -104,6 +104,7 @@ def _lib_locked():
         L.np2_batch_set_priority.argtypes = [vp, C.c_int]
         L.np2_batch_set_priority.restype = C.c_int
         L.np2_batch_last_diff_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.np2_batch_last_call_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.np2_batch_flush_log.argtypes = [vp, C.POINTER(vp)]
         L.np2_shard_plan.argtypes = [vp, u32, u32, u32, u32, C.POINTER(np2_shard_plan_t)]
         L.np2_shard_upload.argtypes = [vp, vp, u32, vp, u32, vp, u64, C.POINTER(np2_shard_plan_t), C.POINTER(vp)]
@@ -352,6 +353,12 @@ class BatchPolisher:
         ms, n = C.c_float(), C.c_int()
         lib().np2_batch_last_diff_ms(self._h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def last_call_ms_inside(self):
+        """(wall ms of the last np2_batch_polish measured inside the call, ms of it after its last flush)"""
+        a, t = C.c_double(), C.c_double()
+        lib().np2_batch_last_call_ms(self._h, C.byref(a), C.byref(t))
+        return a.value, t.value
 
     def flush_log(self):
         """[(host ms, issue ms, device-wait ms)] per flush of the last polish call."""

@@ -77,6 +77,7 @@ struct np2_batch {
     // where a wave's wall time goes (ms, cumulative): host phases between flushes, issuing commands, waiting for the GPU
     double t_last_end = 0, ms_host = 0, ms_issue = 0, ms_wait = 0;
     std::vector<double> flush_log; // per flush of the last polish call: host, issue, wait (ms)
+    double call_ms = 0, tail_ms = 0; // the last polish call, measured inside it: whole / after its last flush
 };
 
 namespace {
@@ -380,6 +381,7 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
     b->diff_used = 0;
     b->flush_log.clear();
     b->t_last_end = now_ms();
+    const double t_call0 = b->t_last_end;
     for (int w0 = 0; w0 < n; w0 += S) { // waves of at most S contigs; contig w0 + i runs on slot i
         const int m = std::min(S, n - w0);
         {
@@ -417,6 +419,8 @@ int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const 
                 b->err = std::string("contig ") + std::to_string(w0 + i) + ": " + np2_last_error(b->slots[i]);
             }
     }
+    b->call_ms = now_ms() - t_call0;
+    b->tail_ms = now_ms() - b->t_last_end;
     if (b->time_diff) {
         b->last_diff_ms = 0;
         b->last_diff_launches = (int)b->diff_used;
@@ -437,6 +441,12 @@ int np2_batch_last_diff_ms(np2_batch_t *b, float *ms, int *launches) {
     if (!b || !ms || !launches) return NP2_E_ARG;
     *ms = b->last_diff_ms;
     *launches = b->last_diff_launches;
+    return NP2_OK;
+}
+int np2_batch_last_call_ms(np2_batch_t *b, double *total_ms, double *tail_ms) {
+    if (!b || !total_ms || !tail_ms) return NP2_E_ARG;
+    *total_ms = b->call_ms;
+    *tail_ms = b->tail_ms;
     return NP2_OK;
 }
 // per flush of the last np2_batch_polish: (host phase before it, command issue, device wait) in ms; returns the count

@@ -268,11 +268,12 @@ struct PinnedPool {
         if (it == live.end()) return false;
         free_.emplace_back(it->second, p);
         live.erase(it);
-        // keep what a batch of contigs hands back between two steps (a pinned allocation costs ~1 ms), but bound the
-        // idle memory: beyond 64 blocks or 1 GiB the oldest go
+        // keep what a batch of contigs hands back between two steps (a pinned allocation costs ~1 ms per MB), but bound
+        // the idle memory: beyond 2 GiB (or 4096 blocks) the oldest go.  (Every context's staging lives here too since
+        // round 3: a count limit of 64 blocks had the 17-contig bench free and re-pin blocks inside every step.)
         size_t held = 0;
         for (auto &f : free_) held += f.first;
-        while (free_.size() > 64 || (held > (1ull << 30) && free_.size() > 8)) {
+        while (free_.size() > 4096 || (held > (2ull << 30) && free_.size() > 8)) {
             held -= free_.front().first;
             (void)hipHostFree(free_.front().second);
             free_.erase(free_.begin());
@@ -711,15 +712,12 @@ template <class F> inline void prim_op(np2_ctx *cx, F f) {
     else
         f(cx->stream);
 }
+// exclusive sums from this length on take the chained multi-block kernel (k_scan_lb_excl: 2048 elements per block; with
+// relaxed status-word atomics it is 6-7 us where the 1024-thread single-block scan needs 11-12)
+static constexpr size_t SCAN_LB_MIN = 3072;
 // exclusive sum of any length: reduce-then-scan over 4096-element tiles (np2_cand.hip)
 inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n, bool write_end = false) {
     if (n >= 0xFFFFF000ull) throw Np2Error(NP2_E_NOMEM, "scan over more than 2^32 elements");
-    static const bool lb_all = getenv("NP2_SCAN_LB") != nullptr; // (experiment: one chained launch instead of three)
-    if (lb_all && (n + 2047) / 2048 <= np2_ctx::LB_MAX_BLOCKS) {
-        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n + 2047) / 2048)), in, out, (uint32_t)n, write_end,
-                            cx->scal.p + S_ERR);
-        return;
-    }
     const uint32_t nt = scan3_tiles((uint32_t)n);
     cx->scan_part.ensure((size_t)nt + 2);
     cx->scan_poff.ensure((size_t)nt + 2);
@@ -728,6 +726,11 @@ inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size
 
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
     // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
+    if (n_plus1 >= SCAN_LB_MIN && n_plus1 <= SCAN_SMALL_MAX) { // a few (dozen) blocks chained by a look-back
+        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n_plus1 + 2047) / 2048)), in, out, (uint32_t)n_plus1,
+                            false, cx->scal.p + S_ERR);
+        return 0;
+    }
     if (n_plus1 <= SCAN_SMALL_MAX) {
         launch_scan_small_excl(cx->stream, in, out, (uint32_t)n_plus1, nullptr, nullptr, false);
         return 0;
@@ -758,7 +761,7 @@ inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
 }
 // exclusive sums of in[0..n) into out[0..n], out[n] = total (in[n] is not read by the short path, cleared for the long one)
 inline void exclusive_total_n(np2_ctx *cx, uint32_t *in, uint32_t *out, size_t n) {
-    if (n >= 8192 && n + 1 <= SCAN_SMALL_MAX) { // a few dozen blocks chained by a look-back
+    if (n >= SCAN_LB_MIN && n + 1 <= SCAN_SMALL_MAX) { // a few (dozen) blocks chained by a look-back
         launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n + 2047) / 2048)), in, out, (uint32_t)n, true,
                             cx->scal.p + S_ERR);
         return;

@@ -37,7 +37,7 @@ __device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch, b
     uint64_t w;
     uint32_t spins = 0;
     for (;;) {
-        w = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(w >> 34) == epoch && ((uint32_t)(w >> 32) & 3u) != 0) break;
         if (++spins > LB_SPIN_LIMIT) {
             timeout = true;
@@ -75,8 +75,8 @@ __device__ __forceinline__ void lb_exclusive2(const Lookback &lb, uint32_t bid, 
         const uint32_t lane = threadIdx.x;
         if (lane == 0) {
             const uint32_t st = bid == 0 ? LB_PREFIX : LB_AGG;
-            __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, st, agg_a), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, st, agg_b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, st, agg_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, st, agg_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t ea = 0, eb = 0;
         if (bid > 0) {
@@ -119,9 +119,9 @@ __device__ __forceinline__ void lb_exclusive2(const Lookback &lb, uint32_t bid, 
                 if (j0 < 0) break;
             }
             if (lane == 0) {
-                __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, LB_PREFIX, ea + agg_a), __ATOMIC_RELEASE,
+                __hip_atomic_store(&lb.status_a[bid], lb_pack(lb.epoch, LB_PREFIX, ea + agg_a), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, LB_PREFIX, eb + agg_b), __ATOMIC_RELEASE,
+                __hip_atomic_store(&lb.status_b[bid], lb_pack(lb.epoch, LB_PREFIX, eb + agg_b), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
         }
