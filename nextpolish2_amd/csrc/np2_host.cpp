@@ -1084,8 +1084,24 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     if (reads[0].aln_t_s != 0 || reads[0].n_cols != L || reads[0].aln_t_e != L - 1 ||
         (reads[0].flags & NP2_READ_DROPPED))
         throw Np2Error(NP2_E_ARG, "reads[0] must be the contig aligned to itself (main.rs:1732-1739)");
-    std::vector<uint64_t> ck(n_reads + 1, 0);
-    std::vector<ChunkDesc> descs;
+    // what goes to the device is built in pinned blocks of the process-wide pool (pageable sources are staged by the
+    // runtime at a fraction of the bus rate, synchronously: 4 MB of descriptors per E. coli-sized contig)
+    struct PinnedTmp {
+        void *p = nullptr;
+        explicit PinnedTmp(size_t bytes) : p(pinned_pool().get(std::max<size_t>(bytes, 64))) {
+            if (!p) throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+        }
+        ~PinnedTmp() { pinned_pool().put(p); }
+    };
+    uint64_t total_chunks = 0;
+    for (uint32_t r = 1; r < n_reads; ++r)
+        if (!(reads[r].flags & NP2_READ_DROPPED)) total_chunks += ((uint64_t)reads[r].n_cols + 2047) / 2048;
+    if (total_chunks >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many pileup columns for one contig");
+    PinnedTmp ck_pin((size_t)(n_reads + 1) * 8), descs_pin((size_t)(total_chunks + 1) * sizeof(ChunkDesc));
+    uint64_t *ck = (uint64_t *)ck_pin.p;
+    ChunkDesc *descs = (ChunkDesc *)descs_pin.p;
+    uint32_t n_descs = 0;
+    ck[0] = 0;
     uint64_t cols = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
         const np2_read_t &rd = reads[r];
@@ -1103,9 +1119,9 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
             cols += rd.n_cols;
         }
         ck[r + 1] = ck[r] + nck;
-        const uint32_t first_chunk = (uint32_t)descs.size();
+        const uint32_t first_chunk = n_descs;
         for (uint32_t k = 0; k < nch; ++k) {
-            ChunkDesc d;
+            ChunkDesc &d = descs[n_descs++];
             memset(&d, 0, sizeof d);
             d.nib_off = rd.nib_off;
             d.ckbase = ck[r];
@@ -1116,19 +1132,22 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
             d.first_chunk = first_chunk;
             d.aln_t_e = rd.aln_t_e;
             d.nck = nck;
-            descs.push_back(d);
         }
     }
     // reads overlapping each contig tile, ascending read index (candidate extraction looks reads up by position)
     const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
-    std::vector<uint32_t> trd_off((size_t)n_tiles + 1, 0), trd;
+    PinnedTmp trd_off_pin(((size_t)n_tiles + 1) * 4);
+    uint32_t *trd_off = (uint32_t *)trd_off_pin.p;
+    memset(trd_off, 0, ((size_t)n_tiles + 1) * 4);
     for (uint32_t r = 0; r < n_reads; ++r)
         if (!(reads[r].flags & NP2_READ_DROPPED))
             for (uint32_t t = reads[r].aln_t_s >> TILE_SHIFT; t <= reads[r].aln_t_e >> TILE_SHIFT; ++t) ++trd_off[t + 1];
     for (uint32_t t = 0; t < n_tiles; ++t) trd_off[t + 1] += trd_off[t];
-    trd.resize(trd_off[n_tiles]);
+    const size_t n_trd = trd_off[n_tiles];
+    PinnedTmp trd_pin((n_trd + 1) * 4);
+    uint32_t *trd = (uint32_t *)trd_pin.p;
     {
-        std::vector<uint32_t> cur(trd_off.begin(), trd_off.end() - 1);
+        std::vector<uint32_t> cur(trd_off, trd_off + n_tiles);
         for (uint32_t r = 0; r < n_reads; ++r)
             if (!(reads[r].flags & NP2_READ_DROPPED))
                 for (uint32_t t = reads[r].aln_t_s >> TILE_SHIFT; t <= reads[r].aln_t_e >> TILE_SHIFT; ++t) trd[cur[t]++] = r;
@@ -1143,14 +1162,14 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     c->L = L;
     c->R = n_reads;
     c->n_tiles = n_tiles;
-    c->tile_rd_off.ensure(trd_off.size());
-    c->tile_rd.ensure(trd.size() + 1);
-    HIPCHK(hipMemcpyAsync(c->tile_rd_off.p, trd_off.data(), trd_off.size() * 4, hipMemcpyHostToDevice, s));
-    if (!trd.empty()) HIPCHK(hipMemcpyAsync(c->tile_rd.p, trd.data(), trd.size() * 4, hipMemcpyHostToDevice, s));
+    c->tile_rd_off.ensure((size_t)n_tiles + 1);
+    c->tile_rd.ensure(n_trd + 1);
+    HIPCHK(hipMemcpyAsync(c->tile_rd_off.p, trd_off, ((size_t)n_tiles + 1) * 4, hipMemcpyHostToDevice, s));
+    if (n_trd) HIPCHK(hipMemcpyAsync(c->tile_rd.p, trd, n_trd * 4, hipMemcpyHostToDevice, s));
     c->nib_bytes = nib_bytes;
     c->n_cols = cols;
     c->n_ckpt = ck[n_reads];
-    c->n_chunks = (uint32_t)descs.size();
+    c->n_chunks = n_descs;
     c->reads.ensure(n_reads);
     const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds
     c->refnib.ensure(((size_t)refbytes + 15) & ~(size_t)15);
@@ -1158,13 +1177,13 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     c->ckpt.ensure(c->n_ckpt + 1);
     c->descs.ensure(c->n_chunks + 1);
     HIPCHK(hipMemcpyAsync(c->reads.p, reads, (size_t)n_reads * sizeof(np2_read_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->ck_off.p, ck.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ck_off.p, ck, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
     if (c->n_chunks)
-        HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)c->n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->descs.p, descs, (size_t)c->n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
     cx->scal.ensure(64);
     zero32(cx, cx->scal.p, 24);
     launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p);
-    auto sc = d2h(cx, cx->scal.p, 1); // also syncs: the host staging vectors above go out of scope
+    auto sc = d2h(cx, cx->scal.p, 1); // also syncs: the pinned staging blocks above go back to the pool
     if (sc[0]) throw Np2Error(NP2_E_ARG, "reads[0] is not a plain self-alignment of the contig");
 }
 } // namespace np2h
