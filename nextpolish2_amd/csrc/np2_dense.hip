@@ -28,10 +28,12 @@ __device__ __forceinline__ uint8_t dense_ref_code(const uint8_t *__restrict__ re
     return (refnib[p >> 1] >> (4 * (p & 1))) & 7;
 }
 
-struct DenseChunk { // what phase 2 needs to know about a chunk of the block (LDS)
+struct DenseChunk { // what phase 2 needs to know about a chunk of the block (LDS): the first 48 bytes of its ChunkDesc,
+    // stored as loaded (three 16-byte pieces from the lane that fetched them) instead of field by field from scalars
     uint64_t nib_off, ckbase;
-    uint32_t read, ts, c0, ncols, nck, pad;
+    uint32_t read, ts, c0, ncols, first_chunk, aln_t_e, nck, pad;
 };
+static_assert(sizeof(DenseChunk) == 48, "DenseChunk mirrors the head of ChunkDesc");
 #ifndef NP2_DENSE_CPW
 #define NP2_DENSE_CPW 4
 #endif
@@ -48,7 +50,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
     __shared__ uint32_t s_total[DENSE_CHUNKS];        // non-insertion columns of the block's chunks
     __shared__ uint2 s_q[DENSE_CHUNKS * 64];          // dirty lanes: {t0, chunk in block << 6 | lane}
-    __shared__ DenseChunk s_desc[DENSE_CHUNKS];
+    __shared__ __attribute__((aligned(16))) DenseChunk s_desc[DENSE_CHUNKS];
     __shared__ uint32_t s_nq;
     __shared__ uint32_t s_tile[DENSE_TSLOTS], s_cnt[DENSE_TSLOTS], s_base[DENSE_TSLOTS]; // phase 2: the tiles the block adds records to
     const uint32_t blk_first = np2_bid * DENSE_CHUNKS;
@@ -68,6 +70,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         if (lane < DENSE_CPW && ch0 + lane < n_chunks) {
             const uint4 *p = reinterpret_cast<const uint4 *>(descs + ch0 + lane);
             q0 = p[0], q1 = p[1], q2 = p[2];
+            uint4 *d = reinterpret_cast<uint4 *>(&s_desc[ch0 + lane - blk_first]); // (read after the block's barriers)
+            d[0] = q0, d[1] = q1, d[2] = q2;
         }
         auto rl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
 #pragma unroll
@@ -139,8 +143,15 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 const uint32_t lo = max(dd[it].first_chunk, blk_first) - blk_first, hi = ch - blk_first; // (hi <= DENSE_CHUNKS <= 64)
                 uint32_t v = lane >= lo && lane < hi ? s_total[lane] : 0u;
                 if (lo < hi) {
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                    carryN += v;
+                    if (DENSE_CHUNKS <= 16) { // a row's worth of lanes: four DPP steps, lane 15 holds the sum
+                        v += dpp_get<0x111, 0xF>(0u, v);
+                        v += dpp_get<0x112, 0xF>(0u, v);
+                        v += dpp_get<0x114, 0xF>(0u, v);
+                        v += dpp_get<0x118, 0xF>(0u, v);
+                        carryN += (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+                    } else {
+                        carryN += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(v), 63);
+                    }
                 }
             }
             const uint32_t jend = min(ch, blk_first);
@@ -162,8 +173,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                         __builtin_amdgcn_s_sleep(2);
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                carryN += v;
+                carryN += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(v), 63);
             }
             carry_[it] = carryN;
         }
@@ -240,10 +250,6 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             }
         }
         if (lane == 0) {
-            DenseChunk dc;
-            dc.nib_off = dd[it].nib_off, dc.ckbase = dd[it].ckbase, dc.read = dd[it].read, dc.ts = ts, dc.c0 = c0, dc.ncols = ncols;
-            dc.nck = dd[it].nck, dc.pad = 0;
-            s_desc[ch - blk_first] = dc;
             if (c0 + 2048 >= ncols) {
                 // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
                 if (ncols == 0 || ts + carryN + total - 1 != dd[it].aln_t_e || dd[it].aln_t_e >= L) atomicOr(err, 2u);
