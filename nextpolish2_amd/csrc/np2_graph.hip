@@ -156,7 +156,8 @@ __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32
     __shared__ uint16_t s_q[CAP];    // position inside the tile
     __shared__ uint16_t s_idx[CAP];  // record indices grouped by position
     __shared__ uint32_t s_cnt[TILE]; // records per position (also the scatter cursor)
-    __shared__ uint32_t s_off[TILE];
+    __shared__ uint16_t s_off[TILE]; // (16 bits are enough below 64 k records and make the 1024 variant 18 KB: 8 blocks per CU, not 7;
+                                     // the 2048 variant 30 KB: 5, not 4)
     __shared__ uint32_t sh[8];
     const uint32_t n = tile_n[np2_bid], tid = threadIdx.x;
     const uint64_t a = (uint64_t)np2_bid * bucket_cap;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32
         const uint32_t c0 = s_cnt[q0], c1 = s_cnt[q0 + 1], c2 = s_cnt[q0 + 2], c3 = s_cnt[q0 + 3];
         uint32_t tot;
         const uint32_t l0 = block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot);
-        s_off[q0] = l0, s_off[q0 + 1] = l0 + c0, s_off[q0 + 2] = l0 + c0 + c1, s_off[q0 + 3] = l0 + c0 + c1 + c2;
+        s_off[q0] = (uint16_t)l0, s_off[q0 + 1] = (uint16_t)(l0 + c0), s_off[q0 + 2] = (uint16_t)(l0 + c0 + c1), s_off[q0 + 3] = (uint16_t)(l0 + c0 + c1 + c2);
         s_cnt[q0] = 0, s_cnt[q0 + 1] = 0, s_cnt[q0 + 2] = 0, s_cnt[q0 + 3] = 0;
     }
     __syncthreads();
@@ -404,7 +405,8 @@ __device__ __forceinline__ void k_tile_offsets_lb(const uint32_t np2_bid, const 
 // the packed DP records, node_off for every position of the tile and the tile's dirty-run starts.
 // Fast path (tile has at most TW_CAP records): records and nodes are staged in LDS, grouping and per-position
 // ordering never touch global memory.  Larger tiles take the same steps on the global arrays.
-static constexpr uint32_t TW_CAP = 1024;
+// (992, not 1024: 32 076 bytes of LDS per block instead of 32 840 — five blocks per CU instead of four)
+static constexpr uint32_t TW_CAP = 992;
 
 __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
