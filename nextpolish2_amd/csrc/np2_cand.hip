@@ -37,31 +37,51 @@ __device__ __forceinline__ void k_scan_small(const uint32_t np2_bid, const uint3
     }
 }
 
-// Mid-sized exclusive sums (8 k .. 64 k elements, length known on the host): the single-block scan above costs ~12 us per
-// 20 k elements whatever its tuning; a few dozen light, uniform blocks are what the decoupled look-back is good at.
-static constexpr uint32_t SCAN_LB_ITEMS = 8; // elements per thread, blocked: thread t owns [8t, 8t + 8) of its block's 2048
+// Exclusive sums whose length is known on the host, any length: blocks of 1024 threads x 8 elements chained by the
+// decoupled look-back (relaxed status words, np2_lookback.hpp).  One kernel for every length on purpose: the contigs of a
+// batch must not pick different kernels for the same step (their queues fall out of step and every later stage goes
+// out in more, smaller launches), and a 1.5 M-element scan is 183 blocks = three look-back hops.
+static constexpr uint32_t SCAN_LB_ITEMS = 8;   // elements per thread, blocked: thread t owns [8t, 8t + 8) of its block's 8192
+static constexpr uint32_t SCAN_LB_THREADS = 1024;
+static constexpr uint32_t SCAN_LB_BLOCK = SCAN_LB_ITEMS * SCAN_LB_THREADS;
 __device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint32_t n, bool write_end,
                                                       uint32_t *__restrict__ err) {
-    __shared__ uint32_t sh[8];
+    __shared__ uint32_t sh[16];
     const uint32_t bid = lb_block_id(lb, sh);
-    const uint32_t i0 = bid * (256 * SCAN_LB_ITEMS) + threadIdx.x * SCAN_LB_ITEMS;
+    const uint32_t i0 = bid * SCAN_LB_BLOCK + threadIdx.x * SCAN_LB_ITEMS;
     uint32_t v[SCAN_LB_ITEMS], sum = 0;
+    const bool wide = (((uintptr_t)in | (uintptr_t)out) & 15) == 0; // (uniform) 16-byte accesses for whole octets
+    if (wide && i0 + SCAN_LB_ITEMS <= n) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(in + i0), b = *reinterpret_cast<const uint4 *>(in + i0 + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
 #pragma unroll
-    for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) {
-        v[k] = i0 + k < n ? in[i0 + k] : 0u;
-        sum += v[k];
+        for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
     }
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) sum += v[k];
     uint32_t total, pre, dummy;
-    uint32_t run = block_excl_scan<OpAdd, 4>(sum, sh, total);
+    uint32_t run = block_excl_scan<OpAdd, 16>(sum, sh, total);
     lb_exclusive2(lb, bid, total, 0u, sh, err, pre, dummy);
     run += pre;
+    if (wide && i0 + SCAN_LB_ITEMS <= n) {
+        uint4 a, b;
+        a.x = run, a.y = a.x + v[0], a.z = a.y + v[1], a.w = a.z + v[2];
+        b.x = a.w + v[3], b.y = b.x + v[4], b.z = b.y + v[5], b.w = b.z + v[6];
+        *reinterpret_cast<uint4 *>(out + i0) = a;
+        *reinterpret_cast<uint4 *>(out + i0 + 4) = b;
+        run = b.w + v[7];
+    } else {
 #pragma unroll
-    for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) {
-        if (i0 + k < n) out[i0 + k] = run;
-        run += v[k];
+        for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
     }
-    if (write_end && bid == n_blocks - 1 && threadIdx.x == 255) out[n] = run; // (the last thread's running sum = total)
+    // (the thread holding element n - 1 ends with the total)
+    if (write_end && n && i0 <= n - 1 && n - 1 < i0 + SCAN_LB_ITEMS) out[n] = run;
+    if (write_end && n == 0 && bid == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
 // Long exclusive sums (one element per contig position / consensus base / band slot): reduce-then-scan.  Tiles of 4096
@@ -673,10 +693,11 @@ void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, ui
 }
 void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, uint32_t *out, uint32_t n, bool write_end,
                           uint32_t *err) {
-    const uint32_t nb = (n + 256 * SCAN_LB_ITEMS - 1) / (256 * SCAN_LB_ITEMS);
-    NP2_LAUNCH(k_scan_lb_excl, dim3(nb), 256, s, lb, nb, in, out, n, write_end, err);
+    const uint32_t nb = scan_lb_blocks(n);
+    NP2_LAUNCH(k_scan_lb_excl, dim3(nb), SCAN_LB_THREADS, s, lb, nb, in, out, n, write_end, err);
 }
 uint32_t scan3_tiles(uint32_t n) { return (n + SCAN3_TILE - 1) / SCAN3_TILE; }
+uint32_t scan_lb_blocks(uint64_t n) { return (uint32_t)std::max<uint64_t>(1, (n + SCAN_LB_BLOCK - 1) / SCAN_LB_BLOCK); }
 void launch_scan3_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part, uint32_t *part_off,
                        bool write_end) {
     if (!n) return;

@@ -712,12 +712,18 @@ template <class F> inline void prim_op(np2_ctx *cx, F f) {
     else
         f(cx->stream);
 }
-// exclusive sums from this length on take the chained multi-block kernel (k_scan_lb_excl: 2048 elements per block; with
-// relaxed status-word atomics it is 6-7 us where the 1024-thread single-block scan needs 11-12)
-static constexpr size_t SCAN_LB_MIN = 3072;
-// exclusive sum of any length: reduce-then-scan over 4096-element tiles (np2_cand.hip)
+// Exclusive sums of host-known length, any length: ONE kernel, blocks of 8192 elements chained by the decoupled
+// look-back (k_scan_lb_excl, np2_cand.hip).  Not a choice by length: a threshold had the contigs of a batch pick
+// different kernels for the same step, their queues fell out of step and every later stage went out in more, smaller
+// launches.  NP2_SCAN3=1 brings back the three-launch reduce-then-scan for long arrays (A/B measurements).
 inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n, bool write_end = false) {
     if (n >= 0xFFFFF000ull) throw Np2Error(NP2_E_NOMEM, "scan over more than 2^32 elements");
+    static const bool scan3 = getenv("NP2_SCAN3") != nullptr;
+    if (!scan3 || n <= SCAN_SMALL_MAX) {
+        launch_scan_lb_excl(cx->stream, next_lookback(cx, scan_lb_blocks(n)), in, out, (uint32_t)n, write_end,
+                            cx->scal.p + S_ERR);
+        return;
+    }
     const uint32_t nt = scan3_tiles((uint32_t)n);
     cx->scan_part.ensure((size_t)nt + 2);
     cx->scan_poff.ensure((size_t)nt + 2);
@@ -725,16 +731,7 @@ inline void scan_large_excl(np2_ctx *cx, const uint32_t *in, uint32_t *out, size
 }
 
 inline uint32_t exclusive_total(np2_ctx *cx, const uint32_t *in, uint32_t *out, size_t n_plus1) {
-    // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); returns out[n_plus1-1] lazily on device
-    if (n_plus1 >= SCAN_LB_MIN && n_plus1 <= SCAN_SMALL_MAX) { // a few (dozen) blocks chained by a look-back
-        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n_plus1 + 2047) / 2048)), in, out, (uint32_t)n_plus1,
-                            false, cx->scal.p + S_ERR);
-        return 0;
-    }
-    if (n_plus1 <= SCAN_SMALL_MAX) {
-        launch_scan_small_excl(cx->stream, in, out, (uint32_t)n_plus1, nullptr, nullptr, false);
-        return 0;
-    }
+    // scans n_plus1 elements (caller guarantees in[n_plus1-1] == 0); out[n_plus1-1] = the total, on the device
     scan_large_excl(cx, in, out, n_plus1);
     return 0;
 }
@@ -759,19 +756,9 @@ inline void scan_incl_sum(np2_ctx *cx, const int32_t *in, int32_t *out, size_t n
 inline void zero32(np2_ctx *cx, void *p, size_t n_elems, size_t elem = 4) {
     op_fill(cx, p, 0, n_elems * elem);
 }
-// exclusive sums of in[0..n) into out[0..n], out[n] = total (in[n] is not read by the short path, cleared for the long one)
+// exclusive sums of in[0..n) into out[0..n], out[n] = total
 inline void exclusive_total_n(np2_ctx *cx, uint32_t *in, uint32_t *out, size_t n) {
-    if (n >= SCAN_LB_MIN && n + 1 <= SCAN_SMALL_MAX) { // a few (dozen) blocks chained by a look-back
-        launch_scan_lb_excl(cx->stream, next_lookback(cx, (uint32_t)((n + 2047) / 2048)), in, out, (uint32_t)n, true,
-                            cx->scal.p + S_ERR);
-        return;
-    }
-    if (n + 1 <= SCAN_SMALL_MAX) {
-        launch_scan_small_excl(cx->stream, in, out, (uint32_t)n, nullptr, nullptr, true);
-        return;
-    }
-    zero32(cx, in + n, 1);
-    exclusive_total(cx, in, out, n + 1);
+    scan_large_excl(cx, in, out, n, true);
 }
 
 // validate the read descriptors, build checkpoint offsets / chunk tables / contig codes for a contig whose

@@ -143,6 +143,7 @@ void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, 
                           uint32_t *err);
 // exclusive sums of any length (reduce-then-scan over 4096-element tiles); part / part_off: scan3_tiles(n) + 1 words each
 uint32_t scan3_tiles(uint32_t n);
+uint32_t scan_lb_blocks(uint64_t n); // blocks of launch_scan_lb_excl over n elements (its look-back descriptor is sized by this)
 void launch_scan3_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part, uint32_t *part_off,
                        bool write_end);
 void launch_scan_small_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_dev,

@@ -7,6 +7,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     m = re.search(r"np2::(\w+)", n)
     if m: return m.group(1)
+    m = re.search(r"_ZNS_\d+(k_[a-z0-9_]+?)E", n) or re.search(r"_ZNS_\d+(k_[a-z0-9_]+)", n)  # (the batched launch template)
+    if m: return m.group(1)
     if "init_lookback" in n: return "prim:init"
     m = re.search(r"wrapped_(\w+?)_config", n)
     if m: return "prim:" + m.group(1)
@@ -23,6 +25,8 @@ for r in rows[a:b]:
     gap = (s - prev_end) / 1e3
     busy += (e - s) / 1e3
     gaps.append(gap)
-    print(f"{(s - t0) / 1e3:9.1f} us  +{gap:6.1f} gap  {(e - s) / 1e3:7.1f} us  {short(r['Kernel_Name'])}")
+    grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+    wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
+    print(f"{(s - t0) / 1e3:9.1f} us  +{gap:6.1f} gap  {(e - s) / 1e3:7.1f} us  {short(r['Kernel_Name'])}  grid {grid}/{wg}")
     prev_end = max(prev_end, e)
 print(f"step span {(prev_end - t0) / 1e3:.1f} us, busy {busy:.1f} us, launches {b - a}, gaps>10us: {sum(g for g in gaps if g > 10):.1f} us, small gaps: {sum(g for g in gaps if 0 < g <= 10):.1f} us")
