@@ -114,17 +114,38 @@ void flush(np2_batch *b) {
                 any |= idx[i] < q.size();
             }
             if (!any) break;
-            // the kernel most queues are waiting to launch (ties: the one of the lowest slot)
+            // Which of the kernels at the queue heads goes out now?  One that no other queue is about to reach: if kernel K
+            // heads some queues and lies a few commands ahead in others, launching it now would launch it again for
+            // those others a moment later — and they would stay one step behind for the rest of the flush, every later
+            // stage going out twice (a contig that takes an extra kernel, or another variant of one, is enough).  So the
+            // head that nobody else has in its near future goes first (the stragglers catch up); ties: the kernel most
+            // queues are waiting for, then the lowest slot.
             const KernelDesc *best = nullptr;
-            int best_n = 0;
+            int best_n = 0, best_defer = 0;
+            static constexpr size_t LOOKAHEAD = 8;
             for (int i = 0; i < n; ++i) {
                 auto &q = b->recs[i].q;
                 if (idx[i] >= q.size()) continue;
                 const KernelDesc *kd = q[idx[i]].kd;
-                int c = 0;
-                for (int j = i; j < n; ++j)
-                    if (idx[j] < b->recs[j].q.size() && b->recs[j].q[idx[j]].kd == kd) ++c;
-                if (c > best_n) best = kd, best_n = c;
+                bool seen = false; // (counted when its first queue came by)
+                for (int j = 0; j < i && !seen; ++j)
+                    seen = idx[j] < b->recs[j].q.size() && b->recs[j].q[idx[j]].kd == kd;
+                if (seen) continue;
+                int c = 0, defer = 0;
+                for (int j = 0; j < n; ++j) {
+                    auto &qj = b->recs[j].q;
+                    if (idx[j] >= qj.size()) continue;
+                    if (qj[idx[j]].kd == kd) {
+                        ++c;
+                        continue;
+                    }
+                    for (size_t k = idx[j] + 1; k < qj.size() && k <= idx[j] + LOOKAHEAD; ++k)
+                        if (qj[k].kd == kd) {
+                            ++defer;
+                            break;
+                        }
+                }
+                if (!best || defer < best_defer || (defer == best_defer && c > best_n)) best = kd, best_n = c, best_defer = defer;
             }
             uint32_t grids[MAXB];
             const void *args[MAXB];

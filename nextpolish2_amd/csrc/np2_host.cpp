@@ -812,7 +812,9 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
         launch_region_measure(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                               cx->reg_bytes.p, cx->reg_maxlen.p, cx->blk_sum.p);
         {
-            const bool wide = n_reg >= 8192; // 2048+ region blocks: chained blocks instead of one
+            // (the chained variant whenever there is a region at all: a threshold had the contigs of a batch pick different
+            // kernels here, and everything up to the vote went out twice, once per half of the batch)
+            const bool wide = n_reg > 0;
             Lookback lb{};
             if (wide) lb = next_lookback(cx, cand_offsets_blocks(n_reg));
             launch_cand_offsets(s, cx->blk_sum.p, n_reg, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p,
