@@ -2,8 +2,9 @@
 
 Usage: nextPolish2 [OPTIONS] <HiFi.map.bam> <genome.fa[.gz]> <short.read.yak>...
 Same positionals, flags, defaults and output format as the reference; contigs are polished on the GPU and written in
-input order.  `-t N` runs up to N contigs concurrently (N np2 contexts on the same GPU, one host thread each, capped at
-4): the host-side phases of one contig (BAM parsing, the phasing vote's Louvain) overlap the GPU phases of another."""
+input order.  `-t N` (N >= 2) keeps two front ends (BGZF inflate on the host pool, GPU columnariser) and two polish
+contexts going side by side: the host-side phases of one contig (BAM parsing, the phasing vote's Louvain) overlap the
+GPU phases of another; the k-mer dumps are streamed into their HBM tables next to the first front ends."""
 import argparse
 import os
 import resource
