@@ -283,3 +283,25 @@ def test_tables_streamed_from_the_dump_files_equal_the_loaded_ones(tmp_path):
         np2io.polisher_from_yak_files([str(tmp_path / "cut.yak")])
     with pytest.raises(Np2Error, match="cannot open"):
         np2io.polisher_from_yak_files([str(tmp_path / "none.yak")])
+
+
+def test_zlib_fallback_of_the_block_decoder_gives_the_same_records(tmp_path):
+    """NP2_INFLATE=zlib (what a host without libdeflate's runtime library runs) against the default decoder: the command
+    line's output is byte-identical."""
+    s = Synth(60000, depth=20, seed=71, diploid=True, read_len_mean=6000.0, read_len_sd=900.0, name="ctgZ")
+    recs = pileup_to_records(s.pileup, tid=0, rng=np.random.default_rng(9), decorate=True)
+    write_bam(str(tmp_path / "m.bam"), [("ctgZ", s.pileup.L)], recs)
+    with open(tmp_path / "g.fa", "wb") as f:
+        f.write(b">ctgZ\n" + s.pileup.ref.tobytes() + b"\n")
+    np2io.write_yak(str(tmp_path / "k21.yak"), s.yak(21))
+    outs = []
+    for mode in ("", "zlib"):
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        if mode:
+            env["NP2_INFLATE"] = mode
+        out = tmp_path / f"out_{mode or 'default'}.fa"
+        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-L", "10000", "-o", str(out), str(tmp_path / "m.bam"),
+                            str(tmp_path / "g.fa"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and outs[0].startswith(b">ctgZ start:")
