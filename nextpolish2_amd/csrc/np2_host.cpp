@@ -144,6 +144,20 @@ struct VoteData {
     bool any = false;                 // false: no read votes anywhere, nobody can lose
     std::vector<uint64_t> pair_key;   // a << 32 | b (a < b), ascending
     std::vector<uint32_t> pair_cnt;   // HETE regions in which the pair agrees | disagrees << 16
+    // ... or, instead of the two vectors, a view of a caller's arrays (np2_vote_decide with one sorted vote: a
+    // chromosome's pair list is 200 MB, not to be copied for nothing)
+    const uint64_t *view_key = nullptr;
+    const uint32_t *view_cnt = nullptr;
+    uint64_t view_n = 0;
+    const uint64_t *keys() const { return view_key ? view_key : pair_key.data(); }
+    const uint32_t *cnts() const { return view_key ? view_cnt : pair_cnt.data(); }
+    uint64_t n_pairs() const { return view_key ? view_n : (uint64_t)pair_key.size(); }
+    void own() { // copy a view into the vectors (the viewed memory is about to be reused)
+        if (!view_key) return;
+        pair_key.assign(view_key, view_key + view_n);
+        pair_cnt.assign(view_cnt, view_cnt + view_n);
+        view_key = nullptr, view_cnt = nullptr, view_n = 0;
+    }
     std::vector<uint32_t> first_key;  // per read: creation rank of its key in the reference's weight map = index of the
                                       // first HETE region it votes in (0xFFFFFFFF: none); shards: see shard_vote_export
     std::vector<int32_t> ref_w;       // per read: summed weight against the contig's own candidate (ref_data[0])
@@ -254,12 +268,9 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
             op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
         }
         op_sync(cx);
-        vd.pair_key.resize(NU);
-        vd.pair_cnt.resize(NU);
-        if (NU) {
-            memcpy(vd.pair_key.data(), pin, (size_t)NU * 8);
-            memcpy(vd.pair_cnt.data(), pin + b_key, (size_t)NU * 4);
-        }
+        // the pairs stay where they landed (the context's pinned read-back staging: valid until its next read-back; a
+        // chromosome's list is 200 MB): the plain pipeline decides the vote right away, a shard copies them first
+        vd.view_key = (const uint64_t *)pin, vd.view_cnt = (const uint32_t *)(pin + b_key), vd.view_n = NU;
         const uint8_t *vb = pin + b_key + b_w;
         vd.first_key.assign((const uint32_t *)vb, (const uint32_t *)vb + R);
         vd.ref_w.assign((const int32_t *)(vb + RP * 4), (const int32_t *)(vb + RP * 4) + R);
@@ -267,6 +278,7 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         vd.bad.assign(vb + RP * 9, vb + RP * 9 + R);
     }
     if (cx->trace) {
+        vd.own(); // (the traces below read back through the same staging)
         trace_put(cx, pass, "hete.lable", d2h(cx, cx->reg_lable.p, n_reg));
         trace_put(cx, pass, "hete.kscore", d2h(cx, cx->kscore.p, pc.NC));
     }
@@ -278,12 +290,13 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
 std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all) {
     if (!vd.any) return {};
     const uint32_t R = vd.R;
-    const uint64_t NU = vd.pair_key.size();
+    const uint64_t NU = vd.n_pairs();
+    const uint32_t *const pair_cnt = vd.cnts();
+    const double t_host0 = now_ms();
     std::vector<std::pair<uint32_t, uint32_t>> keys;
     for (uint32_t r = 0; r < R; ++r)
         if (vd.first_key[r] != 0xFFFFFFFFu) keys.emplace_back(vd.first_key[r], r);
     std::sort(keys.begin(), keys.end());
-    const double t_host0 = now_ms();
     const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
     double t_mark = t_host0;
     auto mark = [&](const char *what) {
@@ -295,17 +308,18 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
     };
     phase::Graph data;
     data.reserve_ids(R);
+    mark("key order");
     for (auto &k : keys) data.add_key(k.second);
+    mark("key table");
     // data weight of a pair = sum(w), unless the pair disagrees in 3 or more regions: then -(#disagreements)
     // (dif <= -3 overwrites, main.rs:996-1002)
     auto weight = [&](uint64_t i) {
-        const int32_t same = (int32_t)(vd.pair_cnt[i] & 0xFFFFu), neg = (int32_t)(vd.pair_cnt[i] >> 16);
+        const int32_t same = (int32_t)(pair_cnt[i] & 0xFFFFu), neg = (int32_t)(pair_cnt[i] >> 16);
         return (float)(neg >= 3 ? -neg : same - neg);
     };
     // data.retain(..) + per-row retain (main.rs:1004-1010) drop the reads flagged bad and every edge pointing at one:
     // those edges are left out while the rows are built (the rows' relative order is all that is kept of them)
-    if (!data.add_edges(NU, [&](uint64_t i) { return (uint32_t)(vd.pair_key[i] >> 32); },
-                        [&](uint64_t i) { return (uint32_t)vd.pair_key[i]; }, weight, use_all ? nullptr : vd.bad.data()))
+    if (!data.add_edges_sorted(vd.keys(), NU, weight, use_all ? nullptr : vd.bad.data()))
         throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
     mark("keys + edges");
     std::vector<uint32_t> bad;
@@ -1731,6 +1745,7 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
     NP2_SHARD_TRY(cx, {
         VoteData vd;
         run_vote_pass(sr->run, vd);
+        vd.own(); // (read-backs follow before the pairs are exported)
         sr->v_key.clear(), sr->v_cnt.clear(), sr->v_read.clear(), sr->v_first.clear(), sr->v_refw.clear(), sr->v_flags.clear();
         if (vd.any) {
             // region index -> contig position: the merged key order of the contig's weight map is by descending region
@@ -1824,6 +1839,10 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
                 xk = sk.data(), xc = sc.data();
             }
             const size_t nx = sorted ? (size_t)x.n_pairs : sk.size();
+            if (n_votes == 1 && sorted) { // the caller's arrays as they are
+                vd.view_key = xk, vd.view_cnt = xc, vd.view_n = nx;
+                continue;
+            }
             if (mk.empty()) {
                 mk.assign(xk, xk + nx);
                 mc.assign(xc, xc + nx);
@@ -1852,8 +1871,10 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
             tc.insert(tc.end(), xc + j, xc + nx);
             mk.swap(tk), mc.swap(tc);
         }
-        vd.pair_key.swap(mk);
-        vd.pair_cnt.swap(mc);
+        if (!vd.view_key) {
+            vd.pair_key.swap(mk);
+            vd.pair_cnt.swap(mc);
+        }
         for (uint32_t r = 0; r < n_reads_total; ++r)
             if (votes_any[r]) vd.first_key[r] = 0xFFFFFFFEu - first_pos[r]; // ascending = right to left
         std::vector<uint32_t> ls = vote_decide(nullptr, vd, opts->use_all_reads != 0);

@@ -16,11 +16,37 @@
 #include <cstdint>
 #include <unordered_map>
 #include <unordered_set>
+#include <memory>
+#include <thread>
 #include <utility>
 #include <vector>
 
 namespace np2 {
 namespace phase {
+
+// Host threads for the order-free parts of a LARGE vote (the read graph of a chromosome-sized diploid contig: 3 x 10^5
+// nodes, 2 x 10^7 pairs): building the adjacency rows and the per-community sums of an aggregation.  Everything whose
+// ORDER the reference's hash containers make observable (key creation, community iteration, new_nid renaming, the
+// Gauss-Seidel sweep itself) stays on one thread.  Small votes never start a thread.
+inline unsigned host_threads() {
+    static const unsigned n = [] {
+        if (const char *e = getenv("NP2_VOTE_THREADS")) return (unsigned)std::max(1, atoi(e));
+        return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+// f(t, lo, hi) over T = min(host_threads, n / min_per_thread) contiguous pieces of [0, n); the caller's thread takes piece 0
+template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F f) {
+    const size_t T = std::max<size_t>(1, std::min<size_t>(host_threads(), min_per_thread ? n / min_per_thread : n));
+    if (T <= 1) {
+        f((unsigned)0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { f((unsigned)t, n * t / T, n * (t + 1) / T); });
+    f((unsigned)0, (size_t)0, n / T);
+    for (auto &x : th) x.join();
+}
 
 template <class V> class SwissOrderMap {
   public:
@@ -248,6 +274,20 @@ typedef SwissOrderMap<Nil> OrderSet;
 // Signed weighted read graph.  `keys` reproduces the creation order of the outer keys of the reference's
 // HashMap<u32, HashMap<u32, f32>> (only that order is observable); the rows are CSR adjacency lists
 // (row iteration order only feeds exact small-integer f32 sums, so it is free).
+// std::allocator whose value-less construct() leaves the element as it is: resize() of a 270 MB edge array must not
+// zero what the fill loops overwrite a moment later (12 of the 19 ms the rows of a chromosome's graph took to build),
+// and its pages are then first touched by the threads that fill them
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        typedef NoInitAlloc<U> other;
+    };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *) noexcept {}
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) {
+        ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+};
 struct Graph {
     typedef std::pair<uint32_t, float> Edge;
     // row iteration helper
@@ -260,7 +300,7 @@ struct Graph {
     OrderSet keys;
     std::vector<uint8_t> is_key; // dense mirror of `keys` (membership tests without hashing)
     std::vector<uint32_t> off;   // CSR row offsets, n_ids() + 1 entries
-    std::vector<Edge> edges;     // directed copies of the undirected edges, grouped by source node
+    std::vector<Edge, NoInitAlloc<Edge>> edges; // directed copies of the undirected edges, grouped by source node
 
     uint32_t n_ids() const { return (uint32_t)is_key.size(); }
     void reserve_ids(uint32_t n) {
@@ -302,6 +342,99 @@ struct Graph {
             edges[cur[a]++] = Edge(b, w);
             edges[cur[b]++] = Edge(a, w);
         }
+        return true;
+    }
+    // The same rows from a pair list SORTED by (a << 32 | b) with a < b (what the vote delivers), on several threads and
+    // still deterministic: every row ends up sorted by neighbour id — its partners below it, then those above it —,
+    // which is also what the serial loop above produces for such a list.  A thread owns a range of ROWS: the partners
+    // above a row are one contiguous run of the list, the partners below it are found by scanning the list from
+    // `maxgap` rows before the range (b - a is bounded by the vote's band).  No atomics, two scans (count, fill).
+    // Returns false if an endpoint is not a key; falls back to add_edges for a list that is not sorted like that.
+    template <class GetW>
+    bool add_edges_sorted(const uint64_t *key, uint64_t n, GetW gw, const uint8_t *skip = nullptr) {
+        auto ga = [&](uint64_t i) { return (uint32_t)(key[i] >> 32); };
+        auto gb = [&](uint64_t i) { return (uint32_t)key[i]; };
+        if (n < (1u << 18) || host_threads() < 2) return add_edges(n, ga, gb, gw, skip);
+        const uint32_t N = n_ids();
+        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
+        // pass 0: endpoints are keys, the list is sorted with a < b, largest b - a
+        struct Chk {
+            bool ok = true, sorted = true;
+            uint32_t maxgap = 0;
+        };
+        std::vector<Chk> chk(host_threads());
+        parallel_ranges(n, 1u << 16, [&](unsigned t, size_t lo, size_t hi) {
+            Chk c;
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t a = ga(i), b = gb(i);
+                if (!has_key(a) || !has_key(b)) c.ok = false;
+                if (a >= b || (i && key[i - 1] >= key[i])) c.sorted = false;
+                else c.maxgap = std::max(c.maxgap, b - a);
+            }
+            chk[t] = c;
+        });
+        uint32_t maxgap = 0;
+        bool sorted = true;
+        for (const Chk &c : chk) {
+            if (!c.ok) return false;
+            sorted = sorted && c.sorted;
+            maxgap = std::max(maxgap, c.maxgap);
+        }
+        if (!sorted) return add_edges(n, ga, gb, gw, skip);
+        const double t1 = now();
+        // row ranges with about the same number of pairs each
+        const size_t T = std::min<size_t>(host_threads(), n >> 16);
+        std::vector<uint32_t> row_lo(T + 1, 0);
+        for (size_t t = 1; t < T; ++t) row_lo[t] = std::max(row_lo[t - 1], ga(n * t / T));
+        row_lo[T] = N;
+        auto first_pair_of = [&](uint32_t row) { // first pair whose a >= row
+            return (size_t)(std::lower_bound(key, key + n, (uint64_t)row << 32) - key);
+        };
+        off.assign((size_t)N + 1, 0);
+        std::vector<uint32_t> n_lo((size_t)N, 0); // partners below each row
+        auto scan = [&](size_t t, bool fill) {
+            const uint32_t r0 = row_lo[t], r1 = row_lo[t + 1];
+            if (r0 >= r1) return;
+            const size_t i_own = first_pair_of(r0), i_end = first_pair_of(r1);
+            const size_t i_beg = first_pair_of(r0 > maxgap ? r0 - maxgap : 0);
+            std::vector<uint32_t> cur_lo, cur_up;
+            if (fill) {
+                cur_lo.assign(off.begin() + r0, off.begin() + r1);
+                cur_up.resize(r1 - r0);
+                for (uint32_t v = r0; v < r1; ++v) cur_up[v - r0] = off[v] + n_lo[v];
+            }
+            for (size_t i = i_beg; i < i_end; ++i) {
+                const uint32_t a = ga(i), b = gb(i);
+                if (skip && (skip[a] | skip[b])) continue;
+                if (b >= r0 && b < r1) { // a partner below row b
+                    if (fill) edges[cur_lo[b - r0]++] = Edge(a, gw(i));
+                    else ++n_lo[b];
+                }
+                if (i >= i_own) { // (a in [r0, r1)) a partner above row a
+                    if (fill) edges[cur_up[a - r0]++] = Edge(b, gw(i));
+                    else ++off[a + 1];
+                }
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, false); });
+            scan(0, false);
+            for (auto &x : th) x.join();
+        }
+        const double t2 = now();
+        for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v] + n_lo[v];
+        edges.resize(off[N]);
+        const double t3 = now();
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, true); });
+            scan(0, true);
+            for (auto &x : th) x.join();
+        }
+        if (prof) fprintf(stderr, "    rows: check %.2f ms, count %.2f ms, offsets + allocation %.2f ms, fill %.2f ms (%zu threads, largest b - a %u)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, T, maxgap);
         return true;
     }
     // drop the rows of the flagged nodes and every edge pointing at one (row order is preserved)
@@ -461,15 +594,58 @@ class SignedLouvain {
     }
     // weight of a community = carried weights + half of every directed internal edge (louvain.rs:124-134)
     float internal_weight(uint32_t cid, const uint32_t *mb, const uint32_t *me, std::vector<uint32_t> &mem) const {
-        float w = 0.f;
+        collect_members(mb, me, mem);
+        return weight_only(cid, mb, me);
+    }
+    void collect_members(const uint32_t *mb, const uint32_t *me, std::vector<uint32_t> &mem) const {
         for (const uint32_t *p = mb; p != me; ++p) {
             const uint32_t v = *p;
             if (level0_) mem.push_back(v);
             else mem.insert(mem.end(), members_[v].begin(), members_[v].end());
+        }
+    }
+    float weight_only(uint32_t cid, const uint32_t *mb, const uint32_t *me) const {
+        float w = 0.f;
+        for (const uint32_t *p = mb; p != me; ++p) {
+            const uint32_t v = *p;
             w += node_w_[v];
             for (const auto &e : g_.adj(v))
                 if (node_id_[e.first] == cid) w += e.second / 2.0f;
         }
+        return w;
+    }
+    // Weights of all live communities (the O(edges) part of an aggregation).  Large graph: threads take ranges of NODES
+    // (after the first sweep a chromosome's graph is a few hundred communities of thousands of reads each) and add into
+    // their own per-community partial sums, which are then added up in thread order.  Every term is a multiple of 0.5,
+    // so the sums are exact — and equal to the member-order sums of weight_only — as long as they stay below 2^22; a
+    // community beyond that is summed again the serial way.
+    std::vector<float> all_weights(const std::vector<uint32_t> &moff, const std::vector<uint32_t> &mlist) const {
+        const size_t n = node_id_.size();
+        std::vector<float> w(n, 0.f);
+        if (g_.edges.size() < (1u << 20) || host_threads() < 2) {
+            for (uint32_t id = 0; id < n; ++id)
+                if (cnt_[id]) w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
+            return w;
+        }
+        std::vector<std::vector<float>> part(host_threads());
+        parallel_ranges(n, 4096, [&](unsigned t, size_t lo, size_t hi) {
+            std::vector<float> &p = part[t];
+            p.assign(n, 0.f);
+            for (size_t v = lo; v < hi; ++v) {
+                if (!g_.has_key((uint32_t)v)) continue;
+                const uint32_t cid = node_id_[v];
+                float acc = node_w_[v];
+                for (const auto &e : g_.adj((uint32_t)v))
+                    if (node_id_[e.first] == cid) acc += e.second / 2.0f;
+                p[cid] += acc;
+            }
+        });
+        for (const auto &p : part)
+            if (!p.empty())
+                for (size_t id = 0; id < n; ++id) w[id] += p[id];
+        for (uint32_t id = 0; id < n; ++id)
+            if (cnt_[id] && !(w[id] > -4194304.f && w[id] < 4194304.f))
+                w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
         return w;
     }
     // iteration order of a community's member set: replay its history into the emulated hash set
@@ -485,6 +661,16 @@ class SignedLouvain {
     }
 
     void aggregate() { // second_stage, louvain.rs:119-195
+        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr && g_.edges.size() >= (1u << 20);
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_m = now();
+        auto mark = [&](const char *what) {
+            if (prof) {
+                const double t = now();
+                fprintf(stderr, "    aggregate: %s %.2f ms\n", what, t - t_m);
+                t_m = t;
+            }
+        };
         OrderSet ncomm;
         std::unordered_map<uint32_t, Community> nnode;
         std::vector<uint32_t> split;
@@ -492,11 +678,15 @@ class SignedLouvain {
         member_lists(moff, mlist);
         // new community key of every current node (members of split communities get their own key)
         std::vector<uint32_t> key_of(node_id_.size(), 0xFFFFFFFFu);
+        mark("member lists");
+        const std::vector<float> w_int = all_weights(moff, mlist);
+        mark("community weights");
         comm_keys_.each([&](uint32_t id, const Nil &) {
             if (cnt_[id] == 0) return;
             Community c;
             c.id = id;
-            c.weight = internal_weight(id, mlist.data() + moff[id], mlist.data() + moff[id + 1], c.members);
+            c.weight = w_int[id];
+            collect_members(mlist.data() + moff[id], mlist.data() + moff[id + 1], c.members);
             for (uint32_t i = moff[id]; i < moff[id + 1]; ++i) key_of[mlist[i]] = id;
             if (c.weight < 0.f) {
                 split.push_back(id);
@@ -505,6 +695,7 @@ class SignedLouvain {
                 nnode[id] = std::move(c);
             }
         });
+        mark("community table");
         for (uint32_t id : split) { // decluster negative communities, louvain.rs:145-165
             for (uint32_t v : member_order(id)) {
                 uint32_t nid = v;
@@ -519,6 +710,7 @@ class SignedLouvain {
                 key_of[v] = nid;
             }
         }
+        mark("declustering");
         // inter-community weights, accumulated over the directed edges (louvain.rs:167-188 computes the same sums);
         // one pass per new community with a small local accumulator (a community touches few others)
         uint32_t max_id = 0;
@@ -535,32 +727,58 @@ class SignedLouvain {
             for (uint32_t v = 0; v < key_of.size(); ++v)
                 if (key_of[v] != 0xFFFFFFFFu) klist[cur[key_of[v]]++] = v;
         }
-        std::vector<std::pair<uint32_t, float>> local;
-        for (uint32_t a = 0; a <= max_id; ++a) {
-            if (koff[a] == koff[a + 1]) continue;
-            local.clear();
-            for (uint32_t i = koff[a]; i < koff[a + 1]; ++i)
-                for (const auto &e : g_.adj(klist[i])) {
-                    const uint32_t b = key_of[e.first];
-                    if (b == a) continue;
-                    bool hit = false;
-                    for (auto &l : local)
-                        if (l.first == b) {
-                            l.second += e.second;
-                            hit = true;
-                            break;
-                        }
-                    if (!hit) local.emplace_back(b, e.second);
+        // (the rows of a range of new ids are independent of every other range: several threads on a large graph, each
+        // keeping its rows in id order; they are appended in id order afterwards)
+        mark("key lists");
+        struct Rows {
+            std::vector<Graph::Edge> edges;
+            std::vector<std::pair<uint32_t, uint32_t>> row; // (id, end offset in edges)
+        };
+        std::vector<Rows> part(host_threads());
+        parallel_ranges((size_t)max_id + 1, g_.edges.size() >= (1u << 20) ? 4096 : (size_t)max_id + 2,
+                        [&](unsigned t, size_t lo, size_t hi) {
+            Rows &out = part[t];
+            std::vector<std::pair<uint32_t, float>> local;
+            for (uint32_t a = (uint32_t)lo; a < (uint32_t)hi; ++a) {
+                if (koff[a] == koff[a + 1]) continue;
+                local.clear();
+                for (uint32_t i = koff[a]; i < koff[a + 1]; ++i)
+                    for (const auto &e : g_.adj(klist[i])) {
+                        const uint32_t b = key_of[e.first];
+                        if (b == a) continue;
+                        bool hit = false;
+                        for (auto &l : local)
+                            if (l.first == b) {
+                                l.second += e.second;
+                                hit = true;
+                                break;
+                            }
+                        if (!hit) local.emplace_back(b, e.second);
+                    }
+                // a node enters the aggregated graph with its first non-zero weight (rows hold only those)
+                local.erase(std::remove_if(local.begin(), local.end(), [](const Graph::Edge &l) { return l.second == 0.f; }),
+                            local.end());
+                if (!local.empty()) {
+                    out.edges.insert(out.edges.end(), local.begin(), local.end());
+                    out.row.emplace_back(a, (uint32_t)out.edges.size());
                 }
-            // a node enters the aggregated graph with its first non-zero weight (rows hold only those)
-            local.erase(std::remove_if(local.begin(), local.end(), [](const Graph::Edge &l) { return l.second == 0.f; }),
-                        local.end());
-            if (!local.empty()) {
-                ng.add_key(a);
-                ng.append_row(a, local);
+            }
+        });
+        mark("inter-community rows");
+        {
+            std::vector<Graph::Edge> row;
+            for (const Rows &r : part) { // (thread t took the t-th range of ids: already in id order)
+                uint32_t b0 = 0;
+                for (const auto &x : r.row) {
+                    row.assign(r.edges.begin() + b0, r.edges.begin() + x.second);
+                    ng.add_key(x.first);
+                    ng.append_row(x.first, row);
+                    b0 = x.second;
+                }
             }
         }
         ng.end_rows();
+        mark("new graph");
         g_ = std::move(ng);
         comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);
@@ -575,6 +793,7 @@ class SignedLouvain {
             members_[kv.first] = std::move(kv.second.members);
             cnt_[kv.first] = 1;
         }
+        mark("state of the next level");
     }
 
     bool collect(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts,

@@ -1,0 +1,44 @@
+"""Host side of the phasing vote on a vote recorded from a GPU run (tools/vote_dump.py: 16 Mb diploid contig, 36.9 k reads,
+1.08 M read pairs, decided there by the single-threaded code of the time): the adjacency rows and the aggregation sums
+are built on several host threads for a graph of this size — the decision must not move."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from nextpolish2_amd.api import Vote, vote_decide
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def load():
+    z = np.load(os.path.join(HERE, "golden", "votes", "vote_16Mb_diploid.npz"))
+    return Vote.unpack(z["packed"]), int(z["n_reads"][0]), z["losers"]
+
+
+def test_recorded_vote_is_decided_the_same_on_several_threads():
+    v, n_reads, want = load()
+    assert len(v.pair_key) >= (1 << 18)  # large enough for the threaded paths
+    got = vote_decide([v], n_reads)
+    assert np.array_equal(got, want)
+    # cut in two "shards" (pairs split in the middle, per-read records of both halves): the merge path
+    h = len(v.pair_key) // 2
+    a = Vote(pair_key=v.pair_key[:h], pair_cnt=v.pair_cnt[:h], read_id=v.read_id, first_pos=v.first_pos, ref_w=v.ref_w, flags=v.flags)
+    b = Vote(pair_key=v.pair_key[h:], pair_cnt=v.pair_cnt[h:])
+    assert np.array_equal(vote_decide([a, b], n_reads), want)
+
+
+def test_one_thread_and_many_agree():
+    code = ("import sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_vote_host_cpu import load\n"
+            "from nextpolish2_amd.api import vote_decide\n"
+            "v, n, want = load()\n"
+            "print(zlib.crc32(vote_decide([v], n).tobytes()))\n" % (ROOT, HERE))
+    outs = []
+    for t in ("1", "8"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, NP2_VOTE_THREADS=t), timeout=600)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1]
