@@ -526,7 +526,9 @@ class SignedLouvain {
     std::vector<uint32_t> node_id_; // community of each (possibly aggregated) node
     std::vector<float> node_w_;     // weight carried by an aggregated node
     bool level0_ = true;                        // nodes are still single reads: members of node v = {v}
-    std::vector<std::vector<uint32_t>> members_; // original read ids of an aggregated node (from the first aggregation on)
+    // original read ids of an aggregated node (from the first aggregation on); by node id, only the nodes that exist (a
+    // vector over all ids was 600 k empty vectors per level for a chromosome's graph)
+    std::unordered_map<uint32_t, std::vector<uint32_t>> members_;
     std::vector<uint32_t> cnt_;                 // members per community
     // member operations of this level in order: (community, +(v + 1) insert / -(v + 1) remove); one flat log instead
     // of a vector per community (thousands of small allocations per contig), filtered when a community is replayed
@@ -601,7 +603,10 @@ class SignedLouvain {
         for (const uint32_t *p = mb; p != me; ++p) {
             const uint32_t v = *p;
             if (level0_) mem.push_back(v);
-            else mem.insert(mem.end(), members_[v].begin(), members_[v].end());
+            else {
+                const std::vector<uint32_t> &m = members_.at(v);
+                mem.insert(mem.end(), m.begin(), m.end());
+            }
         }
     }
     float weight_only(uint32_t cid, const uint32_t *mb, const uint32_t *me) const {
@@ -705,7 +710,7 @@ class SignedLouvain {
                 c.id = nid;
                 c.weight = node_w_[v];
                 if (level0_) c.members = {v};
-                else c.members = members_[v];
+                else c.members = members_.at(v);
                 nnode[nid] = std::move(c);
                 key_of[v] = nid;
             }
@@ -783,7 +788,8 @@ class SignedLouvain {
         comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);
         node_w_.assign(max_id + 1, 0.f);
-        members_.assign(max_id + 1, {});
+        members_.clear();
+        members_.reserve(nnode.size());
         level0_ = false;
         cnt_.assign(max_id + 1, 0);
         oplog_.clear();
