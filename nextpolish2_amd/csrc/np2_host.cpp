@@ -881,22 +881,35 @@ struct ResultOut {
     bool want_pos = true;
     bool want_bases = true; // false: the sequence stays on the device (np2_last_result_device / np2_result_fetch_begin)
 };
-void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, ResultOut &r) {
+// M_cap: what the host knows the length is at most (the device buffers hold that many elements).  The sequence is copied
+// out up to that bound in the SAME wait that brings the length back (one device round trip per contig less than
+// "length first, then the copy"; the bound exceeds the length by the splice rounds' growth allowance, a few per cent).
+void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, uint32_t M_cap, ResultOut &r) {
     const double t0 = now_ms();
     // final length + the error word of everything that ran without a read-back since the last one
     // (the same post carries the first and the last consensus position: the FASTA header span)
-    const std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                nullptr, dpos, cx->scal.p + S_M1);
+    std::vector<uint32_t> sc;
+    if (r.want_bases || r.want_pos) {
+        const uint32_t seq = ++cx->mbox_seq;
+        launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, dpos, cx->scal.p + S_M1);
+        if (r.want_bases) r.bases = (uint8_t *)pinned_pool().get((size_t)M_cap + 1);
+        if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M_cap + 1) * 4);
+        if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
+        if (r.want_bases) op_d2h(cx, r.bases, dbase, M_cap);
+        if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)M_cap * 4);
+        op_sync(cx);
+        if (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
+            throw Np2Error(NP2_E_DEVICE, "mailbox not posted after a synchronisation");
+        sc.assign(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
+    } else {
+        sc = fetch_scal(cx, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dpos, cx->scal.p + S_M1);
+    }
     check_region_err(cx, sc[S_ERR]);
     const uint32_t M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
+    if (M > M_cap) throw Np2Error(NP2_E_DEVICE, "internal: consensus longer than its bound");
     r.len = M;
-    if (r.want_bases) r.bases = (uint8_t *)pinned_pool().get((size_t)M + 1);
-    if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M + 1) * 4);
-    if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
-    if (r.want_bases) op_d2h(cx, r.bases, dbase, M);
-    if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)M * 4);
-    if (r.want_bases || r.want_pos) op_sync(cx);
     cx->last_first_pos = sc[S_M1];
     cx->last_last_pos = sc[S_M2];
     cx->last_dbase = dbase;
@@ -1014,7 +1027,7 @@ void run_final_pass(PolishRun &r, ResultOut &result) {
     run_pass_front(r);
     const uint32_t n_reg = r.n_reg;
     if (n_reg == 0) {
-        fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, result);
+        fetch_result(cx, cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, r.M, result);
         return;
     }
     PassCounts &pc = r.pc;
@@ -1045,7 +1058,7 @@ void run_final_pass(PolishRun &r, ResultOut &result) {
         trace_region_tables(cx, (int)r.pass, "rech" + std::to_string(y), pc, true);
         if (cx->trace) trace_cns(cx, (int)r.pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
     }
-    fetch_result(cx, cur.pos, cur.base, cur.M_p, result);
+    fetch_result(cx, cur.pos, cur.base, cur.M_p, cur.M_cap, result);
 }
 
 void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
