@@ -430,6 +430,7 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     __shared__ uint32_t s_nkey[TW_CAP]; // node: bases | delta << 16
     __shared__ uint32_t s_ncnt[TW_CAP];
     __shared__ uint32_t s_nmin[TW_CAP];
+    __shared__ long long s_gain[4];
     const uint32_t tid = threadIdx.x;
     const uint64_t a = tl.begin(np2_bid);
     const uint32_t n = tl.tile_n[np2_bid];
@@ -442,25 +443,52 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
         cnt[i] = 0;
         dcov[i] = 0;
     }
+    if (tid == 0) dcov[TILE] = 0;
+    __syncthreads(); // (LDS only: nothing in flight yet)
+    // Two chains of dependent loads — the tile's records (key, read -> alive) and its read list (read -> alive, span: the
+    // coverage, Msa::coverage, main.rs:232-241, as a difference array) — and a third on thread 0 (is the position left
+    // of the tile dirty?): requested level by level for all of them, not one chain after the other (by the phase
+    // timers the read list alone, behind a barrier of its own, was 18 % of a tile's time).
+    const uint32_t ro0 = tile_rd_off[np2_bid], ro1 = tile_rd_off[np2_bid + 1];
+    uint64_t rk[4];
+    uint32_t rv[4];
+    const uint32_t ci = ro0 + tid;
+    const bool hasc = ci < ro1;
+    uint32_t cr = 0;
+    if (hasc) cr = tile_rd[ci];
+    if (fast) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t i = tid + 256 * j;
+            rk[j] = 0, rv[j] = 0;
+            if (i < n) rk[j] = keys[a + i], rv[j] = vals[a + i];
+        }
+    }
+    uint8_t cal = 0;
+    uint32_t cts = 0, cte = 0;
+    if (hasc) cal = alive[cr], cts = reads[cr].aln_t_s, cte = reads[cr].aln_t_e;
+    if (fast) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t i = tid + 256 * j;
+            if (i < n) {
+                s_k[i] = rk[j];
+                s_v[i] = rv[j] | (alive[rv[j]] ? 0x80000000u : 0u);
+            }
+        }
+    }
     if (tid == 0) {
-        dcov[TILE] = 0;
         prevd = 0;
         if (start) {
             const uint64_t pa = tl.begin(np2_bid - 1);
             prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[np2_bid - 1], start - 1) ? 1u : 0u;
         }
     }
-    if (fast) {
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint32_t r = vals[a + i];
-            s_k[i] = keys[a + i];
-            s_v[i] = r | (alive[r] ? 0x80000000u : 0u);
-        }
+    if (hasc && cal) {
+        atomicAdd(&dcov[max(cts, start) - start], 1);
+        atomicAdd(&dcov[min(cte, start + TILE - 1) - start + 1], -1);
     }
-    __syncthreads();
-    // ---- coverage of the tile's positions (Msa::coverage, main.rs:232-241): difference array over the live reads
-    //      overlapping the tile, then a block-wide inclusive scan ----------------------------------------------
-    for (uint32_t i = tile_rd_off[np2_bid] + tid; i < tile_rd_off[np2_bid + 1]; i += 256) {
+    for (uint32_t i = ci + 256; i < ro1; i += 256) { // (a tile under more than 256 reads)
         const uint32_t r = tile_rd[i];
         if (!alive[r]) continue;
         const uint32_t ts = reads[r].aln_t_s, te = reads[r].aln_t_e;
@@ -475,10 +503,9 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
         uint32_t tot;
         const int32_t pre = (int32_t)block_excl_scan_256((uint32_t)(d0 + d1 + d2 + d3), sh, tot);
         cv[0] = pre + d0, cv[1] = cv[0] + d1, cv[2] = cv[1] + d2, cv[3] = cv[2] + d3;
-        for (uint32_t j = 0; j < 4; ++j)
-            if (q + j < npos) cov[start + q + j] = cv[j];
-        // the on-chip DP of short runs keeps coverages and counts in 16 bits: tell it when that does not hold
-        if (max(max(cv[0], cv[1]), max(cv[2], cv[3])) >= deep_min) atomicOr(deep_flag, 1u); // (65536; lower in a test)
+        // (stored at the end of the kernel with everything else that goes to memory: a barrier waits for the stores
+        // issued before it, and there are a dozen barriers to come — by the phase timers a third of a tile's time was
+        // spent at barriers waiting for the coverage / node_off / emission stores of the phase before)
     }
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
@@ -533,9 +560,6 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     uint32_t tot;
     const uint32_t l0 = block_excl_scan_256(c0 + c1 + c2 + c3, sh, tot); // tile-local node index of position q0
     const uint32_t off[5] = {l0, l0 + c0, l0 + c0 + c1, l0 + c0 + c1 + c2, l0 + c0 + c1 + c2 + c3};
-    for (uint32_t j = 0; j < 4; ++j)
-        if (q0 + j < npos) node_off[start + q0 + j] = nbase + off[j];
-    if (np2_bid == n_tiles - 1 && tid == 255) node_off[L] = nbase + off[4];
     // ---- order the nodes of each position, emit the packed records ---------------------------------------
     const uint32_t cj[4] = {c0, c1, c2, c3};
     if (fast) {
@@ -559,15 +583,7 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
                 s_nmin[x] = m;
             }
         }
-        __syncthreads();
-        for (uint32_t i = tid; i < nn; i += 256) { // coalesced write-out
-            const uint32_t kk = s_nkey[i], c = s_ncnt[i];
-            const uint32_t o = nbase + i;
-            nd.bases[o] = (uint16_t)(kk >> 16);
-            nd.delta[o] = (uint16_t)kk;
-            nd.count[o] = c;
-            nrec[o] = make_uint2((kk >> 16) | (kk << 16), c);
-        }
+        // (the sorted nodes are written out at the end: they stay in LDS untouched until then)
     } else {
         for (uint32_t j = 0; j < 4; ++j) {
             if (cj[j] == 0) continue;
@@ -599,39 +615,67 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     //      best-path score: a clean position after a clean one adds 10 * c0 - 4 * cov = 6 * cov -------------------
     // per position: bit 0 = has exception nodes, bit 1 = coverage below 2 (what the consensus write-out needs to know
     // about a position, in one byte instead of two node offsets and the coverage); four positions per store
-    if (q0 < npos) {
-        uint32_t pf = 0;
+    uint32_t pf = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) pf |= ((cj[j] ? 1u : 0u) | (cv[j] < 2 ? 2u : 0u)) << (8 * j);
-        *reinterpret_cast<uint32_t *>(pflag + start + q0) = pf; // (padded past L)
-    }
+    for (uint32_t j = 0; j < 4; ++j) pf |= ((cj[j] ? 1u : 0u) | (cv[j] < 2 ? 2u : 0u)) << (8 * j);
     const bool pd0 = q0 ? cnt[q0 - 1] != 0 : prevd != 0;
+    // the contig codes of the thread's four positions: two bytes of the nibble-packed contig (start + q0 is a multiple of 4)
+    const uint32_t ref4 = q0 < npos ? *reinterpret_cast<const uint16_t *>(refnib + ((start + q0) >> 1)) : 0u;
+    uint32_t em[4];
     {
         long long gain = 0;
         bool pdirty = pd0;
         for (uint32_t j = 0; j < 4; ++j) {
             const bool d = cj[j] != 0;
+            em[j] = d ? 0u : (((ref4 >> (4 * j)) & 7) != 4 ? 1u : 0u);
             if (q0 + j < npos) {
-                emit[start + q0 + j] = d ? 0u : (((refnib[(start + q0 + j) >> 1] >> (4 * ((start + q0 + j) & 1))) & 7) != 4 ? 1u : 0u);
                 if (!d && !pdirty) gain += 6LL * cv[j];
             }
             pdirty = d;
         }
         for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
-        __shared__ long long s_gain[4];
         if ((tid & 63) == 0) s_gain[tid >> 6] = gain;
         __syncthreads();
-        // one value per tile, summed later (same-address atomics from every tile would serialise at L2)
-        if (tid == 0) tile_gain[np2_bid] = s_gain[0] + s_gain[1] + s_gain[2] + s_gain[3];
     }
     // ---- dirty-run starts ----------------------------------------------------------------------------------
     const bool s0 = c0 && !pd0, s1 = c1 && !c0, s2 = c2 && !c1, s3 = c3 && !c2;
     uint32_t r = tile_roff[np2_bid] +
                  block_excl_scan_256((uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3, sh, tot);
+    // ---- everything that goes to memory, after the last barrier ------------------------------------------------
     if (s0) run_start[r++] = start + q0;
     if (s1) run_start[r++] = start + q0 + 1;
     if (s2) run_start[r++] = start + q0 + 2;
     if (s3) run_start[r++] = start + q0 + 3;
+    if (q0 < npos) {
+        *reinterpret_cast<uint32_t *>(pflag + start + q0) = pf; // (padded past L)
+        if (q0 + 4 <= npos) { // whole quads (start + q0 is a multiple of 4: 16-byte stores)
+            *reinterpret_cast<int4 *>(cov + start + q0) = make_int4(cv[0], cv[1], cv[2], cv[3]);
+            *reinterpret_cast<uint4 *>(node_off + start + q0) = make_uint4(nbase + off[0], nbase + off[1], nbase + off[2], nbase + off[3]);
+            *reinterpret_cast<uint4 *>(emit + start + q0) = make_uint4(em[0], em[1], em[2], em[3]);
+        } else {
+            for (uint32_t j = 0; j < 4; ++j)
+                if (q0 + j < npos) {
+                    cov[start + q0 + j] = cv[j];
+                    node_off[start + q0 + j] = nbase + off[j];
+                    emit[start + q0 + j] = em[j];
+                }
+        }
+    }
+    if (np2_bid == n_tiles - 1 && tid == 255) node_off[L] = nbase + off[4];
+    // the on-chip DP of short runs keeps coverages and counts in 16 bits: tell it when that does not hold
+    if (max(max(cv[0], cv[1]), max(cv[2], cv[3])) >= deep_min) atomicOr(deep_flag, 1u); // (65536; lower in a test)
+    // one value per tile, summed later (same-address atomics from every tile would serialise at L2)
+    if (tid == 0) tile_gain[np2_bid] = s_gain[0] + s_gain[1] + s_gain[2] + s_gain[3];
+    if (fast) {
+        for (uint32_t i = tid; i < nn; i += 256) { // coalesced write-out of the tile's nodes
+            const uint32_t kk = s_nkey[i], c = s_ncnt[i];
+            const uint32_t o = nbase + i;
+            nd.bases[o] = (uint16_t)(kk >> 16);
+            nd.delta[o] = (uint16_t)kk;
+            nd.count[o] = c;
+            nrec[o] = make_uint2((kk >> 16) | (kk << 16), c);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
