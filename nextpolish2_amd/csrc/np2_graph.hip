@@ -431,6 +431,7 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     __shared__ uint32_t s_ncnt[TW_CAP];
     __shared__ uint32_t s_nmin[TW_CAP];
     __shared__ long long s_gain[4];
+    __shared__ uint32_t s_wt[16];
     const uint32_t tid = threadIdx.x;
     const uint64_t a = tl.begin(np2_bid);
     const uint32_t n = tl.tile_n[np2_bid];
@@ -509,7 +510,64 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     }
     // ---- nodes in key order ---------------------------------------------------------------------------
     uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += 256) { // uniform trip count: the block scans below need every thread
+    if (fast) {
+        // all (up to four) records of a thread at once: group heads count their live members, then ONE exchange of the
+        // per-wave node counts of the four 256-record slices (ballots) places every node — instead of a block scan
+        // (two barriers) per slice
+        bool isn[4];
+        uint32_t gcv[4], gmv[4], lr[4];
+        const uint32_t lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t i = tid + 256 * j;
+            isn[j] = false, gcv[j] = 0, gmv[j] = 0xFFFFFFFFu;
+            if (i < n) {
+                const uint64_t k = s_k[i];
+                if (i == 0 || s_k[i - 1] != k) {
+                    uint32_t gc = 0, gm = 0xFFFFFFFFu;
+                    for (uint32_t jj = i; jj < n && s_k[jj] == k; ++jj) {
+                        const uint32_t v = s_v[jj];
+                        if (v >> 31) {
+                            ++gc;
+                            gm = min(gm, v & 0x7FFFFFFFu);
+                        }
+                    }
+                    isn[j] = gc != 0, gcv[j] = gc, gmv[j] = gm;
+                }
+            }
+            const uint64_t bal = __ballot(isn[j]);
+            lr[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (lane == 0) s_wt[wv * 4 + j] = (uint32_t)__builtin_popcountll(bal);
+        }
+        __syncthreads();
+        uint32_t tot_j[4], before_w[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            tot_j[j] = 0, before_w[j] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint32_t t = s_wt[w * 4 + j];
+                tot_j[j] += t;
+                if (w < wv) before_w[j] += t;
+            }
+        }
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (isn[j]) {
+                const uint32_t i = tid + 256 * j;
+                const uint64_t k = s_k[i];
+                const uint32_t li = base + before_w[j] + lr[j]; // node index inside the tile
+                s_nkey[li] = (uint32_t)k;                       // bases << 16 | delta1 in the key's low word
+                s_ncnt[li] = gcv[j];
+                s_nmin[li] = gmv[j];
+                atomicAdd(&cnt[(uint32_t)(k >> 32) - start], 1u);
+            }
+            base += tot_j[j];
+        }
+        carry = base;
+    }
+    for (uint32_t c0 = 0; !fast && c0 < n; c0 += 256) { // uniform trip count: the block scans below need every thread
         const uint32_t i = c0 + tid;
         uint32_t gc = 0, gm = 0xFFFFFFFFu;
         bool isnode = false;
