@@ -884,7 +884,8 @@ struct ResultOut {
 // M_cap: what the host knows the length is at most (the device buffers hold that many elements).  The sequence is copied
 // out up to that bound in the SAME wait that brings the length back (one device round trip per contig less than
 // "length first, then the copy"; the bound exceeds the length by the splice rounds' growth allowance, a few per cent).
-void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, uint32_t M_cap, ResultOut &r) {
+void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const uint32_t *M_p, uint32_t M_cap, ResultOut &r,
+                  uint32_t M_likely = 0xFFFFFFFFu) {
     const double t0 = now_ms();
     // final length + the error word of everything that ran without a read-back since the last one
     // (the same post carries the first and the last consensus position: the FASTA header span)
@@ -896,12 +897,21 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
         if (r.want_bases) r.bases = (uint8_t *)pinned_pool().get((size_t)M_cap + 1);
         if (r.want_pos) r.pos = (uint32_t *)pinned_pool().get(((size_t)M_cap + 1) * 4);
         if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
-        if (r.want_bases) op_d2h(cx, r.bases, dbase, M_cap);
-        if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)M_cap * 4);
+        // (M_likely: a tighter guess of the length — every splice round reserves the full growth allowance, a region
+        // is spliced in one of them —; should the sequence be longer after all, its rest follows in a second copy)
+        const uint32_t first = std::min(M_cap, M_likely);
+        if (r.want_bases) op_d2h(cx, r.bases, dbase, first);
+        if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)first * 4);
         op_sync(cx);
         if (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
             throw Np2Error(NP2_E_DEVICE, "mailbox not posted after a synchronisation");
         sc.assign(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
+        if (sc[S_M0] > first && sc[S_M0] <= M_cap) {
+            const uint32_t rest = sc[S_M0] - first;
+            if (r.want_bases) op_d2h(cx, r.bases + first, dbase + first, rest);
+            if (r.want_pos) op_d2h(cx, r.pos + first, dpos + first, (size_t)rest * 4);
+            op_sync(cx);
+        }
     } else {
         sc = fetch_scal(cx, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dpos, cx->scal.p + S_M1);
     }
@@ -1058,7 +1068,7 @@ void run_final_pass(PolishRun &r, ResultOut &result) {
         trace_region_tables(cx, (int)r.pass, "rech" + std::to_string(y), pc, true);
         if (cx->trace) trace_cns(cx, (int)r.pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
     }
-    fetch_result(cx, cur.pos, cur.base, cur.M_p, cur.M_cap, result);
+    fetch_result(cx, cur.pos, cur.base, cur.M_p, cur.M_cap, result, r.M + pc.grow);
 }
 
 void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {
