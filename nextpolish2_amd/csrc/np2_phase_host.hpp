@@ -542,33 +542,41 @@ class SignedLouvain {
         std::vector<uint32_t> visit = g_.keys.key_list();
         std::sort(visit.begin(), visit.end());
         std::vector<uint8_t> dirty(g_.n_ids(), 1);
-        std::vector<std::pair<uint32_t, float>> gains;
+        // gains per neighbouring community: a slot per community id, valid for the node whose stamp it carries (in the
+        // first sweep every neighbour is a community of its own: a list searched per edge was quadratic in the degree)
+        std::vector<float> acc(g_.n_ids(), 0.f);
+        std::vector<uint32_t> stamp(g_.n_ids(), 0u), touched;
+        uint32_t tick = 0;
         for (bool again = true; again;) {
             again = false;
             for (uint32_t v : visit) {
                 if (!dirty[v]) continue;
                 dirty[v] = 0;
                 const uint32_t cur = node_id_[v];
-                gains.clear();
+                touched.clear();
+                if (++tick == 0) { // (the stamps wrapped: start over)
+                    std::fill(stamp.begin(), stamp.end(), 0u);
+                    tick = 1;
+                }
                 for (const auto &e : g_.adj(v)) {
                     const uint32_t c = node_id_[e.first];
-                    bool hit = false;
-                    for (auto &gn : gains)
-                        if (gn.first == c) {
-                            gn.second += e.second;
-                            hit = true;
-                            break;
-                        }
-                    if (!hit) gains.emplace_back(c, e.second);
+                    if (stamp[c] != tick) {
+                        stamp[c] = tick;
+                        acc[c] = e.second;
+                        touched.push_back(c);
+                    } else {
+                        acc[c] += e.second; // (edge order, like the list it replaces)
+                    }
                 }
-                if (gains.empty()) continue;
-                size_t best = 0; // max weight, ties -> smaller community id (louvain.rs:99-101)
-                for (size_t i = 1; i < gains.size(); ++i)
-                    if (gains[i].second > gains[best].second ||
-                        (gains[i].second == gains[best].second && gains[i].first < gains[best].first))
-                        best = i;
-                if (gains[best].second > 0.f && gains[best].first != cur) {
-                    const uint32_t to = gains[best].first;
+                if (touched.empty()) continue;
+                uint32_t bc = touched[0]; // max weight, ties -> smaller community id (louvain.rs:99-101)
+                float bw = acc[bc];
+                for (size_t i = 1; i < touched.size(); ++i) {
+                    const uint32_t c = touched[i];
+                    if (acc[c] > bw || (acc[c] == bw && c < bc)) bc = c, bw = acc[c];
+                }
+                if (bw > 0.f && bc != cur) {
+                    const uint32_t to = bc;
                     node_id_[v] = to;
                     ++cnt_[to];
                     --cnt_[cur];
