@@ -361,9 +361,15 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
                        "reference would panic: the weight of two conflicting community is not less than 0");
     mark("louvain + ranking");
     if (cx) cx->timing.host.push_back({"wall_louvain", (float)(now_ms() - t_host0)});
-    for (uint32_t b : bad) losers.push_back(b);
-    std::sort(losers.begin(), losers.end());
-    losers.erase(std::unique(losers.begin(), losers.end()), losers.end());
+    // ascending, each once (flags over the read ids: a comparison sort of a chromosome's 3 x 10^5 losers was 12 ms)
+    std::vector<uint8_t> lost(R, 0);
+    for (uint32_t b : bad) lost[b] = 1;
+    for (uint32_t l : losers)
+        if (l < R) lost[l] = 1;
+        else throw Np2Error(NP2_E_DEVICE, "internal: loser outside the contig's reads");
+    losers.clear();
+    for (uint32_t r = 0; r < R; ++r)
+        if (lost[r]) losers.push_back(r);
     return losers;
 }
 
