@@ -305,10 +305,25 @@ __device__ __forceinline__ void k_tile_count(const uint32_t np2_bid, const uint3
             prevd = prev_pos_dirty(keys, vals, alive, pa, pa + tl.tile_n[np2_bid - 1], start - 1) ? 1u : 0u;
         }
     }
-    if (fast) {
-        for (uint32_t i = tid; i < n; i += 256) {
-            s_k[i] = keys[a + i];
-            s_live[i] = alive[vals[a + i]];
+    if (fast) { // (all of a thread's records requested before the first is used: keys and reads, then the reads' liveness)
+        uint64_t rk[TC_CAP / 256];
+        uint32_t rv[TC_CAP / 256];
+#pragma unroll
+        for (uint32_t j = 0; j < TC_CAP / 256; ++j) {
+            const uint32_t i = tid + 256 * j;
+            rk[j] = 0, rv[j] = 0;
+            if (i < n) rk[j] = keys[a + i], rv[j] = vals[a + i];
+        }
+        uint8_t rl[TC_CAP / 256];
+#pragma unroll
+        for (uint32_t j = 0; j < TC_CAP / 256; ++j) {
+            const uint32_t i = tid + 256 * j;
+            rl[j] = i < n ? alive[rv[j]] : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < TC_CAP / 256; ++j) {
+            const uint32_t i = tid + 256 * j;
+            if (i < n) s_k[i] = rk[j], s_live[i] = rl[j];
         }
     }
     __syncthreads();
