@@ -590,9 +590,10 @@ inline void op_copy_d2d(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
 // driver a transfer is a copy KERNEL reading / writing host memory over the bus: the copies of all contigs of a batch
 // go out as one launch instead of one blit per contig.  Large transfers keep the DMA path.
 static constexpr size_t KERNEL_COPY_MAX = 1u << 20;
-// (device -> host: a copy kernel holds CU slots while its stores trickle over the bus — with several batch groups on
-// one device those slots are another group's; beyond a few pages the DMA engine takes it)
-static constexpr size_t KERNEL_D2H_MAX = 64u << 10;
+// (device -> host: round 2 sent everything beyond 64 KiB through hipMemcpyAsync — which on this stack is a blit KERNEL
+// per transfer anyway, with a 12 us submission gap between two of them: 37 transfers per assembly step.  One merged copy
+// kernel for all contigs of a batch has no gaps: +6 % with one batch group, +3 % with four.  NP2_KERNEL_D2H_MAX for A/B.)
+static const size_t KERNEL_D2H_MAX = getenv("NP2_KERNEL_D2H_MAX") ? (size_t)atol(getenv("NP2_KERNEL_D2H_MAX")) : (size_t)(4u << 20);
 inline void op_d2h(np2_ctx *cx, void *pinned_dst, const void *src, size_t bytes) {
     if (!bytes) return;
     if (Recorder *r = tl_recorder()) {
