@@ -31,7 +31,7 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
 # profiles/r03_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r03_ecoli_pmc_fetch_write.json
 # (the round-3 kernel; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9 KB)
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 37425.2 + 38324.4) * 1024), "ecoli": int((2 * 51030.3 + 38787.2) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 37310.1 + 38273.2) * 1024), "ecoli": int((2 * 51076.1 + 38885.0) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
