@@ -30,6 +30,11 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
 # profiles/r03_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r03_ecoli_pmc_fetch_write.json
 # (the round-3 kernel; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9 KB)
+PMC_SOURCE = {"yeast": "profiles/r03_yeast_pmc_fetch_write.json (HEAD ca575b9)", "ecoli": "profiles/r03_ecoli_pmc_fetch_write.json (HEAD ca575b9)"}
+# k-mer table probes per polished bp the reference algorithm makes on these workloads (the oracle's kmer_probes stat over
+# the whole assembly: kappa of SURVEY.md §8(d)); measured again whenever the cpu_baseline leg runs
+KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
+KAPPA_SOURCE = "profiles/r04_kappa.json"
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
 PMC_TRAFFIC = {"yeast": int((2 * 37310.1 + 38273.2) * 1024), "ecoli": int((2 * 51076.1 + 38885.0) * 1024)}
 
@@ -79,9 +84,24 @@ class Groups:
         for b in self.bps:
             b.set_timing(on)
 
-    def run(self, opts, steps, after_step=None, exclusive=False):
+    def slot_results(self, g):
+        """[(contig index, device address, length)] of group g's last wave (np2_last_result_device of its slot contexts)."""
+        import ctypes as C
+        from nextpolish2_amd.api import lib
+        out = []
+        for slot, i in enumerate(self.members[g]):
+            p, n = C.c_void_p(), C.c_uint64()
+            rc = lib().np2_last_result_device(lib().np2_batch_slot_ctx(self.bps[g]._h, slot), C.byref(p), C.byref(n))
+            if rc != 0:
+                raise RuntimeError("np2_last_result_device on a batch slot")
+            out.append((i, p.value, n.value))
+        return out
+
+    def run(self, opts, steps, after_step=None, exclusive=False, stage=None):
         """`steps` passes over the assembly.  after_step(out) runs on the calling thread once every group has delivered
-        a step (the groups may be one step ahead of it by then).  exclusive: one group at a time (the roofline kernel
+        a step (the groups may be one step ahead of it by then).  stage(k, items): called on a group's thread when it has
+        delivered step k, with slot_results of its contigs (the multi-rank run copies them, device to device, into the
+        buffer the step's all-gather sends).  exclusive: one group at a time (the roofline kernel
         measured without other kernels next to it).  -> (outputs of the last step, per-step sum of the k_diff_reads
         launch durations in ms, launches per step, mean np2_batch_polish call time in ms)"""
         G = len(self.bps)
@@ -98,6 +118,8 @@ class Groups:
                 res = self.bps[g].polish([self.contigs[i] for i in self.members[g]], opts)
                 for i, r in zip(self.members[g], res):
                     outs[k & 1][i] = r
+                if stage is not None:
+                    stage(k, self.slot_results(g))
                 ms, launches = self.bps[g].last_diff_ms()
                 acc[g][0] += ms
                 acc[g][1] = launches
@@ -117,7 +139,7 @@ class Groups:
             for k in range(steps):
                 with cv:
                     cv.wait_for(lambda: min(done) >= k + 1)
-                after_step(outs[k & 1])
+                after_step(outs[k & 1]) if stage is None else after_step(k, outs[k & 1])
                 with cv:
                     seen[0] = k + 1
                     cv.notify_all()
@@ -158,7 +180,7 @@ def cpu_baseline(syn, yaks, opts, max_threads, n_jobs=256):
     ob, op = base.polish(syn[big].pileup, opts)
     st = time.perf_counter() - t1
     single = syn[big].pileup.L / st / 1e6
-    results = {}
+    results, probes = {}, {}
 
     def run(n, jobs_wanted):
         # n worker threads pull contigs from one queue (the reference's bounded channel, main.rs:1700-1715)
@@ -179,6 +201,7 @@ def cpu_baseline(syn, yaks, opts, max_threads, n_jobs=256):
                 done[w] += syn[jobs[j]].pileup.L
                 if j < len(syn):
                     results[jobs[j]] = r
+                    probes[jobs[j]] = orc.stats()["kmer_probes"]  # k-mer table probes the reference algorithm makes
         ths = [threading.Thread(target=work, args=(w,)) for w in range(n)]
         t1 = time.perf_counter()
         for t in ths:
@@ -210,6 +233,7 @@ def cpu_baseline(syn, yaks, opts, max_threads, n_jobs=256):
                       f"contig per thread like the reference's workers (main.rs:1717-1843), in-memory k-mer tables, one "
                       f"shared copy (variant (ii) of BASELINE.md): {v_all:.2f} Mbp/s in {dt_all:.1f} s",
             "single_thread": round(single, 4), "host_cores": cores, "usable_cpus": usable,
+            "kmer_probes_per_bp": round(sum(probes.values()) / max(1, sum(syn[i].pileup.L for i in probes)), 5),
             "note": "usable_cpus = the container's CFS quota (cpu.max); the box shows host_cores hardware threads, but threads "
                     "beyond the quota are throttled, not run (profiles/r03_cpu_baseline_scaling_probe.log: 256 threads reach "
                     "a third of the 17-thread rate with 238 s of system time)"}, results
@@ -329,6 +353,30 @@ def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=2):
                     "staging and device blocks come from the process-wide pools the first run filled"}
 
 
+def dist_setup():
+    """(rank, world, device index, torch device of this rank's GPU, device the collectives' tensors live on, backend).
+    NP2_BENCH_BACKEND (default nccl = RCCL over xGMI) picks the torch.distributed backend: with gloo the collectives go
+    through host memory, which lets several ranks share ONE GPU — the rehearsal of the multi-rank code paths on a
+    one-GPU box (tests/test_gpu_dist.py); a rank's device is LOCAL_RANK modulo the devices the box has."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("NP2_BENCH_BACKEND", "nccl")
+    idx = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    return rank, world, idx, dev, cdev, backend
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N ranks on
     this node (127.0.0.1 rendezvous on a free port) and relay their output; rank 0's JSON line carries n_gpus == N."""
@@ -365,17 +413,10 @@ def main_strong(a):
     from nextpolish2_amd.dist import polish_sharded
     from nextpolish2_amd.synth import Synth, concat_pileups
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, world, local_rank, dev, cdev, backend = dist_setup()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     distributed = "RANK" in os.environ
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
     L = int(a.contig_mb * 1e6 * a.scale)
     n_parts = 16
     # every rank generates the same contig (seeded) and keeps only its shard in HBM
@@ -393,7 +434,7 @@ def main_strong(a):
     last = [None]
 
     def step():
-        b, _, span = polish_sharded(pol, pu, opts, device=dev if distributed else None, want_pos=False, dst=0, with_span=True,
+        b, _, span = polish_sharded(pol, pu, opts, device=cdev if distributed else None, want_pos=False, dst=0, with_span=True,
                                     plans=plans, resident=shard)
         last[0] = (b, span)
 
@@ -417,7 +458,7 @@ def main_strong(a):
     dt = time.perf_counter() - t0
     gc.enable()
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = pu.L * a.steps / dt / 1e6
@@ -510,17 +551,10 @@ def main():
     from nextpolish2_amd.dist import SequenceGatherer
     from nextpolish2_amd.synth import Synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, world, local_rank, dev, cdev, backend = dist_setup()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
 
     # synthetic inputs (SURVEY.md §8d recipe), one assembly per rank
     diploid = a.workload == "yeast"
@@ -533,9 +567,17 @@ def main():
     opts = Opts()
     groups = Groups(pol, contigs, lengths, max(1, min(a.groups, len(contigs))))
     total_len = sum(lengths)
-    gatherer = SequenceGatherer(total_len + total_len // 16 + 4096, dev) if distributed else None
-
     single = len(contigs) == 1  # one contig (configs[1]): the plain context path, output fetch deferred by one step
+    gatherer = None
+    if distributed:
+        # RCCL all-gather of this rank's polished assembly, one per step, fed from the device: a contig's polished bytes
+        # go from its slot context's result buffer into its slot of the staging buffer (device to device) as soon as its
+        # batch group has delivered it; two staging buffers, because the groups may be one step ahead of the collective
+        caps = [l + l // 16 + 1024 for l in lengths]
+        gatherer = SequenceGatherer(sum(caps) + 16 * len(caps) + 4096, dev, collective_device=cdev, n_local=2)
+        if not single:
+            gatherer.set_slots(caps)
+
     pending = [False]
     last = [None]
 
@@ -555,8 +597,8 @@ def main():
             pending[0] = False
         return [(np.array(last[0]), span)]
 
-    # RCCL all-gather of this rank's polished assembly (contigs concatenated in input order), one per step
-    after = (lambda o: gatherer.gather(np.concatenate([x[0] for x in o]))) if distributed else None
+    after = (lambda k, o: gatherer.gather_staged(k & 1, [len(x[0]) for x in o])) if distributed else None
+    stage = (lambda k, items: gatherer.stage(k & 1, items)) if distributed else None
 
     def sync():
         if distributed:
@@ -568,7 +610,7 @@ def main():
             out = step_single()
         drain_single(out)
     elif a.warmup:
-        groups.run(opts, a.warmup, after)
+        groups.run(opts, a.warmup, after, stage=stage)
     groups.set_timing(True)  # HIP events around the batched k_diff_reads launches, on the batch streams
     diff_ms, diff_launches, call_ms = [], 0, 0.0
     import gc
@@ -587,7 +629,7 @@ def main():
             diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
             diff_launches = 1
     else:
-        out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after)
+        out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after, stage=stage)
         call_breakdown = groups.call_breakdown
         diff_ms.append(ms)
     if single:
@@ -606,13 +648,13 @@ def main():
     bases = [np.array(o[0]) for o in out]
     spans = [o[1] for o in out]
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     total_bp = total_len
     if distributed:  # every rank polishes its own assembly: sum their lengths
-        tb = torch.tensor([total_len], dtype=torch.int64, device=dev)
+        tb = torch.tensor([total_len], dtype=torch.int64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bp = int(tb.item())
     value = total_bp * a.steps / dt / 1e6
@@ -640,6 +682,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_diff_reads", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": PMC_TRAFFIC[a.workload] if (a.depth == 30 and a.scale == 1.0 and diff_launches == PMC_LAUNCHES[a.workload]) else None,
+                     "traffic_source": f"not measured in this run: {PMC_SOURCE[a.workload]}, 2 x FETCH_SIZE + WRITE_SIZE per launch",
                      "alg_bytes_per_launch": int(alg_bytes / max(1, diff_launches)), "launches_per_step": diff_launches,
                      "avg_launch_ms": round(avg_ms / max(1, diff_launches), 4),
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},
@@ -678,6 +721,18 @@ def main():
         same = [bool(np.array_equal(ob, bases[i]) and (int(op[0]), int(op[-1])) == tuple(spans[i])) for i, (ob, op) in oracle_out.items()]
         out_line["fasta_identical_to_oracle"] = bool(len(same) == len(syn) and all(same))
         out_line["oracle_checked_contigs"] = len(same)
+    # the path as a whole against the HBM roofline, by SURVEY.md §8(d)'s own formula: B bytes per polished bp =
+    # iter_count x 0.5 B per pileup column (the reference streams the pileup once per pass) + 2 (contig in, consensus
+    # out) + 8 B per k-mer table probe; achieved = Mbp/s x 1e6 x B
+    kappa, ksrc = KAPPA[a.workload], KAPPA_SOURCE
+    if "cpu_baseline" in out_line:
+        kappa, ksrc = out_line["cpu_baseline"]["kmer_probes_per_bp"], "the oracle's kmer_probes stat, this run"
+    b_per_bp = 2 * 0.5 * (n_cols + total_len) / total_len + 2 + 8 * kappa
+    out_line["roofline_path"] = {"bound": "hbm", "what": "whole hot path (SURVEY.md 8d: achieved = Mbp/s x 1e6 x B)",
+                                 "bytes_per_bp": round(b_per_bp, 3), "kappa_probes_per_bp": kappa, "kappa_source": ksrc,
+                                 "achieved": round(value / max(1, world) * b_per_bp / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(value / max(1, world) * b_per_bp / 1e3 / HBM_PEAK_GBS, 5),
+                                 "note": "per GPU; B = iter_count x 0.5 x pileup columns (read 0 included) / bp + 2 + 8 x kappa"}
     out_line["polished_equals_truth_contigs"] = int(sum(bases[i].tobytes() == syn[i].hap1 for i in range(len(syn))))
     if rank == 0:
         print(json.dumps(out_line), flush=True)

@@ -370,37 +370,53 @@ class _DeviceBytes:
 
 
 class SequenceGatherer:
-    """Per-step all-gather of one polished contig per rank, kept on the device.
+    """Per-step all-gather of one polished contig — or one polished assembly — per rank, kept on the device.
 
-    Buffers are allocated once; a step costs one padded uint8 all-gather (length word + the polished bytes) — on GPUs that is RCCL over xGMI with no host round trip.  The collectives are enqueued on torch's
-    current stream and not waited for: they overlap the next contig's kernels, which run on the np2 context's own
-    stream.  `gather_device` returns as soon as the context's result buffer has been copied out (device to device), so
-    the context is free to start its next contig."""
+    Buffers are allocated once; a step costs one padded uint8 all-gather (length word + the polished bytes) — on GPUs
+    that is RCCL over xGMI with no host round trip.  The collectives are enqueued on torch's current stream and not
+    waited for: they overlap the next contig's kernels, which run on the np2 context's own stream.  `gather_device`
+    returns as soon as the context's result buffer has been copied out (device to device), so the context is free to
+    start its next contig.
+
+    An assembly of several contigs (the batch driver's output) is gathered from the device as well: every contig has a
+    fixed slot in the rank's staging buffer (`set_slots`), `stage` copies a contig's result buffer (np2_last_result_device
+    of its slot context) into its slot as soon as its batch group has delivered it — device to device, any thread —,
+    and `gather_staged` sends the staging buffer with the table of the contigs' lengths in front.  `n_local` staging
+    buffers let the groups stage step k + 1 while step k is still being sent.
+
+    `collective_device`: where the tensors handed to torch.distributed live — the GPU for backend nccl (default), the
+    host for gloo (several ranks on one GPU: tests; the staging buffer then crosses PCIe once per step)."""
 
     HDR = 8  # every rank's slot starts with its sequence length (int64), so one collective moves both
 
-    def __init__(self, capacity, device, group=None):
+    def __init__(self, capacity, device, group=None, collective_device=None, n_local=1):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.device = torch.device(device)
+        self.cdev = torch.device(collective_device) if collective_device is not None else self.device
         self.cap = (int(capacity) + 7) & ~7
-        stride = self.HDR + self.cap
-        self.local = torch.zeros(stride, dtype=torch.uint8, device=self.device)
-        self.flat = torch.zeros(self.world * stride, dtype=torch.uint8, device=self.device)
+        stride = self.stride = self.HDR + self.cap
+        self.locals = [torch.zeros(stride, dtype=torch.uint8, device=self.device) for _ in range(max(1, n_local))]
+        self.local = self.locals[0]
+        self.flat = torch.zeros(self.world * stride, dtype=torch.uint8, device=self.cdev)
         self.bufs = [self.flat[r * stride + self.HDR:(r + 1) * stride] for r in range(self.world)]
         self.lens = [self.flat[r * stride:r * stride + self.HDR].view(torch.int64) for r in range(self.world)]
         self._len_host = torch.zeros(1, dtype=torch.int64)
-        self._hdr = self.local[:self.HDR].view(torch.int64)
         self._views = {}  # (device address, length) -> zero-copy tensor (the np2 result buffers are few and stable)
+        self._slot_off = None
         if self.device.type == "cuda":
             self._len_host = self._len_host.pin_memory()
             self._copied = torch.cuda.Event()
 
-    def _exchange(self):
+    def _exchange(self, local=None):
+        local = self.local if local is None else local
         if not dist.is_initialized():
-            self.flat.copy_(self.local)
-        else:
-            dist.all_gather_into_tensor(self.flat, self.local, group=self.group)
+            self.flat.copy_(local)
+        elif self.cdev == self.device:
+            dist.all_gather_into_tensor(self.flat, local, group=self.group)
+        else:  # (gloo: through host memory)
+            parts = [self.flat[r * self.stride:(r + 1) * self.stride] for r in range(self.world)]
+            dist.all_gather(parts, local.to(self.cdev), group=self.group)
         return self.bufs, self.lens
 
     def gather_tensor(self, src):
@@ -409,7 +425,7 @@ class SequenceGatherer:
         if n > self.cap:
             raise ValueError("polished contig longer than the gather capacity")
         self._len_host[0] = n
-        self._hdr.copy_(self._len_host, non_blocking=True)
+        self.local[:self.HDR].view(torch.int64).copy_(self._len_host, non_blocking=True)
         self.local[self.HDR:self.HDR + n].copy_(src, non_blocking=True)
         if self.device.type == "cuda":
             self._copied.record()
@@ -418,22 +434,77 @@ class SequenceGatherer:
             self._copied.synchronize()  # src (and the pinned length word) may be reused from here on
         return out
 
+    def _view(self, ptr, n):
+        view = self._views.get((ptr, n))
+        if view is None:
+            if len(self._views) > 256:
+                self._views.clear()
+            with torch.cuda.device(self.device):
+                view = self._views[(ptr, n)] = torch.as_tensor(_DeviceBytes(ptr, n), device=self.device)
+        return view
+
     def gather_device(self, ptr, n):
         """Gather straight from a device buffer (np2_last_result_device): no host round trip."""
         if n > self.cap:
             raise ValueError("polished contig longer than the gather capacity")
-        view = self._views.get((ptr, n))
-        if view is None:
-            if len(self._views) > 16:
-                self._views.clear()
-            with torch.cuda.device(self.device):
-                view = self._views[(ptr, n)] = torch.as_tensor(_DeviceBytes(ptr, n), device=self.device)
-        return self.gather_tensor(view)
+        return self.gather_tensor(self._view(ptr, n))
+
+    # ---- an assembly of several contigs, staged on the device contig by contig ----
+    def set_slots(self, capacities):
+        """Contig i of this rank's assembly owns `capacities[i]` bytes of the staging buffer (behind the length table)."""
+        caps = [(int(c) + 7) & ~7 for c in capacities]
+        self._slot_cap = caps
+        self._table = 8 * len(caps)
+        self._slot_off = [self.HDR + self._table + int(x) for x in np.concatenate([[0], np.cumsum(caps)[:-1]])]
+        if self._table + sum(caps) > self.cap:
+            raise ValueError("slots exceed the gather capacity")
+        self._tab_host = torch.zeros(len(caps), dtype=torch.int64)
+        if self.device.type == "cuda":
+            self._tab_host = self._tab_host.pin_memory()
+
+    def stage(self, which, items):
+        """items: [(contig index, device address, length)] — copied device to device into staging buffer `which`; returns
+        when the copies are done (the result buffers may be overwritten by the next polish call)."""
+        local = self.locals[which]
+        ev = None
+        for i, ptr, n in items:
+            if n > self._slot_cap[i]:
+                raise ValueError("polished contig longer than its gather slot")
+            if n:
+                local[self._slot_off[i]:self._slot_off[i] + n].copy_(self._view(ptr, n), non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+
+    def gather_staged(self, which, lengths):
+        """Send staging buffer `which`: lengths[i] = polished length of contig i (the table in front of the slots)."""
+        local = self.locals[which]
+        self._len_host[0] = self._table + sum(self._slot_cap)
+        self._tab_host.copy_(torch.as_tensor(np.asarray(lengths, dtype=np.int64)))
+        local[:self.HDR].view(torch.int64).copy_(self._len_host, non_blocking=True)
+        local[self.HDR:self.HDR + self._table].view(torch.int64).copy_(self._tab_host, non_blocking=True)
+        if self.device.type == "cuda":
+            self._copied.record()
+        out = self._exchange(local)
+        if self.device.type == "cuda":
+            self._copied.synchronize()
+        return out
 
     def gather(self, bases):
         """bases: 1-D uint8 numpy array on the host. Returns (list of device tensors, lengths)."""
         return self.gather_tensor(torch.from_numpy(np.ascontiguousarray(bases)).to(self.device))
 
     def to_host(self):
-        """{rank: bytes} of the last gather (only for verification / output, not part of the hot loop)."""
-        return {r: self.bufs[r][: int(self.lens[r].item())].cpu().numpy().tobytes() for r in range(self.world)}
+        """{rank: bytes} of the last gather (only for verification / output, not part of the hot loop): the rank's
+        sequence — or, after gather_staged, its contigs' sequences end to end (slots are as on this rank: the ranks of a
+        weak-scaling run hold assemblies of the same contig lengths)."""
+        out = {}
+        for r in range(self.world):
+            raw = self.bufs[r][: int(self.lens[r].item())].cpu().numpy()
+            if self._slot_off is None:
+                out[r] = raw.tobytes()
+                continue
+            tab = raw[:self._table].view(np.int64)
+            out[r] = b"".join(raw[o - self.HDR:o - self.HDR + int(n)].tobytes() for o, n in zip(self._slot_off, tab))
+        return out
