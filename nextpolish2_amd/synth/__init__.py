@@ -25,7 +25,7 @@ def build():
     out = os.path.join(_HERE, "libnp2_synth.so")
     if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
         return out
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, src])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
     return out
 
 
@@ -52,6 +52,8 @@ def lib():
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
         L.np2s_yak_build_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_double, C.c_uint64,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        L.np2s_yak_build_multi_mt.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_double, C.c_uint64, C.c_uint32,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
         L.np2s_bam_records.restype = C.c_uint32
         L.np2s_bam_records.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -116,13 +118,18 @@ class Synth:
         return Yak(k, words, off)
 
     @staticmethod
-    def yak_assembly(synths, k, coverage=60.0, read_len=150, seed=7):
-        """One yak table over every contig of a synthetic assembly (what `yak count` on the short reads gives)."""
+    def yak_assembly(synths, k, coverage=60.0, read_len=150, seed=7, threads=0):
+        """One yak table over every contig of a synthetic assembly (what `yak count` on the short reads gives).
+        threads > 1: built on that many host threads (chromosome-scale inputs; the same recipe, other random draws)."""
         dip = synths[0].diploid
         lam = coverage * (read_len - k + 1) / read_len / (2 if dip else 1)
         hs = (C.c_void_p * len(synths))(*[s._h for s in synths])
         w, n, o = C.c_void_p(), C.c_uint64(), C.c_void_p()
-        if lib().np2s_yak_build_multi(hs, len(synths), k, lam, seed, C.byref(w), C.byref(n), C.byref(o)) != 0:
+        if threads > 1:
+            rc = lib().np2s_yak_build_multi_mt(hs, len(synths), k, lam, seed, threads, C.byref(w), C.byref(n), C.byref(o))
+        else:
+            rc = lib().np2s_yak_build_multi(hs, len(synths), k, lam, seed, C.byref(w), C.byref(n), C.byref(o))
+        if rc != 0:
             raise ValueError("k must be in [2, 32)")
         return Yak(k, _copy(w.value, n.value * 8, np.uint64), _copy(o.value, 1025 * 8, np.uint64))
 

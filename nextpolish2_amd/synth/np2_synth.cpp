@@ -14,11 +14,13 @@
 #include "../../include/np2.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -590,6 +592,118 @@ int np2s_yak_build_multi(void **hs_in, uint32_t n_h, uint32_t k, double lambda, 
 int np2s_yak_build(void *h, uint32_t k, double lambda, uint64_t seed, const uint64_t **words,
                    uint64_t *n_words, const uint64_t **bucket_off) {
     return np2s_yak_build_multi(&h, 1, k, lambda, seed, words, n_words, bucket_off);
+}
+
+// The same table recipe on `n_threads` host threads, for chromosome-scale test inputs (a 248 Mb diploid contig is 5 x 10^8
+// k-mers: 80-100 s through the serial builder).  Haplotypes are cut into pieces whose k-mers go to per-thread lists of the
+// 1024 file buckets (hash & 1023); every bucket is then sorted, counted and drawn with a random stream of its own.  The
+// table has the same distribution as the serial one but NOT the same words (the serial builder draws one stream over
+// the globally sorted k-mers), so seeded small inputs keep using np2s_yak_build_multi.
+int np2s_yak_build_multi_mt(void **hs_in, uint32_t n_h, uint32_t k, double lambda, uint64_t seed, uint32_t n_threads,
+                            const uint64_t **words, uint64_t *n_words, const uint64_t **bucket_off) {
+    if (k < 2 || k >= 32 || n_h == 0) return -1;
+    if (n_threads < 1) n_threads = 1;
+    Synth *S = (Synth *)hs_in[0];
+    struct Piece {
+        const std::string *s;
+        size_t lo, hi; // k-mers ENDING in [lo, hi) — the scan starts k - 1 characters earlier
+    };
+    std::vector<Piece> pieces;
+    const size_t PIECE = 1 << 20;
+    for (uint32_t g = 0; g < n_h; ++g) {
+        Synth *G = (Synth *)hs_in[g];
+        for (int h = 0; h < (G->P.diploid ? 2 : 1); ++h) {
+            const std::string &q = G->hap_seq[h];
+            for (size_t lo = 0; lo < q.size(); lo += PIECE) pieces.push_back({&q, lo, std::min(q.size(), lo + PIECE)});
+        }
+    }
+    const uint64_t mask = (1ULL << (2 * k)) - 1, shift = 2 * (k - 1);
+    std::vector<std::vector<std::vector<uint64_t>>> part(n_threads, std::vector<std::vector<uint64_t>>(1024));
+    std::atomic<size_t> next_piece{0};
+    auto collect = [&](uint32_t t) {
+        uint8_t code[256];
+        memset(code, 4, sizeof code);
+        code[(int)'A'] = 0, code[(int)'C'] = 1, code[(int)'G'] = 2, code[(int)'T'] = 3;
+        auto &mine = part[t];
+        for (;;) {
+            const size_t pi = next_piece.fetch_add(1);
+            if (pi >= pieces.size()) break;
+            const Piece &pc = pieces[pi];
+            const std::string &q = *pc.s;
+            uint64_t fw = 0, rv = 0;
+            uint32_t l = 0;
+            for (size_t i = pc.lo >= k - 1 ? pc.lo - (k - 1) : 0; i < pc.hi; ++i) {
+                const uint64_t c = code[(unsigned char)q[i]];
+                if (c > 3) {
+                    l = 0;
+                    continue;
+                }
+                fw = (fw << 2 | c) & mask;
+                rv = (rv >> 2) | (3 ^ c) << shift;
+                if (++l >= k && i >= pc.lo) {
+                    const uint64_t x = yak_hash64(fw < rv ? fw : rv, mask);
+                    mine[x & 1023].push_back(x);
+                }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(collect, t);
+        for (auto &x : th) x.join();
+    }
+    std::vector<std::vector<uint64_t>> buckets(1024);
+    std::atomic<uint32_t> next_bucket{0};
+    auto reduce = [&]() {
+        std::vector<uint64_t> v;
+        for (;;) {
+            const uint32_t b = next_bucket.fetch_add(1);
+            if (b >= 1024) break;
+            v.clear();
+            for (uint32_t t = 0; t < n_threads; ++t) {
+                v.insert(v.end(), part[t][b].begin(), part[t][b].end());
+                std::vector<uint64_t>().swap(part[t][b]);
+            }
+            std::sort(v.begin(), v.end());
+            Rng rng(seed ^ (0xabcdULL * k) ^ (0x9E3779B97F4A7C15ULL * (b + 1)));
+            auto &out = buckets[b];
+            for (size_t i = 0; i < v.size();) {
+                size_t j = i;
+                while (j < v.size() && v[j] == v[i]) ++j;
+                uint32_t c = rng.poisson(lambda * (double)(j - i));
+                if (c > 1023) c = 1023;
+                if (c > 0) out.push_back((v[i] >> 10) << 10 | c);
+                i = j;
+            }
+            for (size_t i = out.size(); i > 1; --i) std::swap(out[i - 1], out[rng.below((uint32_t)i)]);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(reduce);
+        for (auto &x : th) x.join();
+    }
+    S->yak_off.assign(1025, 0);
+    for (size_t b = 0; b < 1024; ++b) S->yak_off[b + 1] = S->yak_off[b] + buckets[b].size();
+    S->yak_words.resize(S->yak_off[1024]);
+    {
+        std::atomic<uint32_t> nb{0};
+        auto place = [&]() {
+            for (;;) {
+                const uint32_t b = nb.fetch_add(1);
+                if (b >= 1024) break;
+                if (!buckets[b].empty()) memcpy(S->yak_words.data() + S->yak_off[b], buckets[b].data(), 8 * buckets[b].size());
+                std::vector<uint64_t>().swap(buckets[b]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(place);
+        for (auto &x : th) x.join();
+    }
+    *words = S->yak_words.data();
+    *n_words = S->yak_words.size();
+    *bucket_off = S->yak_off.data();
+    return 0;
 }
 
 // Pack explicit (target, query) gapped strings into the boundary format — the literal

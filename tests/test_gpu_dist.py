@@ -53,6 +53,37 @@ def test_bench_under_torchrun_with_one_rank():
     assert out["end_to_end"]["value"] > 0 and out["end_to_end"]["identical_to_resident_path"] is True
 
 
+def _bench_line(args, env_extra=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, env=env, cwd=ROOT, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_gpus_2_rehearsed_with_gloo_on_one_gpu():
+    """`bench.py --gpus N` spawns its own ranks (spawn_ranks) and runs the N-rank branches of both scaling modes.  A box
+    with one GPU cannot run two RCCL ranks, so NP2_BENCH_BACKEND=gloo lets both ranks share device 0 with the collectives
+    going through host memory — the code paths (shard protocol over two ranks, staged assembly all-gather, max-over-ranks
+    timing, the line with n_gpus == 2) are the ones the driver's SCALE run takes; results must equal the one-rank run."""
+    gloo = {"NP2_BENCH_BACKEND": "gloo"}
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
+    strong = ["--scaling", "strong", "--contig-mb", "2"] + common
+    one = _bench_line(["--gpus", "1"] + strong)
+    two = _bench_line(["--gpus", "2"] + strong, gloo)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["polished_equals_truth"] and two["polished_equals_truth"]
+    assert one["output_crc32"] == two["output_crc32"] and one["span"] == two["span"]
+    weak = ["--scale", "0.05"] + common
+    one = _bench_line(["--gpus", "1"] + weak)
+    two = _bench_line(["--gpus", "2"] + weak, gloo)  # (asserts inside: the all-gathered bytes are rank 0's polished assembly)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert one["output_crc32"] == two["output_crc32"]
+    assert two["config"]["assembly_bp"] == one["config"]["assembly_bp"] and two["value"] > 0
+    # one E. coli-sized contig per rank: the single-contig branch (deferred fetch + gather from the device result buffer)
+    two = _bench_line(["--gpus", "2", "--workload", "ecoli", "--scale", "0.1"] + common, gloo)
+    assert two["n_gpus"] == 2 and two["polished_equals_truth_contigs"] == 1
+
+
 def test_deferred_output_fetch_overlaps_the_next_contig():
     """np2_result_fetch_begin / _end: the host copy of contig i is started after contig i and collected after contig
     i + 1; results equal the synchronous path."""
