@@ -19,6 +19,7 @@
 #include "hashbrown_emul.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -233,11 +235,27 @@ struct KmerInfo {
         size_t nb = (size_t)1 << pre;
         Buckets &sets = *sets_p;
         sets.assign(nb, {});
-        for (size_t b = 0; b < nb; ++b) {
+        over_buckets(nb, y.n_words, [&](size_t b) {
             sets[b].reserve(y.bucket_off[b + 1] - y.bucket_off[b]);
             for (uint64_t i = y.bucket_off[b]; i < y.bucket_off[b + 1]; ++i)
                 sets[b].emplace_back(y.words[i] >> 10, (uint16_t)(y.words[i] & 1023));
+        });
+    }
+    // The file buckets are independent: a table of human size (10^8 words and more: the chromosome-scale parity tests) is
+    // loaded and filtered on several host threads; the result does not depend on the thread count.
+    template <class F> static void over_buckets(size_t nb, uint64_t n_words, F f) {
+        unsigned nt = n_words < (1u << 24) ? 1 : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (nt == 1) {
+            for (size_t b = 0; b < nb; ++b) f(b);
+            return;
         }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&]() {
+                for (size_t b; (b = next.fetch_add(1)) < nb;) f(b);
+            });
+        for (auto &x : th) x.join();
     }
     // Variant (i) of the CPU baseline: the reference keeps no table in memory, every scoring phase
     // re-reads the whole .yak dump and probes its candidate set once per file word (retrieve_kmers, kmer.rs:132-170).
@@ -298,7 +316,9 @@ struct KmerInfo {
         sorted_p = std::make_shared<Buckets>(); // (a clone keeps the previous filter of its parent untouched)
         Buckets &sorted = *sorted_p;
         sorted.assign(sets.size(), {});
-        for (size_t b = 0; b < sets.size(); ++b) {
+        uint64_t n_words = 0;
+        for (auto &v : sets) n_words += v.size();
+        over_buckets(sets.size(), n_words, [&](size_t b) {
             auto &s = sorted[b];
             for (auto &e : sets[b])
                 if (e.second >= min_count) s.push_back(e);
@@ -312,7 +332,7 @@ struct KmerInfo {
                 s[w++] = s[i];
             }
             s.resize(w);
-        }
+        });
         built_min = min_count;
     }
     uint16_t get_or0(uint64_t hash) const { // kmer.rs:123-125 + unwrap_or(0)

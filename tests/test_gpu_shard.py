@@ -157,7 +157,8 @@ def test_full_size_chr1_single_gpu_and_two_intervals():
     with ThreadPoolExecutor(n_parts) as ex:
         parts = list(ex.map(lambda i: Synth(L // n_parts, depth=30, seed=500 + i), range(n_parts)))
     pu = concat_pileups([p.pileup for p in parts], "chr1")
-    yaks = [Synth.yak_assembly(parts, k) for k in (21, 31)]
+    from nextpolish2_amd._cpus import usable_cpus
+    yaks = [Synth.yak_assembly(parts, k, threads=usable_cpus()) for k in (21, 31)]
     truth = b"".join(p.hap1 for p in parts)
     assert pu.ref.tobytes() != truth and pu.L > 247_000_000
     pol = Polisher(yaks)
@@ -170,6 +171,64 @@ def test_full_size_chr1_single_gpu_and_two_intervals():
     c.free()
     b3, p3 = polish_sharded_local(pol, pu, Opts(), n_shards=2)
     assert np.array_equal(b1, b3) and np.array_equal(p1, p3)
+
+
+def test_full_size_chr1_diploid_whole_two_and_four_intervals(capsys):
+    """BASELINE.json configs[3] with what the config name says — injected SNVs / indels — as a DIPLOID 248 Mb contig
+    (15x + 15x reads of two haplotypes, SNP 0.5 %, indel 0.2 %): ~570 k reads, a heterozygous region every ~140 bp, the
+    phasing vote with its host-side Louvain over ~280 k reads (main.rs:948-1015, louvain.rs:72-195, 290-356) at
+    chromosome scale.  Whole contig == cut into 2 == cut into 4 reference intervals (the 2- and 4-GPU layouts, run here
+    one after the other), byte for byte; a second call is identical; the polished sequence is the contig's own haplotype
+    (hap1: the assembly is hap1 + errors and -m ref keeps the community that agrees with it) wherever that is
+    unambiguous — checked piece by piece on the 16 generated pieces through the position array; the host side of the
+    vote is logged."""
+    from concurrent.futures import ThreadPoolExecutor
+    from nextpolish2_amd._cpus import usable_cpus
+    from nextpolish2_amd.api import ShardRun, shard_plan
+    from nextpolish2_amd.dist import _run_local
+    n_parts, L = 16, 248_000_000
+    with ThreadPoolExecutor(n_parts) as ex:
+        parts = list(ex.map(lambda i: Synth(L // n_parts, depth=30, seed=500 + i, diploid=True), range(n_parts)))
+    pu = concat_pileups([p.pileup for p in parts], "chr1")
+    yaks = [Synth.yak_assembly(parts, k, threads=usable_cpus()) for k in (21, 31)]
+    haps = [p.hap1 for p in parts]
+    part_len = [p.pileup.L for p in parts]
+    del parts
+    assert pu.L > 247_000_000 and pu.n_reads > 500_000
+    pol = Polisher(yaks)
+    c = pol.upload(pu)
+    pol.set_timing(True)
+    b1, p1 = pol.polish_resident(c, Opts())
+    tm = pol.timings()
+    pol.set_timing(False)
+    assert np.all(p1[1:] >= p1[:-1]) and int(p1[0]) == 0 and int(p1[-1]) == pu.L - 1
+    b2, _ = pol.polish_resident(c, Opts(), want_pos=False)
+    assert np.array_equal(b1, b2)
+    c.free()
+    # the contig's own haplotype, piece by piece
+    cuts = np.searchsorted(p1, np.cumsum([0] + part_len))
+    stats = []  # per piece: (length difference, mismatches when the lengths agree else -1)
+    for k, h in enumerate(haps):
+        got = b1[cuts[k]:cuts[k + 1]]
+        stats.append((len(got) - len(h), int(np.count_nonzero(got != np.frombuffer(h, dtype=np.uint8))) if len(got) == len(h) else -1))
+    msg = (f"diploid 248 Mb contig: {pu.n_reads} reads; host vote (wall_louvain) {tm.get('wall_louvain', 0.0):.1f} ms, wall_vote "
+           f"{tm.get('wall_vote', 0.0):.1f} ms; per piece (length - hap1 length, mismatches or -1): {stats}")
+    with capsys.disabled():
+        print("\n  " + msg)
+    assert abs(len(b1) - sum(len(h) for h in haps)) <= 64 and all(abs(d) <= 8 for d, _ in stats), msg
+    assert sum(m == 0 for _, m in stats) >= n_parts // 2 and all(m <= 64 for _, m in stats), msg
+    whole = b1.tobytes()
+    for ns in (2, 4):
+        plans = shard_plan(pu, ns, 65536)
+        ctxs = [pol.clone() for _ in range(ns)]
+        runs = [ShardRun(ctxs[k], pu, plans[k], Opts(), 1024) for k in range(ns)]
+        try:
+            bs, ps = _run_local(runs, plans, pu.n_reads, Opts(), True)
+        finally:
+            for r in runs:
+                r.close()
+        assert bs.tobytes() == whole and np.array_equal(ps, p1), f"{ns} intervals differ from the whole contig"
+        del runs, ctxs
 
 
 def test_shards_read_straight_from_the_bam_number_their_reads_contig_wide(tmp_path):
