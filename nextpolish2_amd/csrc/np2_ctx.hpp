@@ -458,7 +458,8 @@ struct np2_ctx {
     DevBuf<uint32_t> mlen; // consensus length after each splice round of the final pass (device-side chain)
     // region logic
     DevBuf<uint8_t> reg_lable, grp, cns_base2, rech_groups, rech_groups_tmp;
-    DevBuf<uint8_t> votepack; // the vote's device-to-host payload gathered into one piece (batch driver)
+    DevBuf<uint8_t> votepack;  // the vote's device-to-host payload in one piece: per-read arrays, row offsets, compact pair words
+    DevBuf<uint8_t> votepack2; // ... of the wide form (shards, sort fallback), gathered by copy kernels (batch driver)
     DevBuf<uint32_t> rech_headjobs; // per RECH region: 0 or 1 + the job count of the group it heads
     DevBuf<uint32_t> ecount, eval, eval_s, eflag, eidx, seed_cand, keep_n, keep_list, cns_pos2, sp_idx_s,
         sp_idx_e, ap_g, ap_s, ap_e, rech, rech_joboff, job_len,

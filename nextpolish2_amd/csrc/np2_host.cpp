@@ -149,10 +149,20 @@ struct VoteData {
     const uint64_t *view_key = nullptr;
     const uint32_t *view_cnt = nullptr;
     uint64_t view_n = 0;
+    // ... or the compact rows of the plain pipeline (k_band_emit_compact: 4 bytes per pair; row a of the reads' band =
+    // words [c_off[a], c_off[a + 1]), word = (b - a - 1) | agree << 8 | disagree << 20), again a view of the staging
+    const uint32_t *c_off = nullptr, *c_pairs = nullptr;
+    std::vector<uint32_t> c_off_own, c_pairs_own;
+    bool compact() const { return c_off != nullptr; }
     const uint64_t *keys() const { return view_key ? view_key : pair_key.data(); }
     const uint32_t *cnts() const { return view_key ? view_cnt : pair_cnt.data(); }
-    uint64_t n_pairs() const { return view_key ? view_n : (uint64_t)pair_key.size(); }
+    uint64_t n_pairs() const { return compact() ? (uint64_t)c_off[R] : view_key ? view_n : (uint64_t)pair_key.size(); }
     void own() { // copy a view into the vectors (the viewed memory is about to be reused)
+        if (compact() && c_off_own.empty()) {
+            c_off_own.assign(c_off, c_off + R + 1);
+            c_pairs_own.assign(c_pairs, c_pairs + c_off[R]);
+            c_off = c_off_own.data(), c_pairs = c_pairs_own.data();
+        }
         if (!view_key) return;
         pair_key.assign(view_key, view_key + view_n);
         pair_cnt.assign(view_cnt, view_cnt + view_n);
@@ -166,8 +176,10 @@ struct VoteData {
 
 // GPU part of the phasing pass: mark_hete (main.rs:916-946), pair votes (948-1002) over the regions whose start lies in
 // [own_lo, own_hi)
+// `wide`: pairs as (a << 32 | b, counts) — what the shards of a contig export and merge; otherwise the compact rows, read
+// back in the SAME wait as the counters that size them (one device round trip and 8 bytes per pair less)
 void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool use_all, int pass, uint32_t own_lo,
-                  uint32_t own_hi, VoteData &vd) {
+                  uint32_t own_hi, VoteData &vd, bool wide = false) {
     hipStream_t s = cx->stream;
     const uint32_t R = c->R, n_reg = pc.n_reg;
     RegionTables rt = region_tables(cx, n_reg);
@@ -181,11 +193,23 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         cx->ecount.ensure(n_reg + 2);
         cx->eoff.ensure(std::max<size_t>(n_reg + 2, (size_t)c->L + 2));
         // per-read vote outputs live in one buffer: [first_reg u32 x RP][ref_w i32 x RP][ref_seen u8 x RP][bad u8 x RP]
+        // (compact: followed by the row offsets and the pair words — one piece to read back)
         const size_t RP = ((size_t)R + 63) & ~(size_t)63;
-        cx->votebuf.ensure(RP * 10);
-        uint32_t *v_first = (uint32_t *)cx->votebuf.p;
-        int32_t *v_refw = (int32_t *)(cx->votebuf.p + RP * 4);
-        uint8_t *v_seen = cx->votebuf.p + RP * 8, *v_bad = cx->votebuf.p + RP * 9;
+        const size_t band_words = (size_t)R * EDGE_BAND;
+        const size_t b_v = RP * 10, b_off = (((size_t)R + 2) * 4 + 15) & ~(size_t)15;
+        uint8_t *vbuf;
+        uint32_t *row_off;
+        if (wide) {
+            cx->votebuf.ensure(b_v);
+            cx->band_off.ensure((size_t)R + 2);
+            vbuf = cx->votebuf.p, row_off = cx->band_off.p;
+        } else {
+            cx->votepack.ensure(b_v + b_off + band_words * 4 + 64);
+            vbuf = cx->votepack.p, row_off = (uint32_t *)(cx->votepack.p + b_v);
+        }
+        uint32_t *v_first = (uint32_t *)vbuf;
+        int32_t *v_refw = (int32_t *)(vbuf + RP * 4);
+        uint8_t *v_seen = vbuf + RP * 8, *v_bad = vbuf + RP * 9;
         op_fill(cx, v_first, 0xFF, RP * 4);
         op_fill(cx, v_refw, 0, RP * 6);
         launch_vote_phase(s, rt, asref, use_all, cx->lq_start.p, own_lo, own_hi, cx->reg_lable.p, cx->grp.p, cx->ecount.p,
@@ -196,21 +220,52 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         // less per phasing pass; with no HETE region the three kernels find nothing to do).  Normal case: the raw pair
         // votes are accumulated in the banded matrix (reads are numbered in start order, partners are close); rows read
         // in order = the sorted unique list, at most EDGE_BAND pairs per read.
-        const size_t band_words = (size_t)R * EDGE_BAND;
         cx->band.ensure(band_words + 4);
         cx->band_n.ensure((size_t)R + 2);
-        cx->band_off.ensure((size_t)R + 2);
         op_fill(cx, cx->scal.p + S_M3, 0, 4);
         launch_edges_row(s, rt, cx->grp.p, cx->ecount.p, cx->pj.p, cx->pcount.p, cx->alive.p, R, cx->band.p, cx->band_n.p,
                          cx->scal.p + S_M3);
-        exclusive_total_n(cx, cx->band_n.p, cx->band_off.p, R);
-        cx->ekey.ensure(band_words + 2);
-        cx->eval.ensure(band_words + 2);
-        launch_band_emit(s, cx->band.p, R, cx->band_off.p, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
+        exclusive_total_n(cx, cx->band_n.p, row_off, R);
+        if (wide) {
+            cx->ekey.ensure(band_words + 2);
+            cx->eval.ensure(band_words + 2);
+            launch_band_emit(s, cx->band.p, R, row_off, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
+        } else {
+            launch_band_emit_compact(s, cx->band.p, R, row_off, (uint32_t *)(cx->votepack.p + b_v + b_off), cx->scal.p + S_NRAW,
+                                     cx->scal.p + S_M3);
+        }
     }
-    bool far = false;
+    const size_t RP = ((size_t)R + 63) & ~(size_t)63;
+    const size_t b_v = RP * 10, b_off = (((size_t)R + 2) * 4 + 15) & ~(size_t)15;
+    auto per_read = [&](const uint8_t *vb) {
+        vd.first_key.assign((const uint32_t *)vb, (const uint32_t *)vb + R);
+        vd.ref_w.assign((const int32_t *)(vb + RP * 4), (const int32_t *)(vb + RP * 4) + R);
+        vd.ref_seen.assign(vb + RP * 8, vb + RP * 8 + R);
+        vd.bad.assign(vb + RP * 9, vb + RP * 9 + R);
+    };
+    bool far = false, have_per_read = false;
     {
-        std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
+        std::vector<uint32_t> sc;
+        uint8_t *pin = nullptr;
+        // pairs the first copy has room for: 64 per read (a 30x diploid pileup has ~36); more follow in a second copy
+        const uint32_t likely = (uint32_t)std::min<size_t>((size_t)R * EDGE_BAND, std::max<size_t>((size_t)R * 64, 1u << 14));
+        if (wide) {
+            sc = fetch_scal(cx, cx->scal.p + S_M0, cx->eoff.p + n_reg);
+        } else {
+            // counters, per-read arrays, row offsets and the pair words in ONE wait: the mailbox post, two copies (the second
+            // one sized on the device by the number of pairs), one synchronisation
+            pin = (uint8_t *)cx->pin_d2h.ensure(b_v + b_off + (size_t)likely * 4 + 64);
+            const uint32_t seq = ++cx->mbox_seq;
+            launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, cx->scal.p + S_M0, cx->eoff.p + n_reg, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            op_d2h(cx, pin, cx->votepack.p, b_v + b_off);
+            launch_copy_counted(cx->stream, (uint32_t *)(pin + b_v + b_off), (const uint32_t *)(cx->votepack.p + b_v + b_off),
+                                (const uint32_t *)(cx->votepack.p + b_v) + R, likely);
+            op_sync(cx);
+            if (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
+                throw Np2Error(NP2_E_DEVICE, "mailbox not posted after a synchronisation");
+            sc.assign(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
+        }
         check_region_err(cx, sc[S_ERR]);
         pc.resolve(sc);
         NE = sc[S_M0];
@@ -220,10 +275,23 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         }
         NU = sc[S_NRAW];
         far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
+        if (!wide) {
+            per_read(pin);
+            have_per_read = true;
+            if (!far) {
+                if (NU > likely) { // more pairs than the first copy had room for: fetch the whole piece again
+                    pin = (uint8_t *)cx->pin_d2h.ensure(b_v + b_off + (size_t)NU * 4 + 64);
+                    op_d2h(cx, pin, cx->votepack.p, b_v + b_off + (size_t)NU * 4);
+                    op_sync(cx);
+                }
+                vd.c_off = (const uint32_t *)(pin + b_v), vd.c_pairs = (const uint32_t *)(pin + b_v + b_off);
+                if (vd.c_off[R] != NU) throw Np2Error(NP2_E_DEVICE, "internal: vote rows and pair count disagree");
+            }
+        }
     }
     vd.any = true;
-    if (NE) {
-        if (far) { // some pair lies outside the band (deep pileup): sort the raw votes instead
+    if (NE && far) { // some pair lies outside the band (deep pileup) or a count outgrew 12 bits: sort the raw votes instead
+        {
             EventTimer t(cx, "vote_phase");
             cx->ekey.ensure(NE + 2);
             cx->ekey_s.ensure(NE + 2);
@@ -248,34 +316,33 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
                                 cx->eval.p, cx->scal.p + S_NRAW);
             NU = fetch_scal(cx)[S_NRAW];
         }
+    } else if (!NE) {
+        NU = 0;
     }
-    // one wait for everything the host side of the vote needs: unique pairs, their counts, the per-read vote arrays
-    const size_t RP = ((size_t)R + 63) & ~(size_t)63;
-    const size_t b_key = ((size_t)NU * 8 + 15) & ~(size_t)15, b_w = ((size_t)NU * 4 + 15) & ~(size_t)15, b_v = RP * 10;
-    {
-        uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_v + 64);
+    if (wide || far) {
+        // one wait for everything the host side of the vote still needs: unique pairs, their counts, (wide:) the per-read
+        // vote arrays
+        const size_t b_key = ((size_t)NU * 8 + 15) & ~(size_t)15, b_w = ((size_t)NU * 4 + 15) & ~(size_t)15;
+        const size_t b_pr = have_per_read ? 0 : b_v;
+        uint8_t *pin = (uint8_t *)cx->pin_d2h.ensure(b_key + b_w + b_pr + 64);
         if (tl_recorder()) {
-            // batch driver: the three pieces are gathered into one device buffer by copy kernels (one launch each for
-            // all contigs of the batch) and cross the bus as ONE DMA transfer per contig instead of three
-            cx->votepack.ensure(b_key + b_w + b_v + 64);
-            op_copy_d2d(cx, cx->votepack.p, cx->ekey.p, (size_t)NU * 8);
-            op_copy_d2d(cx, cx->votepack.p + b_key, cx->eval.p, (size_t)NU * 4);
-            op_copy_d2d(cx, cx->votepack.p + b_key + b_w, cx->votebuf.p, b_v);
-            op_d2h(cx, pin, cx->votepack.p, b_key + b_w + b_v);
+            // batch driver: the pieces are gathered into one device buffer by copy kernels (one launch each for all
+            // contigs of the batch) and cross the bus as ONE transfer per contig
+            cx->votepack2.ensure(b_key + b_w + b_pr + 64);
+            op_copy_d2d(cx, cx->votepack2.p, cx->ekey.p, (size_t)NU * 8);
+            op_copy_d2d(cx, cx->votepack2.p + b_key, cx->eval.p, (size_t)NU * 4);
+            if (b_pr) op_copy_d2d(cx, cx->votepack2.p + b_key + b_w, cx->votebuf.p, b_pr);
+            op_d2h(cx, pin, cx->votepack2.p, b_key + b_w + b_pr);
         } else {
             op_d2h(cx, pin, cx->ekey.p, (size_t)NU * 8);
             op_d2h(cx, pin + b_key, cx->eval.p, (size_t)NU * 4);
-            op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_v);
+            if (b_pr) op_d2h(cx, pin + b_key + b_w, cx->votebuf.p, b_pr);
         }
         op_sync(cx);
         // the pairs stay where they landed (the context's pinned read-back staging: valid until its next read-back; a
         // chromosome's list is 200 MB): the plain pipeline decides the vote right away, a shard copies them first
         vd.view_key = (const uint64_t *)pin, vd.view_cnt = (const uint32_t *)(pin + b_key), vd.view_n = NU;
-        const uint8_t *vb = pin + b_key + b_w;
-        vd.first_key.assign((const uint32_t *)vb, (const uint32_t *)vb + R);
-        vd.ref_w.assign((const int32_t *)(vb + RP * 4), (const int32_t *)(vb + RP * 4) + R);
-        vd.ref_seen.assign(vb + RP * 8, vb + RP * 8 + R);
-        vd.bad.assign(vb + RP * 9, vb + RP * 9 + R);
+        if (b_pr) per_read(pin + b_key + b_w);
     }
     if (cx->trace) {
         vd.own(); // (the traces below read back through the same staging)
@@ -291,7 +358,7 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
     if (!vd.any) return {};
     const uint32_t R = vd.R;
     const uint64_t NU = vd.n_pairs();
-    const uint32_t *const pair_cnt = vd.cnts();
+    const uint32_t *const pair_cnt = vd.compact() ? nullptr : vd.cnts();
     const double t_host0 = now_ms();
     // reads with a key, by (creation rank, read): the reads come in read order, so a STABLE sort by rank alone does it —
     // two 16-bit counting passes (a comparison sort of a chromosome's 3 x 10^5 keys was 12 ms)
@@ -334,8 +401,13 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
     };
     // data.retain(..) + per-row retain (main.rs:1004-1010) drop the reads flagged bad and every edge pointing at one:
     // those edges are left out while the rows are built (the rows' relative order is all that is kept of them)
-    if (!data.add_edges_sorted(vd.keys(), NU, weight, use_all ? nullptr : vd.bad.data()))
-        throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
+    auto weight_c = [](uint32_t w) {
+        const int32_t same = (int32_t)((w >> 8) & 0xFFFu), neg = (int32_t)(w >> 20);
+        return (float)(neg >= 3 ? -neg : same - neg);
+    };
+    const bool ok = vd.compact() ? data.add_edges_rows(vd.c_off, vd.c_pairs, R, weight_c, use_all ? nullptr : vd.bad.data())
+                                 : data.add_edges_sorted(vd.keys(), NU, weight, use_all ? nullptr : vd.bad.data());
+    if (!ok) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
     mark("keys + edges");
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
@@ -944,6 +1016,7 @@ struct PolishRun {
     uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu; // regions this run votes over (sub-contig coordinates)
     uint32_t T = 0, pass = 0, M = 0, n_reg = 0;
     bool reuse = false;
+    bool wide_votes = false; // the shards of a contig export (a << 32 | b, counts) pairs; the plain pipeline reads compact rows
     PassCounts pc;
     bool final_pass() const { return pass + 1 == o.iter_count; }
 };
@@ -1013,7 +1086,7 @@ void run_vote_pass(PolishRun &r, VoteData &vd) {
         cx->kscore_saved.ensure((size_t)r.pc.NC_cap + 2);
         op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(r.pc.known ? r.pc.NC : r.pc.NC_cap) * 2);
     }
-    vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd);
+    vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd, r.wide_votes);
 }
 
 // the reads the vote removed (align_bases = empty, main.rs:1548-1550), then on to the next pass
@@ -1764,6 +1837,7 @@ int np2_shard_begin(np2_ctx_t *cx, np2_contig_t *c, const np2_shard_plan_t *pl, 
     sr->run.cx = cx, sr->run.c = c, sr->run.o = *opts;
     sr->run.own_lo = pl->own_lo - pl->sub_lo;
     sr->run.own_hi = pl->own_hi - pl->sub_lo;
+    sr->run.wide_votes = true; // (exported as np2_vote_t and merged with the other shards')
     try {
         if (c->L != pl->sub_hi - pl->sub_lo || c->R != 1 + (pl->read_hi - pl->read_lo))
             throw Np2Error(NP2_E_ARG, "contig is not the upload of this shard plan");
@@ -1921,6 +1995,24 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
         }
         for (uint32_t r = 0; r < n_reads_total; ++r)
             if (votes_any[r]) vd.first_key[r] = 0xFFFFFFFEu - first_pos[r]; // ascending = right to left
+        if (getenv("NP2_VOTE_COMPACT")) {
+            // test hook (no device needed): the same vote in the compact row form the plain pipeline reads back from the
+            // vote kernels, so that the row builder over that form is checked against recorded votes on the CPU
+            const uint64_t *k = vd.keys();
+            const uint32_t *cn = vd.cnts();
+            const uint64_t np = vd.n_pairs();
+            vd.c_off_own.assign((size_t)n_reads_total + 1, 0);
+            vd.c_pairs_own.resize(np);
+            for (uint64_t i = 0; i < np; ++i) {
+                const uint32_t a = (uint32_t)(k[i] >> 32), b = (uint32_t)k[i], same = cn[i] & 0xFFFFu, neg = cn[i] >> 16;
+                if (b <= a || b - a - 1 > 255u || same > VOTE_CNT_MAX || neg > VOTE_CNT_MAX || (i && k[i - 1] >= k[i]))
+                    return NP2_E_UNSUPPORTED; // (such a vote takes the wide form)
+                ++vd.c_off_own[a + 1];
+                vd.c_pairs_own[i] = (b - a - 1) | (same << 8) | (neg << 20);
+            }
+            for (uint32_t r = 0; r < n_reads_total; ++r) vd.c_off_own[r + 1] += vd.c_off_own[r];
+            vd.c_off = vd.c_off_own.data(), vd.c_pairs = vd.c_pairs_own.data();
+        }
         std::vector<uint32_t> ls = vote_decide(nullptr, vd, opts->use_all_reads != 0);
         *n_losers = (uint32_t)ls.size();
         for (size_t i = 0; i < ls.size(); ++i) losers[i] = ls[i];

@@ -89,6 +89,21 @@ __device__ __forceinline__ void k_copy(const uint32_t np2_bid, const uint32_t np
         for (uint64_t i = o; i < min(o + 16, n); ++i) dst[i] = src[i];
     }
 }
+// copy of n 32-bit words where n = min(*n_dev, cap) lives on the device: the grid is sized by the host's bound, the
+// threads walk the real length (16 bytes per thread and step).  A read-back whose size is only known on the device
+// rides in the same wait as the counters that say how large it is.
+__device__ __forceinline__ void k_copy_counted(const uint32_t np2_bid, const uint32_t np2_nb, uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
+                                               const uint32_t *__restrict__ n_dev, uint32_t cap) {
+    const uint32_t n = min(*n_dev, cap);
+    const bool wide = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+    for (uint64_t o = ((uint64_t)np2_bid * 256 + threadIdx.x) * 4; o < n; o += (uint64_t)np2_nb * 256 * 4) {
+        if (wide && o + 4 <= n) {
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+        } else {
+            for (uint64_t i = o; i < min(o + 4, (uint64_t)n); ++i) dst[i] = src[i];
+        }
+    }
+}
 __device__ __forceinline__ void k_init_alive(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads, uint32_t R, uint8_t *__restrict__ alive) {
     uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
@@ -1453,6 +1468,9 @@ void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte) {
 }
 void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes) {
     if (bytes) NP2_LAUNCH(k_copy, grid1((bytes + 15) / 16), 256, s, dst, src, bytes);
+}
+void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap) {
+    if (cap) NP2_LAUNCH(k_copy_counted, dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 1023) / 1024, 2048))), 256, s, dst, src, n_dev, cap);
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
     NP2_LAUNCH(k_init_alive, grid1(R), 256, s, reads, R, alive);

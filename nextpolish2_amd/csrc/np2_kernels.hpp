@@ -83,6 +83,8 @@ void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox,
                  const uint32_t *ends_of = nullptr, uint32_t *ends_dst = nullptr);
 void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte);
 void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes);
+// min(*n_dev, cap) 32-bit words, the count read on the device
+void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
 // DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
@@ -226,6 +228,11 @@ void launch_edges_row(hipStream_t s, const RegionTables &rt, const uint8_t *grp,
                       const uint32_t *pcount, const uint8_t *alive, uint32_t R, uint32_t *band, uint32_t *row_n, uint32_t *ovf);
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out);
+// the same pairs in 4 bytes each, row by row: word = (b - a - 1) | agreeing regions << 8 | disagreeing regions << 20
+// (12 bits each; a larger count bumps *ovf and the host takes the sort path), row a = [row_off[a], row_off[a + 1])
+static constexpr uint32_t VOTE_CNT_MAX = 0xFFFu;
+void launch_band_emit_compact(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint32_t *pairs,
+                              uint32_t *n_out, uint32_t *ovf);
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag, uint32_t *wout);
 void launch_edge_compact(hipStream_t s, const uint64_t *ekey, const uint32_t *flag, const uint32_t *idx, const uint32_t *wout,
                          uint32_t n, uint64_t *ukey, uint32_t *uw, uint32_t *n_out);

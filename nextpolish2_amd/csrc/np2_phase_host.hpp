@@ -437,6 +437,71 @@ struct Graph {
         if (prof) fprintf(stderr, "    rows: check %.2f ms, count %.2f ms, offsets + allocation %.2f ms, fill %.2f ms (%zu threads, largest b - a %u)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, T, maxgap);
         return true;
     }
+    // The same rows from the COMPACT pair rows of the vote kernels (k_band_emit_compact): row a of the band = words
+    // [row_off[a], row_off[a + 1]), word & 255 = b - a - 1, the rest decoded by gw(word).  The pairs come in the order of
+    // the sorted (a, b) list, so the result is the one add_edges_sorted / add_edges give for that list: every row holds
+    // its partners below it (ascending), then those above it (ascending).  Threads own row ranges; the partners below a
+    // row sit in the rows of the 256 reads before it.
+    template <class GetW>
+    bool add_edges_rows(const uint32_t *row_off, const uint32_t *cp, uint32_t R, GetW gw, const uint8_t *skip = nullptr) {
+        const uint32_t N = n_ids();
+        if (R > N) return false;
+        const uint64_t n = row_off[R];
+        const uint32_t BAND = 256;
+        const size_t T = (n < (1u << 18) || host_threads() < 2) ? 1 : std::min<size_t>(host_threads(), n >> 16);
+        // endpoints are keys
+        std::vector<uint8_t> bad_t(T, 0);
+        std::vector<uint32_t> row_lo(T + 1, 0);
+        for (size_t t = 1; t < T; ++t)
+            row_lo[t] = std::max<uint32_t>(row_lo[t - 1], (uint32_t)(std::upper_bound(row_off, row_off + R + 1, (uint32_t)(n * t / T)) - row_off - 1));
+        row_lo[T] = R;
+        off.assign((size_t)N + 1, 0);
+        std::vector<uint32_t> n_lo((size_t)N, 0); // partners below each row
+        std::vector<uint32_t> cur_lo_all, cur_up_all;
+        auto scan = [&](size_t t, bool fill) {
+            const uint32_t r0 = row_lo[t], r1 = row_lo[t + 1];
+            if (r0 >= r1) return;
+            const uint32_t rb = r0 > BAND ? r0 - BAND : 0;
+            std::vector<uint32_t> cur_lo, cur_up;
+            if (fill) {
+                cur_lo.assign(off.begin() + r0, off.begin() + r1);
+                cur_up.resize(r1 - r0);
+                for (uint32_t v = r0; v < r1; ++v) cur_up[v - r0] = off[v] + n_lo[v];
+            }
+            for (uint32_t a = rb; a < r1; ++a) {
+                const uint32_t i0 = row_off[a], i1 = row_off[a + 1];
+                if (i0 == i1) continue;
+                if (!fill && a >= r0 && !has_key(a)) bad_t[t] = 1;
+                const bool sa = skip && skip[a];
+                for (uint32_t i = i0; i < i1; ++i) {
+                    const uint32_t w = cp[i], b = a + 1 + (w & 255u);
+                    if (!fill && a >= r0 && !has_key(b)) bad_t[t] = 1;
+                    if (sa || b >= N || (skip && skip[b])) continue;
+                    if (b >= r0 && b < r1) { // a partner below row b
+                        if (fill) edges[cur_lo[b - r0]++] = Edge(a, gw(w));
+                        else ++n_lo[b];
+                    }
+                    if (a >= r0) { // a partner above row a
+                        if (fill) edges[cur_up[a - r0]++] = Edge(b, gw(w));
+                        else ++off[a + 1];
+                    }
+                }
+            }
+        };
+        auto run = [&](bool fill) {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, fill); });
+            scan(0, fill);
+            for (auto &x : th) x.join();
+        };
+        run(false);
+        for (uint8_t b : bad_t)
+            if (b) return false;
+        for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v] + n_lo[v];
+        edges.resize(off[N]);
+        run(true);
+        return true;
+    }
     // drop the rows of the flagged nodes and every edge pointing at one (row order is preserved)
     void drop_nodes(const uint8_t *bad) {
         const uint32_t N = n_ids();

@@ -401,6 +401,37 @@ __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32
         }
 }
 
+// the compact form the plain pipeline reads back (4 bytes per pair instead of 12: the pair list is the largest thing a
+// phasing pass sends over the bus): the rows keep their order, a row's read is implied by row_off
+__device__ __forceinline__ void k_band_emit_compact(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
+                                                    const uint32_t *__restrict__ row_off, uint32_t *__restrict__ pairs,
+                                                    uint32_t *__restrict__ n_out, uint32_t *__restrict__ ovf) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    if (a >= R) return;
+    if (a == R - 1 && lane == 0) *n_out = row_off[R];
+    if (row_off[a + 1] == row_off[a]) return;
+    const uint4 w = *reinterpret_cast<const uint4 *>(band + (uint64_t)a * EDGE_BAND + lane * 4);
+    const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t c = (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    uint32_t o = row_off[a] + inc - c;
+    bool big = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (v[k]) {
+            const uint32_t same = v[k] & 0xFFFFu, neg = v[k] >> 16;
+            big = big || same > VOTE_CNT_MAX || neg > VOTE_CNT_MAX;
+            pairs[o] = (lane * 4 + k) | ((same & VOTE_CNT_MAX) << 8) | ((neg & VOTE_CNT_MAX) << 20);
+            ++o;
+        }
+    if (big) atomicAdd(ovf, 1u);
+}
+
 // reduce sorted edges to per-pair counts: agreeing regions | disagreeing regions << 16
 __device__ __forceinline__ void k_edge_reduce(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ ekey, const uint32_t *__restrict__ eval, uint32_t n,
                               uint32_t *__restrict__ flag, uint32_t *__restrict__ wout) {
@@ -1063,6 +1094,10 @@ void launch_edges_write(hipStream_t s, const RegionTables &rt, const uint8_t *re
 void launch_edges_row(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, const uint32_t *pj,
                       const uint32_t *pcount, const uint8_t *alive, uint32_t R, uint32_t *band, uint32_t *row_n, uint32_t *ovf) {
     if (R) NP2_LAUNCH(k_edges_row, g1((uint64_t)R * 64), 256, s, rt, grp, ecount, pj, pcount, alive, R, band, row_n, ovf);
+}
+void launch_band_emit_compact(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint32_t *pairs,
+                              uint32_t *n_out, uint32_t *ovf) {
+    if (R) NP2_LAUNCH(k_band_emit_compact, g1((uint64_t)R * 64), 256, s, band, R, row_off, pairs, n_out, ovf);
 }
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
                       uint32_t *n_out) {
