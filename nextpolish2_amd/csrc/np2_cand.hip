@@ -163,6 +163,13 @@ struct CandCtx {
     const uint32_t *tile_rd;
     uint32_t n_tiles;
     uint32_t ksize;
+    const uint64_t *rec_key;  // sorted exception records by contig tile (bucketed layout) ...
+    const uint32_t *rec_read;
+    const uint32_t *tile_n;
+    const uint16_t *rec_pidx; // ... and where the records of every 16th position of a tile begin (nullptr: not available)
+    uint32_t bucket_cap;
+    const uint32_t *refnib;
+    uint32_t L;
 };
 
 // checkpoint lookup: a non-insertion column at or before the first column of t_pos == start, and its t_pos
@@ -443,112 +450,232 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
     return x - v;
 }
 
-// Reads paired with region g (main.rs:1445-1476): those whose region interval [pj, pj + pcount) holds g.  A pair that
-// yields a non-empty string has lq_end[g] inside the read, so the reads overlapping that position's contig tile are
-// the only ones to test; the list is ascending in read index = the order the reference visits alignseqs in.
-// Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col.
-__device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
-                                                        uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
-                                                        uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
-                                                        uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
-    // A wavefront owns two consecutive regions; when both have at most 32 reads to look at (the usual case at 30x) they
-    // are measured side by side in the two halves of the wave, otherwise one after the other over all 64 lanes.
-    // blk_sum: per group of 4 regions, three arrays of n_mb entries: candidates, bytes, longest kept strings
-    __shared__ uint32_t s_w[3][8];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t n_mb = (n_reg + 3) / 4;
-    const uint32_t g0 = (np2_bid * 4 + wv) * 2;
-    uint32_t st[2], en[2], la[2], lb[2];
-#pragma unroll
-    for (uint32_t h = 0; h < 2; ++h) {
-        const bool live = g0 + h < n_reg;
-        st[h] = live ? cx.lq_start[g0 + h] : 0u, en[h] = live ? cx.lq_end[g0 + h] : 0u;
-        const uint32_t tile = min(en[h] >> TILE_SHIFT, cx.n_tiles - 1);
-        la[h] = live ? cx.tile_rd_off[tile] : 0u, lb[h] = live ? cx.tile_rd_off[tile + 1] : 0u;
+// ------------------------------------------------------------------------------------------------------
+// The contig's own candidate for most reads.  A read without an exception record at the positions [start, end + k + 2]
+// carries, column for column, the contig's bases there (a mismatch, a deleted base or an insertion column makes the
+// dense pass file records at its position and the two after it), so its candidate string is the contig's substring
+// and its first k-mer the contig's: nothing of the read has to be decoded.  That holds for 2/3 of the (read, region)
+// pairs of a diploid phasing pass and 9/10 of the pairs of a haploid or final pass.  A block takes 16 regions, four
+// per wavefront: (A) every region looks up the records around it (k_tile_sort's index of every 16th position) and marks
+// the reads that have one — a binary search of the record's read in the region's read list, in LDS —; (B) the pairs
+// that do need their read ("dirty": a record in the window, a read ending inside it) go through one queue for the
+// whole block and are decoded by consecutive threads: full wavefronts of the expensive path instead of one or two
+// such lanes holding up every wavefront; (C) the regions' waves rank their candidates and write the kept slots.
+// A region the shortcut does not cover (its window leaves its tile, the contig has a non-ACGT letter there, more than
+// 64 reads over the tile, no record index) decodes every pair the old way.
+// ------------------------------------------------------------------------------------------------------
+static constexpr uint32_t RM_RPW = 4;                // regions per wavefront
+static constexpr uint32_t RM_REG = 4 * RM_RPW;       // regions per 256-thread block
+static constexpr uint32_t CAND_CLEAN = 0xFFFFFFFFu;  // kept_col of a candidate that is the contig's own string
+static constexpr uint32_t CLEAN_MAX_LEN = 64;
+
+__device__ __forceinline__ void wave_lds_sync() { // LDS written by this wavefront is read by this wavefront
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) { // set bits of m at lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ np2_read_t rinfo_read(const ReadInfo &ri) {
+    return np2_read_t{ri.aln_t_s, ri.aln_t_e, (uint64_t)ri.nib16 << 4, ri.n_cols, 0u};
+}
+
+// Is region [st, en] of tile `tile` (read list [la, lb)) covered by the shortcut?  (uniform over the wavefront)
+__device__ __forceinline__ bool region_shortcut_ok(const CandCtx &cx, uint32_t g, uint32_t st, uint32_t en, uint32_t tile, uint32_t la, uint32_t lb) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t we = en + cx.ksize + 2;
+    if (cx.rec_pidx == nullptr || lb - la > 64 || lb == la || en - st + 1 > CLEAN_MAX_LEN || we >= cx.L) return false;
+    if ((st >> TILE_SHIFT) != tile || (we >> TILE_SHIFT) != tile) return false;
+    if (cx.tile_n[tile] > cx.bucket_cap) return false; // (spilled records: not in the bucket)
+    if (cx.tile_rd[la] != 0) return false;             // the contig itself leads every tile's read list ...
+    {
+        const ReadInfo r0 = cx.rinfo[0];                // ... and is paired with every region (its candidate is the first kept)
+        if (!(r0.pcount != 0 && r0.pj <= g && g - r0.pj < r0.pcount)) return false;
     }
-    const bool packed = g0 + 1 < n_reg && lb[0] - la[0] <= 32 && lb[1] - la[1] <= 32; // (uniform)
-    if (packed) {
-        const uint32_t h = lane >> 5, li = lane & 31, g = g0 + h;
-        const uint32_t i = (h ? la[1] : la[0]) + li, ie = h ? lb[1] : lb[0];
+    // the contig's letters at [st, en + k] are all A/C/G/T (nibble p at bits 4 (p & 7) of word p >> 3)
+    const uint32_t w0 = st >> 3, w1 = (en + cx.ksize) >> 3; // at most 13 words
+    bool bad = false;
+    if (w0 + lane <= w1) {
+        const uint32_t w = cx.refnib[w0 + lane];
+        uint32_t m = 0x44444444u;
+        if (w0 + lane == w0) m &= 0xFFFFFFFFu << (4 * (st & 7));
+        if (w0 + lane == w1) m &= 0xFFFFFFFFu >> (4 * (7 - ((en + cx.ksize) & 7)));
+        bad = (w & m) != 0;
+    }
+    return __ballot(bad) == 0;
+}
+
+// every pair of a region decoded by the region's wavefront, 64 reads per round (the path regions outside the shortcut take)
+__device__ __forceinline__ void region_measure_inline(const CandCtx &cx, uint32_t g, uint32_t st, uint32_t en, uint32_t la, uint32_t lb,
+                                                      uint32_t *__restrict__ kept_read, uint32_t *__restrict__ kept_len,
+                                                      uint32_t *__restrict__ kept_col, uint32_t &kept, uint32_t &bytes, uint32_t &mx) {
+    const uint32_t lane = threadIdx.x & 63;
+    kept = 0, bytes = 0, mx = 0;
+    for (uint32_t c0 = la; c0 < lb && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
+        const uint32_t i = c0 + lane;
         uint32_t r = 0, len = 0, col = 0;
-        if (i < ie) {
+        if (i < lb) {
             r = cx.tile_rd[i];
             const ReadInfo ri = cx.rinfo[r]; // (pcount is 0 for a dropped read)
-            if (ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount) {
-                const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
-                len = cand_measure(cx, r, rd, ri.ck_off, h ? st[1] : st[0], h ? en[1] : en[0], col);
-            }
+            if (ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount) len = cand_measure(cx, r, rinfo_read(ri), ri.ck_off, st, en, col);
         }
-        const uint32_t ne = (uint32_t)(__ballot(len > 0) >> (lane & 32)); // this half's non-empty candidates
-        const uint32_t before = (uint32_t)__builtin_popcount(ne & ((1u << li) - 1u));
-        if (len > 0) { // (at most 32 of them: the cap of 60 cannot bite)
+        const uint64_t ne = __ballot(len > 0);
+        const uint32_t before = kept + lanes_below(ne);
+        const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
+        if (keep) {
             const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
             kept_read[slot] = r;
             kept_len[slot] = len;
             kept_col[slot] = col;
         }
-        uint32_t bytes = len, mx = len;
+        kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
+        bytes += wave_sum(keep ? len : 0u);
+        mx = max(mx, keep ? len : 0u);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+}
+
+// Reads paired with region g (main.rs:1445-1476): those whose region interval [pj, pj + pcount) holds g.  A pair that
+// yields a non-empty string has lq_end[g] inside the read, so the reads overlapping that position's contig tile are
+// the only ones to test; the list is ascending in read index = the order the reference visits alignseqs in.
+// Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col
+// (kept_col == CAND_CLEAN: the contig's own string, nothing to decode).
+__device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
+                                                        uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
+                                                        uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
+                                                        uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
+    // blk_sum: per group of 4 regions (= one wavefront's), three arrays of n_mb entries: candidates, bytes, longest kept strings
+    __shared__ uint32_t s_reads[4][64];
+    __shared__ uint32_t s_dm[4][2];
+    __shared__ uint32_t s_len[RM_REG][64];
+    __shared__ uint32_t s_col[RM_REG][64];
+    __shared__ uint32_t s_q[RM_REG * 64];
+    __shared__ uint32_t s_qn;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n_mb = (n_reg + 3) / 4, mb = np2_bid * 4 + wv, g0 = mb * 4;
+    if (threadIdx.x == 0) s_qn = 0;
+    __syncthreads();
+    uint32_t rr[RM_RPW], state[RM_RPW]; // this lane's read per region; 0 no pair, 1 the contig's string, 2 queued
+    uint32_t sum_k = 0, sum_b = 0, sum_m = 0; // the group's totals (uniform)
+    uint32_t fastmask = 0;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            bytes += __shfl_xor(bytes, o);
-            mx = max(mx, (uint32_t)__shfl_xor(mx, o));
-        }
-        if (li == 0) {
-            const uint32_t kept = (uint32_t)__builtin_popcount(ne);
-            reg_ncand[g] = kept;
-            reg_bytes[g] = bytes;
-            reg_maxlen[g] = mx;
-            s_w[0][2 * wv + h] = kept;
-            s_w[1][2 * wv + h] = bytes;
-            s_w[2][2 * wv + h] = mx; // the longest string a splice can put in place of this region
-        }
-    } else {
-#pragma unroll
-        for (uint32_t h = 0; h < 2; ++h) {
-            const uint32_t g = g0 + h;
-            const bool live = g < n_reg;
-            uint32_t kept = 0, bytes = 0, mx = 0;
-            for (uint32_t c0 = la[h]; c0 < lb[h] && kept < LQSEQ_MAX_CAN_COUNT; c0 += 64) {
-                const uint32_t i = c0 + lane;
-                uint32_t r = 0, len = 0, col = 0;
-                if (i < lb[h]) {
-                    r = cx.tile_rd[i];
-                    const ReadInfo ri = cx.rinfo[r];
-                    if (ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount) {
-                        const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
-                        len = cand_measure(cx, r, rd, ri.ck_off, st[h], en[h], col);
-                    }
-                }
-                const uint64_t ne = __ballot(len > 0);
-                const uint32_t before = kept + (uint32_t)__builtin_popcountll(ne & ((1ULL << lane) - 1ULL));
-                const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
-                if (keep) {
-                    const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
-                    kept_read[slot] = r;
-                    kept_len[slot] = len;
-                    kept_col[slot] = col;
-                }
-                kept = min(kept + (uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
-                bytes += wave_sum(keep ? len : 0u);
-                mx = max(mx, keep ? len : 0u);
-            }
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
+        rr[h] = 0, state[h] = 0;
+        if (g >= n_reg) continue;
+        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
+        const uint32_t tile = min(en >> TILE_SHIFT, cx.n_tiles - 1);
+        const uint32_t la = cx.tile_rd_off[tile], lb = cx.tile_rd_off[tile + 1];
+        if (!region_shortcut_ok(cx, g, st, en, tile, la, lb)) {
+            uint32_t kept, bytes, mx;
+            region_measure_inline(cx, g, st, en, la, lb, kept_read, kept_len, kept_col, kept, bytes, mx);
             if (lane == 0) {
-                if (live) {
-                    reg_ncand[g] = kept;
-                    reg_bytes[g] = bytes;
-                    reg_maxlen[g] = mx;
+                reg_ncand[g] = kept;
+                reg_bytes[g] = bytes;
+                reg_maxlen[g] = mx;
+            }
+            sum_k += kept, sum_b += bytes, sum_m += mx;
+            continue;
+        }
+        fastmask |= 1u << h;
+        const uint32_t nlist = lb - la;
+        uint32_t r = 0xFFFFFFFFu;
+        bool paired = false, ends_inside = false;
+        if (lane < nlist) {
+            r = cx.tile_rd[la + lane];
+            const ReadInfo ri = cx.rinfo[r];
+            paired = ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount;
+            ends_inside = ri.aln_t_e < en + cx.ksize; // (the first k-mer needs the columns up to start + k - 1)
+        }
+        rr[h] = r;
+        s_reads[wv][lane] = r;
+        if (lane < 2) s_dm[wv][lane] = 0;
+        wave_lds_sync();
+        // records of the tile at positions [st, en + k + 2]
+        const uint32_t tstart = tile << TILE_SHIFT, ws = st, we = en + cx.ksize + 2;
+        const uint32_t tn = cx.tile_n[tile];
+        uint32_t lo = 0, hi = 0;
+        if (tn) {
+            const uint32_t j0 = (ws - tstart) >> 4, j1 = ((we - tstart) >> 4) + 1;
+            lo = cx.rec_pidx[(size_t)tile * (TILE / 16) + j0];
+            hi = j1 < TILE / 16 ? (uint32_t)cx.rec_pidx[(size_t)tile * (TILE / 16) + j1] : tn;
+        }
+        const uint64_t a = (uint64_t)tile * cx.bucket_cap;
+        for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            if (i < hi) {
+                const uint32_t pos = (uint32_t)(cx.rec_key[a + i] >> 32), q = cx.rec_read[a + i];
+                if (pos >= ws && pos <= we) {
+                    uint32_t x = 0, y = nlist; // first list entry >= q
+                    while (x < y) {
+                        const uint32_t m = (x + y) >> 1;
+                        if (s_reads[wv][m] < q) x = m + 1; else y = m;
+                    }
+                    if (x < nlist && s_reads[wv][x] == q) atomicOr(&s_dm[wv][x >> 5], 1u << (x & 31));
                 }
-                s_w[0][2 * wv + h] = kept;
-                s_w[1][2 * wv + h] = bytes;
-                s_w[2][2 * wv + h] = mx;
             }
         }
+        wave_lds_sync();
+        const bool marked = (s_dm[wv][lane >> 5] >> (lane & 31)) & 1u;
+        const uint32_t stt = !paired ? 0u : ((marked || ends_inside) && r != 0) ? 2u : 1u; // (the contig has no records)
+        state[h] = stt;
+        const uint64_t dq = __ballot(stt == 2u);
+        uint32_t qb = 0;
+        if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
+        qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+        if (stt == 2u) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
+        wave_lds_sync(); // (s_reads / s_dm are reused by the next region)
     }
     __syncthreads();
-    if (threadIdx.x < 6) { // two groups of 4 regions per block
-        const uint32_t k = threadIdx.x >> 1, m = threadIdx.x & 1, mb = np2_bid * 2 + m;
-        if (mb < n_mb) blk_sum[k * n_mb + mb] = s_w[k][4 * m] + s_w[k][4 * m + 1] + s_w[k][4 * m + 2] + s_w[k][4 * m + 3];
+    // (B) the pairs that need their read, one per thread
+    const uint32_t nq = s_qn;
+    for (uint32_t e = threadIdx.x; e < nq; e += 256) {
+        const uint32_t w = s_q[e], slot = w >> 6, ln = w & 63;
+        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * 4 + slot % RM_RPW;
+        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
+        const uint32_t tile = min(en >> TILE_SHIFT, cx.n_tiles - 1);
+        const uint32_t r = cx.tile_rd[cx.tile_rd_off[tile] + ln];
+        const ReadInfo ri = cx.rinfo[r];
+        uint32_t col = 0;
+        const uint32_t len = cand_measure(cx, r, rinfo_read(ri), ri.ck_off, st, en, col);
+        s_len[slot][ln] = len;
+        s_col[slot][ln] = col;
+    }
+    __syncthreads();
+    // (C) rank and keep
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        if (!((fastmask >> h) & 1u)) continue;
+        const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
+        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
+        uint32_t len = 0, col = CAND_CLEAN;
+        if (state[h] == 1u) len = en - st + 1;
+        else if (state[h] == 2u) len = s_len[slot][lane], col = s_col[slot][lane];
+        const uint64_t ne = __ballot(len > 0);
+        const uint32_t before = lanes_below(ne);
+        const bool keep = len > 0 && before < LQSEQ_MAX_CAN_COUNT;
+        if (keep) {
+            const size_t ks = (size_t)g * LQSEQ_MAX_CAN_COUNT + before;
+            kept_read[ks] = rr[h];
+            kept_len[ks] = len;
+            kept_col[ks] = col;
+        }
+        const uint32_t kept = min((uint32_t)__builtin_popcountll(ne), (uint32_t)LQSEQ_MAX_CAN_COUNT);
+        const uint32_t bytes = wave_sum(keep ? len : 0u);
+        uint32_t mx = keep ? len : 0u;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+        if (lane == 0) {
+            reg_ncand[g] = kept;
+            reg_bytes[g] = bytes;
+            reg_maxlen[g] = mx; // the longest string a splice can put in place of this region
+        }
+        sum_k += kept, sum_b += bytes, sum_m += mx;
+    }
+    if (lane == 0 && mb < n_mb) {
+        blk_sum[mb] = sum_k;
+        blk_sum[n_mb + mb] = sum_b;
+        blk_sum[2 * n_mb + mb] = sum_m;
     }
 }
 
@@ -620,19 +747,11 @@ __device__ __forceinline__ void k_cand_offsets_lb(const uint32_t np2_bid, const 
     }
 }
 
-// one lane per kept candidate (at most 60 per region).  A wavefront owns two consecutive regions: at 30x a region keeps
-// ~30 candidates, so when both have at most 32 they are written side by side in the two halves of the wave, otherwise
-// one after the other.
-__device__ __forceinline__ uint32_t half_excl(uint32_t v) { // exclusive prefix sum inside each 32-lane half
-    const uint32_t hl = threadIdx.x & 31;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        const uint32_t t = __shfl_up(x, o, 32);
-        if (hl >= (uint32_t)o) x += t;
-    }
-    return x - v;
-}
+// Second pass, once the offsets are known: order, string offset, string and first k-mer of every kept candidate.  One
+// wavefront per region (four regions per wavefront, one after the other), one lane per kept candidate (at most 60).  The
+// candidates that are the contig's own string (kept_col == CAND_CLEAN) copy it from LDS, where the region's wavefront
+// put it straight from the nibble-packed contig, and take the k-mer of the contig's own candidate (read 0, always the
+// first of such a region); the others — and read 0 — go through the block's queue and are decoded by consecutive threads.
 __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
                                                       const uint32_t *__restrict__ kept_len,
                                                       const uint32_t *__restrict__ kept_col,
@@ -645,41 +764,96 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
                                                       uint32_t seq_cap, uint32_t *__restrict__ cand_order,
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g0 = 2 * (np2_bid * 4 + (threadIdx.x >> 6));
-    if (g0 >= n_reg) return;
-    const bool has1 = g0 + 1 < n_reg;
-    const bool packed = has1 && reg_ncand[g0] <= 32 && reg_ncand[g0 + 1] <= 32; // (uniform)
-    const uint32_t rounds = (has1 && !packed) ? 2u : 1u;
-    for (uint32_t round = 0; round < rounds; ++round) {
-        const uint32_t g = packed ? g0 + (lane >> 5) : g0 + round; // this lane's region
-        const uint32_t li = packed ? (lane & 31) : lane;            // ... and its candidate index in it
-        if (g == n_reg - 1 && li == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
-        // offsets of the region: the prefix of its block of 4 regions (k_region_measure's blocks) + the regions before
-        // it inside that block
-        const uint32_t mb = g >> 2;
-        uint32_t oc = blk_coff[mb], ob = blk_soff[mb];
-        for (uint32_t w = mb * 4; w < g; ++w) {
-            oc += reg_ncand[w];
-            ob += reg_bytes[w];
-        }
-        if (li == 0) {
+    __shared__ uint8_t s_str[RM_REG][CLEAN_MAX_LEN];
+    __shared__ uint64_t s_km[RM_REG];
+    __shared__ uint32_t s_so[RM_REG][64];
+    __shared__ uint32_t s_oc[RM_REG];
+    __shared__ uint32_t s_q[RM_REG * 64];
+    __shared__ uint32_t s_qn;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t mb = np2_bid * 4 + wv, g0 = mb * 4;
+    if (threadIdx.x == 0) s_qn = 0;
+    __syncthreads();
+    uint32_t oc = 0, ob = 0;
+    if (g0 < n_reg) oc = blk_coff[mb], ob = blk_soff[mb];
+    uint32_t clean_h = 0;        // regions of this wavefront with candidates that are the contig's string (uniform)
+    uint32_t my_len[RM_RPW], my_so[RM_RPW], my_ci[RM_RPW];
+    bool my_clean[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
+        my_len[h] = 0, my_so[h] = 0, my_ci[h] = 0, my_clean[h] = false;
+        if (g >= n_reg) continue;
+        if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
+        const uint32_t n = reg_ncand[g];
+        if (lane == 0) {
             cand_off[g] = oc;
             reg_soff[g] = ob;
+            s_oc[slot] = oc;
         }
-        const uint32_t n = reg_ncand[g];
-        const bool act = li < n;
-        const size_t slot = (size_t)g * LQSEQ_MAX_CAN_COUNT + li;
-        const uint32_t len = act ? kept_len[slot] : 0u;
-        const uint32_t so = ob + (packed ? half_excl(len) : wave_excl(len));
-        const uint32_t ci = oc + li;
-        if (act && ci < cand_cap && (uint64_t)so + len <= seq_cap) {
-            const uint32_t r = kept_read[slot];
-            const ReadInfo ri = cx.rinfo[r];
-            const np2_read_t rd{ri.aln_t_s, 0u, ri.nib_off, ri.n_cols, 0u};
+        const bool act = lane < n;
+        const size_t ks = (size_t)g * LQSEQ_MAX_CAN_COUNT + lane;
+        const uint32_t len = act ? kept_len[ks] : 0u;
+        const uint32_t col = act ? kept_col[ks] : 0u;
+        const uint32_t so = ob + wave_excl(len);
+        const uint32_t ci = oc + lane;
+        const bool ok = act && ci < cand_cap && (uint64_t)so + len <= seq_cap;
+        uint32_t r = 0;
+        if (ok) {
+            r = kept_read[ks];
             cand_order[ci] = r;
             cand_seq_off[ci] = so;
-            cand_write(cx, r, rd, ri.pj, g, kept_col[slot], max(cx.lq_start[g], rd.aln_t_s), len, cand_seq + so, &cand_kmer[ci]);
+        }
+        const bool clean = ok && col == CAND_CLEAN;
+        const uint64_t cm = __ballot(clean);
+        // read 0's kept_col says "clean" too (its string is the contig's by definition): it is decoded for the k-mer
+        const bool queued = ok && (!clean || (lane == 0 && r == 0));
+        my_len[h] = len, my_so[h] = so, my_ci[h] = ci, my_clean[h] = clean && !queued;
+        s_so[slot][lane] = so;
+        if (cm) {
+            clean_h |= 1u << h;
+            // the contig's bases at [start, end]: one per lane, straight from the nibble-packed contig (all A/C/G/T here)
+            const uint32_t st = cx.lq_start[g], ln0 = cx.lq_end[g] - st + 1;
+            if (lane < ln0) {
+                const uint32_t p = st + lane;
+                s_str[slot][lane] = (uint8_t)((0x54474341u >> (8 * ((cx.refnib[p >> 3] >> (4 * (p & 7))) & 3))) & 0xFFu);
+            }
+        }
+        const uint64_t dq = __ballot(queued);
+        uint32_t qb = 0;
+        if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
+        qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+        if (queued) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
+        oc += n;
+        ob += reg_bytes[g];
+    }
+    __syncthreads();
+    const uint32_t nq = s_qn;
+    for (uint32_t e = threadIdx.x; e < nq; e += 256) {
+        const uint32_t w = s_q[e], slot = w >> 6, li = w & 63;
+        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * 4 + slot % RM_RPW;
+        const size_t ks = (size_t)g * LQSEQ_MAX_CAN_COUNT + li;
+        const uint32_t r = kept_read[ks], len = kept_len[ks];
+        uint32_t col = kept_col[ks];
+        const ReadInfo ri = cx.rinfo[r];
+        const np2_read_t rd = rinfo_read(ri);
+        const uint32_t t0 = max(cx.lq_start[g], rd.aln_t_s);
+        if (col == CAND_CLEAN) col = t0; // (read 0: column index == position)
+        const uint32_t ci = s_oc[slot] + li;
+        uint64_t km;
+        cand_write(cx, r, rd, ri.pj, g, col, t0, len, cand_seq + s_so[slot][li], &km);
+        cand_kmer[ci] = km;
+        if (li == 0 && r == 0) s_km[slot] = km;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        if (!((clean_h >> h) & 1u)) continue;
+        const uint32_t slot = wv * RM_RPW + h;
+        if (my_clean[h]) {
+            cand_kmer[my_ci[h]] = s_km[slot];
+            uint8_t *dst = cand_seq + my_so[h];
+            for (uint32_t j = 0; j < my_len[h]; ++j) dst[j] = s_str[slot][j];
         }
     }
 }
@@ -714,13 +888,14 @@ void launch_scan_small_min(hipStream_t s, const int32_t *in, int32_t *out, uint3
 }
 static CandCtx mk_cand(const CandPtrs &c) {
     return CandCtx{c.reads, c.nib,    c.ck_off, c.ckpt,        c.lq_start, c.lq_end, c.pj,
-                   c.pcount, c.alive, c.rinfo, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize};
+                   c.pcount, c.alive, c.rinfo, c.tile_rd_off, c.tile_rd, c.n_tiles,  c.ksize,
+                   c.rec_key, c.rec_read, c.tile_n, c.rec_pidx, c.bucket_cap, c.refnib, c.L};
 }
 void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uint32_t *kept_read, uint32_t *kept_len,
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum) {
     if (n_reg)
-        NP2_LAUNCH(k_region_measure, dim3((n_reg + 7) / 8), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
+        NP2_LAUNCH(k_region_measure, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,
@@ -737,7 +912,7 @@ void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const
                          uint32_t *reg_soff, uint32_t cand_cap, uint32_t seq_cap, uint32_t *cand_order, uint64_t *cand_kmer,
                          uint32_t *cand_seq_off, uint8_t *cand_seq) {
     if (n_reg)
-        NP2_LAUNCH(k_region_write, dim3((n_reg + 7) / 8), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off, cand_seq);
+        NP2_LAUNCH(k_region_write, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, blk_coff, blk_soff, cand_off, reg_soff, cand_cap, seq_cap, cand_order, cand_kmer, cand_seq_off, cand_seq);
 }
 
 } // namespace np2

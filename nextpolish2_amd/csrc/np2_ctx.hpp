@@ -482,6 +482,8 @@ struct np2_ctx {
     DevBuf<uint8_t> run_flag; // long runs handed from the eight-lane DP kernel to the per-thread one
     uint32_t deep_min = 65536; // coverage from which the on-chip DP of short runs is off (NP2_TEST_DEEP_COV lowers it: tests)
     DevBuf<uint32_t> lq_list, hbits; // consensus indices of the low-quality bases; bitmap of the raw regions' head indices
+    DevBuf<uint16_t> tile_pidx;  // per tile: first record at or beyond every 16th position (k_tile_sort)
+    bool pidx_valid = false;     // false after the device-wide sort fallback
     DevBuf<ReadInfo> rinfo;      // per read and pass: descriptor + checkpoint offset + region interval in one line
     DevBuf<uint32_t> lqc, lqoff; // low-quality bases written per dirty run, and their exclusive scan
     DevBuf<uint8_t> pflag;               // per contig position: has exception nodes | coverage below 2

@@ -144,7 +144,7 @@ __device__ __forceinline__ void k_tile_layout_lb(const uint32_t np2_bid, const u
 // at 2048 records made this the longest kernel of the diploid workload.  Pairs are unique, so the result does not
 // depend on the order the bucket was filled in.
 template <uint32_t CAP>
-__device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32_t np2_nb, const np2_read_t *__restrict__ reads,
+__device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32_t np2_nb, uint16_t *__restrict__ pidx, const np2_read_t *__restrict__ reads,
                                                    const uint8_t *__restrict__ nib, const uint32_t *__restrict__ tile_n,
                                                    uint32_t bucket_cap, uint64_t *__restrict__ keys,
                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ err,
@@ -196,6 +196,8 @@ __device__ __forceinline__ void k_tile_sort(const uint32_t np2_bid, const uint32
         const uint32_t q = s_q[i];
         s_idx[s_off[q] + atomicAdd(&s_cnt[q], 1u)] = (uint16_t)i;
     }
+    // where the records of every 16th position begin: candidate extraction looks up the records around an LQ region
+    if (tid < TILE / 16) pidx[(size_t)np2_bid * (TILE / 16) + tid] = s_off[tid * 16];
     __syncthreads();
     for (uint32_t d = tid; d < n; d += 256) {
         const uint32_t i = s_idx[d], q = s_q[i], b = s_off[q], m = s_cnt[q];
@@ -763,18 +765,18 @@ void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uin
     else
         NP2_LAUNCH(k_tile_layout, dim3(1), 1024, s, tile_cur, n_tiles, bucket_cap, tile_n, tile_scan, tile_scanb, ovf_cnt, out);
 }
-void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+void launch_tile_sort(hipStream_t s, uint16_t *pidx, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
                       uint32_t *err) {
     const uint32_t ALL = 0xFFFFFFFFu;
     if (max_tile <= 1024) {
-        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, ALL);
+        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, pidx, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, ALL);
     } else {
-        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, 1024u);
+        NP2_LAUNCH(k_tile_sort<1024>, dim3(n_tiles), 256, s, pidx, reads, nib, tile_n, bucket_cap, keys, vals, err, 0u, 1024u);
         if (max_tile <= 2048 && TILE_CAP > 2048)
-            NP2_LAUNCH(k_tile_sort<2048>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
+            NP2_LAUNCH(k_tile_sort<2048>, dim3(n_tiles), 256, s, pidx, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
         else
-            NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
+            NP2_LAUNCH(k_tile_sort<TILE_CAP>, dim3(n_tiles), 256, s, pidx, reads, nib, tile_n, bucket_cap, keys, vals, err, 1024u, ALL);
     }
 }
 void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,

@@ -650,9 +650,11 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         EventTimer t(cx, "sort_exceptions");
         if (sc[S_M2] == 0) {
             // raw records -> node keys, sorted by (key, read) inside LDS, tile by tile, in place
-            launch_tile_sort(s, c->reads.p, c->nib.p, cx->tile_n.p, n_tiles, bcap, sc[S_M1], cx->keys_raw.p,
+            cx->tile_pidx.ensure((size_t)n_tiles * (TILE / 16) + 64);
+            launch_tile_sort(s, cx->tile_pidx.p, c->reads.p, c->nib.p, cx->tile_n.p, n_tiles, bcap, sc[S_M1], cx->keys_raw.p,
                              cx->vals_raw.p, cx->scal.p + S_ERR);
             cx->bucket_cap = bcap;
+            cx->pidx_valid = true;
         } else {
             // some tile holds more records than a bucket (e.g. a long insertion carried by every read): gather
             // buckets + spill area into one array and sort it device-wide
@@ -671,6 +673,7 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
                     throw Np2Error(NP2_E_DEVICE, "rocprim radix_sort_pairs failed");
             });
             cx->bucket_cap = 0;
+            cx->pidx_valid = false;
         }
         return;
     }
@@ -907,7 +910,10 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->kscore.ensure((size_t)NC_cap + 2);
     cx->long_list.ensure((size_t)NC_cap + 2);
     CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
-                cx->pcount.p, cx->alive.p, cx->rinfo.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles, cx->yaks[0].k};
+                cx->pcount.p, cx->alive.p, cx->rinfo.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles, cx->yaks[0].k,
+                cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p,
+                (cx->pidx_valid && cx->bucket_cap && !getenv("NP2_CAND_DECODE_ALL")) ? cx->tile_pidx.p : nullptr, cx->bucket_cap,
+                (const uint32_t *)c->refnib.p, c->L};
     {
         EventTimer t(cx, "candidates");
         // every live read covers a contiguous interval [pj, pj + pcount) of the region list
@@ -1240,6 +1246,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         const np2_read_t &rd = reads[r];
         const bool dropped = rd.flags & NP2_READ_DROPPED;
         if (rd.nib_off & 15) throw Np2Error(NP2_E_ARG, "nib_off must be a multiple of 16");
+        if (rd.nib_off >> 36) throw Np2Error(NP2_E_NOMEM, "a contig's nibble streams must stay below 64 GiB");
         if (!dropped && (rd.aln_t_e >= L || rd.aln_t_s > rd.aln_t_e))
             throw Np2Error(NP2_E_ARG, "read span outside the contig");
         if (rd.nib_off + ((uint64_t)(rd.n_cols + 1) >> 1) + 1 + 16 > nib_bytes)

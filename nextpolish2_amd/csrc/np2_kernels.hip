@@ -1266,7 +1266,7 @@ __device__ __forceinline__ void k_pair_count(const uint32_t np2_bid, const uint3
     }
     pj[r] = j;
     pcount[r] = cnt;
-    rinfo[r] = ReadInfo{rd.aln_t_s, rd.n_cols, rd.nib_off, ck_off[r], j, cnt};
+    rinfo[r] = ReadInfo{rd.aln_t_s, rd.n_cols, (uint32_t)(rd.nib_off >> 4), rd.aln_t_e, ck_off[r], j, cnt};
 }
 
 // ------------------------------------------------------------------------------------------

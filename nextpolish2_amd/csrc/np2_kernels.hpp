@@ -46,7 +46,8 @@ struct GraphPtrs {
 // (region, read) pair then costs one memory transaction for the read instead of six scattered ones)
 struct __attribute__((aligned(16))) ReadInfo {
     uint32_t aln_t_s, n_cols;
-    uint64_t nib_off;
+    uint32_t nib16;        // nib_off / 16 (nibble streams are 16-byte aligned; a contig's pileup stays below 64 GiB)
+    uint32_t aln_t_e;      // inclusive last position
     uint64_t ck_off;       // first checkpoint of the read
     uint32_t pj, pcount;   // the read's region interval [pj, pj + pcount); 0 regions for a dropped read
 };
@@ -65,6 +66,16 @@ struct CandPtrs {
     const uint32_t *tile_rd;
     uint32_t n_tiles;
     uint32_t ksize;
+    // the sorted exception records of the dense pass, by contig tile (bucketed layout), and the index k_tile_sort leaves:
+    // rec_pidx[tile * 64 + j] = first record of the tile at or beyond its position 16 j (nullptr: not available — the
+    // device-wide sort took over —, every candidate is then decoded from its read)
+    const uint64_t *rec_key;
+    const uint32_t *rec_read;
+    const uint32_t *tile_n;
+    const uint16_t *rec_pidx;
+    uint32_t bucket_cap;
+    const uint32_t *refnib;
+    uint32_t L;
 };
 struct YakDev {
     const uint64_t *table; // 1024 sub-tables of (1 << cap_log2) slots
@@ -172,7 +183,8 @@ uint32_t tile_scan_blocks(uint32_t n_tiles); // blocks of the look-back variants
 void launch_tile_layout(hipStream_t s, uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint32_t *tile_n,
                         uint32_t *tile_scan, uint32_t *tile_scanb, const uint32_t *ovf_cnt, uint32_t *out,
                         const Lookback *lb = nullptr, uint32_t *err = nullptr);
-void launch_tile_sort(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
+// (pidx: 64 entries per tile, see CandPtrs::rec_pidx)
+void launch_tile_sort(hipStream_t s, uint16_t *pidx, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,
                       uint32_t n_tiles, uint32_t bucket_cap, uint32_t max_tile, uint64_t *keys, uint32_t *vals,
                       uint32_t *err);
 void launch_gather_buckets(hipStream_t s, const np2_read_t *reads, const uint8_t *nib, const uint32_t *tile_n,

@@ -135,6 +135,58 @@ def _exchange(payload, failure, device, group, what):
     return [g[8:] for g in got]
 
 
+def _decide_on_owner(payload, failure, n_reads_total, opts, device, group, owner=0):
+    """The contig-wide decision of one phasing pass, taken ONCE: the ranks' votes are gathered onto `owner` (variable
+    lengths: a tiny all-gather of status + length, then one padded gather — RCCL over xGMI with backend nccl), the owner
+    merges and decides them (np2_vote_decide: the Louvain of louvain.rs:290-356 on the merged read graph, host only), and
+    the reads it removes come back to every rank as a bitmap of n_reads_total bits in one broadcast.  (Every rank deciding
+    the same all-gathered votes for itself — round 3 — put the ~130 ms of a chromosome's host vote on every rank's
+    critical path and sent 370 MB of votes to eight ranks.)  Any rank's failure — its vote, or the owner's decision —
+    reaches every rank as ShardMismatch in the same collectives."""
+    from .api import Vote, vote_decide
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    device = device or torch.device("cpu")
+    body = np.zeros(0, dtype=np.uint8) if failure is not None else np.ascontiguousarray(payload, dtype=np.uint8)
+    if world == 1:
+        if failure is not None:
+            raise ShardMismatch(f"phasing vote failed: {failure}") from failure
+        return vote_decide([Vote.unpack(body)], n_reads_total, opts)
+    head = torch.tensor([0 if failure is None else 1, body.shape[0]], dtype=torch.int64, device=device)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    heads = [h.cpu().numpy() for h in heads]
+    bad = [r for r, h in enumerate(heads) if int(h[0]) != 0]
+    if bad:
+        raise ShardMismatch(f"phasing vote failed on rank(s) {bad}" + (f": {failure}" if rank in bad else "")) from failure
+    lens = [int(h[1]) for h in heads]
+    cap = max(1, max(lens))
+    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if body.shape[0]:
+        buf[:body.shape[0]] = torch.from_numpy(body).to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == owner else None
+    dist.gather(buf, parts, dst=owner, group=group)
+    n_bytes = (n_reads_total + 7) // 8
+    out = torch.zeros(8 + n_bytes, dtype=torch.uint8, device=device)  # [status byte, 7 x pad][bitmap]
+    err = None
+    if rank == owner:
+        try:
+            votes = [Vote.unpack(parts[r][:lens[r]].cpu().numpy()) for r in range(world)]
+            losers = vote_decide(votes, n_reads_total, opts)
+            bits = np.zeros(n_bytes * 8, dtype=np.uint8)
+            bits[losers] = 1
+            host = np.concatenate([np.zeros(8, dtype=np.uint8), np.packbits(bits, bitorder="little")])
+        except Exception as e:  # noqa: BLE001 — the other ranks wait in the broadcast below: tell them
+            err = e
+            host = np.concatenate([np.ones(8, dtype=np.uint8), np.zeros(n_bytes, dtype=np.uint8)])
+        out.copy_(torch.from_numpy(host).to(device))
+    dist.broadcast(out, src=owner, group=group)
+    got = out.cpu().numpy()
+    if got[0] != 0:
+        raise ShardMismatch(f"the contig-wide vote failed on rank {owner}" + (f": {err}" if err is not None else "")) from err
+    return np.flatnonzero(np.unpackbits(got[8:], bitorder="little")[:n_reads_total]).astype(np.uint32)
+
+
 def check_strips(metas, plans):
     """Neighbouring shards computed the `verify` positions on either side of their common cut independently: the high
     strip of shard k must equal the low strip of shard k + 1 base for base and position for position, otherwise the halo
@@ -249,15 +301,14 @@ def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
 
 def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
     """Shard protocol of one rank among `world` (one process per GPU): every phase's exchange carries the ranks' status."""
-    from .api import ShardPiece, Vote, vote_decide
+    from .api import ShardPiece
     while run.passes_left() > 1:
         err, payload = None, None
         try:
             payload = run.vote().pack()
         except Exception as e:  # noqa: BLE001 — any failure of this rank's shard ends the sharded attempt everywhere
             err = e
-        raws = _exchange(payload, err, device, group, "phasing vote")
-        losers = vote_decide([Vote.unpack(x) for x in raws], n_reads_total, opts)
+        losers = _decide_on_owner(payload, err, n_reads_total, opts, device, group)
         run.apply(losers)
     err, pc = None, None
     try:
@@ -278,9 +329,9 @@ def polish_sharded(polisher, pileup, opts=None, halo=65536, verify=1024, device=
     """Polish one contig cut into world_size reference intervals, one per rank (one process per GPU).
 
     Every rank holds the contig's host pileup (or at least its own shard's reads) and uploads only its shard.  Per
-    phasing pass the ranks all-gather their votes (pair counts of the HETE regions they own, per-read vote records —
-    a few MB per Mb of diploid contig) and each runs the contig-wide decision on the merged votes (host only,
-    deterministic: no broadcast needed); the removed reads are applied to every shard.  The final pass leaves each
+    phasing pass the ranks' votes (pair counts of the HETE regions they own, per-read vote records — a few MB per Mb of
+    diploid contig) are gathered onto rank 0, which takes the contig-wide decision on the merged votes once (host only)
+    and broadcasts the removed reads as a bitmap (_decide_on_owner); they are applied to every shard.  The final pass leaves each
     shard's polished sub-contig on its device; the ranks exchange the short strips around the cuts (checked on every
     rank) and the owned slices are gathered from the device buffers (RCCL over xGMI with backend nccl) onto rank `dst`
     (None: every rank).  Returns (bases, pos) there — pos None unless want_pos — and (None, None) on the other ranks."""
