@@ -481,31 +481,6 @@ __device__ __forceinline__ np2_read_t rinfo_read(const ReadInfo &ri) {
     return np2_read_t{ri.aln_t_s, ri.aln_t_e, (uint64_t)ri.nib16 << 4, ri.n_cols, 0u};
 }
 
-// Is region [st, en] of tile `tile` (read list [la, lb)) covered by the shortcut?  (uniform over the wavefront)
-__device__ __forceinline__ bool region_shortcut_ok(const CandCtx &cx, uint32_t g, uint32_t st, uint32_t en, uint32_t tile, uint32_t la, uint32_t lb) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t we = en + cx.ksize + 2;
-    if (cx.rec_pidx == nullptr || lb - la > 64 || lb == la || en - st + 1 > CLEAN_MAX_LEN || we >= cx.L) return false;
-    if ((st >> TILE_SHIFT) != tile || (we >> TILE_SHIFT) != tile) return false;
-    if (cx.tile_n[tile] > cx.bucket_cap) return false; // (spilled records: not in the bucket)
-    if (cx.tile_rd[la] != 0) return false;             // the contig itself leads every tile's read list ...
-    {
-        const ReadInfo r0 = cx.rinfo[0];                // ... and is paired with every region (its candidate is the first kept)
-        if (!(r0.pcount != 0 && r0.pj <= g && g - r0.pj < r0.pcount)) return false;
-    }
-    // the contig's letters at [st, en + k] are all A/C/G/T (nibble p at bits 4 (p & 7) of word p >> 3)
-    const uint32_t w0 = st >> 3, w1 = (en + cx.ksize) >> 3; // at most 13 words
-    bool bad = false;
-    if (w0 + lane <= w1) {
-        const uint32_t w = cx.refnib[w0 + lane];
-        uint32_t m = 0x44444444u;
-        if (w0 + lane == w0) m &= 0xFFFFFFFFu << (4 * (st & 7));
-        if (w0 + lane == w1) m &= 0xFFFFFFFFu >> (4 * (7 - ((en + cx.ksize) & 7)));
-        bad = (w & m) != 0;
-    }
-    return __ballot(bad) == 0;
-}
-
 // every pair of a region decoded by the region's wavefront, 64 reads per round (the path regions outside the shortcut take)
 __device__ __forceinline__ void region_measure_inline(const CandCtx &cx, uint32_t g, uint32_t st, uint32_t en, uint32_t la, uint32_t lb,
                                                       uint32_t *__restrict__ kept_read, uint32_t *__restrict__ kept_len,
@@ -546,8 +521,8 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
                                                         uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
     // blk_sum: per group of 4 regions (= one wavefront's), three arrays of n_mb entries: candidates, bytes, longest kept strings
-    __shared__ uint32_t s_reads[4][64];
-    __shared__ uint32_t s_dm[4][2];
+    __shared__ uint32_t s_reads[RM_REG][64];
+    __shared__ uint32_t s_dm[RM_REG][2];
     __shared__ uint32_t s_len[RM_REG][64];
     __shared__ uint32_t s_col[RM_REG][64];
     __shared__ uint32_t s_q[RM_REG * 64];
@@ -556,76 +531,131 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     const uint32_t n_mb = (n_reg + 3) / 4, mb = np2_bid * 4 + wv, g0 = mb * 4;
     if (threadIdx.x == 0) s_qn = 0;
     __syncthreads();
-    uint32_t rr[RM_RPW], state[RM_RPW]; // this lane's read per region; 0 no pair, 1 the contig's string, 2 queued
-    uint32_t sum_k = 0, sum_b = 0, sum_m = 0; // the group's totals (uniform)
+    // (A) The four regions of a wavefront go through every step TOGETHER: each step is a chain link of dependent loads
+    // (region -> tile -> read list -> read info / records), and a wavefront that walked the chain region by region spent
+    // its time waiting for one load at a time (measured: slower than decoding every pair).
+    uint32_t st[RM_RPW], en[RM_RPW], tile[RM_RPW], la[RM_RPW], lb[RM_RPW], tn[RM_RPW];
+    bool live[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const uint32_t g = g0 + h;
+        live[h] = g < n_reg;
+        const uint32_t gg = live[h] ? g : n_reg - 1;
+        st[h] = cx.lq_start[gg], en[h] = cx.lq_end[gg];
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        tile[h] = min(en[h] >> TILE_SHIFT, cx.n_tiles - 1);
+        la[h] = cx.tile_rd_off[tile[h]], lb[h] = cx.tile_rd_off[tile[h] + 1];
+        tn[h] = cx.rec_pidx ? cx.tile_n[tile[h]] : 0u;
+    }
+    const ReadInfo r0 = cx.rinfo[0]; // the contig itself: paired with every region it is to lend its string to
+    uint32_t rr[RM_RPW], lo[RM_RPW], hi[RM_RPW], refw[RM_RPW];
+    bool wok[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const uint32_t g = g0 + h, nlist = lb[h] - la[h], we = en[h] + cx.ksize + 2;
+        wok[h] = live[h] && cx.rec_pidx != nullptr && nlist != 0 && nlist <= 64 && en[h] - st[h] + 1 <= CLEAN_MAX_LEN && we < cx.L &&
+                 (st[h] >> TILE_SHIFT) == tile[h] && (we >> TILE_SHIFT) == tile[h] && tn[h] <= cx.bucket_cap &&
+                 r0.pcount != 0 && r0.pj <= g && g - r0.pj < r0.pcount;
+        rr[h] = (wok[h] && lane < nlist) ? cx.tile_rd[la[h] + lane] : 0xFFFFFFFFu;
+        // the contig's letters at [start, end + k]: A/C/G/T only (nibble p at bits 4 (p & 7) of word p >> 3; <= 13 words)
+        const uint32_t w0 = st[h] >> 3, w1 = (en[h] + cx.ksize) >> 3;
+        refw[h] = 0;
+        if (wok[h] && w0 + lane <= w1) {
+            uint32_t m = 0x44444444u;
+            if (lane == 0) m &= 0xFFFFFFFFu << (4 * (st[h] & 7));
+            if (w0 + lane == w1) m &= 0xFFFFFFFFu >> (4 * (7 - ((en[h] + cx.ksize) & 7)));
+            refw[h] = cx.refnib[w0 + lane] & m;
+        }
+        // the tile's records around [start, end + k + 2]: from the index of every 16th position
+        lo[h] = 0, hi[h] = 0;
+        if (wok[h] && tn[h]) {
+            const uint32_t tstart = tile[h] << TILE_SHIFT;
+            const uint32_t j0 = (st[h] - tstart) >> 4, j1 = ((we - tstart) >> 4) + 1;
+            lo[h] = cx.rec_pidx[(size_t)tile[h] * (TILE / 16) + j0];
+            hi[h] = j1 < TILE / 16 ? (uint32_t)cx.rec_pidx[(size_t)tile[h] * (TILE / 16) + j1] : tn[h];
+        }
+    }
+    uint32_t pjv[RM_RPW], pcv[RM_RPW], tev[RM_RPW], rpos[RM_RPW], rq[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        pjv[h] = 0, pcv[h] = 0, tev[h] = 0, rpos[h] = 0xFFFFFFFFu, rq[h] = 0;
+        if (rr[h] != 0xFFFFFFFFu) {
+            const ReadInfo *ri = cx.rinfo + rr[h];
+            const uint2 pp = *reinterpret_cast<const uint2 *>(&ri->pj);
+            pjv[h] = pp.x, pcv[h] = pp.y, tev[h] = ri->aln_t_e;
+        }
+        const uint32_t i = lo[h] + lane; // first 64 records of the window
+        if (i < hi[h]) {
+            const uint64_t a = (uint64_t)tile[h] * cx.bucket_cap + i;
+            rpos[h] = (uint32_t)(cx.rec_key[a] >> 32), rq[h] = cx.rec_read[a];
+        }
+    }
     uint32_t fastmask = 0;
 #pragma unroll
     for (uint32_t h = 0; h < RM_RPW; ++h) {
-        const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
-        rr[h] = 0, state[h] = 0;
-        if (g >= n_reg) continue;
-        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
-        const uint32_t tile = min(en >> TILE_SHIFT, cx.n_tiles - 1);
-        const uint32_t la = cx.tile_rd_off[tile], lb = cx.tile_rd_off[tile + 1];
-        if (!region_shortcut_ok(cx, g, st, en, tile, la, lb)) {
-            uint32_t kept, bytes, mx;
-            region_measure_inline(cx, g, st, en, la, lb, kept_read, kept_len, kept_col, kept, bytes, mx);
-            if (lane == 0) {
-                reg_ncand[g] = kept;
-                reg_bytes[g] = bytes;
-                reg_maxlen[g] = mx;
+        const uint32_t slot = wv * RM_RPW + h;
+        const bool fast = wok[h] && (uint32_t)__builtin_amdgcn_readfirstlane((int)rr[h]) == 0 && __ballot(refw[h] != 0) == 0;
+        if (fast) fastmask |= 1u << h;
+        s_reads[slot][lane] = rr[h];
+        if (lane < 2) s_dm[slot][lane] = 0;
+    }
+    wave_lds_sync();
+    auto mark = [&](uint32_t slot, uint32_t nlist, uint32_t pos, uint32_t q, uint32_t ws, uint32_t we) {
+        if (pos >= ws && pos <= we) { // the record's read in the region's (ascending) read list
+            uint32_t x = 0, y = nlist;
+            while (x < y) {
+                const uint32_t m = (x + y) >> 1;
+                if (s_reads[slot][m] < q) x = m + 1; else y = m;
             }
-            sum_k += kept, sum_b += bytes, sum_m += mx;
-            continue;
+            if (x < nlist && s_reads[slot][x] == q) atomicOr(&s_dm[slot][x >> 5], 1u << (x & 31));
         }
-        fastmask |= 1u << h;
-        const uint32_t nlist = lb - la;
-        uint32_t r = 0xFFFFFFFFu;
-        bool paired = false, ends_inside = false;
-        if (lane < nlist) {
-            r = cx.tile_rd[la + lane];
-            const ReadInfo ri = cx.rinfo[r];
-            paired = ri.pcount != 0 && ri.pj <= g && g - ri.pj < ri.pcount;
-            ends_inside = ri.aln_t_e < en + cx.ksize; // (the first k-mer needs the columns up to start + k - 1)
-        }
-        rr[h] = r;
-        s_reads[wv][lane] = r;
-        if (lane < 2) s_dm[wv][lane] = 0;
-        wave_lds_sync();
-        // records of the tile at positions [st, en + k + 2]
-        const uint32_t tstart = tile << TILE_SHIFT, ws = st, we = en + cx.ksize + 2;
-        const uint32_t tn = cx.tile_n[tile];
-        uint32_t lo = 0, hi = 0;
-        if (tn) {
-            const uint32_t j0 = (ws - tstart) >> 4, j1 = ((we - tstart) >> 4) + 1;
-            lo = cx.rec_pidx[(size_t)tile * (TILE / 16) + j0];
-            hi = j1 < TILE / 16 ? (uint32_t)cx.rec_pidx[(size_t)tile * (TILE / 16) + j1] : tn;
-        }
-        const uint64_t a = (uint64_t)tile * cx.bucket_cap;
-        for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+    };
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        if (!((fastmask >> h) & 1u)) continue;
+        const uint32_t slot = wv * RM_RPW + h, nlist = lb[h] - la[h], ws = st[h], we = en[h] + cx.ksize + 2;
+        mark(slot, nlist, rpos[h], rq[h], ws, we);
+        for (uint32_t c0 = lo[h] + 64; c0 < hi[h]; c0 += 64) { // (a window of more than 64 records)
             const uint32_t i = c0 + lane;
-            if (i < hi) {
-                const uint32_t pos = (uint32_t)(cx.rec_key[a + i] >> 32), q = cx.rec_read[a + i];
-                if (pos >= ws && pos <= we) {
-                    uint32_t x = 0, y = nlist; // first list entry >= q
-                    while (x < y) {
-                        const uint32_t m = (x + y) >> 1;
-                        if (s_reads[wv][m] < q) x = m + 1; else y = m;
-                    }
-                    if (x < nlist && s_reads[wv][x] == q) atomicOr(&s_dm[wv][x >> 5], 1u << (x & 31));
-                }
+            if (i < hi[h]) {
+                const uint64_t a = (uint64_t)tile[h] * cx.bucket_cap + i;
+                mark(slot, nlist, (uint32_t)(cx.rec_key[a] >> 32), cx.rec_read[a], ws, we);
             }
         }
-        wave_lds_sync();
-        const bool marked = (s_dm[wv][lane >> 5] >> (lane & 31)) & 1u;
-        const uint32_t stt = !paired ? 0u : ((marked || ends_inside) && r != 0) ? 2u : 1u; // (the contig has no records)
+    }
+    wave_lds_sync();
+    uint32_t state[RM_RPW]; // 0 no pair, 1 the contig's string, 2 queued
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        state[h] = 0;
+        if (!((fastmask >> h) & 1u)) continue;
+        const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
+        const bool paired = rr[h] != 0xFFFFFFFFu && pcv[h] != 0 && pjv[h] <= g && g - pjv[h] < pcv[h];
+        const bool marked = (s_dm[slot][lane >> 5] >> (lane & 31)) & 1u;
+        const bool ends_inside = tev[h] < en[h] + cx.ksize; // (the first k-mer needs the columns up to start + k - 1)
+        const uint32_t stt = !paired ? 0u : ((marked || ends_inside) && rr[h] != 0) ? 2u : 1u; // (the contig has no records)
         state[h] = stt;
         const uint64_t dq = __ballot(stt == 2u);
         uint32_t qb = 0;
         if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
         qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
         if (stt == 2u) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
-        wave_lds_sync(); // (s_reads / s_dm are reused by the next region)
+    }
+    uint32_t sum_k = 0, sum_b = 0, sum_m = 0; // the group's totals (uniform)
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) { // regions outside the shortcut: every pair decoded here
+        if (!live[h] || ((fastmask >> h) & 1u)) continue;
+        const uint32_t g = g0 + h;
+        uint32_t kept, bytes, mx;
+        region_measure_inline(cx, g, st[h], en[h], la[h], lb[h], kept_read, kept_len, kept_col, kept, bytes, mx);
+        if (lane == 0) {
+            reg_ncand[g] = kept;
+            reg_bytes[g] = bytes;
+            reg_maxlen[g] = mx;
+        }
+        sum_k += kept, sum_b += bytes, sum_m += mx;
     }
     __syncthreads();
     // (B) the pairs that need their read, one per thread
@@ -633,12 +663,10 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     for (uint32_t e = threadIdx.x; e < nq; e += 256) {
         const uint32_t w = s_q[e], slot = w >> 6, ln = w & 63;
         const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * 4 + slot % RM_RPW;
-        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
-        const uint32_t tile = min(en >> TILE_SHIFT, cx.n_tiles - 1);
-        const uint32_t r = cx.tile_rd[cx.tile_rd_off[tile] + ln];
+        const uint32_t r = s_reads[slot][ln];
         const ReadInfo ri = cx.rinfo[r];
         uint32_t col = 0;
-        const uint32_t len = cand_measure(cx, r, rinfo_read(ri), ri.ck_off, st, en, col);
+        const uint32_t len = cand_measure(cx, r, rinfo_read(ri), ri.ck_off, cx.lq_start[g], cx.lq_end[g], col);
         s_len[slot][ln] = len;
         s_col[slot][ln] = col;
     }
@@ -648,9 +676,8 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     for (uint32_t h = 0; h < RM_RPW; ++h) {
         if (!((fastmask >> h) & 1u)) continue;
         const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
-        const uint32_t st = cx.lq_start[g], en = cx.lq_end[g];
         uint32_t len = 0, col = CAND_CLEAN;
-        if (state[h] == 1u) len = en - st + 1;
+        if (state[h] == 1u) len = en[h] - st[h] + 1;
         else if (state[h] == 2u) len = s_len[slot][lane], col = s_col[slot][lane];
         const uint64_t ne = __ballot(len > 0);
         const uint32_t before = lanes_below(ne);
@@ -779,53 +806,62 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
     uint32_t clean_h = 0;        // regions of this wavefront with candidates that are the contig's string (uniform)
     uint32_t my_len[RM_RPW], my_so[RM_RPW], my_ci[RM_RPW];
     bool my_clean[RM_RPW];
+    // (the four regions' loads level by level, not region after region: see k_region_measure)
+    uint32_t n[RM_RPW], rb[RM_RPW], st[RM_RPW], ln0[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const uint32_t g = g0 + h;
+        n[h] = 0, rb[h] = 0, st[h] = 0, ln0[h] = 0;
+        if (g < n_reg) n[h] = reg_ncand[g], rb[h] = reg_bytes[g], st[h] = cx.lq_start[g], ln0[h] = cx.lq_end[g] - st[h] + 1;
+    }
+    uint32_t len[RM_RPW], col[RM_RPW], rd_[RM_RPW], refc[RM_RPW];
+#pragma unroll
+    for (uint32_t h = 0; h < RM_RPW; ++h) {
+        const size_t ks = (size_t)(g0 + h) * LQSEQ_MAX_CAN_COUNT + lane;
+        const bool act = lane < n[h];
+        len[h] = act ? kept_len[ks] : 0u;
+        col[h] = act ? kept_col[ks] : 0u;
+        rd_[h] = act ? kept_read[ks] : 0u;
+        const uint32_t p = st[h] + lane; // (used only by regions with clean candidates: lane < ln0 <= 64 there)
+        refc[h] = (n[h] && lane < ln0[h] && ln0[h] <= CLEAN_MAX_LEN) ? cx.refnib[p >> 3] >> (4 * (p & 7)) : 0u;
+    }
 #pragma unroll
     for (uint32_t h = 0; h < RM_RPW; ++h) {
         const uint32_t g = g0 + h, slot = wv * RM_RPW + h;
         my_len[h] = 0, my_so[h] = 0, my_ci[h] = 0, my_clean[h] = false;
         if (g >= n_reg) continue;
         if (g == n_reg - 1 && lane == 0 && cand_off[n_reg] < cand_cap) cand_seq_off[cand_off[n_reg]] = reg_soff[n_reg];
-        const uint32_t n = reg_ncand[g];
         if (lane == 0) {
             cand_off[g] = oc;
             reg_soff[g] = ob;
             s_oc[slot] = oc;
         }
-        const bool act = lane < n;
-        const size_t ks = (size_t)g * LQSEQ_MAX_CAN_COUNT + lane;
-        const uint32_t len = act ? kept_len[ks] : 0u;
-        const uint32_t col = act ? kept_col[ks] : 0u;
-        const uint32_t so = ob + wave_excl(len);
+        const bool act = lane < n[h];
+        const uint32_t so = ob + wave_excl(len[h]);
         const uint32_t ci = oc + lane;
-        const bool ok = act && ci < cand_cap && (uint64_t)so + len <= seq_cap;
-        uint32_t r = 0;
+        const bool ok = act && ci < cand_cap && (uint64_t)so + len[h] <= seq_cap;
         if (ok) {
-            r = kept_read[ks];
-            cand_order[ci] = r;
+            cand_order[ci] = rd_[h];
             cand_seq_off[ci] = so;
         }
-        const bool clean = ok && col == CAND_CLEAN;
+        const bool clean = ok && col[h] == CAND_CLEAN;
         const uint64_t cm = __ballot(clean);
         // read 0's kept_col says "clean" too (its string is the contig's by definition): it is decoded for the k-mer
-        const bool queued = ok && (!clean || (lane == 0 && r == 0));
-        my_len[h] = len, my_so[h] = so, my_ci[h] = ci, my_clean[h] = clean && !queued;
+        const bool queued = ok && (!clean || (lane == 0 && rd_[h] == 0));
+        my_len[h] = len[h], my_so[h] = so, my_ci[h] = ci, my_clean[h] = clean && !queued;
         s_so[slot][lane] = so;
         if (cm) {
             clean_h |= 1u << h;
             // the contig's bases at [start, end]: one per lane, straight from the nibble-packed contig (all A/C/G/T here)
-            const uint32_t st = cx.lq_start[g], ln0 = cx.lq_end[g] - st + 1;
-            if (lane < ln0) {
-                const uint32_t p = st + lane;
-                s_str[slot][lane] = (uint8_t)((0x54474341u >> (8 * ((cx.refnib[p >> 3] >> (4 * (p & 7))) & 3))) & 0xFFu);
-            }
+            if (lane < ln0[h]) s_str[slot][lane] = (uint8_t)((0x54474341u >> (8 * (refc[h] & 3))) & 0xFFu);
         }
         const uint64_t dq = __ballot(queued);
         uint32_t qb = 0;
         if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
         qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
         if (queued) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
-        oc += n;
-        ob += reg_bytes[g];
+        oc += n[h];
+        ob += rb[h];
     }
     __syncthreads();
     const uint32_t nq = s_qn;

@@ -57,6 +57,9 @@ def lib():
         L.np2s_bam_records.restype = C.c_uint32
         L.np2s_bam_records.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.np2s_bam_records_at.restype = C.c_uint32
+        L.np2s_bam_records_at.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.np2s_free_buf.argtypes = [C.c_void_p]
         L.np2s_pack_alignment.restype = C.c_uint64
         L.np2s_pack_alignment.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
@@ -94,11 +97,12 @@ class Synth:
         ptr = lib().np2s_hap(self._h, 1, C.byref(n32))
         self.hap2 = _copy(ptr, n32.value, np.uint8).tobytes()
 
-    def bam_records(self, tid=0):
+    def bam_records(self, tid=0, pos0=0, name0=0):
         """The reads as encoded BAM alignment records (see np2s_bam_records): -> (blob bytes, record offsets [n + 1],
-        positions [n], reference lengths [n]) for bamio.write_bam_raw."""
+        positions [n], reference lengths [n]) for bamio.write_bam_raw.  pos0 / name0: position and record-name offset of a
+        generated piece inside a contig laid out of several (concat_pileups)."""
         b, o, p, r = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        n = lib().np2s_bam_records(self._h, tid, C.byref(b), C.byref(o), C.byref(p), C.byref(r))
+        n = lib().np2s_bam_records_at(self._h, tid, pos0, name0, C.byref(b), C.byref(o), C.byref(p), C.byref(r))
         off = _copy(o.value, (n + 1) * 8, np.uint64)
         out = (bytes((C.c_uint8 * int(off[n])).from_address(b.value)) if n else b"", off,
                _copy(p.value, n * 4, np.int32), _copy(r.value, n * 4, np.uint32))

@@ -479,7 +479,14 @@ const uint8_t *np2s_nibbles(void *h, uint64_t *nbytes) {
 // SEQ, missing qualities, MAPQ 60, alternating strand flag), coordinate-sorted and concatenated; rec_off[i] .. rec_off[i + 1] delimits record
 // i, pos[i] / ref_len[i] are what an index needs.  Test / bench infrastructure: whole-assembly BAM files without a
 // per-column Python loop.  Returns the number of records; buffers are malloc'ed (np2s_free_buf).
+// pos0: added to every position (a contig laid out of several generated pieces: concat_pileups); name0: number of the first record's name
+uint32_t np2s_bam_records_at(void *h, int32_t tid, uint32_t pos0, uint32_t name0, uint8_t **blob, uint64_t **rec_off, int32_t **pos,
+                             uint32_t **ref_len);
 uint32_t np2s_bam_records(void *h, int32_t tid, uint8_t **blob, uint64_t **rec_off, int32_t **pos, uint32_t **ref_len) {
+    return np2s_bam_records_at(h, tid, 0, 0, blob, rec_off, pos, ref_len);
+}
+uint32_t np2s_bam_records_at(void *h, int32_t tid, uint32_t pos0, uint32_t name0, uint8_t **blob, uint64_t **rec_off, int32_t **pos,
+                             uint32_t **ref_len) {
     Synth *S = (Synth *)h;
     const uint32_t n = S->reads.size() > 1 ? (uint32_t)S->reads.size() - 1 : 0;
     std::vector<uint8_t> out;
@@ -521,18 +528,18 @@ uint32_t np2s_bam_records(void *h, int32_t tid, uint8_t **blob, uint64_t **rec_o
             else cig.push_back(16 | op);
         }
         char name[24];
-        const int ln = snprintf(name, sizeof name, "r%u", i) + 1;
+        const int ln = snprintf(name, sizeof name, "r%u", name0 + i) + 1;
         off[i] = out.size();
-        ps[i] = (int32_t)rd.aln_t_s;
+        ps[i] = (int32_t)(pos0 + rd.aln_t_s);
         rl[i] = rlen;
         const uint32_t l_seq = (uint32_t)seq.size();
         const uint32_t body = 32 + (uint32_t)ln + 4 * (uint32_t)cig.size() + (l_seq + 1) / 2 + l_seq;
         put32(out, body);
         put32(out, (uint32_t)tid);
-        put32(out, rd.aln_t_s);
+        put32(out, pos0 + rd.aln_t_s);
         out.push_back((uint8_t)ln);
         out.push_back(60);
-        const uint16_t bin = reg2bin(rd.aln_t_s, (int64_t)rd.aln_t_s + (rlen ? rlen : 1));
+        const uint16_t bin = reg2bin((int64_t)pos0 + rd.aln_t_s, (int64_t)pos0 + rd.aln_t_s + (rlen ? rlen : 1));
         out.push_back((uint8_t)bin), out.push_back((uint8_t)(bin >> 8));
         out.push_back((uint8_t)cig.size()), out.push_back((uint8_t)(cig.size() >> 8));
         const uint16_t flag = (i & 1) ? 16 : 0;

@@ -1,9 +1,11 @@
 """The hand-derived known answers of tests/test_oracle_pinning.py (Cartesian recheck of chained regions, the seed rules
 of fill_seed_lqseqs), asked of the HIP path through the C ABI: the same pileups, the same expectations written out in
 those tests — not a comparison with the oracle."""
+import numpy as np
 import pytest
 
 import test_oracle_pinning as tp
+import test_oracle_pinning2 as tp2
 from nextpolish2_amd import Polisher
 
 pytestmark = pytest.mark.gpu
@@ -15,3 +17,30 @@ pytestmark = pytest.mark.gpu
 def test_hand_derived_final_pass_cases_on_the_hip_path(monkeypatch, case):
     monkeypatch.setattr(tp.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))
     case()
+
+
+@pytest.mark.parametrize("case", [tp2.test_lq_region_pad_extend_and_delayed_close,
+                                  tp2.test_decode_limit_invalid_kmer_and_columns_before_the_start,
+                                  tp2.test_homopolymer_length_difference_is_not_a_heterozygous_marker,
+                                  tp2.test_three_disagreements_override_the_summed_pair_weight])
+def test_second_set_of_hand_derived_cases_on_the_hip_path(monkeypatch, case):
+    """LQ close / pad / extend, decode limit + start filter, is_valid_snp, dif <= -3: the expectations written out in
+    tests/test_oracle_pinning2.py, asked of the HIP path (traces through np2_trace_get)."""
+    monkeypatch.setattr(tp2.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))
+    case()
+
+
+def test_clip_filter_first_range_on_the_product_front_end():
+    """filter_alignseqs_by_clip's first range (main.rs:531-574) through np2_contig_from_records: the hand-derived flags of
+    tests/test_oracle_pinning2.py::test_clip_filter_first_range_is_the_whole_contig."""
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import records_to_arrays
+    ref, recs = tp2.clip_case()
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pol = Polisher([])
+    c = np2io.contig_from_records(pol, ref.encode(), arr, cig, seq4, np2io.FrontOpts())
+    got = np2io.export_contig(pol, c, np.frombuffer(ref.encode(), dtype=np.uint8))
+    L = len(ref)
+    assert got.reads["aln_t_s"].tolist() == [0, 10, 400, 1000, 3000, L - 1620]
+    assert got.reads["aln_t_e"].tolist() == [L - 1, 1609, 1999, 2599, 4599, L - 21]
+    assert (got.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 1, 0]
