@@ -690,6 +690,7 @@ def main():
                      "units_per_launch_bp": int(total_len / max(1, diff_launches))},
         "flush_ms": {"per_group_totals_host_issue_wait": [[round(sum(f[j] for f in fl), 3) for j in range(3)] for fl in flush_log],
                      "flushes_per_step": [len(fl) for fl in flush_log],
+                     "per_flush_host_issue_wait_group0": flush_log[0] if flush_log else None,
                      "batch_call_ms_mean": round(float(call_ms), 3) if not single else None,
                      "call_breakdown_ms_per_group": None if single else call_breakdown},
         "host_cpu": {"cpu_seconds_per_wall_second": round(cpu_dt / dt, 2),

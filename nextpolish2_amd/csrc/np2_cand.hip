@@ -464,7 +464,11 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 // A region the shortcut does not cover (its window leaves its tile, the contig has a non-ACGT letter there, more than
 // 64 reads over the tile, no record index) decodes every pair the old way.
 // ------------------------------------------------------------------------------------------------------
-static constexpr uint32_t RM_RPW = 4;                // regions per wavefront
+#ifndef NP2_RM_RPW
+#define NP2_RM_RPW 4
+#endif
+static constexpr uint32_t RM_RPW = NP2_RM_RPW;       // regions per wavefront (a multiple of 4: the offsets go by groups of 4 regions)
+static_assert(RM_RPW % 4 == 0 && RM_RPW <= 16, "regions per wavefront");
 static constexpr uint32_t RM_REG = 4 * RM_RPW;       // regions per 256-thread block
 static constexpr uint32_t CAND_CLEAN = 0xFFFFFFFFu;  // kept_col of a candidate that is the contig's own string
 static constexpr uint32_t CLEAN_MAX_LEN = 64;
@@ -525,12 +529,10 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     __shared__ uint32_t s_dm[RM_REG][2];
     __shared__ uint32_t s_len[RM_REG][64];
     __shared__ uint32_t s_col[RM_REG][64];
-    __shared__ uint32_t s_q[RM_REG * 64];
-    __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_q[4][RM_RPW * 64]; // one queue per wavefront: the wavefronts of a block never wait for each other
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t n_mb = (n_reg + 3) / 4, mb = np2_bid * 4 + wv, g0 = mb * 4;
-    if (threadIdx.x == 0) s_qn = 0;
-    __syncthreads();
+    const uint32_t n_mb = (n_reg + 3) / 4, g0 = (np2_bid * 4 + wv) * RM_RPW, mb0 = g0 / 4;
+    uint32_t nq = 0; // (uniform)
     // (A) The four regions of a wavefront go through every step TOGETHER: each step is a chain link of dependent loads
     // (region -> tile -> read list -> read info / records), and a wavefront that walked the chain region by region spent
     // its time waiting for one load at a time (measured: slower than decoding every pair).
@@ -638,12 +640,10 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
         const uint32_t stt = !paired ? 0u : ((marked || ends_inside) && rr[h] != 0) ? 2u : 1u; // (the contig has no records)
         state[h] = stt;
         const uint64_t dq = __ballot(stt == 2u);
-        uint32_t qb = 0;
-        if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
-        qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-        if (stt == 2u) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
+        if (stt == 2u) s_q[wv][nq + lanes_below(dq)] = (slot << 6) | lane;
+        nq += (uint32_t)__builtin_popcountll(dq);
     }
-    uint32_t sum_k = 0, sum_b = 0, sum_m = 0; // the group's totals (uniform)
+    uint32_t sum_k[RM_RPW / 4] = {}, sum_b[RM_RPW / 4] = {}, sum_m[RM_RPW / 4] = {}; // totals of the groups of 4 regions (uniform)
 #pragma unroll
     for (uint32_t h = 0; h < RM_RPW; ++h) { // regions outside the shortcut: every pair decoded here
         if (!live[h] || ((fastmask >> h) & 1u)) continue;
@@ -655,14 +655,13 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
             reg_bytes[g] = bytes;
             reg_maxlen[g] = mx;
         }
-        sum_k += kept, sum_b += bytes, sum_m += mx;
+        sum_k[h / 4] += kept, sum_b[h / 4] += bytes, sum_m[h / 4] += mx;
     }
-    __syncthreads();
-    // (B) the pairs that need their read, one per thread
-    const uint32_t nq = s_qn;
-    for (uint32_t e = threadIdx.x; e < nq; e += 256) {
-        const uint32_t w = s_q[e], slot = w >> 6, ln = w & 63;
-        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * 4 + slot % RM_RPW;
+    wave_lds_sync();
+    // (B) the pairs that need their read, one per lane
+    for (uint32_t e = lane; e < nq; e += 64) {
+        const uint32_t w = s_q[wv][e], slot = w >> 6, ln = w & 63;
+        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * RM_RPW + slot % RM_RPW;
         const uint32_t r = s_reads[slot][ln];
         const ReadInfo ri = cx.rinfo[r];
         uint32_t col = 0;
@@ -670,7 +669,7 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
         s_len[slot][ln] = len;
         s_col[slot][ln] = col;
     }
-    __syncthreads();
+    wave_lds_sync();
     // (C) rank and keep
 #pragma unroll
     for (uint32_t h = 0; h < RM_RPW; ++h) {
@@ -697,13 +696,15 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
             reg_bytes[g] = bytes;
             reg_maxlen[g] = mx; // the longest string a splice can put in place of this region
         }
-        sum_k += kept, sum_b += bytes, sum_m += mx;
+        sum_k[h / 4] += kept, sum_b[h / 4] += bytes, sum_m[h / 4] += mx;
     }
-    if (lane == 0 && mb < n_mb) {
-        blk_sum[mb] = sum_k;
-        blk_sum[n_mb + mb] = sum_b;
-        blk_sum[2 * n_mb + mb] = sum_m;
-    }
+#pragma unroll
+    for (uint32_t q = 0; q < RM_RPW / 4; ++q)
+        if (lane == 0 && mb0 + q < n_mb) {
+            blk_sum[mb0 + q] = sum_k[q];
+            blk_sum[n_mb + mb0 + q] = sum_b[q];
+            blk_sum[2 * n_mb + mb0 + q] = sum_m[q];
+        }
 }
 
 // candidate / sequence offsets of every region; totals -> *n_cand, *n_bytes and the closing cand_seq_off entry
@@ -795,14 +796,12 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
     __shared__ uint64_t s_km[RM_REG];
     __shared__ uint32_t s_so[RM_REG][64];
     __shared__ uint32_t s_oc[RM_REG];
-    __shared__ uint32_t s_q[RM_REG * 64];
-    __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_q[4][RM_RPW * 64]; // one queue per wavefront
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t mb = np2_bid * 4 + wv, g0 = mb * 4;
-    if (threadIdx.x == 0) s_qn = 0;
-    __syncthreads();
-    uint32_t oc = 0, ob = 0;
-    if (g0 < n_reg) oc = blk_coff[mb], ob = blk_soff[mb];
+    const uint32_t g0 = (np2_bid * 4 + wv) * RM_RPW, mb0 = g0 / 4;
+    uint32_t nq = 0; // (uniform)
+    uint32_t oc = 0, ob = 0; // (running over the wavefront's regions: the groups of 4 follow each other)
+    if (g0 < n_reg) oc = blk_coff[mb0], ob = blk_soff[mb0];
     uint32_t clean_h = 0;        // regions of this wavefront with candidates that are the contig's string (uniform)
     uint32_t my_len[RM_RPW], my_so[RM_RPW], my_ci[RM_RPW];
     bool my_clean[RM_RPW];
@@ -856,18 +855,15 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
             if (lane < ln0[h]) s_str[slot][lane] = (uint8_t)((0x54474341u >> (8 * (refc[h] & 3))) & 0xFFu);
         }
         const uint64_t dq = __ballot(queued);
-        uint32_t qb = 0;
-        if (lane == 0 && dq) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(dq));
-        qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-        if (queued) s_q[qb + lanes_below(dq)] = (slot << 6) | lane;
+        if (queued) s_q[wv][nq + lanes_below(dq)] = (slot << 6) | lane;
+        nq += (uint32_t)__builtin_popcountll(dq);
         oc += n[h];
         ob += rb[h];
     }
-    __syncthreads();
-    const uint32_t nq = s_qn;
-    for (uint32_t e = threadIdx.x; e < nq; e += 256) {
-        const uint32_t w = s_q[e], slot = w >> 6, li = w & 63;
-        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * 4 + slot % RM_RPW;
+    wave_lds_sync();
+    for (uint32_t e = lane; e < nq; e += 64) {
+        const uint32_t w = s_q[wv][e], slot = w >> 6, li = w & 63;
+        const uint32_t g = (np2_bid * 4 + slot / RM_RPW) * RM_RPW + slot % RM_RPW;
         const size_t ks = (size_t)g * LQSEQ_MAX_CAN_COUNT + li;
         const uint32_t r = kept_read[ks], len = kept_len[ks];
         uint32_t col = kept_col[ks];
@@ -881,7 +877,7 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
         cand_kmer[ci] = km;
         if (li == 0 && r == 0) s_km[slot] = km;
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (uint32_t h = 0; h < RM_RPW; ++h) {
         if (!((clean_h >> h) & 1u)) continue;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <exception>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -198,6 +199,9 @@ template <class T> struct DevBuf {
     void release() {
         if (p) {
             if (cached) {
+                // (normally the owner has finished its device work; when an exception unwinds through it, a transfer or a
+                // kernel of its stream may still be in flight and the next taker of the block would be corrupted)
+                if (std::uncaught_exceptions() > 0 && dev_sync_depth() == 0) (void)hipDeviceSynchronize();
                 dev_cache().put(p, cache_bytes);
             } else if (Recorder *r = tl_recorder()) {
                 // recorded, not yet issued commands may name it: released after the next flush

@@ -1230,7 +1230,10 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         explicit PinnedTmp(size_t bytes) : p(pinned_pool().get(std::max<size_t>(bytes, 64))) {
             if (!p) throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
         }
-        ~PinnedTmp() { pinned_pool().put(p); }
+        ~PinnedTmp() {
+            if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize(); // (an upload out of it may still be in flight)
+            pinned_pool().put(p);
+        }
     };
     uint64_t total_chunks = 0;
     for (uint32_t r = 1; r < n_reads; ++r)
@@ -1505,9 +1508,11 @@ int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
         HIPCHK(hipMemcpyAsync(c->nib.p, nibbles, nib_bytes, hipMemcpyHostToDevice, cx->stream));
         finish_contig(cx, c, reads, n_reads, L, nib_bytes);
     } catch (const Np2Error &e) {
+        (void)hipStreamSynchronize(cx->stream); // (the nibble upload may still be in flight: the blocks go back to the cache)
         delete c;
         return fail(cx, e);
     } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
         delete c;
         return fail(cx, Np2Error(NP2_E_NOMEM, std::string("unexpected exception: ") + ex.what()));
     }

@@ -173,27 +173,34 @@ def test_full_size_chr1_single_gpu_and_two_intervals():
     assert np.array_equal(b1, b3) and np.array_equal(p1, p3)
 
 
-def _edits(got, want, look=48):
-    """Number of local edits (substitution, insertion or deletion of up to 8 bases; anything else counts once per `look`
-    bases) that turn `want` into `got`, found by walking both from the left and re-synchronising after every difference;
-    -1 if they never fall back into step."""
+def _edits(got, want, look=48, reach=16, max_edits=1000):
+    """Number of local differences (any mix of substituted, inserted and deleted bases within `reach` positions) between
+    `got` and `want`, found by walking both from the left and re-synchronising after every difference on `look` equal
+    bases; -1 if they fall out of step or differ in more than max_edits places."""
     i = j = n_edits = 0
+    block = 1 << 20
+    cands = sorted(((di, dj) for di in range(reach + 1) for dj in range(reach + 1) if di + dj), key=lambda x: (x[0] + x[1], abs(x[0] - x[1])))
     while True:
-        n = min(len(got) - i, len(want) - j)
-        d = np.flatnonzero(got[i:i + n] != want[j:j + n])
-        if len(d) == 0:
-            return n_edits + (1 if (len(got) - i) != (len(want) - j) else 0)
-        k = int(d[0])
-        for di, dj in [(1, 1)] + [x for q in range(1, 9) for x in ((q, 0), (0, q))] + [(2, 2), (3, 3)]:
+        k = None
+        while k is None:  # first difference at or after (i, j), a block at a time
+            n = min(len(got) - i, len(want) - j, block)
+            if n <= 0:
+                return n_edits + (1 if (len(got) - i) != (len(want) - j) else 0)
+            d = np.flatnonzero(got[i:i + n] != want[j:j + n])
+            if len(d):
+                k = int(d[0])
+            else:
+                i, j = i + n, j + n
+        for di, dj in cands:
             a, b = got[i + k + di:i + k + di + look], want[j + k + dj:j + k + dj + look]
             m = min(len(a), len(b))
             if m == 0 or np.array_equal(a[:m], b[:m]):
                 i, j, n_edits = i + k + di, j + k + dj, n_edits + 1
                 break
-        else:  # a longer or a compound difference: count it once and look for common ground a little further on
-            i, j, n_edits = i + k + look, j + k + look, n_edits + 1
-            if n_edits > 100000:
-                return -1
+        else:
+            return -1
+        if n_edits > max_edits:
+            return -1
 
 
 def test_full_size_chr1_diploid_whole_two_and_four_intervals(capsys):
