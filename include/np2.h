@@ -242,6 +242,10 @@ typedef struct np2_shard_piece {
 int np2_shard_final_device(np2_shard_run_t *run, np2_shard_piece_t *out);
 int np2_shard_fetch(np2_shard_run_t *run, uint8_t *dst_bases, uint32_t *dst_pos /* NULL: bases only; contig coordinates */);
 void *np2_alloc_pinned(uint64_t bytes); /* page-locked host memory from the result pool; np2_free releases it */
+/* The library keeps released device blocks (a twelfth of the device's memory at most, NP2_DEV_CACHE_GB) for its next
+ * allocations instead of returning them to the driver; a caller about to allocate device memory by other means (torch,
+ * RCCL buffers) hands the idle ones back with this.  Blocks in use are not touched. */
+void np2_trim_device_cache(void);
 
 /* Host-only test hook: key iteration order of the SwissTable order model behind np2_phase_vote after a script of
  * operations (0 insert, 1 remove, 2 entry().or_insert) — pinned by hand-traced vectors in tests/test_swiss_vectors.py. */

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
-    "np2_shard_final_device", "np2_shard_fetch", "np2_alloc_pinned",
+    "np2_shard_final_device", "np2_shard_fetch", "np2_alloc_pinned", "np2_trim_device_cache",
     "np2_shard_end", "np2_swiss_order", "np2_batch_set_timing", "np2_batch_set_priority", "np2_batch_last_diff_ms", "np2_batch_stats", "np2_batch_last_call_ms",
 ]
 
@@ -118,6 +118,8 @@ def _lib_locked():
         L.np2_shard_fetch.argtypes = [vp, vp, vp]
         L.np2_alloc_pinned.argtypes = [u64]
         L.np2_alloc_pinned.restype = vp
+        L.np2_trim_device_cache.argtypes = []
+        L.np2_trim_device_cache.restype = None
         L.np2_shard_end.argtypes = [vp]
         L.np2_shard_end.restype = None
         L.np2_swiss_order.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]

@@ -136,7 +136,7 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
     import torch
     import torch.distributed as dist
 
-    from .dist import ShardMismatch, all_gather_sequences, assign_contigs, polish_sharded_bam
+    from .dist import ShardMismatch, all_gather_arrays, all_gather_sequences, assign_contigs, polish_sharded_bam
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = a.dist_backend or "nccl"
     dev_idx = a.device % max(1, torch.cuda.device_count())
@@ -161,14 +161,22 @@ def _main_distributed(a, argv, t0, out, yaks, opts, fopts):
             # all): the shards disagree, a splice cursor got stuck inside one (NP2_E_UNSUPPORTED), or one failed for a
             # reason of its own -> rank 0 polishes the contig unsharded (and reports a genuine error itself)
             print(f"[WARN] {name}: {e}; polishing it unsharded", file=sys.stderr)
-            b = None
+            b, fb_err = None, None
             if rank == 0:
-                c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
                 try:
-                    b, p = pol.polish_resident(c, opts, want_pos=a.out_pos)
-                    span = (int(p[0]), int(p[-1])) if a.out_pos else (p[0], p[1])
-                finally:
-                    c.free()
+                    c = np2io.contig_from_bam(pol, bam, name, seq, fopts)
+                    try:
+                        b, p = pol.polish_resident(c, opts, want_pos=a.out_pos)
+                        span = (int(p[0]), int(p[-1])) if a.out_pos else (p[0], p[1])
+                    finally:
+                        c.free()
+                except Exception as e2:  # noqa: BLE001 — the other ranks wait below: they must learn of it
+                    fb_err = e2
+            # a genuine error on rank 0 ends the run on every rank (nobody is left waiting in the next contig's collective)
+            verdict = all_gather_arrays(np.array([0 if fb_err is None else 1], dtype=np.uint8), device=xdev)
+            if int(verdict[0][0]):
+                dist.destroy_process_group()
+                raise SystemExit(f"Error: {name}: {fb_err if fb_err is not None else 'the unsharded fallback failed on rank 0'}")
         if rank == 0:
             records[i] = _record(a, name, np.asarray(b).tobytes(), int(span[0]), int(span[1]), p if a.out_pos else None)
     # 2. the other contigs: whole, one rank each, longest first
@@ -209,6 +217,11 @@ def main(argv=None):
     a = build_parser().parse_args(argv)
     if a.model.lower() not in ("ref", "len"):
         raise SystemExit("error: invalid value for --model (ref|len)")
+    for y in a.yak:  # (before the output file exists: a broken dump must not leave a partial output behind)
+        try:
+            np2io.check_yak_header(y)
+        except ValueError as e:
+            raise SystemExit(f"Error: {e}")
     out = sys.stdout.buffer
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
     if distributed:
@@ -306,11 +319,12 @@ def main(argv=None):
 
     try:
         with ThreadPoolExecutor(max_workers=n_front) as fpool, ThreadPoolExecutor(max_workers=n_workers) as pool:
-            pending = []  # records in input order: bytes or futures
+            pending, pending_len = [], []  # records in input order: bytes or futures; the contigs' lengths
 
             def drain(keep):
                 while len(pending) > keep:
                     rec = pending.pop(0)
+                    pending_len.pop(0)
                     out.write(rec if isinstance(rec, bytes) else rec.result())
 
             for name, seq in np2io.read_fasta(a.fa):
@@ -322,11 +336,18 @@ def main(argv=None):
                         pending.append(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
                     else:
                         pending.append(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
+                    pending_len.append(len(seq))
                 else:
                     if not base_future:  # the first contig to polish: tables into HBM next to its front end
                         base_future.append(yak_pool.submit(build_base))
                     pending.append(pool.submit(polish, name, fpool.submit(front, name, seq)))
-                drain(2 * n_workers + n_front)  # bounded look-ahead: that many contigs held in memory at most
+                    pending_len.append(len(seq))
+                # bounded look-ahead: that many contigs held in memory at most — and, for long contigs, at most ~2 Gb of
+                # contig in flight (a resident 30x pileup is ~16 bytes per base of HBM: three chromosomes, not six)
+                keep = 2 * n_workers + n_front
+                while keep > 1 and sum(pending_len[-keep:]) > 2_000_000_000:
+                    keep -= 1
+                drain(keep)
             drain(0)
             out.flush()
             if prof:

@@ -45,7 +45,16 @@ struct DevCache {
     std::mutex mu;
     std::map<std::pair<int, size_t>, std::vector<void *>> free_; // (device, bytes) -> blocks
     size_t cached = 0;
-    static constexpr size_t LIMIT = 24ull << 30; // idle bytes kept; beyond that blocks go back to the driver
+    // idle bytes kept; beyond that blocks go back to the driver: NP2_DEV_CACHE_GB, else a twelfth of the device's memory
+    // (24 GB of an MI355X's 288), found when the first block comes back
+    size_t LIMIT = 0;
+    void set_limit() {
+        if (LIMIT) return;
+        if (const char *e = getenv("NP2_DEV_CACHE_GB")) LIMIT = (size_t)(atof(e) * (double)(1ull << 30));
+        size_t fr = 0, tot = 0;
+        if (!LIMIT && hipMemGetInfo(&fr, &tot) == hipSuccess) LIMIT = tot / 12;
+        if (!LIMIT) LIMIT = 24ull << 30;
+    }
     static size_t size_class(size_t bytes) { // four classes per octave (<= 25 % slack), at least 4 KiB
         size_t b = std::max<size_t>(bytes, 4096);
         unsigned lg = 63 - (unsigned)__builtin_clzll(b);
@@ -79,6 +88,7 @@ struct DevCache {
         bool over;
         {
             std::lock_guard<std::mutex> l(mu);
+            set_limit();
             free_[{dev, bytes}].push_back(p);
             cached += bytes;
             over = cached > LIMIT;
@@ -144,7 +154,11 @@ struct DevSlabs {
                 return p;
             }
         void *b = nullptr;
-        HIPCHK(hipMalloc(&b, SLAB));
+        if (hipMalloc(&b, SLAB) != hipSuccess) {
+            (void)hipGetLastError();
+            dev_cache().trim(0); // (the idle blocks of the size-class cache may be what is missing)
+            HIPCHK(hipMalloc(&b, SLAB));
+        }
         slabs.push_back(Slab{dev, (uint8_t *)b, bytes});
         return b;
     }

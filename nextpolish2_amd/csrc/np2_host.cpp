@@ -2096,6 +2096,7 @@ int np2_shard_final(np2_shard_run_t *h, uint8_t **out_bases, uint32_t **out_pos,
 }
 
 void *np2_alloc_pinned(uint64_t bytes) { return pinned_pool().get((size_t)bytes + 1); }
+void np2_trim_device_cache(void) { dev_cache().trim(0); }
 
 int np2_shard_final_device(np2_shard_run_t *h, np2_shard_piece_t *out) {
     ShardRun *sr = (ShardRun *)h;

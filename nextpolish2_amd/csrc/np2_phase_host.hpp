@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <memory>
+#include <exception>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -42,10 +43,21 @@ template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F f) {
         f((unsigned)0, (size_t)0, n);
         return;
     }
+    // (an exception in a piece — bad_alloc from a per-thread array — is carried to the caller's thread, not std::terminate)
+    std::vector<std::exception_ptr> err(T);
+    auto guarded = [&](size_t t, size_t lo, size_t hi) {
+        try {
+            f((unsigned)t, lo, hi);
+        } catch (...) {
+            err[t] = std::current_exception();
+        }
+    };
     std::vector<std::thread> th;
-    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { f((unsigned)t, n * t / T, n * (t + 1) / T); });
-    f((unsigned)0, (size_t)0, n / T);
+    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { guarded(t, n * t / T, n * (t + 1) / T); });
+    guarded(0, (size_t)0, n / T);
     for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 template <class V> class SwissOrderMap {
@@ -705,25 +717,31 @@ class SignedLouvain {
                 if (cnt_[id]) w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
             return w;
         }
-        std::vector<std::vector<float>> part(host_threads());
+        // partial sums in double: every term is a multiple of 0.5 below 2^22 in magnitude, so a double holds any partial
+        // and any total exactly whatever the order (a float partial beyond 2^23 would drop the halves even when the
+        // community's total is small again); a total within the float-exact range equals the reference's member-order sum
+        std::vector<std::vector<double>> part(host_threads());
         parallel_ranges(n, 4096, [&](unsigned t, size_t lo, size_t hi) {
-            std::vector<float> &p = part[t];
-            p.assign(n, 0.f);
+            std::vector<double> &p = part[t];
+            p.assign(n, 0.0);
             for (size_t v = lo; v < hi; ++v) {
                 if (!g_.has_key((uint32_t)v)) continue;
                 const uint32_t cid = node_id_[v];
-                float acc = node_w_[v];
+                double acc = node_w_[v];
                 for (const auto &e : g_.adj((uint32_t)v))
-                    if (node_id_[e.first] == cid) acc += e.second / 2.0f;
+                    if (node_id_[e.first] == cid) acc += (double)e.second / 2.0;
                 p[cid] += acc;
             }
         });
+        std::vector<double> wd(n, 0.0);
         for (const auto &p : part)
             if (!p.empty())
-                for (size_t id = 0; id < n; ++id) w[id] += p[id];
-        for (uint32_t id = 0; id < n; ++id)
-            if (cnt_[id] && !(w[id] > -4194304.f && w[id] < 4194304.f))
-                w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
+                for (size_t id = 0; id < n; ++id) wd[id] += p[id];
+        for (uint32_t id = 0; id < n; ++id) {
+            if (!cnt_[id]) continue;
+            if (wd[id] > -4194304.0 && wd[id] < 4194304.0) w[id] = (float)wd[id];
+            else w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
+        }
         return w;
     }
     // iteration order of a community's member set: replay its history into the emulated hash set

@@ -259,6 +259,10 @@ def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
     on_gpu = device is not None and torch.device(device).type == "cuda"
     sub_lo = int(run.plan.sub_lo)
 
+    if on_gpu:
+        from .api import lib
+        lib().np2_trim_device_cache()  # (torch is about to allocate gather buffers: idle np2 blocks go back to the driver)
+
     def one(kind):
         dt_t, dt_n = (torch.uint8, np.uint8) if kind == "bases" else (torch.int32, np.uint32)
         n = pc.own_len
@@ -302,17 +306,23 @@ def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
 def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
     """Shard protocol of one rank among `world` (one process per GPU): every phase's exchange carries the ranks' status."""
     from .api import ShardPiece
+    apply_err = None
     while run.passes_left() > 1:
-        err, payload = None, None
+        err, payload = apply_err, None
         try:
-            payload = run.vote().pack()
+            if err is None:
+                payload = run.vote().pack()
         except Exception as e:  # noqa: BLE001 — any failure of this rank's shard ends the sharded attempt everywhere
             err = e
         losers = _decide_on_owner(payload, err, n_reads_total, opts, device, group)
-        run.apply(losers)
-    err, pc = None, None
+        try:
+            run.apply(losers)
+        except Exception as e:  # noqa: BLE001 — reported with the next exchange's status word: nobody waits for this rank
+            apply_err = e
+    err, pc = apply_err, None
     try:
-        pc = run.final_device()
+        if err is None:
+            pc = run.final_device()
     except Exception as e:  # noqa: BLE001
         err = e
     raws = _exchange(pc.strips() if pc is not None else None, err, device, group, "final pass")

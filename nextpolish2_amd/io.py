@@ -130,6 +130,23 @@ def load_yak(path):
     return yk
 
 
+def check_yak_header(path):
+    """The cheap part of a dump's validation (kmer.rs:73-90: magic, counter bits; what this implementation supports:
+    k < 32, pre == 10) without reading its words: the command line runs it on every dump BEFORE it opens its output, like
+    the reference, which loads its yak files before the first contig.  Returns k; raises ValueError with the message."""
+    import struct
+    with open(path, "rb") as f:
+        hd = f.read(16)
+    if len(hd) != 16 or hd[:4] != b"YAK\x02":
+        raise ValueError("The input binary k-mer dump file is incompatible.")
+    k, pre, cbits = struct.unpack("<III", hd[4:])
+    if cbits != 10:
+        raise ValueError("different YAK_COUNTER_BITS")
+    if k >= 32 or k < 2 or pre != 10:
+        raise ValueError(f"{path}: k = {k}, prefix bits = {pre}: only k < 32 with the default 10 prefix bits is supported")
+    return k
+
+
 def polisher_from_yak_files(paths, device=0):
     """np2_ctx_create_from_files: a Polisher whose HBM k-mer tables are built from the dumps as they are read (no host
     copy of the words; tables ordered by k, option.rs:238)."""
