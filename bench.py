@@ -278,7 +278,8 @@ def kernel_path_host_buffers(pol, syn, opts, bases, workers=4):
     for c in ctxs[1:]:
         c.close()
     return {"value": round(total / best / 1e6, 2), "unit": "Mbp/s", "wall_ms": round(best * 1e3, 2), "workers": workers,
-            "h2d_bytes": nbytes, "identical_to_resident_path": bool(same),
+            "h2d_bytes": nbytes, "h2d_gbs_at_least": round(nbytes / best / 1e9, 2),  # (the polish itself is inside the same wall time)
+            "identical_to_resident_path": bool(same),
             "path": "host-resident packed pileups -> np2_polish_contig (upload + polish + free) per contig, "
                     f"{workers} contexts sharing the k-mer tables; best of 3"}
 

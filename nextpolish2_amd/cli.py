@@ -279,6 +279,8 @@ def main(argv=None):
         # dumps -> HBM tables in one go (np2_ctx_create_from_files: each file streamed to the device as it is read, one
         # host thread per dump); the device is not touched before a contig needs polishing
         t_b = time.time()
+        if prof:
+            print(f"[np2 profile] k-mer dumps: start at +{t_b - t0:.3f} s", file=sys.stderr)
         pol = np2io.polisher_from_yak_files(a.yak, device=a.device)
         if prof:
             print(f"[np2 profile] k-mer dumps read + tables in HBM {time.time() - t_b:.3f} s (at +{time.time() - t0:.3f} s)", file=sys.stderr)
@@ -287,8 +289,13 @@ def main(argv=None):
     def front(name, seq):
         """the contig's pileup, resident in HBM (np2_contig_from_bam) — on this thread's table-less context"""
         if getattr(tls, "fpol", None) is None:
+            t_c = time.time()
             tls.fpol = Polisher([], device=a.device)
+            t_b = time.time()
             tls.bam = np2io.Bam(a.bam)
+            if prof:
+                print(f"[np2 profile] front-end thread: context {1e3 * (t_b - t_c):.1f} ms, BAM + index opened {1e3 * (time.time() - t_b):.1f} ms "
+                      f"(at +{time.time() - t0:.3f} s)", file=sys.stderr)
         t_f = time.time()
         c = np2io.contig_from_bam(tls.fpol, tls.bam, name, seq, fopts)
         if prof:

@@ -92,6 +92,7 @@ static constexpr int64_t SCORE_NEG = INT64_MIN >> 1; // main.rs:1661
 
 // consensus base classes for the LQ state machine (main.rs:1586-1625)
 enum : uint8_t { CLS_HQ = 0, CLS_LQ = 1, CLS_RESET = 2 };
+static constexpr uint32_t GROW_ERR = 0x1000u;   // device error word: a splice round would outgrow the GUESSED growth allowance (retried with the exact one)
 static constexpr uint32_t LQ_LIST_ERR = 0x800u; // device error word: the list of low-quality bases overflowed its bound
 
 // checkpoint grid: column index of the reference column at every CKPT-th contig position

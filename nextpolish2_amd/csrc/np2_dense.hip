@@ -160,13 +160,14 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 uint32_t v = 0;
                 if (j < jend) {
                     uint32_t spins = 0;
+                    uint64_t t_wait0 = 0;
                     for (;;) {
                         const uint64_t sw = __hip_atomic_load(&chunk_st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((uint32_t)(sw >> 32) == epoch) {
                             v = (uint32_t)sw;
                             break;
                         }
-                        if (++spins > (1u << 22)) {
+                        if (lb_gave_up(spins, t_wait0)) { // (20 s of wall clock: np2_lookback.hpp)
                             timeout = true;
                             break;
                         }

@@ -124,6 +124,11 @@ void trace_region_tables(np2_ctx *cx, int pass, const std::string &tag, const Pa
     if (tag == "cand") trace_put(cx, pass, "cand.kmer", d2h(cx, cx->cand_kmer.p, pc.NC));
 }
 
+// the final pass ran its splice rounds with a guessed growth allowance that turned out too small (nothing was written
+// out of bounds: k_splice_plan): run_final_pass repeats the pass with the exact one
+struct GrowRetry : Np2Error {
+    GrowRetry() : Np2Error(NP2_E_DEVICE, "internal: guessed growth allowance too small") {}
+};
 void check_region_err(np2_ctx *cx, uint32_t e) {
     (void)cx;
     if (e & 4u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: seq2 order is equal to 0");
@@ -133,6 +138,7 @@ void check_region_err(np2_ctx *cx, uint32_t e) {
     if (e & 64u) throw Np2Error(NP2_E_REFPANIC, "reference would panic: consensus index out of bounds in reupdate");
     if (e & 128u) throw Np2Error(NP2_E_NOMEM, "cartesian product of chained LQ regions is too large");
     if (e & LB_ERR) throw Np2Error(NP2_E_DEVICE, "device-wide scan timed out waiting for a predecessor block");
+    if (e & GROW_ERR) throw GrowRetry();
     if (e & LQ_LIST_ERR) throw Np2Error(NP2_E_DEVICE, "internal: more low-quality bases than their list was sized for");
 }
 
@@ -478,7 +484,7 @@ CnsDev splice_gpu(np2_ctx *cx, const CnsDev &in, uint32_t n_reg, uint8_t lable, 
                        cx->sp_idx_e.p, stuck_p);
     launch_splice_plan(s, next_lookback(cx, region_lb_blocks(n_reg)), cx->reg_lable.p, lable, n_reg, stuck_p,
                        cx->sp_idx_s.p, cx->sp_idx_e.p, cx->seed_cand.p, cx->cand_seq_off.p, cx->ap_g.p, cx->ap_s.p,
-                       cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, nap_p, in.M_p, cx->mlen.p + version,
+                       cx->ap_e.p, cx->ap_delta.p, cx->ap_shift.p, nap_p, in.M_p, cx->mlen.p + version, out_cap,
                        cx->scal.p + S_ERR);
     launch_splice_write(s, in.pos, in.base, in.M_p, in.M_cap, cx->ap_g.p, cx->ap_s.p, cx->ap_e.p, cx->ap_delta.p,
                         cx->ap_shift.p, nap_p, n_reg, cx->lq_start.p, cx->seed_cand.p, cx->cand_seq_off.p,
@@ -637,9 +643,11 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
                                cx->scal.p + S_M3, cx->scal.p + S_M0, wide ? &lb : nullptr, cx->scal.p + S_ERR);
         }
         std::vector<uint32_t> sc = fetch_scal(cx);
+        // (a wait that gave up — in the dense pass or in k_tile_layout — first: what follows it in the kernel is undefined,
+        // the descriptor check included)
+        if (sc[S_ERR] & ~2u) check_region_err(cx, sc[S_ERR] & ~2u);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");
-        check_region_err(cx, sc[S_ERR]); // (a look-back timeout in k_tile_layout would leave T / S_M1 / S_M2 undefined)
         if (sc[S_M2] > ovf_cap) { // the spill area itself overflowed: grow and redo the dense pass
             ovf_cap = (uint64_t)sc[S_M2] * 5 / 4 + 65536;
             continue;
@@ -1022,6 +1030,7 @@ struct PolishRun {
     uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu; // regions this run votes over (sub-contig coordinates)
     uint32_t T = 0, pass = 0, M = 0, n_reg = 0;
     bool reuse = false;
+    uint32_t grow_prev = 0xFFFFFFFFu; // growth bound of the previous (phasing) pass, read back with its vote for free
     bool wide_votes = false; // the shards of a contig export (a << 32 | b, counts) pairs; the plain pipeline reads compact rows
     PassCounts pc;
     bool final_pass() const { return pass + 1 == o.iter_count; }
@@ -1093,6 +1102,7 @@ void run_vote_pass(PolishRun &r, VoteData &vd) {
         op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(r.pc.known ? r.pc.NC : r.pc.NC_cap) * 2);
     }
     vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd, r.wide_votes);
+    if (r.pc.known) r.grow_prev = r.pc.grow;
 }
 
 // the reads the vote removed (align_bases = empty, main.rs:1548-1550), then on to the next pass
@@ -1113,7 +1123,7 @@ void run_apply_losers(PolishRun &r, const std::vector<uint32_t> &losers) {
     ++r.pass;
 }
 
-void run_final_pass(PolishRun &r, ResultOut &result) {
+void run_final_pass(PolishRun &r, ResultOut &result, bool exact_grow = false) {
     np2_ctx *cx = r.cx;
     np2_contig *c = r.c;
     hipStream_t s = cx->stream;
@@ -1131,29 +1141,52 @@ void run_final_pass(PolishRun &r, ResultOut &result) {
     cx->reg_lable.ensure(n_reg + 2);
     cx->seed_cand.ensure(n_reg + 2);
     cx->keep_n.ensure(n_reg + 2);
-    if (!pc.known) pc.resolve(fetch_scal(cx)); // the splice rounds need the growth bound
-    cx->keep_list.ensure((size_t)pc.NC_cap + 2);
-    cx->keep_ks.ensure((size_t)pc.NC_cap + 2);
-    {
-        EventTimer t(cx, "seed");
-        launch_seed(s, rt, r.o.max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
-                    cx->keep_ks.p, cx->scal.p + S_ERR);
+    // The splice rounds need an allowance for the consensus' growth (the sum of the regions' longest kept candidates, on
+    // the device: S_GROW).  Reading it back is a device round trip of its own; after a phasing pass its value there is
+    // known — the final pass has fewer reads and mostly fewer regions — so twice that, guarded on the device, is used
+    // instead, and the pass is repeated with the exact figure should a round outgrow it (never observed).
+    static const bool no_guess = getenv("NP2_EXACT_GROW") != nullptr;
+    bool guessed = false;
+    if (!pc.known) {
+        if (r.grow_prev != 0xFFFFFFFFu && !exact_grow && !no_guess && !cx->trace && (uint64_t)r.grow_prev * 2 + 4096 < 0x7FFFFFFFull) {
+            pc.grow = r.grow_prev * 2 + 4096;
+            if (const char *e = getenv("NP2_TEST_GROW_GUESS")) pc.grow = (uint32_t)atol(e); // test hook: force the retry
+            guessed = true;
+        } else {
+            pc.resolve(fetch_scal(cx));
+        }
     }
-    if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
-    trace_region_tables(cx, (int)r.pass, "seed", pc, true);
-    CnsDev cur{cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, r.M}; // eoff[L] = length of the raw consensus
-    bool to_b = true;
-    uint32_t version = 0;
-    cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.grow, to_b, version++);
-    to_b = !to_b;
-    if (cx->trace) trace_cns(cx, (int)r.pass, "cns_succ", fetch_cns_dev(cx, cur));
-    for (size_t y = 0; y < cx->yaks.size(); ++y) {
-        cur = recheck_gpu(cx, cur, pc, (int)y, r.o.min_kmer_count, y == 0, to_b, version++);
+    try {
+        cx->keep_list.ensure((size_t)pc.NC_cap + 2);
+        cx->keep_ks.ensure((size_t)pc.NC_cap + 2);
+        {
+            EventTimer t(cx, "seed");
+            launch_seed(s, rt, r.o.max_indel_len, cx->reg_lable.p, cx->seed_cand.p, cx->keep_n.p, cx->keep_list.p,
+                        cx->keep_ks.p, cx->scal.p + S_ERR);
+        }
+        if (cx->trace) check_region_err(cx, d2h(cx, cx->scal.p + S_ERR, 1)[0]);
+        trace_region_tables(cx, (int)r.pass, "seed", pc, true);
+        CnsDev cur{cx->cns_pos.p, cx->cns_base.p, cx->eoff.p + c->L, r.M}; // eoff[L] = length of the raw consensus
+        bool to_b = true;
+        uint32_t version = 0;
+        cur = splice_gpu(cx, cur, n_reg, LB_SUCC, pc.grow, to_b, version++);
         to_b = !to_b;
-        trace_region_tables(cx, (int)r.pass, "rech" + std::to_string(y), pc, true);
-        if (cx->trace) trace_cns(cx, (int)r.pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
+        if (cx->trace) trace_cns(cx, (int)r.pass, "cns_succ", fetch_cns_dev(cx, cur));
+        for (size_t y = 0; y < cx->yaks.size(); ++y) {
+            cur = recheck_gpu(cx, cur, pc, (int)y, r.o.min_kmer_count, y == 0, to_b, version++);
+            to_b = !to_b;
+            trace_region_tables(cx, (int)r.pass, "rech" + std::to_string(y), pc, true);
+            if (cx->trace) trace_cns(cx, (int)r.pass, "cns_rech" + std::to_string(y), fetch_cns_dev(cx, cur));
+        }
+        fetch_result(cx, cur.pos, cur.base, cur.M_p, cur.M_cap, result, guessed ? r.M + r.grow_prev : r.M + pc.grow);
+    } catch (const GrowRetry &) {
+        if (!guessed) throw;
+        if (result.bases) pinned_pool().put(result.bases), result.bases = nullptr;
+        if (result.pos) pinned_pool().put(result.pos), result.pos = nullptr;
+        op_fill(cx, cx->scal.p + S_ERR, 0, 4); // (every other bit of the word would have been reported first)
+        r.reuse = false;
+        run_final_pass(r, result, true);
     }
-    fetch_result(cx, cur.pos, cur.base, cur.M_p, cur.M_cap, result, r.M + pc.grow);
 }
 
 void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &result) {

@@ -650,6 +650,81 @@ struct SecSeq { // SEQ of a primary alignment in read orientation (4-bit BAM cod
     std::vector<uint8_t> seq4;
     uint32_t len = 0;
 };
+// The SEQ bytes of a contig's records on their way to the device: batch by batch (one refill of the inflater: <= 128 MiB
+// of BAM, ~40 MB of SEQ) through two alternating pinned pieces, each uploaded as soon as its records are copied.  The
+// whole contig's SEQ as ONE pinned array (round 3) is 3.7 GB for a 248 Mb chromosome at 30x: page-locking that much takes
+// ~1 s per 4 GB, grown by reallocation it was 1.5 - 5 s — and the driver serialises it with every other allocation of
+// the process (the k-mer tables' hipMalloc waited 4.8 s behind it: tools/alloc_probe.py, profiles/r04_e2e_chr1_*).
+struct SeqStream {
+    hipStream_t s = nullptr;
+    np2h::DevBuf<uint8_t> dev; // the contig's SEQ bytes, contiguous (capacity kept from contig to contig)
+    uint64_t n = 0;            // bytes uploaded
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int turn = 0;
+    SeqStream() { dev.cached = true; }
+    ~SeqStream() {
+        if (s) (void)hipStreamSynchronize(s); // (the device block goes back to the cache: nothing of ours may be in flight)
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) np2h::pinned_pool().put(pin[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    }
+    void begin(hipStream_t stream, uint64_t expect_bytes) {
+        s = stream;
+        n = 0;
+        if (dev.cap < expect_bytes + 64) {
+            HIPCHK(hipStreamSynchronize(s));
+            dev.ensure(expect_bytes + 64);
+        }
+    }
+    uint8_t *piece(size_t bytes) { // staging for the next batch
+        const int i = turn;
+        if (busy[i]) {
+            HIPCHK(hipEventSynchronize(ev[i]));
+            busy[i] = false;
+        }
+        if (pin_cap[i] < bytes) {
+            if (pin[i]) np2h::pinned_pool().put(pin[i]);
+            pin[i] = nullptr, pin_cap[i] = 0;
+            const size_t want = bytes + bytes / 4 + (1u << 20);
+            pin[i] = np2h::pinned_pool().get(want);
+            if (!pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            pin_cap[i] = want;
+        }
+        if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        return (uint8_t *)pin[i];
+    }
+    void push(size_t bytes) { // the piece handed out last holds `bytes` bytes that follow the n uploaded so far
+        if (dev.cap < n + bytes + 64) { // the estimate fell short: a larger block, what is there copied over on the device
+            np2h::DevBuf<uint8_t> bigger;
+            bigger.cached = true;
+            bigger.ensure((n + bytes) * 3 / 2 + 64);
+            if (n) HIPCHK(hipMemcpyAsync(bigger.p, dev.p, n, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            std::swap(bigger.p, dev.p);
+            std::swap(bigger.cap, dev.cap);
+            std::swap(bigger.cache_bytes, dev.cache_bytes);
+            std::swap(bigger.slab_bytes, dev.slab_bytes);
+        }
+        const int i = turn;
+        if (bytes) {
+            HIPCHK(hipMemcpyAsync(dev.p + n, pin[i], bytes, hipMemcpyHostToDevice, s));
+            HIPCHK(hipEventRecord(ev[i], s));
+            busy[i] = true;
+        }
+        n += bytes;
+        turn ^= 1;
+    }
+    void finish() { // 16 readable zero bytes behind the last record's SEQ (the columnariser loads whole words)
+        if (dev.cap < n + 64) push(0);
+        HIPCHK(hipMemsetAsync(dev.p + n, 0, 16, s));
+        n += 16;
+    }
+};
+
 struct np2_bam {
     Bgzf z;
     std::vector<std::string> ref_names;
@@ -662,7 +737,8 @@ struct np2_bam {
     // -S: secondary alignments carry no SEQ; recovered from the primary record of the same read (secondary.rs:82-148)
     bool sec_loaded = false;
     std::unordered_map<std::string, SecSeq> sec;
-    PinnedBytes seq4; // SEQ staging of the contig being read (capacity kept across contigs)
+    PinnedBytes seq4; // SEQ staging of the contig being read (-S, and callers without a context; capacity kept across contigs)
+    SeqStream seqs;   // ... streamed to the device batch by batch (the usual path)
     BgzfBatch batch;  // batch inflater (its buffer is reused from contig to contig)
     const uint8_t *map = nullptr; // the whole file, mapped read-only (BgzfBatch inflates out of it)
     size_t map_len = 0;
@@ -749,9 +825,11 @@ struct FrontWork {
     ~FrontWork() { delete c; }
 };
 
+// seq4: the records' SEQ bytes on the host (uploaded here) — or, with d_seq_in, already on the device (SeqStream, on
+// this context's stream)
 void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_bamrec_t *recs, uint32_t n_recs,
                  const uint32_t *cigar, const uint8_t *seq4, uint64_t seq4_bytes, const np2_front_opts_t *o,
-                 const ShardSpec *sp, FrontWork &fw) {
+                 const ShardSpec *sp, FrontWork &fw, const uint8_t *d_seq_in = nullptr) {
     const double t_a0 = np2h::now_ms();
     HIPCHK(hipSetDevice(cx->device));
     hipStream_t s = cx->stream;
@@ -768,7 +846,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
         hipStream_t s;
         ~StreamIdleOnExit() { (void)hipStreamSynchronize(s); }
     } seq_guard{s};
-    if (seq4_bytes) {
+    if (seq4_bytes && !d_seq_in) {
         d_seq.ensure(seq4_bytes + 16);
         HIPCHK(hipMemcpyAsync(d_seq.p, seq4, seq4_bytes, hipMemcpyHostToDevice, s));
     }
@@ -922,7 +1000,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
         launch_pack_ref(s, d_ref.p, L, c->nib.p);
         std::vector<FrontOut> fout(n);
         if (n) {
-            d_seq.ensure(seq4_bytes + 16); // (already there unless the records carry no SEQ at all)
+            if (!d_seq_in) d_seq.ensure(seq4_bytes + 16); // (already there unless the records carry no SEQ at all)
             d_rec.ensure(n);
             d_ops.ensure(fops.size() + 1);
             d_out.ensure(n);
@@ -931,7 +1009,7 @@ void front_begin(np2_ctx *cx, const uint8_t *ref_glob, uint32_t L_in, const np2_
             HIPCHK(hipMemcpyAsync(d_ops.p, fops.data(), fops.size() * sizeof(FrontOp), hipMemcpyHostToDevice, s));
             {
                 np2h::EventTimer t(cx, "columnarise");
-                launch_columnarise(s, d_rec.p, n, d_ops.p, d_ref.p, d_seq.p, c->nib.p, d_out.p);
+                launch_columnarise(s, d_rec.p, n, d_ops.p, d_ref.p, d_seq_in ? d_seq_in : d_seq.p, c->nib.p, d_out.p);
             }
             fout = np2h::d2h(cx, d_out.p, n);
             t_b2 = np2h::now_ms();
@@ -1059,10 +1137,15 @@ void contig_from_records(np2_ctx *cx, const uint8_t *ref, uint32_t L, const np2_
 
 // The records of reference `tid` that overlap [zone_lo, zone_hi) (the whole contig: [0, L)), in file order, as
 // np2_bamrec_t + CIGAR words + SEQ bytes (pinned staging of the handle); optionally their BGZF virtual offsets.
+// With `up_stream` (and without -S) the SEQ bytes do not stay on the host: they go to bam->seqs.dev batch by batch
+// (SeqStream), *seq_bytes is their total, bam->seq4 stays empty.
 void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t zone_hi, const np2_front_opts_t *opts,
-                   std::vector<np2_bamrec_t> &recs, std::vector<uint32_t> &cigar, std::vector<uint64_t> *voffs) {
+                   std::vector<np2_bamrec_t> &recs, std::vector<uint32_t> &cigar, std::vector<uint64_t> *voffs,
+                   hipStream_t up_stream = nullptr, uint64_t *seq_bytes = nullptr) {
         PinnedBytes &seq4 = bam->seq4;
         seq4.clear();
+        const bool streamed = up_stream != nullptr && !opts->use_secondary;
+        uint64_t seq_total = 0; // (streamed: the running SEQ offset that seq4.size() is otherwise)
         if (opts->use_secondary) load_secondary_seqs(bam);
         // where to start: the whole contig from its first record; a zone from the linear index (the smallest offset of a
         // record overlapping the 16 kb window of zone_lo; an empty window takes the next one's, like htslib)
@@ -1078,6 +1161,14 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
             z.map = bam->map, z.map_len = bam->map_len;
             z.seek(start_off, false);
             if (bam->ref_end[tid]) z.hint_fpos = (size_t)(bam->ref_end[tid] >> 16);
+            if (streamed) {
+                // SEQ is about a third of a record with qualities (half without), BAM deflates 3 - 6x: 2.5 bytes of SEQ per
+                // compressed byte is rarely short (and a shortfall only costs one device-side copy)
+                const uint64_t c_lo = start_off >> 16, c_hi = bam->ref_end[tid] ? (bam->ref_end[tid] >> 16) : (uint64_t)bam->map_len;
+                double frac = 1.0;
+                if (zone_lo > 0 || zone_hi < L) frac = std::min(1.0, ((double)zone_hi - zone_lo + 65536.0) / std::max<double>(1.0, L));
+                bam->seqs.begin(up_stream, (uint64_t)((c_hi > c_lo ? (double)(c_hi - c_lo) : 0.0) * 2.5 * frac) + (32u << 20));
+            }
             // Per refill (up to 128 MiB of inflated BAM, inflated in parallel): one light sequential walk over the record
             // length fields finds this contig's records — on this thread, WHILE the pool inflates, trailing the blocks as
             // they complete (10 k records = 10 k cache misses into lines other cores just wrote: 1.6 ms of an E. coli-sized
@@ -1093,7 +1184,8 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
             while (!stop) {
                 rr.clear();
                 size_t p = 0;
-                uint64_t co = cigar.size(), so = seq4.size();
+                uint64_t co = cigar.size(), so = streamed ? seq_total : seq4.size();
+                const uint64_t so0 = so;
                 double t_walk = 0;
                 const std::function<void()> walk = [&]() {
                 const double t_w0 = np2h::now_ms();
@@ -1157,7 +1249,12 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                 if (voffs)
                     for (auto &q : rr) voffs->push_back(q.voff);
                 cigar.resize(co);
-                if (!opts->use_secondary) seq4.resize(so);
+                uint8_t *seq_dst = nullptr; // where SEQ byte offset so0 of this batch goes
+                if (streamed) seq_dst = bam->seqs.piece((size_t)(so - so0));
+                else if (!opts->use_secondary) {
+                    seq4.resize(so);
+                    seq_dst = seq4.data() + so0;
+                }
                 const double t_w2 = np2h::now_ms();
                 z.ms_walk += t_walk, z.ms_size += t_w2 - t_w1;
                 if (!opts->use_secondary) {
@@ -1176,9 +1273,13 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                         r.l_seq = q.l_seq;
                         r.seq_off = q.seq_off;
                         for (uint32_t k = 0; k < q.n_cigar; ++k) cigar[q.cigar_off + k] = le32(pc + 4 * k);
-                        memcpy(seq4.data() + q.seq_off, pc + (size_t)q.n_cigar * 4, ((size_t)q.l_seq + 1) / 2);
+                        memcpy(seq_dst + (q.seq_off - so0), pc + (size_t)q.n_cigar * 4, ((size_t)q.l_seq + 1) / 2);
                         recs[r0 + i] = r;
                     });
+                    if (streamed) {
+                        bam->seqs.push((size_t)(so - so0));
+                        seq_total = so;
+                    }
                 } else {
                     for (size_t i = 0; i < rr.size(); ++i) { // -S: secondary records take their SEQ from the primary's
                         const RecRef &q = rr[i];
@@ -1222,7 +1323,14 @@ void fetch_records(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t
                 }
             }
         }
-    seq4.resize(seq4.size() + 16, 0);
+    if (streamed) {
+        if (start_off == ~0ull) bam->seqs.begin(up_stream, 0);
+        bam->seqs.finish();
+        if (seq_bytes) *seq_bytes = bam->seqs.n;
+    } else {
+        seq4.resize(seq4.size() + 16, 0);
+        if (seq_bytes) *seq_bytes = seq4.size();
+    }
 }
 
 } // namespace
@@ -1419,18 +1527,24 @@ void yak_file_to_table(YakFile &yf, int device, hipStream_t given) {
         while ((1ull << cl) < mx * 2 + 2) ++cl;
         const size_t slots = nb << cl;
         const double t1 = np2h::now_ms();
+        double ta[6] = {t1, t1, t1, t1, t1, t1};
         if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ta[0] = np2h::now_ms();
         yf.table.k = yf.k;
         yf.table.cap_log2 = cl;
         yf.table.table = std::make_shared<np2h::DevBuf<uint64_t>>();
         yf.table.table->ensure(slots);
+        ta[1] = np2h::now_ms();
         HIPCHK(hipMemsetAsync(yf.table.table->p, 0xFF, slots * 8, st));
+        ta[2] = np2h::now_ms();
         np2h::DevBuf<uint64_t> d_raw, d_off;
         np2h::DevBuf<uint32_t> d_dup;
         d_raw.ensure(body_words + 1);
+        ta[3] = np2h::now_ms();
         d_off.ensure(nb + 1);
         d_dup.ensure(1);
         HIPCHK(hipMemsetAsync(d_dup.p, 0, 4, st));
+        ta[4] = np2h::now_ms();
         const size_t PIECE = (size_t)8 << 20;
         for (int i = 0; i < 2; ++i) {
             pin[i] = (uint8_t *)np2h::pinned_pool().get(PIECE);
@@ -1438,6 +1552,10 @@ void yak_file_to_table(YakFile &yf, int device, hipStream_t given) {
             HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
         }
         const double t2 = np2h::now_ms();
+        if (prof)
+            fprintf(stderr, "  yak k=%u allocations: stream %.1f ms, table (%.1f GB) %.1f ms, memset call %.1f ms, file image (%.1f GB) %.1f ms, "
+                            "small buffers %.1f ms, pinned pieces + events %.1f ms\n", yf.k, ta[0] - t1, slots * 8 / 1e9, ta[1] - ta[0],
+                    ta[2] - ta[1], body_words * 8 / 1e9, ta[3] - ta[2], ta[4] - ta[3], t2 - ta[4]);
         const size_t body = body_words * 8;
         size_t piece = 0;
         for (size_t o = 0; o < body; o += PIECE, ++piece) {
@@ -1680,14 +1798,22 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
         const double t_p0 = np2h::now_ms();
         bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = bam->batch.ms_walk = bam->batch.ms_size = bam->batch.ms_copy = 0;
-        fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr);
+        HIPCHK(hipSetDevice(cx->device));
+        uint64_t seq_bytes = 0;
+        fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr, cx->stream, &seq_bytes);
         const double t_p1 = np2h::now_ms();
-        contig_from_records(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq4.size(), opts, out);
+        {
+            const bool streamed = !opts->use_secondary;
+            FrontWork fw;
+            front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), seq4.data(), seq_bytes, opts, nullptr, fw,
+                        streamed ? bam->seqs.dev.p : nullptr);
+            front_finish(cx, fw, out);
+        }
         if (prof)
             fprintf(stderr, "np2_contig_from_bam %s: inflate+parse %.2f ms (block headers %.2f, inflate [%s] %.2f, buffer moves %.2f, record "
                             "walk %.2f, array sizing %.2f, record copies %.2f; %zu records, %zu SEQ bytes), records->pileup %.2f ms\n",
                     name, t_p1 - t_p0, bam->batch.ms_read, Inflater::get().name(), bam->batch.ms_inflate, bam->batch.ms_drop,
-                    bam->batch.ms_walk, bam->batch.ms_size, bam->batch.ms_copy, recs.size(), seq4.size(), np2h::now_ms() - t_p1);
+                    bam->batch.ms_walk, bam->batch.ms_size, bam->batch.ms_copy, recs.size(), (size_t)seq_bytes, np2h::now_ms() - t_p1);
         np2h::flush_timings(cx);
     } catch (const np2h::Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);
@@ -1736,7 +1862,9 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         pl.zone_hi = (uint64_t)own_hi + halo < L ? own_hi + halo : L;
         std::vector<np2_bamrec_t> recs;
         std::vector<uint32_t> cigar;
-        fetch_records(bam, tid, L, pl.zone_lo, pl.zone_hi, opts, recs, cigar, &io->rec_voff);
+        HIPCHK(hipSetDevice(cx->device));
+        uint64_t seq_bytes = 0;
+        fetch_records(bam, tid, L, pl.zone_lo, pl.zone_hi, opts, recs, cigar, &io->rec_voff, cx->stream, &seq_bytes);
         // the sub-contig: from the first start to the last reference end among the fetched records
         uint32_t slo = pl.zone_lo, shi = pl.zone_hi;
         for (const np2_bamrec_t &r : recs) {
@@ -1752,8 +1880,8 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         pl.sub_hi = own_hi == L ? L : shi;
         ShardSpec sp;
         sp.sub_lo = pl.sub_lo, sp.sub_hi = pl.sub_hi, sp.zone_lo = pl.zone_lo, sp.zone_hi = pl.zone_hi;
-        front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), bam->seq4.data(), bam->seq4.size(), opts, &sp,
-                    io->fw);
+        front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), bam->seq4.data(), seq_bytes, opts, &sp, io->fw,
+                    opts->use_secondary ? nullptr : bam->seqs.dev.p);
         for (size_t i = 1; i < io->fw.reads.size(); ++i) {
             const np2_bamrec_t &r = recs[io->fw.rec_of[i]];
             if ((uint32_t)r.pos >= own_lo && (uint32_t)r.pos < own_hi) io->own_voff.push_back(io->rec_voff[io->fw.rec_of[i]]);

@@ -32,19 +32,29 @@ struct Lookback {
 };
 
 static constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
-static constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
-static constexpr uint32_t LB_ERR = 0x400u; // or-ed into the error word on a spin timeout
+// A wait gives up after LB_WAIT_TICKS of the constant 100 MHz wall clock (20 s), looked at every 1024 spins: a count of
+// spins is a fraction of a second to a few seconds depending on the sleep and the memory latency — too short when the
+// device is shared with another process whose kernels hold the chip for a scheduling quantum at a time (two ranks
+// rehearsing on one GPU: the dense pass of a 124 Mb shard timed out waiting for its predecessors' status words).
+static constexpr uint64_t LB_WAIT_TICKS = 2000000000ull;
+static constexpr uint32_t LB_ERR = 0x400u; // or-ed into the error word on a wait that gave up
+__device__ __forceinline__ bool lb_gave_up(uint32_t &spins, uint64_t &t0) {
+    if ((++spins & 1023u) != 0) return false;
+    const uint64_t now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    return now - t0 > LB_WAIT_TICKS;
+}
 
 __device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint32_t state, uint32_t value) {
     return ((uint64_t)epoch << 34) | ((uint64_t)state << 32) | value;
 }
 __device__ __forceinline__ uint64_t lb_wait(const uint64_t *p, uint32_t epoch, bool &timeout) {
-    uint64_t w;
+    uint64_t w, t0 = 0;
     uint32_t spins = 0;
     for (;;) {
         w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(w >> 34) == epoch && ((uint32_t)(w >> 32) & 3u) != 0) break;
-        if (++spins > LB_SPIN_LIMIT) {
+        if (lb_gave_up(spins, t0)) {
             timeout = true;
             break;
         }

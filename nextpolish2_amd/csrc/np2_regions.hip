@@ -621,7 +621,7 @@ __device__ __forceinline__ void k_splice_plan(const uint32_t np2_bid, const uint
                                                      uint32_t *__restrict__ ap_s, uint32_t *__restrict__ ap_e,
                                                      int32_t *__restrict__ ap_delta, int32_t *__restrict__ ap_shift_incl,
                                                      uint32_t *__restrict__ n_ap, const uint32_t *__restrict__ M_in,
-                                                     uint32_t *__restrict__ M_out, uint32_t *__restrict__ err) {
+                                                     uint32_t *__restrict__ M_out, uint32_t out_cap, uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[8];
     const uint32_t bid = lb_block_id(lb, sh);
     // four consecutive regions per thread (a quarter of the blocks: the look-back is a chain over the blocks)
@@ -664,8 +664,18 @@ __device__ __forceinline__ void k_splice_plan(const uint32_t np2_bid, const uint
         ld += (uint32_t)delta[k];
     }
     if (bid == n_blocks - 1 && threadIdx.x == 0) {
-        *n_ap = pre_c + cnt;
-        *M_out = *M_in + pre_d + dsum;
+        const uint32_t m_out = *M_in + pre_d + dsum;
+        if (m_out > out_cap) {
+            // the output buffers were sized with a guessed growth allowance and this round would outgrow them: nothing is
+            // spliced (the consensus is copied as it is — that fits), the host sees GROW_ERR and repeats the pass with the
+            // exact allowance
+            atomicOr(err, GROW_ERR);
+            *n_ap = 0;
+            *M_out = *M_in;
+        } else {
+            *n_ap = pre_c + cnt;
+            *M_out = m_out;
+        }
     }
 }
 // copy the bases outside the applied regions to their shifted places.  A block covers SPLICE_SPAN consecutive consensus
@@ -1125,9 +1135,9 @@ void launch_splice_find(hipStream_t s, const uint32_t *cns_pos, const uint32_t *
 void launch_splice_plan(hipStream_t s, const Lookback &lb, const uint8_t *reg_lable, uint8_t lable, uint32_t n_reg,
                         const uint32_t *stuck, const uint32_t *idx_s, const uint32_t *idx_e, const uint32_t *seed_cand,
                         const uint32_t *seq_off, uint32_t *ap_g, uint32_t *ap_s, uint32_t *ap_e, int32_t *ap_delta,
-                        int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t *err) {
+                        int32_t *ap_shift_incl, uint32_t *n_ap, const uint32_t *M_in, uint32_t *M_out, uint32_t out_cap, uint32_t *err) {
     const uint32_t nb = region_lb_blocks(n_reg);
-    NP2_LAUNCH(k_splice_plan, dim3(nb), 256, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e, seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, err);
+    NP2_LAUNCH(k_splice_plan, dim3(nb), 256, s, lb, nb, reg_lable, lable, n_reg, stuck, idx_s, idx_e, seed_cand, seq_off, ap_g, ap_s, ap_e, ap_delta, ap_shift_incl, n_ap, M_in, M_out, out_cap, err);
 }
 void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *in_base, const uint32_t *M_p, uint32_t M_cap,
                          const uint32_t *ap_g, const uint32_t *ap_s, const uint32_t *ap_e, const int32_t *ap_delta,

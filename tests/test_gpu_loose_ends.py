@@ -121,3 +121,26 @@ def test_soak_contexts_and_batches_share_one_gpu():
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not bad
+
+
+def test_guessed_growth_allowance_and_its_retry(monkeypatch, small_diploid):
+    """The final pass sizes its splice rounds with twice the phasing pass's growth bound instead of reading the exact bound
+    back (one device round trip less); a round that would outgrow the guess splices nothing, raises GROW_ERR and the pass
+    is repeated with the exact bound.  NP2_TEST_GROW_GUESS=0 forces that; NP2_EXACT_GROW=1 is the read-back path."""
+    import numpy as np
+    from nextpolish2_amd import Opts, Polisher
+    from oracle.np2_oracle import Oracle
+    s, yaks = small_diploid
+    ob, op = Oracle(yaks).polish(s.pileup, Opts())
+    gb, gp = Polisher(yaks).polish(s.pileup, Opts())
+    assert np.array_equal(gb, ob) and np.array_equal(gp, op)
+    monkeypatch.setenv("NP2_TEST_GROW_GUESS", "0")
+    gb, gp = Polisher(yaks).polish(s.pileup, Opts())
+    assert np.array_equal(gb, ob) and np.array_equal(gp, op)
+    from nextpolish2_amd import BatchPolisher
+    pol = Polisher(yaks)
+    c = pol.upload(s.pileup)
+    bp = BatchPolisher(pol, 2)
+    for bb, pp in bp.polish([c, c], Opts(), want_pos=True):
+        assert np.array_equal(bb, ob) and np.array_equal(pp, op)
+    bp.close()
