@@ -66,6 +66,11 @@ struct np2_batch {
     // completion word of a flush: host-mapped, written by the last kernel of the flush
     uint32_t *done_host = nullptr, *done_dev = nullptr;
     uint32_t done_seq = 0;
+    std::atomic<uint32_t> issued_seq{0}; // completion sequence of the last flush that has been issued
+    std::atomic<uint32_t> done_pub{0};   // ... of the last flush known to have completed (the waiters sleep on it)
+    std::atomic<bool> spinner{false};    // one pipeline at a time polls the device's completion word for all of them
+    double t_issued_last = 0;            // when it was
+    uint32_t wait_logged_seq = 0;        // the flush whose device wait has been entered in the log (once per flush)
 
     // HIP-event timing of the batched dense kernel (bench roofline): pairs recorded around its launches
     bool time_diff = false;
@@ -82,6 +87,30 @@ struct np2_batch {
 
 namespace {
 
+// Recorder::sync_fn: wait until every running pipeline of the wave has reached a synchronisation point; the last one
+// to arrive flushes for all.
+// A pipeline that reached its synchronisation point before the others waits for the group's flush: a short spin (the
+// common case — the pipelines of a wave arrive within microseconds of each other and a flush of a few kernels is over
+// in tens of microseconds), then it sleeps on the generation word.  (Spinning for the whole wait had every waiting
+// pipeline of every batch group hold a core: 60+ busy host threads for one GPU.)
+inline void wait_generation(std::atomic<uint32_t> &gen, uint32_t seen) {
+    static const double spin_us = getenv("NP2_BATCH_SPIN_US") ? atof(getenv("NP2_BATCH_SPIN_US")) : 30.0;
+    const double t_end = now_ms() + spin_us * 1e-3;
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (gen.load(std::memory_order_acquire) != seen) return;
+            __builtin_ia32_pause();
+        }
+        if (now_ms() >= t_end) break;
+    }
+    while (gen.load(std::memory_order_acquire) == seen)
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+inline void publish_generation(std::atomic<uint32_t> &gen, uint32_t next) {
+    gen.store(next, std::memory_order_release);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
 // one-thread kernel that marks the end of a flush in host-mapped memory
 __device__ __forceinline__ void k_flush_done(const uint32_t np2_bid, const uint32_t np2_nb, uint32_t *__restrict__ word, uint32_t seq) {
     if (threadIdx.x == 0) {
@@ -90,8 +119,10 @@ __device__ __forceinline__ void k_flush_done(const uint32_t np2_bid, const uint3
     }
 }
 
-// Issue every recorded command of the active slots on the batch stream, merging equal kernels at the queue heads, then
-// wait for the device.  Called with sync_mu held by the last thread that arrived.
+// Issue every recorded command of the active slots on the batch stream, merging equal kernels at the queue heads; the
+// completion word of the flush (b->issued_seq) is posted by its last kernel.  Called with sync_mu held by the last
+// thread that arrived; the WAIT for the device is the business of the pipelines that need it (wait_done): a pipeline
+// that only wanted its commands on their way goes on at once.
 void flush(np2_batch *b) {
     const int n = (int)b->recs.size();
     const double t_begin = now_ms();
@@ -188,16 +219,7 @@ void flush(np2_batch *b) {
         const uint32_t seq = ++b->done_seq;
         NP2_LAUNCH(k_flush_done, 1, 64, s, b->done_dev, seq);
         t_issued = now_ms();
-        uint64_t spins = 0;
-        while (__atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xFFFF) == 0) {
-                hipError_t e = hipStreamQuery(s);
-                if (e != hipSuccess && e != hipErrorNotReady)
-                    throw Np2Error(NP2_E_DEVICE, std::string("device error during a batch flush: ") + hipGetErrorString(e));
-                if (e == hipSuccess && __atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) != seq)
-                    throw Np2Error(NP2_E_DEVICE, "batch flush completed without posting");
-            }
-        }
+        b->issued_seq.store(seq, std::memory_order_release);
     } catch (const std::exception &ex) {
         b->fail_msg = ex.what();
         b->failed.store(true);
@@ -208,43 +230,66 @@ void flush(np2_batch *b) {
     tl_recorder() = saved;
     for (auto &r : b->recs) r.clear();
     ++b->stat_flushes;
-    const double t_end = now_ms();
     b->ms_host += t_begin - b->t_last_end;
     b->ms_issue += t_issued - t_begin;
-    b->ms_wait += t_end - t_issued;
     b->flush_log.push_back(t_begin - b->t_last_end);
     b->flush_log.push_back(t_issued - t_begin);
-    b->flush_log.push_back(t_end - t_issued);
-    b->t_last_end = t_end;
+    b->flush_log.push_back(0.0); // (device wait: entered by the first pipeline that waits for this flush, wait_done)
+    b->t_last_end = t_issued;
+    b->t_issued_last = t_issued;
 }
 
-// Recorder::sync_fn: wait until every running pipeline of the wave has reached a synchronisation point; the last one
-// to arrive flushes for all.
-// A pipeline that reached its synchronisation point before the others waits for the group's flush: a short spin (the
-// common case — the pipelines of a wave arrive within microseconds of each other and a flush of a few kernels is over
-// in tens of microseconds), then it sleeps on the generation word.  (Spinning for the whole wait had every waiting
-// pipeline of every batch group hold a core: 60+ busy host threads for one GPU.)
-inline void wait_generation(std::atomic<uint32_t> &gen, uint32_t seen) {
-    static const double spin_us = getenv("NP2_BATCH_SPIN_US") ? atof(getenv("NP2_BATCH_SPIN_US")) : 30.0;
-    const double t_end = now_ms() + spin_us * 1e-3;
+// wait until the flush with completion sequence `seq` (or a later one) has run on the device.  The device posts the
+// sequence number in host-mapped memory, which nothing can sleep on: ONE of the waiting pipelines polls it and publishes
+// what it saw, the others sleep on the published word (every waiter polling for itself had 17 threads spinning through
+// the other pipelines' host phases: 13 of the container's 16 CPUs busy).
+void wait_done(np2_batch *b, uint32_t seq) {
     for (;;) {
-        for (int i = 0; i < 64; ++i) {
-            if (gen.load(std::memory_order_acquire) != seen) return;
-            __builtin_ia32_pause();
+        const uint32_t pub = b->done_pub.load(std::memory_order_acquire);
+        if ((int32_t)(pub - seq) >= 0 || b->failed.load()) break;
+        bool expected = false;
+        if (b->spinner.compare_exchange_strong(expected, true)) {
+            uint64_t spins = 0;
+            uint32_t cur;
+            while ((int32_t)((cur = __atomic_load_n(b->done_host, __ATOMIC_ACQUIRE)) - seq) < 0) {
+                if (b->failed.load()) break;
+                if ((++spins & 0xFFFF) == 0) {
+                    hipError_t e = hipStreamQuery(b->stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) {
+                        b->fail_msg = std::string("device error during a batch flush: ") + hipGetErrorString(e);
+                        b->failed.store(true);
+                        break;
+                    }
+                    if (e == hipSuccess && (int32_t)(__atomic_load_n(b->done_host, __ATOMIC_ACQUIRE) - seq) < 0) {
+                        b->fail_msg = "batch flush completed without posting";
+                        b->failed.store(true);
+                        break;
+                    }
+                }
+                __builtin_ia32_pause();
+            }
+            b->spinner.store(false);
+            publish_generation(b->done_pub, b->failed.load() ? pub + 1 : cur); // (wakes the sleepers either way)
+            if (b->failed.load()) return;
+            continue;
         }
-        if (now_ms() >= t_end) break;
+        wait_generation(b->done_pub, pub);
     }
-    while (gen.load(std::memory_order_acquire) == seen)
-        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
-}
-inline void publish_generation(std::atomic<uint32_t> &gen, uint32_t next) {
-    gen.store(next, std::memory_order_release);
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    if (b->failed.load()) return;
+    std::lock_guard<std::mutex> l(b->sync_mu);
+    if (b->wait_logged_seq != seq && b->issued_seq.load() == seq && !b->flush_log.empty()) { // first waiter of the newest flush
+        const double t = now_ms();
+        b->wait_logged_seq = seq;
+        b->ms_wait += t - b->t_issued_last;
+        b->flush_log.back() = t - b->t_issued_last;
+        b->t_last_end = t;
+    }
 }
 
-void group_sync(Recorder *r) {
+void group_sync(Recorder *r, bool need_done) {
     np2_batch *b = (np2_batch *)r->group;
     uint32_t my_gen;
+    bool flushed = false;
     {
         std::lock_guard<std::mutex> l(b->sync_mu);
         my_gen = b->flush_gen.load(std::memory_order_relaxed);
@@ -252,11 +297,12 @@ void group_sync(Recorder *r) {
             flush(b);
             b->n_waiting = 0;
             publish_generation(b->flush_gen, my_gen + 1);
-            if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
-            return;
+            flushed = true;
         }
     }
-    wait_generation(b->flush_gen, my_gen);
+    if (!flushed) wait_generation(b->flush_gen, my_gen);
+    // (a later flush may have been issued by now: its sequence number is larger and its completion implies ours)
+    if (need_done && !b->failed.load()) wait_done(b, b->issued_seq.load(std::memory_order_acquire));
     if (b->failed.load()) throw Np2Error(NP2_E_DEVICE, "batch flush failed: " + b->fail_msg);
 }
 

@@ -589,10 +589,17 @@ inline void flush_timings(np2_ctx *cx) {
 // device-to-device copies are kernels (so that they batch across contigs), host transfers are generic recorded
 // operations, a synchronisation flushes the whole group.
 inline void recorder_sync(Recorder *r) {
-    r->sync_fn(r);
+    r->sync_fn(r, true);
     for (auto &g : r->graveyard) // (the flush has waited for the device)
         dev_release_idle(g.first, (g.second >> 63) ? 0 : g.second, (g.second >> 63) ? (g.second & ~(1ull << 63)) : 0);
     r->graveyard.clear();
+}
+// The commands recorded so far are to be issued (with the rest of the batch group's), but the caller goes on with host
+// work that does not need their results: no wait for the device, nothing released.  Without a recorder the launches
+// went straight to the stream: nothing to do.
+inline void op_submit(np2_ctx *cx) {
+    (void)cx;
+    if (Recorder *r = tl_recorder()) r->sync_fn(r, false);
 }
 inline void op_sync(np2_ctx *cx) {
     if (Recorder *r = tl_recorder())

@@ -178,6 +178,7 @@ struct VoteData {
                                       // first HETE region it votes in (0xFFFFFFFF: none); shards: see shard_vote_export
     std::vector<int32_t> ref_w;       // per read: summed weight against the contig's own candidate (ref_data[0])
     std::vector<uint8_t> ref_seen, bad;
+    const uint8_t *d_bad = nullptr;   // the `bad` flags where the vote kernel left them on the device (until the next vote)
 };
 
 // GPU part of the phasing pass: mark_hete (main.rs:916-946), pair votes (948-1002) over the regions whose start lies in
@@ -284,6 +285,7 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         if (!wide) {
             per_read(pin);
             have_per_read = true;
+            vd.d_bad = cx->votepack.p + RP * 9;
             if (!far) {
                 if (NU > likely) { // more pairs than the first copy had room for: fetch the whole piece again
                     pin = (uint8_t *)cx->pin_d2h.ensure(b_v + b_off + (size_t)NU * 4 + 64);
@@ -777,8 +779,7 @@ void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
 // DP + backtrack + LQ regions; returns consensus length M and region count
 // One read-back at the end: consensus length, region count, error word.  The consensus length stays on the device
 // (eoff[L]) while the consensus and the LQ regions are built; launches and buffers are sized by M <= L + T.
-void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T, uint32_t &M,
-                           uint32_t &n_reg) {
+void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T) {
     hipStream_t s = cx->stream;
     const uint32_t L = c->L;
     if ((uint64_t)L + T + 2 >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "consensus bound exceeds 32 bits");
@@ -876,6 +877,10 @@ void consensus_and_regions(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_
         launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
                               cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
     }
+}
+// ... and the read-back that ends the stage: consensus length, region count, the error word
+void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t &M, uint32_t &n_reg) {
+    const uint32_t *M_p = cx->eoff.p + c->L;
     std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
     check_region_err(cx, sc[S_ERR]);
     if (sc[S_BEST] == 0xFFFFFFFFu)
@@ -1030,6 +1035,7 @@ struct PolishRun {
     uint32_t own_lo = 0, own_hi = 0xFFFFFFFFu; // regions this run votes over (sub-contig coordinates)
     uint32_t T = 0, pass = 0, M = 0, n_reg = 0;
     bool reuse = false;
+    bool front_issued = false; // graph, DP, consensus and LQ regions of pass `pass` are already on their way (polish_impl)
     uint32_t grow_prev = 0xFFFFFFFFu; // growth bound of the previous (phasing) pass, read back with its vote for free
     bool wide_votes = false; // the shards of a contig export (a << 32 | b, counts) pairs; the plain pipeline reads compact rows
     PassCounts pc;
@@ -1062,14 +1068,16 @@ void run_pass_front(PolishRun &r) {
     np2_contig *c = r.c;
     if (!r.reuse) {
         uint32_t n_nodes = 0, n_runs = 0;
-        {
+        if (!r.front_issued) {
             WallTimer w(cx, "wall_graph");
             build_graph(cx, c, r.T, n_nodes, n_runs);
         }
         trace_graph(cx, c, (int)r.pass, n_nodes);
         {
             WallTimer w(cx, "wall_cns_lq");
-            consensus_and_regions(cx, c, n_nodes, n_runs, r.T, r.M, r.n_reg);
+            if (!r.front_issued) consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
+            r.front_issued = false;
+            consensus_and_regions_finish(cx, c, r.M, r.n_reg);
         }
         if (cx->trace) {
             trace_cns(cx, (int)r.pass, "cns_raw", fetch_cns(cx, r.M));
@@ -1193,10 +1201,51 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     PolishRun r;
     r.cx = cx, r.c = c, r.o = *o;
     run_begin(r);
+    static const bool no_spec = getenv("NP2_NO_SPECULATE") != nullptr;
     while (!r.final_pass()) {
         VoteData vd;
         run_vote_pass(r, vd);
-        run_apply_losers(r, vote_decide(cx, vd, o->use_all_reads != 0));
+        const bool use_all = o->use_all_reads != 0;
+        // The host side of the vote (key order, rows, Louvain: ~1 ms for a 1.5 Mb diploid contig) is the longest host
+        // phase of a step, and the device has nothing to do for this contig meanwhile.  Without -r the vote kernel has
+        // already flagged the reads that disagree with the contig at a marker (main.rs:977); the Louvain only adds the
+        // reads of conflicting communities AMONG the others, which is rare (never on the synthetic diploid workloads:
+        // the removed reads are exactly the flagged ones).  So the next pass starts on the flagged reads alone — graph, DP,
+        // consensus and LQ regions go to the device BEFORE the host decides —, and if the decision removes more reads
+        // than that the pass is simply started again with them (results are a pure function of the live reads).
+        size_t n_bad = 0;
+        if (vd.any && vd.d_bad && !use_all && !cx->trace && !no_spec)
+            for (uint8_t b : vd.bad) n_bad += b;
+        const bool spec = n_bad > 0;
+        if (spec) {
+            launch_kill_flagged(cx->stream, vd.d_bad, c->R, cx->alive.p);
+            ++r.pass; // (what run_apply_losers does; the pass cannot be a reuse of the last one: reads are going)
+            r.reuse = false;
+            uint32_t n_nodes = 0, n_runs = 0;
+            build_graph(cx, c, r.T, n_nodes, n_runs);
+            consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
+            op_submit(cx);
+        }
+        std::vector<uint32_t> losers = vote_decide(cx, vd, use_all);
+        if (!spec) {
+            run_apply_losers(r, losers);
+            continue;
+        }
+        std::vector<uint32_t> extra; // removed by the decision but not flagged
+        for (uint32_t id : losers) {
+            REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
+            if (!vd.bad[id]) extra.push_back(id);
+        }
+        if (extra.empty() && losers.size() == n_bad && !getenv("NP2_TEST_MISSPECULATE")) { // (test hook: take the other branch)
+            r.front_issued = true; // the pass that is on its way is the right one
+        } else {
+            cx->kill_ids.ensure(extra.size() + 1);
+            if (!extra.empty()) {
+                h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);
+                launch_kill_reads(cx->stream, cx->kill_ids.p, (uint32_t)extra.size(), cx->alive.p);
+            }
+            r.front_issued = false; // started again by run_pass_front
+        }
     }
     run_final_pass(r, result);
 }

@@ -108,6 +108,11 @@ __device__ __forceinline__ void k_init_alive(const uint32_t np2_bid, const uint3
     uint32_t r = np2_bid * blockDim.x + threadIdx.x;
     if (r < R) alive[r] = (reads[r].flags & NP2_READ_DROPPED) ? 0 : 1;
 }
+// the reads the phasing vote flagged on the device (they disagree with the contig's candidate at a marker, main.rs:977)
+__device__ __forceinline__ void k_kill_flagged(const uint32_t np2_bid, const uint32_t np2_nb, const uint8_t *__restrict__ flag, uint32_t n, uint8_t *__restrict__ alive) {
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) alive[i] = 0;
+}
 __device__ __forceinline__ void k_kill_reads(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ ids, uint32_t n, uint8_t *__restrict__ alive) {
     uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i < n) alive[ids[i]] = 0;
@@ -1474,6 +1479,9 @@ void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, cons
 }
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive) {
     NP2_LAUNCH(k_init_alive, grid1(R), 256, s, reads, R, alive);
+}
+void launch_kill_flagged(hipStream_t s, const uint8_t *flag, uint32_t n, uint8_t *alive) {
+    if (n) NP2_LAUNCH(k_kill_flagged, grid1(n), 256, s, flag, n, alive);
 }
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) NP2_LAUNCH(k_kill_reads, grid1(n), 256, s, ids, n, alive);

@@ -98,6 +98,7 @@ void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes
 void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
+void launch_kill_flagged(hipStream_t s, const uint8_t *flag, uint32_t n, uint8_t *alive); // alive[i] = 0 where flag[i]
 // DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
 // the generic kernel (independent of the first: the two may run on different streams); finish: score total, best end
 // node, backtrack of the contig-end run, emission fix-up left of the path start.

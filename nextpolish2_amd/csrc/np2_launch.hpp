@@ -93,7 +93,9 @@ struct Recorder {
     std::vector<uint64_t> arena; // argument packs (8-byte aligned)
     void *group = nullptr;       // owned by the batch driver
     int slot = 0;
-    void (*sync_fn)(Recorder *) = nullptr; // flush every queue of the group, wait for the device
+    // flush every queue of the group; need_done: wait for the device too (false: the commands only have to be on their
+    // way — a pipeline that goes on with host work the device is not needed for)
+    void (*sync_fn)(Recorder *, bool need_done) = nullptr;
     void push_kernel(const KernelDesc *kd, uint32_t grid, const void *args, size_t bytes) {
         Cmd c;
         c.kd = kd;

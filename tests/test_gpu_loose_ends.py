@@ -144,3 +144,42 @@ def test_guessed_growth_allowance_and_its_retry(monkeypatch, small_diploid):
     for bb, pp in bp.polish([c, c], Opts(), want_pos=True):
         assert np.array_equal(bb, ob) and np.array_equal(pp, op)
     bp.close()
+
+
+def test_next_pass_started_before_the_vote_is_decided(monkeypatch, small_diploid):
+    """polish_impl starts the next pass on the reads the vote kernel flagged while the host still decides the vote; when
+    the decision removes other reads as well the pass is started again (NP2_TEST_MISSPECULATE forces that branch);
+    NP2_NO_SPECULATE... is read once per process, so the plain order is covered by the traced runs of every parity test
+    (tracing switches the early start off).  All three must give the oracle's result — also through the batch driver,
+    where the early start is a flush nobody waits for."""
+    import numpy as np
+    from nextpolish2_amd import BatchPolisher, Opts, Polisher
+    from nextpolish2_amd.synth import Synth
+    from oracle.np2_oracle import Oracle
+    s, yaks = small_diploid
+    s2 = Synth(90000, depth=30, seed=23, diploid=True, read_len_mean=9000.0, read_len_sd=1500.0)
+    for opts in (Opts(), Opts(iter_count=3)):
+        ob, op = Oracle(yaks).polish(s.pileup, opts)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("NP2_TEST_MISSPECULATE", env)
+            else:
+                monkeypatch.delenv("NP2_TEST_MISSPECULATE", raising=False)
+            pol = Polisher(yaks)
+            gb, gp = pol.polish(s.pileup, opts)
+            assert np.array_equal(gb, ob) and np.array_equal(gp, op)
+            c = pol.upload(s.pileup)
+            bp = BatchPolisher(pol, 3)
+            for bb, pp in bp.polish([c, c, c], opts, want_pos=True):
+                assert np.array_equal(bb, ob) and np.array_equal(pp, op)
+            bp.close()
+    # contigs of different sizes in one batch: their pipelines reach the early start at different moments
+    y2 = [Synth.yak_assembly([s, s2], k) for k in (21, 31)]
+    o2 = Oracle(y2)
+    exp = [o2.polish(x.pileup, Opts()) for x in (s, s2)]
+    pol = Polisher(y2)
+    cs = [pol.upload(x.pileup) for x in (s, s2)]
+    bp = BatchPolisher(pol, 2)
+    for (bb, pp), (ob, op) in zip(bp.polish(cs, Opts(), want_pos=True), exp):
+        assert np.array_equal(bb, ob) and np.array_equal(pp, op)
+    bp.close()
