@@ -127,7 +127,7 @@ class Groups:
                 inside, tail = self.bps[g].last_call_ms_inside()
                 acc[g][3] += inside
                 acc[g][4] += tail
-                acc[g][5] += sum(sum(f) for f in self.bps[g].flush_log())
+                acc[g][5] += self.bps[g].flush_total_ms()
                 with cv:
                     done[g] = k + 1
                     turn[0] += 1

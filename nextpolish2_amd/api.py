@@ -371,6 +371,12 @@ class BatchPolisher:
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(3 * n,)).copy()
         return [tuple(round(float(x), 3) for x in a[3 * i:3 * i + 3]) for i in range(n)]
 
+    def flush_total_ms(self):
+        """host + issue + wait over the flushes of the last polish call (one number: cheap enough for a timed loop)"""
+        p = C.c_void_p()
+        n = lib().np2_batch_flush_log(self._h, C.byref(p))
+        return float(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(3 * n,)).sum()) if n else 0.0
+
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         lib().np2_batch_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
@@ -382,11 +388,11 @@ class BatchPolisher:
         n = len(contigs)
         o = (opts or Opts()).c()
         hs = (C.c_void_p * n)(*[c._h for c in contigs])
-        ob = (C.c_void_p * n)()
-        op = (C.c_void_p * n)()
-        on = (C.c_uint64 * n)()
-        rcs = (C.c_int * n)()
-        span = (C.c_uint32 * (2 * n))()
+        key = (n, want_pos, keep_on_device)
+        if getattr(self, "_arrs_key", None) != key:  # (the argument arrays of the last call shape are kept)
+            self._arrs = ((C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_uint64 * n)(), (C.c_int * n)(), (C.c_uint32 * (2 * n))())
+            self._arrs_key = key
+        ob, op, on, rcs, span = self._arrs
         import time as _t
         _t0 = _t.perf_counter()
         rc = lib().np2_batch_polish(self._h, hs, n, C.byref(o), None if keep_on_device else ob,

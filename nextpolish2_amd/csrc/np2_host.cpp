@@ -19,6 +19,8 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <future>
+#include <functional>
 #include <vector>
 
 using namespace np2;
@@ -1097,11 +1099,12 @@ void run_pass_front(PolishRun &r) {
 }
 
 // a phasing pass up to the votes (vd.any == false: nobody votes)
-void run_vote_pass(PolishRun &r, VoteData &vd) {
+void run_vote_pass(PolishRun &r, VoteData &vd, const std::function<void()> *after_front = nullptr) {
     np2_ctx *cx = r.cx;
     vd = VoteData();
     vd.R = r.c->R;
     run_pass_front(r);
+    if (after_front) (*after_front)(); // (polish_impl: the previous pass's vote is settled before this pass votes)
     if (r.n_reg == 0) return;
     WallTimer w(cx, "wall_vote");
     const bool may_reuse = cx->reuse_identical_pass && !cx->trace;
@@ -1202,52 +1205,105 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     r.cx = cx, r.c = c, r.o = *o;
     run_begin(r);
     static const bool no_spec = getenv("NP2_NO_SPECULATE") != nullptr;
-    while (!r.final_pass()) {
-        VoteData vd;
-        run_vote_pass(r, vd);
-        const bool use_all = o->use_all_reads != 0;
-        // The host side of the vote (key order, rows, Louvain: ~1 ms for a 1.5 Mb diploid contig) is the longest host
-        // phase of a step, and the device has nothing to do for this contig meanwhile.  Without -r the vote kernel has
-        // already flagged the reads that disagree with the contig at a marker (main.rs:977); the Louvain only adds the
-        // reads of conflicting communities AMONG the others, which is rare (never on the synthetic diploid workloads:
-        // the removed reads are exactly the flagged ones).  So the next pass starts on the flagged reads alone — graph, DP,
-        // consensus and LQ regions go to the device BEFORE the host decides —, and if the decision removes more reads
-        // than that the pass is simply started again with them (results are a pure function of the live reads).
+    const bool use_all = o->use_all_reads != 0;
+    // The host side of the vote (key order, rows, Louvain: ~1 ms for a 1.5 Mb diploid contig, 100 ms for a chromosome) is
+    // the longest host phase of a contig, and the device has nothing to do for it meanwhile.  Without -r the vote kernel
+    // has already flagged the reads that disagree with the contig at a marker (main.rs:977); the Louvain only adds the
+    // reads of conflicting communities AMONG the others, which is rare (never on the synthetic diploid workloads: the
+    // removed reads are exactly the flagged ones).  So the vote is decided on a helper thread (a contig on its own
+    // context) or next to the first part of the pass (batch driver) while this pipeline goes on
+    // with the next pass on the flagged reads alone: its graph, DP, consensus and LQ regions go to the device at once
+    // (a flush nobody waits for in the batch driver), the rest of the pass follows; the decision is awaited before the
+    // next vote is collected, or before the result is handed out, and if it removes other reads as well the pass is
+    // simply done again with them (its results are a pure function of the live reads).
+    struct Decision {
+        std::vector<uint32_t> losers;
+        double ms = 0;
+    };
+    struct Pending {
+        std::future<Decision> fut;
+        std::shared_ptr<VoteData> vd;
         size_t n_bad = 0;
-        if (vd.any && vd.d_bad && !use_all && !cx->trace && !no_spec)
-            for (uint8_t b : vd.bad) n_bad += b;
-        const bool spec = n_bad > 0;
-        if (spec) {
-            launch_kill_flagged(cx->stream, vd.d_bad, c->R, cx->alive.p);
-            ++r.pass; // (what run_apply_losers does; the pass cannot be a reuse of the last one: reads are going)
-            r.reuse = false;
-            uint32_t n_nodes = 0, n_runs = 0;
-            build_graph(cx, c, r.T, n_nodes, n_runs);
-            consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
-            op_submit(cx);
+        bool active = false;
+    } pend;
+    // -> true if the pass under way is the right one; false: the reads the decision removes beyond the flagged ones are
+    // taken out now and the pass has to be done again
+    auto settle = [&]() -> bool {
+        if (!pend.active) return true;
+        pend.active = false;
+        Decision d = pend.fut.get(); // (rethrows what the decision threw: the reference's panics)
+        cx->timing.host.push_back({"wall_louvain", (float)d.ms});
+        std::vector<uint32_t> extra;
+        for (uint32_t id : d.losers) {
+            REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
+            if (!pend.vd->bad[id]) extra.push_back(id);
         }
-        std::vector<uint32_t> losers = vote_decide(cx, vd, use_all);
-        if (!spec) {
-            run_apply_losers(r, losers);
+        if (extra.empty() && d.losers.size() == pend.n_bad && !getenv("NP2_TEST_MISSPECULATE")) return true; // (test hook)
+        if (!extra.empty()) {
+            cx->kill_ids.ensure(extra.size() + 1);
+            h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);
+            launch_kill_reads(cx->stream, cx->kill_ids.p, (uint32_t)extra.size(), cx->alive.p);
+        }
+        r.reuse = false;
+        r.front_issued = false;
+        return false;
+    };
+    const std::function<void()> settle_then_redo = [&]() {
+        if (!settle()) run_pass_front(r); // (again, on the right reads)
+    };
+    while (!r.final_pass()) {
+        auto vd = std::make_shared<VoteData>();
+        run_vote_pass(r, *vd, &settle_then_redo);
+        size_t n_bad = 0;
+        if (vd->any && vd->d_bad && !use_all && !cx->trace && !no_spec)
+            for (uint8_t b : vd->bad) n_bad += b;
+        if (n_bad == 0) {
+            run_apply_losers(r, vote_decide(cx, *vd, use_all));
             continue;
         }
-        std::vector<uint32_t> extra; // removed by the decision but not flagged
-        for (uint32_t id : losers) {
-            REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
-            if (!vd.bad[id]) extra.push_back(id);
-        }
-        if (extra.empty() && losers.size() == n_bad && !getenv("NP2_TEST_MISSPECULATE")) { // (test hook: take the other branch)
-            r.front_issued = true; // the pass that is on its way is the right one
+        launch_kill_flagged(cx->stream, vd->d_bad, c->R, cx->alive.p);
+        ++r.pass; // (what run_apply_losers does; the pass cannot be a reuse of the last one: reads are going)
+        r.reuse = false;
+        uint32_t n_nodes = 0, n_runs = 0;
+        build_graph(cx, c, r.T, n_nodes, n_runs);
+        consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
+        r.front_issued = true;
+        op_submit(cx);
+        vd->own(); // (the pairs sit in the context's read-back staging, which the pipeline goes on using)
+        pend.vd = vd;
+        pend.n_bad = n_bad;
+        pend.active = true;
+        auto decide = [vd, use_all]() {
+            Decision d;
+            const double t0 = now_ms();
+            d.losers = vote_decide(nullptr, *vd, use_all);
+            d.ms = now_ms() - t0;
+            return d;
+        };
+        if (tl_recorder() == nullptr) {
+            // one contig on its own context (a chromosome: ~100 ms of host vote next to ~50 ms of device work for the pass)
+            pend.fut = std::async(std::launch::async, decide);
         } else {
-            cx->kill_ids.ensure(extra.size() + 1);
-            if (!extra.empty()) {
-                h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);
-                launch_kill_reads(cx->stream, cx->kill_ids.p, (uint32_t)extra.size(), cx->alive.p);
+            // Under the batch driver the decision is taken here and now, next to the part of the pass that is already on
+            // its way: with four batch groups the device is the busy part of a step, and seventeen more host threads
+            // deciding votes beside the pipelines' own cost more than the rest of the overlap gave (3.72 ms per
+            // yeast-sized assembly this way, 3.9 - 4.1 with helper threads; 4.06 without any early start).
+            std::promise<Decision> p;
+            pend.fut = p.get_future();
+            try {
+                p.set_value(decide());
+            } catch (...) {
+                p.set_exception(std::current_exception());
             }
-            r.front_issued = false; // started again by run_pass_front
+            (void)settle(); // (a decision that removes more reads: the pass is started again by the next run_pass_front)
         }
     }
-    run_final_pass(r, result);
+    for (;;) {
+        run_final_pass(r, result);
+        if (settle()) break;
+        if (result.bases) pinned_pool().put(result.bases), result.bases = nullptr;
+        if (result.pos) pinned_pool().put(result.pos), result.pos = nullptr;
+    }
 }
 
 
