@@ -584,9 +584,8 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     for (uint32_t h = 0; h < RM_RPW; ++h) {
         pjv[h] = 0, pcv[h] = 0, tev[h] = 0, rpos[h] = 0xFFFFFFFFu, rq[h] = 0;
         if (rr[h] != 0xFFFFFFFFu) {
-            const ReadInfo *ri = cx.rinfo + rr[h];
-            const uint2 pp = *reinterpret_cast<const uint2 *>(&ri->pj);
-            pjv[h] = pp.x, pcv[h] = pp.y, tev[h] = ri->aln_t_e;
+            const uint4 q = *reinterpret_cast<const uint4 *>(&cx.rinfo[rr[h]].aln_t_e); // (the pairing half: one request)
+            tev[h] = q.x, pjv[h] = q.y, pcv[h] = q.z;
         }
         const uint32_t i = lo[h] + lane; // first 64 records of the window
         if (i < hi[h]) {

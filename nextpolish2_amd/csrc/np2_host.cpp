@@ -1450,6 +1450,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     c->nib_bytes = nib_bytes;
     c->n_cols = cols;
     c->n_ckpt = ck[n_reads];
+    if (c->n_ckpt >> 32) throw Np2Error(NP2_E_NOMEM, "too many pileup columns for one contig (checkpoint offsets are 32-bit)");
     c->n_chunks = n_descs;
     c->reads.ensure(n_reads);
     const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds

@@ -1271,7 +1271,7 @@ __device__ __forceinline__ void k_pair_count(const uint32_t np2_bid, const uint3
     }
     pj[r] = j;
     pcount[r] = cnt;
-    rinfo[r] = ReadInfo{rd.aln_t_s, rd.n_cols, (uint32_t)(rd.nib_off >> 4), rd.aln_t_e, ck_off[r], j, cnt};
+    rinfo[r] = ReadInfo{rd.aln_t_s, rd.n_cols, (uint32_t)(rd.nib_off >> 4), (uint32_t)ck_off[r], rd.aln_t_e, j, cnt, 0u};
 }
 
 // ------------------------------------------------------------------------------------------

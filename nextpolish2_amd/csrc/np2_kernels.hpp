@@ -45,11 +45,14 @@ struct GraphPtrs {
 // what candidate extraction needs to know about a read, in one 32-byte line (built per pass by k_pair_count: a
 // (region, read) pair then costs one memory transaction for the read instead of six scattered ones)
 struct __attribute__((aligned(16))) ReadInfo {
+    // first half: what decoding a candidate needs
     uint32_t aln_t_s, n_cols;
     uint32_t nib16;        // nib_off / 16 (nibble streams are 16-byte aligned; a contig's pileup stays below 64 GiB)
+    uint32_t ck_off;       // first checkpoint of the read (a contig has fewer than 2^32 of them: 137 G pileup columns)
+    // second half: what pairing a read with a region needs — ONE 16-byte request per (read, region) pair
     uint32_t aln_t_e;      // inclusive last position
-    uint64_t ck_off;       // first checkpoint of the read
     uint32_t pj, pcount;   // the read's region interval [pj, pj + pcount); 0 regions for a dropped read
+    uint32_t pad;
 };
 struct CandPtrs {
     const np2_read_t *reads;
