@@ -312,9 +312,12 @@ def main(argv=None):
                     tls.pol = b0 if not base else b0.clone()
                     base.append(tls.pol)
             t_p = time.time()
+            if prof:
+                tls.pol.set_timing(True)
             bases, pos = tls.pol.polish_resident(contig, opts, want_pos=a.out_pos)
             if prof:
-                print(f"[np2 profile] {name}: polish {1e3 * (time.time() - t_p):.1f} ms (done at +{time.time() - t0:.3f} s)", file=sys.stderr)
+                tm = {k: round(v, 1) for k, v in tls.pol.timings().items() if k.startswith("wall_") and v >= 1.0}
+                print(f"[np2 profile] {name}: polish {1e3 * (time.time() - t_p):.1f} ms (done at +{time.time() - t0:.3f} s); host clock per stage (ms): {tm}", file=sys.stderr)
         finally:
             contig.free()
         b = bases.tobytes()

@@ -167,7 +167,7 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                             v = (uint32_t)sw;
                             break;
                         }
-                        if (lb_gave_up(spins, t_wait0)) { // (20 s of wall clock: np2_lookback.hpp)
+                        if (lb_gave_up(spins, t_wait0)) { // (4 s of wall clock: np2_lookback.hpp)
                             timeout = true;
                             break;
                         }

@@ -78,6 +78,15 @@ for rep in range(2):
     same = open(out, "rb").read() == want
     log(f"run {rep}: nextPolish2 (one rank) {dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {rc}, FASTA == resident path: {same}")
 env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+# the same command as a process of its own (what a user runs: interpreter + HIP start-up included, nothing warm)
+out1 = os.path.join(td, "fresh.fa")
+t = time.time()
+r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-t", "2", "-o", out1, bam, fa] + ypaths, env=env, cwd=ROOT,
+                   capture_output=True, timeout=900)
+dt = time.time() - t
+sys.stderr.write(r.stderr.decode()[-4000:])
+log(f"fresh process: nextPolish2 {dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {r.returncode}, FASTA == resident path: "
+    f"{r.returncode == 0 and open(out1, 'rb').read() == want}")
 out2 = os.path.join(td, "two.fa")
 t = time.time()
 r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
