@@ -65,21 +65,22 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         bool live;
     } dd[DENSE_CPW];
     {
+        // (the wave's chunk indices are uniform: the descriptors arrive as scalar loads, all requested together, and cost
+        // no VALU issue slot; the copy phase 2 reads goes to LDS from lanes 0..CPW-1 as three 16-byte pieces each)
         const uint32_t ch0 = DENSE_CPW * pw;
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
         if (lane < DENSE_CPW && ch0 + lane < n_chunks) {
             const uint4 *p = reinterpret_cast<const uint4 *>(descs + ch0 + lane);
-            q0 = p[0], q1 = p[1], q2 = p[2];
+            const uint4 q0 = p[0], q1 = p[1], q2 = p[2];
             uint4 *d = reinterpret_cast<uint4 *>(&s_desc[ch0 + lane - blk_first]); // (read after the block's barriers)
             d[0] = q0, d[1] = q1, d[2] = q2;
         }
-        auto rl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
 #pragma unroll
         for (uint32_t it = 0; it < DENSE_CPW; ++it) {
-            dd[it].nib_off = (uint64_t)rl(q0.x, it) | ((uint64_t)rl(q0.y, it) << 32);
-            dd[it].ckbase = (uint64_t)rl(q0.z, it) | ((uint64_t)rl(q0.w, it) << 32);
-            dd[it].read = rl(q1.x, it), dd[it].ts = rl(q1.y, it), dd[it].c0 = rl(q1.z, it), dd[it].ncols = rl(q1.w, it);
-            dd[it].first_chunk = rl(q2.x, it), dd[it].aln_t_e = rl(q2.y, it), dd[it].nck = rl(q2.z, it);
+            const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(ch0 + it, n_chunks - 1));
+            const ChunkDesc *dp = descs + ci;
+            dd[it].nib_off = dp->nib_off, dd[it].ckbase = dp->ckbase;
+            dd[it].read = dp->read, dd[it].ts = dp->ts, dd[it].c0 = dp->c0, dd[it].ncols = dp->ncols;
+            dd[it].first_chunk = dp->first_chunk, dd[it].aln_t_e = dp->aln_t_e, dd[it].nck = dp->nck;
             dd[it].live = ch0 + it < n_chunks;
         }
     }

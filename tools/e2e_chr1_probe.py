@@ -58,6 +58,25 @@ with open(fa, "wb") as f:
     f.write(b">chr1\n" + pu.ref.tobytes() + b"\n")
 log(f"BAM {os.path.getsize(bam) / 2**30:.2f} GiB (+ .bai), FASTA written in {time.time() - t:.1f} s")
 del parts
+env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", NP2_CLI_PROFILE="1", NP2_IO_PROFILE="1")
+first_outs = []
+if os.environ.get("NP2_E2E_FRESH_FIRST"):
+    # Before this process has touched the GPU: the command as the first user of the device, then again at once (the previous
+    # process's ~58 GB of HBM were freed a moment ago), then after a pause.  NP2_E2E_THREADS: its -t.
+    # NP2_E2E_FRESH_FIRST = "pause:threads,..." (default: at once, at once, after 12 s, at once; -t 2)
+    spec = os.environ["NP2_E2E_FRESH_FIRST"]
+    plan = [(0, "2"), (0, "2"), (12, "2"), (0, "2")] if spec == "1" else [(int(x.split(":")[0]), x.split(":")[1]) for x in spec.split(",")]
+    for rep, (pause, nt) in enumerate(plan):
+        time.sleep(pause)
+        o = os.path.join(td, f"first{rep}.fa")
+        t = time.time()
+        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-t", nt, "-o", o, bam, fa] + ypaths, env=env, cwd=ROOT,
+                           capture_output=True, timeout=900)
+        dt = time.time() - t
+        sys.stderr.write(r.stderr.decode()[-4000:])
+        sys.stderr.flush()
+        log(f"fresh process {rep} (-t {nt}, started {pause} s after the previous one ended): {dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {r.returncode}")
+        first_outs.append(o)
 # the resident path's answer
 t = time.time()
 pol = Polisher(yaks)
@@ -68,6 +87,10 @@ c.free()
 pol.close()
 del pol, yaks
 log(f"resident path (tables, upload, polish): {time.time() - t:.1f} s")
+for o in first_outs:
+    log(f"{os.path.basename(o)} == resident path: {open(o, 'rb').read() == want}")
+if os.environ.get("NP2_E2E_ONLY_FRESH"):
+    sys.exit(0)
 os.environ["NP2_CLI_PROFILE"] = "1"
 os.environ["NP2_IO_PROFILE"] = "1"
 for rep in range(2):
@@ -87,6 +110,15 @@ dt = time.time() - t
 sys.stderr.write(r.stderr.decode()[-4000:])
 log(f"fresh process: nextPolish2 {dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {r.returncode}, FASTA == resident path: "
     f"{r.returncode == 0 and open(out1, 'rb').read() == want}")
+trace = os.environ.get("NP2_E2E_TRACE")
+if trace:  # the same process under rocprofv3 (kernel + HIP API timeline: tools/trace_stalls.py reads it)
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--hip-trace", "--output-format", "csv", "-d", trace, "--", sys.executable, "-m",
+                        "nextpolish2_amd.cli", "-t", "2", "-o", os.path.join(td, "traced.fa"), bam, fa] + ypaths, env=env, cwd=ROOT,
+                       capture_output=True, timeout=900)
+    sys.stderr.write(r.stderr.decode()[-3000:])
+    log(f"traced run rc {r.returncode}")
+if os.environ.get("NP2_E2E_SKIP_2RANK"):
+    sys.exit(0)
 out2 = os.path.join(td, "two.fa")
 t = time.time()
 r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
