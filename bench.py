@@ -153,6 +153,18 @@ class Groups:
                 sum(x[2] for x in acc) / max(1, steps * G))
 
 
+def thread_cpu_ns():
+    """run time in ns of every thread of this process so far (schedstat), with its name"""
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            ns = int(open(f"/proc/self/task/{tid}/schedstat").read().split()[0])
+            out[int(tid)] = (ns, open(f"/proc/self/task/{tid}/comm").read().strip())
+        except Exception:
+            pass
+    return out
+
+
 def cpu_throttle_stat():
     """(periods, throttled periods, throttled microseconds) of this container's CPU quota so far (cgroup v2), or None"""
     try:
@@ -624,6 +636,7 @@ def main():
     time.sleep(float(os.environ.get("NP2_BENCH_SETTLE_S", "0.3")))
     sync()
     thr0 = cpu_throttle_stat()
+    thr_cpu0 = thread_cpu_ns()
     cpu_t0 = time.process_time()
     t0 = time.perf_counter()
     if single:
@@ -641,6 +654,14 @@ def main():
     dt = time.perf_counter() - t0
     cpu_dt = time.process_time() - cpu_t0
     thr1 = cpu_throttle_stat()
+    thr_cpu1 = thread_cpu_ns()
+    by_name = {}
+    for tid, (ns, name) in thr_cpu1.items():
+        d = ns - thr_cpu0.get(tid, (0, name))[0]
+        if d > 0:
+            e = by_name.setdefault(name, [0, 0.0])
+            e[0] += 1
+            e[1] += d / 1e9
     gc.enable()
     flush_log = [] if single else [b.flush_log() for b in groups.bps]
     excl = None
@@ -695,6 +716,7 @@ def main():
                      "batch_call_ms_mean": round(float(call_ms), 3) if not single else None,
                      "call_breakdown_ms_per_group": None if single else call_breakdown},
         "host_cpu": {"cpu_seconds_per_wall_second": round(cpu_dt / dt, 2),
+                     "by_thread_name": {k: {"threads": v[0], "cpus": round(v[1] / dt, 2)} for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:8]},
                      "quota_periods_throttled_in_timed_region": None if not (thr0 and thr1) else thr1[1] - thr0[1],
                      "throttled_ms_in_timed_region": None if not (thr0 and thr1) else round((thr1[2] - thr0[2]) / 1e3, 2)},
     }

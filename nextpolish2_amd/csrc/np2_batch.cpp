@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <pthread.h>
 
 #include <linux/futex.h>
 #include <sys/syscall.h>
@@ -94,7 +95,8 @@ namespace {
 // in tens of microseconds), then it sleeps on the generation word.  (Spinning for the whole wait had every waiting
 // pipeline of every batch group hold a core: 60+ busy host threads for one GPU.)
 inline void wait_generation(std::atomic<uint32_t> &gen, uint32_t seen) {
-    static const double spin_us = getenv("NP2_BATCH_SPIN_US") ? atof(getenv("NP2_BATCH_SPIN_US")) : 30.0;
+    // (30 us until round 4: 1.5 CPUs of a rank's 6.9 went into it for no measurable gain — profiles/r04_host_cpu.txt)
+    static const double spin_us = getenv("NP2_BATCH_SPIN_US") ? atof(getenv("NP2_BATCH_SPIN_US")) : (wait_naps() ? 0.0 : 5.0);
     const double t_end = now_ms() + spin_us * 1e-3;
     for (;;) {
         for (int i = 0; i < 64; ++i) {
@@ -251,9 +253,10 @@ void wait_done(np2_batch *b, uint32_t seq) {
         if (b->spinner.compare_exchange_strong(expected, true)) {
             uint64_t spins = 0;
             uint32_t cur;
+            HostWait hw; // (spins, or naps when the process is short of CPUs: np2_ctx.hpp)
             while ((int32_t)((cur = __atomic_load_n(b->done_host, __ATOMIC_ACQUIRE)) - seq) < 0) {
                 if (b->failed.load()) break;
-                if ((++spins & 0xFFFF) == 0) {
+                if ((++spins & (wait_naps() ? 0xFFu : 0xFFFFu)) == 0) {
                     hipError_t e = hipStreamQuery(b->stream);
                     if (e != hipSuccess && e != hipErrorNotReady) {
                         b->fail_msg = std::string("device error during a batch flush: ") + hipGetErrorString(e);
@@ -266,7 +269,7 @@ void wait_done(np2_batch *b, uint32_t seq) {
                         break;
                     }
                 }
-                __builtin_ia32_pause();
+                hw.pause();
             }
             b->spinner.store(false);
             publish_generation(b->done_pub, b->failed.load() ? pub + 1 : cur); // (wakes the sleepers either way)
@@ -327,6 +330,7 @@ void leave_wave(np2_batch *b, Recorder *r) {
 
 void worker_main(np2_batch *b, int slot) {
     (void)hipSetDevice(b->device);
+    (void)pthread_setname_np(pthread_self(), "np2-slot"); // (bench.py's per-thread CPU accounting reads the names)
     uint64_t seen = 0;
     for (;;) {
         Job job;

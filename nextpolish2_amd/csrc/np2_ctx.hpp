@@ -3,6 +3,7 @@
 #include "../../include/np2.h"
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
+#include "np2_hostcpu.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -18,6 +19,7 @@
 #include <vector>
 
 namespace np2h {
+
 using namespace np2;
 
 
@@ -523,10 +525,15 @@ static_assert(S_M1 % 2 == 0 && S_LAST0 % 2 == 0 && S_GAIN0 % 2 == 0, "64-bit dev
 static constexpr int NP2_MAX_YAK = 15; // splice rounds 0 .. n_yak index mlen[16] and the counters behind S_COUNT
 static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it
 
-struct WallTimer {
+inline double thread_cpu_ms() { // CPU time of the calling thread
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+struct WallTimer { // host clock of a stage, and the CPU time the calling thread spent in it ("cpu" + name without "wall")
     np2_ctx *cx;
     const char *name;
-    double t0;
+    double t0, c0 = 0;
     WallTimer(np2_ctx *c, const char *n);
     ~WallTimer();
 };
@@ -550,9 +557,12 @@ struct EventTimer {
     }
 };
 
-inline WallTimer::WallTimer(np2_ctx *c, const char *n) : cx(c), name(n), t0(c->stage_timing ? now_ms() : 0.0) {}
+inline WallTimer::WallTimer(np2_ctx *c, const char *n) : cx(c), name(n), t0(c->stage_timing ? now_ms() : 0.0), c0(c->stage_timing ? thread_cpu_ms() : 0.0) {}
 inline WallTimer::~WallTimer() {
-    if (cx->stage_timing) cx->timing.host.push_back({name, (float)(now_ms() - t0)});
+    if (cx->stage_timing) {
+        cx->timing.host.push_back({name, (float)(now_ms() - t0)});
+        if (strncmp(name, "wall", 4) == 0) cx->timing.host.push_back({std::string("cpu") + (name + 4), (float)(thread_cpu_ms() - c0)});
+    }
 }
 
 inline void flush_timings(np2_ctx *cx) {
@@ -691,8 +701,10 @@ inline std::vector<uint32_t> fetch_scal(np2_ctx *cx, uint32_t *d0, const uint32_
         return std::vector<uint32_t>(cx->mbox_host + 1, cx->mbox_host + 1 + S_COUNT);
     }
     uint64_t spins = 0;
+    HostWait hw;
     while (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq) {
-        if ((++spins & 0xFFFF) == 0) { // a failed launch / device fault would never post: surface it
+        hw.pause();
+        if ((++spins & (wait_naps() ? 0xFFu : 0xFFFFu)) == 0) { // a failed launch / device fault would never post: surface it
             hipError_t e = hipStreamQuery(cx->stream);
             if (e != hipSuccess && e != hipErrorNotReady)
                 throw Np2Error(NP2_E_DEVICE, std::string("device error while waiting for the mailbox: ") + hipGetErrorString(e));

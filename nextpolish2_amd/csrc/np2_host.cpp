@@ -1669,10 +1669,11 @@ int np2_polish_resident(np2_ctx_t *cx, np2_contig_t *c, const np2_opts_t *opts, 
     ResultOut r;
     r.want_pos = out_pos != nullptr;
     r.want_bases = out_bases != nullptr;
-    const double t_wall0 = now_ms();
+    const double t_wall0 = now_ms(), t_cpu0 = thread_cpu_ms();
     try {
         polish_impl(cx, c, opts, r);
         cx->timing.host.push_back({"wall_polish", (float)(now_ms() - t_wall0)});
+        cx->timing.host.push_back({"cpu_polish", (float)(thread_cpu_ms() - t_cpu0)});
         flush_timings(cx);
     } catch (const Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream);

@@ -265,38 +265,10 @@ class IoPool {
             (*j.fn)(i);
         }
     }
-    // CPUs this process may actually use: the cgroup's CFS quota where there is one (a container that sees 256 hardware
-    // threads may be allowed 16 CPUs' worth of time: 64 inflate threads then spend their time throttled), else the
-    // hardware's count
-    static unsigned usable_cpus() {
-        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
-            char q[64];
-            unsigned long long per = 0;
-            if (fscanf(f, "%63s %llu", q, &per) == 2 && per && strcmp(q, "max") != 0)
-                hw = std::min<unsigned>(hw, (unsigned)std::max<unsigned long long>(1, (strtoull(q, nullptr, 10) + per - 1) / per));
-            fclose(f);
-        } else {
-            long long quota = -1, per = 0; // cgroup v1
-            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-                if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-                fclose(g);
-            }
-            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (fscanf(g, "%lld", &per) != 1) per = 0;
-                fclose(g);
-            }
-            if (quota > 0 && per > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + per - 1) / per));
-        }
-        return hw;
-    }
     IoPool() {
         // sized by the hardware, not by the quota: the pool works in bursts of a few milliseconds (one contig's inflate),
         // which a CFS quota does not throttle — measured on a box with 256 hardware threads and a quota of 16 CPUs: an
         // E. coli-sized contig's records arrive in 8 ms with 64 workers and in 18 ms with 16
-        (void)&usable_cpus;
         unsigned hw = std::thread::hardware_concurrency();
         unsigned n = std::min<unsigned>(64, std::max<unsigned>(2, hw / 2));
         if (const char *e = getenv("NP2_IO_THREADS")) n = (unsigned)std::max(1, atoi(e));

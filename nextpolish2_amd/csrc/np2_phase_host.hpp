@@ -20,6 +20,7 @@
 #include <exception>
 #include <thread>
 #include <utility>
+#include "np2_hostcpu.hpp"
 #include <vector>
 
 namespace np2 {
@@ -32,7 +33,7 @@ namespace phase {
 inline unsigned host_threads() {
     static const unsigned n = [] {
         if (const char *e = getenv("NP2_VOTE_THREADS")) return (unsigned)std::max(1, atoi(e));
-        return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::min(16u, std::max(1u, np2h::usable_cpus() / np2h::local_ranks())); // (this rank's share of the allowed CPUs)
     }();
     return n;
 }
