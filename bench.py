@@ -42,7 +42,11 @@ PMC_TRAFFIC = {"yeast": int((2 * 37482.8 + 38299.1) * 1024), "ecoli": int((2 * 5
 def make_assembly(lengths, depth, seed0, diploid):
     from nextpolish2_amd.synth import Synth
     def one(a):
-        s = Synth(a[1], depth=depth, seed=seed0 + a[0], diploid=diploid, name=f"chr{a[0] + 1}")
+        kw = {}
+        if os.environ.get("NP2_BENCH_ERR_SCALE"):  # experiments only: error rates of the generator scaled (0 = none)
+            f = float(os.environ["NP2_BENCH_ERR_SCALE"])
+            kw = dict(read_err_rate=0.002 * f, asm_err_rate=1e-4 * f, snp_rate=0.005 * f, hap_indel_rate=0.002 * f)
+        s = Synth(a[1], depth=depth, seed=seed0 + a[0], diploid=diploid, name=f"chr{a[0] + 1}", **kw)
         # reads in coordinate order (ties in generation order), the order a sorted BAM presents them in: the resident
         # pileups and the BAM written from the same generator (Synth.bam_records) then describe the same input
         r = s.pileup.reads
