@@ -530,7 +530,7 @@ __device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const u
     __shared__ uint32_t s_len[RM_REG][64];
     __shared__ uint32_t s_col[RM_REG][64];
     __shared__ uint32_t s_q[4][RM_RPW * 64]; // one queue per wavefront: the wavefronts of a block never wait for each other
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: the region-level loads below are scalar)
     const uint32_t n_mb = (n_reg + 3) / 4, g0 = (np2_bid * 4 + wv) * RM_RPW, mb0 = g0 / 4;
     uint32_t nq = 0; // (uniform)
     // (A) The four regions of a wavefront go through every step TOGETHER: each step is a chain link of dependent loads
@@ -796,7 +796,7 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
     __shared__ uint32_t s_so[RM_REG][64];
     __shared__ uint32_t s_oc[RM_REG];
     __shared__ uint32_t s_q[4][RM_RPW * 64]; // one queue per wavefront
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g0 = (np2_bid * 4 + wv) * RM_RPW, mb0 = g0 / 4;
     uint32_t nq = 0; // (uniform)
     uint32_t oc = 0, ob = 0; // (running over the wavefront's regions: the groups of 4 follow each other)
@@ -926,7 +926,8 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum) {
     if (n_reg)
-        NP2_LAUNCH(k_region_measure, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
+        NP2_LAUNCH_WAVES(k_region_measure, 8, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, // (65 registers without the floor: 7 waves)
+                         mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
 void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg, uint32_t *blk_coff, uint32_t *blk_soff,

@@ -97,7 +97,7 @@ __device__ __forceinline__ void k_columnarise(const uint32_t np2_bid, const uint
                                                      const uint8_t *__restrict__ seq4, uint8_t *__restrict__ nib,
                                                      FrontOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); // (one record per wavefront)
     if (r >= n_recs) return;
     const FrontRec rc = recs[r];
     const uint32_t N = rc.n_cols;

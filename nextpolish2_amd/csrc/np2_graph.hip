@@ -422,8 +422,11 @@ __device__ __forceinline__ void k_tile_offsets_lb(const uint32_t np2_bid, const 
 // the packed DP records, node_off for every position of the tile and the tile's dirty-run starts.
 // Fast path (tile has at most TW_CAP records): records and nodes are staged in LDS, grouping and per-position
 // ordering never touch global memory.  Larger tiles take the same steps on the global arrays.
-// (992, not 1024: 32 076 bytes of LDS per block instead of 32 840 — five blocks per CU instead of four)
-static constexpr uint32_t TW_CAP = 992;
+// LDS per block decides how many tiles a CU works on at once, and a tile's time is a chain of a dozen barriers and three
+// levels of dependent loads: the node arrays (key, count, first read) live in the memory of the staged records, which are
+// dead by the time the nodes are written (every thread keeps its own four record keys in registers across the barrier
+// in between) — 19.9 KB per block = 8 blocks per CU (with separate arrays: 32 KB = 5; round 4)
+static constexpr uint32_t TW_CAP = 960;
 
 __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint64_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ vals, TileLayout tl,
@@ -442,11 +445,12 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
     __shared__ int32_t dcov[TILE + 1];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t prevd;
-    __shared__ uint64_t s_k[TW_CAP];    // record keys
-    __shared__ uint32_t s_v[TW_CAP];    // record read | live << 31
-    __shared__ uint32_t s_nkey[TW_CAP]; // node: bases | delta << 16
-    __shared__ uint32_t s_ncnt[TW_CAP];
-    __shared__ uint32_t s_nmin[TW_CAP];
+    __shared__ __attribute__((aligned(8))) uint32_t s_raw[3 * TW_CAP];
+    uint64_t *const s_k = reinterpret_cast<uint64_t *>(s_raw); // record keys          } until the barrier that follows the
+    uint32_t *const s_v = s_raw + 2 * TW_CAP;                  // record read | live << 31 } grouping of the records
+    uint32_t *const s_ncnt = s_raw;                            // node: live members      } from then on
+    uint32_t *const s_nmin = s_raw + TW_CAP;                   // node: first live read   }
+    uint32_t *const s_nkey = s_raw + 2 * TW_CAP;               // node: bases | delta << 16 }
     __shared__ long long s_gain[4];
     __shared__ uint32_t s_wt[16];
     const uint32_t tid = threadIdx.x;
@@ -533,13 +537,15 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
         // (two barriers) per slice
         bool isn[4];
         uint32_t gcv[4], gmv[4], lr[4];
-        const uint32_t lane = tid & 63, wv = tid >> 6;
+        uint64_t kown[4]; // (the thread's own record keys: the node arrays overwrite the staged records below)
+        const uint32_t lane = tid & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t i = tid + 256 * j;
-            isn[j] = false, gcv[j] = 0, gmv[j] = 0xFFFFFFFFu;
+            isn[j] = false, gcv[j] = 0, gmv[j] = 0xFFFFFFFFu, kown[j] = 0;
             if (i < n) {
                 const uint64_t k = s_k[i];
+                kown[j] = k;
                 if (i == 0 || s_k[i - 1] != k) {
                     uint32_t gc = 0, gm = 0xFFFFFFFFu;
                     for (uint32_t jj = i; jj < n && s_k[jj] == k; ++jj) {
@@ -572,8 +578,7 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             if (isn[j]) {
-                const uint32_t i = tid + 256 * j;
-                const uint64_t k = s_k[i];
+                const uint64_t k = kown[j];
                 const uint32_t li = base + before_w[j] + lr[j]; // node index inside the tile
                 s_nkey[li] = (uint32_t)k;                       // bases << 16 | delta1 in the key's low word
                 s_ncnt[li] = gcv[j];
@@ -590,39 +595,19 @@ __device__ __forceinline__ void k_tile_write(const uint32_t np2_bid, const uint3
         bool isnode = false;
         uint64_t k = 0;
         if (i < n) {
-            if (fast) {
-                k = s_k[i];
-                if (i == 0 || s_k[i - 1] != k) {
-                    for (uint32_t j = i; j < n && s_k[j] == k; ++j) {
-                        const uint32_t v = s_v[j];
-                        if (v >> 31) {
-                            ++gc;
-                            gm = min(gm, v & 0x7FFFFFFFu);
-                        }
-                    }
-                    isnode = gc != 0;
-                }
-            } else {
-                k = keys[a + i];
-                isnode = group_head(keys, vals, alive, a + i, a, b, gc, gm);
-            }
+            k = keys[a + i];
+            isnode = group_head(keys, vals, alive, a + i, a, b, gc, gm);
         }
         uint32_t tot;
         const uint32_t rank = block_excl_scan_256(isnode ? 1u : 0u, sh, tot);
         if (isnode) {
             const uint32_t li = carry + rank; // node index inside the tile
             const uint32_t q = (uint32_t)(k >> 32) - start;
-            if (fast) {
-                s_nkey[li] = (uint32_t)k; // bases << 16 | delta1 in the key's low word
-                s_ncnt[li] = gc;
-                s_nmin[li] = gm;
-            } else {
-                const uint32_t o = nbase + li;
-                nd.bases[o] = (uint16_t)(k >> 16);
-                nd.delta[o] = (uint16_t)k;
-                nd.count[o] = gc;
-                nd.minr[o] = gm;
-            }
+            const uint32_t o = nbase + li;
+            nd.bases[o] = (uint16_t)(k >> 16);
+            nd.delta[o] = (uint16_t)k;
+            nd.count[o] = gc;
+            nd.minr[o] = gm;
             atomicAdd(&cnt[q], 1u);
         }
         carry += tot;

@@ -1403,7 +1403,8 @@ __device__ __forceinline__ uint16_t wave_score_string(const YakDev &y, const uin
 
 __device__ __forceinline__ void k_score_strings(const uint32_t np2_bid, const uint32_t np2_nb, YakDev y, const uint8_t *__restrict__ strs, const uint64_t *__restrict__ off,
                                 uint64_t n, uint16_t min_count, uint16_t *__restrict__ out, uint32_t own_strings) {
-    const uint64_t w = ((uint64_t)np2_bid * blockDim.x + threadIdx.x) >> 6;
+    // (one string per wavefront: the index is uniform, said so the loads of its offsets are scalar)
+    const uint64_t w = ((uint64_t)np2_bid * (blockDim.x >> 6)) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (w >= n) return;
     // own_strings: built by this library from 3-bit codes (and padded by 32 bytes), not handed in by a caller
     const uint16_t sc = own_strings ? wave_score_string(y, strs + off[w], (uint32_t)(off[w + 1] - off[w]), min_count)
@@ -1443,7 +1444,7 @@ __device__ __forceinline__ void k_cand_score_long(const uint32_t np2_bid, const 
                                   const uint32_t *__restrict__ n_long, uint16_t min_count,
                                   uint16_t *__restrict__ kscore) {
     const uint32_t nl = *n_long;
-    for (uint32_t w = (np2_bid * blockDim.x + threadIdx.x) >> 6; w < nl; w += (np2_nb * blockDim.x) >> 6) {
+    for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); w < nl; w += (np2_nb * blockDim.x) >> 6) {
         const uint32_t c = long_list[w];
         const uint16_t sc = wave_score_string(y, cand_seq + cand_seq_off[c], cand_seq_off[c + 1] - cand_seq_off[c],
                                               min_count);

@@ -72,6 +72,16 @@ __global__ __launch_bounds__(BLOCK) void k_np2_batched(const Batch<N, A...> B) {
     call_body<Body, A...>(blockIdx.x - B.off[slot], B.off[slot + 1] - B.off[slot], B.a[slot],
                           std::index_sequence_for<A...>{});
 }
+// The same with a floor on the waves per SIMD the register allocator has to leave room for (NP2_LAUNCH_WAVES): a kernel
+// that is a chain of dependent loads and sits one or two registers above an occupancy step.
+template <int BLOCK, int WAVES, auto Body, int N, class... A>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_np2_batched_w(const Batch<N, A...> B) {
+    uint32_t slot = 0;
+    if (B.n > 1)
+        while (slot + 1 < B.n && blockIdx.x >= B.off[slot + 1]) ++slot;
+    call_body<Body, A...>(blockIdx.x - B.off[slot], B.off[slot + 1] - B.off[slot], B.a[slot],
+                          std::index_sequence_for<A...>{});
+}
 
 // ---- recorder ----------------------------------------------------------------------------------------------------
 struct KernelDesc {
@@ -124,7 +134,7 @@ template <class... A> struct Sig<void (*)(uint32_t, uint32_t, A...)> {
     using pack_t = Pack<A...>;
     static constexpr int N = batch_slots<A...>();
     static pack_t make(A... a) { return PackMaker<A...>::make(a...); }
-    template <int BLOCK, auto Body> static void launch_n(hipStream_t s, int n, const uint32_t *grids, const void *const *args) {
+    template <int BLOCK, auto Body, int WAVES = 0> static void launch_n(hipStream_t s, int n, const uint32_t *grids, const void *const *args) {
         Batch<N, A...> B;
         B.n = (uint32_t)n;
         B.off[0] = 0;
@@ -133,10 +143,11 @@ template <class... A> struct Sig<void (*)(uint32_t, uint32_t, A...)> {
             memcpy(&B.a[i], args[i], sizeof(pack_t));
         }
         for (int i = n; i < MAXB; ++i) B.off[i + 1] = B.off[n];
-        hipLaunchKernelGGL((k_np2_batched<BLOCK, Body, N, A...>), dim3(B.off[n]), dim3(BLOCK), 0, s, B);
+        if constexpr (WAVES == 0) hipLaunchKernelGGL((k_np2_batched<BLOCK, Body, N, A...>), dim3(B.off[n]), dim3(BLOCK), 0, s, B);
+        else hipLaunchKernelGGL((k_np2_batched_w<BLOCK, WAVES, Body, N, A...>), dim3(B.off[n]), dim3(BLOCK), 0, s, B);
     }
-    template <int BLOCK, auto Body> static const KernelDesc *desc(const char *name) {
-        static const KernelDesc d{name, (uint32_t)sizeof(pack_t), N, &launch_n<BLOCK, Body>};
+    template <int BLOCK, auto Body, int WAVES = 0> static const KernelDesc *desc(const char *name) {
+        static const KernelDesc d{name, (uint32_t)sizeof(pack_t), N, &launch_n<BLOCK, Body, WAVES>};
         return &d;
     }
 };
@@ -147,16 +158,16 @@ inline uint32_t grid_x(int g) { return (uint32_t)g; }
 inline uint32_t grid_x(uint64_t g) { return (uint32_t)g; }
 inline uint32_t grid_x(long g) { return (uint32_t)g; }
 
-template <int BLOCK, auto Body, class... P> inline void launch(const char *name, hipStream_t s, uint32_t grid, P &&...p) {
+template <int BLOCK, auto Body, int WAVES = 0, class... P> inline void launch(const char *name, hipStream_t s, uint32_t grid, P &&...p) {
     using S = Sig<decltype(Body)>;
     if (grid == 0) return;
     const typename S::pack_t pk = S::make(std::forward<P>(p)...);
     if (Recorder *r = tl_recorder()) {
-        r->push_kernel(S::template desc<BLOCK, Body>(name), grid, &pk, sizeof pk);
+        r->push_kernel(S::template desc<BLOCK, Body, WAVES>(name), grid, &pk, sizeof pk);
         return;
     }
     const void *ap = &pk;
-    S::template launch_n<BLOCK, Body>(s, 1, &grid, &ap);
+    S::template launch_n<BLOCK, Body, WAVES>(s, 1, &grid, &ap);
 }
 
 } // namespace np2
@@ -164,3 +175,6 @@ template <int BLOCK, auto Body, class... P> inline void launch(const char *name,
 // NP2_LAUNCH(kernel body, grid (dim3 or integer; x only), block size (compile-time constant), stream, args...)
 #define NP2_LAUNCH(kernel, grid, block, s, ...) \
     ::np2::launch<(int)(block), &kernel>(#kernel, s, ::np2::grid_x(grid), __VA_ARGS__)
+// ... with at least `waves` resident waves per SIMD (the register allocator may spill to get there)
+#define NP2_LAUNCH_WAVES(kernel, waves, grid, block, s, ...) \
+    ::np2::launch<(int)(block), &kernel, (int)(waves)>(#kernel, s, ::np2::grid_x(grid), __VA_ARGS__)

@@ -187,7 +187,7 @@ __device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint3
     // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
     // (the usual case at 30x), otherwise one after the other over all 64 lanes
     const uint32_t wl = threadIdx.x & 63;
-    const uint32_t g0 = ((np2_bid * blockDim.x + threadIdx.x) >> 6) * 2;
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)) * 2; // (uniform)
     if (g0 >= rt.n_reg) return;
     const bool has1 = g0 + 1 < rt.n_reg;
     const bool packed = has1 && rt.cand_off[g0 + 1] - rt.cand_off[g0] <= 32 && rt.cand_off[g0 + 2] - rt.cand_off[g0 + 1] <= 32;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void k_edges_write(const uint32_t np2_bid, const uint
                                                      const uint32_t *__restrict__ eoff, uint64_t *__restrict__ ekey,
                                                      uint32_t *__restrict__ eval) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); // (uniform)
     if (g >= rt.n_reg || ecount[g] == 0) return;
     const uint32_t c0 = rt.cand_off[g], n = rt.cand_off[g + 1] - c0;
     uint32_t order = 0xFFFFFFFFu, gi = 0;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void k_edges_row(const uint32_t np2_bid, const uint32
                                             const uint32_t *__restrict__ pcount, const uint8_t *__restrict__ alive, uint32_t R,
                                             uint32_t *__restrict__ band, uint32_t *__restrict__ row_n, uint32_t *__restrict__ ovf) {
     __shared__ uint32_t s_row[4][EDGE_BAND];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t a = np2_bid * 4 + wv;
     if (a >= R) return;
     uint32_t *row = s_row[wv];
@@ -379,7 +379,7 @@ __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32
                                             const uint32_t *__restrict__ row_off, uint64_t *__restrict__ ukey,
                                             uint32_t *__restrict__ ucnt, uint32_t *__restrict__ n_out) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); // (uniform)
     if (a >= R) return;
     if (a == R - 1 && lane == 0) *n_out = row_off[R];
     if (row_off[a + 1] == row_off[a]) return;
@@ -407,7 +407,7 @@ __device__ __forceinline__ void k_band_emit_compact(const uint32_t np2_bid, cons
                                                     const uint32_t *__restrict__ row_off, uint32_t *__restrict__ pairs,
                                                     uint32_t *__restrict__ n_out, uint32_t *__restrict__ ovf) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t a = (np2_bid * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); // (uniform)
     if (a >= R) return;
     if (a == R - 1 && lane == 0) *n_out = row_off[R];
     if (row_off[a + 1] == row_off[a]) return;
@@ -471,7 +471,7 @@ __device__ __forceinline__ void k_seed(const uint32_t np2_bid, const uint32_t np
     // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
     // (the usual case at 30x), otherwise one after the other over all 64 lanes
     const uint32_t wl = threadIdx.x & 63;
-    const uint32_t g0 = ((np2_bid * blockDim.x + threadIdx.x) >> 6) * 2;
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)) * 2; // (uniform)
     if (g0 >= rt.n_reg) return;
     const bool has1 = g0 + 1 < rt.n_reg;
     const bool packed = has1 && rt.cand_off[g0 + 1] - rt.cand_off[g0] <= 32 && rt.cand_off[g0 + 2] - rt.cand_off[g0 + 1] <= 32;
