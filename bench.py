@@ -30,13 +30,13 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
 # profiles/r03_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r03_ecoli_pmc_fetch_write.json
 # (the round-3 kernel; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9 KB)
-PMC_SOURCE = {"yeast": "profiles/r04_yeast_pmc_fetch_write.json (round 4; the dense kernel is round 3's)", "ecoli": "profiles/r04_ecoli_pmc_fetch_write.json (round 4)"}
+PMC_SOURCE = {"yeast": "profiles/r04_yeast_pmc_fetch_write.json (round 4, re-recorded at the end of the round)", "ecoli": "profiles/r04_ecoli_pmc_fetch_write.json (round 4)"}
 # k-mer table probes per polished bp the reference algorithm makes on these workloads (the oracle's kmer_probes stat over
 # the whole assembly: kappa of SURVEY.md §8(d)); measured again whenever the cpu_baseline leg runs
 KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
 KAPPA_SOURCE = "profiles/r04_kappa.json"
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 37482.8 + 38299.1) * 1024), "ecoli": int((2 * 51270.1 + 38793.8) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 37785.2 + 38303.5) * 1024), "ecoli": int((2 * 51917.3 + 38867.0) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):

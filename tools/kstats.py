@@ -8,7 +8,7 @@ out = []
 for r in rows:
     n = r["Name"]
     m = re.search(r"np2::(\w+)", n)
-    mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
+    mb = re.search(r"k_np2_batched(?:_wILi\d+ELi|ILi)(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
     if mb:  # generic batched kernel template (np2_launch.hpp): the body's name is mangled inside
         ln = int(mb.group(2))
         nm = mb.group(3)[:ln]

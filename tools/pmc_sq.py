@@ -6,7 +6,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        mb = re.search(r"k_np2_batchedILi(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
+        mb = re.search(r"k_np2_batched(?:_wILi\d+ELi|ILi)(\d+)ETnDaXadL_ZN(?:S_|3np2|12_GLOBAL__N_1)*(\d+)(k_[a-zA-Z_0-9]+)", n)
         m = re.search(r"np2::(\w+)", n)
         name = mb.group(3)[:int(mb.group(2))] if mb else (m.group(1) if m else n[:40])
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
