@@ -791,7 +791,7 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
                                                       uint32_t seq_cap, uint32_t *__restrict__ cand_order,
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
-    __shared__ uint8_t s_str[RM_REG][CLEAN_MAX_LEN];
+    __shared__ __attribute__((aligned(4))) uint8_t s_str[RM_REG][CLEAN_MAX_LEN];
     __shared__ uint64_t s_km[RM_REG];
     __shared__ uint32_t s_so[RM_REG][64];
     __shared__ uint32_t s_oc[RM_REG];
@@ -883,8 +883,12 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
         const uint32_t slot = wv * RM_RPW + h;
         if (my_clean[h]) {
             cand_kmer[my_ci[h]] = s_km[slot];
+            // (four bases per store: the string starts at any byte of cand_seq, the hardware takes unaligned dwords)
+            typedef uint32_t u32_any __attribute__((aligned(1)));
             uint8_t *dst = cand_seq + my_so[h];
-            for (uint32_t j = 0; j < my_len[h]; ++j) dst[j] = s_str[slot][j];
+            const uint32_t L4 = my_len[h] & ~3u;
+            for (uint32_t j = 0; j < L4; j += 4) *reinterpret_cast<u32_any *>(dst + j) = *reinterpret_cast<const uint32_t *>(&s_str[slot][j]);
+            for (uint32_t j = L4; j < my_len[h]; ++j) dst[j] = s_str[slot][j];
         }
     }
 }
