@@ -171,3 +171,20 @@ def test_full_size_yeast_assembly_through_the_batch_driver():
     ob, op = o.polish(syn[big].pileup, Opts())
     assert np.array_equal(ob, out1[big][0]) and np.array_equal(op, out1[big][1])
     assert len(o.trace(0, "invalid_ids")) > 1000
+
+
+@pytest.mark.parametrize("env", [dict(NP2_WAIT="nap"), dict(NP2_WAIT="nap", LOCAL_WORLD_SIZE="8", NP2_BATCH_SPIN_US="0"),
+                                 dict(NP2_WAIT="spin", NP2_BATCH_SPIN_US="30")], ids=["nap", "nap-8-ranks", "spin"])
+def test_waiting_by_naps_or_by_spinning_changes_nothing(env):
+    """np2_hostcpu.hpp: host threads that wait for the device nap when the process is short of CPUs (eight ranks of a node
+    in a small container) and spin otherwise.  The policy is read once per process: a process of its own per setting runs
+    the batch driver and a plain context on random contig mixes against the oracle (tests/tools/fuzz_batch.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_batch.py"), "911", "3"], capture_output=True,
+                       timeout=600, cwd=root, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    last = r.stdout.decode().strip().splitlines()[-1]
+    assert last.startswith("batch cases 3 bad 0"), r.stdout.decode()[-2000:]
