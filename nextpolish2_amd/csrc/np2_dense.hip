@@ -60,8 +60,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     // round by readlane; 2: the chunks' 16 bytes per lane; 3 (after the block-wide exchange of the chunk totals): the
     // status words of chunks in earlier blocks, where a read started there; 4: the contig windows of all chunks.
     struct Desc {
-        uint64_t nib_off, ckbase;
-        uint32_t read, ts, c0, ncols, first_chunk, aln_t_e, nck;
+        uint64_t nib_off;
+        uint32_t read, ts, c0, ncols, first_chunk;
         bool live;
     } dd[DENSE_CPW];
     {
@@ -78,9 +78,10 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         for (uint32_t it = 0; it < DENSE_CPW; ++it) {
             const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(ch0 + it, n_chunks - 1));
             const ChunkDesc *dp = descs + ci;
-            dd[it].nib_off = dp->nib_off, dd[it].ckbase = dp->ckbase;
+            dd[it].nib_off = dp->nib_off;
             dd[it].read = dp->read, dd[it].ts = dp->ts, dd[it].c0 = dp->c0, dd[it].ncols = dp->ncols;
-            dd[it].first_chunk = dp->first_chunk, dd[it].aln_t_e = dp->aln_t_e, dd[it].nck = dp->nck;
+            dd[it].first_chunk = dp->first_chunk; // (ckbase, nck, aln_t_e: read from the LDS copy where they are used —
+            // held in scalar registers across both phases they were a good part of ~100 spill moves per wave)
             dd[it].live = ch0 + it < n_chunks;
         }
     }
@@ -231,7 +232,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             if (n_ins == 0 && nth < nonins) {
                 const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
                 const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                if (idx < dd[it].nck) ckpt[dd[it].ckbase + idx] = lc0 + nth;
+                const DenseChunk &dl = s_desc[ch - blk_first];
+                if (idx < dl.nck) ckpt[dl.ckbase + idx] = lc0 + nth;
             }
         }
         // A bad column marks itself and the two columns after it (3-column-mers): the flags of the lane's last two
@@ -254,7 +256,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         if (lane == 0) {
             if (c0 + 2048 >= ncols) {
                 // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
-                if (ncols == 0 || ts + carryN + total - 1 != dd[it].aln_t_e || dd[it].aln_t_e >= L) atomicOr(err, 2u);
+                const uint32_t te = s_desc[ch - blk_first].aln_t_e;
+                if (ncols == 0 || ts + carryN + total - 1 != te || te >= L) atomicOr(err, 2u);
                 if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
             }
         }
