@@ -384,6 +384,8 @@ def dist_setup():
     idx = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(idx)
     dev = torch.device("cuda", idx)
+    from nextpolish2_amd.dist import note_ranks_per_device
+    note_ranks_per_device(int(os.environ.get("LOCAL_WORLD_SIZE", world)), torch.cuda.device_count())
     if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":

@@ -237,6 +237,9 @@ def main(argv=None):
     if a.device is None:
         a.device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
     if distributed:
+        import torch
+        from .dist import note_ranks_per_device
+        note_ranks_per_device(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))), torch.cuda.device_count())
         out = _init_distributed(a)  # process group first; the output-file verdict is rank 0's, shared with everyone
     # main.rs:1547 compares the raw option with "ref" (case-sensitive)
     opts = Opts(min_kmer_count=a.min_kmer_count, max_indel_len=a.max_indel_len, iter_count=a.iter_count,

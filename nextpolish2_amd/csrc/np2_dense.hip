@@ -438,6 +438,35 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     }
 }
 
+// The chunks' non-insertion column counts ahead of the dense pass (one wavefront per chunk, one pass over the nibbles):
+// with every status word already carrying this launch's epoch no chunk of k_diff_reads ever waits for another.  The
+// dense pass publishes the counts itself and normally needs no help — its waits are for lower-numbered, already
+// running blocks —, except when ANOTHER PROCESS shares the device: a queue preempted by draining stops dispatching blocks
+// that resident ones wait for (np2_lookback.hpp).  Used then (NP2_DENSE_PRECOUNT, or after a wait that gave up).
+__device__ __forceinline__ void k_chunk_counts(const uint32_t np2_bid, const uint32_t np2_nb, const ChunkDesc *__restrict__ descs, uint32_t n_chunks,
+                                               const uint8_t *__restrict__ nib, uint64_t *__restrict__ chunk_st, uint32_t epoch) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (ch >= n_chunks) return;
+    const ChunkDesc *dp = descs + ch;
+    const uint32_t c0 = dp->c0, ncols = dp->ncols;
+    const uint32_t lc0 = c0 + lane * 32;
+    const uint32_t nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (nv) v = *reinterpret_cast<const uint4 *>(nib + dp->nib_off + (lc0 >> 1));
+    N128 w;
+    w.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
+    w.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
+    if (c0 == 0 && lane == 0) w.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
+    const N128 m = n_below(nv);
+    const N128 I{w.lo & NF3 & m.lo, w.hi & NF3 & m.hi};
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(nv - n_popc(I)), 63);
+    if (lane == 0) __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_chunk_counts(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, uint64_t *chunk_st, uint32_t epoch) {
+    if (n_chunks) NP2_LAUNCH(k_chunk_counts, dim3((n_chunks + 3) / 4), 256, s, descs, n_chunks, nib, chunk_st, epoch);
+}
+
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
                        const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,

@@ -623,12 +623,17 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         cx->chunk_st.ensure(NCH + 2);
         zero32(cx, cx->chunk_st.p, cx->chunk_st.cap, 8);
     }
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    // chunk counts ahead of the dense pass (launch_chunk_counts): when this process shares the device with another one
+    // (NP2_DENSE_PRECOUNT: set by the host side for ranks rehearsing on one GPU), or once a chunk's wait gave up
+    static const bool precount_env = getenv("NP2_DENSE_PRECOUNT") != nullptr;
+    bool precount = precount_env;
+    for (int attempt = 0; attempt < 4; ++attempt) {
         if (ovf_cap >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many exception nodes");
         cx->keys_raw.ensure(buckets + ovf_cap + 1);
         cx->vals_raw.ensure(buckets + ovf_cap + 1);
         zero32(cx, cx->scal.p, SCAL_TOTAL);
         if (++cx->chunk_epoch == 0) ++cx->chunk_epoch; // 0 = never written
+        if (precount) launch_chunk_counts(s, c->descs.p, NCH, c->nib.p, cx->chunk_st.p, cx->chunk_epoch);
         {
             EventTimer t(cx, "diff_reads", true);
             launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
@@ -649,6 +654,12 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         std::vector<uint32_t> sc = fetch_scal(cx);
         // (a wait that gave up — in the dense pass or in k_tile_layout — first: what follows it in the kernel is undefined,
         // the descriptor check included)
+        static const bool test_fail = getenv("NP2_TEST_DENSE_LB_FAIL") != nullptr; // (test hook: the first attempt "gave up")
+        if (test_fail && attempt == 0 && !precount) sc[S_ERR] |= LB_ERR;
+        if ((sc[S_ERR] & LB_ERR) && !precount) { // (cursors, scalars and epoch start over with the next attempt)
+            precount = true;
+            continue;
+        }
         if (sc[S_ERR] & ~2u) check_region_err(cx, sc[S_ERR] & ~2u);
         if (sc[S_ERR] & 2u)
             throw Np2Error(NP2_E_ARG, "packed read inconsistent with its descriptor (n_cols / aln_t_e / terminator)");

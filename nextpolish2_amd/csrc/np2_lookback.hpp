@@ -34,12 +34,13 @@ struct Lookback {
 static constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
 // A wait gives up after LB_WAIT_TICKS of the constant 100 MHz wall clock (4 s), looked at every 1024 spins (a count of
 // spins is anything from a fraction of a second to seconds, depending on the sleep and the memory latency).
-// Known limit: with TWO PROCESSES on one device (ranks rehearsing on one GPU) the dense pass can stall for good — its
-// chunks wait for status words of lower-numbered blocks, which is safe while blocks are dispatched in order, but a queue
-// that is being preempted by draining stops dispatching while blocks already resident on other XCDs still wait for
-// ones that now never start.  The wait then gives up, the contig's sharded attempt fails on every rank and it is
-// polished unsharded (measured: tools/e2e_chr1_probe.py, two 124 Mb shards; small contigs' kernels are too short to
-// collide).  One process per GPU — the supported layout — does not have the problem.
+// TWO PROCESSES on one device (ranks rehearsing on one GPU) are the one case in which a wait of the DENSE PASS can hang:
+// its chunks wait for status words of lower-numbered blocks, which is safe while blocks are dispatched in order, but a
+// queue that is being preempted by draining stops dispatching while blocks already resident on other XCDs still wait
+// for ones that now never start (measured: tools/e2e_chr1_probe.py, two 124 Mb shards; small contigs' kernels are too
+// short to collide).  A process that knows it shares its device takes the chunks' counts from a pre-pass instead
+// (NP2_DENSE_PRECOUNT, dist.note_ranks_per_device: no chunk waits for another), and a dense pass whose wait gave up is
+// repeated that way (run_diff).  The ticket-ordered look-backs below wait only for blocks that are already resident.
 static constexpr uint64_t LB_WAIT_TICKS = 400000000ull;
 static constexpr uint32_t LB_ERR = 0x400u; // or-ed into the error word on a wait that gave up
 __device__ __forceinline__ bool lb_gave_up(uint32_t &spins, uint64_t &t0) {

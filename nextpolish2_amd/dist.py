@@ -569,3 +569,13 @@ class SequenceGatherer:
             tab = raw[:self._table].view(np.int64)
             out[r] = b"".join(raw[o - self.HDR:o - self.HDR + int(n)].tobytes() for o, n in zip(self._slot_off, tab))
         return out
+
+
+def note_ranks_per_device(n_local_ranks, n_devices):
+    """Tell the native side that this process shares its GPU with other ranks (rehearsals of the multi-rank paths on a box
+    with fewer GPUs than ranks): the dense pass then takes its chunks' column counts from a pre-pass instead of having
+    chunks wait for lower-numbered blocks — a wait that a queue preempted in favour of another process can leave
+    hanging (csrc/np2_lookback.hpp, launch_chunk_counts).  Must run before the first contig is polished."""
+    import os
+    if n_devices > 0 and n_local_ranks > n_devices:
+        os.environ.setdefault("NP2_DENSE_PRECOUNT", "1")

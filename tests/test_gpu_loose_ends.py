@@ -183,3 +183,23 @@ def test_next_pass_started_before_the_vote_is_decided(monkeypatch, small_diploid
     for (bb, pp), (ob, op) in zip(bp.polish(cs, Opts(), want_pos=True), exp):
         assert np.array_equal(bb, ob) and np.array_equal(pp, op)
     bp.close()
+
+
+@pytest.mark.parametrize("env", [dict(NP2_DENSE_PRECOUNT="1"), dict(NP2_TEST_DENSE_LB_FAIL="1")], ids=["precount", "after-a-wait-that-gave-up"])
+def test_dense_pass_with_its_chunk_counts_from_a_pre_pass(env):
+    """run_diff (csrc/np2_host.cpp): the chunks' column counts from launch_chunk_counts — for a process that shares its GPU
+    (NP2_DENSE_PRECOUNT) and as the second attempt after a chunk's wait gave up (test hook: the first attempt is declared
+    failed, so cursors, scalars and the status epoch must start over cleanly).  Same results as ever: random contig mixes
+    through the batch driver and plain contexts against the oracle, in a process of its own (the switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_batch.py"), "912", "3"], capture_output=True,
+                       timeout=600, cwd=root, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().strip().splitlines()[-1].startswith("batch cases 3 bad 0"), r.stdout.decode()[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_polish.py"), "913", "25"], capture_output=True,
+                       timeout=600, cwd=root, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().strip().splitlines()[-1].startswith("cases 25 bad 0"), r.stdout.decode()[-2000:]

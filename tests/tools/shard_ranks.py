@@ -17,6 +17,8 @@ backend = os.environ.get("NP2_SHARD_BACKEND", "gloo")
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 n_gpu = torch.cuda.device_count()
 dev_idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_gpu)
+from nextpolish2_amd.dist import note_ranks_per_device
+note_ranks_per_device(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))), n_gpu)
 if backend == "nccl":
     torch.cuda.set_device(dev_idx)
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_idx))
