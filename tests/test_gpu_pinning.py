@@ -6,6 +6,7 @@ import pytest
 
 import test_oracle_pinning as tp
 import test_oracle_pinning2 as tp2
+import test_oracle_pinning3 as tp3
 from nextpolish2_amd import Polisher
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +28,16 @@ def test_second_set_of_hand_derived_cases_on_the_hip_path(monkeypatch, case):
     """LQ close / pad / extend, decode limit + start filter, is_valid_snp, dif <= -3: the expectations written out in
     tests/test_oracle_pinning2.py, asked of the HIP path (traces through np2_trace_get)."""
     monkeypatch.setattr(tp2.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))
+    case()
+
+
+@pytest.mark.parametrize("case", [tp3.test_equal_paths_the_later_node_wins_unless_it_starts_with_a_gap,
+                                  tp3.test_at_the_contig_end_the_last_node_of_maximal_score_wins,
+                                  tp3.test_an_insertion_carried_by_half_of_the_rows_is_taken,
+                                  tp3.test_reads_that_start_at_position_one_move_the_start_of_the_consensus_position_two_does_not])
+def test_dp_tie_breaks_on_the_hip_path(monkeypatch, case):
+    """The consensus DP's tie rules (main.rs:1664, 1676), expectations written out in tests/test_oracle_pinning3.py."""
+    monkeypatch.setattr(tp3.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))
     case()
 
 
