@@ -55,3 +55,17 @@ def test_clip_filter_first_range_on_the_product_front_end():
     assert got.reads["aln_t_s"].tolist() == [0, 10, 400, 1000, 3000, L - 1620]
     assert got.reads["aln_t_e"].tolist() == [L - 1, 1609, 1999, 2599, 4599, L - 21]
     assert (got.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 1, 0]
+
+
+def test_read_admission_boundaries_and_trim_on_the_product_front_end():
+    """main.rs:1758-1771 and trim(8) through np2_contig_from_records: the expectations of
+    tests/test_oracle_pinning3.py::test_read_admission_boundaries_and_trim."""
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import records_to_arrays
+    ref, recs, want = tp3.admission_case()
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pol = Polisher([])
+    c = np2io.contig_from_records(pol, ref.encode(), arr, cig, seq4, np2io.FrontOpts())
+    got = np2io.export_contig(pol, c, np.frombuffer(ref.encode(), dtype=np.uint8))
+    assert list(zip(got.reads["aln_t_s"].tolist(), got.reads["aln_t_e"].tolist())) == want
+    assert (got.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]

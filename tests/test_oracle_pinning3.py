@@ -92,3 +92,53 @@ def test_reads_that_start_at_position_one_move_the_start_of_the_consensus_positi
     for S, first in ((1, 1), (2, 0)):
         base, pos = _raw(ref, [(S, ref[S:], ref[S:])] * 9)
         assert base == ref[first:] and pos == list(range(first, len(ref)))
+
+
+# ---- read admission and trim(8), main.rs:1758-1801, 447-513 ------------------------------------------------------------------
+def admission_case():
+    """(contig, records, expected (aln_t_s, aln_t_e) of the admitted reads in order) — see the test below for the derivation."""
+    rng = np.random.default_rng(79)
+    ref = "".join("ACGT"[c] for c in rng.integers(0, 4, 500_100))
+    comp = {"A": "C", "C": "G", "G": "T", "T": "A"}
+
+    def rec(pos, n, mapq=60, flag=0, clip_back=0, mism=()):
+        seq = list(ref[pos:pos + n])
+        for i in mism:
+            seq[i] = comp[seq[i]]
+        cigar = [("M", n)] + ([("S", clip_back)] if clip_back else [])
+        return dict(tid=0, pos=pos, mapq=mapq, flag=flag, cigar=cigar, seq="".join(seq) + "A" * clip_back)
+    recs = [rec(100, 1500, mapq=1),                    # mapq <= min_map_qual (1)                       -> dropped
+            rec(200, 1500, mapq=2),                    # mapq 2                                          -> kept
+            rec(300, 1000),                            # rlen <= min_read_len (1000)                     -> dropped
+            rec(400, 1001),                            # rlen 1001                                       -> kept
+            rec(500, 1500, flag=0x4),                  # unmapped                                        -> dropped
+            rec(600, 1500, flag=0x400),                # duplicate                                       -> dropped
+            rec(700, 1500, flag=0x800),                # supplementary, use_supplementary off            -> dropped
+            rec(800, 1500, flag=0x100),                # secondary, use_secondary off                    -> dropped
+            rec(900, 1200, clip_back=1202),            # span 1200 < (2402 * 0.5) as i64 = 1201          -> dropped
+            rec(1000, 1200, clip_back=1201),           # span 1200 >= (2401 * 0.5) as i64 = 1200         -> kept (clipped: labelled)
+            rec(3000, 1500, mism=(3, 1490)),           # trim: first / last run of 8 matches             -> [3004, 4499]
+            rec(5000, 1500, mism=(7, 1492)),           #                                                 -> [5008, 6491]
+            rec(7000, 1500, mism=(8, 1491))]           # columns 0-7 and 1492-1499 match: nothing is cut  -> [7000, 8499]
+    want = [(0, len(ref) - 1), (200, 1699), (400, 1400), (1000, 2199), (3004, 4499), (5008, 6491), (7000, 8499)]
+    return ref, recs, want
+
+
+def test_read_admission_boundaries_and_trim():
+    """main.rs:1758-1771, defaults of option.rs (min_map_qual 1, min_read_len 1000, -a 500.5): a record is skipped when
+    flags & 0x404, mapq <= 1, rlen <= 1000 (rlen = query length by CIGAR, clips included), secondary / supplementary
+    without their switches, or reference span < max(500, (rlen as f32 * 0.5) as i64) — strict: 1200 against 2401 * 0.5
+    = 1200.5 -> 1200 passes, against 2402 * 0.5 = 1201 does not.  trim(8), main.rs:447-513: the alignment begins with
+    its first and ends with its last run of 8 matching columns — a mismatch in column 3 moves the start to column 4, in
+    column 7 to column 8, in column 8 not at all (columns 0-7 match); from the back (n = 1500 columns), a mismatch in column
+    n - 8 leaves only 7 matching columns behind it: the read ends with the 8 matches before it, in column n - 9; a
+    mismatch in column n - 9 or n - 10 has 8 or 9 matches behind it and cuts nothing.  The read of 1200 + 1201 clipped bases is
+    clipped (1200 + 100 < 2401): on a contig of 500 100 bases it is kept with a label, and emptied by the clip filter
+    (inside (50, L - 51): tests/test_oracle_pinning2.py)."""
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import records_to_arrays
+    ref, recs, want = admission_case()
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pu = orc.front_end(ref.encode(), arr, cig, asc, asc_off, np2io.FrontOpts())
+    assert list(zip(pu.reads["aln_t_s"].tolist(), pu.reads["aln_t_e"].tolist())) == want
+    assert (pu.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]
