@@ -34,7 +34,8 @@ def test_second_set_of_hand_derived_cases_on_the_hip_path(monkeypatch, case):
 @pytest.mark.parametrize("case", [tp3.test_equal_paths_the_later_node_wins_unless_it_starts_with_a_gap,
                                   tp3.test_at_the_contig_end_the_last_node_of_maximal_score_wins,
                                   tp3.test_an_insertion_carried_by_half_of_the_rows_is_taken,
-                                  tp3.test_reads_that_start_at_position_one_move_the_start_of_the_consensus_position_two_does_not])
+                                  tp3.test_reads_that_start_at_position_one_move_the_start_of_the_consensus_position_two_does_not,
+                                  tp3.test_a_region_keeps_its_first_sixty_candidates_in_read_order])
 def test_dp_tie_breaks_on_the_hip_path(monkeypatch, case):
     """The consensus DP's tie rules (main.rs:1664, 1676), expectations written out in tests/test_oracle_pinning3.py."""
     monkeypatch.setattr(tp3.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))
@@ -69,3 +70,15 @@ def test_read_admission_boundaries_and_trim_on_the_product_front_end():
     got = np2io.export_contig(pol, c, np.frombuffer(ref.encode(), dtype=np.uint8))
     assert list(zip(got.reads["aln_t_s"].tolist(), got.reads["aln_t_e"].tolist())) == want
     assert (got.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]
+
+
+def test_cigar_operations_and_clipping_on_the_product_front_end():
+    """fill_with_cigar / is_clip (main.rs:386-440, 1796-1797) through np2_contig_from_records (k_columnarise): the strings
+    and flags written out in tests/test_oracle_pinning3.py::test_cigar_operations_and_what_counts_as_clipped."""
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import records_to_arrays
+    ref, recs, want = tp3.cigar_case()
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    pol = Polisher([])
+    c = np2io.contig_from_records(pol, ref.encode(), arr, cig, seq4, np2io.FrontOpts())
+    tp3.check_cigar_case(np2io.export_contig(pol, c, np.frombuffer(ref.encode(), dtype=np.uint8)), ref, want)

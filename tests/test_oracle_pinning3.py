@@ -142,3 +142,81 @@ def test_read_admission_boundaries_and_trim():
     pu = orc.front_end(ref.encode(), arr, cig, asc, asc_off, np2io.FrontOpts())
     assert list(zip(pu.reads["aln_t_s"].tolist(), pu.reads["aln_t_e"].tolist())) == want
     assert (pu.reads["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]
+
+
+# ---- the 60-candidate cap, main.rs:1474 ------------------------------------------------------------------------------------
+def test_a_region_keeps_its_first_sixty_candidates_in_read_order():
+    """generate_lqseqs_from_tags_kmer, main.rs:1440-1474: the reads are visited in alignseqs order (the contig is entry 0)
+    and a region that already holds LQSEQ_MAX_CAN_COUNT = 60 strings takes no more.  71 rows on the sequence of
+    tests/test_oracle_pinning2.py's first case; 4 reads carry another base at X = 100: the best nodes of X, X + 1, X + 2
+    have 67 of 71 rows, qv = 67 * 100 / 71 = 94 < 95 -> the region [97, 104] derived there.
+    The 4 variant reads first:  the contig's string, the 4 variants, 55 more of the contig's = 60 strings (11 reads unseen);
+    the 4 variant reads last:   60 times the contig's string — the variants, reads 67-70, never enter the table."""
+    from test_oracle_pinning2 import _cands
+    X = 100
+    ref = backbone(220, 31)
+    alt = other(ref[X], skip=(ref[X - 1], ref[X + 1]))
+    var = put(ref, X, alt)
+    for alns, want in (([(0, ref, var)] * 4 + [(0, ref, ref)] * 66, [ref[97:105]] + [var[97:105]] * 4 + [ref[97:105]] * 55),
+                       ([(0, ref, ref)] * 66 + [(0, ref, var)] * 4, [ref[97:105]] * 60)):
+        o = orc.Oracle([yak_counted([(ref, 50)], 21)])
+        o.set_trace(True)
+        o.polish(pileup_from_alignments(ref, alns), Opts(iter_count=1))
+        assert (o.trace(0, "lq.start").tolist(), o.trace(0, "lq.end").tolist()) == ([97], [104])
+        assert _cands(o)[0] == want
+
+
+# ---- fill_with_cigar and is_clip, main.rs:386-440, 1796-1797 ---------------------------------------------------------------
+def cigar_case():
+    """(contig, records, expected [(aln_t_s, t_aln, q_aln) or None for a read the clip filter empties]) — derivation below."""
+    rng = np.random.default_rng(83)
+    ref = "".join("ACGT"[c] for c in rng.integers(0, 4, 500_100))
+    comp = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    i1, i2 = comp[ref[2599]], comp[ref[2600]]  # two inserted bases (neither equal to its neighbours: no ambiguity to argue about)
+    seq_a = ref[2000:2600] + i1 + i2 + ref[2600:3100] + ref[3103:3503]
+    aln_a = (2000, ref[2000:2600] + "--" + ref[2600:3503], ref[2000:2600] + i1 + i2 + ref[2600:3100] + "---" + ref[3103:3503])
+    x = comp[ref[6800]]
+    seq_f = ref[6000:6800] + x + ref[6801:7601]
+    recs = [dict(tid=0, pos=2000, mapq=60, flag=0, cigar=[("M", 600), ("I", 2), ("M", 500), ("D", 3), ("M", 400)], seq=seq_a),
+            dict(tid=0, pos=5000, mapq=60, flag=0, cigar=[("H", 10), ("S", 150), ("M", 1600)], seq="A" * 150 + ref[5000:6600]),
+            dict(tid=0, pos=6000, mapq=60, flag=0, cigar=[("=", 800), ("X", 1), ("=", 800)], seq=seq_f),
+            dict(tid=0, pos=8000, mapq=60, flag=0, cigar=[("S", 150), ("M", 1600)], seq="A" * 150 + ref[8000:9600]),
+            dict(tid=0, pos=10000, mapq=60, flag=0, cigar=[("M", 1600), ("S", 150), ("H", 10)], seq=ref[10000:11600] + "C" * 150)]
+    want = [aln_a, (5000, ref[5000:6600], ref[5000:6600]), (6000, ref[6000:7601], seq_f), None, None]
+    return ref, recs, want
+
+
+def _read_bytes(pu, i):
+    r = pu.reads[i]
+    return (int(r["aln_t_s"]), int(r["aln_t_e"]), int(r["n_cols"]), pu.nibbles[int(r["nib_off"]):int(r["nib_off"]) + (int(r["n_cols"]) + 2) // 2].tobytes())
+
+
+def check_cigar_case(pu, ref, want):
+    assert pu.n_reads == 1 + len(want)
+    assert (pu.reads["flags"] & 1).tolist() == [0] + [1 if w is None else 0 for w in want]
+    exp = pileup_from_alignments(ref, [w for w in want if w is not None])
+    k = 1
+    for i, w in enumerate(want, start=1):
+        if w is None:
+            continue
+        assert _read_bytes(pu, i) == _read_bytes(exp, k), i
+        k += 1
+
+
+def test_cigar_operations_and_what_counts_as_clipped():
+    """fill_with_cigar, main.rs:386-440: M / = / X copy query and contig columns, I puts '-' into the contig string, D into
+    the query string, H is skipped; 600M 2I 500M 3D 400M at 2000 therefore gives the two strings written out in cigar_case
+    (1505 columns, aln_t_e = 2000 + 1503 - 1), and 800= 1X 800= is one mismatch column.  A soft clip sets aln_q_s if it is
+    the FIRST operation and aln_q_e = qs - l otherwise (main.rs:395-402); aln_q_e == 0 is then taken for "not set"
+    (main.rs:436-438).  is_clip = aln_q_e - aln_q_s + max_clip_len(100) < rlen with rlen counting soft AND hard clips:
+      150S 1600M        aln_q_s = 150, aln_q_e = 1750:  1600 + 100 < 1750                      -> clipped;
+      1600M 150S 10H    aln_q_e = 1600:                 1600 + 100 < 1760                      -> clipped;
+      10H 150S 1600M    the soft clip is not first: aln_q_s stays 0, aln_q_e = 150 - 150 = 0 = "not set" -> 1750 at the end:
+                        1750 + 100 < 1760 is false                                             -> NOT clipped.
+    On this contig of 500 100 bases clipped reads are kept with a label and emptied by the clip filter (both lie inside
+    (50, L - 51): tests/test_oracle_pinning2.py): flags bit 0."""
+    from nextpolish2_amd import io as np2io
+    from nextpolish2_amd.bamio import records_to_arrays
+    ref, recs, want = cigar_case()
+    arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
+    check_cigar_case(orc.front_end(ref.encode(), arr, cig, asc, asc_off, np2io.FrontOpts()), ref, want)
