@@ -220,3 +220,31 @@ def test_cigar_operations_and_what_counts_as_clipped():
     ref, recs, want = cigar_case()
     arr, cig, seq4, asc, asc_off = records_to_arrays(recs)
     check_cigar_case(orc.front_end(ref.encode(), arr, cig, asc, asc_off, np2io.FrontOpts()), ref, want)
+
+
+# ---- k-mer score of a candidate longer than k, main.rs:743-770 ---------------------------------------------------------------
+def test_a_long_candidate_scores_the_rarest_of_its_kmers():
+    """retrieve_kmer_count, main.rs:756-764: a candidate string longer than k scores the MINIMUM table count over all of
+    its k-mers (a missing k-mer counts 0), a shorter one the count of its first k-mer.  The pileup of
+    tests/test_oracle_pinning.py's long-indel case (the contig lacks 25 bases, reads 4 and 5 carry them); the table
+    holds the true sequence at count 50 — and one 21-mer from the middle of the 25 inserted bases again, written later,
+    at count c (a k-mer keeps the count of the last sequence that holds it).  The inserting candidates' strings hold
+    that 21-mer, so their score is min(50, ..., c, ..., 50) = c:
+        c = 7                          -> k-scores [0, 0, 0, 0, 7, 7, 0, 0, 0]  (the others' first k-mer spans the junction)
+        c = 4 < min_kmer_count = 5     -> the k-mer is not retrieved at all (kmer.rs: `<`), reads as 0, the minimum is 0:
+                                          no candidate with a k-mer in the table, nothing is inserted."""
+    truth = backbone(260, 9)
+    pos = 100
+    ins = truth[pos:pos + 25]
+    ref = truth[:pos] + truth[pos + 25:]
+    t_aln = ref[:pos] + "-" * 25 + ref[pos:]
+    q_aln = ref[:pos] + ins + ref[pos:]
+    alns = [(0, ref, ref)] * 3 + [(0, t_aln, q_aln)] * 2 + [(0, ref, ref)] * 3
+    rare = truth[pos + 2:pos + 23]
+    assert len(rare) == 21 and rare in ins
+    for c, want in ((7, [0, 0, 0, 0, 7, 7, 0, 0, 0]), (4, [0] * 9)):
+        o = orc.Oracle([yak_counted([(truth, 50), (rare, c)], 21)])
+        o.set_trace(True)
+        b, _ = o.polish(pileup_from_alignments(ref, alns), Opts(max_indel_len=30, iter_count=1, min_kmer_count=5))
+        assert o.trace(0, "cand.kscore").tolist() == want
+        assert b.tobytes().decode() == (truth if c == 7 else ref)
