@@ -248,3 +248,29 @@ def test_a_long_candidate_scores_the_rarest_of_its_kmers():
         b, _ = o.polish(pileup_from_alignments(ref, alns), Opts(max_indel_len=30, iter_count=1, min_kmer_count=5))
         assert o.trace(0, "cand.kscore").tolist() == want
         assert b.tobytes().decode() == (truth if c == 7 else ref)
+
+
+# ---- fill_order_stat's first-come tie, main.rs:812-848, 862-899 -------------------------------------------------------------
+def test_two_alleles_of_equal_support_the_first_in_read_order_seeds():
+    """Nine rows at X: the contig and reads 7, 8 carry c0 (no k-mer of it in the table: k-score 0), reads 1-3 carry B,
+    reads 4-6 carry A; the table holds both the A and the B haplotype at count 50.  fill_order_stat visits the candidates
+    with a k-score > 0 in order: B (candidate 1) has 3 copies -> max1 = (3, 1); A (candidate 4) has 3 copies as well and
+    `c > max1_c` is false -> it becomes max2, B stays: sudoseed = B's string.  order_stat = {1: 3, 4: 3}; the contig's
+    string occurs 3 times (> 1), so order 0 is entered with min_c = get_min_count(9) = 3; retain_sort_seqs sorts stably
+    by that count, descending — orders 0, 1, 4 (3 each) before the rest (0) — and cuts below min_c:
+                          retained candidates [0, 1, 4], the seed is B: the spliced consensus carries B at X.
+    With the A reads before the B reads the same reasoning seeds A."""
+    X = 100
+    ref = backbone(220, 31)
+    a, b_ = [x for x in "ACGT" if x not in (ref[X], ref[X - 1], ref[X + 1])][:2]
+    hap_a, hap_b = put(ref, X, a), put(ref, X, b_)
+    for first, second in ((hap_b, hap_a), (hap_a, hap_b)):
+        alns = [(0, ref, first)] * 3 + [(0, ref, second)] * 3 + [(0, ref, ref)] * 2
+        o = orc.Oracle([yak_counted([(hap_a, 50), (hap_b, 50)], 21)])
+        o.set_trace(True)
+        o.polish(pileup_from_alignments(ref, alns), Opts(iter_count=1))
+        assert (o.trace(0, "lq.start").tolist(), o.trace(0, "lq.end").tolist()) == ([97], [104])
+        assert [k > 0 for k in o.trace(0, "cand.kscore").tolist()] == [False, True, True, True, True, True, True, False, False]
+        assert o.trace(0, "seed.order").tolist() == [0, 1, 4]
+        assert o.trace(0, "seed.sudo").tobytes().decode() == first[97:105]
+        assert o.trace(0, "cns_succ.base").tobytes().decode() == first
