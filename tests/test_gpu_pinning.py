@@ -37,7 +37,8 @@ def test_second_set_of_hand_derived_cases_on_the_hip_path(monkeypatch, case):
                                   tp3.test_reads_that_start_at_position_one_move_the_start_of_the_consensus_position_two_does_not,
                                   tp3.test_a_region_keeps_its_first_sixty_candidates_in_read_order,
                                   tp3.test_a_long_candidate_scores_the_rarest_of_its_kmers,
-                                  tp3.test_two_alleles_of_equal_support_the_first_in_read_order_seeds])
+                                  tp3.test_two_alleles_of_equal_support_the_first_in_read_order_seeds,
+                                  tp3.test_a_marker_needs_min_c_reads_and_singletons_take_no_part])
 def test_dp_tie_breaks_on_the_hip_path(monkeypatch, case):
     """The consensus DP's tie rules (main.rs:1664, 1676), expectations written out in tests/test_oracle_pinning3.py."""
     monkeypatch.setattr(tp3.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))

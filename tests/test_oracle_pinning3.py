@@ -274,3 +274,29 @@ def test_two_alleles_of_equal_support_the_first_in_read_order_seeds():
         assert o.trace(0, "seed.order").tolist() == [0, 1, 4]
         assert o.trace(0, "seed.sudo").tobytes().decode() == first[97:105]
         assert o.trace(0, "cns_succ.base").tobytes().decode() == first
+
+
+# ---- mark_hete_lqseqs and the reads a marker removes, main.rs:916-946, 948-980 ------------------------------------------------
+def test_a_marker_needs_min_c_reads_and_singletons_take_no_part():
+    """Twenty rows at X (get_min_count(20) = 3); the table holds every allele used, so all candidates score > 0.
+    mark_hete_lqseqs: a region is a marker when its second most frequent string has max2_c >= min_c copies (same length
+    as the first, and a valid SNP); in a marker, candidates whose string has fewer than min_c copies lose their k-score.
+    phase_reads_by_lqseqs without -r: a read whose candidate differs from the contig's (candidate 0) at a marker is
+    removed (main.rs:972-980); candidates with k-score 0 are skipped.
+      2 reads carry B:                        max2_c = 2 < 3: no marker                     -> nobody is removed;
+      3 reads carry B (reads 17-19):          marker                                        -> reads 17, 18, 19 removed;
+      9 reads carry B (10-18), read 19 a C:   marker; C has 1 copy < 3: its k-score is zeroed -> reads 10-18 removed, 19 stays."""
+    X = 100
+    ref = backbone(220, 31)
+    b_, c_ = [x for x in "ACGT" if x not in (ref[X], ref[X - 1], ref[X + 1])][:2]
+    hb, hc = put(ref, X, b_), put(ref, X, c_)
+    yak = yak_counted([(ref, 50), (hb, 50), (hc, 50)], 21)
+    for alns, removed in (([(0, ref, ref)] * 17 + [(0, ref, hb)] * 2, []),
+                          ([(0, ref, ref)] * 16 + [(0, ref, hb)] * 3, [17, 18, 19]),
+                          ([(0, ref, ref)] * 9 + [(0, ref, hb)] * 9 + [(0, ref, hc)], list(range(10, 19)))):
+        o = orc.Oracle([yak])
+        o.set_trace(True)
+        o.polish(pileup_from_alignments(ref, alns), Opts(iter_count=2))
+        assert (o.trace(0, "lq.start").tolist(), o.trace(0, "lq.end").tolist()) == ([97], [104])
+        assert sorted(o.trace(0, "invalid_ids").tolist()) == removed
+        assert (int(o.trace(0, "hete.lable")[0]) & 0x40 != 0) == bool(removed)  # LQSEQS_LABLE_HETE, main.rs:657
