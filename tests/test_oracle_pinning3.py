@@ -300,3 +300,26 @@ def test_a_marker_needs_min_c_reads_and_singletons_take_no_part():
         assert (o.trace(0, "lq.start").tolist(), o.trace(0, "lq.end").tolist()) == ([97], [104])
         assert sorted(o.trace(0, "invalid_ids").tolist()) == removed
         assert (int(o.trace(0, "hete.lable")[0]) & 0x40 != 0) == bool(removed)  # LQSEQS_LABLE_HETE, main.rs:657
+
+
+# ---- yak_hash64, kmer.rs:223-233 ---------------------------------------------------------------------------------------------
+def test_yak_hash64_known_answers():
+    """kmer.rs:223-233 with mask = 4^k - 1.  By hand for k = 2 (mask 15: every right shift gives 0, every left shift by
+    >= 4 vanishes under the mask):  0 -> !0 & 15 = 15 -> 15 * 265 = 3975 = 7 (mod 16) -> 7 * 21 = 147 = 3 (mod 16) -> 3;
+    5 -> !5 & 15 = 10 -> 2650 = 10 (mod 16) -> 210 = 2 (mod 16) -> 2.  For the k-mer sizes in use, a second restatement
+    written here from the Rust text, step by step, must agree on random keys."""
+    assert orc.yak_hash64(0, 2) == 3 and orc.yak_hash64(5, 2) == 2
+
+    def h(key, mask):
+        key = (~key + (key << 21)) & mask
+        key ^= key >> 24
+        key = (key + (key << 3) + (key << 8)) & mask
+        key ^= key >> 14
+        key = (key + (key << 2) + (key << 4)) & mask
+        key ^= key >> 28
+        return (key + (key << 31)) & mask
+    rng = np.random.default_rng(5)
+    for k in (17, 21, 27, 31):
+        mask = (1 << (2 * k)) - 1
+        for key in rng.integers(0, mask, 2000, dtype=np.uint64).tolist():
+            assert orc.yak_hash64(key, k) == h(key, mask)
