@@ -464,6 +464,9 @@ __device__ __forceinline__ uint32_t wave_excl(uint32_t v) { // exclusive prefix 
 // A region the shortcut does not cover (its window leaves its tile, the contig has a non-ACGT letter there, more than
 // 64 reads over the tile, no record index) decodes every pair the old way.
 // ------------------------------------------------------------------------------------------------------
+#ifndef NP2_RM_WAVES
+#define NP2_RM_WAVES 8 // floor on k_region_measure's resident waves per SIMD
+#endif
 #ifndef NP2_RM_RPW
 #define NP2_RM_RPW 4
 #endif
@@ -930,7 +933,7 @@ void launch_region_measure(hipStream_t s, const CandPtrs &c, uint32_t n_reg, uin
                            uint32_t *kept_col, uint32_t *reg_ncand, uint32_t *reg_bytes, uint32_t *reg_maxlen,
                            uint32_t *blk_sum) {
     if (n_reg)
-        NP2_LAUNCH_WAVES(k_region_measure, 8, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, // (65 registers without the floor: 7 waves)
+        NP2_LAUNCH_WAVES(k_region_measure, NP2_RM_WAVES, dim3((n_reg + RM_REG - 1) / RM_REG), 256, s, // (65 registers without the floor: 7 waves)
                          mk_cand(c), n_reg, kept_read, kept_len, kept_col, reg_ncand, reg_bytes, reg_maxlen, blk_sum);
 }
 uint32_t cand_offsets_blocks(uint32_t n_reg) { return ((n_reg + 3) / 4 + 1023) / 1024; }
