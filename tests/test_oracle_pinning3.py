@@ -323,3 +323,27 @@ def test_yak_hash64_known_answers():
         mask = (1 << (2 * k)) - 1
         for key in rng.integers(0, mask, 2000, dtype=np.uint64).tolist():
             assert orc.yak_hash64(key, k) == h(key, mask)
+
+
+# ---- the recheck prefers the contig's string, main.rs:1366-1395 ---------------------------------------------------------------
+def test_the_recheck_prefers_a_valid_contig_string_over_the_majority():
+    """Nine rows at X: the contig and reads 1, 2 carry c0, reads 3-8 carry B; the table holds BOTH haplotypes.
+    fill_seed_lqseqs: the contig's string has 3 copies -> max1 = (3, 0); B (first at candidate 3) has 6 > 3 -> max1 = (6, 3):
+    sudoseed = B.  order_stat = {0: 3, 3: 6} (only the first copy of a string has an entry), min_c = get_min_count(9) = 3;
+    retain_sort_seqs sorts by that count, descending, and cuts below 3:  retained candidates [3, 0], the spliced consensus
+    carries B.  reupdate_consensus_with_lqseqs with the same table: both strings make k-mers that are in it; the choice
+    loop `if c == 0 || seq.order == 0 { c = p + 1 }` (main.rs:1371-1376) takes the first valid string — B — and then
+    moves to the contig's because its order is 0 ("in case ref is prefer"):
+                          the recheck puts the contig's string back — the result is the contig, six reads of nine notwithstanding."""
+    X = 100
+    ref = backbone(220, 31)
+    b_ = other(ref[X], skip=(ref[X - 1], ref[X + 1]))
+    hb = put(ref, X, b_)
+    o = orc.Oracle([yak_counted([(ref, 50), (hb, 50)], 21)])
+    o.set_trace(True)
+    b, _ = o.polish(pileup_from_alignments(ref, [(0, ref, ref)] * 2 + [(0, ref, hb)] * 6), Opts(iter_count=1))
+    assert (o.trace(0, "lq.start").tolist(), o.trace(0, "lq.end").tolist()) == ([97], [104])
+    assert o.trace(0, "seed.order").tolist() == [3, 0]
+    assert o.trace(0, "cns_succ.base").tobytes().decode() == hb
+    assert o.trace(0, "rech0.sudo").tobytes().decode() == ref[97:105]
+    assert b.tobytes().decode() == ref
