@@ -347,3 +347,27 @@ def test_the_recheck_prefers_a_valid_contig_string_over_the_majority():
     assert o.trace(0, "cns_succ.base").tobytes().decode() == hb
     assert o.trace(0, "rech0.sudo").tobytes().decode() == ref[97:105]
     assert b.tobytes().decode() == ref
+
+
+def test_two_valid_strings_go_on_to_the_next_table():
+    """main.rs:1378-1395, 1421-1428: a region with two or more valid strings keeps its RECH label for the next (longer-k)
+    table; a recheck that finds no valid string leaves the choice as it was unless it is the first one.  The pileup of
+    test_two_alleles_of_equal_support_the_first_in_read_order_seeds (retained candidates [c0, B, A], c0 without k-mers in
+    any table, seed = B):
+      k21 {A, B}                  both valid, B is the first valid one in the retained order     -> B
+      k21 {A, B}, k31 {A}         the region is checked again with k = 31: only A is valid       -> A
+      k21 {A, B}, k31 {neither}   nothing valid in the second recheck (iter_count = 2)           -> stays B."""
+    X = 100
+    ref = backbone(220, 31)
+    a, b_ = [x for x in "ACGT" if x not in (ref[X], ref[X - 1], ref[X + 1])][:2]
+    hap_a, hap_b = put(ref, X, a), put(ref, X, b_)
+    alns = [(0, ref, hap_b)] * 3 + [(0, ref, hap_a)] * 3 + [(0, ref, ref)] * 2
+    k21 = yak_counted([(hap_a, 50), (hap_b, 50)], 21)
+    for yaks, want in (([k21], hap_b), ([k21, yak_counted([(hap_a, 50)], 31)], hap_a),
+                       ([k21, yak_counted([(backbone(220, 32), 50)], 31)], hap_b)):
+        o = orc.Oracle(yaks)
+        o.set_trace(True)
+        b, _ = o.polish(pileup_from_alignments(ref, alns), Opts(iter_count=1))
+        assert o.trace(0, "seed.order").tolist() == [0, 1, 4]
+        assert o.trace(0, "rech0.sudo").tobytes().decode() == hap_b[97:105]
+        assert b.tobytes().decode() == want
