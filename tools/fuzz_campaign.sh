@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 NL=${1:-2000}; NW=${2:-2000}; NH=${3:-60}
 mkdir -p gpurun_out/fuzz
-wait_all() { for i in $(seq 1 400); do n=$(pgrep -c -f "tests/tools/fuzz_" || true); [ "$n" = "0" ] && break; sleep 3; done; }
+wait_all() { for i in $(seq 1 400); do n=$(pgrep -c -f "^python tests/tools/fuzz_" || true); [ "$n" = "0" ] && break; sleep 3; done; }
 for s in 5001 5002 5003 5004; do (timeout 1500 python tests/tools/fuzz_polish.py $s $NL > gpurun_out/fuzz/polish_$s.log 2>&1 &) ; done
 for s in 6001 6002 6003 6004 6005 6006; do (timeout 1500 python tests/tools/fuzz_polish.py $s $NW wide > gpurun_out/fuzz/wide_$s.log 2>&1 &) ; done
 for s in 4003 4004; do (timeout 1500 python tests/tools/fuzz_front.py $s 400 > gpurun_out/fuzz/front_$s.log 2>&1 &) ; done
