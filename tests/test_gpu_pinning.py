@@ -40,7 +40,8 @@ def test_second_set_of_hand_derived_cases_on_the_hip_path(monkeypatch, case):
                                   tp3.test_two_alleles_of_equal_support_the_first_in_read_order_seeds,
                                   tp3.test_a_marker_needs_min_c_reads_and_singletons_take_no_part,
                                   tp3.test_the_recheck_prefers_a_valid_contig_string_over_the_majority,
-                                  tp3.test_two_valid_strings_go_on_to_the_next_table])
+                                  tp3.test_two_valid_strings_go_on_to_the_next_table,
+                                  tp3.test_with_all_reads_the_model_decides_which_haplotype_goes])
 def test_dp_tie_breaks_on_the_hip_path(monkeypatch, case):
     """The consensus DP's tie rules (main.rs:1664, 1676), expectations written out in tests/test_oracle_pinning3.py."""
     monkeypatch.setattr(tp3.orc, "Oracle", lambda yaks: Polisher(yaks, device=0))

@@ -371,3 +371,30 @@ def test_two_valid_strings_go_on_to_the_next_table():
         assert o.trace(0, "seed.order").tolist() == [0, 1, 4]
         assert o.trace(0, "rech0.sudo").tobytes().decode() == hap_b[97:105]
         assert b.tobytes().decode() == want
+
+
+# ---- which haplotype goes: -r with the two models, louvain.rs:290-339, 72-117 ---------------------------------------------------
+def test_with_all_reads_the_model_decides_which_haplotype_goes():
+    """One marker; the contig and reads 1-3 carry c0, reads 4-9 carry B, both haplotypes in the table; -r (use_all_reads), so
+    no read is removed just for disagreeing with the contig (main.rs:977) and all nine enter the graph: +1 inside a
+    haplotype, -1 across.  first_stage (louvain.rs:72-117) visits the nodes in ascending order and moves a node to the
+    neighbouring community of largest positive gain, ties to the smaller id: 1 -> community 2 (gain 1 with 2 and with 3),
+    2 stays (its own community ties with 3 and is the smaller), 3 -> 2; 4 -> 5, 5 stays, 6-9 -> 5; nothing moves in the
+    next sweep.  Two communities, {1, 2, 3} of internal weight 3 and {4, ..., 9} of weight 15, joined by -18: a conflict.
+      model "len" (no reference row): ranked by weight, {4..9} first -> the conflicting {1, 2, 3} is removed;
+      model "ref": ranked by agreement with the contig's candidate, (+3, 3) for {1, 2, 3} against (-6, -6) -> reads 4-9 go.
+    Without -r the six B reads are removed before any graph is built, whatever the model."""
+    X = 100
+    ref = backbone(220, 31)
+    b_ = other(ref[X], skip=(ref[X - 1], ref[X + 1]))
+    hb = put(ref, X, b_)
+    alns = [(0, ref, ref)] * 3 + [(0, ref, hb)] * 6
+    yak = yak_counted([(ref, 50), (hb, 50)], 21)
+    for opts, removed in ((Opts(iter_count=2, use_all_reads=True, model="len"), [1, 2, 3]),
+                          (Opts(iter_count=2, use_all_reads=True, model="ref"), [4, 5, 6, 7, 8, 9]),
+                          (Opts(iter_count=2, use_all_reads=False, model="len"), [4, 5, 6, 7, 8, 9])):
+        o = orc.Oracle([yak])
+        o.set_trace(True)
+        o.polish(pileup_from_alignments(ref, alns), opts)
+        assert int(o.trace(0, "hete.lable")[0]) & 0x40
+        assert sorted(o.trace(0, "invalid_ids").tolist()) == removed
