@@ -36,7 +36,7 @@ PMC_SOURCE = {"yeast": "profiles/r04_yeast_pmc_fetch_write.json (round 4, re-rec
 KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
 KAPPA_SOURCE = "profiles/r04_kappa.json"
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 37785.2 + 38303.5) * 1024), "ecoli": int((2 * 51917.3 + 38867.0) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 37805.7 + 38330.9) * 1024), "ecoli": int((2 * 52134.0 + 38965.5) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
