@@ -307,7 +307,10 @@ def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
     """Shard protocol of one rank among `world` (one process per GPU): every phase's exchange carries the ranks' status."""
     from .api import ShardPiece
     apply_err = None
-    while run.passes_left() > 1:
+    # The number of phasing passes is fixed BEFORE the loop (it is opts.iter_count - 1 on every rank): a rank whose apply()
+    # failed has not advanced its pass counter, and a loop on passes_left() would send it back into _decide_on_owner
+    # (all-gather of a 2-word head) while the others enter the final _exchange (1-word length): mismatched collectives.
+    for _ in range(max(0, run.passes_left() - 1)):
         err, payload = apply_err, None
         try:
             if err is None:

@@ -154,6 +154,8 @@ class _ReplayRun:
         return Vote.from_bytes(self.fx[f"vote{self.rank}"].tobytes())
 
     def apply(self, losers):
+        if self.fail_at == "apply" and self.rank == 1:  # (np2_shard_apply throws BEFORE advancing the pass counter)
+            raise RuntimeError("NP2_E_NOMEM: (injected) the shard could not apply the decision")
         self.losers = np.asarray(losers)
         self.left = 1
 
@@ -227,9 +229,10 @@ def test_rank_protocol_on_recorded_shards_gloo():
 
 
 def test_a_failing_shard_ends_the_sharded_attempt_on_every_rank():
-    """One rank's shard fails (in its phasing pass / in its final pass): every rank raises ShardMismatch out of the same
+    """One rank's shard fails (in its phasing pass / applying the LAST phasing pass's decision, which leaves its pass
+    counter where it was / in its final pass): every rank raises ShardMismatch out of the same
     exchange instead of waiting for the other in the next collective — the caller then polishes the contig unsharded."""
-    for where in ("vote", "final"):
+    for where in ("vote", "apply", "final"):
         assert _spawn_protocol(where) == [(0, "mismatch", True), (1, "mismatch", True)]
 
 
