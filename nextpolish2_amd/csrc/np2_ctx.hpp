@@ -508,6 +508,10 @@ struct np2_ctx {
     DevBuf<uint32_t> lqc, lqoff; // low-quality bases written per dirty run, and their exclusive scan
     DevBuf<uint8_t> pflag;               // per contig position: has exception nodes | coverage below 2
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
+    DevBuf<uint16_t> pf_slots; // fused pass front: per-tile consensus entries
+    DevBuf<uint32_t> pf_bad;   // ... tiles listed for the big variant
+    bool front_fused = false;  // the pass front under way went through the fused kernels (np2_passfront.hip)
+    uint32_t front_redos = 0;  // passes the fused front handed back to the unfused kernels (tests read it through the timings)
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;
     DevBuf<uint64_t> soff;
@@ -519,11 +523,16 @@ namespace np2h {
 
 
 enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S_DUP, S_LAST0, S_LAST1, S_GAIN0,
-            S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_NLQ, S_PAD0, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW, S_COUNT = 26 };
-static_assert(S_M1 % 2 == 0 && S_LAST0 % 2 == 0 && S_GAIN0 % 2 == 0, "64-bit device counters live in these slot pairs");
+            S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_NLQ, S_PF, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW,
+            // the fused pass front (np2_passfront.hip): S_PF = flag word of the pass under way (above), tiles listed for the big
+            // variant, the flags as the host reads them, total of the path-score gains, best end node's relative score
+            S_NBAD, S_PFOUT, S_PFGAIN0, S_PFGAIN1, S_PFEND0, S_PFEND1, S_COUNT = 32 };
+static_assert(S_M1 % 2 == 0 && S_LAST0 % 2 == 0 && S_GAIN0 % 2 == 0 && S_PFGAIN0 % 2 == 0 && S_PFEND0 % 2 == 0,
+              "64-bit device counters live in these slot pairs");
 
 static constexpr int NP2_MAX_YAK = 15; // splice rounds 0 .. n_yak index mlen[16] and the counters behind S_COUNT
-static constexpr uint32_t SCAL_TOTAL = 64; // posted block (S_COUNT) + per-splice-round counters behind it
+static constexpr uint32_t SCAL_TOTAL = 96; // posted block (S_COUNT) + per-splice-round counters behind it
+static_assert(S_COUNT + 2 * (NP2_MAX_YAK + 2) <= SCAL_TOTAL && S_COUNT < 64, "round counters behind the posted block; the mailbox holds 64 words");
 
 inline double thread_cpu_ms() { // CPU time of the calling thread
     timespec ts;

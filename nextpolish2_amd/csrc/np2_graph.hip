@@ -368,9 +368,24 @@ __device__ __forceinline__ void k_tile_offsets(const uint32_t np2_bid, const uin
                                                        const uint32_t *__restrict__ tile_nr, uint32_t n_tiles,
                                                        uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
                                                        uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
-                                                       uint32_t *__restrict__ reset, uint32_t n_reset) {
+                                                       uint32_t *__restrict__ reset, uint32_t n_reset,
+                                                       const long long *__restrict__ tile_gain,
+                                                       unsigned long long *__restrict__ gain_total) {
     __shared__ uint32_t sh[16];
     if (threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars (best, path begin, gains, ...)
+    if (tile_gain) { // the fused pass front: the tiles' shares of the path score, summed (one block: no atomics)
+        __shared__ long long sg[16];
+        long long v = 0;
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x) v += tile_gain[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) sg[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tsum = 0;
+            for (uint32_t w = 0; w < blockDim.x / 64; ++w) tsum += sg[w];
+            *gain_total = (unsigned long long)tsum;
+        }
+    }
     const uint32_t ta = block_scan_array<OpAdd>(
         n_tiles, sh, [&](uint32_t i) { return tile_nn[i]; }, [&](uint32_t i, uint32_t pre, uint32_t) { tile_noff[i] = pre; });
     const uint32_t tb = block_scan_array<OpAdd>(
@@ -386,11 +401,20 @@ __device__ __forceinline__ void k_tile_offsets_lb(const uint32_t np2_bid, const 
                                                          uint32_t *__restrict__ tile_noff, uint32_t *__restrict__ tile_roff,
                                                          uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ n_runs,
                                                          uint32_t *__restrict__ reset, uint32_t n_reset,
-                                                         uint32_t *__restrict__ err) {
+                                                         uint32_t *__restrict__ err, const long long *__restrict__ tile_gain,
+                                                         unsigned long long *__restrict__ gain_total) {
     __shared__ uint32_t sh[8];
     if (np2_bid == 0 && threadIdx.x < n_reset) reset[threadIdx.x] = 0; // per-pass device scalars
     const uint32_t bid = lb_block_id(lb, sh);
     const uint32_t i0 = (bid * 256 + threadIdx.x) * TLB_ITEMS;
+    if (tile_gain) { // (*gain_total was zeroed by k_pf_tile; one atomic per wavefront of a few dozen blocks)
+        long long v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < TLB_ITEMS; ++k)
+            if (i0 + k < n_tiles) v += tile_gain[i0 + k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(gain_total, (unsigned long long)v);
+    }
     uint32_t a[TLB_ITEMS], b[TLB_ITEMS], sa = 0, sb = 0;
 #pragma unroll
     for (uint32_t k = 0; k < TLB_ITEMS; ++k) {
@@ -780,11 +804,12 @@ void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals
 }
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
                          uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
-                         uint32_t n_reset, const Lookback *lb, uint32_t *err) {
+                         uint32_t n_reset, const Lookback *lb, uint32_t *err, const long long *tile_gain,
+                         unsigned long long *gain_total) {
     if (lb)
-        NP2_LAUNCH(k_tile_offsets_lb, dim3(tile_scan_blocks(n_tiles)), 256, s, *lb, tile_scan_blocks(n_tiles), tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset, err);
+        NP2_LAUNCH(k_tile_offsets_lb, dim3(tile_scan_blocks(n_tiles)), 256, s, *lb, tile_scan_blocks(n_tiles), tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset, err, tile_gain, gain_total);
     else
-        NP2_LAUNCH(k_tile_offsets, dim3(1), 1024, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset);
+        NP2_LAUNCH(k_tile_offsets, dim3(1), 1024, s, tile_nn, tile_nr, n_tiles, tile_noff, tile_roff, n_nodes, n_runs, reset, n_reset, tile_gain, gain_total);
 }
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,

@@ -792,18 +792,14 @@ void trace_graph(np2_ctx *cx, np2_contig *c, int pass, uint32_t n_nodes) {
 // DP + backtrack + LQ regions; returns consensus length M and region count
 // One read-back at the end: consensus length, region count, error word.  The consensus length stays on the device
 // (eoff[L]) while the consensus and the LQ regions are built; launches and buffers are sized by M <= L + T.
-void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T) {
-    hipStream_t s = cx->stream;
+struct CnsBounds {
+    uint32_t M_cap, lq_cap, n_words;
+};
+CnsBounds cns_buffers(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T) {
     const uint32_t L = c->L;
     if ((uint64_t)L + T + 2 >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "consensus bound exceeds 32 bits");
     const uint32_t M_cap = L + T + 2; // a path node emits at most one base; exception nodes <= T
-    GraphPtrs gp = graph_ptrs(cx, c);
-    cx->n0_besti.ensure(L + 2);
-    cx->run_gain.ensure((size_t)n_runs + 2);
-    cx->run_flag.ensure((size_t)n_runs + 2);
-    cx->emit.ensure(L + 2);
     cx->eoff.ensure(L + 2);
-    cx->bt_path.ensure((size_t)M_cap + 2);
     cx->cns_pos.ensure(M_cap + 2);
     cx->cns_base.ensure(M_cap + 2);
     cx->cns_cls.ensure(M_cap + 2);
@@ -827,6 +823,38 @@ void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, u
     const uint32_t n_words = (M_cap + 31) / 32;
     cx->lq_list.ensure((size_t)lq_cap + 2);
     cx->hbits.ensure((size_t)n_words + 2);
+    return CnsBounds{M_cap, lq_cap, n_words};
+}
+// raw LQ regions from the list of low-quality bases (n_lq of them, a device-side count): chain heads marked in a bitmap
+// over the emission indices, heads per word scanned, regions written out in bit order (right -> left, the reference's
+// numbering), then merged (main.rs:1613-1615)
+void lq_regions_issue(np2_ctx *cx, const CnsBounds &b, const uint32_t *M_p, const uint32_t *n_lq) {
+    hipStream_t s = cx->stream;
+    EventTimer t(cx, "lq_regions");
+    zero32(cx, cx->hbits.p, b.n_words + 1);
+    launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, cx->lq_list.p, n_lq, b.lq_cap, cx->lq_kind.p,
+                   cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, cx->rstart.p, cx->rend.p);
+    launch_lq_bits_count(s, cx->hbits.p, b.n_words, cx->rflag.p);
+    exclusive_total(cx, cx->rflag.p, cx->ridx.p, (size_t)b.n_words + 1); // (rflag[n_words] = 0)
+    launch_scatter_regions(s, cx->hbits.p, b.n_words, cx->ridx.p, cx->rstart.p, cx->rend.p, cx->raw_start.p,
+                           cx->raw_end.p, cx->scal.p + S_NRAW);
+    launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p);
+    launch_scan_small_excl(s, cx->headflag.p, cx->hidx.p, b.M_cap, cx->scal.p + S_NRAW, nullptr, false);
+    launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
+                          cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
+}
+
+void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_runs, uint32_t T) {
+    hipStream_t s = cx->stream;
+    const uint32_t L = c->L;
+    const CnsBounds cb = cns_buffers(cx, c, n_nodes, n_runs, T);
+    const uint32_t M_cap = cb.M_cap, lq_cap = cb.lq_cap;
+    GraphPtrs gp = graph_ptrs(cx, c);
+    cx->n0_besti.ensure(L + 2);
+    cx->run_gain.ensure((size_t)n_runs + 2);
+    cx->run_flag.ensure((size_t)n_runs + 2);
+    cx->emit.ensure(L + 2);
+    cx->bt_path.ensure((size_t)M_cap + 2);
     cx->lqc.ensure((size_t)n_runs + 4);
     cx->lqoff.ensure((size_t)n_runs + 4);
     const uint32_t *const n_lq = cx->lqoff.p + n_runs; // total of the scanned per-run counts (n_runs: host-side bound)
@@ -870,33 +898,94 @@ void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, u
         exclusive_total(cx, cx->emit.p, cx->eoff.p, (size_t)L + 1);
         launch_bt_write(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->emit.p, cx->eoff.p, cx->bt_path.p,
                         cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, cx->lq_nothead.p, cx->lqc.p);
-    }
-    {
-        EventTimer t(cx, "lq_regions");
-        // raw regions: chain heads marked in a bitmap over the emission indices, heads per word scanned, regions
-        // written out in bit order (right -> left, the reference's numbering)
         exclusive_total(cx, cx->lqc.p, cx->lqoff.p, (size_t)n_runs + 1); // (lqc[n_runs] = 0)
         launch_lq_list(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->emit.p, cx->eoff.p, cx->bt_path.p,
                        cx->lqoff.p, lq_cap, cx->lq_list.p, cx->scal.p + S_ERR);
-        zero32(cx, cx->hbits.p, n_words + 1);
-        launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, cx->lq_list.p, n_lq, lq_cap, cx->lq_kind.p,
-                       cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, cx->rstart.p, cx->rend.p);
-        launch_lq_bits_count(s, cx->hbits.p, n_words, cx->rflag.p);
-        exclusive_total(cx, cx->rflag.p, cx->ridx.p, (size_t)n_words + 1); // (rflag[n_words] = 0)
-        launch_scatter_regions(s, cx->hbits.p, n_words, cx->ridx.p, cx->rstart.p, cx->rend.p, cx->raw_start.p,
-                               cx->raw_end.p, cx->scal.p + S_NRAW);
-        launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p);
-        launch_scan_small_excl(s, cx->headflag.p, cx->hidx.p, M_cap, cx->scal.p + S_NRAW, nullptr, false);
-        launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
-                              cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
     }
+    lq_regions_issue(cx, cb, M_p, n_lq);
+}
+
+// The same stage through the fused pass front (np2_passfront.hip): records of a tile -> the tile's piece of the consensus
+// in one kernel, one scan over the per-tile counts, one compaction; no graph arrays in memory.  Needs the bucketed record
+// layout with k_tile_sort's position index.  A pass the fused kernels cannot hold (PF_REDO) or whose best path score is
+// negative is redone by the kernels above (pass_front_finish).
+bool front_can_fuse(np2_ctx *cx) {
+    // (read per pass, not cached: the tests switch it inside one process)
+    return getenv("NP2_FRONT_UNFUSED") == nullptr && cx->bucket_cap != 0 && cx->pidx_valid;
+}
+static uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *e = getenv(name);
+    return e ? (uint32_t)atol(e) : dflt;
+}
+void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
+    hipStream_t s = cx->stream;
+    const uint32_t L = c->L;
+    const uint32_t n_tiles = (L + TILE - 1) >> TILE_SHIFT;
+    const CnsBounds cb = cns_buffers(cx, c, T, std::min<uint32_t>(T, L), T);
+    cx->pf_slots.ensure(pf_slot_entries(n_tiles, T));
+    cx->pf_bad.ensure((size_t)n_tiles + 2);
+    // (test hooks: lower the LDS variants' limits so that small inputs take the big variant / the unfused redo)
+    const uint32_t cap_lim = env_u32("NP2_PF_CAP", PF_CAP), cap_big = env_u32("NP2_PF_CAP_BIG", PF_CAP_BIG),
+                   halo_lim = env_u32("NP2_PF_HALO", PF_HALO) & ~15u, cov_max = env_u32("NP2_PF_COV_MAX", PF_COV_MAX);
+    PfTile a{cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->tile_pidx.p, cx->alive.p, c->reads.p,
+             c->tile_rd_off.p, c->tile_rd.p, c->refnib.p, cx->pf_slots.p, cx->tile_nn.p, cx->tile_nr.p,
+             (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p,
+             (long long *)(cx->scal.p + S_PFEND0), (unsigned long long *)(cx->scal.p + S_PFGAIN0), L, n_tiles, cx->bucket_cap,
+             cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min)};
+    uint32_t *const M_p = cx->eoff.p + L;
+    uint32_t *const n_lq = cx->scal.p + S_NRUNS;
+    {
+        EventTimer t(cx, "pass_front");
+        launch_pf_tile(s, a);
+        // consensus offset and low-quality offset of every tile, their totals (consensus length -> eoff[L]), the total of the
+        // gains; also resets the per-pass scalars S_BEST .. S_NLQ like the unfused build
+        const bool wide = n_tiles >= 2048;
+        Lookback lb{};
+        if (wide) lb = next_lookback(cx, tile_scan_blocks(n_tiles));
+        launch_tile_offsets(s, cx->tile_nn.p, cx->tile_nr.p, n_tiles, cx->tile_noff.p, cx->tile_roff.p, M_p, n_lq,
+                            cx->scal.p + S_BEST, S_NLQ + 1 - S_BEST, wide ? &lb : nullptr, cx->scal.p + S_ERR,
+                            (const long long *)cx->tile_gain.p, (unsigned long long *)(cx->scal.p + S_PFGAIN0));
+        launch_pf_compact(s, n_tiles, cx->pf_slots.p, cx->tile_scan.p, cx->tile_nn.p, cx->tile_noff.p, cx->tile_roff.p,
+                          cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, cx->lq_nothead.p, cx->lq_list.p, cb.lq_cap,
+                          cx->scal.p + S_ERR, cx->scal.p + S_PF, cx->scal.p + S_PFOUT, cx->scal.p + S_NBAD);
+    }
+    lq_regions_issue(cx, cb, M_p, n_lq);
+}
+
+// graph + consensus + LQ regions of a pass, issued (no wait): fused where possible
+void pass_front_issue(np2_ctx *cx, np2_contig *c, uint32_t T, int pass, bool force_unfused = false) {
+    cx->front_fused = !force_unfused && front_can_fuse(cx);
+    if (!cx->front_fused || cx->trace) { // (stage traces of the graph come from the unfused build)
+        uint32_t n_nodes = 0, n_runs = 0;
+        {
+            WallTimer w(cx, "wall_graph");
+            build_graph(cx, c, T, n_nodes, n_runs);
+        }
+        trace_graph(cx, c, pass, n_nodes);
+        if (!cx->front_fused) {
+            consensus_and_regions_issue(cx, c, n_nodes, n_runs, T);
+            return;
+        }
+    }
+    pass_front_fused_issue(cx, c, T);
 }
 // ... and the read-back that ends the stage: consensus length, region count, the error word
-void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t &M, uint32_t &n_reg) {
+void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t T, int pass, uint32_t &M, uint32_t &n_reg) {
     const uint32_t *M_p = cx->eoff.p + c->L;
     std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
+    if (cx->front_fused) {
+        const int64_t total = (int64_t)(((uint64_t)sc[S_PFGAIN1] << 32) | sc[S_PFGAIN0]);
+        const int64_t end_rel = (int64_t)(((uint64_t)sc[S_PFEND1] << 32) | sc[S_PFEND0]);
+        const bool negative = end_rel <= SCORE_NEG / 2 || total + end_rel < 0; // main.rs:1651,1680: no end node reaches 0
+        if ((sc[S_PFOUT] & PF_REDO) || negative) {
+            ++cx->front_redos;
+            cx->timing.host.push_back({"front_redo", 1.0f}); // (a count, read through np2_last_timings by the tests)
+            pass_front_issue(cx, c, T, pass, true);
+            sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
+        }
+    }
     check_region_err(cx, sc[S_ERR]);
-    if (sc[S_BEST] == 0xFFFFFFFFu)
+    if (!cx->front_fused && sc[S_BEST] == 0xFFFFFFFFu)
         throw Np2Error(NP2_E_UNSUPPORTED,
                        "best path score is negative at the contig end (reference would emit its default node)");
     M = sc[S_M0];
@@ -1080,17 +1169,11 @@ void run_pass_front(PolishRun &r) {
     np2_ctx *cx = r.cx;
     np2_contig *c = r.c;
     if (!r.reuse) {
-        uint32_t n_nodes = 0, n_runs = 0;
-        if (!r.front_issued) {
-            WallTimer w(cx, "wall_graph");
-            build_graph(cx, c, r.T, n_nodes, n_runs);
-        }
-        trace_graph(cx, c, (int)r.pass, n_nodes);
         {
             WallTimer w(cx, "wall_cns_lq");
-            if (!r.front_issued) consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
+            if (!r.front_issued) pass_front_issue(cx, c, r.T, (int)r.pass);
             r.front_issued = false;
-            consensus_and_regions_finish(cx, c, r.M, r.n_reg);
+            consensus_and_regions_finish(cx, c, r.T, (int)r.pass, r.M, r.n_reg);
         }
         if (cx->trace) {
             trace_cns(cx, (int)r.pass, "cns_raw", fetch_cns(cx, r.M));
@@ -1275,9 +1358,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
         launch_kill_flagged(cx->stream, vd->d_bad, c->R, cx->alive.p);
         ++r.pass; // (what run_apply_losers does; the pass cannot be a reuse of the last one: reads are going)
         r.reuse = false;
-        uint32_t n_nodes = 0, n_runs = 0;
-        build_graph(cx, c, r.T, n_nodes, n_runs);
-        consensus_and_regions_issue(cx, c, n_nodes, n_runs, r.T);
+        pass_front_issue(cx, c, r.T, (int)r.pass);
         r.front_issued = true;
         op_submit(cx);
         vd->own(); // (the pairs sit in the context's read-back staging, which the pipeline goes on using)
@@ -1473,7 +1554,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     HIPCHK(hipMemcpyAsync(c->ck_off.p, ck, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
     if (c->n_chunks)
         HIPCHK(hipMemcpyAsync(c->descs.p, descs, (size_t)c->n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
-    cx->scal.ensure(64);
+    cx->scal.ensure(SCAL_TOTAL);
     zero32(cx, cx->scal.p, 24);
     launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p);
     auto sc = d2h(cx, cx->scal.p, 1); // also syncs: the pinned staging blocks above go back to the pool

@@ -201,15 +201,48 @@ void launch_gather_spill(hipStream_t s, const np2_read_t *reads, const uint8_t *
 void launch_tile_count(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, uint32_t n_tiles, const uint8_t *alive,
                        uint32_t *tile_nn, uint32_t *tile_nr);
+// (tile_gain != nullptr: the per-tile shares of the path score are added up into *gain_total as well — the fused pass front)
 void launch_tile_offsets(hipStream_t s, const uint32_t *tile_nn, const uint32_t *tile_nr, uint32_t n_tiles,
                          uint32_t *tile_noff, uint32_t *tile_roff, uint32_t *n_nodes, uint32_t *n_runs, uint32_t *reset,
-                         uint32_t n_reset, const Lookback *lb = nullptr, uint32_t *err = nullptr);
+                         uint32_t n_reset, const Lookback *lb = nullptr, uint32_t *err = nullptr,
+                         const long long *tile_gain = nullptr, unsigned long long *gain_total = nullptr);
 void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals, const uint32_t *tile_n,
                        const uint32_t *tile_scan, uint32_t bucket_cap, const uint32_t *tile_noff, const uint32_t *tile_roff,
                        uint32_t n_tiles, const uint8_t *alive, uint32_t L, NodeArrays nd, uint2 *nrec, uint32_t *node_off,
                        uint32_t *run_start, const np2_read_t *reads, const uint32_t *tile_rd_off, const uint32_t *tile_rd,
                        int32_t *cov, const uint8_t *refnib, uint32_t *emit, long long *tile_gain, uint32_t *deep_flag, uint32_t deep_min,
                        uint8_t *pflag);
+
+// ---- np2_passfront.hip: the front of a pass on chip (records of a tile -> the tile's piece of the consensus) -----------
+static constexpr uint32_t PF_CAP = 960;      // records (tile + halo) the ordinary variant stages in LDS
+static constexpr uint32_t PF_HALO = 64;      // positions of the next tile it sees
+static constexpr uint32_t PF_CAP_BIG = 3584; // the big variant (listed tiles): records, and a whole tile of halo
+static constexpr uint32_t PF_COV_MAX = 8192; // coverage from which a pass goes through the unfused kernels (32-bit scores, 14-bit counts)
+static constexpr uint32_t PF_REDO = 1u;      // flag word: this pass has to be redone by the unfused kernels
+struct PfTile {
+    const uint64_t *keys; // sorted records, bucketed layout: tile t at [t * bucket_cap, + tile_n[t])
+    const uint32_t *vals;
+    const uint32_t *tile_n, *tile_scan;
+    const uint16_t *pidx;  // per tile: first record at or beyond every 16th position (k_tile_sort)
+    const uint8_t *alive;
+    const np2_read_t *reads;
+    const uint32_t *tile_rd_off, *tile_rd;
+    const uint8_t *refnib;
+    uint16_t *slots;       // per-tile consensus entries: position in the tile | base code << 11 | class << 14
+    uint32_t *tile_cnt, *tile_lq; // entries / low-quality entries per tile
+    long long *tile_gain;  // the tile's share of the path score
+    uint32_t *flags, *n_bad, *bad_list;
+    long long *end_rel;    // score of the best end node relative to the total of the gains
+    unsigned long long *gain_total; // (zeroed here for k_tile_offsets)
+    uint32_t L, n_tiles, bucket_cap;
+    uint32_t cap_lim, cap_lim_big, halo_lim, cov_max; // PF_CAP, PF_CAP_BIG, PF_HALO, PF_COV_MAX unless a test lowers them
+};
+uint64_t pf_slot_entries(uint32_t n_tiles, uint64_t T); // 16-bit entries the slot array needs
+void launch_pf_tile(hipStream_t s, const PfTile &a);
+void launch_pf_compact(hipStream_t s, uint32_t n_tiles, const uint16_t *slots, const uint32_t *tile_scan, const uint32_t *tile_cnt,
+                       const uint32_t *tile_coff, const uint32_t *tile_lqoff, uint32_t *cns_pos, uint8_t *cns_base,
+                       uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lq_list, uint32_t lq_cap, uint32_t *err, uint32_t *flags,
+                       uint32_t *flags_out, uint32_t *n_bad);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)
