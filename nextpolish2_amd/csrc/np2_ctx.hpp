@@ -510,6 +510,7 @@ struct np2_ctx {
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
     DevBuf<uint16_t> pf_slots; // fused pass front: per-tile consensus entries
     DevBuf<uint32_t> pf_bad;   // ... tiles listed for the big variant
+    DevBuf<uint64_t> pf_prof;  // ... phase timers (NP2_PF_PROF)
     bool front_fused = false;  // the pass front under way went through the fused kernels (np2_passfront.hip)
     uint32_t front_redos = 0;  // passes the fused front handed back to the unfused kernels (tests read it through the timings)
     DevBuf<uint16_t> kscore_saved;

@@ -930,13 +930,43 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
     PfTile a{cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->tile_pidx.p, cx->alive.p, c->reads.p,
              c->tile_rd_off.p, c->tile_rd.p, c->refnib.p, cx->pf_slots.p, cx->tile_nn.p, cx->tile_nr.p,
              (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p,
-             (long long *)(cx->scal.p + S_PFEND0), (unsigned long long *)(cx->scal.p + S_PFGAIN0), L, n_tiles, cx->bucket_cap,
+             (long long *)(cx->scal.p + S_PFEND0), (unsigned long long *)(cx->scal.p + S_PFGAIN0), nullptr, L, n_tiles, cx->bucket_cap,
              cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min)};
     uint32_t *const M_p = cx->eoff.p + L;
     uint32_t *const n_lq = cx->scal.p + S_NRUNS;
+    const bool prof = getenv("NP2_PF_PROF") != nullptr && tl_recorder() == nullptr; // (phase timers of the tile kernel: a tool's switch)
+    if (prof) {
+        cx->pf_prof.ensure((size_t)n_tiles * 8 + 8);
+        zero32(cx, cx->pf_prof.p, (size_t)n_tiles * 8, 8);
+        a.prof = (unsigned long long *)cx->pf_prof.p;
+    }
     {
         EventTimer t(cx, "pass_front");
         launch_pf_tile(s, a);
+        if (prof) {
+            auto st = d2h(cx, cx->pf_prof.p, (size_t)n_tiles * 8);
+            double sum[8] = {0}, mx[8] = {0};
+            size_t cnt = 0;
+            for (uint32_t t = 0; t < n_tiles; ++t) {
+                const uint64_t *q = st.data() + (size_t)t * 8;
+                if (!q[7] || !q[0]) continue; // (a tile the small variant did not finish)
+                ++cnt;
+                for (int i = 1; i < 8; ++i) {
+                    const double d = (double)(q[i] - q[i - 1]);
+                    sum[i] += d, mx[i] = std::max(mx[i], d);
+                }
+            }
+            {
+                auto tn = d2h(cx, cx->tile_n.p, n_tiles);
+                uint32_t h[6] = {0};
+                for (uint32_t v : tn) ++h[v <= 480 ? 0 : v <= 960 ? 1 : v <= 1440 ? 2 : v <= 1920 ? 3 : v <= 3584 ? 4 : 5];
+                fprintf(stderr, "[pf_prof] records per tile <=480 / 960 / 1440 / 1920 / 3584 / more: %u %u %u %u %u %u; ", h[0], h[1], h[2], h[3], h[4], h[5]);
+            }
+            fprintf(stderr, "listed for the big variant: %u; ", d2h(cx, cx->scal.p + S_NBAD, 1)[0]);
+            fprintf(stderr, "tiles %zu of %u; mean / max clocks per phase (loads, cover+nodes, offsets+sort, DP, reduce, count+scan, write):", cnt, n_tiles);
+            for (int i = 1; i < 8; ++i) fprintf(stderr, " %.0f/%.0f", cnt ? sum[i] / cnt : 0.0, mx[i]);
+            fprintf(stderr, "\n");
+        }
         // consensus offset and low-quality offset of every tile, their totals (consensus length -> eoff[L]), the total of the
         // gains; also resets the per-pass scalars S_BEST .. S_NLQ like the unfused build
         const bool wide = n_tiles >= 2048;

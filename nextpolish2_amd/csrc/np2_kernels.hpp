@@ -234,6 +234,7 @@ struct PfTile {
     uint32_t *flags, *n_bad, *bad_list;
     long long *end_rel;    // score of the best end node relative to the total of the gains
     unsigned long long *gain_total; // (zeroed here for k_tile_offsets)
+    unsigned long long *prof;       // nullptr, or 8 clock stamps per tile (NP2_PF_PROF)
     uint32_t L, n_tiles, bucket_cap;
     uint32_t cap_lim, cap_lim_big, halo_lim, cov_max; // PF_CAP, PF_CAP_BIG, PF_HALO, PF_COV_MAX unless a test lowers them
 };

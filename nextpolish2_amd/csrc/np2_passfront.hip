@@ -35,6 +35,8 @@ static constexpr uint32_t PF_COUNT_BITS = 14;                 // node word: coun
 static constexpr uint32_t PF_IDX_MASK = (1u << PF_COUNT_BITS) - 1;
 static constexpr uint32_t PF_VISITED = 0x80000000u;
 static constexpr uint32_t PF_N0_VISITED = 0x8000u;            // per-position word: best predecessor of N0 | visited << 15
+static constexpr uint32_t PF_N0_WEAK = 0x4000u;               // ... before the DP: a dirty position whose exception nodes all lose (| e0)
+static constexpr uint32_t PF_N0_STRONG = 0x2000u;             // ... a dirty position that needs the DP
 static constexpr int32_t PF_NEG = -(1 << 30);                 // "unreachable" in the 32-bit relative scores
 
 __device__ __forceinline__ uint8_t pf_ref_code(const uint8_t *__restrict__ refnib, uint32_t p) {
@@ -85,6 +87,11 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t L = A.L, start = t << TILE_SHIFT;
+    // (phase timers of a tile, thread 0, for tools/pf_prof.py: NP2_PF_PROF)
+    auto stamp = [&](uint32_t i) {
+        if (A.prof && tid == 0) A.prof[(size_t)t * 8 + i] = (unsigned long long)clock64();
+    };
+    stamp(0);
     const uint32_t npos = min((uint32_t)TILE, L - start);          // positions this tile emits clean bases for
     const bool has_next = t + 1 < A.n_tiles;
     const uint32_t n = A.tile_n[t];
@@ -195,6 +202,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         add_read(i, A.alive[r], A.reads[r].aln_t_s, A.reads[r].aln_t_e);
     }
     __syncthreads();
+    stamp(1);
     // ---- coverage of the thread's positions (four of the tile + its share of the halo) -----------------------------------
     int32_t cv[4], cvh[HP];
     {
@@ -275,6 +283,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     }
     __syncthreads();
     (void)nn;
+    stamp(2);
     // ---- node offsets of the positions, coverage and contig codes into their final LDS places ----------------------------
     const uint32_t c0 = s_cnt[q0], c1 = s_cnt[q0 + 1], c2 = s_cnt[q0 + 2], c3 = s_cnt[q0 + 3];
     uint32_t ch[HP], chs = 0;
@@ -351,6 +360,35 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
             o += ch[j];
         }
     }
+    // ---- which dirty positions need the DP at all?  If every exception node whose second column lies one position back has
+    // a smaller count than the contig's node, and every node of an insertion column (second column at the same position) a
+    // negative weight (10 * count < 4 * coverage), then a path that leaves the contig's nodes anywhere in the run scores
+    // strictly less than the one that stays on them — no tie rule gets a say — and the run's consensus is the contig's.
+    // That is what a sequencing error in one read out of thirty looks like: ~9 runs of 10.  The word carries e0 (the
+    // exception columns that are not insertion columns: count of N0 = coverage - e0) for the gain and the quality class.
+    auto weak_word = [&](uint32_t o0, uint32_t cnt, int32_t cov) -> uint16_t {
+        uint32_t e0 = 0, maxrep = 0;
+        bool ok = true;
+        for (uint32_t k = o0; k < o0 + cnt; ++k) {
+            const uint32_t key = s_nkey[k], c = s_ncw[k];
+            if (key & 0x1000u)
+                ok = ok && 10 * c < 4 * (uint32_t)cov;
+            else
+                e0 += c, maxrep = max(maxrep, c);
+        }
+        return (uint16_t)((ok && maxrep + e0 < (uint32_t)cov) ? (PF_N0_WEAK | e0) : PF_N0_STRONG);
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (cj[j]) s_n0bi[q0 + j] = weak_word(off[j], cj[j], cv[j]);
+    {
+        uint32_t o = lh;
+#pragma unroll
+        for (uint32_t j = 0; j < HP; ++j) {
+            if (ch[j]) s_n0bi[TILE + tid * HP + j] = weak_word(o, ch[j], cvh[j]);
+            o += ch[j];
+        }
+    }
     // ---- clean positions' share of the path score, dirty-run starts ---------------------------------------------------------
     long long gain = 0;
     {
@@ -378,10 +416,41 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         }
         return;
     }
+    stamp(3);
     // ---- DP + backtrack: one thread per dirty run that starts in this tile -------------------------------------------------
-    for (uint32_t r = tid; r < n_runs; r += 256) {
+    // The kernel is bound by instruction issue, and a wavefront pays for the longest path among its lanes: the runs go to
+    // consecutive lanes of ONE wavefront (a tile has a few dozen), which one rotates with the tile (a block's four
+    // wavefronts sit on the CU's four SIMDs).
+    for (uint32_t r = (tid + 256 - 64 * (t & 3)) & 255; r < n_runs; r += 256) {
         const uint32_t qa = s_run[r];
         const uint32_t a = start + qa;
+        if (a >= 3) { // all positions weak (above): the path stays on the contig's nodes
+            uint32_t q = qa;
+            int32_t g = 0;
+            bool weak = true, closed = false;
+            for (; q < ext; ++q) {
+                const uint32_t x = s_n0bi[q];
+                if (x == 0) { // the clean position that closes the run
+                    closed = true;
+                    break;
+                }
+                if (!(x & PF_N0_WEAK)) {
+                    weak = false;
+                    break;
+                }
+                const int32_t cov = s_cov[q];
+                g += 10 * (cov - (int32_t)(x & 0x1FFFu)) - 4 * cov;
+                s_n0bi[q] = (uint16_t)(x | PF_N0_VISITED); // (the DP below starts over on these words if the run turns out strong)
+            }
+            if (weak && closed) {
+                gain += g + 6 * (int32_t)s_cov[q];
+                continue;
+            }
+            if (weak && start + q != L) { // still open at the end of the halo
+                s_flag[1] = 1;
+                continue;
+            }
+        }
         // scores relative to N0(a - 1); a run starting at position 1 or 2 competes with a read's start node on absolute
         // scores (k_dp_bt_*'s early_run_base): N0(0) is a path start, position 1 is clean when a == 2
         int32_t base = 0;
@@ -519,9 +588,11 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
             widx = bi;
         }
     }
+    stamp(4);
     for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
     if (lane == 0) s_gain[wv] = gain;
     __syncthreads();
+    stamp(5);
     if (s_flag[1]) { // (uniform) a run did not close inside the halo
         if (tid == 0) {
             A.tile_cnt[t] = 0, A.tile_lq[t] = 0, A.tile_gain[t] = 0;
@@ -566,21 +637,24 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         }
         return m;
     };
+    // (offsets, coverage and contig codes come back from LDS here: kept in registers across the DP they cost a third of the
+    // kernel's occupancy)
+    auto pos_do = [&](uint32_t q, uint16_t *out, uint32_t &n_lq) -> uint32_t {
+        const uint32_t o0 = s_off[q];
+        return pos_entries(q, s_off[q + 1] - o0, o0, (int32_t)s_cov[q], s_ref[3 + q], out, n_lq);
+    };
     uint32_t em[4], emh[HP], ems = 0, emhs = 0, dummy = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
-        em[j] = pos_entries(q0 + j, cj[j], off[j], cv[j], (ref4 >> (4 * j)) & 7, nullptr, dummy);
+        em[j] = pos_do(q0 + j, nullptr, dummy);
         ems += em[j];
     }
-    {
-        uint32_t o = lh;
 #pragma unroll
-        for (uint32_t j = 0; j < HP; ++j) {
-            emh[j] = 0;
-            if (tid * HP + j < HALO && ch[j]) emh[j] = pos_entries(TILE + tid * HP + j, ch[j], o, cvh[j], refh[j], nullptr, dummy);
-            emhs += emh[j];
-            o += ch[j];
-        }
+    for (uint32_t j = 0; j < HP; ++j) {
+        emh[j] = 0;
+        const uint32_t q = TILE + tid * HP + j;
+        if (tid * HP + j < HALO && s_off[q + 1] != s_off[q]) emh[j] = pos_do(q, nullptr, dummy);
+        emhs += emh[j];
     }
     uint32_t etot;
     uint32_t eo = block_excl_scan<OpAdd, 4>(ems, sh, etot);
@@ -592,24 +666,22 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     } else {
         eh = etot + block_excl_scan<OpAdd, 4>(emhs, sh, ehtot);
     }
+    stamp(6);
     uint16_t *const slot = A.slots + pf_slot_off(A.tile_scan, t);
     uint32_t n_lq = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
-        if (em[j]) pos_entries(q0 + j, cj[j], off[j], cv[j], (ref4 >> (4 * j)) & 7, slot + eo, n_lq);
+        if (em[j]) pos_do(q0 + j, slot + eo, n_lq);
         eo += em[j];
     }
-    {
-        uint32_t o = lh;
 #pragma unroll
-        for (uint32_t j = 0; j < HP; ++j) {
-            if (emh[j]) pos_entries(TILE + tid * HP + j, ch[j], o, cvh[j], refh[j], slot + eh, n_lq);
-            eh += emh[j];
-            o += ch[j];
-        }
+    for (uint32_t j = 0; j < HP; ++j) {
+        if (emh[j]) pos_do(TILE + tid * HP + j, slot + eh, n_lq);
+        eh += emh[j];
     }
     if (n_lq) atomicAdd(&s_flag[3], n_lq);
     __syncthreads();
+    stamp(7);
     if (tid == 0) {
         A.tile_cnt[t] = etot + ehtot;
         A.tile_lq[t] = s_flag[3];
