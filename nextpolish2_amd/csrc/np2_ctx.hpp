@@ -509,7 +509,7 @@ struct np2_ctx {
     DevBuf<uint8_t> pflag;               // per contig position: has exception nodes | coverage below 2
     DevBuf<uint32_t> dp_list; // runs the short-run DP kernel left to the long-run kernels (batch driver: one stream)
     DevBuf<uint16_t> pf_slots; // fused pass front: per-tile consensus entries
-    DevBuf<uint32_t> pf_bad;   // ... tiles listed for the big variant
+    DevBuf<uint32_t> pf_bad, pf_bad2; // ... tiles listed for the middle / the big variant
     DevBuf<uint64_t> pf_prof;  // ... phase timers (NP2_PF_PROF)
     bool front_fused = false;  // the pass front under way went through the fused kernels (np2_passfront.hip)
     uint32_t front_redos = 0;  // passes the fused front handed back to the unfused kernels (tests read it through the timings)
@@ -527,7 +527,7 @@ enum Scal { S_ERR = 0, S_NNODES, S_NRUNS, S_BEST, S_PATHBEGIN, S_NRAW, S_NREG, S
             S_GAIN1, S_DEEP, S_NDPLIST, S_NRECH, S_NGROUPS, S_NLONG, S_NLQ, S_PF, S_M0, S_M1, S_M2, S_M3, S_NC, S_SB, S_GROW,
             // the fused pass front (np2_passfront.hip): S_PF = flag word of the pass under way (above), tiles listed for the big
             // variant, the flags as the host reads them, total of the path-score gains, best end node's relative score
-            S_NBAD, S_PFOUT, S_PFGAIN0, S_PFGAIN1, S_PFEND0, S_PFEND1, S_COUNT = 32 };
+            S_NBAD, S_PFOUT, S_PFGAIN0, S_PFGAIN1, S_PFEND0, S_PFEND1, S_NBAD2, S_PFPAD, S_COUNT = 34 };
 static_assert(S_M1 % 2 == 0 && S_LAST0 % 2 == 0 && S_GAIN0 % 2 == 0 && S_PFGAIN0 % 2 == 0 && S_PFEND0 % 2 == 0,
               "64-bit device counters live in these slot pairs");
 

@@ -924,12 +924,13 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
     const CnsBounds cb = cns_buffers(cx, c, T, std::min<uint32_t>(T, L), T);
     cx->pf_slots.ensure(pf_slot_entries(n_tiles, T));
     cx->pf_bad.ensure((size_t)n_tiles + 2);
+    cx->pf_bad2.ensure((size_t)n_tiles + 2);
     // (test hooks: lower the LDS variants' limits so that small inputs take the big variant / the unfused redo)
     const uint32_t cap_lim = env_u32("NP2_PF_CAP", PF_CAP), cap_big = env_u32("NP2_PF_CAP_BIG", PF_CAP_BIG),
                    halo_lim = env_u32("NP2_PF_HALO", PF_HALO) & ~15u, cov_max = env_u32("NP2_PF_COV_MAX", PF_COV_MAX);
     PfTile a{cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->tile_pidx.p, cx->alive.p, c->reads.p,
              c->tile_rd_off.p, c->tile_rd.p, c->refnib.p, cx->pf_slots.p, cx->tile_nn.p, cx->tile_nr.p,
-             (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p,
+             (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p, cx->scal.p + S_NBAD2, cx->pf_bad2.p,
              (long long *)(cx->scal.p + S_PFEND0), (unsigned long long *)(cx->scal.p + S_PFGAIN0), nullptr, L, n_tiles, cx->bucket_cap,
              cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min)};
     uint32_t *const M_p = cx->eoff.p + L;
@@ -962,7 +963,7 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
                 for (uint32_t v : tn) ++h[v <= 480 ? 0 : v <= 960 ? 1 : v <= 1440 ? 2 : v <= 1920 ? 3 : v <= 3584 ? 4 : 5];
                 fprintf(stderr, "[pf_prof] records per tile <=480 / 960 / 1440 / 1920 / 3584 / more: %u %u %u %u %u %u; ", h[0], h[1], h[2], h[3], h[4], h[5]);
             }
-            fprintf(stderr, "listed for the big variant: %u; ", d2h(cx, cx->scal.p + S_NBAD, 1)[0]);
+            fprintf(stderr, "listed for the middle / the big variant: %u / %u; ", d2h(cx, cx->scal.p + S_NBAD, 1)[0], d2h(cx, cx->scal.p + S_NBAD2, 1)[0]);
             fprintf(stderr, "tiles %zu of %u; mean / max clocks per phase (loads, cover+nodes, offsets+sort, DP, reduce, count+scan, write):", cnt, n_tiles);
             for (int i = 1; i < 8; ++i) fprintf(stderr, " %.0f/%.0f", cnt ? sum[i] / cnt : 0.0, mx[i]);
             fprintf(stderr, "\n");
@@ -977,7 +978,7 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
                             (const long long *)cx->tile_gain.p, (unsigned long long *)(cx->scal.p + S_PFGAIN0));
         launch_pf_compact(s, n_tiles, cx->pf_slots.p, cx->tile_scan.p, cx->tile_nn.p, cx->tile_noff.p, cx->tile_roff.p,
                           cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, cx->lq_nothead.p, cx->lq_list.p, cb.lq_cap,
-                          cx->scal.p + S_ERR, cx->scal.p + S_PF, cx->scal.p + S_PFOUT, cx->scal.p + S_NBAD);
+                          cx->scal.p + S_ERR, cx->scal.p + S_PF, cx->scal.p + S_PFOUT, cx->scal.p + S_NBAD, cx->scal.p + S_NBAD2);
     }
     lq_regions_issue(cx, cb, M_p, n_lq);
 }

@@ -216,7 +216,8 @@ void launch_tile_write(hipStream_t s, const uint64_t *keys, const uint32_t *vals
 // ---- np2_passfront.hip: the front of a pass on chip (records of a tile -> the tile's piece of the consensus) -----------
 static constexpr uint32_t PF_CAP = 960;      // records (tile + halo) the ordinary variant stages in LDS
 static constexpr uint32_t PF_HALO = 64;      // positions of the next tile it sees
-static constexpr uint32_t PF_CAP_BIG = 3584; // the big variant (listed tiles): records, and a whole tile of halo
+static constexpr uint32_t PF_CAP_MID = 2048; // the middle variant (tiles the ordinary one listed): records; the same halo
+static constexpr uint32_t PF_CAP_BIG = 3584; // the big variant (tiles the middle one listed): records, and a whole tile of halo
 static constexpr uint32_t PF_COV_MAX = 8192; // coverage from which a pass goes through the unfused kernels (32-bit scores, 14-bit counts)
 static constexpr uint32_t PF_REDO = 1u;      // flag word: this pass has to be redone by the unfused kernels
 struct PfTile {
@@ -231,7 +232,7 @@ struct PfTile {
     uint16_t *slots;       // per-tile consensus entries: position in the tile | base code << 11 | class << 14
     uint32_t *tile_cnt, *tile_lq; // entries / low-quality entries per tile
     long long *tile_gain;  // the tile's share of the path score
-    uint32_t *flags, *n_bad, *bad_list;
+    uint32_t *flags, *n_bad, *bad_list, *n_bad2, *bad_list2;
     long long *end_rel;    // score of the best end node relative to the total of the gains
     unsigned long long *gain_total; // (zeroed here for k_tile_offsets)
     unsigned long long *prof;       // nullptr, or 8 clock stamps per tile (NP2_PF_PROF)
@@ -243,7 +244,7 @@ void launch_pf_tile(hipStream_t s, const PfTile &a);
 void launch_pf_compact(hipStream_t s, uint32_t n_tiles, const uint16_t *slots, const uint32_t *tile_scan, const uint32_t *tile_cnt,
                        const uint32_t *tile_coff, const uint32_t *tile_lqoff, uint32_t *cns_pos, uint8_t *cns_base,
                        uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lq_list, uint32_t lq_cap, uint32_t *err, uint32_t *flags,
-                       uint32_t *flags_out, uint32_t *n_bad);
+                       uint32_t *flags_out, uint32_t *n_bad, uint32_t *n_bad2);
 
 // ---- np2_regions.hip: region-logic kernels --------------------------------------------------------
 struct RegionTables { // GPU-resident candidate tables of one pass (LqSeqs / LqSeq, main.rs:647-667)

@@ -57,7 +57,9 @@ __device__ __forceinline__ uint64_t pf_slot_off(const uint32_t *__restrict__ til
     return (uint64_t)t * (TILE + 1) + tile_scan[t] + 2ull * (tile_scan[t + 1] - tile_scan[1]);
 }
 
-template <uint32_t CAP, uint32_t HALO, bool BIG>
+// LEVEL 0: every tile; 1: the tiles level 0 listed (more records); 2: the tiles level 1 listed (more records still, and a
+// whole tile of halo); what level 2 cannot hold sets PF_REDO
+template <uint32_t CAP, uint32_t HALO, int LEVEL>
 __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) {
     constexpr uint32_t E = TILE + HALO;                 // positions a block sees
     constexpr uint32_t RPT = (CAP + 255) / 256;         // records per thread
@@ -95,7 +97,18 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     const uint32_t npos = min((uint32_t)TILE, L - start);          // positions this tile emits clean bases for
     const bool has_next = t + 1 < A.n_tiles;
     const uint32_t n = A.tile_n[t];
-    const uint32_t cap = min(CAP, BIG ? A.cap_lim_big : A.cap_lim);
+    constexpr bool BIG = LEVEL == 2;
+    const uint32_t cap = min(CAP, LEVEL == 2 ? A.cap_lim_big : (LEVEL == 1 ? max(A.cap_lim, min(A.cap_lim_big, PF_CAP_MID)) : A.cap_lim));
+    // a tile this level cannot hold goes on the next level's list (uniform; thread 0)
+    auto hand_on = [&]() {
+        A.tile_cnt[t] = 0, A.tile_lq[t] = 0, A.tile_gain[t] = 0; // (an empty slot, should nobody redo the tile)
+        if (LEVEL == 2)
+            atomicOr(A.flags, PF_REDO);
+        else if (LEVEL == 1)
+            A.bad_list2[atomicAdd(A.n_bad2, 1u)] = t;
+        else
+            A.bad_list[atomicAdd(A.n_bad, 1u)] = t;
+    };
     // the halo: PF_HALO positions (a test may lower it; a multiple of 16) — the big variant takes as much of the next tile as
     // its record capacity allows (k_tile_sort's index: records before every 16th position)
     uint32_t halo = BIG ? HALO : min(HALO, A.halo_lim), nh = 0; // nh: records of the next tile inside the halo
@@ -124,13 +137,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     const bool fits = nt <= cap;
     __syncthreads();
     if (!fits) { // (uniform)
-        if (tid == 0) {
-            A.tile_cnt[t] = 0, A.tile_lq[t] = 0, A.tile_gain[t] = 0; // (an empty slot, should nobody redo the tile)
-            if (BIG)
-                atomicOr(A.flags, PF_REDO);
-            else
-                A.bad_list[atomicAdd(A.n_bad, 1u)] = t;
-        }
+        if (tid == 0) hand_on();
         return;
     }
     // ---- level 1 of the dependent loads: records, read lists, the contig codes ----------------------------------------
@@ -594,13 +601,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     __syncthreads();
     stamp(5);
     if (s_flag[1]) { // (uniform) a run did not close inside the halo
-        if (tid == 0) {
-            A.tile_cnt[t] = 0, A.tile_lq[t] = 0, A.tile_gain[t] = 0;
-            if (BIG)
-                atomicOr(A.flags, PF_REDO);
-            else
-                A.bad_list[atomicAdd(A.n_bad, 1u)] = t;
-        }
+        if (tid == 0) hand_on();
         return;
     }
     // ---- write-out: every position emits its bases (clean: the contig's; dirty: the marked nodes, in node order) ------------
@@ -695,13 +696,21 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
 }
 
 __device__ __forceinline__ void k_pf_tile(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {
-    pf_tile_body<PF_CAP, PF_HALO, false>(np2_bid, A);
+    pf_tile_body<PF_CAP, PF_HALO, 0>(np2_bid, A);
 }
-// the tiles the kernel above listed, with room for 3584 records and a whole tile of halo (a handful of blocks walk the list)
-__device__ __forceinline__ void k_pf_tile_big(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {
+// the tiles the kernel above listed, with room for 2048 records (a handful of blocks walk the list) ...
+__device__ __forceinline__ void k_pf_tile_mid(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {
     const uint32_t nb = *A.n_bad;
     for (uint32_t i = np2_bid; i < nb; i += np2_nb) {
-        pf_tile_body<PF_CAP_BIG, TILE, true>(A.bad_list[i], A);
+        pf_tile_body<PF_CAP_MID, PF_HALO, 1>(A.bad_list[i], A);
+        __syncthreads();
+    }
+}
+// ... and what that one listed, with room for 3584 records and a whole tile of halo
+__device__ __forceinline__ void k_pf_tile_big(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {
+    const uint32_t nb = *A.n_bad2;
+    for (uint32_t i = np2_bid; i < nb; i += np2_nb) {
+        pf_tile_body<PF_CAP_BIG, TILE, 2>(A.bad_list2[i], A);
         __syncthreads();
     }
 }
@@ -715,13 +724,14 @@ __device__ __forceinline__ void k_pf_compact(const uint32_t np2_bid, const uint3
                                              uint8_t *__restrict__ cns_cls, uint8_t *__restrict__ lq_nothead,
                                              uint32_t *__restrict__ lq_list, uint32_t lq_cap, uint32_t *__restrict__ err,
                                              uint32_t *__restrict__ flags, uint32_t *__restrict__ flags_out,
-                                             uint32_t *__restrict__ n_bad) {
+                                             uint32_t *__restrict__ n_bad, uint32_t *__restrict__ n_bad2) {
     __shared__ uint32_t s_w[4];
     const uint32_t t = np2_bid, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (t == 0 && tid == 0) { // the pass's flags to where the host reads them; flags and bad-tile counter ready for the next pass
         *flags_out = *flags;
         *flags = 0;
         *n_bad = 0;
+        *n_bad2 = 0;
     }
     const uint32_t n = tile_cnt[t], o0 = tile_coff[t], start = t << TILE_SHIFT;
     const uint16_t *__restrict__ src = slots + pf_slot_off(tile_scan, t);
@@ -767,14 +777,15 @@ __device__ __forceinline__ void k_pf_compact(const uint32_t np2_bid, const uint3
 uint64_t pf_slot_entries(uint32_t n_tiles, uint64_t T) { return (uint64_t)n_tiles * (TILE + 1) + 3 * T + 64; }
 void launch_pf_tile(hipStream_t s, const PfTile &a) {
     NP2_LAUNCH(k_pf_tile, dim3(a.n_tiles), 256, s, a);
-    NP2_LAUNCH(k_pf_tile_big, dim3(std::min<uint32_t>(a.n_tiles, 256u)), 256, s, a);
+    NP2_LAUNCH(k_pf_tile_mid, dim3(std::min<uint32_t>(a.n_tiles, 256u)), 256, s, a);
+    NP2_LAUNCH(k_pf_tile_big, dim3(std::min<uint32_t>(a.n_tiles, 64u)), 256, s, a);
 }
 void launch_pf_compact(hipStream_t s, uint32_t n_tiles, const uint16_t *slots, const uint32_t *tile_scan, const uint32_t *tile_cnt,
                        const uint32_t *tile_coff, const uint32_t *tile_lqoff, uint32_t *cns_pos, uint8_t *cns_base,
                        uint8_t *cns_cls, uint8_t *lq_nothead, uint32_t *lq_list, uint32_t lq_cap, uint32_t *err, uint32_t *flags,
-                       uint32_t *flags_out, uint32_t *n_bad) {
+                       uint32_t *flags_out, uint32_t *n_bad, uint32_t *n_bad2) {
     NP2_LAUNCH(k_pf_compact, dim3(n_tiles), 256, s, slots, tile_scan, tile_cnt, tile_coff, tile_lqoff, cns_pos, cns_base, cns_cls,
-               lq_nothead, lq_list, lq_cap, err, flags, flags_out, n_bad);
+               lq_nothead, lq_list, lq_cap, err, flags, flags_out, n_bad, n_bad2);
 }
 
 } // namespace np2
