@@ -420,11 +420,28 @@ def spawn_ranks(n):
 
 
 def main_strong(a):
-    """Strong scaling on BASELINE configs[3]: ONE contig (248 Mb by default), 30x simulated HiFi, k21 + k31, cut into one
-    reference interval per rank (np2_shard_*; nextpolish2_amd.dist.polish_sharded).  The shards are resident in HBM before
-    the timed region; a step = the whole hot path of the contig: every rank's dense pass, its phasing pass, the all-gather
-    of the votes (RCCL), the contig-wide decision, the final pass, the strips around the cuts exchanged and checked, the
-    owned slices gathered from the device buffers onto rank 0 (RCCL over xGMI) and landed in one host array there."""
+    """`--scaling strong`: the strong-scaling line on its own (strong_measure below) — BASELINE configs[3], ONE contig of
+    248 Mb by default, diploid ("chr1 with injected SNV / indel") unless --haploid."""
+    setup = dist_setup()
+    if setup[1] != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={setup[1]}")
+    import torch.distributed as dist
+    out_line = strong_measure(a, setup, a.contig_mb, a.steps, a.warmup, not a.haploid, cpu_base=not a.no_cpu_baseline)
+    if setup[0] == 0:
+        print(json.dumps(out_line), flush=True)
+    if "RANK" in os.environ:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def strong_measure(a, setup, contig_mb, steps, warmup, diploid, cpu_base=False):
+    """Strong scaling: ONE contig, 30x simulated HiFi (15x per haplotype when diploid), k21 + k31, cut into one reference
+    interval per rank (np2_shard_*; nextpolish2_amd.dist.polish_sharded).  The shards are resident in HBM before the timed
+    region; a step = the whole hot path of the contig: every rank's dense pass, its phasing pass, the votes gathered onto
+    rank 0 (RCCL), the contig-wide decision there, the removed reads broadcast, the final pass, the strips around the cuts
+    exchanged and checked, the owned slices gathered from the device buffers onto rank 0 (RCCL over xGMI) and landed in one
+    host array there.  Returns the JSON object of the line (complete on rank 0)."""
     import torch
     import torch.distributed as dist
     from nextpolish2_amd import Opts, Polisher
@@ -432,15 +449,13 @@ def main_strong(a):
     from nextpolish2_amd.dist import polish_sharded
     from nextpolish2_amd.synth import Synth, concat_pileups
 
-    rank, world, local_rank, dev, cdev, backend = dist_setup()
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    rank, world, local_rank, dev, cdev, backend = setup
     distributed = "RANK" in os.environ
-    L = int(a.contig_mb * 1e6 * a.scale)
+    L = int(contig_mb * 1e6 * a.scale)
     n_parts = 16
     # every rank generates the same contig (seeded) and keeps only its shard in HBM
     with ThreadPoolExecutor(min(n_parts, os.cpu_count() or 1)) as ex:
-        parts = list(ex.map(lambda i: Synth(L // n_parts, depth=a.depth, seed=500 + i), range(n_parts)))
+        parts = list(ex.map(lambda i: Synth(L // n_parts, depth=a.depth, seed=500 + i, diploid=diploid), range(n_parts)))
     pu = concat_pileups([p.pileup for p in parts], "chr1")
     ks = [21, 31]
     yaks = [Synth.yak_assembly(parts, k) for k in ks]
@@ -463,24 +478,30 @@ def main_strong(a):
         torch.cuda.synchronize()
 
     diff_ms = []
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     import gc
     gc.collect()
     gc.disable()
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
         diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    stages = None
+    if os.environ.get("NP2_BENCH_STAGES"):  # one more, untimed step with every stage timer armed: where a step's time goes
+        pol.set_timing(True)
+        step()
+        stages = {k: round(v, 3) for k, v in sorted(pol.timings().items(), key=lambda kv: -kv[1])}
+        pol.set_timing(False)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = pu.L * a.steps / dt / 1e6
+    value = pu.L * steps / dt / 1e6
     # roofline of this rank's k_diff_reads launch: the reads of its zone, whole (sub-contig [sub_lo, sub_hi))
     pl = plans[rank]
     rd = pu.reads[pl.read_lo:pl.read_hi]
@@ -491,11 +512,13 @@ def main_strong(a):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out_line = {
         "metric": "polished reference Mbp/s (whole node) at 30x HiFi + k21/k31; FASTA identical to oracle",
-        "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"one contig of {pu.L / 1e6:.1f} Mb (BASELINE configs[3]: human chr1-sized), 30x simulated HiFi, "
+        "config": {"workload": f"one {'diploid' if diploid else 'haploid'} contig of {pu.L / 1e6:.1f} Mb (BASELINE configs[3]: human chr1 is 248 Mb), "
+                               f"30x simulated HiFi{' (15x per haplotype)' if diploid else ''}, "
                                f"k21 + k31 yak, cut into {world} reference interval(s), one per MI355X",
+                   "diploid": bool(diploid),
                    "contig_bp": pu.L, "depth": a.depth, "reads": pu.n_reads, "pileup_columns": int(pu.n_columns()) - pu.L,
                    "yak_k": ks, "iter_count": 2, "halo": 65536, "verify": 1024,
                    "parallelism": f"reference-interval shards x{world}: votes all-gathered and decided contig-wide per phasing "
@@ -506,17 +529,20 @@ def main_strong(a):
                      "alg_bytes_per_launch": int(alg_bytes), "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 4),
                      "units_per_launch_bp": int(pl.sub_hi - pl.sub_lo), "note": "rank 0's launch over its shard"},
     }
+    if stages is not None:
+        out_line["stage_ms_one_step"] = stages
     if rank == 0:
         b, span = last[0]
-        out_line["polished_equals_truth"] = bool(b.tobytes() == truth)
+        if not diploid:  # (a diploid contig is polished towards its reads' haplotypes: no single truth string)
+            out_line["polished_equals_truth"] = bool(b.tobytes() == truth)
         import zlib
         out_line["output_crc32"] = zlib.crc32(b.tobytes())  # (the same contig whatever N: the N-rank result must reproduce it)
         out_line["span"] = [int(span[0]), int(span[1])]
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu_base:
         # CPU baseline on a bounded sample: the reference polishes one contig on ONE thread whatever -t says
         # (main.rs:1726-1837), so the sample is a shorter contig of the same recipe on one core
         from oracle.np2_oracle import Oracle
-        sm = Synth(8_000_000, depth=a.depth, seed=77)
+        sm = Synth(8_000_000, depth=a.depth, seed=77, diploid=diploid)
         ys = [sm.yak(k) for k in ks]
         t1 = time.perf_counter()
         ob, op = Oracle(ys).polish(sm.pileup, opts)
@@ -529,13 +555,8 @@ def main_strong(a):
                                               "whatever -t says",
                                     "wall_s": round(st, 1)}
         out_line["fasta_identical_to_oracle"] = bool(np.array_equal(ob, gb) and np.array_equal(op, gp))
-    if rank == 0:
-        print(json.dumps(out_line), flush=True)
     free_shard(pol, shard)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0
+    return out_line
 
 
 def main():
@@ -555,6 +576,11 @@ def main():
                     help="weak (default): one assembly per GPU (BASELINE configs[2] at N = 1); strong: ONE long contig "
                          "(--workload chr1, BASELINE configs[3]) cut into one reference interval per GPU")
     ap.add_argument("--contig-mb", type=float, default=248.0, help="--scaling strong: length of the contig in Mb")
+    ap.add_argument("--haploid", action="store_true", help="--scaling strong: a haploid contig (no phasing vote to decide)")
+    ap.add_argument("--strong-mb", type=float, default=62.0,
+                    help="--gpus N > 1: length of the diploid contig behind the 'strong' sub-result of the weak line (0: none)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each: the first is the line's value, all of them its median / min / max")
     a = ap.parse_args()
     if a.scaling == "strong":
         a.workload = "chr1"
@@ -572,7 +598,8 @@ def main():
     from nextpolish2_amd.dist import SequenceGatherer
     from nextpolish2_amd.synth import Synth
 
-    rank, world, local_rank, dev, cdev, backend = dist_setup()
+    setup = dist_setup()
+    rank, world, local_rank, dev, cdev, backend = setup
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
@@ -668,8 +695,22 @@ def main():
             e = by_name.setdefault(name, [0, 0.0])
             e[0] += 1
             e[1] += d / 1e9
-    gc.enable()
     flush_log = [] if single else [b.flush_log() for b in groups.bps]
+    # the same region again (--repeats - 1 times, after the one the line's value comes from): boxes of the pool differ by
+    # several per cent and a region is tens of milliseconds, so the line also carries the median and the spread
+    region_dt = [dt]
+    for _ in range(max(0, a.repeats - 1)):
+        sync()
+        t1 = time.perf_counter()
+        if single:
+            for _ in range(a.steps):
+                o2 = step_single()
+            drain_single(o2)
+        else:
+            groups.run(opts, a.steps, after, stage=stage)
+        sync()
+        region_dt.append(time.perf_counter() - t1)
+    gc.enable()
     excl = None
     if not single and len(groups.bps) > 1 and not a.no_exclusive:  # the roofline kernel without other groups' kernels next to it (untimed)
         _, ms_x, k_x, _ = groups.run(opts, 2, None, exclusive=True)
@@ -678,9 +719,10 @@ def main():
     bases = [np.array(o[0]) for o in out]
     spans = [o[1] for o in out]
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        t = torch.tensor(region_dt, dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        region_dt = [float(x) for x in t.tolist()]
+        dt = region_dt[0]
 
     total_bp = total_len
     if distributed:  # every rank polishes its own assembly: sum their lengths
@@ -688,6 +730,7 @@ def main():
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bp = int(tb.item())
     value = total_bp * a.steps / dt / 1e6
+    total_bp_of = lambda rd, k: total_bp * k / float(np.median(rd)) / 1e6  # noqa: E731
     # roofline of the dominant kernel k_diff_reads (one batched launch per group and step): algorithmic bytes =
     # 0.5 B per streamed pileup column (packed nibbles, read once) + 0.5 B per contig base (nibble-packed contig)
     n_cols = sum(int(s.pileup.n_columns()) - s.pileup.L for s in syn)  # read 0 (the contig itself) is not streamed
@@ -704,6 +747,10 @@ def main():
         "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "ms_per_step_regions": {"n": len(region_dt), "median": round(float(np.median(region_dt)) / a.steps * 1e3, 3),
+                                "min": round(min(region_dt) / a.steps * 1e3, 3), "max": round(max(region_dt) / a.steps * 1e3, 3),
+                                "value_at_median": round(total_bp_of(region_dt, a.steps), 3),
+                                "note": "the same timed region repeated; `value` / `ms_per_step` are the FIRST region's"},
         "config": {"workload": wl + f", 1 assembly per MI355X", "contigs": len(lengths), "assembly_bp": total_len,
                    "depth": a.depth, "scale": a.scale, "reads": n_reads, "pileup_columns": int(n_cols), "yak_k": ks, "iter_count": 2,
                    "min_ctg_len": min(lengths), "batch_groups": 0 if single else len(groups.bps),
@@ -765,6 +812,10 @@ def main():
                                  "achieved": round(value / max(1, world) * b_per_bp / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(value / max(1, world) * b_per_bp / 1e3 / HBM_PEAK_GBS, 5),
                                  "note": "per GPU; B = iter_count x 0.5 x pileup columns (read 0 included) / bp + 2 + 8 x kappa"}
+    if world > 1 and a.strong_mb > 0:
+        # north_star's other curve — ONE assembly over the N GPUs: a diploid contig cut into N reference intervals, on the same
+        # ranks, after the weak line's timed region (its own barrier + synchronize brackets; untouched by the value above)
+        out_line["strong"] = strong_measure(a, setup, a.strong_mb, max(2, a.steps // 4), 1, True)
     import zlib
     out_line["output_crc32"] = zlib.crc32(b"".join(b.tobytes() for b in bases))  # rank 0's polished assembly (the same for every N)
     out_line["polished_equals_truth_contigs"] = int(sum(bases[i].tobytes() == syn[i].hap1 for i in range(len(syn))))

@@ -67,18 +67,29 @@ def test_bench_gpus_2_rehearsed_with_gloo_on_one_gpu():
     timing, the line with n_gpus == 2) are the ones the driver's SCALE run takes; results must equal the one-rank run."""
     gloo = {"NP2_BENCH_BACKEND": "gloo"}
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
-    strong = ["--scaling", "strong", "--contig-mb", "2"] + common
+    strong = ["--scaling", "strong", "--contig-mb", "2", "--haploid"] + common
     one = _bench_line(["--gpus", "1"] + strong)
     two = _bench_line(["--gpus", "2"] + strong, gloo)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["polished_equals_truth"] and two["polished_equals_truth"]
     assert one["output_crc32"] == two["output_crc32"] and one["span"] == two["span"]
-    weak = ["--scale", "0.05"] + common
+    # the default strong workload is DIPLOID (configs[3]: "chr1 with injected SNV / indel"): the vote is gathered, decided on
+    # rank 0 and its decision broadcast
+    dip = ["--scaling", "strong", "--contig-mb", "2"] + common
+    one_d = _bench_line(["--gpus", "1"] + dip)
+    two_d = _bench_line(["--gpus", "2"] + dip, gloo)
+    assert one_d["config"]["diploid"] and one_d["output_crc32"] == two_d["output_crc32"] and one_d["span"] == two_d["span"]
+    assert one_d["output_crc32"] != one["output_crc32"]
+    weak = ["--scale", "0.05", "--strong-mb", "2", "--repeats", "2"] + common
     one = _bench_line(["--gpus", "1"] + weak)
     two = _bench_line(["--gpus", "2"] + weak, gloo)  # (asserts inside: the all-gathered bytes are rank 0's polished assembly)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
     assert one["output_crc32"] == two["output_crc32"]
     assert two["config"]["assembly_bp"] == one["config"]["assembly_bp"] and two["value"] > 0
+    assert one["ms_per_step_regions"]["n"] == 2 and "strong" not in one
+    # ... and what a SCALE run of the driver's command line gets beside the weak figure: the same diploid contig over the N ranks
+    st = two["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["output_crc32"] == one_d["output_crc32"] and st["span"] == one_d["span"]
     # one E. coli-sized contig per rank: the single-contig branch (deferred fetch + gather from the device result buffer)
     two = _bench_line(["--gpus", "2", "--workload", "ecoli", "--scale", "0.1"] + common, gloo)
     assert two["n_gpus"] == 2 and two["polished_equals_truth_contigs"] == 1
