@@ -497,6 +497,13 @@ def strong_measure(a, setup, contig_mb, steps, warmup, diploid, cpu_base=False):
         step()
         stages = {k: round(v, 3) for k, v in sorted(pol.timings().items(), key=lambda kv: -kv[1])}
         pol.set_timing(False)
+        os.environ["NP2_DIST_PROFILE"] = "1"  # ... and the wall clock of the protocol's phases on this rank (Python side included)
+        t1 = time.perf_counter()
+        step()
+        from nextpolish2_amd.dist import PHASE_MS
+        stages = {"protocol_phases_ms": {k: round(v, 2) for k, v in PHASE_MS.items()}, "protocol_step_ms": round((time.perf_counter() - t1) * 1e3, 2),
+                  "context_stage_ms": stages}
+        del os.environ["NP2_DIST_PROFILE"]
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

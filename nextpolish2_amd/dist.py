@@ -303,9 +303,23 @@ def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
     return b, p
 
 
+PHASE_MS = {}  # wall clock per phase of the last _run_ranked on this rank (NP2_DIST_PROFILE=1: bench.py reports it)
+
+
 def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
     """Shard protocol of one rank among `world` (one process per GPU): every phase's exchange carries the ranks' status."""
+    import os
+    import time
     from .api import ShardPiece
+    prof = os.environ.get("NP2_DIST_PROFILE") is not None
+    PHASE_MS.clear()
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if prof:
+            now = time.perf_counter()
+            PHASE_MS[name] = PHASE_MS.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
     apply_err = None
     # The number of phasing passes is fixed BEFORE the loop (it is opts.iter_count - 1 on every rank): a rank whose apply()
     # failed has not advanced its pass counter, and a loop on passes_left() would send it back into _decide_on_owner
@@ -314,24 +328,32 @@ def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
         err, payload = apply_err, None
         try:
             if err is None:
-                payload = run.vote().pack()
+                payload = run.vote()
+                lap("vote_pass")
+                payload = payload.pack()
+                lap("vote_pack")
         except Exception as e:  # noqa: BLE001 — any failure of this rank's shard ends the sharded attempt everywhere
             err = e
         losers = _decide_on_owner(payload, err, n_reads_total, opts, device, group)
+        lap("vote_decide")
         try:
             run.apply(losers)
         except Exception as e:  # noqa: BLE001 — reported with the next exchange's status word: nobody waits for this rank
             apply_err = e
+        lap("apply")
     err, pc = apply_err, None
     try:
         if err is None:
             pc = run.final_device()
     except Exception as e:  # noqa: BLE001
         err = e
+    lap("final_pass")
     raws = _exchange(pc.strips() if pc is not None else None, err, device, group, "final pass")
     metas = [ShardPiece.unpack_strips(x) for x in raws]
     check_strips(metas, plans)  # (every rank sees the same strips: the same verdict everywhere)
+    lap("strips")
     b, p = gather_slices(run, pc, [m["own_len"] for m in metas], want_pos, device=device, group=group, dst=dst)
+    lap("gather_slices")
     full = [m for m in metas if m["own_len"]]
     span = (full[0]["first_pos"], full[-1]["last_pos"]) if full else (0, 0)
     return b, p, span

@@ -1,8 +1,8 @@
-"""Hand-derived known answers, third set: the tie-breaks of the consensus DP (get_cns_from_align_tags, main.rs:1643-1683).
+"""Hand-derived known answers, third set: the tie-breaks of the consensus DP (get_cns_from_align_tags, main.rs:1645-1687).
 A node's best predecessor is replaced by a LATER one of EQUAL score unless that one starts with a gap
-(`score > kmer_score || (score == kmer_score && base1.q_base != 4)`, main.rs:1664), nodes being visited in the order the
+(`score > kmer_score || (score == kmer_score && base1.q_base != 4)`, main.rs:1670), nodes being visited in the order the
 reads pushed them (the contig is read 0, main.rs:1732-1739) after a stable sort by delta (Msa::sort, main.rs:227-229);
-at the last position the LAST node of maximal score wins (`kmer_score >= global_best_kmer.score`, main.rs:1676).
+at the last position the LAST node of maximal score wins (`kmer_score >= global_best_kmer.score`, main.rs:1680).
 tests/test_gpu_pinning.py asks the same of the HIP path."""
 import numpy as np
 
@@ -56,7 +56,7 @@ def test_at_the_contig_end_the_last_node_of_maximal_score_wins():
 
 def test_an_insertion_carried_by_half_of_the_rows_is_taken():
     """Msa::coverage (main.rs:232-241: the counts of the nodes whose last column is NOT an insertion column, which sort()
-    put first) and the score 10 * count - 4 * coverage (main.rs:1652-1663).  Ten rows; k reads carry one extra base after
+    put first) and the score 10 * count - 4 * coverage (main.rs:1658-1669).  Ten rows; k reads carry one extra base after
     position P.  Their columns P - 1, P, ins, P + 1, P + 2 make the nodes (P - 1, P, ins) — filed under position P with
     delta 1, so it does not count towards coverage(P) = 10 —, (P, ins, P + 1) and (ins, P + 1, P + 2); the other rows go
     through (P - 1, P, P + 1) and (P, P + 1, P + 2), and both paths meet again in (P + 1, P + 2, P + 3).  Between the
@@ -77,9 +77,9 @@ def test_an_insertion_carried_by_half_of_the_rows_is_taken():
 
 
 def test_reads_that_start_at_position_one_move_the_start_of_the_consensus_position_two_does_not():
-    """main.rs:1660-1662: a predecessor whose first column is a read's head sentinel is skipped once the node's middle
+    """main.rs:1664-1668: a predecessor whose first column is a read's head sentinel is skipped once the node's middle
     column lies at t_pos >= 3 ("this can prevent the later backtracking algorithm from stopping at the start mapping
-    position of reads"), and the backtrack ends at the first node whose middle column is a head sentinel (main.rs:1628).
+    position of reads"), and the backtrack ends at the first node whose middle column is a head sentinel (main.rs:1629).
     Nine reads begin at position S, the contig (one row) at 0.
     S = 1: the reads' nodes (h, h, 1) and (h, 1, 2) score 10 * 9 - 4 * 10 = 50 and 100; the contig's (h, h, 0), (h, 0, 1),
            (0, 1, 2) score 10 - 4 = 6, 6 + 10 - 40 = -24 and -54.  The node (1, 2, 3) looks at position 2 for predecessors
