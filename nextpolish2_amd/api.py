@@ -446,11 +446,14 @@ class Vote:
             setattr(self, name, np.ascontiguousarray(arrays.get(name, np.zeros(0, dtype=dt)), dtype=dt))
 
     @classmethod
-    def from_c(cls, v: np2_vote_t):
+    def from_c(cls, v: np2_vote_t, copy=True):
+        """copy=False: views of the run's arrays (borrowed until the run's next call: a chromosome's pair list is hundreds
+        of MB — packed or decided right away, it need not be copied first)."""
         def arr(ptr, n, dt):
             if not n:
                 return np.zeros(0, dtype=dt)
-            return np.frombuffer((C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+            a = np.frombuffer((C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)
+            return a.copy() if copy else a
         return cls(pair_key=arr(v.pair_key, v.n_pairs, np.uint64), pair_cnt=arr(v.pair_cnt, v.n_pairs, np.uint32),
                    read_id=arr(v.read_id, v.n_reads, np.uint32), first_pos=arr(v.first_pos, v.n_reads, np.uint32),
                    ref_w=arr(v.ref_w, v.n_reads, np.int32), flags=arr(v.flags, v.n_reads, np.uint8))
@@ -538,10 +541,14 @@ class ShardRun:
     def passes_left(self):
         return lib().np2_shard_passes_left(self._r)
 
-    def vote(self) -> Vote:
+    def vote(self, copy=True) -> Vote:
         v = np2_vote_t()
         self._pol._check(lib().np2_shard_vote(self._r, C.byref(v)))
-        return Vote.from_c(v)
+        return Vote.from_c(v, copy)
+
+    def vote_view(self) -> Vote:
+        """vote() without the copy: valid until this run's next call (the shard protocol packs or decides it at once)."""
+        return self.vote(copy=False)
 
     def apply(self, losers):
         a = np.ascontiguousarray(losers, dtype=np.uint32)

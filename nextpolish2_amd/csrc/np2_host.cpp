@@ -181,6 +181,7 @@ struct VoteData {
     std::vector<int32_t> ref_w;       // per read: summed weight against the contig's own candidate (ref_data[0])
     std::vector<uint8_t> ref_seen, bad;
     const uint8_t *d_bad = nullptr;   // the `bad` flags where the vote kernel left them on the device (until the next vote)
+    bool key_added = false;           // (wide form) the pair keys already carry the shard's read-number shift
 };
 
 // GPU part of the phasing pass: mark_hete (main.rs:916-946), pair votes (948-1002) over the regions whose start lies in
@@ -188,7 +189,7 @@ struct VoteData {
 // `wide`: pairs as (a << 32 | b, counts) — what the shards of a contig export and merge; otherwise the compact rows, read
 // back in the SAME wait as the counters that size them (one device round trip and 8 bytes per pair less)
 void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool use_all, int pass, uint32_t own_lo,
-                  uint32_t own_hi, VoteData &vd, bool wide = false) {
+                  uint32_t own_hi, VoteData &vd, bool wide = false, uint64_t key_add = 0) {
     hipStream_t s = cx->stream;
     const uint32_t R = c->R, n_reg = pc.n_reg;
     RegionTables rt = region_tables(cx, n_reg);
@@ -238,7 +239,7 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         if (wide) {
             cx->ekey.ensure(band_words + 2);
             cx->eval.ensure(band_words + 2);
-            launch_band_emit(s, cx->band.p, R, row_off, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW);
+            launch_band_emit(s, cx->band.p, R, row_off, cx->ekey.p, cx->eval.p, cx->scal.p + S_NRAW, key_add);
         } else {
             launch_band_emit_compact(s, cx->band.p, R, row_off, (uint32_t *)(cx->votepack.p + b_v + b_off), cx->scal.p + S_NRAW,
                                      cx->scal.p + S_M3);
@@ -352,6 +353,7 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         // the pairs stay where they landed (the context's pinned read-back staging: valid until its next read-back; a
         // chromosome's list is 200 MB): the plain pipeline decides the vote right away, a shard copies them first
         vd.view_key = (const uint64_t *)pin, vd.view_cnt = (const uint32_t *)(pin + b_key), vd.view_n = NU;
+        vd.key_added = wide && !far; // (the sort path's keys are local)
         if (b_pr) per_read(pin + b_key + b_w);
     }
     if (cx->trace) {
@@ -1171,6 +1173,7 @@ struct PolishRun {
     bool front_issued = false; // graph, DP, consensus and LQ regions of pass `pass` are already on their way (polish_impl)
     uint32_t grow_prev = 0xFFFFFFFFu; // growth bound of the previous (phasing) pass, read back with its vote for free
     bool wide_votes = false; // the shards of a contig export (a << 32 | b, counts) pairs; the plain pipeline reads compact rows
+    uint64_t key_add = 0;    // ... with the shard's read-number shift added on the device (s << 32 | s)
     PassCounts pc;
     bool final_pass() const { return pass + 1 == o.iter_count; }
 };
@@ -1237,7 +1240,7 @@ void run_vote_pass(PolishRun &r, VoteData &vd, const std::function<void()> *afte
         cx->kscore_saved.ensure((size_t)r.pc.NC_cap + 2);
         op_copy_d2d(cx, cx->kscore_saved.p, cx->kscore.p, (size_t)(r.pc.known ? r.pc.NC : r.pc.NC_cap) * 2);
     }
-    vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd, r.wide_votes);
+    vote_collect(cx, r.c, r.pc, r.o.model_ref != 0, r.o.use_all_reads != 0, (int)r.pass, r.own_lo, r.own_hi, vd, r.wide_votes, r.key_add);
     if (r.pc.known) r.grow_prev = r.pc.grow;
 }
 
@@ -2137,21 +2140,41 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
     np2_ctx *cx = sr->run.cx;
     NP2_SHARD_TRY(cx, {
         VoteData vd;
+        const np2_shard_plan_t &pl = sr->plan;
+        // (local read i >= 1 is contig read read_lo + i - 1 and read 0 never enters a pair: one 64-bit add renumbers both
+        // ends, and the keys stay sorted; the emitting kernel adds it — a chromosome's shard exports tens of millions of pairs)
+        const uint64_t shift = pl.read_lo - 1, add = (shift << 32) | shift;
+        sr->run.key_add = add;
         run_vote_pass(sr->run, vd);
-        vd.own(); // (read-backs follow before the pairs are exported)
         sr->v_key.clear(), sr->v_cnt.clear(), sr->v_read.clear(), sr->v_first.clear(), sr->v_refw.clear(), sr->v_flags.clear();
+        const uint64_t *out_key = nullptr;
+        const uint32_t *out_cnt = nullptr;
+        size_t out_np = 0;
         if (vd.any) {
             // region index -> contig position: the merged key order of the contig's weight map is by descending region
-            // start (regions are listed right to left, main.rs:1613-1620), read index within a region
-            std::vector<uint32_t> start = d2h(cx, cx->lq_start.p, sr->run.n_reg);
-            const np2_shard_plan_t &pl = sr->plan;
-            // (local read i >= 1 is contig read read_lo + i - 1 and read 0 never enters a pair: one 64-bit add renumbers
-            // both ends, and the keys stay sorted)
-            const size_t np = vd.pair_key.size();
-            const uint64_t shift = pl.read_lo - 1, add = (shift << 32) | shift;
-            sr->v_key.resize(np);
-            for (size_t i = 0; i < np; ++i) sr->v_key[i] = vd.pair_key[i] + add;
-            sr->v_cnt.swap(vd.pair_cnt);
+            // start (regions are listed right to left, main.rs:1613-1620), read index within a region.  (Read back through
+            // a staging block of its own: the pairs are still where the vote's read-back left them, in the context's.)
+            std::vector<uint32_t> start(sr->run.n_reg);
+            if (sr->run.n_reg) {
+                void *tmp = pinned_pool().get((size_t)sr->run.n_reg * 4 + 64);
+                op_d2h(cx, tmp, cx->lq_start.p, (size_t)sr->run.n_reg * 4);
+                op_sync(cx);
+                memcpy(start.data(), tmp, (size_t)sr->run.n_reg * 4);
+                pinned_pool().put(tmp);
+            }
+            out_np = (size_t)vd.n_pairs();
+            if (vd.view_key && vd.key_added) {
+                // the pairs stay in the read-back staging: valid until this context's next read-back, i.e. the next np2_shard_*
+                // call of this run (np2.h) — no host pass over them at all
+                out_key = vd.view_key, out_cnt = vd.view_cnt;
+            } else {
+                const uint64_t *k = vd.keys();
+                const uint32_t *cn = vd.cnts();
+                sr->v_key.resize(out_np);
+                for (size_t i = 0; i < out_np; ++i) sr->v_key[i] = k[i] + (vd.key_added ? 0 : add);
+                sr->v_cnt.assign(cn, cn + out_np);
+                out_key = sr->v_key.data(), out_cnt = sr->v_cnt.data();
+            }
             for (uint32_t r = 0; r < vd.R; ++r) {
                 const bool votes = vd.first_key[r] != 0xFFFFFFFFu;
                 if (!votes && !vd.ref_seen[r] && !vd.bad[r]) continue;
@@ -2161,9 +2184,9 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
                 sr->v_flags.push_back((uint8_t)((votes ? 1 : 0) | (vd.ref_seen[r] ? 2 : 0) | (vd.bad[r] ? 4 : 0)));
             }
         }
-        out->n_pairs = sr->v_key.size();
-        out->pair_key = sr->v_key.data();
-        out->pair_cnt = sr->v_cnt.data();
+        out->n_pairs = out_np;
+        out->pair_key = out_key;
+        out->pair_cnt = out_cnt;
         out->n_reads = (uint32_t)sr->v_read.size();
         out->read_id = sr->v_read.data();
         out->first_pos = sr->v_first.data();

@@ -279,7 +279,7 @@ static constexpr uint32_t EDGE_BAND = 256;
 void launch_edges_row(hipStream_t s, const RegionTables &rt, const uint8_t *grp, const uint32_t *ecount, const uint32_t *pj,
                       const uint32_t *pcount, const uint8_t *alive, uint32_t R, uint32_t *band, uint32_t *row_n, uint32_t *ovf);
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
-                      uint32_t *n_out);
+                      uint32_t *n_out, uint64_t key_add = 0);
 // the same pairs in 4 bytes each, row by row: word = (b - a - 1) | agreeing regions << 8 | disagreeing regions << 20
 // (12 bits each; a larger count bumps *ovf and the host takes the sort path), row a = [row_off[a], row_off[a + 1])
 static constexpr uint32_t VOTE_CNT_MAX = 0xFFFu;

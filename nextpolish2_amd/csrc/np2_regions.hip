@@ -377,7 +377,8 @@ __device__ __forceinline__ void k_edges_row(const uint32_t np2_bid, const uint32
 // host turns the counts into the weight sum(w), or -(#-1) if #(-1) >= 3, main.rs:996-1002 — after merging shards)
 __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ band, uint32_t R,
                                             const uint32_t *__restrict__ row_off, uint64_t *__restrict__ ukey,
-                                            uint32_t *__restrict__ ucnt, uint32_t *__restrict__ n_out) {
+                                            uint32_t *__restrict__ ucnt, uint32_t *__restrict__ n_out, uint64_t key_add) {
+    // (key_add: a shard's local read numbers become the contig's on the way out — s << 32 | s for a shift of s)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)((np2_bid * blockDim.x + threadIdx.x) >> 6)); // (uniform)
     if (a >= R) return;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void k_band_emit(const uint32_t np2_bid, const uint32
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (v[k]) {
-            ukey[o] = ((uint64_t)a << 32) | (a + 1 + lane * 4 + k);
+            ukey[o] = (((uint64_t)a << 32) | (a + 1 + lane * 4 + k)) + key_add;
             ucnt[o] = v[k];
             ++o;
         }
@@ -1110,8 +1111,8 @@ void launch_band_emit_compact(hipStream_t s, const uint32_t *band, uint32_t R, c
     if (R) NP2_LAUNCH(k_band_emit_compact, g1((uint64_t)R * 64), 256, s, band, R, row_off, pairs, n_out, ovf);
 }
 void launch_band_emit(hipStream_t s, const uint32_t *band, uint32_t R, const uint32_t *row_off, uint64_t *ukey, uint32_t *uw,
-                      uint32_t *n_out) {
-    if (R) NP2_LAUNCH(k_band_emit, g1((uint64_t)R * 64), 256, s, band, R, row_off, ukey, uw, n_out);
+                      uint32_t *n_out, uint64_t key_add) {
+    if (R) NP2_LAUNCH(k_band_emit, g1((uint64_t)R * 64), 256, s, band, R, row_off, ukey, uw, n_out, key_add);
 }
 void launch_edge_reduce(hipStream_t s, const uint64_t *ekey, const uint32_t *eval, uint32_t n, uint32_t *flag,
                         uint32_t *wout) {

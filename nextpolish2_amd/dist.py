@@ -147,11 +147,11 @@ def _decide_on_owner(payload, failure, n_reads_total, opts, device, group, owner
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     device = device or torch.device("cpu")
-    body = np.zeros(0, dtype=np.uint8) if failure is not None else np.ascontiguousarray(payload, dtype=np.uint8)
-    if world == 1:
+    if world == 1:  # (the Vote itself: nothing to pack for nobody)
         if failure is not None:
             raise ShardMismatch(f"phasing vote failed: {failure}") from failure
-        return vote_decide([Vote.unpack(body)], n_reads_total, opts)
+        return vote_decide([payload if isinstance(payload, Vote) else Vote.unpack(payload)], n_reads_total, opts)
+    body = np.zeros(0, dtype=np.uint8) if failure is not None else np.ascontiguousarray(payload, dtype=np.uint8)
     head = torch.tensor([0 if failure is None else 1, body.shape[0]], dtype=torch.int64, device=device)
     heads = [torch.zeros_like(head) for _ in range(world)]
     dist.all_gather(heads, head, group=group)
@@ -258,6 +258,12 @@ def gather_slices(run, pc, lens, want_pos, device=None, group=None, dst=0):
     total, cap = sum(lens), max(1, max(lens))
     on_gpu = device is not None and torch.device(device).type == "cuda"
     sub_lo = int(run.plan.sub_lo)
+    if world == 1:  # one rank: the owned slice goes straight from the device into the pinned result arrays
+        b = pinned_array(total, np.uint8)
+        p = pinned_array(total, np.uint32) if want_pos else None
+        if pc.own_len:
+            run.fetch(b, p)
+        return b, p
 
     if on_gpu:
         from .api import lib
@@ -311,6 +317,7 @@ def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
     import os
     import time
     from .api import ShardPiece
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     prof = os.environ.get("NP2_DIST_PROFILE") is not None
     PHASE_MS.clear()
     t_last = [time.perf_counter()]
@@ -328,10 +335,11 @@ def _run_ranked(run, plans, n_reads_total, opts, want_pos, device, group, dst):
         err, payload = apply_err, None
         try:
             if err is None:
-                payload = run.vote()
+                payload = getattr(run, "vote_view", run.vote)()  # (borrowed arrays: packed or decided before the run goes on)
                 lap("vote_pass")
-                payload = payload.pack()
-                lap("vote_pack")
+                if world > 1:
+                    payload = payload.pack()
+                    lap("vote_pack")
         except Exception as e:  # noqa: BLE001 — any failure of this rank's shard ends the sharded attempt everywhere
             err = e
         losers = _decide_on_owner(payload, err, n_reads_total, opts, device, group)

