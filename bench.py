@@ -426,7 +426,7 @@ def main_strong(a):
     if setup[1] != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={setup[1]}")
     import torch.distributed as dist
-    out_line = strong_measure(a, setup, a.contig_mb, a.steps, a.warmup, not a.haploid, cpu_base=not a.no_cpu_baseline)
+    out_line = strong_measure(a, setup, a.contig_mb * a.scale, a.steps, a.warmup, not a.haploid, cpu_base=not a.no_cpu_baseline)
     if setup[0] == 0:
         print(json.dumps(out_line), flush=True)
     if "RANK" in os.environ:
@@ -451,7 +451,7 @@ def strong_measure(a, setup, contig_mb, steps, warmup, diploid, cpu_base=False):
 
     rank, world, local_rank, dev, cdev, backend = setup
     distributed = "RANK" in os.environ
-    L = int(contig_mb * 1e6 * a.scale)
+    L = int(contig_mb * 1e6)
     n_parts = 16
     # every rank generates the same contig (seeded) and keeps only its shard in HBM
     with ThreadPoolExecutor(min(n_parts, os.cpu_count() or 1)) as ex:

@@ -44,7 +44,9 @@ __device__ __forceinline__ void k_scan_small(const uint32_t np2_bid, const uint3
 static constexpr uint32_t SCAN_LB_ITEMS = 8;   // elements per thread, blocked: thread t owns [8t, 8t + 8) of its block's 8192
 static constexpr uint32_t SCAN_LB_THREADS = 1024;
 static constexpr uint32_t SCAN_LB_BLOCK = SCAN_LB_ITEMS * SCAN_LB_THREADS;
-__device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
+// (POPC: the elements are the population counts of the words of `in` — the LQ head bitmap —, element n - 1 is a closing 0)
+template <bool POPC>
+__device__ __forceinline__ void scan_lb_excl_body(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
                                                       uint32_t *__restrict__ out, uint32_t n, bool write_end,
                                                       uint32_t *__restrict__ err) {
     __shared__ uint32_t sh[16];
@@ -52,12 +54,16 @@ __device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uin
     const uint32_t i0 = bid * SCAN_LB_BLOCK + threadIdx.x * SCAN_LB_ITEMS;
     uint32_t v[SCAN_LB_ITEMS], sum = 0;
     const bool wide = (((uintptr_t)in | (uintptr_t)out) & 15) == 0; // (uniform) 16-byte accesses for whole octets
-    if (wide && i0 + SCAN_LB_ITEMS <= n) {
+    if (wide && i0 + SCAN_LB_ITEMS <= (POPC ? n - 1 : n)) {
         const uint4 a = *reinterpret_cast<const uint4 *>(in + i0), b = *reinterpret_cast<const uint4 *>(in + i0 + 4);
         v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
     } else {
 #pragma unroll
-        for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
+        for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) v[k] = i0 + k < (POPC ? n - 1 : n) ? in[i0 + k] : 0u;
+    }
+    if (POPC) {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) v[k] = (uint32_t)__builtin_popcount(v[k]);
     }
 #pragma unroll
     for (uint32_t k = 0; k < SCAN_LB_ITEMS; ++k) sum += v[k];
@@ -82,6 +88,15 @@ __device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uin
     // (the thread holding element n - 1 ends with the total)
     if (write_end && n && i0 <= n - 1 && n - 1 < i0 + SCAN_LB_ITEMS) out[n] = run;
     if (write_end && n == 0 && bid == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+__device__ __forceinline__ void k_scan_lb_excl(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
+                                               uint32_t *__restrict__ out, uint32_t n, bool write_end, uint32_t *__restrict__ err) {
+    scan_lb_excl_body<false>(np2_bid, np2_nb, lb, n_blocks, in, out, n, write_end, err);
+}
+__device__ __forceinline__ void k_scan_lb_popc(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, uint32_t n_blocks, const uint32_t *__restrict__ in,
+                                               uint32_t *__restrict__ out, uint32_t n, bool write_end, uint32_t *__restrict__ err) {
+    scan_lb_excl_body<true>(np2_bid, np2_nb, lb, n_blocks, in, out, n, write_end, err);
 }
 
 // Long exclusive sums (one element per contig position / consensus base / band slot): reduce-then-scan.  Tiles of 4096
@@ -909,6 +924,10 @@ void launch_scan_lb_excl(hipStream_t s, const Lookback &lb, const uint32_t *in, 
     NP2_LAUNCH(k_scan_lb_excl, dim3(nb), SCAN_LB_THREADS, s, lb, nb, in, out, n, write_end, err);
 }
 uint32_t scan3_tiles(uint32_t n) { return (n + SCAN3_TILE - 1) / SCAN3_TILE; }
+void launch_scan_lb_popc(hipStream_t s, const Lookback &lb, const uint32_t *bits, uint32_t *out, uint32_t n_words, uint32_t *err) {
+    const uint32_t nb = scan_lb_blocks((uint64_t)n_words + 1);
+    NP2_LAUNCH(k_scan_lb_popc, dim3(nb), SCAN_LB_THREADS, s, lb, nb, bits, out, n_words + 1, false, err);
+}
 uint32_t scan_lb_blocks(uint64_t n) { return (uint32_t)std::max<uint64_t>(1, (n + SCAN_LB_BLOCK - 1) / SCAN_LB_BLOCK); }
 void launch_scan3_excl(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part, uint32_t *part_off,
                        bool write_end) {

@@ -833,15 +833,15 @@ CnsBounds cns_buffers(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, uint32_t n_r
 void lq_regions_issue(np2_ctx *cx, const CnsBounds &b, const uint32_t *M_p, const uint32_t *n_lq) {
     hipStream_t s = cx->stream;
     EventTimer t(cx, "lq_regions");
-    zero32(cx, cx->hbits.p, b.n_words + 1);
+    // (the head bitmap is cleared by k_lq_scan, its words counted inside the scan, the merge flags formed inside theirs:
+    // three launches less per pass than one kernel per step)
     launch_lq_scan(s, cx->cns_pos.p, cx->cns_base.p, cx->cns_cls.p, M_p, cx->lq_list.p, n_lq, b.lq_cap, cx->lq_kind.p,
-                   cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, cx->rstart.p, cx->rend.p);
-    launch_lq_bits_count(s, cx->hbits.p, b.n_words, cx->rflag.p);
-    exclusive_total(cx, cx->rflag.p, cx->ridx.p, (size_t)b.n_words + 1); // (rflag[n_words] = 0)
+                   cx->lq_next.p, cx->lq_nothead.p, cx->hbits.p, b.n_words + 1, cx->rstart.p, cx->rend.p);
+    launch_scan_lb_popc(s, next_lookback(cx, scan_lb_blocks((size_t)b.n_words + 1)), cx->hbits.p, cx->ridx.p, b.n_words,
+                        cx->scal.p + S_ERR);
     launch_scatter_regions(s, cx->hbits.p, b.n_words, cx->ridx.p, cx->rstart.p, cx->rend.p, cx->raw_start.p,
                            cx->raw_end.p, cx->scal.p + S_NRAW);
-    launch_lq_merge_flag(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p);
-    launch_scan_small_excl(s, cx->headflag.p, cx->hidx.p, b.M_cap, cx->scal.p + S_NRAW, nullptr, false);
+    launch_lq_merge_scan(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, b.M_cap, cx->headflag.p, cx->hidx.p);
     launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
                           cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);
 }

@@ -1086,8 +1086,10 @@ __device__ __forceinline__ void k_lq_scan(const uint32_t np2_bid, const uint32_t
                           const uint8_t *__restrict__ cns_cls, const uint32_t *__restrict__ M_p,
                           const uint32_t *__restrict__ lq_list, const uint32_t *__restrict__ n_lq_p,
                           uint32_t lq_cap, uint8_t *__restrict__ lq_kind, uint32_t *__restrict__ lq_next,
-                          uint8_t *__restrict__ lq_nothead) {
+                          uint8_t *__restrict__ lq_nothead, uint32_t *__restrict__ hbits, uint32_t n_hwords) {
     const uint32_t M = *M_p, n_lq = min(*n_lq_p, lq_cap);
+    // (the head bitmap k_lq_region marks in, cleared here: a fill launch of its own less per pass)
+    for (uint32_t w = np2_bid * blockDim.x + threadIdx.x; w < n_hwords; w += np2_nb * blockDim.x) hbits[w] = 0;
     for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n_lq; j += np2_nb * blockDim.x) {
         const uint32_t i = lq_list[j];
         const uint32_t p = M - 1 - i;
@@ -1199,6 +1201,19 @@ __device__ __forceinline__ void k_lq_merge_flag(const uint32_t np2_bid, const ui
     const uint32_t n = *n_raw; // on the device: grid-stride over whatever it turns out to be
     for (uint32_t j = np2_bid * blockDim.x + threadIdx.x; j < n; j += np2_nb * blockDim.x)
         headflag[j] = !(j >= 1 && raw_end[j] >= raw_start[j - 1]);
+}
+// ... the flags and their exclusive scan in one single-block kernel (head j's merged region is number hidx[j])
+__device__ __forceinline__ void k_lq_merge_scan(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
+                                                const uint32_t *__restrict__ n_raw, uint32_t n_host, uint32_t *__restrict__ headflag,
+                                                uint32_t *__restrict__ hidx) {
+    __shared__ uint32_t sh[16];
+    const uint32_t n = min(*n_raw, n_host);
+    block_scan_array<OpAdd>(
+        n, sh, [&](uint32_t j) { return (j >= 1 && raw_end[j] >= raw_start[j - 1]) ? 0u : 1u; },
+        [&](uint32_t j, uint32_t pre, uint32_t v) {
+            hidx[j] = pre;
+            headflag[j] = v;
+        });
 }
 __device__ __forceinline__ void k_lq_merge_write(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ raw_start, const uint32_t *__restrict__ raw_end,
                                  const uint32_t *__restrict__ n_raw, const uint32_t *__restrict__ headflag,
@@ -1527,8 +1542,8 @@ void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
 static inline dim3 lq_grid(uint32_t cap) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 255) / 256, 2048))); }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
-                    uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t *rstart, uint32_t *rend) {
-    NP2_LAUNCH(k_lq_scan, lq_grid(lq_cap), 256, s, cns_pos, cns_base, cns_cls, M_p, lq_list, n_lq, lq_cap, lq_kind, lq_next, lq_nothead);
+                    uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t n_hwords, uint32_t *rstart, uint32_t *rend) {
+    NP2_LAUNCH(k_lq_scan, lq_grid(std::max(lq_cap, n_hwords / 4)), 256, s, cns_pos, cns_base, cns_cls, M_p, lq_list, n_lq, lq_cap, lq_kind, lq_next, lq_nothead, hbits, n_hwords);
     NP2_LAUNCH(k_lq_region, lq_grid(lq_cap), 256, s, cns_pos, cns_base, M_p, lq_list, n_lq, lq_cap, lq_kind, lq_next, lq_nothead, hbits, rstart, rend);
 }
 void launch_lq_bits_count(hipStream_t s, const uint32_t *hbits, uint32_t n_words, uint32_t *wcnt) {
@@ -1542,6 +1557,10 @@ void launch_scatter_regions(hipStream_t s, const uint32_t *hbits, uint32_t n_wor
 void launch_lq_merge_flag(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                           uint32_t *headflag) {
     NP2_LAUNCH(k_lq_merge_flag, dim3(256), 256, s, raw_start, raw_end, n_raw, headflag);
+}
+void launch_lq_merge_scan(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw, uint32_t n_host,
+                          uint32_t *headflag, uint32_t *hidx) {
+    NP2_LAUNCH(k_lq_merge_scan, dim3(1), 1024, s, raw_start, raw_end, n_raw, n_host, headflag, hidx);
 }
 void launch_lq_merge_write(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
                            const uint32_t *headflag, const uint32_t *hidx, uint32_t *lq_start, uint32_t *lq_end,

@@ -6,7 +6,7 @@ set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
-ARGS="--no-cpu-baseline --no-end-to-end --no-exclusive --steps 10 --warmup 2 $*"
+ARGS="--no-cpu-baseline --no-end-to-end --no-exclusive --repeats 1 --steps 10 --warmup 2 $*"
 python bench.py --no-cpu-baseline --no-end-to-end "$@" > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python bench.py $ARGS > $OUT/${TAG}_kt.log 2>&1
 cp $OUT/${TAG}_kt/kt_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
