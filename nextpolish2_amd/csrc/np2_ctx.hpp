@@ -512,6 +512,7 @@ struct np2_ctx {
     DevBuf<uint32_t> pf_bad, pf_bad2; // ... tiles listed for the middle / the big variant
     DevBuf<uint64_t> pf_prof;  // ... phase timers (NP2_PF_PROF)
     bool front_fused = false;  // the pass front under way went through the fused kernels (np2_passfront.hip)
+    bool pf_big = getenv("NP2_PF_BIG") != nullptr; // k_pf_tile_big is launched (from the first pass that needed it on; NP2_PF_BIG: always)
     uint32_t front_redos = 0;  // passes the fused front handed back to the unfused kernels (tests read it through the timings)
     DevBuf<uint16_t> kscore_saved;
     DevBuf<uint8_t> sstr;

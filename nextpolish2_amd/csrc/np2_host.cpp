@@ -934,7 +934,7 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
              c->tile_rd_off.p, c->tile_rd.p, c->refnib.p, cx->pf_slots.p, cx->tile_nn.p, cx->tile_nr.p,
              (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p, cx->scal.p + S_NBAD2, cx->pf_bad2.p,
              (long long *)(cx->scal.p + S_PFEND0), (unsigned long long *)(cx->scal.p + S_PFGAIN0), nullptr, L, n_tiles, cx->bucket_cap,
-             cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min)};
+             cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min), cx->pf_big ? 1u : 0u};
     uint32_t *const M_p = cx->eoff.p + L;
     uint32_t *const n_lq = cx->scal.p + S_NRUNS;
     const bool prof = getenv("NP2_PF_PROF") != nullptr && tl_recorder() == nullptr; // (phase timers of the tile kernel: a tool's switch)
@@ -1010,6 +1010,7 @@ void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t T, int pa
         const int64_t total = (int64_t)(((uint64_t)sc[S_PFGAIN1] << 32) | sc[S_PFGAIN0]);
         const int64_t end_rel = (int64_t)(((uint64_t)sc[S_PFEND1] << 32) | sc[S_PFEND0]);
         const bool negative = end_rel <= SCORE_NEG / 2 || total + end_rel < 0; // main.rs:1651,1680: no end node reaches 0
+        if (sc[S_PFOUT] & PF_NEED_BIG) cx->pf_big = true; // (sticky: the next fused pass of this context launches it)
         if ((sc[S_PFOUT] & PF_REDO) || negative) {
             ++cx->front_redos;
             cx->timing.host.push_back({"front_redo", 1.0f}); // (a count, read through np2_last_timings by the tests)
@@ -1065,6 +1066,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     {
         EventTimer t(cx, "candidates");
         // every live read covers a contiguous interval [pj, pj + pcount) of the region list
+        // (both in one single-block kernel measured 58 us against 7.5 + 6: a block's worth of binary searches is a latency chain)
         launch_read_m(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, n_reg, cx->mval.p);
         scan_incl_min(cx, cx->mval.p, cx->smin.p, R);
         launch_pair_count(s, c->reads.p, R, cx->alive.p, cx->lq_start.p, cx->lq_end.p, n_reg, cx->smin.p, cx->pj.p,

@@ -224,6 +224,7 @@ static constexpr uint32_t PF_CAP_MID = 2048; // the middle variant (tiles the or
 static constexpr uint32_t PF_CAP_BIG = 3584; // the big variant (tiles the middle one listed): records, and a whole tile of halo
 static constexpr uint32_t PF_COV_MAX = 8192; // coverage from which a pass goes through the unfused kernels (32-bit scores, 14-bit counts)
 static constexpr uint32_t PF_REDO = 1u;      // flag word: this pass has to be redone by the unfused kernels
+static constexpr uint32_t PF_NEED_BIG = 2u;  // ... because a tile needed the big variant, which was not launched (it is from then on)
 struct PfTile {
     const uint64_t *keys; // sorted records, bucketed layout: tile t at [t * bucket_cap, + tile_n[t])
     const uint32_t *vals;
@@ -242,6 +243,7 @@ struct PfTile {
     unsigned long long *prof;       // nullptr, or 8 clock stamps per tile (NP2_PF_PROF)
     uint32_t L, n_tiles, bucket_cap;
     uint32_t cap_lim, cap_lim_big, halo_lim, cov_max; // PF_CAP, PF_CAP_BIG, PF_HALO, PF_COV_MAX unless a test lowers them
+    uint32_t big_enabled;  // the big variant is part of the launch sequence (once a contig of this context has needed it)
 };
 uint64_t pf_slot_entries(uint32_t n_tiles, uint64_t T); // 16-bit entries the slot array needs
 void launch_pf_tile(hipStream_t s, const PfTile &a);

@@ -104,6 +104,8 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         A.tile_cnt[t] = 0, A.tile_lq[t] = 0, A.tile_gain[t] = 0; // (an empty slot, should nobody redo the tile)
         if (LEVEL == 2)
             atomicOr(A.flags, PF_REDO);
+        else if (LEVEL == 1 && !A.big_enabled)
+            atomicOr(A.flags, PF_REDO | PF_NEED_BIG); // (the big variant is not launched until a contig has needed it once)
         else if (LEVEL == 1)
             A.bad_list2[atomicAdd(A.n_bad2, 1u)] = t;
         else
@@ -778,7 +780,7 @@ uint64_t pf_slot_entries(uint32_t n_tiles, uint64_t T) { return (uint64_t)n_tile
 void launch_pf_tile(hipStream_t s, const PfTile &a) {
     NP2_LAUNCH(k_pf_tile, dim3(a.n_tiles), 256, s, a);
     NP2_LAUNCH(k_pf_tile_mid, dim3(std::min<uint32_t>(a.n_tiles, 256u)), 256, s, a);
-    NP2_LAUNCH(k_pf_tile_big, dim3(std::min<uint32_t>(a.n_tiles, 64u)), 256, s, a);
+    if (a.big_enabled) NP2_LAUNCH(k_pf_tile_big, dim3(std::min<uint32_t>(a.n_tiles, 64u)), 256, s, a);
 }
 void launch_pf_compact(hipStream_t s, uint32_t n_tiles, const uint16_t *slots, const uint32_t *tile_scan, const uint32_t *tile_cnt,
                        const uint32_t *tile_coff, const uint32_t *tile_lqoff, uint32_t *cns_pos, uint8_t *cns_base,

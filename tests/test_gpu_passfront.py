@@ -38,7 +38,8 @@ def test_fused_equals_unfused_equals_oracle(monkeypatch, seed, depth, err, diplo
     ob, op = orc.Oracle(yaks).polish(s.pileup, Opts())
     fb, fp, ft = _polish(yaks, s.pileup)
     assert np.array_equal(fb, ob) and np.array_equal(fp, op)
-    assert "front_redo" not in ft
+    # (60x at 1 % errors fills tiles beyond the middle variant: one pass is handed back before the big one joins the launches)
+    assert ft.get("front_redo", 0) <= (1 if depth >= 60 else 0)
     monkeypatch.setenv("NP2_FRONT_UNFUSED", "1")
     ub, up, _ = _polish(yaks, s.pileup)
     assert np.array_equal(ub, ob) and np.array_equal(up, op)
@@ -50,7 +51,8 @@ def test_tiles_that_do_not_fit_go_to_the_big_variant(monkeypatch, cap, halo):
     tile, is listed and redone by k_pf_tile_big (3584 records, a whole tile of halo) — no pass is handed back."""
     monkeypatch.setenv("NP2_PF_CAP", str(cap))
     monkeypatch.setenv("NP2_PF_HALO", str(halo))
-    for seed, depth, err in ((911, 30, 0.004), (912, 10, 0.03)):
+    monkeypatch.setenv("NP2_PF_BIG", "1")  # (the big variant in the launch sequence from the start: see the next test)
+    for seed, depth, err in ((911, 30, 0.004), (912, 15, 0.008)):
         s = Synth(60000, depth=depth, seed=seed, diploid=True, read_err_rate=err, read_len_mean=5000.0, read_len_sd=1200.0)
         yaks = [s.yak(21)]
         ob, op = orc.Oracle(yaks).polish(s.pileup, Opts())
@@ -62,10 +64,28 @@ def test_tiles_that_do_not_fit_go_to_the_big_variant(monkeypatch, cap, halo):
     check_all_stages(s.pileup, [s.yak(21), s.yak(31)], Opts())
 
 
+def test_the_big_variant_joins_the_launch_sequence_once_a_contig_has_needed_it(monkeypatch):
+    """k_pf_tile_big (a whole tile of halo) is two launches per step that an ordinary pileup never needs: a context launches
+    it from the first pass on in which the middle variant could not hold a tile — that pass is redone by the unfused
+    kernels, the later ones are fused again."""
+    monkeypatch.setenv("NP2_PF_HALO", "0")  # (no halo: a run that reaches the end of its tile is open — for the middle variant too)
+    s = Synth(60000, depth=20, seed=914, diploid=True, read_err_rate=0.006, read_len_mean=5000.0, read_len_sd=1200.0)
+    yaks = [s.yak(21)]
+    ob, op = orc.Oracle(yaks).polish(s.pileup, Opts())
+    g = Polisher(yaks)
+    b, p = g.polish(s.pileup, Opts())
+    assert np.array_equal(b, ob) and np.array_equal(p, op)
+    assert g.timings().get("front_redo", 0) == 1  # the first pass that needed it; the second pass of the same call was fused
+    b, p = g.polish(s.pileup, Opts())
+    assert np.array_equal(b, ob) and np.array_equal(p, op)
+    assert "front_redo" not in g.timings()
+
+
 @pytest.mark.parametrize("hook", [{"NP2_PF_CAP": "48", "NP2_PF_CAP_BIG": "48"}, {"NP2_PF_COV_MAX": "20"}])
 def test_a_pass_the_fused_front_cannot_hold_is_redone_unfused(monkeypatch, hook):
     for k, v in hook.items():
         monkeypatch.setenv(k, v)
+    monkeypatch.setenv("NP2_PF_BIG", "1")
     s = Synth(60000, depth=30, seed=921, diploid=True, read_len_mean=7000.0, read_len_sd=1500.0)
     yaks = [s.yak(21), s.yak(31)]
     ob, op = orc.Oracle(yaks).polish(s.pileup, Opts())
