@@ -487,7 +487,10 @@ def strong_measure(a, setup, contig_mb, steps, warmup, diploid, cpu_base=False):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-        diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+        tm = pol.timings()
+        diff_ms.append(tm.get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+        if "diff_probe" in tm:  # (NP2_DENSE_PROBE: a part of the dense pass launched once more, tools/dense_probe.sh)
+            print(f"diff_probe {tm['diff_probe']:.4f} ms (diff_reads {tm.get('diff_reads', 0.0):.4f})", file=sys.stderr)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -682,7 +685,10 @@ def main():
     if single:
         for _ in range(a.steps):
             out = step_single()
-            diff_ms.append(pol.timings().get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+            tm = pol.timings()
+            diff_ms.append(tm.get("diff_reads", 0.0))  # HIP events around k_diff_reads on the context's own stream
+            if "diff_probe" in tm:  # (NP2_DENSE_PROBE: a part of the dense pass launched once more, tools/dense_probe.sh)
+                print(f"diff_probe {tm['diff_probe']:.4f} ms (diff_reads {tm.get('diff_reads', 0.0):.4f})", file=sys.stderr)
             diff_launches = 1
     else:
         out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after, stage=stage)

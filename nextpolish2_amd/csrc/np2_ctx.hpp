@@ -405,10 +405,11 @@ struct np2_contig {
     uint64_t nib_bytes = 0, n_cols = 0, n_ckpt = 0;
     DevBuf<np2_read_t> reads;
     DevBuf<uint8_t> nib;
-    DevBuf<uint8_t> refnib; // nibble-packed contig codes (+ padding), also viewed as uint64_t words
+    DevBuf<uint8_t> refnib; // nibble-packed contig codes (+ padding), also viewed as uint64_t words; then the dense pass's copies
+    uint32_t ref_stride = 0; // bytes of each of the three copies
     DevBuf<uint64_t> ck_off;
     DevBuf<uint32_t> ckpt;
-    // 2048-column chunks of the streamed reads (read 0 and dropped reads have none)
+    // DENSE_COLS-column chunks of the streamed reads (read 0 and dropped reads have none)
     uint32_t n_chunks = 0;
     DevBuf<ChunkDesc> descs;
     // reads overlapping each contig tile (ascending read index), CSR

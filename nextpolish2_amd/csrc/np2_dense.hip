@@ -35,32 +35,66 @@ struct DenseChunk { // what phase 2 needs to know about a chunk of the block (LD
 };
 static_assert(sizeof(DenseChunk) == 48, "DenseChunk mirrors the head of ChunkDesc");
 #ifndef NP2_DENSE_CPW
-#define NP2_DENSE_CPW 4
+#define NP2_DENSE_CPW 2
 #endif
-static constexpr uint32_t DENSE_CPW = NP2_DENSE_CPW;                 // chunks per wavefront: their loads are all in flight together
+static constexpr uint32_t DENSE_CPW = NP2_DENSE_CPW;     // chunks per wavefront: their loads are all in flight together
 static constexpr uint32_t DENSE_CHUNKS = 4 * DENSE_CPW;  // chunks per 256-thread block
-static constexpr uint32_t DENSE_TSLOTS = DENSE_CPW > 4 ? 128 : 64;             // tile table of a block (>= 3 tiles per chunk)
+static constexpr uint32_t DENSE_HALVES = DENSE_COLS / 32; // 32-column pieces of a chunk: phase 2's unit (two per lane)
+static constexpr uint32_t DENSE_TSLOTS = DENSE_CPW > 2 ? 128 : 64; // tile table of a block (a chunk's columns lie in <= 5 tiles)
+static constexpr uint32_t DENSE_STAGE = 1024;            // records of a round of phase 2 staged in LDS
+static_assert(DENSE_COLS == 4096, "a lane of phase 1 holds 64 columns");
+static_assert(DENSE_CHUNKS * DENSE_HALVES <= 1024 && DENSE_TSLOTS <= 128, "stage entry: piece in 10 bits, column in 5, tile slot above");
+static_assert(DENSE_CHUNKS * (DENSE_COLS / TILE + 1) <= DENSE_TSLOTS, "tile table too small");
 
+typedef uint32_t dense_u32x4 __attribute__((ext_vector_type(4)));
+// 16 bytes from any byte address (gfx950 in the HSA's unaligned access mode: one global_load_dwordx4)
+__device__ __forceinline__ dense_u32x4 dense_load16u(const uint8_t *p) {
+    dense_u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+// the packed stream's own nibble order (even column in the high nibble): bits of dword k (columns 8 k .. 8 k + 7) that
+// belong to the first nv columns of a 32-column piece
+__device__ __forceinline__ uint32_t dense_native_below(uint32_t nv, uint32_t k) {
+    const uint32_t m = nv > 8 * k ? min(8u, nv - 8 * k) : 0u;
+    const uint32_t by = m >> 1;
+    uint32_t r = by >= 4 ? 0xFFFFFFFFu : ((1u << (8 * by)) - 1u);
+    if (m & 1) r |= 0xF0u << (8 * by);
+    return r;
+}
+static constexpr uint32_t NF3W = 0x88888888u;
+
+// Phase 1 works on the stream as it lies in memory: 64 columns = two 16-byte pieces per lane, compared with a copy of the
+// contig in the SAME nibble order (k_encode_ref writes two: codes 2k | 2k+1 per byte for an even first position, 2k+1 |
+// 2k+2 for an odd one), so that "this piece agrees with the contig" is four XORs and two ORs per piece, with no nibble
+// swap, no alignment shifts and no column masks; one wave scan serves both pieces of a lane.
 __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint32_t np2_nb, const ChunkDesc *__restrict__ descs, uint32_t n_chunks, const uint8_t *__restrict__ nib,
-    const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, uint32_t L,
+    const uint32_t *__restrict__ refw32, const uint8_t *__restrict__ refnib, const uint8_t *__restrict__ refeo, uint32_t eo_stride, uint32_t L,
     uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ tile_cur, uint32_t n_tiles,
     uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *__restrict__ ovf_cnt,
-    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err) {
+    uint32_t *__restrict__ ckpt, uint64_t *__restrict__ chunk_st, uint32_t epoch, uint32_t *__restrict__ err, uint32_t probe) {
+    // (probe != 0: a timing experiment — tools/dense_probe.sh — that stops after a part of the kernel; launched after the
+    // real pass, it rewrites what that one wrote and nothing else)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
     __shared__ uint32_t s_total[DENSE_CHUNKS];        // non-insertion columns of the block's chunks
-    __shared__ uint2 s_q[DENSE_CHUNKS * 64];          // dirty lanes: {t0, chunk in block << 6 | lane}
+    __shared__ uint2 s_q[DENSE_CHUNKS * DENSE_HALVES]; // dirty pieces: {t0, chunk in block << 7 | piece}
     __shared__ __attribute__((aligned(16))) DenseChunk s_desc[DENSE_CHUNKS];
     __shared__ uint32_t s_nq;
-    __shared__ uint32_t s_tile[DENSE_TSLOTS], s_cnt[DENSE_TSLOTS], s_base[DENSE_TSLOTS]; // phase 2: the tiles the block adds records to
+    __shared__ uint32_t s_tile[DENSE_TSLOTS], s_cnt[DENSE_TSLOTS], s_base[DENSE_TSLOTS], s_off[DENSE_TSLOTS + 1]; // phase 2: the tiles the block adds records to
+    __shared__ uint2 s_stage[DENSE_STAGE];            // phase 2: records of a round, grouped by tile: {t_pos, piece | column << 10 | tile slot << 15}
     const uint32_t blk_first = np2_bid * DENSE_CHUNKS;
     if (threadIdx.x == 0) s_nq = 0;
-    // A wave's time is a chain of memory round trips, not instructions (phase 1 issues ~160 VALU per chunk): everything
-    // that can be requested together is.  Round trip 1: the descriptors of the wave's chunks, one per lane, handed
-    // round by readlane; 2: the chunks' 16 bytes per lane; 3 (after the block-wide exchange of the chunk totals): the
-    // status words of chunks in earlier blocks, where a read started there; 4: the contig windows of all chunks.
+#ifdef NP2_DENSE_PAD_LDS // (occupancy experiment: fewer resident blocks per CU)
+    __shared__ uint32_t s_pad[NP2_DENSE_PAD_LDS / 4];
+    if (probe == 77) s_pad[threadIdx.x] = epoch, atomicOr(err, s_pad[(threadIdx.x * 7) & 255]);
+#endif
+    // A wave's time is a chain of memory round trips on top of its instructions: everything that can be requested together
+    // is.  Round trip 1: the descriptors of the wave's chunks (scalar loads); 2: the chunks' 32 bytes per lane; 3 (after
+    // the block-wide exchange of the chunk totals): the status words of chunks in earlier blocks, where a read started
+    // there; 4: the contig windows of all pieces.
     struct Desc {
-        uint64_t nib_off;
+        uint64_t nib_off, ckbase;
         uint32_t read, ts, c0, ncols, first_chunk;
         bool live;
     } dd[DENSE_CPW];
@@ -78,54 +112,67 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         for (uint32_t it = 0; it < DENSE_CPW; ++it) {
             const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(ch0 + it, n_chunks - 1));
             const ChunkDesc *dp = descs + ci;
-            dd[it].nib_off = dp->nib_off;
+            dd[it].nib_off = dp->nib_off, dd[it].ckbase = dp->ckbase;
             dd[it].read = dp->read, dd[it].ts = dp->ts, dd[it].c0 = dp->c0, dd[it].ncols = dp->ncols;
-            dd[it].first_chunk = dp->first_chunk; // (ckbase, nck, aln_t_e: read from the LDS copy where they are used —
-            // held in scalar registers across both phases they were a good part of ~100 spill moves per wave)
+            dd[it].first_chunk = dp->first_chunk; // (nck, aln_t_e: read from the LDS copy where they are used)
             dd[it].live = ch0 + it < n_chunks;
         }
     }
     // ---- phase A: load the chunks, count their non-insertion columns and publish the counts at once.  A chunk needs
     //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
     //      already running waves, which publish within a microsecond of starting ---------------------------------------
-    N128 w_[DENSE_CPW];
-    uint32_t nv_[DENSE_CPW], nonins_[DENSE_CPW], incl_[DENSE_CPW], total_[DENSE_CPW];
-    uint4 v_[DENSE_CPW];
+    dense_u32x4 va_[DENSE_CPW], vb_[DENSE_CPW];
+    uint32_t nv_[DENSE_CPW], nA_[DENSE_CPW], nB_[DENSE_CPW], incl_[DENSE_CPW], total_[DENSE_CPW];
     bool full_[DENSE_CPW];
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) { // (all loads first)
-        const uint32_t lc0 = dd[it].c0 + lane * 32;
-        const bool full = dd[it].live && dd[it].ncols - dd[it].c0 >= 2048; // every lane of the wave holds 32 columns
+        const uint32_t lc0 = dd[it].c0 + lane * 64;
+        const bool full = dd[it].live && dd[it].ncols - dd[it].c0 >= DENSE_COLS; // every lane of the wave holds 64 columns
         full_[it] = full;
-        nv_[it] = !dd[it].live ? 0u : (full ? 32u : (lc0 < dd[it].ncols ? min(32u, dd[it].ncols - lc0) : 0u));
-        v_[it] = make_uint4(0, 0, 0, 0);
-        if (nv_[it]) v_[it] = *reinterpret_cast<const uint4 *>(nib + dd[it].nib_off + (lc0 >> 1));
+        nv_[it] = !dd[it].live ? 0u : (full ? 64u : (lc0 < dd[it].ncols ? min(64u, dd[it].ncols - lc0) : 0u));
+        // (unconditional loads, all in flight together: a lane past the read's end reads the stream's last bytes — 16 bytes
+        // of padding follow every stream — and what it gets is masked by its column count)
+        const uint32_t last = (max(dd[it].ncols, 1u) - 1u) >> 1;
+        const uint8_t *p = nib + dd[it].nib_off;
+        va_[it] = dense_load16u(p + min(lc0 >> 1, last));
+        vb_[it] = dense_load16u(p + min((lc0 >> 1) + 16u, last));
     }
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
         const uint32_t ch = DENSE_CPW * pw + it;
-        const uint32_t nv = nv_[it];
-        N128 w;
-        w.lo = (uint64_t)swap_nib(v_[it].x) | ((uint64_t)swap_nib(v_[it].y) << 32);
-        w.hi = (uint64_t)swap_nib(v_[it].z) | ((uint64_t)swap_nib(v_[it].w) << 32);
-        if (dd[it].c0 == 0 && lane == 0) w.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-        N128 I{w.lo & NF3, w.hi & NF3}; // insertion columns
-        if (!full_[it]) { // (uniform: 97 % of the chunks are whole, their lanes need no column masks)
-            const N128 m = n_below(nv);
-            I.lo &= m.lo, I.hi &= m.hi;
+        if (dd[it].c0 == 0 && lane == 0) va_[it].x &= ~0x80u; // column 0 is never an insertion column (main.rs:325,332-335)
+        const dense_u32x4 a = va_[it], b = vb_[it];
+        uint32_t iA = (uint32_t)__builtin_popcount(a.x & NF3W) + (uint32_t)__builtin_popcount(a.y & NF3W) +
+                      (uint32_t)__builtin_popcount(a.z & NF3W) + (uint32_t)__builtin_popcount(a.w & NF3W);
+        uint32_t iB = (uint32_t)__builtin_popcount(b.x & NF3W) + (uint32_t)__builtin_popcount(b.y & NF3W) +
+                      (uint32_t)__builtin_popcount(b.z & NF3W) + (uint32_t)__builtin_popcount(b.w & NF3W);
+        uint32_t nA = 32u - iA, nB = 32u - iB;
+        if (!full_[it]) { // (uniform) the read ends in this chunk: one lane holds a partial piece, the lanes after it none
+            const uint32_t nv = nv_[it], nvA = min(nv, 32u), nvB = nv - nvA;
+            if (nvA != 32u) {
+                iA = nvA ? (uint32_t)__builtin_popcount(a.x & NF3W & dense_native_below(nvA, 0)) + (uint32_t)__builtin_popcount(a.y & NF3W & dense_native_below(nvA, 1)) +
+                               (uint32_t)__builtin_popcount(a.z & NF3W & dense_native_below(nvA, 2)) + (uint32_t)__builtin_popcount(a.w & NF3W & dense_native_below(nvA, 3))
+                         : 0u;
+                nA = nvA - iA;
+            }
+            if (nvB != 32u) {
+                iB = nvB ? (uint32_t)__builtin_popcount(b.x & NF3W & dense_native_below(nvB, 0)) + (uint32_t)__builtin_popcount(b.y & NF3W & dense_native_below(nvB, 1)) +
+                               (uint32_t)__builtin_popcount(b.z & NF3W & dense_native_below(nvB, 2)) + (uint32_t)__builtin_popcount(b.w & NF3W & dense_native_below(nvB, 3))
+                         : 0u;
+                nB = nvB - iB;
+            }
         }
-        const uint32_t nonins = nv - n_popc(I);
-        const uint32_t incl = wave_incl_scan<OpAdd>(nonins);
+        const uint32_t incl = wave_incl_scan<OpAdd>(nA + nB);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane == 0 && dd[it].live) {
             __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_total[ch - blk_first] = total;
         }
-        w_[it] = w;
-        nonins_[it] = nonins, incl_[it] = incl, total_[it] = total;
+        nA_[it] = nA, nB_[it] = nB, incl_[it] = incl, total_[it] = total;
     }
+    if (probe == 1) return;
     __syncthreads();
-    // ---- phase B: t_pos, contig codes, compare; clean lanes finish here, dirty ones are queued ----------------------------
+    // ---- phase B: t_pos, contig codes, compare; clean pieces finish here, dirty ones are queued ---------------------------
     uint32_t carry_[DENSE_CPW];
     {
         bool timeout = false;
@@ -142,18 +189,15 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             uint32_t carryN = 0; // non-insertion columns of the read before this chunk
             // earlier chunks of the read inside this block: from LDS; the ones in earlier blocks: from their status words
             {
-                const uint32_t lo = max(dd[it].first_chunk, blk_first) - blk_first, hi = ch - blk_first; // (hi <= DENSE_CHUNKS <= 64)
+                const uint32_t lo = max(dd[it].first_chunk, blk_first) - blk_first, hi = ch - blk_first; // (hi <= DENSE_CHUNKS <= 16)
                 uint32_t v = lane >= lo && lane < hi ? s_total[lane] : 0u;
-                if (lo < hi) {
-                    if (DENSE_CHUNKS <= 16) { // a row's worth of lanes: four DPP steps, lane 15 holds the sum
-                        v += dpp_get<0x111, 0xF>(0u, v);
-                        v += dpp_get<0x112, 0xF>(0u, v);
-                        v += dpp_get<0x114, 0xF>(0u, v);
-                        v += dpp_get<0x118, 0xF>(0u, v);
-                        carryN += (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
-                    } else {
-                        carryN += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(v), 63);
-                    }
+                if (lo < hi) { // a row's worth of lanes: four DPP steps, lane 15 holds the sum
+                    static_assert(DENSE_CHUNKS <= 16, "the block's chunk totals are summed inside one DPP row");
+                    v += dpp_get<0x111, 0xF>(0u, v);
+                    v += dpp_get<0x112, 0xF>(0u, v);
+                    v += dpp_get<0x114, 0xF>(0u, v);
+                    v += dpp_get<0x118, 0xF>(0u, v);
+                    carryN += (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
                 }
             }
             const uint32_t jend = min(ch, blk_first);
@@ -182,91 +226,96 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         }
         if (__ballot(timeout) && lane == 0) atomicOr(err, LB_ERR);
     }
-    // the 32 contig codes starting at t0 (t_pos of the lane's first non-insertion column): one unaligned 20-byte window
-    // of the nibble-packed contig per chunk, all of them requested before the first is used
-    uint32_t t0_[DENSE_CPW], r_[DENSE_CPW][5];
+    // the 32 contig codes of every piece, starting at the t_pos of its first non-insertion column: 16 bytes of the copy
+    // whose nibble parity matches, at whatever byte they start; all of them requested before the first is used.
+    // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer; such a
+    // read is reported by the descriptor check at the end of its last chunk)
+    uint32_t t0_[DENSE_CPW];
+    dense_u32x4 ra_[DENSE_CPW], rb_[DENSE_CPW];
+    const uint32_t win_lim = (L >> 1) + 32;
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
-        t0_[it] = dd[it].ts + carry_[it] + (incl_[it] - nonins_[it]);
-        // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer;
-        // such a read is reported by the descriptor check at the end of its last chunk)
-        const uint32_t q = min(t0_[it] >> 3, (L >> 3) + 8);
-#pragma unroll
-        for (uint32_t k = 0; k < 5; ++k) r_[it][k] = refw32[q + k];
+        const uint32_t tA = dd[it].ts + carry_[it] + (incl_[it] - nA_[it] - nB_[it]), tB = tA + nA_[it];
+        t0_[it] = tA;
+        ra_[it] = dense_load16u(refeo + ((tA & 1) ? eo_stride : 0u) + min(tA >> 1, win_lim));
+        rb_[it] = dense_load16u(refeo + ((tB & 1) ? eo_stride : 0u) + min(tB >> 1, win_lim));
     }
-    uint32_t prev_top = 0; // flags of the last two columns of the previous chunk (when this one continues it)
+    uint32_t prev_top = 0; // "one of the last two columns of the previous chunk is bad" (when this one continues it)
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
         const uint32_t ch = DENSE_CPW * pw + it;
         if (!dd[it].live) break;
-        const uint8_t *base = nib + dd[it].nib_off; // start of the READ's stream
         const uint32_t ncols = dd[it].ncols, ts = dd[it].ts, c0 = dd[it].c0;
-        const uint32_t lc0 = c0 + lane * 32;
-        const N128 w = w_[it];
-        const uint32_t nv = nv_[it], nonins = nonins_[it], total = total_[it], carryN = carry_[it], t0 = t0_[it];
+        const uint32_t lc0 = c0 + lane * 64;
+        const uint32_t nA = nA_[it], nB = nB_[it], total = total_[it], carryN = carry_[it];
+        const uint32_t tA = t0_[it], tB = tA + nA;
         const bool cont = it != 0 && dd[it].read == dd[it ? it - 1 : 0].read && c0 != 0;
-        N128 R;
-        {
-            const uint32_t sh = (t0 & 7) * 4;
-            const uint32_t a0 = __builtin_amdgcn_alignbit(r_[it][1], r_[it][0], sh), a1 = __builtin_amdgcn_alignbit(r_[it][2], r_[it][1], sh);
-            const uint32_t a2 = __builtin_amdgcn_alignbit(r_[it][3], r_[it][2], sh), a3 = __builtin_amdgcn_alignbit(r_[it][4], r_[it][3], sh);
-            R.lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
-            R.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
+        // columns that differ from the contig, insertion columns among them (the contig's copies carry no flag bit)
+        const dense_u32x4 xa = va_[it] ^ ra_[it], xb = vb_[it] ^ rb_[it];
+        uint32_t oA = xa.x | xa.y | xa.z | xa.w, oB = xb.x | xb.y | xb.z | xb.w;
+        // A bad column marks itself and the two columns after it (3-column-mers): the last two columns of a piece reach
+        // into the next one.  After an insertion column a piece's window is no longer the contig's: assume the worst.
+        uint32_t topA = nA != 32u ? 1u : xa.w >> 24, topB = nB != 32u ? 1u : xb.w >> 24;
+        bool okA = true, okB = true; // the piece holds 32 columns
+        if (!full_[it]) { // (uniform) a partial piece goes to phase 2, which masks; an empty one nowhere
+            const uint32_t nv = nv_[it];
+            okA = nv >= 32u, okB = nv == 64u;
+            if (!okA) oA = nv ? 1u : 0u, topA = 0;
+            if (!okB) oB = nv > 32u ? 1u : 0u, topB = 0;
         }
-        // bad columns as far as a lane WITHOUT insertion columns is concerned (exact for those lanes; a lane with an
-        // insertion column is dirty whatever the rest says): code differs from the contig (nibble != 0 -> + 7 carries
-        // into bit 3) or the insertion flag itself; columns past the read's end are cleared
-        N128 B0;
-        B0.lo = ((((w.lo ^ R.lo) & ~NF3) + ~NF3) | w.lo) & NF3;
-        B0.hi = ((((w.hi ^ R.hi) & ~NF3) + ~NF3) | w.hi) & NF3;
-        if (!full_[it]) {
-            const N128 m = n_below(nv);
-            B0.lo &= m.lo, B0.hi &= m.hi;
-        }
-        const uint32_t n_ins = nv - nonins;
-        // checkpoint: column of the reference column at the next multiple of CKPT (lanes without insertion columns:
-        // column index and position advance together)
+        // checkpoints: column of the reference column at the next multiple of CKPT (a whole piece without insertion columns
+        // holds exactly one, and column index and position advance together; phase 2 writes the others')
         {
-            const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
-            const uint32_t nth = tstar - t0; // 0-based index among the lane's non-insertion columns
-            if (n_ins == 0 && nth < nonins) {
-                const uint32_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
-                const uint32_t idx = (tstar >> CKPT_SHIFT) - ck_first;
-                const DenseChunk &dl = s_desc[ch - blk_first];
-                if (idx < dl.nck) ckpt[dl.ckbase + idx] = lc0 + nth;
+            const uint64_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
+            uint32_t *const ckb = ckpt + (dd[it].ckbase - ck_first);
+            const uint32_t nck = s_desc[ch - blk_first].nck;
+            const uint32_t tsA = (tA + CKPT - 1) & ~(CKPT - 1), tsB = (tB + CKPT - 1) & ~(CKPT - 1);
+            if (probe != 2) {
+                if (okA && nA == 32u && (tsA >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsA >> CKPT_SHIFT] = lc0 + (tsA - tA);
+                if (okB && nB == 32u && (tsB >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsB >> CKPT_SHIFT] = lc0 + 32u + (tsB - tB);
             }
         }
-        // A bad column marks itself and the two columns after it (3-column-mers): the flags of the lane's last two
-        // columns reach into the next lane.  An insertion-bearing lane's flags are not exact here: assume the worst.
-        const uint32_t top = n_ins ? 0x88000000u : (uint32_t)(B0.hi >> 32);
-        uint32_t pb = wave_prev_lane(0u, top);
-        if (lane == 0) pb = cont ? prev_top : (c0 > 0 ? 0x88000000u : 0u); // (chunk start inside a read: phase 2 looks)
-        const bool dirty = nv != 0 && ((B0.lo | B0.hi) != 0 || (pb & 0x88000000u) != 0 || (lc0 == 0 && ts != 0));
-        prev_top = (uint32_t)__builtin_amdgcn_readlane((int)top, 63);
-        const uint64_t dm = __ballot(dirty);
-        if (dm) {
+        uint32_t pb = wave_prev_lane(0u, topB);
+        if (lane == 0) pb = cont ? prev_top : (c0 > 0 ? 1u : 0u); // (chunk start inside a read: phase 2 looks)
+        prev_top = (uint32_t)__builtin_amdgcn_readlane((int)topB, 63);
+        const bool dirtyA = oA != 0 || (pb != 0 && nv_[it] != 0) || (lc0 == 0 && ts != 0);
+        const bool dirtyB = oB != 0 || (topA != 0 && nv_[it] > 32u);
+        const uint64_t dmA = __ballot(dirtyA), dmB = __ballot(dirtyB);
+        if (probe == 2 || probe == 3) { // (keep the comparison alive)
+            if ((dmA ^ dmB) == 0x123456789ABCDEFull && lane == 0) atomicOr(err, 0x80000000u);
+            continue;
+        }
+        if (dmA | dmB) {
+            const uint32_t cA = (uint32_t)__builtin_popcountll(dmA);
             uint32_t qb = 0;
-            if (lane == 0) qb = atomicAdd(&s_nq, (uint32_t)__builtin_popcountll(dm));
+            if (lane == 0) qb = atomicAdd(&s_nq, cA + (uint32_t)__builtin_popcountll(dmB));
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            if (dirty) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                s_q[qb + rank] = make_uint2(t0, ((ch - blk_first) << 6) | lane);
+            const uint32_t tag = ((ch - blk_first) << 7) | (lane << 1);
+            if (dirtyA) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmA, 0u));
+                s_q[qb + rank] = make_uint2(tA, tag);
+            }
+            if (dirtyB) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmB, 0u));
+                s_q[qb + cA + rank] = make_uint2(tB, tag | 1u);
             }
         }
         if (lane == 0) {
-            if (c0 + 2048 >= ncols) {
+            if (c0 + DENSE_COLS >= ncols) {
                 // last chunk: the packed stream must agree with its descriptor (AlignSeq::new, main.rs:279-312)
+                const uint8_t *base = nib + dd[it].nib_off; // start of the READ's stream
                 const uint32_t te = s_desc[ch - blk_first].aln_t_e;
                 if (ncols == 0 || ts + carryN + total - 1 != te || te >= L) atomicOr(err, 2u);
                 if ((nib_at(base, ncols) & 15) != 15) atomicOr(err, 2u);
             }
         }
     }
+    if (probe == 2 || probe == 3 || probe == 4) return;
     __syncthreads();
-    // ---- phase 2: one thread per dirty lane ---------------------------------------------------------------------------------
-    // Records go straight into the bucket of their contig tile; the block reserves its place in a bucket ONCE per tile
-    // (a 32-entry tile table in LDS: the block's 8 chunks touch at most 24 tiles), so that what a block adds to a tile
-    // is one contiguous piece written through one L2.  (Reserving per lane left every bucket line shared by fragments
+    // ---- phase 2: one thread per dirty piece --------------------------------------------------------------------------------
+    // Records go into the bucket of their contig tile; the block reserves its place in a bucket ONCE per tile (a tile
+    // table in LDS: a chunk's columns lie in at most 5 tiles), so that what a block adds to a tile is one contiguous piece
+    // written through one L2.  (Reserving per lane left every bucket line shared by fragments
     // of a dozen blocks on different XCDs: the scattered partial-line stores cost 5x the rest of the kernel.)
     const uint32_t nq = s_nq;
     for (uint32_t q0 = 0; q0 < nq; q0 += 256) { // (uniform; one round unless more than half of the lanes are dirty)
@@ -277,12 +326,13 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         __syncthreads();
         const uint32_t qi = q0 + threadIdx.x;
         N128 E{0, 0}, NI{0, 0};
-        uint32_t t0 = 0, lc0 = 0, read = 0, cnt = 0, n_lo = 0, tA = 0, sl_lo = 0, sl_hi = 0, loc_lo = 0, loc_hi = 0;
+        uint32_t t0 = 0, lc0 = 0, read = 0, cnt = 0, n_lo = 0, tA = 0, sl_lo = 0, sl_hi = 0, loc_lo = 0, loc_hi = 0, q_tag = 0;
         if (qi < nq) {
             const uint2 qe = s_q[qi];
-            const uint32_t ln = qe.y & 63;
+            q_tag = qe.y;
+            const uint32_t ln = qe.y & (DENSE_HALVES - 1);
             t0 = qe.x;
-            const DenseChunk dc = s_desc[qe.y >> 6];
+            const DenseChunk dc = s_desc[qe.y >> 7];
             const uint32_t ts = dc.ts;
             lc0 = dc.c0 + ln * 32;
             read = dc.read;
@@ -358,8 +408,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 E.lo &= V.lo;
                 E.hi &= V.hi;
             }
-            // checkpoint of a lane with insertion columns: the (nth + 1)-th non-insertion column
-            if (nonins != nv) {
+            // checkpoint of a piece with insertion columns, or of a partial one: the (nth + 1)-th non-insertion column
+            if (nonins != nv || nv != 32u) {
                 const uint32_t tstar = (t0 + CKPT - 1) & ~(CKPT - 1);
                 const uint32_t nth = tstar - t0;
                 if (nth < nonins) {
@@ -404,37 +454,90 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 loc_hi = atomicAdd(&s_cnt[sl_hi], cnt - n_lo);
             }
         }
+        if (probe == 5) { // (everything up to the reservation; keep the counts alive)
+            if (cnt == 0x7FFFFFFFu) atomicOr(err, 0x80000000u);
+            return;
+        }
         __syncthreads();
-        if (threadIdx.x < DENSE_TSLOTS && s_tile[threadIdx.x] != 0xFFFFFFFFu)
-            s_base[threadIdx.x] = atomicAdd(&tile_cur[s_tile[threadIdx.x]], s_cnt[threadIdx.x]);
-        __syncthreads();
-        if (cnt) {
-            const uint32_t b_lo = s_base[sl_lo] + loc_lo, b_hi = s_base[sl_hi] + loc_hi;
-            N128 e = E;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t col = n_ctz(e) >> 2;
-                if (e.lo) e.lo &= e.lo - 1ULL; else e.hi &= e.hi - 1ULL;
-                const uint32_t t = t_of(col);
-                const bool hi = i >= n_lo;
-                const uint32_t tile = hi ? tA + 1 : tA;
-                const uint32_t slot = hi ? b_hi + (i - n_lo) : b_lo + i;
-                bool ok = tile < n_tiles;
-                uint64_t dst = 0;
-                if (ok) {
-                    if (slot < bucket_cap) {
-                        dst = (uint64_t)tile * bucket_cap + slot;
-                    } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
-                        const uint32_t x = atomicAdd(ovf_cnt, 1u);
-                        dst = ovf_base + x;
-                        ok = x < ovf_cap;
-                    }
-                }
-                if (ok) {
-                    out_keys[dst] = ((uint64_t)t << 32) | (lc0 + col);
-                    out_vals[dst] = read;
+        // The block's place in every bucket, ONE atomic per tile — whose round trip to memory (agent scope: past the L2s)
+        // nobody waits for: the records are formed meanwhile, into an LDS stage grouped by tile, and leave it as whole
+        // contiguous pieces once the places are known.
+        uint32_t gbase = 0;
+        if (threadIdx.x < 64) { // (wave 0: DENSE_TSLOTS is one or two slots per lane)
+            uint32_t c[DENSE_TSLOTS / 64], sum = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < DENSE_TSLOTS / 64; ++k) {
+                c[k] = s_cnt[threadIdx.x * (DENSE_TSLOTS / 64) + k];
+                sum += c[k];
+            }
+            const uint32_t incl = wave_incl_scan<OpAdd>(sum);
+            uint32_t o = incl - sum;
+#pragma unroll
+            for (uint32_t k = 0; k < DENSE_TSLOTS / 64; ++k) {
+                const uint32_t sl = threadIdx.x * (DENSE_TSLOTS / 64) + k;
+                s_off[sl] = o;
+                o += c[k];
+                if (c[k]) { // (k = 0 only keeps its result in a register; the rare second slot of a lane waits)
+                    const uint32_t b = atomicAdd(&tile_cur[s_tile[sl]], c[k]);
+                    if (k == 0) gbase = b; else s_base[sl] = b;
                 }
             }
+            if (threadIdx.x == 63) s_off[DENSE_TSLOTS] = incl;
         }
+        __syncthreads();
+        const uint32_t n_rec = s_off[DENSE_TSLOTS];
+        const bool staged = n_rec <= DENSE_STAGE; // (uniform)
+        if (!staged) { // more records than the stage holds (pileups far from HiFi statistics): straight to memory
+            if (threadIdx.x < 64 && s_cnt[threadIdx.x * (DENSE_TSLOTS / 64)]) s_base[threadIdx.x * (DENSE_TSLOTS / 64)] = gbase;
+            __syncthreads();
+        }
+        auto put = [&](uint32_t tile, uint32_t slot, uint64_t key, uint32_t val) {
+            uint64_t dst;
+            bool ok = true;
+            if (slot < bucket_cap) {
+                dst = (uint64_t)tile * bucket_cap + slot;
+            } else { // the tile's bucket is full: spill (rare; the host then takes the device-wide sort)
+                const uint32_t x = atomicAdd(ovf_cnt, 1u);
+                dst = ovf_base + x;
+                ok = x < ovf_cap;
+            }
+            if (ok) {
+                out_keys[dst] = key;
+                out_vals[dst] = val;
+            }
+        };
+        if (cnt) {
+            // (a position >= L has no tile: the descriptor check reports the read)
+            const bool ok_lo = n_lo && tA < n_tiles, ok_hi = cnt - n_lo && tA + 1 < n_tiles;
+            const uint32_t b_lo = (staged ? s_off[sl_lo] : s_base[sl_lo]) + loc_lo, b_hi = (staged ? s_off[sl_hi] : s_base[sl_hi]) + loc_hi;
+            N128 e = E;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                // t_pos of column c = t0 - 1 + the non-insertion columns up to and including c (a leading insertion column
+                // belongs to t0 - 1)
+                const N128 m = n_mask_through_first(e);
+                const uint32_t col = (n_popc(N128{m.lo & NF3, m.hi & NF3})) - 1u;
+                const uint32_t t = t0 + n_popc(N128{NI.lo & m.lo, NI.hi & m.hi}) - 1u;
+                e.lo &= ~m.lo, e.hi &= ~m.hi;
+                const bool hi = i >= n_lo;
+                if (!(hi ? ok_hi : ok_lo)) continue;
+                const uint32_t slot = hi ? b_hi + (i - n_lo) : b_lo + i;
+                if (staged)
+                    s_stage[slot] = make_uint2(t, q_tag | (col << 10) | ((hi ? sl_hi : sl_lo) << 15));
+                else
+                    put(hi ? tA + 1 : tA, slot, ((uint64_t)t << 32) | (lc0 + col), read);
+            }
+        }
+        if (staged) {
+            if (threadIdx.x < 64 && s_cnt[threadIdx.x * (DENSE_TSLOTS / 64)]) s_base[threadIdx.x * (DENSE_TSLOTS / 64)] = gbase;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n_rec; i += 256) {
+                const uint2 r = s_stage[i];
+                const uint32_t sl = r.y >> 15, pc = r.y & 1023u, col = (r.y >> 10) & 31u;
+                const DenseChunk &dc = s_desc[pc >> 7];
+                put(s_tile[sl], s_base[sl] + (i - s_off[sl]), ((uint64_t)r.x << 32) | (dc.c0 + (pc & (DENSE_HALVES - 1)) * 32u + col), dc.read);
+            }
+        }
+        if (q0 + 256 < nq) __syncthreads(); // (the tables and the stage are reused by the next round)
     }
 }
 
@@ -450,17 +553,19 @@ __device__ __forceinline__ void k_chunk_counts(const uint32_t np2_bid, const uin
     if (ch >= n_chunks) return;
     const ChunkDesc *dp = descs + ch;
     const uint32_t c0 = dp->c0, ncols = dp->ncols;
-    const uint32_t lc0 = c0 + lane * 32;
-    const uint32_t nv = lc0 < ncols ? min(32u, ncols - lc0) : 0u;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (nv) v = *reinterpret_cast<const uint4 *>(nib + dp->nib_off + (lc0 >> 1));
-    N128 w;
-    w.lo = (uint64_t)swap_nib(v.x) | ((uint64_t)swap_nib(v.y) << 32);
-    w.hi = (uint64_t)swap_nib(v.z) | ((uint64_t)swap_nib(v.w) << 32);
-    if (c0 == 0 && lane == 0) w.lo &= ~8ULL; // column 0 is never an insertion column (main.rs:325,332-335)
-    const N128 m = n_below(nv);
-    const N128 I{w.lo & NF3 & m.lo, w.hi & NF3 & m.hi};
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(nv - n_popc(I)), 63);
+    const uint32_t lc0 = c0 + lane * 64;
+    const uint32_t nv = lc0 < ncols ? min(64u, ncols - lc0) : 0u;
+    const uint32_t nvA = min(nv, 32u), nvB = nv - nvA;
+    dense_u32x4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
+    const uint8_t *p = nib + dp->nib_off + (lc0 >> 1);
+    if (nvA) a = *reinterpret_cast<const dense_u32x4 *>(p);
+    if (nvB) b = *reinterpret_cast<const dense_u32x4 *>(p + 16);
+    if (c0 == 0 && lane == 0) a.x &= ~0x80u; // column 0 is never an insertion column (main.rs:325,332-335)
+    const uint32_t ins = (uint32_t)__builtin_popcount(a.x & NF3W & dense_native_below(nvA, 0)) + (uint32_t)__builtin_popcount(a.y & NF3W & dense_native_below(nvA, 1)) +
+                         (uint32_t)__builtin_popcount(a.z & NF3W & dense_native_below(nvA, 2)) + (uint32_t)__builtin_popcount(a.w & NF3W & dense_native_below(nvA, 3)) +
+                         (uint32_t)__builtin_popcount(b.x & NF3W & dense_native_below(nvB, 0)) + (uint32_t)__builtin_popcount(b.y & NF3W & dense_native_below(nvB, 1)) +
+                         (uint32_t)__builtin_popcount(b.z & NF3W & dense_native_below(nvB, 2)) + (uint32_t)__builtin_popcount(b.w & NF3W & dense_native_below(nvB, 3));
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(nv - ins), 63);
     if (lane == 0) __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_chunk_counts(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, uint64_t *chunk_st, uint32_t epoch) {
@@ -468,11 +573,11 @@ void launch_chunk_counts(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunk
 }
 
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib,
-                       const uint64_t *refw, const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals,
+                       const uint64_t *refw, const uint8_t *refnib, const uint8_t *refeo, uint32_t eo_stride, uint32_t L, uint64_t *keys, uint32_t *vals,
                        uint32_t *tile_cur, uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap,
-                       uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err) {
+                       uint32_t *ovf_cnt, uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err, uint32_t probe) {
     if (n_chunks)
-        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + DENSE_CHUNKS - 1) / DENSE_CHUNKS), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err);
+        NP2_LAUNCH(k_diff_reads, dim3((n_chunks + DENSE_CHUNKS - 1) / DENSE_CHUNKS), 256, s, descs, n_chunks, nib, (const uint32_t *)refw, refnib, refeo, eo_stride, L, keys, vals, tile_cur, n_tiles, bucket_cap, ovf_base, ovf_cap, ovf_cnt, ckpt, chunk_st, epoch, err, probe);
 }
 
 } // namespace np2

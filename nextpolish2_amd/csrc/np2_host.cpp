@@ -638,9 +638,16 @@ void run_diff(np2_ctx *cx, np2_contig *c, uint32_t &T) {
         if (precount) launch_chunk_counts(s, c->descs.p, NCH, c->nib.p, cx->chunk_st.p, cx->chunk_epoch);
         {
             EventTimer t(cx, "diff_reads", true);
-            launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, L,
+            launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, c->refnib.p + c->ref_stride, c->ref_stride, L,
                               cx->keys_raw.p, cx->vals_raw.p, cx->tile_cur.p, n_tiles, bcap, buckets, (uint32_t)ovf_cap,
                               cx->scal.p + S_M3, c->ckpt.p, cx->chunk_st.p, cx->chunk_epoch, cx->scal.p + S_ERR);
+        }
+        static const uint32_t probe = getenv("NP2_DENSE_PROBE") ? (uint32_t)atoi(getenv("NP2_DENSE_PROBE")) : 0u;
+        if (probe) { // (timing experiment: a part of the dense pass once more, tools/dense_probe.sh)
+            EventTimer t(cx, "diff_probe", true);
+            launch_diff_reads(s, c->descs.p, NCH, c->nib.p, (const uint64_t *)c->refnib.p, c->refnib.p, c->refnib.p + c->ref_stride, c->ref_stride, L,
+                              cx->keys_raw.p, cx->vals_raw.p, cx->tile_cur.p, n_tiles, bcap, buckets, (uint32_t)ovf_cap,
+                              cx->scal.p + S_M3, c->ckpt.p, cx->chunk_st.p, cx->chunk_epoch, cx->scal.p + S_ERR, probe);
         }
         {
             EventTimer t(cx, "sort_exceptions");
@@ -1503,7 +1510,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     };
     uint64_t total_chunks = 0;
     for (uint32_t r = 1; r < n_reads; ++r)
-        if (!(reads[r].flags & NP2_READ_DROPPED)) total_chunks += ((uint64_t)reads[r].n_cols + 2047) / 2048;
+        if (!(reads[r].flags & NP2_READ_DROPPED)) total_chunks += ((uint64_t)reads[r].n_cols + DENSE_COLS - 1) / DENSE_COLS;
     if (total_chunks >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many pileup columns for one contig");
     PinnedTmp ck_pin((size_t)(n_reads + 1) * 8), descs_pin((size_t)(total_chunks + 1) * sizeof(ChunkDesc));
     uint64_t *ck = (uint64_t *)ck_pin.p;
@@ -1524,7 +1531,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         if (!dropped) {
             const uint32_t first = (rd.aln_t_s + CKPT - 1) >> CKPT_SHIFT, last = rd.aln_t_e >> CKPT_SHIFT;
             nck = last >= first ? last - first + 1 : 0;
-            if (r != 0) nch = (rd.n_cols + 2047) / 2048;
+            if (r != 0) nch = (uint32_t)(((uint64_t)rd.n_cols + DENSE_COLS - 1) / DENSE_COLS);
             cols += rd.n_cols;
         }
         ck[r + 1] = ck[r] + nck;
@@ -1536,7 +1543,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
             d.ckbase = ck[r];
             d.read = r;
             d.ts = rd.aln_t_s;
-            d.c0 = k * 2048;
+            d.c0 = k * DENSE_COLS;
             d.ncols = rd.n_cols;
             d.first_chunk = first_chunk;
             d.aln_t_e = rd.aln_t_e;
@@ -1582,7 +1589,8 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
     c->n_chunks = n_descs;
     c->reads.ensure(n_reads);
     const uint32_t refbytes = ((L + 1) >> 1) + 96; // padding so that 128-bit probes near the end stay in bounds
-    c->refnib.ensure(((size_t)refbytes + 15) & ~(size_t)15);
+    c->ref_stride = (refbytes + 15) & ~15u; // (the dense pass's two copies follow the codes: launch_encode_ref)
+    c->refnib.ensure(3 * (size_t)c->ref_stride);
     c->ck_off.ensure(n_reads + 1);
     c->ckpt.ensure(c->n_ckpt + 1);
     c->descs.ensure(c->n_chunks + 1);
@@ -1592,7 +1600,7 @@ void finish_contig(np2_ctx *cx, np2_contig *c, const np2_read_t *reads, uint32_t
         HIPCHK(hipMemcpyAsync(c->descs.p, descs, (size_t)c->n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
     cx->scal.ensure(SCAL_TOTAL);
     zero32(cx, cx->scal.p, 24);
-    launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, cx->scal.p);
+    launch_encode_ref(s, c->nib.p + reads[0].nib_off, L, c->refnib.p, refbytes, c->ref_stride, cx->scal.p);
     auto sc = d2h(cx, cx->scal.p, 1); // also syncs: the pinned staging blocks above go back to the pool
     if (sc[0]) throw Np2Error(NP2_E_ARG, "reads[0] is not a plain self-alignment of the contig");
 }

@@ -28,7 +28,7 @@ __device__ __forceinline__ uint8_t ref_code(const uint8_t *__restrict__ refnib, 
 // K0: contig codes from read 0 (the contig aligned to itself, main.rs:1732-1739)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void k_encode_ref(const uint32_t np2_bid, const uint32_t np2_nb, const uint8_t *__restrict__ read0, uint32_t L, uint8_t *__restrict__ refnib,
-                             uint32_t nbytes_total, uint32_t *__restrict__ err) {
+                             uint32_t nbytes_total, uint32_t stride, uint32_t *__restrict__ err) {
     uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i >= nbytes_total) return;
     uint32_t c0 = 2 * i, c1 = 2 * i + 1;
@@ -38,6 +38,10 @@ __device__ __forceinline__ void k_encode_ref(const uint32_t np2_bid, const uint3
     if (c0 < L && (hi & 7) == 7) atomicOr(err, 1u);
     if (c1 < L && (lo & 7) == 7) atomicOr(err, 1u);
     refnib[i] = (uint8_t)((hi & 7) | ((lo & 7) << 4));
+    // the dense pass's copies, in the packed streams' nibble order: positions 2 i | 2 i + 1 and 2 i + 1 | 2 i + 2
+    const uint8_t nx = c1 + 1 < L ? (uint8_t)((read0[i + 1] >> 4) & 7) : (uint8_t)0;
+    refnib[stride + i] = (uint8_t)(((hi & 7) << 4) | (lo & 7));
+    refnib[2 * (size_t)stride + i] = (uint8_t)(((lo & 7) << 4) | nx);
 }
 
 // gather up to four device-resident counters into scalar slots, then post the whole scalar block to host-mapped memory
@@ -1476,8 +1480,8 @@ namespace np2 {
 static inline dim3 grid1(uint64_t n, uint32_t bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes,
-                       uint32_t *err) {
-    NP2_LAUNCH(k_encode_ref, grid1(nbytes), 256, s, read0, L, refnib, nbytes, err);
+                       uint32_t stride, uint32_t *err) {
+    NP2_LAUNCH(k_encode_ref, grid1(nbytes), 256, s, read0, L, refnib, nbytes, stride, err);
 }
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0,
                  const uint32_t *s0, uint32_t *d1, const uint32_t *s1, uint32_t *d2, const uint32_t *s2, uint32_t *d3,

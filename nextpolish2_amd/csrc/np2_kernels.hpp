@@ -14,7 +14,8 @@ static constexpr uint32_t TILE = 1u << TILE_SHIFT;
 static constexpr uint32_t TILE_CAP = 4096;  // records per tile bucket = what a tile can sort inside LDS (larger
                                             // tiles spill to the overflow area and take the device-wide sort)
 
-struct ChunkDesc { // one 2048-column chunk of a streamed read (built on the host at upload)
+static constexpr uint32_t DENSE_COLS = 4096; // columns of a chunk of the dense pass: 64 per lane of a wavefront
+struct ChunkDesc { // one DENSE_COLS-column chunk of a streamed read (built on the host at upload)
     uint64_t nib_off;     // byte offset of the READ's nibble stream
     uint64_t ckbase;      // first checkpoint slot of the read
     uint32_t read, ts;    // read index, aln_t_s
@@ -86,12 +87,15 @@ struct YakDev {
     uint32_t k;
 };
 
-void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t *err);
+// refnib: [0, stride) the contig's codes, position p in nibble p & 1 of byte p >> 1; [stride, 2 stride) and [2 stride,
+// 3 stride) the same codes in the packed streams' own order (even column in the high nibble) for windows that start at an
+// even / odd position (k_diff_reads)
+void launch_encode_ref(hipStream_t s, const uint8_t *read0, uint32_t L, uint8_t *refnib, uint32_t nbytes, uint32_t stride, uint32_t *err);
 void launch_chunk_counts(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, uint64_t *chunk_st, uint32_t epoch);
 void launch_diff_reads(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, const uint64_t *refw,
-                       const uint8_t *refnib, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *tile_cur,
+                       const uint8_t *refnib, const uint8_t *refeo, uint32_t eo_stride, uint32_t L, uint64_t *keys, uint32_t *vals, uint32_t *tile_cur,
                        uint32_t n_tiles, uint32_t bucket_cap, uint64_t ovf_base, uint32_t ovf_cap, uint32_t *ovf_cnt,
-                       uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err);
+                       uint32_t *ckpt, uint64_t *chunk_st, uint32_t epoch, uint32_t *err, uint32_t probe = 0);
 void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox, uint32_t seq, uint32_t *d0 = nullptr,
                  const uint32_t *s0 = nullptr, uint32_t *d1 = nullptr, const uint32_t *s1 = nullptr, uint32_t *d2 = nullptr,
                  const uint32_t *s2 = nullptr, uint32_t *d3 = nullptr, const uint32_t *s3 = nullptr,

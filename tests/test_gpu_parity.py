@@ -103,7 +103,7 @@ def test_hand_made_edge_cases():
 
 def wild_pileup(seed, L=9000, n_reads=36, ins_p=0.03, del_p=0.03, sub_p=0.03, long_ins=True):
     """Random alignments far outside HiFi statistics: dense indels, insertion runs up to 100 columns (crossing the
-    32-column lanes and 2048-column chunks of the dense kernel), N/M letters, reads starting at positions 0..2."""
+    32-column pieces and 4096-column chunks of the dense kernel), N/M letters, reads starting at positions 0..2."""
     rng = np.random.default_rng(seed)
     ref = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
     alns = []
@@ -147,7 +147,7 @@ def test_wild_pileups_all_stages(seed):
 def test_wild_pileup_long_reads_cross_chunks():
     from test_oracle import yak_from_seqs
     ref, pu = wild_pileup(11, L=30000, n_reads=24, ins_p=0.02, del_p=0.01, sub_p=0.01)
-    assert int(pu.reads["n_cols"][1:].max()) > 3 * 2048
+    assert int(pu.reads["n_cols"][1:].max()) > 3 * 4096
     check_all_stages(pu, [yak_from_seqs([ref], 21, count=30)], Opts())
 
 
@@ -183,10 +183,10 @@ def test_long_insertion_overflows_a_tile():
 
 
 def test_very_long_reads_span_many_chunks_and_blocks():
-    # reads of > 64 chunks (131 k columns): the dense pass sums the counts of a read's earlier chunks across several
+    # reads of > 64 chunks (262 k columns): the dense pass sums the counts of a read's earlier chunks across several
     # 64-wide windows of status words and across thread blocks
-    s = Synth(400000, depth=6, seed=91, read_len_mean=180000.0, read_len_sd=20000.0)
-    assert int(s.pileup.reads["n_cols"][1:].max()) > 70 * 2048
+    s = Synth(600000, depth=6, seed=91, read_len_mean=330000.0, read_len_sd=20000.0)
+    assert int(s.pileup.reads["n_cols"][1:].max()) > 70 * 4096
     gb, _ = check_all_stages(s.pileup, [s.yak(21)], Opts())
     assert gb.tobytes() == s.hap1
 
