@@ -271,8 +271,16 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             const uint32_t nck = s_desc[ch - blk_first].nck;
             const uint32_t tsA = (tA + CKPT - 1) & ~(CKPT - 1), tsB = (tB + CKPT - 1) & ~(CKPT - 1);
             if (probe != 2) {
-                if (okA && nA == 32u && (tsA >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsA >> CKPT_SHIFT] = lc0 + (tsA - tA);
-                if (okB && nB == 32u && (tsB >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsB >> CKPT_SHIFT] = lc0 + 32u + (tsB - tB);
+                const bool wA = okA && nA == 32u && (tsA >> CKPT_SHIFT) - (uint32_t)ck_first < nck;
+                const bool wB = okB && nB == 32u && (tsB >> CKPT_SHIFT) - (uint32_t)ck_first < nck;
+                const uint32_t cA = lc0 + (tsA - tA), cB = lc0 + 32u + (tsB - tB);
+                if (wA && wB) { // (nA == 32: tsB == tsA + CKPT, the two slots are neighbours — one 8-byte store, a wave's 512 contiguous bytes)
+                    const uint2 two = make_uint2(cA, cB);
+                    __builtin_memcpy(ckb + (tsA >> CKPT_SHIFT), &two, 8);
+                } else {
+                    if (wA) ckb[tsA >> CKPT_SHIFT] = cA;
+                    if (wB) ckb[tsB >> CKPT_SHIFT] = cB;
+                }
             }
         }
         uint32_t pb = wave_prev_lane(0u, topB);
