@@ -8,6 +8,7 @@
 // 16, fxhash 0.2.1): SwissOrderMap below reproduces that *order* (insert / entry-insert /
 // erase / retain / grow / in-place rehash), not the container's performance.
 #pragma once
+#include <emmintrin.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -76,17 +77,16 @@ template <class V> class SwissOrderMap {
         const uint64_t h = hash(key);
         const uint8_t tag = (uint8_t)(h >> 57);
         size_t pos = (size_t)h & mask_, stride = 0;
-        for (;;) {
-            bool saw_empty = false;
-            for (size_t b = 0; b < kGroup; ++b) {
-                const uint8_t c = ctrl_[pos + b];
-                if (c == tag) {
-                    const size_t i = (pos + b) & mask_;
-                    if (keys_[i] == key && !(ctrl_[i] & 0x80)) return i;
-                }
-                saw_empty |= (c == kEmpty);
+        const __m128i vtag = _mm_set1_epi8((char)tag), vempty = _mm_set1_epi8((char)kEmpty);
+        for (;;) { // (a group of 16 control bytes per step, like hashbrown's own SSE2 group)
+            const __m128i g = _mm_loadu_si128(reinterpret_cast<const __m128i *>(ctrl_.data() + pos));
+            unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(g, vtag));
+            while (m) {
+                const size_t i = (pos + (size_t)__builtin_ctz(m)) & mask_;
+                m &= m - 1;
+                if (keys_[i] == key && !(ctrl_[i] & 0x80)) return i;
             }
-            if (saw_empty) return npos;
+            if (_mm_movemask_epi8(_mm_cmpeq_epi8(g, vempty))) return npos;
             stride += kGroup;
             pos = (pos + stride) & mask_;
         }
@@ -185,14 +185,15 @@ template <class V> class SwissOrderMap {
     size_t probe_free(uint64_t h) const {
         size_t pos = (size_t)h & mask_, stride = 0;
         for (;;) {
-            for (size_t b = 0; b < kGroup; ++b)
-                if (ctrl_[pos + b] & 0x80) {
-                    size_t r = (pos + b) & mask_;
-                    if (!(ctrl_[r] & 0x80)) // tiny table: matched a trailing byte, rescan from 0
-                        for (r = 0; !(ctrl_[r] & 0x80); ++r) {
-                        }
-                    return r;
-                }
+            // (empty and deleted control bytes have their top bit set)
+            const unsigned m = (unsigned)_mm_movemask_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(ctrl_.data() + pos)));
+            if (m) {
+                size_t r = (pos + (size_t)__builtin_ctz(m)) & mask_;
+                if (!(ctrl_[r] & 0x80)) // tiny table: matched a trailing byte, rescan from 0
+                    for (r = 0; !(ctrl_[r] & 0x80); ++r) {
+                    }
+                return r;
+            }
             stride += kGroup;
             pos = (pos + stride) & mask_;
         }
@@ -616,55 +617,130 @@ class SignedLouvain {
         // The reference re-evaluates every node in every sweep until a sweep moves nothing.  A node's decision is a
         // pure function of its neighbours' community ids, so a node none of whose neighbours moved since its last
         // evaluation cannot move: only "dirty" nodes are evaluated (same visit order, identical outcome).
+        //
+        // Sweeps after the first one of a large graph move next to nothing (a chromosome's read graph: 272 k nodes evaluated,
+        // 60 moved), but every node is dirty, because all of its neighbours moved in the first sweep.  Such a sweep is
+        // evaluated AHEAD, on all threads, against the state the sweep starts from; the sweep itself then walks the nodes
+        // in order and takes a node's pre-computed decision unless one of its neighbours has moved earlier in this very
+        // sweep — then, and for nodes that became dirty during the sweep, the decision is computed on the spot as before.
+        // A pre-computed decision saw exactly the neighbour communities the serial sweep would show it, so it is the same.
         bool moved_any = false;
-        std::vector<uint32_t> visit = g_.keys.key_list();
-        std::sort(visit.begin(), visit.end());
+        std::vector<uint32_t> visit; // the keys in ascending order (louvain.rs:77: sorted): a scan of the dense mirror
+        visit.reserve(g_.keys.size());
+        for (uint32_t v = 0; v < g_.n_ids(); ++v)
+            if (g_.has_key(v)) visit.push_back(v);
         std::vector<uint8_t> dirty(g_.n_ids(), 1);
         // gains per neighbouring community: a slot per community id, valid for the node whose stamp it carries (in the
         // first sweep every neighbour is a community of its own: a list searched per edge was quadratic in the degree)
         std::vector<float> acc(g_.n_ids(), 0.f);
         std::vector<uint32_t> stamp(g_.n_ids(), 0u), touched;
         uint32_t tick = 0;
+        // decision of v against the current state: the community it moves to, or its own
+        auto decide = [&](uint32_t v) -> uint32_t {
+            const uint32_t cur = node_id_[v];
+            touched.clear();
+            if (++tick == 0) { // (the stamps wrapped: start over)
+                std::fill(stamp.begin(), stamp.end(), 0u);
+                tick = 1;
+            }
+            for (const auto &e : g_.adj(v)) {
+                const uint32_t c = node_id_[e.first];
+                if (stamp[c] != tick) {
+                    stamp[c] = tick;
+                    acc[c] = e.second;
+                    touched.push_back(c);
+                } else {
+                    acc[c] += e.second; // (edge order, like the list it replaces)
+                }
+            }
+            if (touched.empty()) return cur;
+            uint32_t bc = touched[0]; // max weight, ties -> smaller community id (louvain.rs:99-101)
+            float bw = acc[bc];
+            for (size_t i = 1; i < touched.size(); ++i) {
+                const uint32_t c = touched[i];
+                if (acc[c] > bw || (acc[c] == bw && c < bc)) bc = c, bw = acc[c];
+            }
+            return bw > 0.f ? bc : cur;
+        };
+        static constexpr uint32_t NO_GUESS = 0xFFFFFFFFu;
+        std::vector<uint32_t> ahead;      // pre-computed decisions of this sweep (NO_GUESS: none)
+        std::vector<uint32_t> stale;      // sweep in which a neighbour of the node last moved (0: never)
+        uint32_t sweep = 0;
+        size_t last_moved = 0;
+        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+        static const bool no_ahead = getenv("NP2_VOTE_NO_AHEAD") != nullptr; // (A/B and tests)
+        static const size_t ahead_min = getenv("NP2_VOTE_AHEAD_MIN") ? (size_t)atol(getenv("NP2_VOTE_AHEAD_MIN")) : (size_t)1 << 15; // (tests: small graphs too)
         for (bool again = true; again;) {
             again = false;
+            ++sweep;
+            size_t n_eval = 0, n_moved = 0, n_taken = 0;
+            const auto t_sw = std::chrono::steady_clock::now();
+            const bool use_ahead = !no_ahead && sweep > 1 && visit.size() >= ahead_min && last_moved >= ahead_min / 64 && host_threads() > 1; // (many moves in the last sweep: many dirty nodes now)
+            if (use_ahead) {
+                ahead.assign(g_.n_ids(), NO_GUESS);
+                if (stale.empty()) stale.assign(g_.n_ids(), 0u);
+                parallel_ranges(visit.size(), 4096, [&](unsigned, size_t lo, size_t hi) {
+                    std::vector<std::pair<uint32_t, float>> local; // (a node's neighbours lie in a handful of communities by now)
+                    for (size_t i = lo; i < hi; ++i) {
+                        const uint32_t v = visit[i];
+                        if (!dirty[v]) continue;
+                        local.clear();
+                        bool give_up = false;
+                        for (const auto &e : g_.adj(v)) {
+                            const uint32_t c = node_id_[e.first];
+                            bool hit = false;
+                            for (auto &l : local)
+                                if (l.first == c) {
+                                    l.second += e.second; // (exact small-integer sums: the order does not matter)
+                                    hit = true;
+                                    break;
+                                }
+                            if (!hit) {
+                                if (local.size() >= 48) {
+                                    give_up = true;
+                                    break;
+                                }
+                                local.emplace_back(c, e.second);
+                            }
+                        }
+                        if (give_up) continue;
+                        uint32_t to = node_id_[v];
+                        if (!local.empty()) {
+                            uint32_t bc = local[0].first;
+                            float bw = local[0].second;
+                            for (size_t k = 1; k < local.size(); ++k)
+                                if (local[k].second > bw || (local[k].second == bw && local[k].first < bc)) bc = local[k].first, bw = local[k].second;
+                            if (bw > 0.f) to = bc;
+                        }
+                        ahead[v] = to;
+                    }
+                });
+            }
             for (uint32_t v : visit) {
                 if (!dirty[v]) continue;
                 dirty[v] = 0;
+                ++n_eval;
                 const uint32_t cur = node_id_[v];
-                touched.clear();
-                if (++tick == 0) { // (the stamps wrapped: start over)
-                    std::fill(stamp.begin(), stamp.end(), 0u);
-                    tick = 1;
-                }
-                for (const auto &e : g_.adj(v)) {
-                    const uint32_t c = node_id_[e.first];
-                    if (stamp[c] != tick) {
-                        stamp[c] = tick;
-                        acc[c] = e.second;
-                        touched.push_back(c);
-                    } else {
-                        acc[c] += e.second; // (edge order, like the list it replaces)
-                    }
-                }
-                if (touched.empty()) continue;
-                uint32_t bc = touched[0]; // max weight, ties -> smaller community id (louvain.rs:99-101)
-                float bw = acc[bc];
-                for (size_t i = 1; i < touched.size(); ++i) {
-                    const uint32_t c = touched[i];
-                    if (acc[c] > bw || (acc[c] == bw && c < bc)) bc = c, bw = acc[c];
-                }
-                if (bw > 0.f && bc != cur) {
-                    const uint32_t to = bc;
+                uint32_t to;
+                const bool fresh = use_ahead && ahead[v] != NO_GUESS && stale[v] != sweep; // (stale: a neighbour moved earlier in this sweep)
+                if (fresh) to = ahead[v], ++n_taken;
+                else to = decide(v);
+                if (to != cur) {
                     node_id_[v] = to;
                     ++cnt_[to];
                     --cnt_[cur];
                     oplog_.emplace_back(to, (int64_t)v + 1);
                     oplog_.emplace_back(cur, -((int64_t)v + 1));
                     for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
+                    if (use_ahead)
+                        for (const auto &e : g_.adj(v)) stale[e.first] = sweep;
                     again = true;
                     moved_any = true;
+                    ++n_moved;
                 }
             }
+            last_moved = n_moved;
+            if (prof) fprintf(stderr, "    sweep: %zu evaluated (%zu decided ahead), %zu moved, %.2f ms\n", n_eval, n_taken, n_moved, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sw).count());
         }
         return moved_any;
     }
@@ -721,26 +797,32 @@ class SignedLouvain {
         // partial sums in double: every term is a multiple of 0.5 below 2^22 in magnitude, so a double holds any partial
         // and any total exactly whatever the order (a float partial beyond 2^23 would drop the halves even when the
         // community's total is small again); a total within the float-exact range equals the reference's member-order sum
+        // (the live communities numbered densely: after the first sweep of a chromosome's graph they are a few hundred among
+        // 6 x 10^5 ids — a partial array over all ids per thread was most of this step)
+        std::vector<uint32_t> dense(n, 0xFFFFFFFFu), live;
+        for (uint32_t id = 0; id < n; ++id)
+            if (cnt_[id]) dense[id] = (uint32_t)live.size(), live.push_back(id);
+        const size_t nc = live.size();
         std::vector<std::vector<double>> part(host_threads());
         parallel_ranges(n, 4096, [&](unsigned t, size_t lo, size_t hi) {
             std::vector<double> &p = part[t];
-            p.assign(n, 0.0);
+            p.assign(nc, 0.0);
             for (size_t v = lo; v < hi; ++v) {
                 if (!g_.has_key((uint32_t)v)) continue;
                 const uint32_t cid = node_id_[v];
                 double acc = node_w_[v];
                 for (const auto &e : g_.adj((uint32_t)v))
                     if (node_id_[e.first] == cid) acc += (double)e.second / 2.0;
-                p[cid] += acc;
+                p[dense[cid]] += acc;
             }
         });
-        std::vector<double> wd(n, 0.0);
+        std::vector<double> wd(nc, 0.0);
         for (const auto &p : part)
             if (!p.empty())
-                for (size_t id = 0; id < n; ++id) wd[id] += p[id];
-        for (uint32_t id = 0; id < n; ++id) {
-            if (!cnt_[id]) continue;
-            if (wd[id] > -4194304.0 && wd[id] < 4194304.0) w[id] = (float)wd[id];
+                for (size_t i = 0; i < nc; ++i) wd[i] += p[i];
+        for (size_t i = 0; i < nc; ++i) {
+            const uint32_t id = live[i];
+            if (wd[i] > -4194304.0 && wd[i] < 4194304.0) w[id] = (float)wd[i];
             else w[id] = weight_only(id, mlist.data() + moff[id], mlist.data() + moff[id + 1]);
         }
         return w;
@@ -947,10 +1029,22 @@ class SignedLouvain {
 // ref_w / ref_seen: the reference haplotype's row (ref_data[0]), indexed by read id; have_ref = row exists
 inline bool losing_reads(Graph graph, bool have_ref, const std::vector<float> &ref_w,
                          const std::vector<uint8_t> &ref_seen, std::vector<uint32_t> &losers) {
+    const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_m = now();
+    auto mark = [&](const char *what) {
+        if (prof) {
+            const double t = now();
+            fprintf(stderr, "  losing_reads: %s %.2f ms\n", what, t - t_m);
+            t_m = t;
+        }
+    };
     SignedLouvain lv(std::move(graph));
+    mark("first-level state");
     std::unordered_map<uint32_t, std::unordered_set<uint32_t>> conflicts;
     std::vector<Community> comms;
     if (!lv.run(conflicts, comms)) return false;
+    mark("levels");
     if (have_ref) {
         std::vector<std::pair<int32_t, float>> key(comms.size());
         for (size_t i = 0; i < comms.size(); ++i) {
@@ -984,6 +1078,7 @@ inline bool losing_reads(Graph graph, bool have_ref, const std::vector<float> &r
     }
     for (const Community &c : comms)
         if (lost.count(c.id)) losers.insert(losers.end(), c.members.begin(), c.members.end());
+    mark("ranking");
     return true;
 }
 

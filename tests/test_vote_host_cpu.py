@@ -46,3 +46,42 @@ def test_one_thread_and_many_agree():
         outs.append(int(r.stdout.strip()))
     import zlib
     assert set(outs) == {zlib.crc32(load()[2].tobytes())}  # == the oracle's decision, whatever the thread count and the form
+
+
+def test_sweeps_decided_ahead_on_all_threads_change_nothing():
+    """SignedLouvain::local_moving (csrc/np2_phase_host.hpp, louvain.rs:72-117): from the second sweep on a large graph's
+    decisions are computed ahead on all threads and taken unless a neighbour moved earlier in the same sweep.  The recorded
+    vote tiled three times along a contig (110 k reads: large enough for that path) and random signed graphs with the
+    threshold lowered to nothing must be decided exactly as with the plain serial sweeps (NP2_VOTE_NO_AHEAD)."""
+    code = ("import sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_vote_host_cpu import load\n"
+            "from test_shard_cpu import _random_votes, _vote\n"
+            "from nextpolish2_amd.api import Vote, vote_decide\n"
+            "from nextpolish2_amd import Opts\n"
+            "v0, R0, _ = load()\n"
+            "span = int(v0.first_pos.max()) + 100000\n"
+            "ks, cs, ids, fp, rw, fl = [], [], [], [], [], []\n"
+            "for c in range(3):\n"
+            "    sh = np.uint64(c * (R0 - 1))\n"
+            "    ks.append(v0.pair_key + ((sh << np.uint64(32)) | sh)); cs.append(v0.pair_cnt)\n"
+            "    ids.append(v0.read_id + np.uint32(c * (R0 - 1))); fp.append(v0.first_pos + np.uint32(c * span))\n"
+            "    rw.append(v0.ref_w); fl.append(v0.flags)\n"
+            "v = Vote(pair_key=np.concatenate(ks), pair_cnt=np.concatenate(cs), read_id=np.concatenate(ids),\n"
+            "         first_pos=np.concatenate(fp), ref_w=np.concatenate(rw), flags=np.concatenate(fl))\n"
+            "crc = zlib.crc32(vote_decide([v], 1 + 3 * (R0 - 1)).tobytes())\n"
+            "rng = np.random.default_rng(5)\n"
+            "for t in range(60):\n"
+            "    n_reads = int(rng.integers(12, 60))\n"
+            "    m = min(n_reads - 1, 40)\n"
+            "    reads, pairs, first, refw, bad = _random_votes(rng, n_reads, int(rng.integers(5, m * (m - 1) // 4)))\n"
+            "    for use_all in (False, True):\n"
+            "        got = vote_decide([_vote(reads.tolist(), pairs, first, refw, bad, set(refw))], n_reads, Opts(use_all_reads=use_all))\n"
+            "        crc = zlib.crc32(got.tobytes(), crc)\n"
+            "print(crc)\n" % (ROOT, HERE))
+    outs = []
+    for extra in ({"NP2_VOTE_NO_AHEAD": "1"}, {"NP2_VOTE_AHEAD_MIN": "1"}, {"NP2_VOTE_AHEAD_MIN": "1", "NP2_VOTE_THREADS": "3"}, {}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, **({"NP2_VOTE_THREADS": "8"} | extra)), timeout=900)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(int(r.stdout.strip()))
+    assert len(set(outs)) == 1, outs
