@@ -958,6 +958,12 @@ class SignedLouvain {
         }
         ng.end_rows();
         mark("new graph");
+        if (g_.edges.size() >= (1u << 22)) {
+            // (freeing a chromosome's first-level graph — 150 MB of edges going back to the kernel page by page — took as
+            // long as a sweep over it: a helper thread drops it)
+            auto old = std::make_shared<Graph>(std::move(g_));
+            std::thread([old]() mutable { old.reset(); }).detach();
+        }
         g_ = std::move(ng);
         comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);
