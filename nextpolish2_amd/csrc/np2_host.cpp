@@ -1772,82 +1772,6 @@ void np2_ctx_set_timing(np2_ctx_t *cx, int enable) {
     if (cx) cx->stage_timing = enable != 0;
 }
 
-namespace np2h {
-// Host buffer of a caller (pageable memory) -> HBM.  hipMemcpyAsync stages such a copy through the runtime's own bounce
-// buffers on the calling thread: 11-16 GB/s measured on a link that gives a pinned copy 54 (tools/ubench_h2d.hip).  Here the
-// buffer goes in pieces through a ring of pinned blocks filled by a few threads at once — a thread copies a piece into its
-// slot and queues the slot's DMA itself, so the host copies of the next pieces run under the DMA of the earlier ones.
-// Returns with every piece queued on `s` (or on the helper stream `s` waits for) and every host read done.
-void upload_pageable(np2_ctx *cx, void *dst, const void *src, size_t bytes) {
-    static const size_t piece = [] {
-        const char *e = getenv("NP2_H2D_PIECE_MIB");
-        return (size_t)std::max(1, e ? atoi(e) : 8) << 20;
-    }();
-    static const unsigned max_threads = [] {
-        const char *e = getenv("NP2_H2D_THREADS");
-        return (unsigned)std::max(1, e ? atoi(e) : (int)std::min(4u, std::max(1u, usable_cpus() / std::max(1u, local_ranks()) / 2)));
-    }();
-    hipStream_t s = cx->stream;
-    const size_t n_pieces = (bytes + piece - 1) / piece;
-    if (n_pieces < 3 || max_threads < 2) { // small: not worth threads
-        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
-        return;
-    }
-    const unsigned T = (unsigned)std::min<size_t>(max_threads, n_pieces);
-    const unsigned n_slots = 2 * T;
-    struct Slot {
-        void *p = nullptr;
-        hipEvent_t ev = nullptr;
-        bool used = false;
-    };
-    std::vector<Slot> slots(n_slots);
-    std::atomic<size_t> next{0};
-    std::vector<std::string> errs(T);
-    auto release = [&] {
-        for (auto &sl : slots) {
-            if (sl.ev) (void)hipEventSynchronize(sl.ev), (void)hipEventDestroy(sl.ev);
-            if (sl.p) pinned_pool().put(sl.p);
-        }
-    };
-    for (auto &sl : slots) {
-        sl.p = pinned_pool().get(piece);
-        if (!sl.p || hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
-            release();
-            throw Np2Error(NP2_E_NOMEM, "pinned staging for the upload");
-        }
-    }
-    auto work = [&](unsigned t) {
-        if (hipSetDevice(cx->device) != hipSuccess) {
-            errs[t] = "hipSetDevice";
-            return;
-        }
-        for (unsigned round = 0;; ++round) { // (thread t owns slots t and T + t, taken in turn)
-            const size_t i = next.fetch_add(1);
-            if (i >= n_pieces) return;
-            Slot &sl = slots[t + T * (round & 1)];
-            if (sl.used && hipEventSynchronize(sl.ev) != hipSuccess) { // the slot's last DMA has read it
-                errs[t] = "hipEventSynchronize";
-                return;
-            }
-            const size_t off = i * piece, n = std::min(piece, bytes - off);
-            memcpy(sl.p, (const uint8_t *)src + off, n);
-            if (hipMemcpyAsync((uint8_t *)dst + off, sl.p, n, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(sl.ev, s) != hipSuccess) {
-                errs[t] = "hipMemcpyAsync";
-                return;
-            }
-            sl.used = true;
-        }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    release(); // (waits for the slots' DMAs: the blocks go back to the pool)
-    for (auto &e : errs)
-        if (!e.empty()) throw Np2Error(NP2_E_NOMEM, "upload: " + e + " failed");
-}
-} // namespace np2h
-
 int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_read_t *reads, uint32_t n_reads,
                       const uint8_t *nibbles, uint64_t nib_bytes, np2_contig_t **out) {
     if (!cx || !out) return NP2_E_ARG;
@@ -1858,7 +1782,9 @@ int np2_contig_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_r
         HIPCHK(hipSetDevice(cx->device));
         if (L < 3 || n_reads < 1 || !reads || !nibbles) throw Np2Error(NP2_E_ARG, "bad contig arguments");
         c->nib.ensure(nib_bytes + 64);
-        upload_pageable(cx, c->nib.p, nibbles, nib_bytes);
+        // (the caller's pageable buffer in one call: the runtime locks its pages and copies at the link's rate — 56 GB/s for
+        // 32 MiB and more, tools/ubench_h2d.hip; a ring of pinned blocks filled by helper threads measured 38-51)
+        HIPCHK(hipMemcpyAsync(c->nib.p, nibbles, nib_bytes, hipMemcpyHostToDevice, cx->stream));
         finish_contig(cx, c, reads, n_reads, L, nib_bytes);
     } catch (const Np2Error &e) {
         (void)hipStreamSynchronize(cx->stream); // (the nibble upload may still be in flight: the blocks go back to the cache)

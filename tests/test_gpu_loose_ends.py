@@ -203,3 +203,32 @@ def test_dense_pass_with_its_chunk_counts_from_a_pre_pass(env):
                        timeout=600, cwd=root, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout.decode().strip().splitlines()[-1].startswith("cases 25 bad 0"), r.stdout.decode()[-2000:]
+
+
+def test_dense_passes_of_two_streams_of_one_process_side_by_side():
+    """k_diff_reads' chunks wait for the status words of lower-numbered blocks of the SAME launch (csrc/np2_dense.hip,
+    np2_lookback.hpp): safe because the blocks of a launch are dispatched in index order, so whatever a resident block waits
+    for is resident or finished — also when a second stream of the same process keeps the device filled with its own
+    blocks (queues of one process are not preempted by draining; two PROCESSES on one device take the pre-counted path, test
+    above).  Two contexts polish contigs with reads of many chunks at the same time, over and over; every result is the
+    oracle's."""
+    ss = [Synth(700000, depth=30, seed=951 + i, diploid=bool(i), read_len_mean=40000.0, read_len_sd=6000.0) for i in range(2)]
+    yaks = [[s.yak(21)] for s in ss]
+    want = [orc.Oracle(y).polish(s.pileup, Opts())[0] for s, y in zip(ss, yaks)]
+    bad = []
+
+    def work(i):
+        g = Polisher(yaks[i])
+        c = g.upload(ss[i].pileup)
+        for _ in range(6):
+            b, _ = g.polish_resident(c, Opts(), want_pos=False)
+            if not np.array_equal(b, want[i]):
+                bad.append(i)
+        c.free()
+        g.close()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad

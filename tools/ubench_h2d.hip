@@ -1,6 +1,7 @@
 // Host -> device transfer rate of a caller's PAGEABLE buffer (what np2_contig_upload is handed) on gfx950: one
-// hipMemcpyAsync (the runtime's own bounce buffers), the same buffer pinned, and the scheme of csrc/np2_host.cpp's
-// upload_pageable — pieces copied by T threads into a ring of pinned blocks, every thread queueing its slot's DMA itself.
+// hipMemcpyAsync (the runtime locks the pages and copies in place), the same buffer pinned, and a hand-made pipeline —
+// pieces copied by T threads into a ring of pinned blocks, every thread queueing its slot's DMA itself (built as
+// upload_pageable in round 5, measured here slower than the plain call, and taken out again).
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_h2d.hip -o tools/bin/ubench_h2d -lpthread ; tools/bin/ubench_h2d
 #include <hip/hip_runtime.h>
 #include <atomic>
