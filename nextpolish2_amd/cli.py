@@ -220,7 +220,7 @@ def main(argv=None):
     for y in a.yak:  # (before the output file exists: a broken dump must not leave a partial output behind)
         try:
             np2io.check_yak_header(y)
-        except ValueError as e:
+        except (ValueError, OSError) as e:  # (a malformed dump, or one that cannot be read at all)
             raise SystemExit(f"Error: {e}")
     out = sys.stdout.buffer
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ

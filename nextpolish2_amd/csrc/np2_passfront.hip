@@ -248,20 +248,33 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         for (uint32_t j = 0; j < RPT; ++j) {
             const uint32_t i = tid + 256 * j;
             isn[j] = false, gcv[j] = 0, gmv[j] = 0xFFFFFFFFu, kown[j] = 0;
-            if (i < nt) {
-                const uint64_t k = s_k[i];
-                kown[j] = k;
-                if (i == 0 || s_k[i - 1] != k) {
-                    uint32_t gc = 0, gm = 0xFFFFFFFFu;
-                    for (uint32_t jj = i; jj < nt && s_k[jj] == k; ++jj) {
-                        const uint32_t v = s_v[jj];
-                        if (v >> 31) {
+            // A group = the records of one key, neighbours in the sorted list, ascending in read number inside the group
+            // (k_tile_sort ranks by (key, read)).  The wavefront's 64 records of this round are consecutive, so a group head
+            // counts its live members from two ballots — heads and live records — and takes its first live read from the
+            // lane that holds it; only a group that runs past the wavefront's last record is walked, from there on.
+            const bool in = i < nt;
+            const uint64_t k = in ? s_k[i] : 0ull;
+            const uint32_t v = in ? s_v[i] : 0u;
+            kown[j] = k;
+            const bool head = in && (i == 0 || s_k[i - 1] != k);
+            const uint64_t hm = __ballot(head), lm = __ballot(in && (v >> 31));
+            const uint64_t above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1ull); // heads after this lane
+            const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;       // first lane past the group (64: none in sight)
+            const uint64_t run = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+            const uint64_t lrun = lm & run;
+            // (every lane takes part in the cross-lane read; the source lane is only meaningful for heads with a live member)
+            const uint32_t firstv = (uint32_t)__shfl((int)v, lrun ? (int)__builtin_ctzll(lrun) : (int)lane);
+            if (head) {
+                uint32_t gc = (uint32_t)__builtin_popcountll(lrun), gm = lrun ? (firstv & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+                if (end == 64u)
+                    for (uint32_t jj = i + (64u - lane); jj < nt && s_k[jj] == k; ++jj) { // (the group goes on in the next wavefront's records)
+                        const uint32_t vv = s_v[jj];
+                        if (vv >> 31) {
                             ++gc;
-                            gm = min(gm, v & 0x7FFFFFFFu);
+                            gm = min(gm, vv & 0x7FFFFFFFu);
                         }
                     }
-                    isn[j] = gc != 0, gcv[j] = gc, gmv[j] = gm;
-                }
+                isn[j] = gc != 0, gcv[j] = gc, gmv[j] = gm;
             }
             const uint64_t bal = __ballot(isn[j]);
             lr[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));

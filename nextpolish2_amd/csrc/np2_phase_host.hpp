@@ -302,6 +302,24 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
         ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
     }
 };
+// f(t) on T threads (the caller's takes t = 0); an exception in any of them — bad_alloc from a per-thread array — is carried
+// to the caller's thread instead of ending the process
+template <class F> void parallel_each(size_t T, F f) {
+    std::vector<std::exception_ptr> err(T);
+    auto guarded = [&](size_t t) {
+        try {
+            f(t);
+        } catch (...) {
+            err[t] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { guarded(t); });
+    guarded(0);
+    for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
 struct Graph {
     typedef std::pair<uint32_t, float> Edge;
     // row iteration helper
@@ -432,22 +450,12 @@ struct Graph {
                 }
             }
         };
-        {
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, false); });
-            scan(0, false);
-            for (auto &x : th) x.join();
-        }
+        parallel_each(T, [&](size_t t) { scan(t, false); });
         const double t2 = now();
         for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v] + n_lo[v];
         edges.resize(off[N]);
         const double t3 = now();
-        {
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, true); });
-            scan(0, true);
-            for (auto &x : th) x.join();
-        }
+        parallel_each(T, [&](size_t t) { scan(t, true); });
         if (prof) fprintf(stderr, "    rows: check %.2f ms, count %.2f ms, offsets + allocation %.2f ms, fill %.2f ms (%zu threads, largest b - a %u)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, T, maxgap);
         return true;
     }
@@ -502,12 +510,7 @@ struct Graph {
                 }
             }
         };
-        auto run = [&](bool fill) {
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { scan(t, fill); });
-            scan(0, fill);
-            for (auto &x : th) x.join();
-        };
+        auto run = [&](bool fill) { parallel_each(T, [&](size_t t) { scan(t, fill); }); };
         run(false);
         for (uint8_t b : bad_t)
             if (b) return false;
