@@ -64,7 +64,25 @@ __device__ __forceinline__ uint32_t dense_native_below(uint32_t nv, uint32_t k) 
 }
 static constexpr uint32_t NF3W = 0x88888888u;
 
-// Phase 1 works on the stream as it lies in memory: 64 columns = two 16-byte pieces per lane, compared with a copy of the
+// non-insertion columns of one chunk, by one wavefront (uniform result)
+__device__ __forceinline__ uint32_t dense_chunk_total(const ChunkDesc *__restrict__ dp, const uint8_t *__restrict__ nib, uint32_t lane) {
+    const uint32_t c0 = dp->c0, ncols = dp->ncols;
+    const uint32_t lc0 = c0 + lane * 64;
+    const uint32_t nv = lc0 < ncols ? min(64u, ncols - lc0) : 0u;
+    const uint32_t nvA = min(nv, 32u), nvB = nv - nvA;
+    dense_u32x4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
+    const uint8_t *p = nib + dp->nib_off + (lc0 >> 1);
+    if (nvA) a = *reinterpret_cast<const dense_u32x4 *>(p);
+    if (nvB) b = *reinterpret_cast<const dense_u32x4 *>(p + 16);
+    if (c0 == 0 && lane == 0) a.x &= ~0x80u; // column 0 is never an insertion column (main.rs:325,332-335)
+    const uint32_t ins = (uint32_t)__builtin_popcount(a.x & NF3W & dense_native_below(nvA, 0)) + (uint32_t)__builtin_popcount(a.y & NF3W & dense_native_below(nvA, 1)) +
+                         (uint32_t)__builtin_popcount(a.z & NF3W & dense_native_below(nvA, 2)) + (uint32_t)__builtin_popcount(a.w & NF3W & dense_native_below(nvA, 3)) +
+                         (uint32_t)__builtin_popcount(b.x & NF3W & dense_native_below(nvB, 0)) + (uint32_t)__builtin_popcount(b.y & NF3W & dense_native_below(nvB, 1)) +
+                         (uint32_t)__builtin_popcount(b.z & NF3W & dense_native_below(nvB, 2)) + (uint32_t)__builtin_popcount(b.w & NF3W & dense_native_below(nvB, 3));
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(nv - ins), 63);
+}
+
+// Phase 1 works on the stream as it lies in memory: 64 columns = two 16-byte pieces per lane (pieces l and 64 + l of the chunk), compared with a copy of the
 // contig in the SAME nibble order (k_encode_ref writes two: codes 2k | 2k+1 per byte for an even first position, 2k+1 |
 // 2k+2 for an odd one), so that "this piece agrees with the contig" is four XORs and two ORs per piece, with no nibble
 // swap, no alignment shifts and no column masks; one wave scan serves both pieces of a lane.
@@ -76,14 +94,26 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     // (probe != 0: a timing experiment — tools/dense_probe.sh — that stops after a part of the kernel; launched after the
     // real pass, it rewrites what that one wrote and nothing else)
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t pw = __builtin_amdgcn_readfirstlane(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // Which chunks a block takes: workgroups go round the 8 XCDs in turn, each with an L2 of its own, and the reads lie
+    // in contig order — taken in launch order every XCD would pull the whole contig (three copies of it) through its L2 and
+    // every tile's bucket would be written through all eight.  Block b takes the (b / 8)-th block of chunks of the
+    // (b % 8)-th eighth of the list instead: an XCD works on one stretch of the contig.  Inside an eighth the order is the
+    // launch order, so a chunk still only waits for blocks dispatched before its own (np2_lookback.hpp); the counts of a
+    // read's chunks that lie in the eighth BEFORE — a handful of chunks per launch — are not waited for but counted again.
+    uint32_t lb = np2_bid, x_first = 0; // this block's place in the list, the first block of its eighth
+    if (np2_nb >= 64) {
+        const uint32_t xq = np2_nb >> 3, xr = np2_nb & 7u, xcd = np2_bid & 7u;
+        x_first = xcd * xq + min(xcd, xr);
+        lb = x_first + (np2_bid >> 3);
+    }
+    const uint32_t pw = __builtin_amdgcn_readfirstlane(lb * (blockDim.x >> 6) + (threadIdx.x >> 6));
     __shared__ uint32_t s_total[DENSE_CHUNKS];        // non-insertion columns of the block's chunks
     __shared__ uint2 s_q[DENSE_CHUNKS * DENSE_HALVES]; // dirty pieces: {t0, chunk in block << 7 | piece}
     __shared__ __attribute__((aligned(16))) DenseChunk s_desc[DENSE_CHUNKS];
     __shared__ uint32_t s_nq;
     __shared__ uint32_t s_tile[DENSE_TSLOTS], s_cnt[DENSE_TSLOTS], s_base[DENSE_TSLOTS], s_off[DENSE_TSLOTS + 1]; // phase 2: the tiles the block adds records to
     __shared__ uint2 s_stage[DENSE_STAGE];            // phase 2: records of a round, grouped by tile: {t_pos, piece | column << 10 | tile slot << 15}
-    const uint32_t blk_first = np2_bid * DENSE_CHUNKS;
+    const uint32_t blk_first = lb * DENSE_CHUNKS;
     if (threadIdx.x == 0) s_nq = 0;
 #ifdef NP2_DENSE_PAD_LDS // (occupancy experiment: fewer resident blocks per CU)
     __shared__ uint32_t s_pad[NP2_DENSE_PAD_LDS / 4];
@@ -121,21 +151,24 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     // ---- phase A: load the chunks, count their non-insertion columns and publish the counts at once.  A chunk needs
     //      the counts of the read's earlier chunks (status word: launch epoch | count); they belong to lower-numbered,
     //      already running waves, which publish within a microsecond of starting ---------------------------------------
+    // A lane holds pieces `lane` and 64 + `lane` of its chunk (each of the two loads of a wavefront is 1 KiB of consecutive
+    // bytes); positions run through pieces 0 .. 127, so the lane's two counts are scanned side by side in one word.
     dense_u32x4 va_[DENSE_CPW], vb_[DENSE_CPW];
-    uint32_t nv_[DENSE_CPW], nA_[DENSE_CPW], nB_[DENSE_CPW], incl_[DENSE_CPW], total_[DENSE_CPW];
+    uint32_t nvA_[DENSE_CPW], nvB_[DENSE_CPW], nA_[DENSE_CPW], nB_[DENSE_CPW], exA_[DENSE_CPW], exB_[DENSE_CPW], total_[DENSE_CPW];
     bool full_[DENSE_CPW];
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) { // (all loads first)
-        const uint32_t lc0 = dd[it].c0 + lane * 64;
-        const bool full = dd[it].live && dd[it].ncols - dd[it].c0 >= DENSE_COLS; // every lane of the wave holds 64 columns
+        const uint32_t lcA = dd[it].c0 + lane * 32, lcB = lcA + DENSE_COLS / 2;
+        const bool full = dd[it].live && dd[it].ncols - dd[it].c0 >= DENSE_COLS; // every piece of the chunk holds 32 columns
         full_[it] = full;
-        nv_[it] = !dd[it].live ? 0u : (full ? 64u : (lc0 < dd[it].ncols ? min(64u, dd[it].ncols - lc0) : 0u));
-        // (unconditional loads, all in flight together: a lane past the read's end reads the stream's last bytes — 16 bytes
+        nvA_[it] = !dd[it].live ? 0u : (full ? 32u : (lcA < dd[it].ncols ? min(32u, dd[it].ncols - lcA) : 0u));
+        nvB_[it] = !dd[it].live ? 0u : (full ? 32u : (lcB < dd[it].ncols ? min(32u, dd[it].ncols - lcB) : 0u));
+        // (unconditional loads, all in flight together: a piece past the read's end reads the stream's last bytes — 16 bytes
         // of padding follow every stream — and what it gets is masked by its column count)
         const uint32_t last = (max(dd[it].ncols, 1u) - 1u) >> 1;
         const uint8_t *p = nib + dd[it].nib_off;
-        va_[it] = dense_load16u(p + min(lc0 >> 1, last));
-        vb_[it] = dense_load16u(p + min((lc0 >> 1) + 16u, last));
+        va_[it] = dense_load16u(p + min(lcA >> 1, last));
+        vb_[it] = dense_load16u(p + min(lcB >> 1, last));
     }
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
@@ -147,8 +180,8 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         uint32_t iB = (uint32_t)__builtin_popcount(b.x & NF3W) + (uint32_t)__builtin_popcount(b.y & NF3W) +
                       (uint32_t)__builtin_popcount(b.z & NF3W) + (uint32_t)__builtin_popcount(b.w & NF3W);
         uint32_t nA = 32u - iA, nB = 32u - iB;
-        if (!full_[it]) { // (uniform) the read ends in this chunk: one lane holds a partial piece, the lanes after it none
-            const uint32_t nv = nv_[it], nvA = min(nv, 32u), nvB = nv - nvA;
+        if (!full_[it]) { // (uniform) the read ends in this chunk: one piece is partial, the pieces after it hold nothing
+            const uint32_t nvA = nvA_[it], nvB = nvB_[it];
             if (nvA != 32u) {
                 iA = nvA ? (uint32_t)__builtin_popcount(a.x & NF3W & dense_native_below(nvA, 0)) + (uint32_t)__builtin_popcount(a.y & NF3W & dense_native_below(nvA, 1)) +
                                (uint32_t)__builtin_popcount(a.z & NF3W & dense_native_below(nvA, 2)) + (uint32_t)__builtin_popcount(a.w & NF3W & dense_native_below(nvA, 3))
@@ -162,13 +195,15 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 nB = nvB - iB;
             }
         }
-        const uint32_t incl = wave_incl_scan<OpAdd>(nA + nB);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t incl = wave_incl_scan<OpAdd>(nA | (nB << 16)); // (64 x 32 < 2^16: the halves do not meet)
+        const uint32_t tot2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t totA = tot2 & 0xFFFFu, total = totA + (tot2 >> 16);
         if (lane == 0 && dd[it].live) {
             __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_total[ch - blk_first] = total;
         }
-        nA_[it] = nA, nB_[it] = nB, incl_[it] = incl, total_[it] = total;
+        nA_[it] = nA, nB_[it] = nB, total_[it] = total;
+        exA_[it] = (incl & 0xFFFFu) - nA, exB_[it] = totA + (incl >> 16) - nB; // non-insertion columns of the chunk before the piece
     }
     if (probe == 1) return;
     __syncthreads();
@@ -201,7 +236,9 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
                 }
             }
             const uint32_t jend = min(ch, blk_first);
-            for (uint32_t j0 = dd[it].first_chunk; j0 < jend; j0 += 64) {
+            const uint32_t jown = min(jend, max(dd[it].first_chunk, x_first * DENSE_CHUNKS)); // chunks before it: another XCD's
+            for (uint32_t j = dd[it].first_chunk; j < jown; ++j) carryN += dense_chunk_total(descs + j, nib, lane);
+            for (uint32_t j0 = jown; j0 < jend; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 uint32_t v = 0;
                 if (j < jend) {
@@ -230,13 +267,13 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
     // whose nibble parity matches, at whatever byte they start; all of them requested before the first is used.
     // (a stream that disagrees with its descriptor could push t0 past the contig: stay inside the padded buffer; such a
     // read is reported by the descriptor check at the end of its last chunk)
-    uint32_t t0_[DENSE_CPW];
+    uint32_t tA_[DENSE_CPW], tB_[DENSE_CPW];
     dense_u32x4 ra_[DENSE_CPW], rb_[DENSE_CPW];
     const uint32_t win_lim = (L >> 1) + 32;
 #pragma unroll
     for (uint32_t it = 0; it < DENSE_CPW; ++it) {
-        const uint32_t tA = dd[it].ts + carry_[it] + (incl_[it] - nA_[it] - nB_[it]), tB = tA + nA_[it];
-        t0_[it] = tA;
+        const uint32_t tA = dd[it].ts + carry_[it] + exA_[it], tB = dd[it].ts + carry_[it] + exB_[it];
+        tA_[it] = tA, tB_[it] = tB;
         ra_[it] = dense_load16u(refeo + ((tA & 1) ? eo_stride : 0u) + min(tA >> 1, win_lim));
         rb_[it] = dense_load16u(refeo + ((tB & 1) ? eo_stride : 0u) + min(tB >> 1, win_lim));
     }
@@ -246,9 +283,9 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         const uint32_t ch = DENSE_CPW * pw + it;
         if (!dd[it].live) break;
         const uint32_t ncols = dd[it].ncols, ts = dd[it].ts, c0 = dd[it].c0;
-        const uint32_t lc0 = c0 + lane * 64;
+        const uint32_t lcA = c0 + lane * 32, lcB = lcA + DENSE_COLS / 2;
         const uint32_t nA = nA_[it], nB = nB_[it], total = total_[it], carryN = carry_[it];
-        const uint32_t tA = t0_[it], tB = tA + nA;
+        const uint32_t tA = tA_[it], tB = tB_[it];
         const bool cont = it != 0 && dd[it].read == dd[it ? it - 1 : 0].read && c0 != 0;
         // columns that differ from the contig, insertion columns among them (the contig's copies carry no flag bit)
         const dense_u32x4 xa = va_[it] ^ ra_[it], xb = vb_[it] ^ rb_[it];
@@ -258,36 +295,32 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
         uint32_t topA = nA != 32u ? 1u : xa.w >> 24, topB = nB != 32u ? 1u : xb.w >> 24;
         bool okA = true, okB = true; // the piece holds 32 columns
         if (!full_[it]) { // (uniform) a partial piece goes to phase 2, which masks; an empty one nowhere
-            const uint32_t nv = nv_[it];
-            okA = nv >= 32u, okB = nv == 64u;
-            if (!okA) oA = nv ? 1u : 0u, topA = 0;
-            if (!okB) oB = nv > 32u ? 1u : 0u, topB = 0;
+            okA = nvA_[it] == 32u, okB = nvB_[it] == 32u;
+            if (!okA) oA = nvA_[it] ? 1u : 0u, topA = 0;
+            if (!okB) oB = nvB_[it] ? 1u : 0u, topB = 0;
         }
         // checkpoints: column of the reference column at the next multiple of CKPT (a whole piece without insertion columns
-        // holds exactly one, and column index and position advance together; phase 2 writes the others')
+        // holds exactly one, and column index and position advance together; phase 2 writes the others'); consecutive lanes
+        // write consecutive slots
         {
             const uint64_t ck_first = (ts + CKPT - 1) >> CKPT_SHIFT;
             uint32_t *const ckb = ckpt + (dd[it].ckbase - ck_first);
             const uint32_t nck = s_desc[ch - blk_first].nck;
             const uint32_t tsA = (tA + CKPT - 1) & ~(CKPT - 1), tsB = (tB + CKPT - 1) & ~(CKPT - 1);
             if (probe != 2) {
-                const bool wA = okA && nA == 32u && (tsA >> CKPT_SHIFT) - (uint32_t)ck_first < nck;
-                const bool wB = okB && nB == 32u && (tsB >> CKPT_SHIFT) - (uint32_t)ck_first < nck;
-                const uint32_t cA = lc0 + (tsA - tA), cB = lc0 + 32u + (tsB - tB);
-                if (wA && wB) { // (nA == 32: tsB == tsA + CKPT, the two slots are neighbours — one 8-byte store, a wave's 512 contiguous bytes)
-                    const uint2 two = make_uint2(cA, cB);
-                    __builtin_memcpy(ckb + (tsA >> CKPT_SHIFT), &two, 8);
-                } else {
-                    if (wA) ckb[tsA >> CKPT_SHIFT] = cA;
-                    if (wB) ckb[tsB >> CKPT_SHIFT] = cB;
-                }
+                if (okA && nA == 32u && (tsA >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsA >> CKPT_SHIFT] = lcA + (tsA - tA);
+                if (okB && nB == 32u && (tsB >> CKPT_SHIFT) - (uint32_t)ck_first < nck) ckb[tsB >> CKPT_SHIFT] = lcB + (tsB - tB);
             }
         }
-        uint32_t pb = wave_prev_lane(0u, topB);
-        if (lane == 0) pb = cont ? prev_top : (c0 > 0 ? 1u : 0u); // (chunk start inside a read: phase 2 looks)
-        prev_top = (uint32_t)__builtin_amdgcn_readlane((int)topB, 63);
-        const bool dirtyA = oA != 0 || (pb != 0 && nv_[it] != 0) || (lc0 == 0 && ts != 0);
-        const bool dirtyB = oB != 0 || (topA != 0 && nv_[it] > 32u);
+        // the piece before piece A of lane l is A of lane l - 1 (lane 0: the previous chunk's last piece), before B of lane l
+        // B of lane l - 1 (lane 0: A of lane 63)
+        const uint32_t tops = (topA ? 1u : 0u) | (topB ? 2u : 0u);
+        uint32_t pb = wave_prev_lane(0u, tops);
+        const uint32_t t63 = (uint32_t)__builtin_amdgcn_readlane((int)tops, 63);
+        if (lane == 0) pb = (cont ? prev_top : (c0 > 0 ? 1u : 0u)) | ((t63 & 1u) << 1); // (chunk start inside a read: phase 2 looks)
+        prev_top = t63 >> 1;
+        const bool dirtyA = oA != 0 || ((pb & 1u) != 0 && nvA_[it] != 0) || (lcA == 0 && ts != 0);
+        const bool dirtyB = oB != 0 || ((pb & 2u) != 0 && nvB_[it] != 0);
         const uint64_t dmA = __ballot(dirtyA), dmB = __ballot(dirtyB);
         if (probe == 2 || probe == 3) { // (keep the comparison alive)
             if ((dmA ^ dmB) == 0x123456789ABCDEFull && lane == 0) atomicOr(err, 0x80000000u);
@@ -298,14 +331,14 @@ __device__ __forceinline__ void k_diff_reads(const uint32_t np2_bid, const uint3
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&s_nq, cA + (uint32_t)__builtin_popcountll(dmB));
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            const uint32_t tag = ((ch - blk_first) << 7) | (lane << 1);
+            const uint32_t tag = ((ch - blk_first) << 7) | lane; // chunk in block | piece
             if (dirtyA) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmA, 0u));
                 s_q[qb + rank] = make_uint2(tA, tag);
             }
             if (dirtyB) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmB, 0u));
-                s_q[qb + cA + rank] = make_uint2(tB, tag | 1u);
+                s_q[qb + cA + rank] = make_uint2(tB, tag | 64u);
             }
         }
         if (lane == 0) {
@@ -559,21 +592,7 @@ __device__ __forceinline__ void k_chunk_counts(const uint32_t np2_bid, const uin
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(np2_bid * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (ch >= n_chunks) return;
-    const ChunkDesc *dp = descs + ch;
-    const uint32_t c0 = dp->c0, ncols = dp->ncols;
-    const uint32_t lc0 = c0 + lane * 64;
-    const uint32_t nv = lc0 < ncols ? min(64u, ncols - lc0) : 0u;
-    const uint32_t nvA = min(nv, 32u), nvB = nv - nvA;
-    dense_u32x4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
-    const uint8_t *p = nib + dp->nib_off + (lc0 >> 1);
-    if (nvA) a = *reinterpret_cast<const dense_u32x4 *>(p);
-    if (nvB) b = *reinterpret_cast<const dense_u32x4 *>(p + 16);
-    if (c0 == 0 && lane == 0) a.x &= ~0x80u; // column 0 is never an insertion column (main.rs:325,332-335)
-    const uint32_t ins = (uint32_t)__builtin_popcount(a.x & NF3W & dense_native_below(nvA, 0)) + (uint32_t)__builtin_popcount(a.y & NF3W & dense_native_below(nvA, 1)) +
-                         (uint32_t)__builtin_popcount(a.z & NF3W & dense_native_below(nvA, 2)) + (uint32_t)__builtin_popcount(a.w & NF3W & dense_native_below(nvA, 3)) +
-                         (uint32_t)__builtin_popcount(b.x & NF3W & dense_native_below(nvB, 0)) + (uint32_t)__builtin_popcount(b.y & NF3W & dense_native_below(nvB, 1)) +
-                         (uint32_t)__builtin_popcount(b.z & NF3W & dense_native_below(nvB, 2)) + (uint32_t)__builtin_popcount(b.w & NF3W & dense_native_below(nvB, 3));
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan<OpAdd>(nv - ins), 63);
+    const uint32_t total = dense_chunk_total(descs + ch, nib, lane);
     if (lane == 0) __hip_atomic_store(&chunk_st[ch], ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_chunk_counts(hipStream_t s, const ChunkDesc *descs, uint32_t n_chunks, const uint8_t *nib, uint64_t *chunk_st, uint32_t epoch) {
