@@ -538,10 +538,11 @@ __device__ __forceinline__ void region_measure_inline(const CandCtx &cx, uint32_
 // the only ones to test; the list is ascending in read index = the order the reference visits alignseqs in.
 // Keeps the first 60 non-empty candidates (main.rs:1474,1509): per region slots kept_read / kept_len / kept_col
 // (kept_col == CAND_CLEAN: the contig's own string, nothing to decode).
-__device__ __forceinline__ void k_region_measure(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
+__device__ __forceinline__ void k_region_measure(const uint32_t np2_bid0, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, uint32_t *__restrict__ kept_read,
                                                         uint32_t *__restrict__ kept_len, uint32_t *__restrict__ kept_col,
                                                         uint32_t *__restrict__ reg_ncand, uint32_t *__restrict__ reg_bytes,
                                                         uint32_t *__restrict__ reg_maxlen, uint32_t *__restrict__ blk_sum) {
+    const uint32_t np2_bid = xcd_order(np2_bid0, np2_nb); // (neighbouring items on one XCD: np2_common.hpp)
     // blk_sum: per group of 4 regions (= one wavefront's), three arrays of n_mb entries: candidates, bytes, longest kept strings
     __shared__ uint32_t s_reads[RM_REG][64];
     __shared__ uint32_t s_dm[RM_REG][2];
@@ -797,7 +798,7 @@ __device__ __forceinline__ void k_cand_offsets_lb(const uint32_t np2_bid, const 
 // candidates that are the contig's own string (kept_col == CAND_CLEAN) copy it from LDS, where the region's wavefront
 // put it straight from the nibble-packed contig, and take the k-mer of the contig's own candidate (read 0, always the
 // first of such a region); the others — and read 0 — go through the block's queue and are decoded by consecutive threads.
-__device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
+__device__ __forceinline__ void k_region_write(const uint32_t np2_bid0, const uint32_t np2_nb, CandCtx cx, uint32_t n_reg, const uint32_t *__restrict__ kept_read,
                                                       const uint32_t *__restrict__ kept_len,
                                                       const uint32_t *__restrict__ kept_col,
                                                       const uint32_t *__restrict__ reg_ncand,
@@ -809,6 +810,7 @@ __device__ __forceinline__ void k_region_write(const uint32_t np2_bid, const uin
                                                       uint32_t seq_cap, uint32_t *__restrict__ cand_order,
                                                       uint64_t *__restrict__ cand_kmer, uint32_t *__restrict__ cand_seq_off,
                                                       uint8_t *__restrict__ cand_seq) {
+    const uint32_t np2_bid = xcd_order(np2_bid0, np2_nb); // (neighbouring items on one XCD: np2_common.hpp)
     __shared__ __attribute__((aligned(4))) uint8_t s_str[RM_REG][CLEAN_MAX_LEN];
     __shared__ uint64_t s_km[RM_REG];
     __shared__ uint32_t s_so[RM_REG][64];

@@ -105,4 +105,17 @@ NP2_HD uint8_t nib_at(const uint8_t *bytes, uint32_t c) {
     return (c & 1) ? (t & 15) : (t >> 4);
 }
 
+
+// XCD-aware order of a grid's workgroups (gfx950: workgroups go round the 8 XCDs in turn, each XCD has an L2 of its own).
+// A kernel whose neighbouring blocks read the same lines — regions or tiles next to each other along the contig share
+// reads, checkpoints, read lists, records — lets block b work on item xcd_order(b, n): the (b / 8)-th item of the (b % 8)-th
+// eighth of the items, so that one XCD's L2 sees one stretch of the contig instead of all of it.  A bijection on [0, n).
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t n) {
+    if (n < 64) return b;
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+#endif
+
 } // namespace np2

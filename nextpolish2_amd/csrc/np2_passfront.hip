@@ -711,7 +711,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
 }
 
 __device__ __forceinline__ void k_pf_tile(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {
-    pf_tile_body<PF_CAP, PF_HALO, 0>(np2_bid, A);
+    pf_tile_body<PF_CAP, PF_HALO, 0>(xcd_order(np2_bid, np2_nb), A); // (neighbouring tiles — shared reads, the halo's records — on one XCD)
 }
 // the tiles the kernel above listed, with room for 2048 records (a handful of blocks walk the list) ...
 __device__ __forceinline__ void k_pf_tile_mid(const uint32_t np2_bid, const uint32_t np2_nb, PfTile A) {

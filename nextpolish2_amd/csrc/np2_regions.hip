@@ -178,12 +178,13 @@ __device__ __forceinline__ bool hp_differs_wave(const SubWave &sw, uint32_t lane
 }
 
 // ---- phasing pass -----------------------------------------------------------------------------
-__device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, uint32_t asref, uint32_t use_all,
+__device__ __forceinline__ void k_vote_phase(const uint32_t np2_bid0, const uint32_t np2_nb, RegionTables rt, uint32_t asref, uint32_t use_all,
                                                     const uint32_t *__restrict__ lq_start, uint32_t own_lo, uint32_t own_hi,
                                                     uint8_t *__restrict__ reg_lable, uint8_t *__restrict__ grp,
                                                     uint32_t *__restrict__ ecount, int32_t *__restrict__ ref_w,
                                                     uint8_t *__restrict__ ref_seen, uint8_t *__restrict__ bad,
                                                     uint32_t *__restrict__ first_reg, uint32_t *__restrict__ err) {
+    const uint32_t np2_bid = xcd_order(np2_bid0, np2_nb); // (neighbouring items on one XCD: np2_common.hpp)
     // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
     // (the usual case at 30x), otherwise one after the other over all 64 lanes
     const uint32_t wl = threadIdx.x & 63;
@@ -301,10 +302,11 @@ __device__ __forceinline__ void k_edges_write(const uint32_t np2_bid, const uint
 // (256 partners = 1 KiB; a region's partners are distinct, so a wave-wide ds_add never collides).  No global atomics:
 // the ~3 M raw pair votes per Mb of a diploid contig stay on chip, the finished row is written once, together with
 // its number of distinct partners.  Pairs further apart than the band bump *ovf (the host then sorts raw votes).
-__device__ __forceinline__ void k_edges_row(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ grp,
+__device__ __forceinline__ void k_edges_row(const uint32_t np2_bid0, const uint32_t np2_nb, RegionTables rt, const uint8_t *__restrict__ grp,
                                             const uint32_t *__restrict__ ecount, const uint32_t *__restrict__ pj,
                                             const uint32_t *__restrict__ pcount, const uint8_t *__restrict__ alive, uint32_t R,
                                             uint32_t *__restrict__ band, uint32_t *__restrict__ row_n, uint32_t *__restrict__ ovf) {
+    const uint32_t np2_bid = xcd_order(np2_bid0, np2_nb); // (neighbouring items on one XCD: np2_common.hpp)
     __shared__ uint32_t s_row[4][EDGE_BAND];
     const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t a = np2_bid * 4 + wv;
@@ -465,10 +467,11 @@ __device__ __forceinline__ void k_edge_compact(const uint32_t np2_bid, const uin
 }
 
 // ---- final pass: seeds -------------------------------------------------------------------------
-__device__ __forceinline__ void k_seed(const uint32_t np2_bid, const uint32_t np2_nb, RegionTables rt, int32_t max_indel_len,
+__device__ __forceinline__ void k_seed(const uint32_t np2_bid0, const uint32_t np2_nb, RegionTables rt, int32_t max_indel_len,
                                               uint8_t *__restrict__ reg_lable, uint32_t *__restrict__ seed_cand,
                                               uint32_t *__restrict__ keep_n, uint32_t *__restrict__ keep_list,
                                               uint16_t *__restrict__ keep_ks, uint32_t *__restrict__ err) {
+    const uint32_t np2_bid = xcd_order(np2_bid0, np2_nb); // (neighbouring items on one XCD: np2_common.hpp)
     // a wavefront owns two consecutive regions: side by side in its two halves when both have at most 32 candidates
     // (the usual case at 30x), otherwise one after the other over all 64 lanes
     const uint32_t wl = threadIdx.x & 63;
