@@ -28,15 +28,15 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
          784333, 1091291, 948066, 85779]
 # HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
-# profiles/r03_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r03_ecoli_pmc_fetch_write.json
-# (the round-3 kernel; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9 KB)
-PMC_SOURCE = {"yeast": "profiles/r04_yeast_pmc_fetch_write.json (round 4, re-recorded at the end of the round)", "ecoli": "profiles/r04_ecoli_pmc_fetch_write.json (round 4)"}
+# profiles/r05_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r05_ecoli_pmc_fetch_write.json
+# (round 5's kernel; round 4's: 2 * 37805.7 + 38330.9 and 2 * 52134.0 + 38965.5 KB; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9)
+PMC_SOURCE = {"yeast": "profiles/r05_yeast_pmc_fetch_write.json (round 5, recorded on the final build)", "ecoli": "profiles/r05_ecoli_pmc_fetch_write.json (round 5)"}
 # k-mer table probes per polished bp the reference algorithm makes on these workloads (the oracle's kmer_probes stat over
 # the whole assembly: kappa of SURVEY.md §8(d)); measured again whenever the cpu_baseline leg runs
 KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
 KAPPA_SOURCE = "profiles/r04_kappa.json"
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
-PMC_TRAFFIC = {"yeast": int((2 * 37805.7 + 38330.9) * 1024), "ecoli": int((2 * 52134.0 + 38965.5) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 26360.4 + 34008.2) * 1024), "ecoli": int((2 * 38842.8 + 31692.6) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):

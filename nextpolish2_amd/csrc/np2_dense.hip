@@ -4,17 +4,19 @@
 // as raw records (t_pos << 32 | column, read) filed under their contig tile, next to the per-read checkpoints.
 //
 // k_diff_reads is the kernel the benchmark's roofline is quoted on: 0.5 B per column + 0.5 B per contig base of
-// algorithmic HBM traffic.  Round 2's version did everything wave-wide and was VALU-issue bound at ~500 VALU
-// instructions per 2048-column chunk (12 % of the HBM peak), most of them on paths a wave enters because ONE of its 64
-// lanes needs them (an insertion run, an exception to emit).  This version splits the work by what a lane holds:
-//   * phase 1, every lane, branch-free: load 16 B, count non-insertion columns, wave scan -> t_pos, fetch the 32 contig
-//     codes at t_pos, one nibble-domain compare.  A lane without insertion columns whose codes all match (94 % of
-//     the lanes of a haploid pileup, ~80 % of a diploid one) is *done* after writing its checkpoint;
-//   * every other lane ("dirty": a mismatch, an insertion, a bad column in the two columns before it, a read start) is
-//     queued in LDS and handled in phase 2 by ONE THREAD per dirty lane, the block's threads taking the queue in
-//     order: insertion runs shift the contig window, exact bad-column mask, exception mask, records, the checkpoint
-//     of an insertion-bearing lane.  The divergent code runs in one or two densely packed wavefronts per block instead
-//     of in all of them.
+// algorithmic HBM traffic.  The work is split by what a 32-column piece of a read holds:
+//   * phase 1, every lane, branch-free, two pieces per lane (64 columns, two 16-byte loads), in the packed stream's own
+//     nibble order: count insertion columns, one wave scan -> t_pos of each piece's first column, 16 bytes of the contig
+//     copy of the matching parity at that position, four XORs.  A piece without insertion columns whose codes all match and
+//     with nothing bad in the two columns before it (90 % of the pieces of a haploid pileup, ~80 % of a diploid one) is
+//     *done* after writing its checkpoint;
+//   * every other piece ("dirty") is queued in LDS and handled in phase 2 by ONE THREAD per piece, the block's threads
+//     taking the queue in order, in the 128-bit nibble domain of np2_nib128.hpp: insertion runs shift the contig window,
+//     exact bad-column mask, exception mask, records (staged in LDS by contig tile and written out as contiguous pieces
+//     while the bucket reservation is in flight), the checkpoint of an insertion-bearing or partial piece.  The divergent
+//     code runs in densely packed wavefronts instead of in all of them.
+// Round 5 measured what bounds it: not instruction issue (367 -> 206 VALU per 2048 columns changed
+// nothing), not the stream (the first part runs at 5.5 TB/s) but its phases in sequence at eight resident blocks per CU.
 #include "np2_common.hpp"
 #include "np2_kernels.hpp"
 #include "np2_blockscan.hpp"
