@@ -356,7 +356,10 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
         // chromosome's list is 200 MB): the plain pipeline decides the vote right away, a shard copies them first
         vd.view_key = (const uint64_t *)pin, vd.view_cnt = (const uint32_t *)(pin + b_key), vd.view_n = NU;
         vd.key_added = wide && !far; // (the sort path's keys are local)
-        if (b_pr) per_read(pin + b_key + b_w);
+        if (b_pr) {
+            per_read(pin + b_key + b_w);
+            if (wide) vd.d_bad = cx->votebuf.p + RP * 9; // (where the vote kernel left the flags: np2_shard_vote's early start)
+        }
     }
     if (cx->trace) {
         vd.own(); // (the traces below read back through the same staging)
@@ -1463,6 +1466,11 @@ struct ShardRun {
     // np2_shard_final_device: the owned slice of the device-resident result
     uint64_t own_off = 0, own_len = 0;
     bool have_piece = false;
+    // the pass started on the reads the vote kernel flagged while the ranks' votes are merged and decided (np2_shard_vote /
+    // np2_shard_apply): the flags it went by, local read numbers
+    bool spec = false;
+    std::vector<uint8_t> spec_bad;
+    size_t spec_n_bad = 0;
 };
 inline uint32_t shard_global_read(const np2_shard_plan_t &pl, uint32_t local) { return local == 0 ? 0u : pl.read_lo + local - 1; }
 
@@ -2207,6 +2215,32 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
         out->first_pos = sr->v_first.data();
         out->ref_w = sr->v_refw.data();
         out->flags = sr->v_flags.data();
+        // The decision is taken elsewhere — votes gathered, merged, Louvain: ~90 ms for a diploid chromosome — and the device
+        // has nothing to do meanwhile.  As in polish_impl the next pass starts at once on the reads the vote kernel has
+        // flagged (main.rs:977: they are removed whatever else the decision says); np2_shard_apply compares: the decision
+        // removes exactly those -> the pass under way is the right one; it removes others too (a read flagged by the
+        // neighbouring shard, a conflicting community) -> they go as well and the pass is started again.  Only kernels are
+        // issued here, no read-back: the exported pairs stay valid where they are.
+        static const bool no_spec = getenv("NP2_NO_SPECULATE") != nullptr;
+        sr->spec = false;
+        if (vd.any && vd.d_bad && !sr->run.o.use_all_reads && !cx->trace && !no_spec) {
+            size_t n_bad = 0;
+            for (uint8_t b : vd.bad) n_bad += b;
+            if (n_bad) {
+                PolishRun &r = sr->run;
+                launch_kill_flagged(cx->stream, vd.d_bad, r.c->R, cx->alive.p);
+                ++r.pass; // (what run_apply_losers does)
+                r.reuse = false;
+                pass_front_issue(cx, r.c, r.T, (int)r.pass);
+                r.front_issued = true;
+                op_submit(cx);
+                sr->spec = true;
+                sr->spec_bad = vd.bad;
+                sr->spec_n_bad = n_bad;
+            }
+        }
+        if (getenv("NP2_SHARD_SPEC_LOG"))
+            fprintf(stderr, "[np2 shard] vote: any %d, flags on the device %d, early start %d (%zu flagged)\n", (int)vd.any, vd.d_bad != nullptr, (int)sr->spec, sr->spec_n_bad);
     })
     return NP2_OK;
 }
@@ -2339,7 +2373,7 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
 
 int np2_shard_apply(np2_shard_run_t *h, const uint32_t *losers, uint32_t n) {
     ShardRun *sr = (ShardRun *)h;
-    if (!sr || (n && !losers) || sr->run.final_pass()) return NP2_E_ARG;
+    if (!sr || (n && !losers) || (sr->run.final_pass() && !sr->spec)) return NP2_E_ARG; // (a pass started early has advanced the counter)
     np2_ctx *cx = sr->run.cx;
     NP2_SHARD_TRY(cx, {
         std::vector<uint32_t> local;
@@ -2347,6 +2381,27 @@ int np2_shard_apply(np2_shard_run_t *h, const uint32_t *losers, uint32_t n) {
         for (uint32_t i = 0; i < n; ++i) {
             if (losers[i] == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: the contig itself was voted out");
             if (losers[i] >= pl.read_lo && losers[i] < pl.read_hi) local.push_back(losers[i] - pl.read_lo + 1);
+        }
+        if (sr->spec) { // the pass is under way on the flagged reads (np2_shard_vote): is it the right one?
+            sr->spec = false;
+            std::vector<uint32_t> extra;
+            size_t n_flagged = 0;
+            for (uint32_t id : local) {
+                REFPANIC_IF(id >= sr->run.c->R, "index out of bounds: alignseqs[id]");
+                if (sr->spec_bad[id]) ++n_flagged; else extra.push_back(id);
+            }
+            if (n_flagged != sr->spec_n_bad) throw Np2Error(NP2_E_DEVICE, "internal: a read flagged by the vote kernel is not among the removed reads");
+            if (getenv("NP2_SHARD_SPEC_LOG")) fprintf(stderr, "[np2 shard] apply: %zu removed here, %zu beyond the flagged ones\n", local.size(), extra.size());
+            if (!extra.empty() || getenv("NP2_TEST_MISSPECULATE")) { // (test hook: the redo branch)
+                if (!extra.empty()) {
+                    cx->kill_ids.ensure(extra.size() + 1);
+                    h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);
+                    launch_kill_reads(cx->stream, cx->kill_ids.p, (uint32_t)extra.size(), cx->alive.p);
+                }
+                sr->run.reuse = false;
+                sr->run.front_issued = false; // (run_pass_front starts the pass again, on the right reads)
+            }
+            return NP2_OK;
         }
         // (no identical-pass reuse across shards: a neighbour's removals are not visible here, the decision would
         // differ from shard to shard only in cost, never in result — but keep it simple)
