@@ -211,7 +211,10 @@ typedef struct np2_shard_run np2_shard_run_t;
 int np2_shard_begin(np2_ctx_t *ctx, np2_contig_t *shard, const np2_shard_plan_t *plan, const np2_opts_t *opts,
                     uint32_t verify, np2_shard_run_t **out);
 int np2_shard_passes_left(np2_shard_run_t *run);          /* iter_count - passes done; 1 = only the final pass is left */
-int np2_shard_vote(np2_shard_run_t *run, np2_vote_t *out); /* a phasing pass up to its votes */
+/* a phasing pass up to its votes.  Without -r the shard starts its NEXT pass at once on the reads its vote kernel flagged
+ * (kernels only: `out` stays valid) and np2_shard_apply settles it; between the two calls np2_shard_passes_left already counts
+ * that pass as begun: fix the number of phasing passes before the loop (iter_count - 1 on every rank), as dist.py does */
+int np2_shard_vote(np2_shard_run_t *run, np2_vote_t *out);
 /* host only: merge the shards' votes of one pass and decide (reads of the whole contig: n_reads_total); losers: capacity
  * n_reads_total */
 int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total, const np2_opts_t *opts, uint32_t *losers,
