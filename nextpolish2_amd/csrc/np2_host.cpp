@@ -422,19 +422,33 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
         const int32_t same = (int32_t)((w >> 8) & 0xFFFu), neg = (int32_t)(w >> 20);
         return (float)(neg >= 3 ? -neg : same - neg);
     };
-    const bool ok = vd.compact() ? data.add_edges_rows(vd.c_off, vd.c_pairs, R, weight_c, use_all ? nullptr : vd.bad.data())
-                                 : data.add_edges_sorted(vd.keys(), NU, weight, use_all ? nullptr : vd.bad.data());
-    if (!ok) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
-    mark("keys + edges");
+    // data.retain(..) on the keys themselves (erase order = bucket order) BEFORE the rows: the rows leave the flagged reads'
+    // edges out by themselves, and with the key table final the first level's community map — the keys inserted into a
+    // fresh map in the table's iteration order, 10 ms of hash-order emulation for a chromosome — is built on a helper
+    // thread beside the rows
     std::vector<uint32_t> bad;
     for (uint32_t r = 0; r < R; ++r)
         if (vd.bad[r]) bad.push_back(r);
-    if (!use_all) // the keys themselves: erase order = bucket order
-        data.keys.keep_if([&](uint32_t k, phase::Nil &) {
-            if (vd.bad[k]) data.is_key[k] = 0;
-            return !vd.bad[k];
-        });
+    if (!use_all) data.keys.keep_if([&](uint32_t k, phase::Nil &) { return !vd.bad[k]; }); // (is_key follows after the rows: they check their endpoints against it)
     mark("retain");
+    std::future<phase::OrderSet> communities;
+    if (data.keys.size() >= (1u << 15) && phase::host_threads() > 1)
+        communities = std::async(std::launch::async, [&data] { return phase::SignedLouvain::first_communities(data.keys); });
+    bool ok = false;
+    try {
+        ok = vd.compact() ? data.add_edges_rows(vd.c_off, vd.c_pairs, R, weight_c, use_all ? nullptr : vd.bad.data())
+                          : data.add_edges_sorted(vd.keys(), NU, weight, use_all ? nullptr : vd.bad.data());
+    } catch (...) {
+        if (communities.valid()) communities.wait(); // (it reads data.keys)
+        throw;
+    }
+    phase::OrderSet comm_pre;
+    if (communities.valid()) comm_pre = communities.get();
+    const bool have_pre = !comm_pre.empty();
+    if (!ok) throw Np2Error(NP2_E_DEVICE, "internal: edge endpoint without a key");
+    if (!use_all)
+        for (uint32_t b : bad) data.is_key[b] = 0;
+    mark("keys + edges");
     std::vector<float> ref_row(R, 0.f);
     std::vector<uint8_t> ref_have(R, 0);
     bool have_ref = false;
@@ -445,7 +459,7 @@ std::vector<uint32_t> vote_decide(np2_ctx *cx, const VoteData &vd, bool use_all)
             have_ref = true;
         }
     std::vector<uint32_t> losers;
-    if (!phase::losing_reads(std::move(data), have_ref, ref_row, ref_have, losers))
+    if (!phase::losing_reads(std::move(data), have_ref, ref_row, ref_have, losers, have_pre ? &comm_pre : nullptr))
         throw Np2Error(NP2_E_REFPANIC,
                        "reference would panic: the weight of two conflicting community is not less than 0");
     mark("louvain + ranking");

@@ -566,16 +566,25 @@ struct Community {
 // the reference's O(deg^2) / O(C^2) membership scans; all sums are exact small-integer f32, so results are equal.
 class SignedLouvain {
   public:
-    explicit SignedLouvain(Graph g) : g_(std::move(g)) {
+    // communities: the community map of louvain.rs:65-68 built ahead by the caller (first_communities: it depends on the
+    // graph's KEYS only, so a chromosome's vote builds it beside the edge rows), or nullptr
+    explicit SignedLouvain(Graph g, OrderSet *communities = nullptr) : g_(std::move(g)) {
         const uint32_t n = g_.n_ids();
         node_id_.resize(n);
         node_w_.assign(n, 0.f);
         cnt_.assign(n, 0);
+        if (communities) comm_keys_ = std::move(*communities);
         for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68 (members_: every node is {itself} until aggregated)
-            comm_keys_.put(v, Nil{});
+            if (!communities) comm_keys_.put(v, Nil{});
             node_id_[v] = v;
             cnt_[v] = 1;
         }
+    }
+    // the first level's community map: a fresh map, the graph's keys inserted in the graph's iteration order
+    static OrderSet first_communities(const OrderSet &graph_keys) {
+        OrderSet c;
+        for (uint32_t v : graph_keys.key_list()) c.put(v, Nil{});
+        return c;
     }
     // returns false if the reference's weight<0 assertion (louvain.rs:234-237) would fire
     bool run(std::unordered_map<uint32_t, std::unordered_set<uint32_t>> &conflicts, std::vector<Community> &out) {
@@ -1037,7 +1046,7 @@ class SignedLouvain {
 // phase_communities (louvain.rs:290-356): reads of the losing communities.
 // ref_w / ref_seen: the reference haplotype's row (ref_data[0]), indexed by read id; have_ref = row exists
 inline bool losing_reads(Graph graph, bool have_ref, const std::vector<float> &ref_w,
-                         const std::vector<uint8_t> &ref_seen, std::vector<uint32_t> &losers) {
+                         const std::vector<uint8_t> &ref_seen, std::vector<uint32_t> &losers, OrderSet *communities = nullptr) {
     const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_m = now();
@@ -1048,7 +1057,7 @@ inline bool losing_reads(Graph graph, bool have_ref, const std::vector<float> &r
             t_m = t;
         }
     };
-    SignedLouvain lv(std::move(graph));
+    SignedLouvain lv(std::move(graph), communities);
     mark("first-level state");
     std::unordered_map<uint32_t, std::unordered_set<uint32_t>> conflicts;
     std::vector<Community> comms;
