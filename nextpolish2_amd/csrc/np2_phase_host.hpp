@@ -642,12 +642,16 @@ class SignedLouvain {
         for (uint32_t v = 0; v < g_.n_ids(); ++v)
             if (g_.has_key(v)) visit.push_back(v);
         std::vector<uint8_t> dirty(g_.n_ids(), 1);
+        if (level0_) oplog_.reserve(2 * visit.size()); // (the first sweep moves nearly every node: two log entries each)
         // gains per neighbouring community: a slot per community id, valid for the node whose stamp it carries (in the
         // first sweep every neighbour is a community of its own: a list searched per edge was quadratic in the degree)
         std::vector<float> acc(g_.n_ids(), 0.f);
         std::vector<uint32_t> stamp(g_.n_ids(), 0u), touched;
         uint32_t tick = 0;
         // decision of v against the current state: the community it moves to, or its own
+        // (mark_all: the first sweep, in which nearly every node moves, flags the neighbours while it reads them — one walk
+        // over the row instead of two; a node flagged without cause is evaluated once more and stays where it is)
+        bool mark_all = false;
         auto decide = [&](uint32_t v) -> uint32_t {
             const uint32_t cur = node_id_[v];
             touched.clear();
@@ -656,6 +660,7 @@ class SignedLouvain {
                 tick = 1;
             }
             for (const auto &e : g_.adj(v)) {
+                if (mark_all) dirty[e.first] = 1;
                 const uint32_t c = node_id_[e.first];
                 if (stamp[c] != tick) {
                     stamp[c] = tick;
@@ -685,6 +690,7 @@ class SignedLouvain {
         for (bool again = true; again;) {
             again = false;
             ++sweep;
+            mark_all = sweep == 1 && level0_;
             size_t n_eval = 0, n_moved = 0, n_taken = 0;
             const auto t_sw = std::chrono::steady_clock::now();
             const bool use_ahead = !no_ahead && sweep > 1 && visit.size() >= ahead_min && last_moved >= ahead_min / 64 && host_threads() > 1; // (many moves in the last sweep: many dirty nodes now)
@@ -743,7 +749,8 @@ class SignedLouvain {
                     --cnt_[cur];
                     oplog_.emplace_back(to, (int64_t)v + 1);
                     oplog_.emplace_back(cur, -((int64_t)v + 1));
-                    for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
+                    if (!mark_all)
+                        for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
                     if (use_ahead)
                         for (const auto &e : g_.adj(v)) stale[e.first] = sweep;
                     again = true;
