@@ -768,12 +768,15 @@ class SignedLouvain {
     void member_lists(std::vector<uint32_t> &off, std::vector<uint32_t> &list) const {
         const size_t n = node_id_.size();
         off.assign(n + 1, 0);
-        const std::vector<uint32_t> keys = g_.keys.key_list();
-        for (uint32_t v : keys) ++off[node_id_[v] + 1];
+        // (the keys by a scan of the dense mirror, not in the table's order: a walk over a chromosome's table was 3 ms)
+        const uint32_t nk = g_.n_ids();
+        for (uint32_t v = 0; v < nk; ++v)
+            if (g_.has_key(v)) ++off[node_id_[v] + 1];
         for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
-        list.resize(keys.size());
+        list.resize(g_.keys.size());
         std::vector<uint32_t> cur(off.begin(), off.end() - 1);
-        for (uint32_t v : keys) list[cur[node_id_[v]]++] = v;
+        for (uint32_t v = 0; v < nk; ++v)
+            if (g_.has_key(v)) list[cur[node_id_[v]]++] = v;
     }
     // weight of a community = carried weights + half of every directed internal edge (louvain.rs:124-134)
     float internal_weight(uint32_t cid, const uint32_t *mb, const uint32_t *me, std::vector<uint32_t> &mem) const {
