@@ -1170,7 +1170,24 @@ __device__ __forceinline__ void k_lq_region(const uint32_t np2_bid, const uint32
         uint32_t lq_s = p > 2 ? p - 2 : 1;
 #define CP(x) cns_pos[M - 1 - (x)]
 #define CB(x) cns_base[M - 1 - (x)]
-        while (lq_s > 1 && (CP(lq_s - 1) == CP(lq_s) || CB(lq_s - 1) == CB(lq_s))) --lq_s;
+        // (the walk over a homopolymer / an insertion column's bases: eight steps out of one round of loads instead of a
+        // dependent load or two per step — emission index x is consensus index M - 1 - x, the walk goes up the consensus)
+        for (;;) {
+            const uint32_t i = M - 1 - lq_s; // consensus index of lq_s; lq_s - k is i + k
+            if (lq_s <= 1) break;
+            if (lq_s >= 9 && i + 8 < M) {
+                uint32_t ps[9];
+                uint8_t bs[9];
+                __builtin_memcpy(ps, cns_pos + i, 36);
+                __builtin_memcpy(bs, cns_base + i, 9);
+                uint32_t k = 0;
+                while (k < 8 && (ps[k + 1] == ps[k] || bs[k + 1] == bs[k])) ++k; // (lq_s - k > 1 throughout: lq_s >= 9)
+                lq_s -= k;
+                if (k < 8) break;
+            } else {
+                if (CP(lq_s - 1) == CP(lq_s) || CB(lq_s - 1) == CB(lq_s)) --lq_s; else break;
+            }
+        }
         rend[p] = CP(lq_s);
         rstart[p] = CP(lq_e);
 #undef CP
@@ -1543,7 +1560,10 @@ void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
                     const uint32_t *lqoff, uint32_t cap, uint32_t *lq_list, uint32_t *err) {
     NP2_LAUNCH(k_lq_list, run_grid(run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, lqoff, cap, lq_list, err);
 }
-static inline dim3 lq_grid(uint32_t cap) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 255) / 256, 2048))); }
+// (grid-stride kernels over a list whose length lives on the device: `cap` is the bound of its buffer — two entries per
+// exception record —, the list itself a twentieth of that; a block per 256 entries of the BOUND was 17 k blocks per
+// yeast-sized batch of which 500 found work, and an empty block still costs its two scalar loads: a block per 2048)
+static inline dim3 lq_grid(uint32_t cap) { return dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 2047) / 2048, 2048))); }
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
                     uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t n_hwords, uint32_t *rstart, uint32_t *rend) {
