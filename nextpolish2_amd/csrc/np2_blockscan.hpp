@@ -80,9 +80,11 @@ __device__ __forceinline__ uint32_t block_scan_array(uint32_t n, uint32_t *sh, L
 #pragma unroll
         for (uint32_t b = 0; b < BS_BATCH; ++b) {
             const uint32_t i0 = s0 + b * BS_TILE + threadIdx.x * BS_ITEMS;
+            const bool tile_live = s0 + b * BS_TILE < n; // (uniform: a short array — a contig's few thousand regions — has one live tile of the eight)
 #pragma unroll
             for (uint32_t k = 0; k < BS_ITEMS; ++k) { // clamped, unconditional loads: all of them are in flight at once
-                const uint32_t x = load(min(i0 + k, n - 1));
+                uint32_t x = Op::ident();
+                if (tile_live) x = load(min(i0 + k, n - 1));
                 v[b][k] = i0 + k < n ? x : Op::ident();
             }
         }
