@@ -1621,6 +1621,8 @@ void launch_cand_score(hipStream_t s, const YakDev &y, const uint32_t *cand_seq_
                        uint16_t *kscore, uint32_t *long_list, uint32_t *n_long) {
     if (!cand_cap) return;
     NP2_LAUNCH(k_cand_score, grid1(cand_cap), 256, s, y, cand_seq_off, cand_kmer, n_cand_p, min_count, kscore, long_list, n_long);
-    NP2_LAUNCH(k_cand_score_long, dim3(1024), 256, s, y, cand_seq_off, cand_seq, long_list, n_long, min_count, kscore);
+    // (a wavefront per listed candidate, grid-stride: the list — candidates longer than k — is a small part of the candidates;
+    // a fixed 1024 blocks per contig were 17 k blocks per yeast-sized batch, nearly all of them empty)
+    NP2_LAUNCH(k_cand_score_long, dim3(std::max<uint32_t>(16, std::min<uint32_t>(1024, cand_cap / 4096))), 256, s, y, cand_seq_off, cand_seq, long_list, n_long, min_count, kscore);
 }
 } // namespace np2
