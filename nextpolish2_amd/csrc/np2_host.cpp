@@ -1062,7 +1062,13 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     REFPANIC_IF(cx->yaks.empty(), "index out of bounds: opt.yak[0]");
     if ((uint64_t)n_reg * LQSEQ_MAX_CAN_COUNT >= 0xFFFFFFF0ull) throw Np2Error(NP2_E_NOMEM, "too many LQ regions");
     const uint32_t NC_cap = n_reg * LQSEQ_MAX_CAN_COUNT;
-    const uint32_t SB_cap = (uint32_t)std::min<uint64_t>(c->n_cols + 64, 0xFFFFFFF0ull);
+    // candidate strings are disjoint pieces of the reads: at most the pileup's columns.  A chromosome-sized contig does not
+    // allocate by that bound (7.7 GB for a 248 Mb contig, 1 % of it used: half a second of the context's first polish) but
+    // reads the exact byte count back once the offsets are known — a read-back of its own, ~60 us, which a contig that
+    // size does not notice and a yeast-sized batch would
+    static const uint64_t exact_from = getenv("NP2_CAND_EXACT_FROM") ? strtoull(getenv("NP2_CAND_EXACT_FROM"), nullptr, 10) : (1ull << 28); // (tests lower it)
+    const bool exact_bytes = c->n_cols >= exact_from && !cx->trace;
+    uint32_t SB_cap = (uint32_t)std::min<uint64_t>(c->n_cols + 64, 0xFFFFFFF0ull);
     cx->mval.ensure(R + 2);
     cx->smin.ensure(R + 2);
     cx->pj.ensure(R + 2);
@@ -1082,7 +1088,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     cx->cand_order.ensure((size_t)NC_cap + 2);
     cx->cand_kmer.ensure((size_t)NC_cap + 2);
     cx->cand_seq_off.ensure((size_t)NC_cap + 2);
-    cx->cand_seq.ensure((size_t)SB_cap + 64);
+    if (!exact_bytes) cx->cand_seq.ensure((size_t)SB_cap + 64);
     cx->kscore.ensure((size_t)NC_cap + 2);
     cx->long_list.ensure((size_t)NC_cap + 2);
     CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
@@ -1111,6 +1117,13 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
                                 cx->scal.p + S_NC, cx->scal.p + S_SB, cx->scal.p + S_GROW, wide ? &lb : nullptr,
                                 cx->scal.p + S_ERR);
         }
+        if (exact_bytes) {
+            const std::vector<uint32_t> sc = fetch_scal(cx);
+            check_region_err(cx, sc[S_ERR]);
+            pc.resolve(sc);
+            SB_cap = (uint32_t)std::min<uint64_t>((uint64_t)pc.SB + 64, SB_cap);
+            cx->cand_seq.ensure((size_t)SB_cap + 64);
+        }
         launch_region_write(s, cp, n_reg, cx->kept_read.p, cx->kept_len.p, cx->kept_col.p, cx->reg_ncand.p,
                             cx->reg_bytes.p, cx->blk_coff.p, cx->blk_soff.p, cx->cand_off.p, cx->reg_soff.p, NC_cap + 1,
                             SB_cap, cx->cand_order.p, cx->cand_kmer.p, cx->cand_seq_off.p, cx->cand_seq.p);
@@ -1123,7 +1136,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     pc.n_reg = n_reg;
     pc.NC_cap = NC_cap;
     pc.SB_cap = SB_cap;
-    pc.known = false;
+    pc.known = exact_bytes; // (NC / SB / grow read back above)
     if (cx->trace) pc.resolve(fetch_scal(cx));
     trace_region_tables(cx, pass, "cand", pc, false);
 }

@@ -232,3 +232,23 @@ def test_dense_passes_of_two_streams_of_one_process_side_by_side():
     for t in th:
         t.join()
     assert not bad
+
+
+def test_candidate_strings_sized_by_a_read_back():
+    """extract_candidates (csrc/np2_host.cpp): a chromosome-sized contig sizes its candidate strings by the exact byte count
+    read back after the offsets scan instead of by the pileup's column count.  With the threshold lowered to nothing
+    (NP2_CAND_EXACT_FROM, read once per process) random contig mixes through the batch driver and plain contexts are the
+    oracle's as ever."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NP2_CAND_EXACT_FROM="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_batch.py"), "922", "3"], capture_output=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().strip().splitlines()[-1].startswith("batch cases 3 bad 0"), r.stdout.decode()[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_polish.py"), "923", "25"], capture_output=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().strip().splitlines()[-1].startswith("cases 25 bad 0"), r.stdout.decode()[-2000:]
