@@ -87,7 +87,11 @@ void np2_contig_free(np2_ctx_t *ctx, np2_contig_t *c);
 
 /* The hot path on an HBM-resident contig: the loop main.rs:1819-1836.
  * Outputs (callee-allocated, release with np2_free): consensus bases (ASCII) and their
- * reference positions (ConsensusBase, main.rs:591-596). */
+ * reference positions (ConsensusBase, main.rs:591-596).
+ * Errors: results never depend on it, but WHICH error is reported can: without -r a pass starts on the reads the vote kernel
+ * flagged while the previous vote is still being decided, so an error of that later pass (NP2_E_NOMEM, a reference panic in
+ * its consensus) may be reported where the reference's sequential loop would have stopped at the vote's own panic
+ * ("weight of two conflicting community").  NP2_NO_SPECULATE=1 restores the reference's order. */
 int np2_polish_resident(np2_ctx_t *ctx, np2_contig_t *c, const np2_opts_t *opts,
                         uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
 

@@ -60,7 +60,9 @@ int np2_ctx_create_from_files(np2_ctx_t **out, int device, const char *const *pa
 
 /* ---- indexed BAM ---- */
 typedef struct np2_bam np2_bam_t;
-int np2_bam_open(const char *path, np2_bam_t **out); /* needs <path>.bai (or <stem>.bai) */
+/* needs <path>.bai (or <stem>.bai).  A handle keeps device-side staging of the FIRST context it is used with (stream, device):
+ * use one handle with contexts of one device only, one thread at a time (nextpolish2_amd.cli: a handle per front-end thread) */
+int np2_bam_open(const char *path, np2_bam_t **out);
 void np2_bam_close(np2_bam_t *b);
 int np2_bam_n_refs(np2_bam_t *b);
 const char *np2_bam_ref_name(np2_bam_t *b, int tid, uint32_t *len);
