@@ -378,7 +378,8 @@ inline CtxStatePool &ctx_state_pool() {
 struct YakTable {
     uint32_t k = 0, cap_log2 = 0;
     std::shared_ptr<DevBuf<uint64_t>> table; // shared by the contexts of one device (np2_ctx_create_shared)
-    YakDev dev() const { return YakDev{table->p, cap_log2, k}; }
+    std::shared_ptr<DevBuf<uint32_t>> ord;   // only for a dump that repeated a key (k_yak_insert_dup)
+    YakDev dev() const { return YakDev{table->p, cap_log2, k, ord ? ord->p : nullptr}; }
 };
 
 struct Timing {
@@ -513,6 +514,30 @@ struct np2_ctx {
     DevBuf<uint32_t> pf_bad, pf_bad2; // ... tiles listed for the middle / the big variant
     DevBuf<uint64_t> pf_prof;  // ... phase timers (NP2_PF_PROF)
     bool front_fused = false;  // the pass front under way went through the fused kernels (np2_passfront.hip)
+    // Test and tool switches, read ONCE when the context is created (getenv on every pass of the hot path,
+    // racing with setenv elsewhere in the process; a stray variable silently forcing a slow branch for good).  A test sets
+    // its variables before it creates its context.
+    struct Hooks {
+        bool front_unfused = false, pf_prof = false, cand_decode_all = false, edge_sort = false, dp_fork = false;
+        bool test_misspeculate = false, shard_spec_log = false, phase_profile = false, exact_grow = false, no_speculate = false;
+        bool has_grow_guess = false;
+        uint32_t grow_guess = 0;
+        bool has_pf_cap = false, has_pf_cap_big = false, has_pf_halo = false, has_pf_cov_max = false;
+        uint32_t pf_cap = 0, pf_cap_big = 0, pf_halo = 0, pf_cov_max = 0;
+        void read() {
+            auto on = [](const char *n) { return getenv(n) != nullptr; };
+            auto u32 = [](const char *n, bool &has, uint32_t &v) {
+                if (const char *e = getenv(n)) has = true, v = (uint32_t)atol(e);
+            };
+            front_unfused = on("NP2_FRONT_UNFUSED"), pf_prof = on("NP2_PF_PROF"), cand_decode_all = on("NP2_CAND_DECODE_ALL");
+            edge_sort = on("NP2_EDGE_SORT"), dp_fork = on("NP2_DP_FORK"), test_misspeculate = on("NP2_TEST_MISSPECULATE");
+            shard_spec_log = on("NP2_SHARD_SPEC_LOG"), phase_profile = on("NP2_PHASE_PROFILE"), exact_grow = on("NP2_EXACT_GROW");
+            no_speculate = on("NP2_NO_SPECULATE");
+            u32("NP2_TEST_GROW_GUESS", has_grow_guess, grow_guess);
+            u32("NP2_PF_CAP", has_pf_cap, pf_cap), u32("NP2_PF_CAP_BIG", has_pf_cap_big, pf_cap_big);
+            u32("NP2_PF_HALO", has_pf_halo, pf_halo), u32("NP2_PF_COV_MAX", has_pf_cov_max, pf_cov_max);
+        }
+    } hooks;
     bool pf_big = getenv("NP2_PF_BIG") != nullptr; // k_pf_tile_big is launched (from the first pass that needed it on; NP2_PF_BIG: always)
     uint32_t front_redos = 0;  // passes the fused front handed back to the unfused kernels (tests read it through the timings)
     DevBuf<uint16_t> kscore_saved;

@@ -286,7 +286,7 @@ void vote_collect(np2_ctx *cx, np2_contig *c, PassCounts &pc, bool asref, bool u
             return;
         }
         NU = sc[S_NRAW];
-        far = sc[S_M3] != 0 || getenv("NP2_EDGE_SORT") != nullptr; // (test hook: force the sort-based path)
+        far = sc[S_M3] != 0 || cx->hooks.edge_sort; // (test hook: force the sort-based path)
         if (!wide) {
             per_read(pin);
             have_per_read = true;
@@ -899,7 +899,7 @@ void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, u
         // (NP2_DP_FORK: the earlier scheme — short and long-run kernels side by side on two streams, each classifying
         // the runs itself; measured ~1 % slower on the E. coli-sized contig once the short kernel had become the
         // shorter of the two; kept as a tested alternative)
-        const bool forked = tl_recorder() == nullptr && getenv("NP2_DP_FORK") != nullptr;
+        const bool forked = tl_recorder() == nullptr && cx->hooks.dp_fork;
         uint32_t *dp_list = nullptr, *n_dp_list = nullptr;
         if (forked) {
             HIPCHK(hipEventRecord(cx->ev_fork, s));
@@ -930,6 +930,8 @@ void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, u
         exclusive_total(cx, cx->lqc.p, cx->lqoff.p, (size_t)n_runs + 1); // (lqc[n_runs] = 0)
         launch_lq_list(s, gp, cx->run_start.p, cx->scal.p + S_NRUNS, n_runs, cx->emit.p, cx->eoff.p, cx->bt_path.p,
                        cx->lqoff.p, lq_cap, cx->lq_list.p, cx->scal.p + S_ERR);
+        launch_default_tail(s, gp, cx->scal.p + S_BEST, M_p, cx->cns_base.p, cx->cns_cls.p, cx->lq_list.p,
+                            cx->lqoff.p + n_runs, lq_cap, cx->scal.p + S_ERR);
     }
     lq_regions_issue(cx, cb, M_p, n_lq);
 }
@@ -939,12 +941,7 @@ void consensus_and_regions_issue(np2_ctx *cx, np2_contig *c, uint32_t n_nodes, u
 // layout with k_tile_sort's position index.  A pass the fused kernels cannot hold (PF_REDO) or whose best path score is
 // negative is redone by the kernels above (pass_front_finish).
 bool front_can_fuse(np2_ctx *cx) {
-    // (read per pass, not cached: the tests switch it inside one process)
-    return getenv("NP2_FRONT_UNFUSED") == nullptr && cx->bucket_cap != 0 && cx->pidx_valid;
-}
-static uint32_t env_u32(const char *name, uint32_t dflt) {
-    const char *e = getenv(name);
-    return e ? (uint32_t)atol(e) : dflt;
+    return !cx->hooks.front_unfused && cx->bucket_cap != 0 && cx->pidx_valid;
 }
 void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
     hipStream_t s = cx->stream;
@@ -955,8 +952,9 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
     cx->pf_bad.ensure((size_t)n_tiles + 2);
     cx->pf_bad2.ensure((size_t)n_tiles + 2);
     // (test hooks: lower the LDS variants' limits so that small inputs take the big variant / the unfused redo)
-    const uint32_t cap_lim = env_u32("NP2_PF_CAP", PF_CAP), cap_big = env_u32("NP2_PF_CAP_BIG", PF_CAP_BIG),
-                   halo_lim = env_u32("NP2_PF_HALO", PF_HALO) & ~15u, cov_max = env_u32("NP2_PF_COV_MAX", PF_COV_MAX);
+    const np2_ctx::Hooks &hk = cx->hooks;
+    const uint32_t cap_lim = hk.has_pf_cap ? hk.pf_cap : PF_CAP, cap_big = hk.has_pf_cap_big ? hk.pf_cap_big : PF_CAP_BIG,
+                   halo_lim = (hk.has_pf_halo ? hk.pf_halo : PF_HALO) & ~15u, cov_max = hk.has_pf_cov_max ? hk.pf_cov_max : PF_COV_MAX;
     PfTile a{cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p, cx->tile_scan.p, cx->tile_pidx.p, cx->alive.p, c->reads.p,
              c->tile_rd_off.p, c->tile_rd.p, c->refnib.p, cx->pf_slots.p, cx->tile_nn.p, cx->tile_nr.p,
              (long long *)cx->tile_gain.p, cx->scal.p + S_PF, cx->scal.p + S_NBAD, cx->pf_bad.p, cx->scal.p + S_NBAD2, cx->pf_bad2.p,
@@ -964,7 +962,7 @@ void pass_front_fused_issue(np2_ctx *cx, np2_contig *c, uint32_t T) {
              cap_lim, cap_big, halo_lim, std::min(cov_max, cx->deep_min), cx->pf_big ? 1u : 0u};
     uint32_t *const M_p = cx->eoff.p + L;
     uint32_t *const n_lq = cx->scal.p + S_NRUNS;
-    const bool prof = getenv("NP2_PF_PROF") != nullptr && tl_recorder() == nullptr; // (phase timers of the tile kernel: a tool's switch)
+    const bool prof = cx->hooks.pf_prof && tl_recorder() == nullptr; // (phase timers of the tile kernel: a tool's switch)
     if (prof) {
         cx->pf_prof.ensure((size_t)n_tiles * 8 + 8);
         zero32(cx, cx->pf_prof.p, (size_t)n_tiles * 8, 8);
@@ -1030,7 +1028,7 @@ void pass_front_issue(np2_ctx *cx, np2_contig *c, uint32_t T, int pass, bool for
     pass_front_fused_issue(cx, c, T);
 }
 // ... and the read-back that ends the stage: consensus length, region count, the error word
-void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t T, int pass, uint32_t &M, uint32_t &n_reg) {
+void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t T, int pass, uint32_t &M, uint32_t &n_reg, bool whole_contig = true) {
     const uint32_t *M_p = cx->eoff.p + c->L;
     std::vector<uint32_t> sc = fetch_scal(cx, cx->scal.p + S_M0, M_p);
     if (cx->front_fused) {
@@ -1046,9 +1044,12 @@ void consensus_and_regions_finish(np2_ctx *cx, np2_contig *c, uint32_t T, int pa
         }
     }
     check_region_err(cx, sc[S_ERR]);
-    if (!cx->front_fused && sc[S_BEST] == 0xFFFFFFFFu)
+    // No end node at score >= 0: k_dp_finish / k_default_tail have walked back from the reference's default node
+    // (main.rs:1651,1680).  Whether the score is negative is a property of the WHOLE contig: a shard cannot tell.
+    if (!cx->front_fused && sc[S_BEST] == 0xFFFFFFFFu && !whole_contig)
         throw Np2Error(NP2_E_UNSUPPORTED,
-                       "best path score is negative at the contig end (reference would emit its default node)");
+                       "best path score is negative at the end of a shard (the reference's default node is chosen by the whole "
+                       "contig's score): polish this contig unsharded");
     M = sc[S_M0];
     if (M == 0) throw Np2Error(NP2_E_REFPANIC, "reference would panic: empty consensus");
     n_reg = sc[S_NRAW] ? sc[S_NREG] : 0;
@@ -1094,7 +1095,7 @@ void extract_candidates(np2_ctx *cx, np2_contig *c, uint32_t n_reg, uint16_t min
     CandPtrs cp{c->reads.p,   c->nib.p,   c->ck_off.p,      c->ckpt.p,    cx->lq_start.p, cx->lq_end.p, cx->pj.p,
                 cx->pcount.p, cx->alive.p, cx->rinfo.p, c->tile_rd_off.p, c->tile_rd.p, c->n_tiles, cx->yaks[0].k,
                 cx->keys_raw.p, cx->vals_raw.p, cx->tile_n.p,
-                (cx->pidx_valid && cx->bucket_cap && !getenv("NP2_CAND_DECODE_ALL")) ? cx->tile_pidx.p : nullptr, cx->bucket_cap,
+                (cx->pidx_valid && cx->bucket_cap && !cx->hooks.cand_decode_all) ? cx->tile_pidx.p : nullptr, cx->bucket_cap,
                 (const uint32_t *)c->refnib.p, c->L};
     {
         EventTimer t(cx, "candidates");
@@ -1249,7 +1250,7 @@ void run_pass_front(PolishRun &r) {
             WallTimer w(cx, "wall_cns_lq");
             if (!r.front_issued) pass_front_issue(cx, c, r.T, (int)r.pass);
             r.front_issued = false;
-            consensus_and_regions_finish(cx, c, r.T, (int)r.pass, r.M, r.n_reg);
+            consensus_and_regions_finish(cx, c, r.T, (int)r.pass, r.M, r.n_reg, !r.wide_votes);
         }
         if (cx->trace) {
             trace_cns(cx, (int)r.pass, "cns_raw", fetch_cns(cx, r.M));
@@ -1326,12 +1327,12 @@ void run_final_pass(PolishRun &r, ResultOut &result, bool exact_grow = false) {
     // the device: S_GROW).  Reading it back is a device round trip of its own; after a phasing pass its value there is
     // known — the final pass has fewer reads and mostly fewer regions — so twice that, guarded on the device, is used
     // instead, and the pass is repeated with the exact figure should a round outgrow it (never observed).
-    static const bool no_guess = getenv("NP2_EXACT_GROW") != nullptr;
+    const bool no_guess = cx->hooks.exact_grow;
     bool guessed = false;
     if (!pc.known) {
         if (r.grow_prev != 0xFFFFFFFFu && !exact_grow && !no_guess && !cx->trace && (uint64_t)r.grow_prev * 2 + 4096 < 0x7FFFFFFFull) {
             pc.grow = r.grow_prev * 2 + 4096;
-            if (const char *e = getenv("NP2_TEST_GROW_GUESS")) pc.grow = (uint32_t)atol(e); // test hook: force the retry
+            if (cx->hooks.has_grow_guess) pc.grow = cx->hooks.grow_guess; // test hook: force the retry
             guessed = true;
         } else {
             pc.resolve(fetch_scal(cx));
@@ -1374,7 +1375,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
     PolishRun r;
     r.cx = cx, r.c = c, r.o = *o;
     run_begin(r);
-    static const bool no_spec = getenv("NP2_NO_SPECULATE") != nullptr;
+    const bool no_spec = cx->hooks.no_speculate;
     const bool use_all = o->use_all_reads != 0;
     // The host side of the vote (key order, rows, Louvain: ~1 ms for a 1.5 Mb diploid contig, 100 ms for a chromosome) is
     // the longest host phase of a contig, and the device has nothing to do for it meanwhile.  Without -r the vote kernel
@@ -1408,7 +1409,7 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
             REFPANIC_IF(id >= c->R, "index out of bounds: alignseqs[id]");
             if (!pend.vd->bad[id]) extra.push_back(id);
         }
-        if (extra.empty() && d.losers.size() == pend.n_bad && !getenv("NP2_TEST_MISSPECULATE")) return true; // (test hook)
+        if (extra.empty() && d.losers.size() == pend.n_bad && !cx->hooks.test_misspeculate) return true; // (test hook)
         if (!extra.empty()) {
             cx->kill_ids.ensure(extra.size() + 1);
             h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);
@@ -1681,6 +1682,7 @@ static void init_ctx_device(np2_ctx *cx, int device) {
         throw Np2Error(NP2_E_DEVICE, "no HIP device available (the np2 hot path has no CPU fallback)");
     if (device < 0 || device >= ndev) throw Np2Error(NP2_E_ARG, "bad device index");
     cx->device = device;
+    cx->hooks.read();
     HIPCHK(hipSetDevice(device));
     CtxDeviceState st;
     if (ctx_state_pool().get(device, st)) {
@@ -1742,7 +1744,13 @@ int np2_ctx_create(np2_ctx_t **out, int device, const np2_yak_t *yaks, int n_yak
             zero32(cx, cx->scal.p, S_COUNT);
             launch_yak_insert(cx->stream, dw.p, doff.p, 1024, mx, t.table->p, cl, cx->scal.p + S_DUP);
             auto sc = d2h(cx, cx->scal.p, S_COUNT);
-            if (sc[S_DUP]) throw Np2Error(NP2_E_UNSUPPORTED, "duplicate k-mer key inside one yak bucket");
+            if (sc[S_DUP]) { // a repeated key (yak writes none): a slot per word, the winner chosen at lookup (kmer.rs:148-167)
+                t.ord = std::make_shared<DevBuf<uint32_t>>();
+                t.ord->ensure(slots);
+                HIPCHK(hipMemsetAsync(t.table->p, 0xFF, slots * 8, cx->stream));
+                launch_yak_insert_dup(cx->stream, dw.p, doff.p, 1024, mx, t.table->p, cl, t.ord->p);
+                HIPCHK(hipStreamSynchronize(cx->stream)); // (dw / doff are released at the end of this scope)
+            }
         }
     } catch (const Np2Error &e) {
         fprintf(stderr, "np2_ctx_create: %s\n", e.what());
@@ -2143,6 +2151,20 @@ int np2_shard_upload(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const np2_re
     }
 }
 
+// a block of the process-wide pinned pool for one read-back
+struct PinnedBlock {
+    void *p = nullptr;
+    explicit PinnedBlock(size_t bytes) : p(pinned_pool().get(std::max<size_t>(bytes, 64))) {
+        if (!p) throw Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+    }
+    ~PinnedBlock() {
+        if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize(); // (a copy into it may still be in flight)
+        pinned_pool().put(p);
+    }
+    PinnedBlock(const PinnedBlock &) = delete;
+    PinnedBlock &operator=(const PinnedBlock &) = delete;
+};
+
 #define NP2_SHARD_TRY(cxp, ...)                                                                      \
     try {                                                                                            \
         __VA_ARGS__                                                                                  \
@@ -2206,11 +2228,10 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
             // a staging block of its own: the pairs are still where the vote's read-back left them, in the context's.)
             std::vector<uint32_t> start(sr->run.n_reg);
             if (sr->run.n_reg) {
-                void *tmp = pinned_pool().get((size_t)sr->run.n_reg * 4 + 64);
-                op_d2h(cx, tmp, cx->lq_start.p, (size_t)sr->run.n_reg * 4);
+                PinnedBlock tmp((size_t)sr->run.n_reg * 4 + 64); // (NP2_E_NOMEM on failure; given back on every path)
+                op_d2h(cx, tmp.p, cx->lq_start.p, (size_t)sr->run.n_reg * 4);
                 op_sync(cx);
-                memcpy(start.data(), tmp, (size_t)sr->run.n_reg * 4);
-                pinned_pool().put(tmp);
+                memcpy(start.data(), tmp.p, (size_t)sr->run.n_reg * 4);
             }
             out_np = (size_t)vd.n_pairs();
             if (vd.view_key && vd.key_added) {
@@ -2248,7 +2269,7 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
         // removes exactly those -> the pass under way is the right one; it removes others too (a read flagged by the
         // neighbouring shard, a conflicting community) -> they go as well and the pass is started again.  Only kernels are
         // issued here, no read-back: the exported pairs stay valid where they are.
-        static const bool no_spec = getenv("NP2_NO_SPECULATE") != nullptr;
+        const bool no_spec = cx->hooks.no_speculate;
         sr->spec = false;
         if (vd.any && vd.d_bad && !sr->run.o.use_all_reads && !cx->trace && !no_spec) {
             size_t n_bad = 0;
@@ -2266,7 +2287,7 @@ int np2_shard_vote(np2_shard_run_t *h, np2_vote_t *out) {
                 sr->spec_n_bad = n_bad;
             }
         }
-        if (getenv("NP2_SHARD_SPEC_LOG"))
+        if (cx->hooks.shard_spec_log)
             fprintf(stderr, "[np2 shard] vote: any %d, flags on the device %d, early start %d (%zu flagged)\n", (int)vd.any, vd.d_bad != nullptr, (int)sr->spec, sr->spec_n_bad);
     })
     return NP2_OK;
@@ -2411,15 +2432,28 @@ int np2_shard_apply(np2_shard_run_t *h, const uint32_t *losers, uint32_t n) {
         }
         if (sr->spec) { // the pass is under way on the flagged reads (np2_shard_vote): is it the right one?
             sr->spec = false;
-            std::vector<uint32_t> extra;
+            std::vector<uint32_t> extra, spared;
             size_t n_flagged = 0;
+            std::vector<uint8_t> removed(sr->run.c->R, 0);
             for (uint32_t id : local) {
                 REFPANIC_IF(id >= sr->run.c->R, "index out of bounds: alignseqs[id]");
+                removed[id] = 1;
                 if (sr->spec_bad[id]) ++n_flagged; else extra.push_back(id);
             }
-            if (n_flagged != sr->spec_n_bad) throw Np2Error(NP2_E_DEVICE, "internal: a read flagged by the vote kernel is not among the removed reads");
-            if (getenv("NP2_SHARD_SPEC_LOG")) fprintf(stderr, "[np2 shard] apply: %zu removed here, %zu beyond the flagged ones\n", local.size(), extra.size());
-            if (!extra.empty() || getenv("NP2_TEST_MISSPECULATE")) { // (test hook: the redo branch)
+            // A decision that KEEPS a read the vote kernel flagged (a replayed or custom loser list; the reference's own
+            // decision removes every flagged read, main.rs:977) is a misspeculation like any other: the read was alive
+            // before the vote, it comes back, and the pass starts again.
+            if (n_flagged != sr->spec_n_bad)
+                for (uint32_t id = 0; id < sr->run.c->R; ++id)
+                    if (sr->spec_bad[id] && !removed[id]) spared.push_back(id);
+            if (cx->hooks.shard_spec_log) fprintf(stderr, "[np2 shard] apply: %zu removed here, %zu beyond the flagged ones, %zu flagged ones kept\n", local.size(), extra.size(), spared.size());
+            if (!extra.empty() || !spared.empty() || cx->hooks.test_misspeculate) { // (test hook: the redo branch)
+                if (!spared.empty()) {
+                    cx->kill_ids.ensure(spared.size() + 1);
+                    h2d_staged(cx, cx->kill_ids.p, spared.data(), spared.size() * 4);
+                    launch_revive_reads(cx->stream, cx->kill_ids.p, (uint32_t)spared.size(), cx->alive.p);
+                    op_sync(cx); // (the staging buffer is reused for the other list right away)
+                }
                 if (!extra.empty()) {
                     cx->kill_ids.ensure(extra.size() + 1);
                     h2d_staged(cx, cx->kill_ids.p, extra.data(), extra.size() * 4);

@@ -1552,7 +1552,13 @@ void yak_file_to_table(YakFile &yf, int device, hipStream_t given) {
         uint32_t *dup = (uint32_t *)pin[1];
         HIPCHK(hipMemcpyAsync(dup, d_dup.p, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (*dup) fail(NP2_E_UNSUPPORTED, "duplicate k-mer key inside one yak bucket");
+        if (*dup) { // a repeated key (yak writes none): a slot per word, the winner chosen at lookup (kmer.rs:148-167)
+            yf.table.ord = std::make_shared<np2h::DevBuf<uint32_t>>();
+            yf.table.ord->ensure(slots);
+            HIPCHK(hipMemsetAsync(yf.table.table->p, 0xFF, slots * 8, st));
+            np2::launch_yak_insert_dup(st, d_raw.p, d_off.p, (uint32_t)nb, mx, yf.table.table->p, cl, yf.table.ord->p, 1);
+            HIPCHK(hipStreamSynchronize(st));
+        }
         if (prof)
             fprintf(stderr, "yak dump -> table (k=%u, %.0f MB): bucket headers %.2f ms, device + staging allocations %.2f ms, read + copy %.2f ms, "
                             "insert %.2f ms\n", yf.k, yf.size / 1e6, t1 - t0, t2 - t1, t3 - t2, np2h::now_ms() - t3);

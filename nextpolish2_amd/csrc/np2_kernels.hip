@@ -121,6 +121,10 @@ __device__ __forceinline__ void k_kill_reads(const uint32_t np2_bid, const uint3
     uint32_t i = np2_bid * blockDim.x + threadIdx.x;
     if (i < n) alive[ids[i]] = 0;
 }
+__device__ __forceinline__ void k_revive_reads(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ ids, uint32_t n, uint8_t *__restrict__ alive) {
+    uint32_t i = np2_bid * blockDim.x + threadIdx.x;
+    if (i < n) alive[ids[i]] = 1;
+}
 
 // ------------------------------------------------------------------------------------------
 // sparse-graph accessors.  Node index 0 at a position is the contig's implicit node N0(p);
@@ -874,7 +878,10 @@ __device__ __forceinline__ void k_dp_bt_short(const uint32_t np2_bid, const uint
 }
 
 // global best node at L-1 (main.rs:1651,1680): later node wins ties, must reach score >= 0
-__device__ uint32_t pick_best(const Graph &g, const int64_t *__restrict__ nscore, int64_t last_n0_score, int64_t total) {
+// (run_a: first position of the run that reaches the contig end.  From position 3 on the run's scores are relative to the
+// node left of it — except those of READ-START nodes, whose score is the absolute 10 count - 4 coverage, main.rs:1659-1660:
+// a read that starts at the very last position competes with that, not with the path's total added on top)
+__device__ uint32_t pick_best(const Graph &g, const int64_t *__restrict__ nscore, int64_t last_n0_score, int64_t total, uint32_t run_a) {
     const uint32_t p = g.L - 1;
     const uint32_t o0 = g.node_off[p], o1 = g.node_off[p + 1];
     if (o1 == o0) return total >= 0 ? 0u : 0xFFFFFFFFu;
@@ -882,7 +889,8 @@ __device__ uint32_t pick_best(const Graph &g, const int64_t *__restrict__ nscore
     uint32_t bi = 0xFFFFFFFFu;
     for (uint32_t idx = 0; idx < 1 + (o1 - o0); ++idx) {
         const int64_t rel = idx ? nscore[o0 + idx - 1] : last_n0_score;
-        const int64_t s = rel <= (SCORE_NEG / 2) ? rel : total + rel;
+        const bool start_node = idx && run_a >= 3 && ((g.nrec[o0 + idx - 1].x >> 4) & 0xFu) == 15u;
+        const int64_t s = (rel <= (SCORE_NEG / 2) || start_node) ? rel : total + rel;
         if (s >= best) {
             best = s;
             bi = idx;
@@ -975,13 +983,37 @@ __device__ __forceinline__ void k_dp_finish(const uint32_t np2_bid, const uint32
     __threadfence();
     const int64_t total = (int64_t)atomicAdd(total_gain, 0ULL); // (the device-coherent value)
     const uint32_t L = g.L;
-    const uint32_t best = pick_best(g, nscore, *last_n0_score, total);
+    const uint32_t best = pick_best(g, nscore, *last_n0_score, total, nr ? run_start[nr - 1] : 0u);
     *best_idx = best;
-    if (nr != 0 && g.node_off[L] != g.node_off[L - 1]) {
+    if (best == 0xFFFFFFFFu) {
+        // No node at L - 1 reaches a score >= 0: the reference walks back from its DEFAULT Kmer (main.rs:1651: bases = 0,
+        // count = 0, besti = 0; main.rs:1564, 1569-1570: an 'A' at L - 1 whose qv is 0 — low quality unless the coverage
+        // is below 2 —, then node 0 of position L - 2, i.e. N0(L - 2), and on along the recorded best predecessors).
+        const uint64_t tail = ((uint64_t)(L - 1) << 32) | ((uint32_t)'A' << 8) | (g.cov[L - 1] < 2 ? CLS_RESET : CLS_LQ);
+        if (nr != 0 && g.node_off[L] != g.node_off[L - 1]) { // the last position is dirty: its run's path starts with the 'A'
+            const uint32_t a = run_start[nr - 1];
+            uint64_t *sl = path + (size_t)a + g.node_off[a];
+            sl[0] = tail;
+            emit[a] = 1u + (a + 2 <= L ? bt_walk(g, a, L - 2, 0u, nbesti, n0_besti, path_begin, sl + 1) : 0u);
+        } else if (nr != 0 && g.node_off[L - 1] != g.node_off[L - 2]) {
+            // L - 1 is clean (k_default_tail rewrites its base), the run ending at L - 2 was entered at N0(L - 1)'s best
+            // predecessor: walked again from N0(L - 2).  The earlier walk may have left a path start behind (positions
+            // 1 and 2 only, main.rs:1666-1668): the few runs that can set one are walked again as well.
+            const uint32_t a = run_start[nr - 1];
+            if (a <= 2) {
+                *path_begin = 0;
+                for (uint32_t r = 0; r + 1 < nr && run_start[r] <= 2; ++r) {
+                    const uint32_t ar = run_start[r];
+                    uint32_t e = ar;
+                    while (g.node_off[e + 2] != g.node_off[e + 1]) ++e; // (the last run follows: e + 1 < L)
+                    emit[ar] = bt_walk(g, ar, e, n0_besti[e + 1], nbesti, n0_besti, path_begin, path + (size_t)ar + g.node_off[ar]);
+                }
+            }
+            emit[a] = bt_walk(g, a, L - 2, 0u, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
+        }
+    } else if (nr != 0 && g.node_off[L] != g.node_off[L - 1]) {
         const uint32_t a = run_start[nr - 1];
-        // (a negative best score at the contig end is reported by the host after its next read-back)
-        emit[a] = best == 0xFFFFFFFFu ? 0u
-                                      : bt_walk(g, a, L - 1, best, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
+        emit[a] = bt_walk(g, a, L - 1, best, nbesti, n0_besti, path_begin, path + (size_t)a + g.node_off[a]);
     }
     const uint32_t pb = atomicMax(path_begin, 0u);
     uint32_t p = 0;
@@ -1054,6 +1086,26 @@ __device__ __forceinline__ void k_cns_runs(const uint32_t np2_bid, const uint32_
         n_lq += __shfl_xor(n_lq, 1);
         n_lq += __shfl_xor(n_lq, 2);
         if (q == 0) lqc[r] = n_lq;
+    }
+}
+// The reference's default node at a CLEAN last position (k_dp_finish has the rest): the base written there becomes 'A'
+// with qv 0 (main.rs:1564-1575) — the last consensus entry, and the last of the low-quality list if coverage >= 2.
+__device__ __forceinline__ void k_default_tail(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ best_idx,
+                                               const uint32_t *__restrict__ node_off, const uint8_t *__restrict__ pflag, uint32_t L,
+                                               const uint32_t *__restrict__ M_p, uint8_t *__restrict__ cns_base,
+                                               uint8_t *__restrict__ cns_cls, uint32_t *__restrict__ lq_list,
+                                               uint32_t *__restrict__ n_lq, uint32_t cap, uint32_t *__restrict__ err) {
+    if (threadIdx.x || np2_bid) return;
+    if (*best_idx != 0xFFFFFFFFu || node_off[L] != node_off[L - 1]) return;
+    const uint32_t M = *M_p;
+    if (!M) return;
+    cns_base[M - 1] = (uint8_t)'A';
+    const bool lq = !(pflag[L - 1] & 2);
+    cns_cls[M - 1] = lq ? CLS_LQ : CLS_RESET;
+    if (lq) {
+        const uint32_t n = *n_lq;
+        if (n >= cap) atomicOr(err, LQ_LIST_ERR);
+        else lq_list[n] = M - 1, *n_lq = n + 1;
     }
 }
 // the consensus indices of the low-quality bases, ascending (runs are in position order): one thread per run that has any
@@ -1344,12 +1396,44 @@ __global__ void k_yak_insert(const uint64_t *__restrict__ words, const uint64_t 
     }
 }
 
+// A dump that repeats a key inside a bucket (yak never writes one): every word keeps a slot of its own and `ord` holds
+// its index in the bucket's file order.  retrieve_kmers (kmer.rs:148-167) streams the file and REPLACES the candidate's
+// entry with every word that passes `count >= min_count`, so the last such word in file order is what get() returns.
+__global__ void k_yak_insert_dup(const uint64_t *__restrict__ words, const uint64_t *__restrict__ bucket_off,
+                                 uint32_t n_buckets, uint64_t *__restrict__ table, uint32_t cap_log2,
+                                 uint32_t *__restrict__ ord, uint32_t gap) {
+    const uint32_t b = blockIdx.y;
+    if (b >= n_buckets) return;
+    const uint64_t n = bucket_off[b + 1] - bucket_off[b] - gap;
+    const uint64_t capm = (1ULL << cap_log2) - 1;
+    uint64_t *tb = table + ((uint64_t)b << cap_log2);
+    uint32_t *ob = ord + ((uint64_t)b << cap_log2);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = words[bucket_off[b] + i];
+        uint64_t s = (w >> 10) & capm;
+        while (atomicCAS((unsigned long long *)&tb[s], (unsigned long long)YAK_EMPTY, (unsigned long long)w) != YAK_EMPTY)
+            s = (s + 1) & capm;
+        ob[s] = (uint32_t)i; // (read by later launches only)
+    }
+}
+
 __device__ __forceinline__ uint16_t yak_get(const YakDev &y, uint64_t x, uint16_t min_count) {
     // KmerInfo::get after retrieve_kmers(min_count) (kmer.rs:123-125,160-166), unwrap_or(0)
     const uint64_t capm = (1ULL << y.cap_log2) - 1;
     const uint64_t *tb = y.table + ((x & 1023) << y.cap_log2);
     const uint64_t key = x >> 10;
     uint64_t s = key & capm;
+    if (y.ord) { // repeated keys: the whole probe cluster, last passing word in file order
+        const uint32_t *ob = y.ord + ((x & 1023) << y.cap_log2);
+        uint16_t c = 0;
+        int64_t at = -1;
+        for (;;) {
+            const uint64_t w = tb[s];
+            if (w == YAK_EMPTY) return c;
+            if ((w >> 10) == key && (uint16_t)(w & 1023) >= min_count && (int64_t)ob[s] > at) at = ob[s], c = (uint16_t)(w & 1023);
+            s = (s + 1) & capm;
+        }
+    }
     for (;;) {
         const uint64_t w = tb[s];
         if (w == YAK_EMPTY) return 0;
@@ -1523,6 +1607,9 @@ void launch_kill_flagged(hipStream_t s, const uint8_t *flag, uint32_t n, uint8_t
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
     if (n) NP2_LAUNCH(k_kill_reads, grid1(n), 256, s, ids, n, alive);
 }
+void launch_revive_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive) {
+    if (n) NP2_LAUNCH(k_revive_reads, grid1(n), 256, s, ids, n, alive);
+}
 static Graph mk_graph(const GraphPtrs &gp) { return Graph{gp.refnib, gp.node_off, gp.nd, gp.cov, gp.L, gp.nrec, gp.deep}; } // (pflag: write-out only)
 
 void launch_dp_short(hipStream_t s, const GraphPtrs &gp, const void *refw, const uint32_t *run_start,
@@ -1559,6 +1646,10 @@ void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_star
                     uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                     const uint32_t *lqoff, uint32_t cap, uint32_t *lq_list, uint32_t *err) {
     NP2_LAUNCH(k_lq_list, run_grid(run_bound), 256, s, run_start, n_runs, run_bound, gp.node_off, emit, eoff, path, lqoff, cap, lq_list, err);
+}
+void launch_default_tail(hipStream_t s, const GraphPtrs &gp, const uint32_t *best_idx, const uint32_t *M_p, uint8_t *cns_base,
+                         uint8_t *cns_cls, uint32_t *lq_list, uint32_t *n_lq, uint32_t cap, uint32_t *err) {
+    NP2_LAUNCH(k_default_tail, 1, 64, s, best_idx, gp.node_off, gp.pflag, gp.L, M_p, cns_base, cns_cls, lq_list, n_lq, cap, err);
 }
 // (grid-stride kernels over a list whose length lives on the device: `cap` is the bound of its buffer — two entries per
 // exception record —, the list itself a twentieth of that; a block per 256 entries of the BOUND was 17 k blocks per
@@ -1607,6 +1698,13 @@ void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *buc
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_yak_insert, dim3(gx, n_buckets), dim3(256), 0, s, words, bucket_off, n_buckets, table,
                        cap_log2, dup_flag, gap);
+}
+void launch_yak_insert_dup(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
+                           uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *ord, uint32_t gap) {
+    uint32_t gx = (uint32_t)((max_bucket + 255) / 256);
+    gx = std::min<uint32_t>(64, std::max<uint32_t>(1, gx));
+    hipLaunchKernelGGL(k_yak_insert_dup, dim3(gx, n_buckets), dim3(256), 0, s, words, bucket_off, n_buckets, table,
+                       cap_log2, ord, gap);
 }
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count,
                    uint16_t *out) {

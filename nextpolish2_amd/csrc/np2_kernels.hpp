@@ -85,6 +85,7 @@ struct YakDev {
     const uint64_t *table; // 1024 sub-tables of (1 << cap_log2) slots
     uint32_t cap_log2;
     uint32_t k;
+    const uint32_t *ord; // nullptr unless the dump repeated a key: a slot's index in its bucket's file order (k_yak_insert_dup)
 };
 
 // refnib: [0, stride) the contig's codes, position p in nibble p & 1 of byte p >> 1; [stride, 2 stride) and [2 stride,
@@ -106,6 +107,7 @@ void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes
 void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);
 void launch_kill_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive);
+void launch_revive_reads(hipStream_t s, const uint32_t *ids, uint32_t n, uint8_t *alive); // alive[ids[i]] = 1 (np2_shard_apply)
 void launch_kill_flagged(hipStream_t s, const uint8_t *flag, uint32_t n, uint8_t *alive); // alive[i] = 0 where flag[i]
 // DP + backtrack of the dirty runs.  Short runs: one fused on-chip kernel; long runs and the run reaching the contig end:
 // the generic kernel (independent of the first: the two may run on different streams); finish: score total, best end
@@ -133,6 +135,9 @@ void launch_bt_write(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_sta
 void launch_lq_list(hipStream_t s, const GraphPtrs &gp, const uint32_t *run_start, const uint32_t *n_runs,
                     uint32_t run_bound, const uint32_t *emit, const uint32_t *eoff, const uint64_t *path,
                     const uint32_t *lqoff, uint32_t cap, uint32_t *lq_list, uint32_t *err);
+// main.rs:1651,1680 with no end node at score >= 0: the default node's 'A' at a clean last position (see k_dp_finish)
+void launch_default_tail(hipStream_t s, const GraphPtrs &gp, const uint32_t *best_idx, const uint32_t *M_p, uint8_t *cns_base,
+                         uint8_t *cns_cls, uint32_t *lq_list, uint32_t *n_lq, uint32_t cap, uint32_t *err);
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
                     uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t n_hwords, uint32_t *rstart, uint32_t *rend);
@@ -153,6 +158,10 @@ void launch_read_m(hipStream_t s, const np2_read_t *reads, uint32_t R, const uin
                    uint32_t n_reg, int32_t *mval);
 void launch_yak_insert(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
                        uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *dup_flag, uint32_t gap = 0);
+// a dump that repeats a key: the table refilled (the caller has reset it to EMPTY) with a slot per WORD and `ord[slot]` =
+// the word's index in its bucket (kmer.rs:148-167: the last word that passes min_count wins, decided at lookup)
+void launch_yak_insert_dup(hipStream_t s, const uint64_t *words, const uint64_t *bucket_off, uint32_t n_buckets,
+                           uint64_t max_bucket, uint64_t *table, uint32_t cap_log2, uint32_t *ord, uint32_t gap = 0);
 void launch_lookup(hipStream_t s, const YakDev &y, const uint64_t *hashes, uint64_t n, uint16_t min_count, uint16_t *out);
 void launch_score_strings(hipStream_t s, const YakDev &y, const uint8_t *strs, const uint64_t *off, uint64_t n,
                           uint16_t min_count, uint16_t *out, bool own_strings);

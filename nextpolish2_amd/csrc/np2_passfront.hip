@@ -567,10 +567,18 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         } else if (start + q == L) {
             // the run reaches the contig end: the best end node (main.rs:1651,1680: the last one of maximal score; that the
             // score is >= 0 is checked by the host against the total of all gains: end_rel + total)
+            // A read-start node's score is the absolute 10 count - 4 coverage (main.rs:1659-1660), the others' are relative
+            // to the node left of the run (a >= 3): one with a negative score can never be chosen (the choice starts at the
+            // default node's 0), one that reaches 0 — a read starting at the very last position with more copies than the
+            // pileup is deep there — competes with the path's total, which only k_dp_finish knows: the pass is handed back.
             int32_t best = pv_s0;
             uint32_t bi = 0;
             for (uint32_t k = 0; k < pv_n; ++k) {
                 const int32_t sc = s_score[pv_k0 + k];
+                if (a >= 3 && ((s_nkey[pv_k0 + k] >> 4) & 0xFu) == 15u) {
+                    if (sc >= 0) atomicOr(A.flags, PF_REDO);
+                    continue;
+                }
                 if (sc >= best) best = sc, bi = k + 1;
             }
             gain -= base;

@@ -13,11 +13,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <unordered_map>
 #include <unordered_set>
 #include <memory>
+#include <mutex>
 #include <exception>
 #include <thread>
 #include <utility>
@@ -55,7 +57,14 @@ template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F f) {
         }
     };
     std::vector<std::thread> th;
-    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { guarded(t, n * t / T, n * (t + 1) / T); });
+    th.reserve(T);
+    for (size_t t = 1; t < T; ++t) {
+        try {
+            th.emplace_back([&, t] { guarded(t, n * t / T, n * (t + 1) / T); });
+        } catch (...) { // (no thread to be had: the piece runs here; the threads already started are joined below)
+            guarded(t, n * t / T, n * (t + 1) / T);
+        }
+    }
     guarded(0, (size_t)0, n / T);
     for (auto &x : th) x.join();
     for (auto &e : err)
@@ -314,7 +323,14 @@ template <class F> void parallel_each(size_t T, F f) {
         }
     };
     std::vector<std::thread> th;
-    for (size_t t = 1; t < T; ++t) th.emplace_back([&, t] { guarded(t); });
+    th.reserve(T);
+    for (size_t t = 1; t < T; ++t) {
+        try {
+            th.emplace_back([&, t] { guarded(t); });
+        } catch (...) { // (no thread to be had: the piece runs here; the threads already started are joined below)
+            guarded(t);
+        }
+    }
     guarded(0);
     for (auto &x : th) x.join();
     for (auto &e : err)
@@ -322,6 +338,37 @@ template <class F> void parallel_each(size_t T, F f) {
 }
 struct Graph {
     typedef std::pair<uint32_t, float> Edge;
+    typedef std::vector<Edge, NoInitAlloc<Edge>> EdgeVec;
+    // The edge array of a chromosome's first-level graph is 150-300 MB.  Giving it back to the kernel page by page took
+    // as long as a sweep over it, and the next vote's array faulted the same pages in again (most of its "fill"): ONE
+    // retired array is kept for the next large graph of the process instead (rounds 4-5 freed it on a detached thread,
+    // which could outlive the library's image: ADVICE round 5).
+    struct Spare {
+        std::mutex m;
+        EdgeVec v;
+    };
+    static Spare &spare() {
+        static Spare *s = new Spare(); // (leaked on purpose: no destructor order to get wrong at exit)
+        return *s;
+    }
+    static void retire(EdgeVec &&v) {
+        Spare &sp = spare();
+        std::lock_guard<std::mutex> lk(sp.m);
+        if (v.capacity() > sp.v.capacity()) sp.v.swap(v);
+        // (the smaller of the two is freed here, on the caller's thread)
+    }
+    void edges_resize(size_t n) { // edges.resize(n), out of the retired array if that one is large enough and ours is not
+        if (n > edges.capacity() && n >= ((size_t)1 << 20)) {
+            Spare &sp = spare();
+            std::lock_guard<std::mutex> lk(sp.m);
+            if (sp.v.capacity() >= n) {
+                edges.swap(sp.v);
+                sp.v = EdgeVec();
+            }
+        }
+        edges.resize(n);
+    }
+    bool rows_sorted = false; // every row: its neighbours below it ascending, then those above it ascending (a vote's rows)
     // row iteration helper
     struct Row {
         const Edge *b, *e;
@@ -332,7 +379,7 @@ struct Graph {
     OrderSet keys;
     std::vector<uint8_t> is_key; // dense mirror of `keys` (membership tests without hashing)
     std::vector<uint32_t> off;   // CSR row offsets, n_ids() + 1 entries
-    std::vector<Edge, NoInitAlloc<Edge>> edges; // directed copies of the undirected edges, grouped by source node
+    EdgeVec edges; // directed copies of the undirected edges, grouped by source node
 
     uint32_t n_ids() const { return (uint32_t)is_key.size(); }
     void reserve_ids(uint32_t n) {
@@ -356,6 +403,7 @@ struct Graph {
     template <class GetA, class GetB, class GetW>
     bool add_edges(uint64_t n, GetA ga, GetB gb, GetW gw, const uint8_t *skip = nullptr) {
         const uint32_t N = n_ids();
+        rows_sorted = false;
         off.assign((size_t)N + 1, 0);
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t a = ga(i), b = gb(i);
@@ -453,7 +501,8 @@ struct Graph {
         parallel_each(T, [&](size_t t) { scan(t, false); });
         const double t2 = now();
         for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v] + n_lo[v];
-        edges.resize(off[N]);
+        edges_resize(off[N]);
+        rows_sorted = true;
         const double t3 = now();
         parallel_each(T, [&](size_t t) { scan(t, true); });
         if (prof) fprintf(stderr, "    rows: check %.2f ms, count %.2f ms, offsets + allocation %.2f ms, fill %.2f ms (%zu threads, largest b - a %u)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, T, maxgap);
@@ -515,7 +564,8 @@ struct Graph {
         for (uint8_t b : bad_t)
             if (b) return false;
         for (uint32_t v = 0; v < N; ++v) off[v + 1] += off[v] + n_lo[v];
-        edges.resize(off[N]);
+        edges_resize(off[N]);
+        rows_sorted = true;
         run(true);
         return true;
     }
@@ -540,6 +590,7 @@ struct Graph {
         is_key.assign(n, 0);
         off.assign((size_t)n + 1, 0);
         edges.clear();
+        rows_sorted = false;
         next_row_ = 0;
     }
     void append_row(uint32_t a, const std::vector<Edge> &row) { // a >= every earlier a
@@ -630,137 +681,217 @@ class SignedLouvain {
         // pure function of its neighbours' community ids, so a node none of whose neighbours moved since its last
         // evaluation cannot move: only "dirty" nodes are evaluated (same visit order, identical outcome).
         //
-        // Sweeps after the first one of a large graph move next to nothing (a chromosome's read graph: 272 k nodes evaluated,
-        // 60 moved), but every node is dirty, because all of its neighbours moved in the first sweep.  Such a sweep is
-        // evaluated AHEAD, on all threads, against the state the sweep starts from; the sweep itself then walks the nodes
-        // in order and takes a node's pre-computed decision unless one of its neighbours has moved earlier in this very
-        // sweep — then, and for nodes that became dirty during the sweep, the decision is computed on the spot as before.
-        // A pre-computed decision saw exactly the neighbour communities the serial sweep would show it, so it is the same.
-        bool moved_any = false;
+        // EXACT DECOMPOSITION OVER COMPONENTS (round 6).  The move rule has no global term: the gain of a node towards a
+        // community is the sum of its OWN edges into it (louvain.rs:84-96), a move touches the member sets of the two
+        // communities only (:103-105), and a community never holds nodes of two connected components (a node only ever
+        // joins the community of a neighbour).  So what a sweep does inside one component depends on nothing outside it:
+        // the state of a component after the reference's global sweeps is the state after the same sweeps restricted to
+        // its nodes in the same ascending order, a sweep over a component that has converged is a no-op (the reference's
+        // outer loop (:78-114) just keeps visiting it), and each community's sequence of member inserts / removes — the one
+        // thing whose ORDER is observable later, through the iteration order of a declustered community's hash set — comes
+        // from one component.  Components are therefore swept to convergence independently, on all threads.  Reads are
+        // numbered in start order and a read votes with its neighbours along the contig, so the cheap exact partition is by
+        // CUT POINTS: an id c such that no edge joins an id below c to one at or above it (prefix maximum of the rows'
+        // largest neighbours, O(nodes)); a piece between two cuts is a union of whole components.
+        //
+        // Sweeps after the first one of a large piece move next to nothing (a chromosome's read graph: 272 k nodes evaluated,
+        // 60 moved), but every node is dirty, because all of its neighbours moved in the first sweep.  When the graph is
+        // ONE piece such a sweep is evaluated AHEAD, on all threads, against the state the sweep starts from; the sweep
+        // itself then walks the nodes in order and takes a node's pre-computed decision unless one of its neighbours has
+        // moved earlier in this very sweep — then, and for nodes that became dirty during the sweep, the decision is
+        // computed on the spot as before.  A pre-computed decision saw exactly the neighbour communities the serial sweep
+        // would show it, so it is the same.
         std::vector<uint32_t> visit; // the keys in ascending order (louvain.rs:77: sorted): a scan of the dense mirror
         visit.reserve(g_.keys.size());
         for (uint32_t v = 0; v < g_.n_ids(); ++v)
             if (g_.has_key(v)) visit.push_back(v);
         std::vector<uint8_t> dirty(g_.n_ids(), 1);
-        if (level0_) oplog_.reserve(2 * visit.size()); // (the first sweep moves nearly every node: two log entries each)
         // gains per neighbouring community: a slot per community id, valid for the node whose stamp it carries (in the
-        // first sweep every neighbour is a community of its own: a list searched per edge was quadratic in the degree)
+        // first sweep every neighbour is a community of its own: a list searched per edge was quadratic in the degree).
+        // Shared by the pieces: a piece only touches the slots of its own ids.
         std::vector<float> acc(g_.n_ids(), 0.f);
-        std::vector<uint32_t> stamp(g_.n_ids(), 0u), touched;
-        uint32_t tick = 0;
-        // decision of v against the current state: the community it moves to, or its own
-        // (mark_all: the first sweep, in which nearly every node moves, flags the neighbours while it reads them — one walk
-        // over the row instead of two; a node flagged without cause is evaluated once more and stays where it is)
-        bool mark_all = false;
-        auto decide = [&](uint32_t v) -> uint32_t {
-            const uint32_t cur = node_id_[v];
-            touched.clear();
-            if (++tick == 0) { // (the stamps wrapped: start over)
-                std::fill(stamp.begin(), stamp.end(), 0u);
-                tick = 1;
-            }
-            for (const auto &e : g_.adj(v)) {
-                if (mark_all) dirty[e.first] = 1;
-                const uint32_t c = node_id_[e.first];
-                if (stamp[c] != tick) {
-                    stamp[c] = tick;
-                    acc[c] = e.second;
-                    touched.push_back(c);
-                } else {
-                    acc[c] += e.second; // (edge order, like the list it replaces)
-                }
-            }
-            if (touched.empty()) return cur;
-            uint32_t bc = touched[0]; // max weight, ties -> smaller community id (louvain.rs:99-101)
-            float bw = acc[bc];
-            for (size_t i = 1; i < touched.size(); ++i) {
-                const uint32_t c = touched[i];
-                if (acc[c] > bw || (acc[c] == bw && c < bc)) bc = c, bw = acc[c];
-            }
-            return bw > 0.f ? bc : cur;
-        };
-        static constexpr uint32_t NO_GUESS = 0xFFFFFFFFu;
-        std::vector<uint32_t> ahead;      // pre-computed decisions of this sweep (NO_GUESS: none)
-        std::vector<uint32_t> stale;      // sweep in which a neighbour of the node last moved (0: never)
-        uint32_t sweep = 0;
-        size_t last_moved = 0;
-        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+        std::vector<uint32_t> stamp(g_.n_ids(), 0u);
         static const bool no_ahead = getenv("NP2_VOTE_NO_AHEAD") != nullptr; // (A/B and tests)
         static const size_t ahead_min = getenv("NP2_VOTE_AHEAD_MIN") ? (size_t)atol(getenv("NP2_VOTE_AHEAD_MIN")) : (size_t)1 << 15; // (tests: small graphs too)
-        for (bool again = true; again;) {
-            again = false;
-            ++sweep;
-            mark_all = sweep == 1 && level0_;
-            size_t n_eval = 0, n_moved = 0, n_taken = 0;
-            const auto t_sw = std::chrono::steady_clock::now();
-            const bool use_ahead = !no_ahead && sweep > 1 && visit.size() >= ahead_min && last_moved >= ahead_min / 64 && host_threads() > 1; // (many moves in the last sweep: many dirty nodes now)
-            if (use_ahead) {
-                ahead.assign(g_.n_ids(), NO_GUESS);
-                if (stale.empty()) stale.assign(g_.n_ids(), 0u);
-                parallel_ranges(visit.size(), 4096, [&](unsigned, size_t lo, size_t hi) {
-                    std::vector<std::pair<uint32_t, float>> local; // (a node's neighbours lie in a handful of communities by now)
-                    for (size_t i = lo; i < hi; ++i) {
-                        const uint32_t v = visit[i];
-                        if (!dirty[v]) continue;
-                        local.clear();
-                        bool give_up = false;
-                        for (const auto &e : g_.adj(v)) {
-                            const uint32_t c = node_id_[e.first];
-                            bool hit = false;
-                            for (auto &l : local)
-                                if (l.first == c) {
-                                    l.second += e.second; // (exact small-integer sums: the order does not matter)
-                                    hit = true;
-                                    break;
-                                }
-                            if (!hit) {
-                                if (local.size() >= 48) {
-                                    give_up = true;
-                                    break;
-                                }
-                                local.emplace_back(c, e.second);
-                            }
-                        }
-                        if (give_up) continue;
-                        uint32_t to = node_id_[v];
-                        if (!local.empty()) {
-                            uint32_t bc = local[0].first;
-                            float bw = local[0].second;
-                            for (size_t k = 1; k < local.size(); ++k)
-                                if (local[k].second > bw || (local[k].second == bw && local[k].first < bc)) bc = local[k].first, bw = local[k].second;
-                            if (bw > 0.f) to = bc;
-                        }
-                        ahead[v] = to;
-                    }
-                });
-            }
-            for (uint32_t v : visit) {
-                if (!dirty[v]) continue;
-                dirty[v] = 0;
-                ++n_eval;
+        static const bool no_pieces = getenv("NP2_VOTE_NO_PIECES") != nullptr; // (A/B and tests: one piece, as before round 6)
+        static const size_t pieces_min = getenv("NP2_VOTE_PIECES_MIN") ? (size_t)atol(getenv("NP2_VOTE_PIECES_MIN")) : (size_t)1 << 13; // (tests: small graphs too)
+        const bool prof = getenv("NP2_PHASE_PROFILE") != nullptr;
+        std::vector<uint32_t> ahead; // pre-computed decisions of a sweep (NO_GUESS: none), one-piece graphs only
+        std::vector<uint32_t> stale; // sweep in which a neighbour of the node last moved (0: never)
+        static constexpr uint32_t NO_GUESS = 0xFFFFFFFFu;
+        typedef std::vector<std::pair<uint32_t, int64_t>> OpLog;
+
+        // all sweeps over visit[lo, hi) — a union of whole components — until one moves nothing
+        auto sweep_piece = [&](size_t lo, size_t hi, OpLog &log, bool whole_graph) -> bool {
+            bool moved_any = false;
+            std::vector<uint32_t> touched;
+            uint32_t tick = 0;
+            const uint32_t id_lo = visit[lo], id_hi = visit[hi - 1] + 1; // (the piece's ids: its share of stamp[] / acc[])
+            // decision of v against the current state: the community it moves to, or its own
+            // (mark_all: the first sweep, in which nearly every node moves, flags the neighbours while it reads them — one
+            // walk over the row instead of two; a node flagged without cause is evaluated once more and stays where it is)
+            bool mark_all = false;
+            auto decide = [&](uint32_t v) -> uint32_t {
                 const uint32_t cur = node_id_[v];
-                uint32_t to;
-                const bool fresh = use_ahead && ahead[v] != NO_GUESS && stale[v] != sweep; // (stale: a neighbour moved earlier in this sweep)
-                if (fresh) to = ahead[v], ++n_taken;
-                else to = decide(v);
-                if (to != cur) {
-                    node_id_[v] = to;
-                    ++cnt_[to];
-                    --cnt_[cur];
-                    oplog_.emplace_back(to, (int64_t)v + 1);
-                    oplog_.emplace_back(cur, -((int64_t)v + 1));
-                    if (!mark_all)
-                        for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
-                    if (use_ahead)
-                        for (const auto &e : g_.adj(v)) stale[e.first] = sweep;
-                    again = true;
-                    moved_any = true;
-                    ++n_moved;
+                touched.clear();
+                if (++tick == 0) { // (the stamps wrapped: start over)
+                    std::fill(stamp.begin() + id_lo, stamp.begin() + id_hi, 0u);
+                    tick = 1;
+                }
+                for (const auto &e : g_.adj(v)) {
+                    if (mark_all) dirty[e.first] = 1;
+                    const uint32_t c = node_id_[e.first];
+                    if (stamp[c] != tick) {
+                        stamp[c] = tick;
+                        acc[c] = e.second;
+                        touched.push_back(c);
+                    } else {
+                        acc[c] += e.second; // (edge order, like the list it replaces)
+                    }
+                }
+                if (touched.empty()) return cur;
+                uint32_t bc = touched[0]; // max weight, ties -> smaller community id (louvain.rs:99-101)
+                float bw = acc[bc];
+                for (size_t i = 1; i < touched.size(); ++i) {
+                    const uint32_t c = touched[i];
+                    if (acc[c] > bw || (acc[c] == bw && c < bc)) bc = c, bw = acc[c];
+                }
+                return bw > 0.f ? bc : cur;
+            };
+            uint32_t sweep = 0;
+            size_t last_moved = 0;
+            for (bool again = true; again;) {
+                again = false;
+                ++sweep;
+                mark_all = sweep == 1 && level0_;
+                size_t n_eval = 0, n_moved = 0, n_taken = 0;
+                const auto t_sw = std::chrono::steady_clock::now();
+                const bool use_ahead = whole_graph && !no_ahead && sweep > 1 && hi - lo >= ahead_min && last_moved >= ahead_min / 64 && host_threads() > 1; // (many moves in the last sweep: many dirty nodes now)
+                if (use_ahead) {
+                    ahead.assign(g_.n_ids(), NO_GUESS);
+                    if (stale.empty()) stale.assign(g_.n_ids(), 0u);
+                    parallel_ranges(visit.size(), 4096, [&](unsigned, size_t plo, size_t phi) {
+                        std::vector<std::pair<uint32_t, float>> local; // (a node's neighbours lie in a handful of communities by now)
+                        for (size_t i = plo; i < phi; ++i) {
+                            const uint32_t v = visit[i];
+                            if (!dirty[v]) continue;
+                            local.clear();
+                            bool give_up = false;
+                            for (const auto &e : g_.adj(v)) {
+                                const uint32_t c = node_id_[e.first];
+                                bool hit = false;
+                                for (auto &l : local)
+                                    if (l.first == c) {
+                                        l.second += e.second; // (exact small-integer sums: the order does not matter)
+                                        hit = true;
+                                        break;
+                                    }
+                                if (!hit) {
+                                    if (local.size() >= 48) {
+                                        give_up = true;
+                                        break;
+                                    }
+                                    local.emplace_back(c, e.second);
+                                }
+                            }
+                            if (give_up) continue;
+                            uint32_t to = node_id_[v];
+                            if (!local.empty()) {
+                                uint32_t bc = local[0].first;
+                                float bw = local[0].second;
+                                for (size_t k = 1; k < local.size(); ++k)
+                                    if (local[k].second > bw || (local[k].second == bw && local[k].first < bc)) bc = local[k].first, bw = local[k].second;
+                                if (bw > 0.f) to = bc;
+                            }
+                            ahead[v] = to;
+                        }
+                    });
+                }
+                for (size_t vi = lo; vi < hi; ++vi) {
+                    const uint32_t v = visit[vi];
+                    if (!dirty[v]) continue;
+                    dirty[v] = 0;
+                    ++n_eval;
+                    const uint32_t cur = node_id_[v];
+                    uint32_t to;
+                    const bool fresh = use_ahead && ahead[v] != NO_GUESS && stale[v] != sweep; // (stale: a neighbour moved earlier in this sweep)
+                    if (fresh) to = ahead[v], ++n_taken;
+                    else to = decide(v);
+                    if (to != cur) {
+                        node_id_[v] = to;
+                        ++cnt_[to];
+                        --cnt_[cur];
+                        log.emplace_back(to, (int64_t)v + 1);
+                        log.emplace_back(cur, -((int64_t)v + 1));
+                        if (!mark_all)
+                            for (const auto &e : g_.adj(v)) dirty[e.first] = 1; // their gains changed
+                        if (use_ahead)
+                            for (const auto &e : g_.adj(v)) stale[e.first] = sweep;
+                        again = true;
+                        moved_any = true;
+                        ++n_moved;
+                    }
+                }
+                last_moved = n_moved;
+                if (prof && whole_graph) fprintf(stderr, "    sweep: %zu evaluated (%zu decided ahead), %zu moved, %.2f ms\n", n_eval, n_taken, n_moved, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sw).count());
+            }
+            return moved_any;
+        };
+
+        if (visit.empty()) return false;
+        // cut points: visit index i starts a piece iff no node before it has a neighbour at or beyond visit[i]
+        std::vector<size_t> cut; // piece starts (visit indices), ascending; cut.back() = visit.size()
+        if (!no_pieces && visit.size() >= pieces_min && host_threads() > 1) {
+            const auto t_c = std::chrono::steady_clock::now();
+            uint32_t reach = 0; // largest neighbour id of the nodes seen so far
+            for (size_t i = 0; i < visit.size(); ++i) {
+                const uint32_t v = visit[i];
+                if (i == 0 || reach < v) cut.push_back(i);
+                const Graph::Row row = g_.adj(v);
+                if (g_.rows_sorted) { // (a vote's rows: the largest neighbour is the last one)
+                    if (!row.empty()) reach = std::max(reach, (row.e - 1)->first);
+                } else {
+                    for (const auto &e : row) reach = std::max(reach, e.first);
                 }
             }
-            last_moved = n_moved;
-            if (prof) fprintf(stderr, "    sweep: %zu evaluated (%zu decided ahead), %zu moved, %.2f ms\n", n_eval, n_taken, n_moved, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sw).count());
+            cut.push_back(visit.size());
+            if (prof) fprintf(stderr, "    pieces: %zu between cut points (%.2f ms)\n", cut.size() - 1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
         }
+        if (cut.size() < 3) { // one piece (or a small graph): as before
+            if (level0_) oplog_.reserve(2 * visit.size()); // (the first sweep moves nearly every node: two log entries each)
+            return sweep_piece(0, visit.size(), oplog_, true);
+        }
+        // Work units of about n / (8 T) nodes: consecutive pieces joined (a union of pieces is a union of components), taken
+        // by the threads from a shared counter — largest first would need a sort; the pieces of a read graph are many and
+        // small next to the few long ones, which come at arbitrary places.
+        const size_t T = std::min<size_t>(host_threads(), cut.size() - 1);
+        const size_t want = std::max<size_t>(256, visit.size() / (8 * T));
+        std::vector<std::pair<size_t, size_t>> unit;
+        for (size_t k = 0; k + 1 < cut.size();) {
+            size_t k1 = k + 1;
+            while (k1 + 1 < cut.size() && cut[k1] - cut[k] < want) ++k1;
+            unit.emplace_back(cut[k], cut[k1]);
+            k = k1;
+        }
+        std::vector<OpLog> logs(unit.size());
+        std::vector<uint8_t> moved(unit.size(), 0);
+        std::atomic<size_t> next{0};
+        const auto t_p = std::chrono::steady_clock::now();
+        parallel_each(std::min(T, unit.size()), [&](size_t) {
+            for (size_t u; (u = next.fetch_add(1)) < unit.size();) {
+                if (level0_) logs[u].reserve(2 * (unit[u].second - unit[u].first));
+                moved[u] = sweep_piece(unit[u].first, unit[u].second, logs[u], false) ? 1 : 0;
+            }
+        });
+        bool moved_any = false;
+        size_t n_log = oplog_.size();
+        for (const OpLog &l : logs) n_log += l.size();
+        oplog_.reserve(n_log);
+        for (size_t u = 0; u < unit.size(); ++u) { // (unit order = id order: deterministic whatever the thread count)
+            oplog_.insert(oplog_.end(), logs[u].begin(), logs[u].end());
+            moved_any = moved_any || moved[u];
+        }
+        if (prof) fprintf(stderr, "    sweeps: %zu work units on %zu threads, %zu log entries, %.2f ms\n", unit.size(), std::min(T, unit.size()), oplog_.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p).count());
         return moved_any;
     }
 
@@ -980,12 +1111,7 @@ class SignedLouvain {
         }
         ng.end_rows();
         mark("new graph");
-        if (g_.edges.size() >= (1u << 22)) {
-            // (freeing a chromosome's first-level graph — 150 MB of edges going back to the kernel page by page — took as
-            // long as a sweep over it: a helper thread drops it)
-            auto old = std::make_shared<Graph>(std::move(g_));
-            std::thread([old]() mutable { old.reset(); }).detach();
-        }
+        if (g_.edges.size() >= (1u << 22)) Graph::retire(std::move(g_.edges)); // (kept for the next large vote: see Graph::Spare)
         g_ = std::move(ng);
         comm_keys_ = std::move(ncomm);
         node_id_.assign(max_id + 1, 0);

@@ -1425,11 +1425,9 @@ static bool get_cns_from_align_tags(Ctx &cx, std::vector<Msa> &msas, std::vector
         }
     }
     // No node at the last position with a score >= 0: the reference backtracks from its *default* Kmer here
-    // (main.rs:1651,1680: a spurious 'A' at L - 1, then node 0 of position L - 2) — the artefact of a contig whose best
-    // path has under 40 % support end to end, which no real pileup produces.  Product and oracle both REFUSE such an
-    // input (NP2_E_UNSUPPORTED; DESIGN.md, deliberate deviations) instead of restating the artefact, so that the two
-    // never disagree; the literal restatement is kept behind NP2O_DEFAULT_NODE=1 (tests/test_oracle.py pins it).
-    if (global_best == &dflt && !getenv("NP2O_DEFAULT_NODE")) throw Unsupported("best path score is negative at the contig end (reference would emit its default node)");
+    // (main.rs:1651,1680: a spurious 'A' at L - 1 with count 0, then node 0 of position L - 2) — the artefact of a contig
+    // whose best path has under 40 % support end to end.  Restated literally (global_best stays &dflt); the product does
+    // the same since round 6 (k_dp_finish / k_default_tail).
     return generate_cns_from_best_score_lq(cx, msas, alignseqs, global_best, out_cns, out);
 }
 

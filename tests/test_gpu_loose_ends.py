@@ -1,5 +1,6 @@
 """Round-2 parity loose ends: --out_pos (main.rs:613-625), the f32 split of -a (option.rs:232,258-259), the documented
-refusal of a negative best score at the contig end (main.rs:1651,1680), and a multi-context soak."""
+reference's walk back from its default node when no end node reaches a score >= 0 (main.rs:1651,1680), repeated keys in a
+k-mer dump (kmer.rs:148-167), and a multi-context soak."""
 import gzip
 import os
 import subprocess
@@ -68,26 +69,142 @@ def test_min_map_len_is_split_in_single_precision(tmp_path):
         c.free()
 
 
-def test_negative_best_score_at_the_contig_end_is_refused():
-    """DESIGN.md deviation: if no node at the last position reaches score >= 0 the reference backtracks from its default
-    node (main.rs:1651,1680: a spurious 'A', then node 0 of position L-2).  Product AND oracle refuse such a pileup with
-    NP2_E_UNSUPPORTED (the oracle restates the artefact only under NP2O_DEFAULT_NODE=1, tests/test_oracle.py): the two
-    never disagree.  Needs a pileup whose best path has < 40 % support everywhere."""
-    rng = np.random.default_rng(7)
-    L = 600
+def _negative_pileup(L, tail_clean, seed=7):
+    """Three full-length reads that disagree with the contig and with each other at every column but the last
+    `tail_clean`: every node of such a position has count 1 under coverage 4, i.e. 10 - 16 = -6 a step."""
+    rng = np.random.default_rng(seed)
     ref = "".join(rng.choice(list("ACGT"), L))
     alns = []
-    for k in range(3):  # three full-length reads that disagree with the contig and with each other at every column
-        q = "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] for c in ref)
+    for k in range(3):
+        q = "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] if i < L - tail_clean else c for i, c in enumerate(ref))
         alns.append((0, ref, q))
-    pu = pileup_from_alignments(ref, alns)
+    return ref, pileup_from_alignments(ref, alns)
+
+
+@pytest.mark.parametrize("tail_clean", [0, 1, 3, 4, 9])
+@pytest.mark.parametrize("iters", [1, 2])
+def test_negative_best_score_walks_back_from_the_default_node(tail_clean, iters):
+    """main.rs:1651,1680: if no node at the last position reaches score >= 0 the reference backtracks from its default
+    Kmer: an 'A' at L - 1 with count 0 (qv 0), then node 0 of position L - 2.  Rounds 2-5 refused such a pileup; product
+    and oracle now both restate it.  tail_clean = 0 / 1: the last position is dirty (its run's path starts with the 'A');
+    3: L - 1 clean, L - 2 dirty (the run ending there is entered at N0(L - 2) instead of N0(L - 1)'s best predecessor);
+    4, 9: a clean tail (only the base and its quality class change)."""
+    L = 600
+    ref, pu = _negative_pileup(L, tail_clean)
     y = Synth(2000, seed=3).yak(21)
-    with pytest.raises(orc.Unsupported) as eo:
-        orc.Oracle([y]).polish(pu, Opts(iter_count=1))
-    assert "negative" in str(eo.value)
-    with pytest.raises(Np2Error) as e:
-        Polisher([y]).polish(pu, Opts(iter_count=1))
-    assert e.value.code == -4 and "negative" in str(e.value)
+    ob, op = orc.Oracle([y]).polish(pu, Opts(iter_count=iters))
+    assert chr(ob[-1]) == "A" and op[-1] == L - 1
+    for env in ({}, {"NP2_FRONT_UNFUSED": "1"}):
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_loose_ends import _negative_pileup\n"
+            "from nextpolish2_amd import Opts, Polisher\nfrom nextpolish2_amd.synth import Synth\n"
+            "ref, pu = _negative_pileup(%d, %d)\n"
+            "g = Polisher([Synth(2000, seed=3).yak(21)])\n"
+            "b, p = g.polish(pu, Opts(iter_count=%d))\n"
+            "np.save(sys.argv[1], b); np.save(sys.argv[2], p)\n" % (ROOT, os.path.join(ROOT, "tests"), L, tail_clean, iters))
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            r = subprocess.run([sys.executable, "-c", code, d + "/b.npy", d + "/p.npy"], capture_output=True, text=True,
+                               env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-2000:]
+            gb, gp = np.load(d + "/b.npy"), np.load(d + "/p.npy")
+        assert np.array_equal(gb, ob) and np.array_equal(gp, op), (tail_clean, iters, env)
+
+
+def test_negative_best_score_on_short_contigs_and_through_the_batch_driver():
+    """The same artefact where the re-walked run touches positions 0-2 (path starts are only accepted there,
+    main.rs:1666-1668), and on the batch driver's recorded launches."""
+    from nextpolish2_amd import BatchPolisher
+    y = Synth(2000, seed=3).yak(21)
+    g, o = Polisher([y]), orc.Oracle([y])
+    pus = []
+    for L, tail in ((5, 3), (6, 3), (7, 0), (9, 4), (40, 3), (40, 0), (300, 3)):
+        for seed in (1, 2):
+            pus.append(_negative_pileup(L, tail, seed)[1])
+    want = [o.polish(pu, Opts(iter_count=1)) for pu in pus]
+    for pu, (ob, op) in zip(pus, want):
+        gb, gp = g.polish(pu, Opts(iter_count=1))
+        assert np.array_equal(gb, ob) and np.array_equal(gp, op), len(pu.ref)
+    cs = [g.upload(pu) for pu in pus]
+    bp = BatchPolisher(g, 4)
+    for (bb, pp), (ob, op) in zip(bp.polish(cs, Opts(iter_count=1), want_pos=True), want):
+        assert np.array_equal(bb, ob) and np.array_equal(pp, op)
+    bp.close()
+
+
+def test_reads_starting_at_the_last_position_compete_on_absolute_scores():
+    """main.rs:1659-1660, 1680: a read-start node's score is the absolute 10 count - 4 coverage, every other node carries the
+    path's accumulated total.  Ten one-column reads with a foreign base at L - 1 over three full-length reads: 10 * 10 -
+    4 * 14 = 44 loses to the contig's node (total ~ 24 a position) — the consensus is the contig's; over a pileup whose
+    best path is negative everywhere the same 44 is the only end node that reaches 0: the consensus is that one base.
+    (the kernels compared the 44 with scores relative to the run's left neighbour.)"""
+    rng = np.random.default_rng(5)
+    L = 200
+    ref = "".join(rng.choice(list("ACGT"), L))
+    x = "ACGT"[("ACGT".index(ref[-1]) + 1) % 4]
+    y = Synth(2000, seed=3).yak(21)
+    o = orc.Oracle([y])
+    # (a) the contig wins
+    alns = [(0, ref, ref)] * 3 + [(L - 1, ref[-1], x)] * 10
+    pu = pileup_from_alignments(ref, alns)
+    ob, op = o.polish(pu, Opts(iter_count=1))
+    assert bytes(ob).decode() == ref
+    # (b) the start node wins
+    alns2 = [(0, ref, "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] for c in ref)) for k in range(3)] + [(L - 1, ref[-1], x)] * 10
+    pu2 = pileup_from_alignments(ref, alns2)
+    ob2, op2 = o.polish(pu2, Opts(iter_count=1))
+    assert bytes(ob2).decode() == x and list(op2) == [L - 1]
+    for env in ({}, {"NP2_FRONT_UNFUSED": "1"}):
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from nextpolish2_amd import Opts, Polisher\nfrom nextpolish2_amd.synth import Synth, pileup_from_alignments\n"
+            "ref, x, L = %r, %r, %d\n"
+            "g = Polisher([Synth(2000, seed=3).yak(21)])\n"
+            "a1 = [(0, ref, ref)] * 3 + [(L - 1, ref[-1], x)] * 10\n"
+            "a2 = [(0, ref, ''.join('ACGT'[('ACGT'.index(c) + 1 + k) %% 4] for c in ref)) for k in range(3)] + [(L - 1, ref[-1], x)] * 10\n"
+            "b1, p1 = g.polish(pileup_from_alignments(ref, a1), Opts(iter_count=1))\n"
+            "b2, p2 = g.polish(pileup_from_alignments(ref, a2), Opts(iter_count=1))\n"
+            "print(bytes(b1).decode()); print(bytes(b2).decode(), list(map(int, p2)))\n" % (ROOT, ref, x, L))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout.strip().splitlines()
+        assert out[-2] == ref and out[-1] == "%s [%d]" % (x, L - 1), (env, out[-2:])
+
+
+def test_repeated_key_in_a_dump_bucket_last_passing_word_wins(tmp_path):
+    """kmer.rs:148-167: retrieve_kmers streams the dump and REPLACES a candidate's entry with every word whose count
+    passes min_kmer_count, so of several words with one key the last passing one in file order is what get() returns
+    (yak writes no such dump; rounds 2-5 refused it).  Boundary form and dump file, against the oracle."""
+    from nextpolish2_amd._types import Yak
+    base = Synth(3000, seed=5).yak(21)
+    rng = np.random.default_rng(11)
+    words, offs = [], [0]
+    picked = []
+    for b in range(1024):
+        w = list(base.words[int(base.bucket_off[b]):int(base.bucket_off[b + 1])])
+        if w and b % 3 == 0:
+            k0 = int(w[0]) >> 10
+            # the key of the bucket's first word four more times, counts 7, 2, 30, 1 - interleaved with the other words
+            for cnt, at in ((7, 1), (2, len(w) // 2 + 1), (30, len(w) + 1), (1, len(w) + 3)):
+                w.insert(min(at, len(w)), np.uint64((k0 << 10) | cnt))
+            picked.append((b, k0))
+        words += w
+        offs.append(len(words))
+    dup = Yak(21, np.array(words, np.uint64), np.array(offs, np.uint64))
+    hashes = np.array([(k0 << 10) | b for b, k0 in picked] + [int(x) for x in rng.integers(0, 1 << 40, 200)], np.uint64)
+    o = orc.Oracle([dup])
+    g = Polisher([dup])
+    np2io.write_yak(str(tmp_path / "dup.yak"), dup)
+    gf = np2io.polisher_from_yak_files([str(tmp_path / "dup.yak")])
+    for mk in (1, 2, 3, 8, 31, 40):
+        want = o.lookup_hashes(0, hashes, mk)
+        assert np.array_equal(g.lookup_hashes(0, hashes, mk), want), mk
+        assert np.array_equal(gf.lookup_hashes(0, hashes, mk), want), mk
+    # (the first word's own count also competes: with min 1 the last word (count 1) wins, with 8 the 30, with 31 nothing
+    #  unless the first word's own count passes)
+    assert set(o.lookup_hashes(0, hashes[:len(picked)], 1).tolist()) == {1}
+    assert set(o.lookup_hashes(0, hashes[:len(picked)], 8).tolist()) == {30}
 
 
 def test_soak_contexts_and_batches_share_one_gpu():

@@ -1,7 +1,7 @@
 """The fused pass front (csrc/np2_passfront.hip: records of a contig tile -> the tile's piece of the raw consensus in one
 kernel) against the oracle and against the unfused kernels it replaces, including the tiles it hands to the big variant and
 the passes it hands back to the unfused kernels.  The limits of the LDS variants are lowered through test hooks
-(NP2_PF_CAP, NP2_PF_CAP_BIG, NP2_PF_HALO, NP2_PF_COV_MAX: read per pass) so that small inputs take those branches."""
+(NP2_PF_CAP, NP2_PF_CAP_BIG, NP2_PF_HALO, NP2_PF_COV_MAX: read when a context is created) so that small inputs take those branches."""
 import numpy as np
 import pytest
 
@@ -112,7 +112,7 @@ def test_contig_ends_and_short_contigs():
             yaks = [s.yak(21)]
             try:
                 ob, op = orc.Oracle(yaks).polish(s.pileup, Opts())
-            except (orc.Unsupported, orc.RefPanic):  # (the same refusal on both sides)
+            except orc.RefPanic:  # (the same refusal on both sides)
                 with pytest.raises(Np2Error):
                     _polish(yaks, s.pileup)
                 continue

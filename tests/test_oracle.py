@@ -265,18 +265,32 @@ def test_refpanic_is_reported_not_crashed():
         orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=0))
 
 
-def test_negative_best_score_default_node_restatement(monkeypatch):
+def test_negative_best_score_default_node_restatement():
     """main.rs:1651,1680: no node at the last position with a score >= 0 -> the reference backtracks from its default
-    Kmer (bases 0: 'A' at L - 1 with count 0, then node 0 of position L - 2).  The oracle refuses such a pileup like the
-    product does (NP2_E_UNSUPPORTED) and restates the artefact only under NP2O_DEFAULT_NODE=1: a trailing 'A' at L - 1
-    behind the best path into node 0 of L - 2."""
+    Kmer (bases 0: 'A' at L - 1 with count 0, then node 0 of position L - 2): a trailing 'A' at L - 1 behind the best path
+    into node 0 of L - 2.  (Rounds 3-5 refused such a pileup in oracle and product alike; both restate it now.)"""
     rng = np.random.default_rng(7)
     L = 600
     ref = "".join(rng.choice(list("ACGT"), L))
     alns = [(0, ref, "".join("ACGT"[("ACGT".index(c) + 1 + k) % 4] for c in ref)) for k in range(3)]
     pu = pileup_from_alignments(ref, alns)
-    with pytest.raises(orc.Unsupported):
-        orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=1))
-    monkeypatch.setenv("NP2O_DEFAULT_NODE", "1")
     b, p = orc.Oracle([empty_yak()]).polish(pu, Opts(iter_count=1))
     assert chr(b[-1]) == "A" and p[-1] == L - 1
+    # every position holds four nodes of count 1 under coverage 4 (-6 a step) and ties go to the LATER node
+    # (main.rs:1671: score == kmer_score && base1 != gap), node order = first-seen order = read order: the walk from node 0
+    # of L - 2 (the contig's own node) follows the contig's nodes back, so the consensus is the contig with its last base
+    # replaced by the default node's 'A'
+    assert len(b) == L and bytes(b[:-1]).decode() == ref[:-1]
+
+
+def test_repeated_dump_key_last_passing_word_wins():
+    """kmer.rs:148-167 (retrieve_kmers): a candidate's entry is REPLACED by every file word with its key whose count passes
+    min_kmer_count — the last such word in file order is what get() returns."""
+    from nextpolish2_amd._types import Yak
+    key = 0x123456
+    words = np.array([(key << 10) | 7, (0x777 << 10) | 3, (key << 10) | 2, (key << 10) | 30, (key << 10) | 1], np.uint64)
+    offs = np.zeros(1025, np.uint64)
+    offs[6:] = len(words)  # all five words in bucket 5
+    o = orc.Oracle([Yak(21, words, offs)])
+    h = np.array([(key << 10) | 5], np.uint64)
+    assert [int(o.lookup_hashes(0, h, mk)[0]) for mk in (1, 2, 3, 8, 30, 31)] == [1, 30, 30, 30, 30, 0]
