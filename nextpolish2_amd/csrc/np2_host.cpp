@@ -2331,9 +2331,20 @@ int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total
             const uint64_t *xk = x.pair_key;
             const uint32_t *xc = x.pair_cnt;
             bool sorted = true;
-            for (uint64_t i = 0; i < x.n_pairs; ++i) {
-                if ((uint32_t)(xk[i] >> 32) >= n_reads_total || (uint32_t)xk[i] >= n_reads_total) return NP2_E_ARG;
-                sorted = sorted && (i == 0 || xk[i - 1] < xk[i]);
+            { // (2 x 10^7 pairs for a chromosome: on all threads)
+                std::vector<uint8_t> st(phase::host_threads(), 0); // bit 0: an endpoint outside the contig's reads, bit 1: unsorted
+                phase::parallel_ranges((size_t)x.n_pairs, (size_t)1 << 18, [&](unsigned t, size_t lo, size_t hi) {
+                    uint8_t f = 0;
+                    for (size_t i = lo; i < hi; ++i) {
+                        if ((uint32_t)(xk[i] >> 32) >= n_reads_total || (uint32_t)xk[i] >= n_reads_total) f |= 1;
+                        if (i && !(xk[i - 1] < xk[i])) f |= 2;
+                    }
+                    st[t] = f;
+                });
+                for (uint8_t f : st) {
+                    if (f & 1) return NP2_E_ARG;
+                    if (f & 2) sorted = false;
+                }
             }
             if (!sorted) {
                 std::vector<std::pair<uint64_t, uint32_t>> tmp(x.n_pairs);

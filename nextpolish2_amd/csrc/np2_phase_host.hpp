@@ -622,14 +622,20 @@ class SignedLouvain {
     explicit SignedLouvain(Graph g, OrderSet *communities = nullptr) : g_(std::move(g)) {
         const uint32_t n = g_.n_ids();
         node_id_.resize(n);
-        node_w_.assign(n, 0.f);
-        cnt_.assign(n, 0);
+        node_w_.resize(n);
+        cnt_.resize(n);
         if (communities) comm_keys_ = std::move(*communities);
-        for (uint32_t v : g_.keys.key_list()) { // louvain.rs:65-68 (members_: every node is {itself} until aggregated)
-            if (!communities) comm_keys_.put(v, Nil{});
-            node_id_[v] = v;
-            cnt_[v] = 1;
-        }
+        else // louvain.rs:65-68: a fresh map, the graph's keys inserted in the graph's iteration order
+            for (uint32_t v : g_.keys.key_list()) comm_keys_.put(v, Nil{});
+        // (members_: every node is {itself} until aggregated; the per-node state by a scan of the dense mirror — on all
+        // threads for a chromosome's 6 x 10^5 ids, each touching its own pages first)
+        parallel_ranges(n, (size_t)1 << 16, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t v = lo; v < hi; ++v) {
+                node_id_[v] = (uint32_t)v; // (only read for keys)
+                node_w_[v] = 0.f;
+                cnt_[v] = g_.is_key[v] ? 1u : 0u;
+            }
+        });
     }
     // the first level's community map: a fresh map, the graph's keys inserted in the graph's iteration order
     static OrderSet first_communities(const OrderSet &graph_keys) {
@@ -843,17 +849,35 @@ class SignedLouvain {
         std::vector<size_t> cut; // piece starts (visit indices), ascending; cut.back() = visit.size()
         if (!no_pieces && visit.size() >= pieces_min && host_threads() > 1) {
             const auto t_c = std::chrono::steady_clock::now();
-            uint32_t reach = 0; // largest neighbour id of the nodes seen so far
-            for (size_t i = 0; i < visit.size(); ++i) {
-                const uint32_t v = visit[i];
-                if (i == 0 || reach < v) cut.push_back(i);
+            // largest neighbour id over the nodes before visit[i] (prefix maximum): chunks on all threads, their maxima chained
+            auto row_reach = [&](uint32_t v) -> uint32_t {
                 const Graph::Row row = g_.adj(v);
+                uint32_t m = 0;
                 if (g_.rows_sorted) { // (a vote's rows: the largest neighbour is the last one)
-                    if (!row.empty()) reach = std::max(reach, (row.e - 1)->first);
+                    if (!row.empty()) m = (row.e - 1)->first;
                 } else {
-                    for (const auto &e : row) reach = std::max(reach, e.first);
+                    for (const auto &e : row) m = std::max(m, e.first);
                 }
-            }
+                return m;
+            };
+            const size_t C = std::max<size_t>(1, std::min<size_t>(host_threads(), visit.size() >> 12));
+            std::vector<uint32_t> cmax(C + 1, 0);
+            std::vector<std::vector<size_t>> ccut(C);
+            std::vector<uint32_t> rmax(visit.size());
+            parallel_each(C, [&](size_t t) {
+                uint32_t m = 0;
+                for (size_t i = visit.size() * t / C; i < visit.size() * (t + 1) / C; ++i) rmax[i] = row_reach(visit[i]), m = std::max(m, rmax[i]);
+                cmax[t + 1] = m;
+            });
+            for (size_t t = 0; t < C; ++t) cmax[t + 1] = std::max(cmax[t + 1], cmax[t]);
+            parallel_each(C, [&](size_t t) {
+                uint32_t reach = cmax[t];
+                for (size_t i = visit.size() * t / C; i < visit.size() * (t + 1) / C; ++i) {
+                    if (i == 0 || reach < visit[i]) ccut[t].push_back(i);
+                    reach = std::max(reach, rmax[i]);
+                }
+            });
+            for (const auto &cc : ccut) cut.insert(cut.end(), cc.begin(), cc.end());
             cut.push_back(visit.size());
             if (prof) fprintf(stderr, "    pieces: %zu between cut points (%.2f ms)\n", cut.size() - 1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
         }
@@ -1013,8 +1037,16 @@ class SignedLouvain {
         mark("member lists");
         const std::vector<float> w_int = all_weights(moff, mlist);
         mark("community weights");
-        comm_keys_.each([&](uint32_t id, const Nil &) {
-            if (cnt_[id] == 0) return;
+        // the live communities in the community map's iteration order (louvain.rs:123: self.communities.iter() filtered for
+        // non-empty sets).  After the first sweep of a chromosome's graph they are a few hundred among 3 x 10^5 keys: found
+        // by a scan of the member counts and ordered by their slot in the table, instead of a walk over the whole table
+        std::vector<std::pair<size_t, uint32_t>> live;
+        for (uint32_t id = 0; id < cnt_.size(); ++id)
+            if (cnt_[id]) live.emplace_back(comm_keys_.find(id), id);
+        std::sort(live.begin(), live.end());
+        for (const auto &sl : live) {
+            const uint32_t id = sl.second;
+            if (sl.first == OrderSet::npos) continue; // (cannot happen: every community id is a key of the map)
             Community c;
             c.id = id;
             c.weight = w_int[id];
@@ -1026,7 +1058,7 @@ class SignedLouvain {
                 ncomm.put(id, Nil{});
                 nnode[id] = std::move(c);
             }
-        });
+        }
         mark("community table");
         for (uint32_t id : split) { // decluster negative communities, louvain.rs:145-165
             for (uint32_t v : member_order(id)) {
@@ -1049,12 +1081,17 @@ class SignedLouvain {
         for (const auto &kv : nnode) max_id = std::max(max_id, kv.first);
         Graph ng;
         ng.begin_rows(max_id + 1);
-        std::vector<uint32_t> koff((size_t)max_id + 2, 0), klist;
-        for (uint32_t v = 0; v < key_of.size(); ++v)
-            if (key_of[v] != 0xFFFFFFFFu) ++koff[key_of[v] + 1];
-        for (size_t i = 0; i + 1 < koff.size(); ++i) koff[i + 1] += koff[i];
-        klist.resize(koff.back());
-        {
+        // nodes per new key.  Without a declustered community the new keys ARE the community ids and the lists the member
+        // lists above (every id of moff is a valid row start: max_id < node_id_.size()); otherwise a second counting sort
+        std::vector<uint32_t> koff, klist;
+        if (split.empty()) {
+            koff.swap(moff), klist.swap(mlist);
+        } else {
+            koff.assign((size_t)max_id + 2, 0);
+            for (uint32_t v = 0; v < key_of.size(); ++v)
+                if (key_of[v] != 0xFFFFFFFFu) ++koff[key_of[v] + 1];
+            for (size_t i = 0; i + 1 < koff.size(); ++i) koff[i + 1] += koff[i];
+            klist.resize(koff.back());
             std::vector<uint32_t> cur(koff.begin(), koff.end() - 1);
             for (uint32_t v = 0; v < key_of.size(); ++v)
                 if (key_of[v] != 0xFFFFFFFFu) klist[cur[key_of[v]]++] = v;

@@ -85,3 +85,80 @@ def test_sweeps_decided_ahead_on_all_threads_change_nothing():
         assert r.returncode == 0, r.stderr.decode()
         outs.append(int(r.stdout.strip()))
     assert len(set(outs)) == 1, outs
+
+
+def test_components_swept_on_all_threads_equal_the_oracle():
+    """SignedLouvain::local_moving, round 6: the first stage decomposes exactly over connected components (louvain.rs:84-96:
+    a node's gain is the sum of its own edges into a neighbour's community; :103-105: a move touches two member sets), so
+    the pieces of the read graph between cut points are swept to convergence on separate threads and their member-set
+    histories concatenated.  With the thresholds lowered to nothing (NP2_VOTE_PIECES_MIN=1) random signed graphs made of
+    many small components along the id axis — with ties, conflicts and negative communities that get declustered, whose
+    member-set iteration order is the one thing a wrong history would change — must be decided exactly like the ORACLE's
+    literal restatement decides them; and the recorded 16 Mb vote tiled eight times (eight components at least) like the
+    serial sweeps (NP2_VOTE_NO_PIECES) decide it."""
+    code = ("import sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from nextpolish2_amd.api import phase_vote, Np2Error\n"
+            "from oracle import np2_oracle as orc\n"
+            "rng = np.random.default_rng(int(sys.argv[1]))\n"
+            "n_checked = 0\n"
+            "for trial in range(150):\n"
+            "    n_comp = int(rng.integers(2, 14))\n"
+            "    pairs, base = {}, 1\n"
+            "    for c in range(n_comp):\n"
+            "        n = int(rng.integers(2, 18))\n"
+            "        ids = np.sort(rng.choice(np.arange(base, base + 3 * n), size=n, replace=False))\n"
+            "        base += 3 * n + int(rng.integers(0, 3))  # (sometimes the next component starts right behind: no gap in the ids)\n"
+            "        for _ in range(int(rng.integers(n - 1, 3 * n))):\n"
+            "            a, b = rng.choice(ids, size=2, replace=False)\n"
+            "            a, b = int(min(a, b)), int(max(a, b))\n"
+            "            same = (a %% 2) == (b %% 2)\n"
+            "            w = float(rng.integers(1, 3)) * (1.0 if (same or rng.random() < 0.15) else -1.0)\n"
+            "            if rng.random() < 0.08: w = -3.0\n"
+            "            pairs[(a, b)] = pairs.get((a, b), 0.0) + w\n"
+            "    plist = sorted((a, b, w) for (a, b), w in pairs.items()) if trial %% 2 else [(a, b, w) for (a, b), w in pairs.items()]\n"
+            "    edges, keys, seen = [], [], set()\n"
+            "    for a, b, w in plist:\n"
+            "        edges.append((a, b, w)); edges.append((b, a, w))\n"
+            "        for k in (a, b):\n"
+            "            if k not in seen: seen.add(k); keys.append(k)\n"
+            "    ref = None\n"
+            "    if trial %% 3 == 0:\n"
+            "        ref = {int(k): float(rng.choice([-1.0, 1.0, 2.0])) for k in rng.choice(keys, size=max(1, len(keys) // 3), replace=False)}\n"
+            "    try:\n"
+            "        exp = orc.phase_communities(edges, ref)\n"
+            "    except orc.RefPanic:\n"
+            "        try:\n"
+            "            phase_vote(keys, plist, ref); raise SystemExit('product accepted what the reference panics on')\n"
+            "        except Np2Error: continue\n"
+            "    got = phase_vote(keys, plist, ref)\n"
+            "    assert got == exp, (trial, got, exp)\n"
+            "    n_checked += 1\n"
+            "print(n_checked)\n" % (ROOT, HERE))
+    for seed, threads in ((1, "4"), (2, "2"), (3, "7")):
+        r = subprocess.run([sys.executable, "-c", code, str(seed)], capture_output=True, timeout=900,
+                           env=dict(os.environ, NP2_VOTE_PIECES_MIN="1", NP2_VOTE_THREADS=threads))
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        assert int(r.stdout.strip()) > 100
+    # the recorded vote, tiled: pieces on all threads == one piece
+    code2 = ("import sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import numpy as np\n"
+             "from test_vote_host_cpu import load\n"
+             "from nextpolish2_amd.api import Vote, vote_decide\n"
+             "v0, R0, _ = load()\n"
+             "span = int(v0.first_pos.max()) + 100000\n"
+             "ks, cs, ids, fp, rw, fl = [], [], [], [], [], []\n"
+             "for c in range(8):\n"
+             "    sh = np.uint64(c * (R0 - 1))\n"
+             "    ks.append(v0.pair_key + ((sh << np.uint64(32)) | sh)); cs.append(v0.pair_cnt)\n"
+             "    ids.append(v0.read_id + np.uint32(c * (R0 - 1))); fp.append(v0.first_pos + np.uint32(c * span))\n"
+             "    rw.append(v0.ref_w); fl.append(v0.flags)\n"
+             "v = Vote(pair_key=np.concatenate(ks), pair_cnt=np.concatenate(cs), read_id=np.concatenate(ids),\n"
+             "         first_pos=np.concatenate(fp), ref_w=np.concatenate(rw), flags=np.concatenate(fl))\n"
+             "print(zlib.crc32(vote_decide([v], 1 + 8 * (R0 - 1)).tobytes()))\n" % (ROOT, HERE))
+    outs = []
+    for extra in ({"NP2_VOTE_NO_PIECES": "1"}, {}, {"NP2_VOTE_THREADS": "3"}):
+        r = subprocess.run([sys.executable, "-c", code2], capture_output=True, env=dict(os.environ, **({"NP2_VOTE_THREADS": "8"} | extra)), timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        outs.append(int(r.stdout.strip()))
+    assert len(set(outs)) == 1, outs
