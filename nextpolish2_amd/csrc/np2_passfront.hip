@@ -42,6 +42,10 @@ static constexpr int32_t PF_NEG = -(1 << 30);                 // "unreachable" i
 __device__ __forceinline__ uint8_t pf_ref_code(const uint8_t *__restrict__ refnib, uint32_t p) {
     return (refnib[p >> 1] >> (4 * (p & 1))) & 7;
 }
+// lane I of the caller's quad (lanes 4 m .. 4 m + 3), one DPP move; every lane of the quad must be active
+template <int I> __device__ __forceinline__ uint32_t pf_quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, I | (I << 2) | (I << 4) | (I << 6), 0xF, 0xF, true);
+}
 __device__ __forceinline__ void pf_n0_key(uint32_t p, uint32_t c2, uint32_t c1, uint32_t c0, uint32_t &b, uint32_t &d) {
     if (p >= 2) {
         b = (c2 << 8) | (c1 << 4) | c0, d = 0;
@@ -439,45 +443,215 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         return;
     }
     stamp(3);
-    // ---- DP + backtrack: one thread per dirty run that starts in this tile -------------------------------------------------
-    // The kernel is bound by instruction issue, and a wavefront pays for the longest path among its lanes: the runs go to
-    // consecutive lanes of ONE wavefront (a tile has a few dozen), which one rotates with the tile (a block's four
-    // wavefronts sit on the CU's four SIMDs).
-    for (uint32_t r = (tid + 256 - 64 * (t & 3)) & 255; r < n_runs; r += 256) {
+    // ---- DP + backtrack of the dirty runs that start in this tile ------------------------------------------------------------
+    // Round 5 gave every run a lane of ONE wavefront: a tile's time in this phase was its longest run (8-9 positions in a
+    // diploid phasing pass) times ~350 wave instructions a position — all (node, predecessor) pairs of a position one after
+    // the other in one lane, 27 k of a tile's 82 k clocks with three wavefronts waiting at the barrier.  Now:
+    //  (1) one thread per run CLASSIFIES it: every position weak (above) -> the path stays on the contig's nodes, done;
+    //      otherwise the run is listed — for a QUAD of lanes if no position holds more than three exception nodes
+    //      (99.3 % of the listed runs of a 30x diploid pass), for a single lane otherwise;
+    //  (2) a quad scores a position in one step: lane 0 owns N0(p), lane j exception node j - 1; each tests ITS node against
+    //      the previous position's four (keys and scores fetched from the quad's lanes by DPP, in the reference's order,
+    //      main.rs:1664-1674), then the nodes whose second column lies at the same position take the earlier nodes of their
+    //      own position in three more rounds (node k's predecessors are final by round k); 64 quads a round over all four
+    //      wavefronts.  Lane 0 closes the run and walks it back.
+    __shared__ uint16_t s_ql[TILE / 2 + 2]; // runs for quads from the front, runs for single lanes from the back
+    __shared__ uint32_t s_nl[2];
+    if (tid < 2) s_nl[tid] = 0;
+    __syncthreads();
+    constexpr uint32_t PF_QN = 3; // exception nodes a quad holds
+    for (uint32_t r = tid; r < n_runs; r += 256) {
         const uint32_t qa = s_run[r];
         const uint32_t a = start + qa;
-        if (a >= 3) { // all positions weak (above): the path stays on the contig's nodes
-            uint32_t q = qa;
-            int32_t g = 0;
-            bool weak = true, closed = false;
-            for (; q < ext; ++q) {
-                const uint32_t x = s_n0bi[q];
-                if (x == 0) { // the clean position that closes the run
-                    closed = true;
-                    break;
-                }
-                if (!(x & PF_N0_WEAK)) {
-                    weak = false;
-                    break;
-                }
-                const int32_t cov = s_cov[q];
-                g += 10 * (cov - (int32_t)(x & 0x1FFFu)) - 4 * cov;
-                s_n0bi[q] = (uint16_t)(x | PF_N0_VISITED); // (the DP below starts over on these words if the run turns out strong)
+        uint32_t q = qa, mxn = 0;
+        int32_t g = 0;
+        bool weak = a >= 3, closed = false;
+        for (; q < ext; ++q) {
+            const uint32_t x = s_n0bi[q];
+            if (x == 0) { // the clean position that closes the run
+                closed = true;
+                break;
             }
-            if (weak && closed) {
-                gain += g + 6 * (int32_t)s_cov[q];
-                continue;
-            }
-            if (weak && start + q != L) { // still open at the end of the halo
-                s_flag[1] = 1;
-                continue;
-            }
+            mxn = max(mxn, (uint32_t)s_off[q + 1] - (uint32_t)s_off[q]);
+            if (!(x & PF_N0_WEAK)) weak = false;
+            const int32_t cov = s_cov[q];
+            g += 10 * (cov - (int32_t)(x & 0x1FFFu)) - 4 * cov;
         }
+        if (weak && closed) {
+            for (uint32_t qq = qa; qq < q; ++qq) s_n0bi[qq] = (uint16_t)(s_n0bi[qq] | PF_N0_VISITED);
+            gain += g + 6 * (int32_t)s_cov[q];
+        } else if (!closed && start + q != L) { // still open at the end of the halo
+            s_flag[1] = 1;
+        } else if (mxn <= PF_QN) {
+            s_ql[atomicAdd(&s_nl[0], 1u)] = (uint16_t)qa;
+        } else {
+            s_ql[TILE / 2 + 1 - atomicAdd(&s_nl[1], 1u)] = (uint16_t)qa;
+        }
+    }
+    __syncthreads();
+    // one (node, predecessor) test: main.rs:1664-1674
+    auto pred_test = [](uint32_t vkey, int32_t ps, uint32_t want, uint32_t kd, bool far, int32_t w, uint32_t pi, int32_t &score,
+                        uint32_t &besti) {
+        const uint32_t vb = vkey & 0xFFFFu, vd = vkey >> 16;
+        const uint32_t v2d = (vb & 0x4000u) ? ((vd + 1u) & 0xFFFFu) : 0u;
+        const uint32_t v1q = (vb >> 8) & 0xFu;
+        const bool ok = (vb & 0x10FFu) == want && v2d == kd && !(far && v1q == 15u); // main.rs:1666-1668
+        const int32_t sc = ps + w;
+        if (ok && (sc > score || (sc == score && v1q != 4u))) score = sc, besti = pi; // main.rs:1670
+    };
+    // the end of a run: its gain, where the walk back begins, the walk (marks the nodes of the path)
+    auto finish_run = [&](uint32_t qa, uint32_t q, bool closed, int32_t s0_cur, int32_t base, int32_t pv_s0, uint32_t pv_k0, uint32_t pv_n) {
+        const uint32_t a = start + qa;
+        uint32_t wq, widx; // where the walk back begins
+        if (closed) {
+            gain += (long long)s0_cur - base;
+            wq = q - 1, widx = s_n0bi[q];
+            s_n0bi[q] = 0; // (the closing position is written out as a clean position: no mark, no index)
+        } else if (start + q == L) {
+            // the run reaches the contig end: the best end node (main.rs:1651,1680: the last one of maximal score; that the
+            // score is >= 0 is checked by the host against the total of all gains: end_rel + total).
+            // A read-start node's score is the absolute 10 count - 4 coverage (main.rs:1659-1660), the others' are relative
+            // to the node left of the run (a >= 3): one with a negative score can never be chosen (the choice starts at the
+            // default node's 0), one that reaches 0 — a read starting at the very last position with more copies than the
+            // pileup is deep there — competes with the path's total, which only k_dp_finish knows: the pass is handed back.
+            int32_t best = pv_s0;
+            uint32_t bi = 0;
+            for (uint32_t k = 0; k < pv_n; ++k) {
+                const int32_t sc = s_score[pv_k0 + k];
+                if (a >= 3 && ((s_nkey[pv_k0 + k] >> 4) & 0xFu) == 15u) {
+                    if (sc >= 0) atomicOr(A.flags, PF_REDO);
+                    continue;
+                }
+                if (sc >= best) best = sc, bi = k + 1;
+            }
+            gain -= base;
+            s_endrel = best <= PF_NEG / 2 ? (long long)SCORE_NEG : (long long)best;
+            s_flag[4] = 1;
+            wq = q - 1, widx = bi;
+        } else { // still open at the end of the halo
+            s_flag[1] = 1;
+            return;
+        }
+        for (;;) {
+            const uint32_t p = start + wq;
+            uint32_t bi;
+            bool back;
+            if (widx == 0) {
+                const uint32_t x = s_n0bi[wq];
+                s_n0bi[wq] = (uint16_t)(x | PF_N0_VISITED);
+                bi = x & PF_IDX_MASK;
+                if (p == 0) break; // N0(0) = (head, head, c0): the path starts here
+                back = true;
+            } else {
+                const uint32_t k = s_off[wq] + widx - 1;
+                const uint32_t x = s_ncw[k], kb = s_nkey[k] & 0xFFFFu;
+                s_ncw[k] = x | PF_VISITED;
+                bi = (x >> PF_COUNT_BITS) & PF_IDX_MASK;
+                if (((kb >> 4) & 0xF) == 15) { // a read's start node: the path begins at p (only reachable for p <= 2)
+                    if (p > 0) atomicMax(&s_flag[2], p);
+                    break;
+                }
+                back = !(kb & 0x1000);
+            }
+            if (back) {
+                if (wq == qa) break; // left the run: N0(a - 1)
+                --wq;
+            }
+            widx = bi;
+        }
+    };
+    const uint32_t n_quad = s_nl[0], n_one = s_nl[1];
+    // (2) quads
+    for (uint32_t r0 = 0; r0 < n_quad; r0 += 64) { // (uniform trip count)
+        const uint32_t r = r0 + (tid >> 2), j = tid & 3;
+        if (r >= n_quad) continue; // (whole quads)
+        const uint32_t qa = s_ql[r];
+        const uint32_t a = start + qa;
         // scores relative to N0(a - 1); a run starting at position 1 or 2 competes with a read's start node on absolute
         // scores (k_dp_bt_*'s early_run_base): N0(0) is a path start, position 1 is clean when a == 2
         int32_t base = 0;
         if (a == 1 || a == 2) base = 6 * (int32_t)s_cov[0] + (a == 2 ? 6 * (int32_t)s_cov[1] : 0);
         uint32_t cc2 = s_ref[qa + 1], cc1 = s_ref[qa + 2], cc0 = s_ref[qa + 3]; // codes of a - 2, a - 1, a  (s_ref[i] = code of start - 3 + i)
+        // this lane's node of the previous position: key, score, valid
+        uint32_t pK = 0;
+        int32_t pS = PF_NEG;
+        uint32_t pV = 0;
+        if (a > 0 && j == 0) {
+            uint32_t b, d;
+            pf_n0_key(a - 1, s_ref[qa], cc2, cc1, b, d);
+            pK = b | (d << 16), pS = base, pV = 1;
+        }
+        int32_t my_score = 0, pv_s0 = base;
+        uint32_t pv_k0 = 0, pv_n = 0;
+        uint32_t q = qa;
+        bool closed = false;
+        for (; q < ext; ++q) {
+            const uint32_t p = start + q;
+            const uint32_t k0 = s_off[q], nq = s_off[q + 1] - k0;
+            const int32_t cov = s_cov[q];
+            uint32_t b0, d0;
+            pf_n0_key(p, cc2, cc1, cc0, b0, d0);
+            const bool valid = j == 0 || j - 1 < nq;
+            uint32_t key = b0 | (d0 << 16), cnt = 0;
+            if (j && valid) key = s_nkey[k0 + j - 1], cnt = s_ncw[k0 + j - 1] & PF_IDX_MASK;
+            const uint32_t ce = (j && valid && node_delta3((uint16_t)key, (uint16_t)(key >> 16)) == 0) ? cnt : 0u;
+            const uint32_t e0 = pf_quad_bcast<1>(ce) + pf_quad_bcast<2>(ce) + pf_quad_bcast<3>(ce);
+            if (j == 0) cnt = (uint32_t)cov - e0;
+            const uint32_t kb = key & 0xFFFFu, kd = key >> 16;
+            const int32_t w = 10 * (int32_t)cnt - 4 * cov;
+            const bool head = ((kb >> 4) & 0xFu) == 15u; // second column is a head sentinel: a path starts here
+            const bool same_pos = (kb & 0x1000u) != 0;   // second column at p, else at p - 1
+            const uint32_t want = ((kb >> 4) & 0xFFu) | (((kb >> 14) & 1u) << 12);
+            int32_t score = head ? w : PF_NEG;
+            uint32_t besti = 0;
+            { // the previous position's nodes, in the reference's order
+                const bool mine = valid && !head && !same_pos, far = p - 1 >= 3;
+                uint32_t vk, vv;
+                int32_t vs;
+                vk = pf_quad_bcast<0>(pK), vs = (int32_t)pf_quad_bcast<0>((uint32_t)pS), vv = pf_quad_bcast<0>(pV);
+                if (mine && vv) pred_test(vk, vs, want, kd, far, w, 0u, score, besti);
+                vk = pf_quad_bcast<1>(pK), vs = (int32_t)pf_quad_bcast<1>((uint32_t)pS), vv = pf_quad_bcast<1>(pV);
+                if (mine && vv) pred_test(vk, vs, want, kd, far, w, 1u, score, besti);
+                vk = pf_quad_bcast<2>(pK), vs = (int32_t)pf_quad_bcast<2>((uint32_t)pS), vv = pf_quad_bcast<2>(pV);
+                if (mine && vv) pred_test(vk, vs, want, kd, far, w, 2u, score, besti);
+                vk = pf_quad_bcast<3>(pK), vs = (int32_t)pf_quad_bcast<3>((uint32_t)pS), vv = pf_quad_bcast<3>(pV);
+                if (mine && vv) pred_test(vk, vs, want, kd, far, w, 3u, score, besti);
+            }
+            { // the earlier nodes of this position (node i is final before round i: its own predecessors are nodes < i)
+                const bool mine = valid && !head && same_pos, far = p >= 3;
+                uint32_t vk;
+                int32_t vs;
+                vk = pf_quad_bcast<0>(key), vs = (int32_t)pf_quad_bcast<0>((uint32_t)score);
+                if (mine && j > 0) pred_test(vk, vs, want, kd, far, w, 0u, score, besti);
+                vk = pf_quad_bcast<1>(key), vs = (int32_t)pf_quad_bcast<1>((uint32_t)score);
+                if (mine && j > 1) pred_test(vk, vs, want, kd, far, w, 1u, score, besti);
+                vk = pf_quad_bcast<2>(key), vs = (int32_t)pf_quad_bcast<2>((uint32_t)score);
+                if (mine && j > 2) pred_test(vk, vs, want, kd, far, w, 2u, score, besti);
+            }
+            if (j == 0) {
+                s_n0bi[q] = (uint16_t)besti;
+                my_score = score;
+            } else if (valid) {
+                s_score[k0 + j - 1] = score;
+                s_ncw[k0 + j - 1] = cnt | (besti << PF_COUNT_BITS);
+            }
+            if (nq == 0) { // the clean position that closes the run
+                closed = true;
+                break;
+            }
+            pK = key, pS = score, pV = valid ? 1u : 0u;
+            pv_k0 = k0, pv_n = nq, pv_s0 = (int32_t)pf_quad_bcast<0>((uint32_t)score);
+            cc2 = cc1, cc1 = cc0, cc0 = s_ref[q + 4];
+        }
+        if (j == 0) finish_run(qa, q, closed, my_score, base, pv_s0, pv_k0, pv_n);
+    }
+    // (3) the runs with a deeper position: one lane each, every (node, predecessor) pair out of LDS
+    for (uint32_t r = tid; r < n_one; r += 256) {
+        const uint32_t qa = s_ql[TILE / 2 + 1 - r];
+        const uint32_t a = start + qa;
+        int32_t base = 0;
+        if (a == 1 || a == 2) base = 6 * (int32_t)s_cov[0] + (a == 2 ? 6 * (int32_t)s_cov[1] : 0);
+        uint32_t cc2 = s_ref[qa + 1], cc1 = s_ref[qa + 2], cc0 = s_ref[qa + 3];
         uint32_t pv_b0 = 0, pv_d0 = 0;
         bool pv_valid = a > 0;
         if (pv_valid) pf_n0_key(a - 1, s_ref[qa], cc2, cc1, pv_b0, pv_d0);
@@ -524,23 +698,10 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
                     }
                     if (ok) {
                         for (uint32_t pi = 0; pi < qn; ++pi) { // predecessors in the reference's order (main.rs:1664-1674)
-                            uint32_t vb = qb0, vd = qd0;
+                            uint32_t vkey = qb0 | (qd0 << 16);
                             int32_t ps = qs0;
-                            if (pi) {
-                                const uint32_t vk = s_nkey[qk0 + pi - 1];
-                                vb = vk & 0xFFFFu, vd = vk >> 16;
-                                ps = s_score[qk0 + pi - 1];
-                            }
-                            if ((vb & 0x10FFu) != want) continue;
-                            const uint32_t v2d = (vb & 0x4000) ? ((vd + 1) & 0xFFFFu) : 0u;
-                            if (v2d != kd) continue;
-                            const uint32_t v1q = (vb >> 8) & 0xFu;
-                            if (qq >= 3 && v1q == 15) continue; // main.rs:1666-1668
-                            const int32_t sc = ps + w;
-                            if (sc > score || (sc == score && v1q != 4)) { // main.rs:1670
-                                score = sc;
-                                besti = pi;
-                            }
+                            if (pi) vkey = s_nkey[qk0 + pi - 1], ps = s_score[qk0 + pi - 1];
+                            pred_test(vkey, ps, want, kd, qq >= 3, w, pi, score, besti);
                         }
                     }
                 }
@@ -559,64 +720,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
             pv_k0 = k0, pv_n = nq, pv_b0 = b0, pv_d0 = d0, pv_s0 = s0_cur, pv_valid = true;
             cc2 = cc1, cc1 = cc0, cc0 = s_ref[q + 4];
         }
-        uint32_t wq, widx; // where the walk back begins
-        if (closed) {
-            gain += (long long)s0_cur - base;
-            wq = q - 1, widx = s_n0bi[q];
-            s_n0bi[q] = 0; // (the closing position is written out as a clean position: no mark, no index)
-        } else if (start + q == L) {
-            // the run reaches the contig end: the best end node (main.rs:1651,1680: the last one of maximal score; that the
-            // score is >= 0 is checked by the host against the total of all gains: end_rel + total)
-            // A read-start node's score is the absolute 10 count - 4 coverage (main.rs:1659-1660), the others' are relative
-            // to the node left of the run (a >= 3): one with a negative score can never be chosen (the choice starts at the
-            // default node's 0), one that reaches 0 — a read starting at the very last position with more copies than the
-            // pileup is deep there — competes with the path's total, which only k_dp_finish knows: the pass is handed back.
-            int32_t best = pv_s0;
-            uint32_t bi = 0;
-            for (uint32_t k = 0; k < pv_n; ++k) {
-                const int32_t sc = s_score[pv_k0 + k];
-                if (a >= 3 && ((s_nkey[pv_k0 + k] >> 4) & 0xFu) == 15u) {
-                    if (sc >= 0) atomicOr(A.flags, PF_REDO);
-                    continue;
-                }
-                if (sc >= best) best = sc, bi = k + 1;
-            }
-            gain -= base;
-            s_endrel = best <= PF_NEG / 2 ? (long long)SCORE_NEG : (long long)best;
-            s_flag[4] = 1;
-            wq = q - 1, widx = bi;
-        } else { // still open at the end of the halo
-            s_flag[1] = 1;
-            continue;
-        }
-        // walk back, marking the nodes of the path
-        for (;;) {
-            const uint32_t p = start + wq;
-            uint32_t bi;
-            bool back;
-            if (widx == 0) {
-                const uint32_t x = s_n0bi[wq];
-                s_n0bi[wq] = (uint16_t)(x | PF_N0_VISITED);
-                bi = x & PF_IDX_MASK;
-                if (p == 0) break; // N0(0) = (head, head, c0): the path starts here
-                back = true;
-            } else {
-                const uint32_t k = s_off[wq] + widx - 1;
-                const uint32_t x = s_ncw[k], kb = s_nkey[k] & 0xFFFFu;
-                s_ncw[k] = x | PF_VISITED;
-                bi = (x >> PF_COUNT_BITS) & PF_IDX_MASK;
-                if (((kb >> 4) & 0xF) == 15) { // a read's start node: the path begins at p (only reachable for p <= 2)
-                    if (p > 0) atomicMax(&s_flag[2], p);
-                    break;
-                }
-                back = !(kb & 0x1000);
-            }
-            if (back) {
-                if (wq == qa) break; // left the run: N0(a - 1)
-                --wq;
-            }
-            widx = bi;
-        }
+        finish_run(qa, q, closed, s0_cur, base, pv_s0, pv_k0, pv_n);
     }
     stamp(4);
     for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
