@@ -7,8 +7,11 @@
  *   record admission + packing    src/main.rs:1758-1817   (filters, fill_with_cigar, is_clip, trim(8),
  *                                                          AlignSeq::new, filter_alignseqs_by_clip)
  *   yak v2 dump header + buckets  src/utils/kmer.rs:72-170
- * BGZF inflate and BAM parsing run on the host (zlib); the CIGAR walk / trim(8) / nibble packing
- * is a HIP kernel that writes the packed pileup straight into HBM (np2_contig_t).
+ * BGZF inflate and BAM parsing run on the host pool (libdeflate / zlib) or — NP2_INFLATE=gpu, and by default when this
+ * rank has fewer than six host CPUs to itself — ON THE DEVICE: the contig's BGZF blocks are uploaded as they lie in the
+ * file, inflated one wavefront per block (csrc/np2_inflate.hip), the records found by walking the inflated stream along
+ * the .bai linear index, and the SEQ bytes read by the columnariser where the inflater left them.  The CIGAR walk /
+ * trim(8) / nibble packing is a HIP kernel that writes the packed pileup straight into HBM (np2_contig_t) either way.
  */
 #ifndef NP2_IO_H
 #define NP2_IO_H
@@ -91,6 +94,12 @@ int np2_shard_bam_begin(np2_ctx_t *ctx, np2_bam_t *bam, const char *name, const 
 int np2_shard_bam_finish(np2_shard_io_t *io, const uint64_t *all_voffsets, uint64_t n_all, np2_shard_plan_t *plan,
                          np2_contig_t **contig, uint32_t *n_reads_total);
 void np2_shard_bam_abort(np2_shard_io_t *io);
+/* A run of whole BGZF blocks (`bgzf`, `n` bytes: a BAM file or a piece of one that starts at a block) inflated on ctx's
+ * device by the kernel np2_contig_from_bam uses, the bytes copied back to `out` (capacity out_cap; *out_len = what the
+ * blocks hold).  kernel_ms (optional): the inflate kernel alone (HIP events).  For parity tests against zlib and for
+ * measuring the kernel; the reference's counterpart is rust-htslib's bgzf reader (main.rs:1745-1757). */
+int np2_bgzf_inflate_device(np2_ctx_t *ctx, const uint8_t *bgzf, uint64_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                            float *kernel_ms);
 /* copy a resident packed pileup back to the host (parity tests / debugging); free both with np2_free */
 int np2_contig_export(np2_ctx_t *ctx, np2_contig_t *c, np2_read_t **reads, uint32_t *n_reads,
                       uint8_t **nibbles, uint64_t *nib_bytes);

@@ -33,6 +33,7 @@ IO_ABI_SYMBOLS = [
     "np2_fasta_open", "np2_fasta_next", "np2_fasta_close", "np2_yak_load", "np2_yak_free", "np2_bam_open", "np2_bam_close",
     "np2_bam_n_refs", "np2_bam_ref_name", "np2_io_last_error", "np2_contig_from_records", "np2_contig_from_bam",
     "np2_contig_export", "np2_shard_bam_begin", "np2_shard_bam_finish", "np2_shard_bam_abort", "np2_ctx_create_from_files",
+    "np2_bgzf_inflate_device",
 ]
 
 ERRORS = {-1: "NP2_E_ARG", -2: "NP2_E_DEVICE", -3: "NP2_E_NOMEM", -4: "NP2_E_UNSUPPORTED", -5: "NP2_E_REFPANIC"}

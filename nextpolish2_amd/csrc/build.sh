@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")"
 ARCH=${NP2_ARCH:-gfx950}
 FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-omit-frame-pointer ${NP2_EXTRA_FLAGS:-}"
-SRCS="np2_dense.hip np2_kernels.hip np2_graph.hip np2_passfront.hip np2_cand.hip np2_regions.hip np2_front.hip np2_prims.hip np2_host.cpp np2_io.cpp np2_batch.cpp"
+SRCS="np2_dense.hip np2_kernels.hip np2_graph.hip np2_passfront.hip np2_cand.hip np2_regions.hip np2_front.hip np2_inflate.hip np2_prims.hip np2_host.cpp np2_io.cpp np2_batch.cpp"
 mkdir -p obj
 pids=()
 objs=()

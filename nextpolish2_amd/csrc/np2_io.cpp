@@ -22,6 +22,8 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include "np2_inflate.hpp"
+#include "np2_inflate_core.hpp"
 namespace {
 
 // Raw-deflate decoder for BGZF blocks (each block is one complete deflate stream of known inflated size): libdeflate's
@@ -712,6 +714,8 @@ struct np2_bam {
     PinnedBytes seq4; // SEQ staging of the contig being read (-S, and callers without a context; capacity kept across contigs)
     SeqStream seqs;   // ... streamed to the device batch by batch (the usual path)
     BgzfBatch batch;  // batch inflater (its buffer is reused from contig to contig)
+    struct GpuFetch *gpu = nullptr; // read extraction on the device (NP2_INFLATE=gpu / auto: fetch_records_gpu); made on first use
+    ~np2_bam();
     const uint8_t *map = nullptr; // the whole file, mapped read-only (BgzfBatch inflates out of it)
     size_t map_len = 0;
 };
@@ -1761,6 +1765,303 @@ int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const
     return NP2_OK;
 }
 
+// ---- read extraction on the device ---------------------------------------------------------------------------------------
+// The contig's BGZF blocks go to the device as they lie in the file, are inflated there (k_bgzf_inflate: one wavefront per
+// block), and the records are found by walking the inflated stream along the .bai linear index (k_bam_chain_*).  The host
+// parses the 18-byte block headers, converts the index's virtual offsets to stream offsets and reads back one
+// np2_bamrec_t + the CIGAR words per record for the admission pass (front_begin) — no payload byte is touched here, and the
+// SEQ bytes never leave the device: a record's seq_off points into the inflated stream, which the columnariser reads in place.
+//
+// When: NP2_INFLATE=gpu, or — unset — when this rank's share of the host is under six CPUs (eight ranks of a node on a
+// 16-CPU quota have two each: the pool's inflate, 3.3 ms per E. coli-sized contig on 64 threads, is 50 ms on two).
+// -S (SEQ of secondary records from their primaries) and reference-interval shards stay on the host path.
+struct GpuFetch {
+    np2h::DevBuf<uint8_t> d_comp, d_inf;
+    np2h::DevBuf<np2::InfBlock> d_blk;
+    np2h::DevBuf<uint32_t> d_status, d_cigar;
+    np2h::DevBuf<uint64_t> d_starts, d_cig_src;
+    np2h::DevBuf<uint2> d_info, d_off;
+    np2h::DevBuf<np2_bamrec_t> d_recs;
+    void *h_recs = nullptr, *h_cigar = nullptr; // pinned blocks the caller reads the records from (until the next fetch)
+    size_t h_recs_cap = 0, h_cigar_cap = 0;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t PIECE = (size_t)16 << 20;
+    GpuFetch() { d_comp.cached = d_inf.cached = true; }
+    ~GpuFetch() {
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) np2h::pinned_pool().put(pin[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+        if (h_recs) np2h::pinned_pool().put(h_recs);
+        if (h_cigar) np2h::pinned_pool().put(h_cigar);
+    }
+    void *host_block(void *&p, size_t &cap, size_t bytes) {
+        if (cap < bytes) {
+            if (p) np2h::pinned_pool().put(p);
+            p = nullptr, cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            p = np2h::pinned_pool().get(want);
+            if (!p) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            cap = want;
+        }
+        return p;
+    }
+    // file bytes [src, src + n) -> dst (device), through two alternating pinned pieces filled by the host pool
+    void upload(const uint8_t *src, size_t n, uint8_t *dst, hipStream_t s) {
+        for (int i = 0; i < 2; ++i) {
+            if (!pin[i]) {
+                pin[i] = np2h::pinned_pool().get(PIECE);
+                if (!pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+            }
+            if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        size_t piece = 0;
+        for (size_t o = 0; o < n; o += PIECE, ++piece) {
+            const int sl = (int)(piece & 1);
+            if (piece >= 2) HIPCHK(hipEventSynchronize(ev[sl]));
+            const size_t want = std::min(PIECE, n - o);
+            uint8_t *stage = (uint8_t *)pin[sl];
+            const size_t SUB = (size_t)1 << 20;
+            IoPool::get().parallel_for((want + SUB - 1) / SUB, 16, [&](size_t k) {
+                memcpy(stage + k * SUB, src + o + k * SUB, std::min(SUB, want - k * SUB));
+            });
+            HIPCHK(hipMemcpyAsync(dst + o, stage, want, hipMemcpyHostToDevice, s));
+            HIPCHK(hipEventRecord(ev[sl], s));
+        }
+    }
+};
+np2_bam::~np2_bam() { delete gpu; }
+
+namespace {
+bool gpu_fetch_wanted() {
+    static const int mode = [] {
+        if (const char *e = getenv("NP2_INFLATE")) return !strcmp(e, "gpu") ? 1 : 0;
+        return np2h::usable_cpus() / std::max(1u, np2h::local_ranks()) < 6u ? 1 : 0;
+    }();
+    return mode == 1;
+}
+struct GpuRecs {
+    const np2_bamrec_t *recs = nullptr;
+    const uint32_t *cigar = nullptr;
+    uint32_t n_recs = 0;
+    const uint8_t *d_stream = nullptr;
+    uint64_t stream_bytes = 0;
+};
+// The records of reference `tid` (all of them: fetch(tid, 0, L)).  false: this BAM / index cannot take the device path
+// (no linear index, an index entry that is not a record start) — the caller reads it the host way.
+bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs &out) {
+    const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
+    const double t0 = np2h::now_ms();
+    const uint64_t start_off = bam->ref_start[tid];
+    if (start_off == ~0ull) return true; // no record of this reference
+    if (bam->lin[tid].empty()) return false;
+    if (!bam->gpu) bam->gpu = new GpuFetch();
+    GpuFetch &g = *bam->gpu;
+    BgzfBatch hdr; // (only its block-header parser is used)
+    hdr.map = bam->map, hdr.map_len = bam->map_len;
+    const size_t c_lo = (size_t)(start_off >> 16);
+    size_t c_hi = bam->ref_end[tid] ? (size_t)(bam->ref_end[tid] >> 16) : bam->map_len; // file offset of the last block wanted
+    std::vector<BgzfBatch::Blk> blks;
+    std::vector<uint64_t> out_off;
+    size_t extra = 0; // blocks beyond the index's end of the reference (an index that understates it costs a second round)
+    for (int round = 0;; ++round) {
+        if (round > 40) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+        // ---- the block table: headers only --------------------------------------------------------------------------------
+        blks.clear();
+        hdr.fpos = c_lo;
+        bool eof = false;
+        size_t beyond = 0;
+        for (;;) {
+            BgzfBatch::Blk b;
+            if (!hdr.read_raw(b)) {
+                eof = true;
+                break;
+            }
+            if (b.file_off > c_hi && beyond++ >= extra) {
+                // (nothing but the end-of-file marker behind the range: the range IS the rest of the file)
+                if (b.isize == 0 && hdr.fpos >= hdr.map_len) eof = true;
+                break;
+            }
+            blks.push_back(b);
+        }
+        if (blks.empty()) return true;
+        const size_t n_blk = blks.size();
+        const uint8_t *c_base = bam->map + c_lo;
+        const size_t c_bytes = (size_t)((blks.back().c + blks.back().clen + 8) - c_base);
+        out_off.assign(n_blk + 1, 0);
+        for (size_t i = 0; i < n_blk; ++i) out_off[i + 1] = out_off[i] + blks[i].isize;
+        const uint64_t total = out_off[n_blk];
+        const double t1 = np2h::now_ms();
+        // ---- file bytes to the device, inflate ------------------------------------------------------------------------------
+        g.d_comp.ensure(c_bytes + 64);
+        g.d_inf.ensure(total + 128);
+        g.d_blk.ensure(n_blk + 1);
+        g.d_status.ensure(n_blk + 8);
+        g.upload(c_base, c_bytes, g.d_comp.p, s);
+        double t_up = 0, t_inf = 0;
+        if (prof) {
+            HIPCHK(hipStreamSynchronize(s));
+            t_up = np2h::now_ms();
+        }
+        std::vector<np2::InfBlock> tb(n_blk);
+        for (size_t i = 0; i < n_blk; ++i) tb[i] = np2::InfBlock{(uint64_t)(blks[i].c - c_base), out_off[i], blks[i].clen, blks[i].isize};
+        np2::InfBlock *h_tb = (np2::InfBlock *)g.host_block(g.h_cigar, g.h_cigar_cap, n_blk * sizeof(np2::InfBlock)); // (free until the records come back)
+        memcpy(h_tb, tb.data(), n_blk * sizeof(np2::InfBlock));
+        HIPCHK(hipMemcpyAsync(g.d_blk.p, h_tb, n_blk * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
+        // status words: [0, n_blk) per block, then n_bad, walk flags, (pad), tail_at (64-bit, 8-byte aligned)
+        const size_t w_bad = (n_blk + 1) & ~(size_t)1, w_flags = w_bad + 1, w_tail = w_bad + 2;
+        HIPCHK(hipMemsetAsync(g.d_status.p, 0, (w_tail + 2) * 4, s));
+        HIPCHK(hipMemsetAsync(g.d_status.p + w_tail, 0xFF, 8, s));
+        HIPCHK(hipMemsetAsync(g.d_inf.p + total, 0, 64, s)); // (the columnariser loads whole words behind the last SEQ)
+        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)n_blk, g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + w_bad);
+        if (prof) {
+            HIPCHK(hipStreamSynchronize(s));
+            t_inf = np2h::now_ms();
+        }
+        // ---- chain starts: the linear index's record starts inside the range ----------------------------------------------------
+        std::vector<uint64_t> starts;
+        starts.push_back(out_off[0] + (start_off & 0xFFFF));
+        {
+            size_t bi = 0;
+            uint64_t prev = start_off;
+            for (uint64_t v : bam->lin[tid]) {
+                if (v <= prev) continue; // (0 = empty window; entries repeat while one record spans several windows)
+                const uint64_t fo = v >> 16;
+                while (bi < n_blk && blks[bi].file_off < fo) ++bi;
+                if (bi == n_blk) break;           // beyond the range read so far
+                if (blks[bi].file_off != fo) return false; // not the start of a block: the index is not this file's
+                const uint64_t so = out_off[bi] + (v & 0xFFFF);
+                if ((v & 0xFFFF) >= blks[bi].isize) return false;
+                starts.push_back(so);
+                prev = v;
+            }
+        }
+        const uint32_t n_chains = (uint32_t)starts.size();
+        g.d_starts.ensure(n_chains + 1);
+        g.d_info.ensure(n_chains + 1);
+        g.d_off.ensure(n_chains + 1);
+        uint64_t *h_st = (uint64_t *)g.host_block(g.h_recs, g.h_recs_cap, (size_t)n_chains * 8 + 64);
+        memcpy(h_st, starts.data(), (size_t)n_chains * 8);
+        HIPCHK(hipMemcpyAsync(g.d_starts.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
+        np2::launch_bam_chain_count(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, g.d_info.p, g.d_status.p + w_flags,
+                                    (unsigned long long *)(g.d_status.p + w_tail));
+        // one wait: block statuses' summary, the walk's flags, the chains' counts
+        std::vector<uint2> info(n_chains);
+        uint32_t tailw[4];
+        HIPCHK(hipMemcpyAsync(h_st, g.d_info.p, (size_t)n_chains * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_tb, g.d_status.p + w_bad, 16, hipMemcpyDeviceToHost, s)); // (stream order: after the table's upload has read it)
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(info.data(), h_st, (size_t)n_chains * 8);
+        memcpy(tailw, h_tb, 16);
+        const double t2 = np2h::now_ms();
+        if (tailw[0]) { // which block, and why
+            std::vector<uint32_t> stv(n_blk);
+            HIPCHK(hipMemcpy(stv.data(), g.d_status.p, n_blk * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n_blk; ++i)
+                if (stv[i]) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed (block at file offset " + std::to_string(blks[i].file_off) + ", status " + std::to_string(stv[i]) + ")");
+        }
+        const uint32_t flags = tailw[1];
+        if (flags & np2::WALK_BAD) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
+        if (flags & np2::WALK_MISALIGNED) return false;
+        if ((flags & (np2::WALK_TAIL | np2::WALK_AT_END)) && !eof) { // the reference's records go on beyond the index's end: further
+            extra = std::max<size_t>(16, extra * 2 + n_blk / 4);
+            continue;
+        }
+        if (flags & np2::WALK_TAIL) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+        // ---- offsets of the chains' records and CIGAR words, the records themselves ---------------------------------------------------
+        std::vector<uint2> off(n_chains);
+        uint64_t n_rec = 0, n_cig = 0;
+        for (uint32_t c = 0; c < n_chains; ++c) {
+            off[c] = make_uint2((uint32_t)n_rec, (uint32_t)n_cig);
+            n_rec += info[c].x, n_cig += info[c].y;
+        }
+        if (n_rec > 0xFFFFFFF0ull || n_cig > 0xFFFFFFF0ull) throw np2h::Np2Error(NP2_E_NOMEM, "too many records for one contig");
+        out.n_recs = (uint32_t)n_rec;
+        out.d_stream = g.d_inf.p;
+        out.stream_bytes = total + 16;
+        if (n_rec) {
+            g.d_recs.ensure(n_rec + 1);
+            g.d_cig_src.ensure(n_rec + 1);
+            g.d_cigar.ensure(n_cig + 1);
+            memcpy(h_st, off.data(), (size_t)n_chains * 8);
+            HIPCHK(hipMemcpyAsync(g.d_off.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
+            np2::launch_bam_chain_write(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, g.d_off.p, g.d_recs.p, g.d_cig_src.p);
+            np2::launch_bam_cigars(s, g.d_inf.p, g.d_recs.p, g.d_cig_src.p, (uint32_t)n_rec, g.d_cigar.p);
+            HIPCHK(hipStreamSynchronize(s)); // (h_st is about to be given up for a larger block)
+            if (prof) fprintf(stderr, "  fetch_records_gpu: offsets + write + cigars %.2f ms\n", np2h::now_ms() - t2);
+            np2_bamrec_t *hr = (np2_bamrec_t *)g.host_block(g.h_recs, g.h_recs_cap, n_rec * sizeof(np2_bamrec_t) + 64);
+            uint32_t *hc = (uint32_t *)g.host_block(g.h_cigar, g.h_cigar_cap, n_cig * 4 + 64);
+            HIPCHK(hipMemcpyAsync(hr, g.d_recs.p, n_rec * sizeof(np2_bamrec_t), hipMemcpyDeviceToHost, s));
+            if (n_cig) HIPCHK(hipMemcpyAsync(hc, g.d_cigar.p, n_cig * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            out.recs = hr, out.cigar = hc;
+        }
+        if (prof)
+            fprintf(stderr, "fetch_records_gpu: %zu blocks (%.1f MB -> %.1f MB), %u chains, %llu records, %llu CIGAR words: headers %.2f ms, "
+                            "upload %.2f ms, inflate %.2f ms, index + count + wait %.2f ms, records back %.2f ms%s\n", n_blk, c_bytes / 1e6, total / 1e6, n_chains,
+                    (unsigned long long)n_rec, (unsigned long long)n_cig, t1 - t0, t_up - t1, t_inf - t_up, t2 - t_inf, np2h::now_ms() - t2, round ? " (after extending the range)" : "");
+        return true;
+    }
+}
+} // namespace
+
+int np2_bgzf_inflate_device(np2_ctx_t *cx, const uint8_t *bgzf, uint64_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                            float *kernel_ms) {
+    if (!cx || (!bgzf && n) || !out_len || (!out && out_cap)) return NP2_E_ARG;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    try {
+        HIPCHK(hipSetDevice(cx->device));
+        hipStream_t s = cx->stream;
+        BgzfBatch hdr;
+        hdr.map = bgzf, hdr.map_len = (size_t)n, hdr.fpos = 0;
+        std::vector<np2::InfBlock> tb;
+        uint64_t total = 0;
+        for (;;) {
+            BgzfBatch::Blk b;
+            if (!hdr.read_raw(b)) break;
+            tb.push_back(np2::InfBlock{(uint64_t)(b.c - bgzf), total, b.clen, b.isize});
+            total += b.isize;
+        }
+        *out_len = total;
+        if (total > out_cap) throw np2h::Np2Error(NP2_E_ARG, "output buffer too small");
+        if (tb.empty()) return NP2_OK;
+        GpuFetch g;
+        g.d_comp.ensure(n + 64);
+        g.d_inf.ensure(total + 64);
+        g.d_blk.ensure(tb.size() + 1);
+        g.d_status.ensure(tb.size() + 8);
+        g.upload(bgzf, (size_t)n, g.d_comp.p, s);
+        HIPCHK(hipMemcpyAsync(g.d_blk.p, tb.data(), tb.size() * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(g.d_status.p, 0, (tb.size() + 4) * 4, s));
+        HIPCHK(hipStreamSynchronize(s)); // (tb is pageable: the copy must have read it before it goes)
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, s));
+        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)tb.size(), g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + tb.size());
+        HIPCHK(hipEventRecord(e1, s));
+        std::vector<uint32_t> st(tb.size() + 1);
+        HIPCHK(hipMemcpyAsync(st.data(), g.d_status.p, st.size() * 4, hipMemcpyDeviceToHost, s));
+        if (total) HIPCHK(hipMemcpyAsync(out, g.d_inf.p, total, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, e0, e1));
+        (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+        e0 = e1 = nullptr;
+        for (size_t i = 0; i < tb.size(); ++i)
+            if (st[i]) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed (block " + std::to_string(i) + ", status " + std::to_string(st[i]) + ")");
+    } catch (const np2h::Np2Error &e) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamSynchronize(cx->stream);
+        return io_fail(e.code, e.what());
+    } catch (const std::exception &ex) {
+        (void)hipStreamSynchronize(cx->stream);
+        return io_fail(NP2_E_NOMEM, ex.what());
+    }
+    return NP2_OK;
+}
+
 int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const uint8_t *ref, uint32_t L,
                         const np2_front_opts_t *opts, np2_contig_t **out) {
     if (!cx || !bam || !name || !ref || !opts || !out) return NP2_E_ARG;
@@ -1778,6 +2079,18 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = bam->batch.ms_walk = bam->batch.ms_size = bam->batch.ms_copy = 0;
         HIPCHK(hipSetDevice(cx->device));
         uint64_t seq_bytes = 0;
+        if (gpu_fetch_wanted() && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
+            GpuRecs gr;
+            if (fetch_records_gpu(bam, tid, L, cx->stream, gr)) {
+                const double t_g1 = np2h::now_ms();
+                FrontWork fw;
+                front_begin(cx, ref, L, gr.recs, gr.n_recs, gr.cigar, nullptr, gr.n_recs ? gr.stream_bytes : 0, opts, nullptr, fw, gr.n_recs ? gr.d_stream : nullptr);
+                front_finish(cx, fw, out);
+                if (prof) fprintf(stderr, "np2_contig_from_bam %s: device read extraction %.2f ms (%u records), records->pileup %.2f ms\n", name, t_g1 - t_p0, gr.n_recs, np2h::now_ms() - t_g1);
+                np2h::flush_timings(cx);
+                return NP2_OK;
+            }
+        }
         fetch_records(bam, tid, L, 0, L, opts, recs, cigar, nullptr, cx->stream, &seq_bytes);
         const double t_p1 = np2h::now_ms();
         {

@@ -12,7 +12,7 @@ assert BAMREC_DTYPE.itemsize == 40
 
 IO_SYMBOLS = ["np2_fasta_open", "np2_fasta_next", "np2_fasta_close", "np2_yak_load", "np2_yak_free", "np2_bam_open",
               "np2_bam_close", "np2_bam_n_refs", "np2_bam_ref_name", "np2_io_last_error", "np2_contig_from_records",
-              "np2_contig_from_bam", "np2_contig_export", "np2_ctx_create_from_files"]
+              "np2_contig_from_bam", "np2_contig_export", "np2_ctx_create_from_files", "np2_bgzf_inflate_device"]
 
 
 class np2_front_opts_t(C.Structure):
@@ -77,6 +77,7 @@ def _bind_locked(L):
                                               C.POINTER(vp)]
         L.np2_contig_from_bam.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.POINTER(np2_front_opts_t), C.POINTER(vp)]
         L.np2_contig_export.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.np2_bgzf_inflate_device.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         _bind_shard(L)
 
 
@@ -287,3 +288,19 @@ def export_contig(pol, contig, ref):
     L.np2_free(pr)
     L.np2_free(pn)
     return Pileup(ref, reads, nib)
+
+
+def bgzf_inflate_device(pol, data):
+    """np2_bgzf_inflate_device: a run of whole BGZF blocks (bytes / uint8 array) inflated on the polisher's device by the
+    kernel np2_contig_from_bam uses -> (inflated bytes as a uint8 array, kernel milliseconds)."""
+    L = _bind()
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+    # ISIZE of every block bounds the output: 64 KiB a block, a block is at least 28 bytes
+    cap = max(1, (len(src) // 28 + 1)) * 65536
+    cap = min(cap, max(1 << 20, len(src) * 1100))  # (deflate expands at most ~1032 x)
+    out = np.empty(cap, dtype=np.uint8)
+    n, ms = C.c_uint64(), C.c_float()
+    rc = L.np2_bgzf_inflate_device(pol._h, src.ctypes.data, len(src), out.ctypes.data, cap, C.byref(n), C.byref(ms))
+    if rc != 0:
+        raise Np2Error(rc, "np2_bgzf_inflate_device: " + (L.np2_io_last_error() or b"").decode())
+    return out[: n.value].copy(), float(ms.value)
