@@ -22,6 +22,7 @@
 #include <algorithm>
 #include "np2_inflate_core.hpp"
 #include "np2_inflate.hpp"
+#include "np2_blockscan.hpp"
 
 namespace np2 {
 
@@ -29,7 +30,9 @@ static constexpr uint32_t INF_RING = 8192;   // output window kept in LDS (bytes
                                              // output where it was flushed to (every byte at least INF_RING back has been)
 static constexpr uint32_t INF_IN = 4096;     // input window
 static constexpr uint32_t INF_CHUNK = 2048;  // input staged per refill
-static constexpr uint32_t INF_FLUSH = 4096;  // output written to memory per flush
+static constexpr uint32_t INF_FLUSH = 2048;  // output written to memory per flush
+static constexpr uint32_t INF_WIDE_SPAN = 2048; // most output one wide step may produce (a chain is cut where it would exceed it)
+static_assert(INF_WIDE_SPAN >= 258 && INF_RING - INF_WIDE_SPAN >= INF_FLUSH + INF_WIDE_SPAN + 258, "far sources of a wide step are flushed");
 
 static_assert(INF_FLUSH + 258 <= INF_RING, "a far match must find its sources flushed");
 struct InfShared {
@@ -69,14 +72,16 @@ __device__ __noinline__ void inf_stage(InfShared &S, const uint8_t *__restrict__
     *reinterpret_cast<uint4 *>(dst + 16) = b;
     inf_sync();
 }
-// whole INF_FLUSH pieces of the ring to memory, 64 bytes a lane; returns the new `flushed`
+// whole INF_FLUSH pieces of the ring to memory, INF_FLUSH / 64 bytes a lane; returns the new `flushed`
 __device__ __noinline__ uint32_t inf_flush(InfShared &S, uint8_t *__restrict__ gout, uint32_t lane, uint32_t flushed, uint32_t out) {
     while (out - flushed >= INF_FLUSH) {
         inf_sync();
-        const uint8_t *src = S.ring + ((flushed & (INF_RING - 1u)) + lane * 64u);
-        uint8_t *dst = gout + flushed + lane * 64u;
+        constexpr uint32_t PER_LANE = INF_FLUSH / 64u;
+        static_assert(PER_LANE % 16u == 0, "whole 16-byte pieces per lane");
+        const uint8_t *src = S.ring + ((flushed & (INF_RING - 1u)) + lane * PER_LANE);
+        uint8_t *dst = gout + flushed + lane * PER_LANE;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
+        for (uint32_t j = 0; j < PER_LANE / 16u; ++j) {
             const uint4 v = *reinterpret_cast<const uint4 *>(src + 16 * j);
             __builtin_memcpy(dst + 16 * j, &v, 16);
         }
@@ -90,8 +95,8 @@ __device__ __noinline__ uint32_t inf_flush(InfShared &S, uint8_t *__restrict__ g
 // match: reads before writes.  A source further back (dist > INF_RING >= len) has left the window — and has been flushed
 // (the flush lags by less than INF_FLUSH <= INF_RING - 258 bytes): it is read back from memory, past this CU's vector
 // cache (the flush's stores went through to L2).
-__device__ __noinline__ void inf_copy_general(InfShared &S, const uint8_t *gout, uint32_t lane, uint32_t out, uint32_t len, uint32_t dist) {
-    if (dist <= INF_RING) {
+__device__ __noinline__ void inf_copy_general(InfShared &S, const uint8_t *gout, uint32_t lane, uint32_t out, uint32_t len, uint32_t dist, uint32_t near) {
+    if (dist <= near) {
         for (uint32_t k0 = 0; k0 < len; k0 += 64) {
             const uint32_t k = k0 + lane;
             uint8_t v = 0;
@@ -100,14 +105,16 @@ __device__ __noinline__ void inf_copy_general(InfShared &S, const uint8_t *gout,
             if (k < len) S.ring[(out + k) & (INF_RING - 1u)] = v;
         }
     } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (this wavefront's flushes have reached L2)
+        // The sources were written by THIS wavefront's flushes — plain stores through this CU's vector cache — and are read
+        // back the same way: inside a workgroup the cache is coherent, so a workgroup-scope fence (wait for the stores) is all
+        // it takes.  Measured on the way: an AGENT-scope release writes the L2 back (buffer_wbl2) — with eight blocks per CU
+        // doing that for each of their ~280 far matches a block's copies went from 1.1 M to 9.8 M clocks —, and agent-scope
+        // (cache-bypassing) LOADS behind a workgroup-scope fence raced with the stores still on their way through the cache.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (uint32_t k0 = 0; k0 < len; k0 += 64) {
             const uint32_t k = k0 + lane;
-            if (k < len) {
-                const uintptr_t a = (uintptr_t)(gout + (out - dist + k));
-                const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                S.ring[(out + k) & (INF_RING - 1u)] = (uint8_t)(w >> (8u * (uint32_t)(a & 3)));
-            }
+            if (k < len) S.ring[(out + k) & (INF_RING - 1u)] = *reinterpret_cast<const volatile uint8_t *>(gout + (out - dist + k));
         }
     }
 }
@@ -126,6 +133,16 @@ struct DevMachine {
     uint8_t *__restrict__ gout;
     uint32_t clen, lane_;
     uint32_t filled = 0, flushed = 0; // input bytes staged / output bytes written to memory (the same in every lane)
+    // phase clocks of a block (NP2_INF_PROF, a tool's switch: np2_bgzf_inflate_device prints their means): [0] the wide
+    // step's decode of 64 offsets, [1] following the chain (literals included), [2] match copies, [3] tokens, [4] matches
+    unsigned long long *prof = nullptr;
+    unsigned long long pacc[7] = {0, 0, 0, 0, 0, 0, 0}; // ([5] table builds, [6] deflate blocks)
+    unsigned long long t_tick = 0;
+    __device__ __forceinline__ void tick(int phase) {
+        if (!prof) return;
+        if (phase == 0) t_tick = clock64();
+        else pacc[5] += clock64() - t_tick, ++pacc[6];
+    }
 
     __device__ __forceinline__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ bool leader() const { return lane_ == 0; }
@@ -177,13 +194,158 @@ struct DevMachine {
             inf_sync();
             if (lane_ < len) S.ring[(out + lane_) & (INF_RING - 1u)] = v;
         } else {
-            inf_copy_general(S, gout, lane_, out, len, dist);
+            inf_copy_general(S, gout, lane_, out, len, dist, INF_RING);
         }
         flush_upto(out + len);
+    }
+    // a match of the wide step: the chain's literals are already in the ring — also those BEHIND this match, up to
+    // INF_WIDE_SPAN bytes ahead of it, which have taken the slots of the window's oldest bytes — so only a source nearer
+    // than INF_RING - INF_WIDE_SPAN is read from the ring, anything further from the flushed output
+    __device__ __forceinline__ void copy_at(uint32_t out, uint32_t len, uint32_t dist) {
+        inf_sync();
+        if (dist >= len && dist <= INF_RING - INF_WIDE_SPAN && len <= 64u) {
+            uint8_t v = 0;
+            if (lane_ < len) v = S.ring[(out - dist + lane_) & (INF_RING - 1u)];
+            inf_sync();
+            if (lane_ < len) S.ring[(out + lane_) & (INF_RING - 1u)] = v;
+        } else {
+            inf_copy_general(S, gout, lane_, out, len, dist, INF_RING - INF_WIDE_SPAN);
+        }
     }
     __device__ __forceinline__ void finish(uint32_t out) {
         commit(out);
         inf_finish(S, gout, lane_, flushed, out);
+    }
+    // THE WIDE STEP.  A symbol at a time, every symbol is a chain — table read, shift, branch: ~1300 clocks, 3.5 ms a block —
+    // that 63 lanes watch.  Here lane i decodes the TOKEN that would start at bit offset i of the stream's next 64 bits — a
+    // literal, an end-of-block code, or a whole match (length code + extra bits + distance code + extra bits: at most 48
+    // bits, and every lane has 64 of its own) — as if a token started there: two LDS gathers and some shifts for all 64
+    // offsets at once.  Only one chain of those offsets is real: the one from offset 0, each token's bit count leading to
+    // the next.  Following it is all that is left to do serially — a readlane and an add per token —, and it carries some
+    // eight tokens per step.  A lane whose bits are no code of the primary tables stops the chain there: the symbol loop of
+    // inflate_stream takes that one token (the long-code path) and comes back.
+    __device__ __forceinline__ uint32_t fast(uint64_t &bb, uint32_t &bc, uint32_t &next, uint32_t &out, uint32_t isize, uint32_t in_limit) {
+        uint32_t bp = next * 8u - bc; // bit offset of the first unconsumed bit
+        uint32_t result = np2inf::ST_OK;
+        for (;;) {
+            if ((bp >> 3) > in_limit) {
+                result = np2inf::ST_IN_OVERRUN;
+                break;
+            }
+            const uint32_t byte_hi = (((bp + 63u) >> 5) << 2) + 12u; // the bytes lane 63 reads end here
+            while (byte_hi > filled) {
+                inf_stage(S, gin, clen, lane_, filled);
+                filled += INF_CHUNK;
+            }
+            const unsigned long long tp0 = prof ? clock64() : 0ull;
+            const uint32_t b = bp + lane_, w = (b >> 5) << 2, sh = b & 31u;
+            const uint32_t d0 = *reinterpret_cast<const uint32_t *>(S.inw + (w & (INF_IN - 1u)));
+            const uint32_t d1 = *reinterpret_cast<const uint32_t *>(S.inw + ((w + 4u) & (INF_IN - 1u)));
+            const uint32_t d2 = *reinterpret_cast<const uint32_t *>(S.inw + ((w + 8u) & (INF_IN - 1u)));
+            uint64_t x = (((uint64_t)d1 << 32) | d0) >> sh;
+            if (sh) x |= (uint64_t)d2 << (64u - sh);
+            const uint32_t e1 = S.lt[(uint32_t)x & ((1u << np2inf::LBITS) - 1u)];
+            const uint32_t l1 = e1 & 15u, k1 = (e1 >> 8) & 3u;
+            // the match reading of my bits (computed by every lane: a second gather whether or not it is used)
+            const uint32_t le = (e1 >> 4) & 15u;
+            uint64_t y = x >> l1;
+            const uint32_t mlen = (e1 >> 16) + ((uint32_t)y & ((1u << le) - 1u));
+            y >>= le;
+            const uint32_t e2 = S.dt[(uint32_t)y & ((1u << np2inf::DBITS) - 1u)];
+            const uint32_t l2 = e2 & 15u, de = (e2 >> 4) & 15u;
+            const uint32_t mdist = (e2 >> 16) + ((uint32_t)(y >> l2) & ((1u << de) - 1u));
+            uint32_t n = 0, kind = 3u, val = 0; // kind: 0 literal, 1 match, 2 end of block, 3 not decodable here (n = 0)
+            if (l1) {
+                if (k1 == np2inf::K_LIT) n = l1, kind = 0, val = e1 >> 16;
+                else if (k1 == np2inf::K_END) n = l1, kind = 2u;
+                else if (k1 == np2inf::K_LEN && l2 && ((e2 >> 8) & 3u) == 0) n = l1 + le + l2 + de, kind = 1u, val = mlen;
+            }
+            const uint32_t T0 = n | (kind << 8) | (val << 16);
+            unsigned long long tp1 = 0;
+            if (prof) {
+                tp1 = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(T0 + (uint32_t)mdist)) * 0ull + clock64(); // (after the gathers have landed)
+                pacc[0] += tp1 - tp0;
+            }
+            // The chain from offset 0: which offsets start a token (a 64-bit scalar mask).  This loop is the serial rest of the
+            // step, a dependent scalar instruction costs this machine ~20 clocks, so it is kept to a lane read, an OR and an
+            // add per token: a lane whose token ends the chain (end of block, not decodable here) reads as 0 bits, and what
+            // stopped it — and the step's output cap — are looked at afterwards.
+            const uint32_t N = kind < 2u ? n : 0u;
+            uint64_t members = 0;
+            uint32_t cur = 0;
+            for (;;) {
+                const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)N, (int)cur);
+                if (!tn) break;
+                members |= 1ull << cur;
+                cur += tn;
+                if (cur >= 64u) break;
+            }
+            uint32_t stop_kind = 0; // 0: ran off the 64 offsets (or reached the step's output cap); 2: end-of-block code (consumed); 3: a token this step cannot decode
+            if (cur < 64u) {
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)T0, (int)cur);
+                stop_kind = (t0 >> 8) & 3u; // (2 or 3: what made the lane read as 0 bits)
+                if (stop_kind == 2u) cur += t0 & 255u;
+            }
+            // output offsets of the chain's tokens (a literal is one byte, a match its length): one scan over the lanes
+            bool mine = (members >> lane_) & 1ull;
+            uint32_t olen = mine ? (kind == 0 ? 1u : val) : 0u;
+            const uint32_t incl = wave_incl_scan<OpAdd>(olen);
+            uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t ooff = incl - olen;
+            if (total > INF_WIDE_SPAN) { // the step's output cap: the chain is cut before the first token that would exceed it
+                const uint64_t over = __ballot(mine && incl > INF_WIDE_SPAN);
+                const uint32_t j = (uint32_t)__builtin_ctzll(over);
+                members &= (1ull << j) - 1ull;
+                mine = mine && lane_ < j;
+                olen = mine ? olen : 0u;
+                total = (uint32_t)__builtin_amdgcn_readlane((int)ooff, (int)j);
+                cur = j, stop_kind = 0;
+            }
+            if (out + total > isize) {
+                result = np2inf::ST_OUT_OVERRUN;
+                break;
+            }
+            if (total) {
+                commit(out); // (literals of the symbol loop still waiting in registers)
+                // every literal of the chain at once ...
+                if (mine && kind == 0) S.ring[(out + ooff) & (INF_RING - 1u)] = (uint8_t)val;
+                // ... and its matches in order (a match may repeat what the tokens before it produced)
+                uint64_t mm = __ballot(mine && kind == 1u);
+                const unsigned long long tc0 = prof ? clock64() : 0ull;
+                while (mm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)T0, (int)j) >> 16;
+                    const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)j);
+                    const uint32_t at = out + (uint32_t)__builtin_amdgcn_readlane((int)ooff, (int)j);
+                    if (dist > at) {
+                        result = np2inf::ST_BAD_DISTANCE;
+                        break;
+                    }
+                    copy_at(at, len, dist);
+                    if (prof) ++pacc[4];
+                }
+                if (prof) pacc[2] += clock64() - tc0;
+                if (result != np2inf::ST_OK) break;
+                out += total;
+                pend_lo = out;
+                flush_upto(out);
+            }
+            if (prof) pacc[1] += clock64() - tp1, pacc[3] += (uint64_t)__builtin_popcountll(members);
+            bp += cur;
+            if (stop_kind == 2u) {
+                result = np2inf::FAST_END_OF_BLOCK;
+                break;
+            }
+            if (stop_kind == 3u) break;
+        }
+        // the symbol loop's bit buffer, from bit offset bp on
+        next = (bp >> 5) << 2;
+        const uint32_t sh = bp & 31u;
+        bb = (uint64_t)(in32(next) >> sh);
+        bc = 32u - sh;
+        next += 4u;
+        return result;
     }
     __device__ __forceinline__ uint32_t slow(int mode, uint32_t bits) { return inf_slow(S, mode, bits); }
     __device__ __forceinline__ uint8_t *lens() { return S.lens; }
@@ -197,16 +359,24 @@ struct DevMachine {
 };
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const InfBlock *__restrict__ blk, uint32_t n_blk, const uint8_t *__restrict__ comp,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ n_bad) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ n_bad,
+                                                     unsigned long long *__restrict__ prof) {
     __shared__ __attribute__((aligned(16))) InfShared S;
     const uint32_t b = blockIdx.x;
     if (b >= n_blk) return;
     const InfBlock B = blk[b];
     DevMachine m{S, comp + B.in_off, out + B.out_off, B.clen, threadIdx.x};
+    m.prof = prof;
+    const unsigned long long t_begin = prof ? clock64() : 0ull;
     uint32_t st = np2inf::ST_OK;
     if (B.isize > 65536u || B.clen > 65536u) st = np2inf::ST_OUT_OVERRUN;
     else st = np2inf::inflate_stream(m, B.clen, B.isize);
     if (st == np2inf::ST_OK) m.finish(B.isize);
+    if (prof && threadIdx.x == 0) {
+        unsigned long long *q = prof + (size_t)b * 8;
+        q[0] = clock64() - t_begin;
+        for (int i = 0; i < 7; ++i) q[1 + i] = m.pacc[i];
+    }
     if (threadIdx.x == 0) {
         status[b] = st;
         if (st != np2inf::ST_OK) atomicAdd(n_bad, 1u);
@@ -320,8 +490,9 @@ __global__ void k_bam_cigars(const uint8_t *__restrict__ st, const np2_bamrec_t 
     for (uint32_t k = lane; k < n; k += 64) cigar[dst + k] = ld32(src + 4ull * k);
 }
 
-void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, const uint8_t *comp, uint8_t *out, uint32_t *status, uint32_t *n_bad) {
-    if (n_blk) hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blk), dim3(64), 0, s, blk, n_blk, comp, out, status, n_bad);
+void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, const uint8_t *comp, uint8_t *out, uint32_t *status, uint32_t *n_bad,
+                         unsigned long long *prof) {
+    if (n_blk) hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blk), dim3(64), 0, s, blk, n_blk, comp, out, status, n_bad, prof);
 }
 void launch_bam_chain_count(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
                             uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at) {

@@ -36,6 +36,7 @@ enum Status : uint32_t {
     ST_IN_OVERRUN = 9,     // stream ran past the block's compressed bytes
     ST_NO_END_CODE = 10,   // literal / length code without symbol 256
 };
+static constexpr uint32_t FAST_END_OF_BLOCK = 0xFFFFFFFEu; // Machine::fast consumed the end-of-block code
 
 struct Code { // one Huffman code (in LDS on the device)
     uint16_t count[MAXBITS + 1]; // codes per length
@@ -164,6 +165,10 @@ NP2_INF_HD uint8_t fixed_lit_len(uint32_t s) { return s < 144 ? 8 : (s < 256 ? 9
 //     uint32_t lit_room(uint32_t out, uint32_t isize);   // bytes put_fast may take from `out` on without a check (0: none)
 //     void put_fast(uint32_t out, uint32_t byte); // output byte `out` inside that allowance
 //     void copy(uint32_t out, uint32_t len, uint32_t dist);   // output [out, out + len) = the bytes `dist` back
+//     uint32_t fast(uint64_t &bb, uint32_t &bc, uint32_t &next, uint32_t &out, uint32_t isize, uint32_t in_limit);
+//                                                 // optional wide step over the current block's symbols: ST_OK (go on with
+//                                                 // the step below, state updated), FAST_END_OF_BLOCK, or an error
+//     void tick(int phase);                       // optional phase clock (0: a block's tables begin, 1: they are ready)
 //     uint32_t slow(int mode, uint32_t bits);     // code_slow on the literal / length (MODE_LITLEN) or distance code
 //     uint8_t *lens();                            // 320 code lengths (shared)
 //     uint32_t *lit_table(), *dist_table();       // shared decode tables
@@ -210,6 +215,7 @@ template <class M> NP2_INF_HD uint32_t inflate_stream(M &m, uint32_t clen, uint3
                 NP2_INF_DROP(8);
             }
         } else {
+            m.tick(0); // (a tool's clock: the block's tables begin)
             uint8_t *lens = m.lens();
             uint32_t hlit, hdist;
             if (btype == 1) {
@@ -320,8 +326,14 @@ template <class M> NP2_INF_HD uint32_t inflate_stream(M &m, uint32_t clen, uint3
                 code_table(m.dist_code(), lens + 288, m.dist_sym(), dt, DBITS, MODE_DIST, m.lane(), m.lanes());
                 m.sync();
             }
+            m.tick(1); // (... are ready)
             const uint32_t *lt = m.lit_table(), *dt = m.dist_table();
             for (;;) {
+                { // the machine's wide step, if it has one (the device: 64 bit offsets decoded at once, see DevMachine::fast)
+                    const uint32_t fs = m.fast(bb, bc, next, out, isize, in_limit);
+                    if (fs == FAST_END_OF_BLOCK) break;
+                    if (fs != ST_OK) NP2_INF_FAIL(fs);
+                }
                 NP2_INF_NEED(32);
                 // A run of literals, the common case (a BAM's SEQ bytes are all literals), without the general step's checks:
                 // the machine says how many bytes may be put unconditionally (`room`: up to ISIZE, and on the device up to the

@@ -1772,8 +1772,9 @@ int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const
 // np2_bamrec_t + the CIGAR words per record for the admission pass (front_begin) — no payload byte is touched here, and the
 // SEQ bytes never leave the device: a record's seq_off points into the inflated stream, which the columnariser reads in place.
 //
-// When: NP2_INFLATE=gpu, or — unset — when this rank's share of the host is under six CPUs (eight ranks of a node on a
-// 16-CPU quota have two each: the pool's inflate, 3.3 ms per E. coli-sized contig on 64 threads, is 50 ms on two).
+// When: NP2_INFLATE=gpu, or — unset — when this rank's share of the host is under twelve CPUs (the two paths tie for an
+// E. coli-sized contig with sixteen: 8.4 - 9 ms either way; eight ranks of a node on a 16-CPU quota have two each, where
+// the pool's path takes 85 ms and this one 9).
 // -S (SEQ of secondary records from their primaries) and reference-interval shards stay on the host path.
 struct GpuFetch {
     np2h::DevBuf<uint8_t> d_comp, d_inf;
@@ -1835,12 +1836,10 @@ struct GpuFetch {
 np2_bam::~np2_bam() { delete gpu; }
 
 namespace {
-bool gpu_fetch_wanted() {
-    static const int mode = [] {
-        if (const char *e = getenv("NP2_INFLATE")) return !strcmp(e, "gpu") ? 1 : 0;
-        return np2h::usable_cpus() / std::max(1u, np2h::local_ranks()) < 6u ? 1 : 0;
-    }();
-    return mode == 1;
+bool gpu_fetch_wanted() { // (read per contig, not per pass: a tool may switch between two reads of the same file)
+    if (const char *e = getenv("NP2_INFLATE")) return !strcmp(e, "gpu");
+    static const bool few_cpus = np2h::usable_cpus() / std::max(1u, np2h::local_ranks()) < 12u;
+    return few_cpus;
 }
 struct GpuRecs {
     const np2_bamrec_t *recs = nullptr;
@@ -2039,8 +2038,27 @@ int np2_bgzf_inflate_device(np2_ctx_t *cx, const uint8_t *bgzf, uint64_t n, uint
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, s));
-        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)tb.size(), g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + tb.size());
+        np2h::DevBuf<uint64_t> d_prof;
+        const bool kprof = getenv("NP2_INF_PROF") != nullptr; // (phase clocks of the inflate kernel: a tool's switch)
+        if (kprof) {
+            d_prof.ensure(tb.size() * 8 + 8);
+            HIPCHK(hipMemsetAsync(d_prof.p, 0, tb.size() * 64, s));
+        }
+        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)tb.size(), g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + tb.size(),
+                                 kprof ? (unsigned long long *)d_prof.p : nullptr);
         HIPCHK(hipEventRecord(e1, s));
+        if (kprof) {
+            std::vector<uint64_t> pr(tb.size() * 8);
+            HIPCHK(hipMemcpyAsync(pr.data(), d_prof.p, pr.size() * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            double sum[8] = {0};
+            for (size_t i = 0; i < tb.size(); ++i)
+                for (int k = 0; k < 8; ++k) sum[k] += (double)pr[i * 8 + k];
+            const double nb = (double)tb.size();
+            fprintf(stderr, "[inf_prof] %zu blocks; mean clocks per block: total %.0f, wide decode %.0f, chain %.0f (of which match copies %.0f); tokens %.0f, matches %.0f; "
+                            "table builds %.0f clocks over %.1f deflate blocks\n",
+                    tb.size(), sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb);
+        }
         std::vector<uint32_t> st(tb.size() + 1);
         HIPCHK(hipMemcpyAsync(st.data(), g.d_status.p, st.size() * 4, hipMemcpyDeviceToHost, s));
         if (total) HIPCHK(hipMemcpyAsync(out, g.d_inf.p, total, hipMemcpyDeviceToHost, s));

@@ -37,6 +37,8 @@ struct HostMachine {
     void copy(uint32_t o, uint32_t len, uint32_t dist) {
         for (uint32_t k = 0; k < len; ++k) out[o + k] = out[o - dist + (dist >= len ? k : k % dist)];
     }
+    uint32_t fast(uint64_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t, uint32_t) { return ST_OK; } // (the one-lane machine has no wide step)
+    void tick(int) {}
     uint32_t slow(int mode, uint32_t bits) { return mode == MODE_LITLEN ? code_slow(lc, ls, bits, mode) : code_slow(dc, ds, bits, mode); }
     uint8_t *lens() { return lens_; }
     uint32_t *lit_table() { return lt; }
