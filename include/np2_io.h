@@ -8,7 +8,7 @@
  *                                                          AlignSeq::new, filter_alignseqs_by_clip)
  *   yak v2 dump header + buckets  src/utils/kmer.rs:72-170
  * BGZF inflate and BAM parsing run on the host pool (libdeflate / zlib) or — NP2_INFLATE=gpu, and by default when this
- * rank has fewer than twelve host CPUs to itself — ON THE DEVICE: the contig's BGZF blocks are uploaded as they lie in the
+ * rank has fewer than twelve host CPUs to itself, or for a reference with 128 MB of BAM and more — ON THE DEVICE: the contig's BGZF blocks are uploaded as they lie in the
  * file, inflated one wavefront per block (csrc/np2_inflate.hip), the records found by walking the inflated stream along
  * the .bai linear index, and the SEQ bytes read by the columnariser where the inflater left them.  The CIGAR walk /
  * trim(8) / nibble packing is a HIP kernel that writes the packed pileup straight into HBM (np2_contig_t) either way.

@@ -136,6 +136,7 @@ struct DevMachine {
     // phase clocks of a block (NP2_INF_PROF, a tool's switch: np2_bgzf_inflate_device prints their means): [0] the wide
     // step's decode of 64 offsets, [1] following the chain (literals included), [2] match copies, [3] tokens, [4] matches
     unsigned long long *prof = nullptr;
+    uint32_t probe = 0; // (NP2_INF_PROBE, a tool's switch: bit 0 no match copies, bit 1 no literal writes, bit 2 no flushes — wrong output, timing only)
     unsigned long long pacc[7] = {0, 0, 0, 0, 0, 0, 0}; // ([5] table builds, [6] deflate blocks)
     unsigned long long t_tick = 0;
     __device__ __forceinline__ void tick(int phase) {
@@ -158,7 +159,7 @@ struct DevMachine {
         return uni(*reinterpret_cast<const uint32_t *>(S.inw + (off & (INF_IN - 1u))));
     }
     __device__ __forceinline__ void flush_upto(uint32_t out) {
-        if (out - flushed >= INF_FLUSH) flushed = inf_flush(S, gout, lane_, flushed, out);
+        if (out - flushed >= INF_FLUSH) flushed = (probe & 4u) ? (out & ~(INF_FLUSH - 1u)) : inf_flush(S, gout, lane_, flushed, out);
     }
     // Literals of a run wait in the lanes' registers — lane (out & 63) holds output byte `out` — and go to the ring 64 at
     // a time (or when anything else needs the ring): per literal one compare-and-select instead of an LDS write under a
@@ -308,9 +309,9 @@ struct DevMachine {
             if (total) {
                 commit(out); // (literals of the symbol loop still waiting in registers)
                 // every literal of the chain at once ...
-                if (mine && kind == 0) S.ring[(out + ooff) & (INF_RING - 1u)] = (uint8_t)val;
+                if (mine && kind == 0 && !(probe & 2u)) S.ring[(out + ooff) & (INF_RING - 1u)] = (uint8_t)val;
                 // ... and its matches in order (a match may repeat what the tokens before it produced)
-                uint64_t mm = __ballot(mine && kind == 1u);
+                uint64_t mm = (probe & 1u) ? 0ull : __ballot(mine && kind == 1u);
                 const unsigned long long tc0 = prof ? clock64() : 0ull;
                 while (mm) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(mm);
@@ -360,13 +361,14 @@ struct DevMachine {
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const InfBlock *__restrict__ blk, uint32_t n_blk, const uint8_t *__restrict__ comp,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t *__restrict__ n_bad,
-                                                     unsigned long long *__restrict__ prof) {
+                                                     unsigned long long *__restrict__ prof, uint32_t probe) {
     __shared__ __attribute__((aligned(16))) InfShared S;
     const uint32_t b = blockIdx.x;
     if (b >= n_blk) return;
     const InfBlock B = blk[b];
     DevMachine m{S, comp + B.in_off, out + B.out_off, B.clen, threadIdx.x};
     m.prof = prof;
+    m.probe = probe;
     const unsigned long long t_begin = prof ? clock64() : 0ull;
     uint32_t st = np2inf::ST_OK;
     if (B.isize > 65536u || B.clen > 65536u) st = np2inf::ST_OUT_OVERRUN;
@@ -491,8 +493,8 @@ __global__ void k_bam_cigars(const uint8_t *__restrict__ st, const np2_bamrec_t 
 }
 
 void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, const uint8_t *comp, uint8_t *out, uint32_t *status, uint32_t *n_bad,
-                         unsigned long long *prof) {
-    if (n_blk) hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blk), dim3(64), 0, s, blk, n_blk, comp, out, status, n_bad, prof);
+                         unsigned long long *prof, uint32_t probe) {
+    if (n_blk) hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blk), dim3(64), 0, s, blk, n_blk, comp, out, status, n_bad, prof, probe);
 }
 void launch_bam_chain_count(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
                             uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at) {

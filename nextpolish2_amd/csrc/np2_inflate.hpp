@@ -24,7 +24,7 @@ static constexpr uint32_t WALK_EARLY_END = 16u; // the contig's records ended be
 // status[b] = np2inf::Status of block b; *n_bad += blocks that failed (both zeroed by the caller)
 // prof (optional): 8 words per block — clocks of the block, of the wide step's decode, of its chain, of its match copies, tokens, matches
 void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, const uint8_t *comp, uint8_t *out, uint32_t *status, uint32_t *n_bad,
-                         unsigned long long *prof = nullptr);
+                         unsigned long long *prof = nullptr, uint32_t probe = 0);
 // starts[0 .. n_chains): stream offsets of record starts, ascending; the last chain ends at a record of another reference or at `end`
 void launch_bam_chain_count(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
                             uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at);

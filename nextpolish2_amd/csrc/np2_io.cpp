@@ -1774,7 +1774,7 @@ int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const
 //
 // When: NP2_INFLATE=gpu, or — unset — when this rank's share of the host is under twelve CPUs (the two paths tie for an
 // E. coli-sized contig with sixteen: 8.4 - 9 ms either way; eight ranks of a node on a 16-CPU quota have two each, where
-// the pool's path takes 85 ms and this one 9).
+// the pool's path takes 85 ms and this one 12), or when the reference's records are 128 MB of BAM and more.
 // -S (SEQ of secondary records from their primaries) and reference-interval shards stay on the host path.
 struct GpuFetch {
     np2h::DevBuf<uint8_t> d_comp, d_inf;
@@ -1836,10 +1836,14 @@ struct GpuFetch {
 np2_bam::~np2_bam() { delete gpu; }
 
 namespace {
-bool gpu_fetch_wanted() { // (read per contig, not per pass: a tool may switch between two reads of the same file)
+bool gpu_fetch_wanted(const np2_bam *bam, int tid) { // (read per contig, not per pass: a tool may switch between two reads of the same file)
     if (const char *e = getenv("NP2_INFLATE")) return !strcmp(e, "gpu");
     static const bool few_cpus = np2h::usable_cpus() / std::max(1u, np2h::local_ranks()) < 12u;
-    return few_cpus;
+    if (few_cpus) return true;
+    // with the host's CPUs to itself the pool's path ties for a bacterial contig (8.4 - 9 ms either way) and loses from a
+    // few hundred MB of BAM on (a 248 Mb chromosome's 2 GB: front end 0.86 - 0.9 s here, 1.1 - 1.5 s there)
+    const uint64_t lo = bam->ref_start[tid], hi = bam->ref_end[tid];
+    return lo != ~0ull && hi && (hi >> 16) > (lo >> 16) && (hi >> 16) - (lo >> 16) >= ((uint64_t)128 << 20);
 }
 struct GpuRecs {
     const np2_bamrec_t *recs = nullptr;
@@ -1858,54 +1862,123 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
     if (bam->lin[tid].empty()) return false;
     if (!bam->gpu) bam->gpu = new GpuFetch();
     GpuFetch &g = *bam->gpu;
-    BgzfBatch hdr; // (only its block-header parser is used)
-    hdr.map = bam->map, hdr.map_len = bam->map_len;
+    const int fd = fileno(bam->z.f);
+    const size_t file_len = bam->map_len;
     const size_t c_lo = (size_t)(start_off >> 16);
-    size_t c_hi = bam->ref_end[tid] ? (size_t)(bam->ref_end[tid] >> 16) : bam->map_len; // file offset of the last block wanted
-    std::vector<BgzfBatch::Blk> blks;
+    size_t c_hi = bam->ref_end[tid] ? (size_t)(bam->ref_end[tid] >> 16) : file_len; // file offset of the last block wanted
+    struct GBlk {
+        uint64_t file_off; // of the block
+        uint32_t hdr_len;  // 12 + XLEN: the raw DEFLATE payload starts there
+        uint32_t clen, isize;
+    };
+    std::vector<GBlk> blks;
     std::vector<uint64_t> out_off;
-    size_t extra = 0; // blocks beyond the index's end of the reference (an index that understates it costs a second round)
+    size_t extra = 0; // bytes read beyond the index's end of the reference (an index that understates it costs a second round)
     for (int round = 0;; ++round) {
         if (round > 40) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-        // ---- the block table: headers only --------------------------------------------------------------------------------
+        // ---- file bytes -> pinned pieces (pread on the pool's threads: the page cache is copied from, no mapping of the file
+        // is faulted in — through the mmap the same 2 GB of a chromosome's BAM took 0.08 to 2.7 s) -> device; the 18-byte
+        // block headers are parsed out of each piece while it is there -----------------------------------------------------------
         blks.clear();
-        hdr.fpos = c_lo;
-        bool eof = false;
-        size_t beyond = 0;
-        for (;;) {
-            BgzfBatch::Blk b;
-            if (!hdr.read_raw(b)) {
-                eof = true;
-                break;
+        const size_t read_end = std::min(file_len, c_hi + 65536 + extra);
+        const size_t c_bytes = read_end - c_lo;
+        g.d_comp.ensure(c_bytes + 64);
+        for (int i = 0; i < 2; ++i) {
+            if (!g.pin[i]) {
+                g.pin[i] = np2h::pinned_pool().get(GpuFetch::PIECE);
+                if (!g.pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
             }
-            if (b.file_off > c_hi && beyond++ >= extra) {
-                // (nothing but the end-of-file marker behind the range: the range IS the rest of the file)
-                if (b.isize == 0 && hdr.fpos >= hdr.map_len) eof = true;
-                break;
-            }
-            blks.push_back(b);
+            if (!g.ev[i]) HIPCHK(hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming));
         }
-        if (blks.empty()) return true;
+        auto small_read = [&](uint64_t off, uint8_t *dst, size_t n) { // a few bytes that straddle a piece
+            if (off + n > file_len || pread(fd, dst, n, (off_t)off) != (ssize_t)n) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+        };
+        uint64_t hdr_at = c_lo; // file offset of the next block header
+        bool eof = false, range_done = false;
+        size_t piece = 0;
+        for (size_t o = 0; o < c_bytes; o += GpuFetch::PIECE, ++piece) {
+            const int sl = (int)(piece & 1);
+            if (piece >= 2) HIPCHK(hipEventSynchronize(g.ev[sl]));
+            const size_t want = std::min(GpuFetch::PIECE, c_bytes - o);
+            uint8_t *stage = (uint8_t *)g.pin[sl];
+            const size_t SUB = (size_t)1 << 20;
+            std::atomic<int> bad{0};
+            IoPool::get().parallel_for((want + SUB - 1) / SUB, 16, [&](size_t k) {
+                size_t got = 0;
+                const size_t n = std::min(SUB, want - k * SUB);
+                while (got < n) {
+                    const ssize_t r = pread(fd, stage + k * SUB + got, n - got, (off_t)(c_lo + o + k * SUB + got));
+                    if (r <= 0) {
+                        bad.store(1);
+                        return;
+                    }
+                    got += (size_t)r;
+                }
+            });
+            if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+            HIPCHK(hipMemcpyAsync(g.d_comp.p + o, stage, want, hipMemcpyHostToDevice, s));
+            HIPCHK(hipEventRecord(g.ev[sl], s));
+            // the headers that begin inside this piece
+            const uint64_t p0 = c_lo + o, p1 = p0 + want;
+            while (!range_done && hdr_at < p1) {
+                if (hdr_at + 18 > file_len) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+                uint8_t hb[18 + 256];
+                const uint8_t *hd = stage + (hdr_at - p0);
+                if (hdr_at + 18 > p1) small_read(hdr_at, hb, 18), hd = hb;
+                if (hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+                const uint32_t xlen = hd[10] | (hd[11] << 8);
+                if (xlen > 256) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+                if (hd == hb || hdr_at + 12 + xlen > p1) small_read(hdr_at, hb, 12 + (size_t)xlen), hd = hb;
+                const uint8_t *ex = hd + 12;
+                uint32_t bsize = 0;
+                for (size_t q = 0; q + 4 <= xlen;) {
+                    const uint32_t slen = ex[q + 2] | (ex[q + 3] << 8);
+                    if (ex[q] == 'B' && ex[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = (ex[q + 4] | (ex[q + 5] << 8)) + 1;
+                    q += 4 + slen;
+                }
+                if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+                if (bsize < 12 + xlen + 8 || hdr_at + bsize > file_len) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+                if (hdr_at + bsize > read_end) { // (the block continues beyond what this round reads: not part of it)
+                    range_done = true;
+                    break;
+                }
+                uint8_t tb8[8];
+                const uint64_t tail = hdr_at + bsize - 8;
+                const uint8_t *tp = stage + (tail - p0);
+                if (tail + 8 > p1) small_read(tail, tb8, 8), tp = tb8;
+                GBlk b;
+                b.file_off = hdr_at, b.hdr_len = 12 + xlen, b.clen = bsize - 12 - xlen - 8;
+                b.isize = tp[4] | (tp[5] << 8) | (tp[6] << 16) | ((uint32_t)tp[7] << 24);
+                blks.push_back(b);
+                hdr_at += bsize;
+            }
+        }
+        if (hdr_at >= file_len) eof = true;
+        else if (hdr_at + 28 == file_len) { // nothing but the end-of-file marker behind the range: the range IS the rest of the file
+            uint8_t mk[28];
+            small_read(hdr_at, mk, 28);
+            if (mk[0] == 31 && mk[1] == 139 && (mk[24] | mk[25] | mk[26] | mk[27]) == 0) eof = true;
+        }
+        if (blks.empty()) {
+            HIPCHK(hipStreamSynchronize(s));
+            return true;
+        }
         const size_t n_blk = blks.size();
-        const uint8_t *c_base = bam->map + c_lo;
-        const size_t c_bytes = (size_t)((blks.back().c + blks.back().clen + 8) - c_base);
         out_off.assign(n_blk + 1, 0);
         for (size_t i = 0; i < n_blk; ++i) out_off[i + 1] = out_off[i] + blks[i].isize;
         const uint64_t total = out_off[n_blk];
         const double t1 = np2h::now_ms();
-        // ---- file bytes to the device, inflate ------------------------------------------------------------------------------
-        g.d_comp.ensure(c_bytes + 64);
+        // ---- inflate ------------------------------------------------------------------------------------------------------------
         g.d_inf.ensure(total + 128);
         g.d_blk.ensure(n_blk + 1);
         g.d_status.ensure(n_blk + 8);
-        g.upload(c_base, c_bytes, g.d_comp.p, s);
         double t_up = 0, t_inf = 0;
         if (prof) {
             HIPCHK(hipStreamSynchronize(s));
             t_up = np2h::now_ms();
         }
         std::vector<np2::InfBlock> tb(n_blk);
-        for (size_t i = 0; i < n_blk; ++i) tb[i] = np2::InfBlock{(uint64_t)(blks[i].c - c_base), out_off[i], blks[i].clen, blks[i].isize};
+        for (size_t i = 0; i < n_blk; ++i) tb[i] = np2::InfBlock{blks[i].file_off + blks[i].hdr_len - c_lo, out_off[i], blks[i].clen, blks[i].isize};
         np2::InfBlock *h_tb = (np2::InfBlock *)g.host_block(g.h_cigar, g.h_cigar_cap, n_blk * sizeof(np2::InfBlock)); // (free until the records come back)
         memcpy(h_tb, tb.data(), n_blk * sizeof(np2::InfBlock));
         HIPCHK(hipMemcpyAsync(g.d_blk.p, h_tb, n_blk * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
@@ -1965,7 +2038,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
         if (flags & np2::WALK_BAD) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
         if (flags & np2::WALK_MISALIGNED) return false;
         if ((flags & (np2::WALK_TAIL | np2::WALK_AT_END)) && !eof) { // the reference's records go on beyond the index's end: further
-            extra = std::max<size_t>(16, extra * 2 + n_blk / 4);
+            extra = std::max<size_t>((size_t)1 << 20, extra * 2 + c_bytes / 4);
             continue;
         }
         if (flags & np2::WALK_TAIL) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
@@ -1998,8 +2071,8 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
             out.recs = hr, out.cigar = hc;
         }
         if (prof)
-            fprintf(stderr, "fetch_records_gpu: %zu blocks (%.1f MB -> %.1f MB), %u chains, %llu records, %llu CIGAR words: headers %.2f ms, "
-                            "upload %.2f ms, inflate %.2f ms, index + count + wait %.2f ms, records back %.2f ms%s\n", n_blk, c_bytes / 1e6, total / 1e6, n_chains,
+            fprintf(stderr, "fetch_records_gpu: %zu blocks (%.1f MB -> %.1f MB), %u chains, %llu records, %llu CIGAR words: file -> pinned pieces (+ block headers) %.2f ms, "
+                            "rest of the upload %.2f ms, inflate %.2f ms, index + count + wait %.2f ms, records back %.2f ms%s\n", n_blk, c_bytes / 1e6, total / 1e6, n_chains,
                     (unsigned long long)n_rec, (unsigned long long)n_cig, t1 - t0, t_up - t1, t_inf - t_up, t2 - t_inf, np2h::now_ms() - t2, round ? " (after extending the range)" : "");
         return true;
     }
@@ -2045,7 +2118,7 @@ int np2_bgzf_inflate_device(np2_ctx_t *cx, const uint8_t *bgzf, uint64_t n, uint
             HIPCHK(hipMemsetAsync(d_prof.p, 0, tb.size() * 64, s));
         }
         np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)tb.size(), g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + tb.size(),
-                                 kprof ? (unsigned long long *)d_prof.p : nullptr);
+                                 kprof ? (unsigned long long *)d_prof.p : nullptr, getenv("NP2_INF_PROBE") ? (uint32_t)atoi(getenv("NP2_INF_PROBE")) : 0u);
         HIPCHK(hipEventRecord(e1, s));
         if (kprof) {
             std::vector<uint64_t> pr(tb.size() * 8);
@@ -2097,7 +2170,7 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         bam->batch.ms_read = bam->batch.ms_inflate = bam->batch.ms_drop = bam->batch.ms_walk = bam->batch.ms_size = bam->batch.ms_copy = 0;
         HIPCHK(hipSetDevice(cx->device));
         uint64_t seq_bytes = 0;
-        if (gpu_fetch_wanted() && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
+        if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
             GpuRecs gr;
             if (fetch_records_gpu(bam, tid, L, cx->stream, gr)) {
                 const double t_g1 = np2h::now_ms();

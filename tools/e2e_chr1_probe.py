@@ -65,17 +65,23 @@ if os.environ.get("NP2_E2E_FRESH_FIRST"):
     # process's ~58 GB of HBM were freed a moment ago), then after a pause.  NP2_E2E_THREADS: its -t.
     # NP2_E2E_FRESH_FIRST = "pause:threads,..." (default: at once, at once, after 12 s, at once; -t 2)
     spec = os.environ["NP2_E2E_FRESH_FIRST"]
-    plan = [(0, "2"), (0, "2"), (12, "2"), (0, "2")] if spec == "1" else [(int(x.split(":")[0]), x.split(":")[1]) for x in spec.split(",")]
-    for rep, (pause, nt) in enumerate(plan):
+    # an entry may go on with ":mode:cpus" — NP2_INFLATE for that process (gpu / libdeflate / zlib; empty: the default rule)
+    # and a taskset CPU list (a rank's share of a node: "0-1")
+    plan = [(0, "2", "", ""), (0, "2", "", ""), (12, "2", "", ""), (0, "2", "", "")] if spec == "1" else \
+        [(int(f[0]), f[1], f[2] if len(f) > 2 else "", f[3] if len(f) > 3 else "") for f in (x.split(":") for x in spec.split(","))]
+    for rep, (pause, nt, mode, cpus) in enumerate(plan):
         time.sleep(pause)
         o = os.path.join(td, f"first{rep}.fa")
         t = time.time()
-        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-t", nt, "-o", o, bam, fa] + ypaths, env=env, cwd=ROOT,
+        e2 = dict(env, **({"NP2_INFLATE": mode} if mode else {}))
+        pre = ["taskset", "-c", cpus] if cpus else []
+        r = subprocess.run(pre + [sys.executable, "-m", "nextpolish2_amd.cli", "-t", nt, "-o", o, bam, fa] + ypaths, env=e2, cwd=ROOT,
                            capture_output=True, timeout=900)
         dt = time.time() - t
         sys.stderr.write(r.stderr.decode()[-4000:])
         sys.stderr.flush()
-        log(f"fresh process {rep} (-t {nt}, started {pause} s after the previous one ended): {dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {r.returncode}")
+        log(f"fresh process {rep} (-t {nt}, NP2_INFLATE={mode or 'default'}, CPUs {cpus or 'all'}, started {pause} s after the previous one ended): "
+            f"{dt:.2f} s = {pu.L / dt / 1e6:.0f} Mbp/s, rc {r.returncode}")
         first_outs.append(o)
 # the resident path's answer
 t = time.time()
