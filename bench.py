@@ -36,6 +36,14 @@ PMC_SOURCE = {"yeast": "profiles/r05_yeast_pmc_fetch_write.json (round 5, record
 KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
 KAPPA_SOURCE = "profiles/r04_kappa.json"
 PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure is the per-launch average of
+# The roofline kernel is the one that streams the pileup — chosen by BYTES, as the contract's `roofline` asks for the
+# dominant kernel of the path's algorithmic traffic — not the one the step spends most time in.  Its share of a step's kernel
+# time and the kernel that leads by time, from the tracked one-group kernel tables (rocprofv3 --kernel-trace --stats of
+# `bench.py --groups 1`; us per step): not measured in the run that prints the line.
+KERNEL_TIME = {"yeast": {"roofline_kernel_us": 144.5, "kernel_sum_us": 3386.0, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 581.1,
+                         "source": "profiles/r06_yeast_one_group_kernels_per_step.txt"},
+               "ecoli": {"roofline_kernel_us": 52.0, "kernel_sum_us": 700.0, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 110.0,
+                         "source": "profiles/r06_ecoli_kernels_per_step.txt"}}
 PMC_TRAFFIC = {"yeast": int((2 * 26360.4 + 34008.2) * 1024), "ecoli": int((2 * 38842.8 + 31692.6) * 1024)}
 
 
@@ -847,7 +855,14 @@ def main():
                      "traffic_source": f"not measured in this run: {PMC_SOURCE[a.workload]}, 2 x FETCH_SIZE + WRITE_SIZE per launch",
                      "alg_bytes_per_launch": int(alg_bytes / max(1, diff_launches)), "launches_per_step": diff_launches,
                      "avg_launch_ms": round(avg_ms / max(1, diff_launches), 4),
-                     "units_per_launch_bp": int(total_len / max(1, diff_launches))},
+                     "units_per_launch_bp": int(total_len / max(1, diff_launches)),
+                     "selected_by": "bytes (the kernel that streams the pileup), not time",
+                     "time_share": (round(KERNEL_TIME[a.workload]["roofline_kernel_us"] / KERNEL_TIME[a.workload]["kernel_sum_us"], 4)
+                                    if (a.depth == 30 and a.scale == 1.0) else None),
+                     "time_dominant_kernel": ({"kernel": KERNEL_TIME[a.workload]["dominant_by_time"],
+                                               "share": round(KERNEL_TIME[a.workload]["dominant_by_time_us"] / KERNEL_TIME[a.workload]["kernel_sum_us"], 4)}
+                                              if (a.depth == 30 and a.scale == 1.0) else None),
+                     "time_share_source": f"not measured in this run: {KERNEL_TIME[a.workload]['source']}"},
         "flush_ms": {"per_group_totals_host_issue_wait": [[round(sum(f[j] for f in fl), 3) for j in range(3)] for fl in flush_log],
                      "flushes_per_step": [len(fl) for fl in flush_log],
                      "per_flush_host_issue_wait_group0": flush_log[0] if flush_log else None,

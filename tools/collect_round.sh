@@ -1,11 +1,24 @@
 cd $GRAFT_REPO_ROOT
-timeout 500 tools/collect_profiles.sh r05_yeast > /dev/null 2>&1
-timeout 500 tools/collect_profiles.sh r05_yeast_one_group --groups 1 > /dev/null 2>&1
-timeout 500 tools/collect_profiles.sh r05_ecoli --workload ecoli > /dev/null 2>&1
-timeout 400 python bench.py > gpurun_out/r05_yeast_bench_default_full.json 2> gpurun_out/r05_yeast_bench_default_full.err
-timeout 300 python bench.py --workload ecoli --no-cpu-baseline > gpurun_out/r05_ecoli_bench_full.json 2> gpurun_out/r05_ecoli_bench_full.err
-timeout 300 python bench.py --workload ecoli --scale 13 --no-cpu-baseline --no-end-to-end --steps 10 --warmup 2 > gpurun_out/r05_60Mb_contig_bench_line.json 2> gpurun_out/r05_60Mb.err
-timeout 600 python bench.py --scaling strong --workload chr1 --gpus 1 --steps 3 --warmup 1 > gpurun_out/r05_strong_chr1_1gpu.json 2> gpurun_out/r05_strong_chr1_1gpu.err
-NP2_IO_PROFILE=1 timeout 300 python tools/bench_frontend.py 4641652 > gpurun_out/r05_frontend_ecoli_size.log 2>&1
-NP2_CLI_PROFILE=1 timeout 300 python tools/cli_probe.py > gpurun_out/r05_cli_assembly_probe.log 2>&1
-ls gpurun_out | grep "^r05_" | head -80
+R=r06
+timeout 500 tools/collect_profiles.sh ${R}_yeast > /dev/null 2>&1
+timeout 500 tools/collect_profiles.sh ${R}_yeast_one_group --groups 1 > /dev/null 2>&1
+timeout 500 tools/collect_profiles.sh ${R}_ecoli --workload ecoli > /dev/null 2>&1
+timeout 400 python bench.py > gpurun_out/${R}_yeast_bench_default_full.json 2> gpurun_out/${R}_yeast_bench_default_full.err
+timeout 300 python bench.py --workload ecoli --no-cpu-baseline > gpurun_out/${R}_ecoli_bench_full.json 2> gpurun_out/${R}_ecoli_bench_full.err
+timeout 300 python bench.py --workload ecoli --scale 13 --no-cpu-baseline --no-end-to-end --steps 10 --warmup 2 > gpurun_out/${R}_60Mb_contig_bench_line.json 2> gpurun_out/${R}_60Mb.err
+NP2_BENCH_STAGES=1 timeout 600 python bench.py --scaling strong --workload chr1 --gpus 1 --steps 3 --warmup 1 > gpurun_out/${R}_strong_chr1_1gpu.json 2> gpurun_out/${R}_strong_chr1_1gpu.err
+timeout 600 python bench.py --scaling strong --workload chr1 --gpus 1 --steps 3 --warmup 1 --haploid > gpurun_out/${R}_strong_chr1_1gpu_haploid.json 2> gpurun_out/${R}_strong_chr1_1gpu_haploid.err
+NP2_PHASE_PROFILE=1 timeout 600 python bench.py --scaling strong --workload chr1 --gpus 1 --steps 2 --warmup 1 2>&1 > /dev/null | grep -E "vote host|losing_reads|sweeps:|pieces:|aggregate|local_moving" | tail -40 > gpurun_out/${R}_strong_chr1_vote_phases.txt
+NP2_IO_PROFILE=1 timeout 300 python tools/bench_frontend.py 4641652 > gpurun_out/${R}_frontend_ecoli_size.log 2>&1
+timeout 600 python tools/inflate_probe.py > gpurun_out/${R}_device_read_extraction_ecoli_size.log 2>&1
+NP2_INF_PROF=1 timeout 300 python tools/inflate_only.py 20000 1200000 4641652 > gpurun_out/${R}_inflate_kernel_sizes.log 2>&1
+for p in 1 2 4; do echo "NP2_INF_PROBE=$p"; NP2_INF_PROBE=$p timeout 300 python tools/inflate_only.py 4641652 2>&1 | grep "^L"; done > gpurun_out/${R}_inflate_kernel_probe.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d gpurun_out/inf_ps -o s --output-format csv -- python tools/inflate_only.py 4641652 > /dev/null 2>&1
+python tools/pmc_sq.py gpurun_out/inf_ps/s_counter_collection.csv | grep -i "inflate\|^kernel" > gpurun_out/${R}_inflate_pmc_sq.txt; rm -rf gpurun_out/inf_ps
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/inf_pf -o f --output-format csv -- python tools/inflate_only.py 4641652 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/inf_pw -o w --output-format csv -- python tools/inflate_only.py 4641652 > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/inf_pf/f_counter_collection.csv gpurun_out/inf_pw/w_counter_collection.csv > gpurun_out/${R}_inflate_pmc_fetch_write.json 2>&1; rm -rf gpurun_out/inf_pf gpurun_out/inf_pw
+NP2_CLI_PROFILE=1 timeout 300 python tools/cli_probe.py > gpurun_out/${R}_cli_assembly_probe.log 2>&1
+python tools/pf_prof.py > gpurun_out/${R}_pf_tile_phases.txt 2>&1
+ls gpurun_out | grep "^${R}_" | head -80
