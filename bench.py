@@ -28,9 +28,9 @@ YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 43988
          784333, 1091291, 948066, 85779]
 # HBM traffic of one k_diff_reads launch, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
 # 2 x FETCH_SIZE (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE):
-# profiles/r05_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r05_ecoli_pmc_fetch_write.json
-# (round 5's kernel; round 4's: 2 * 37805.7 + 38330.9 and 2 * 52134.0 + 38965.5 KB; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9)
-PMC_SOURCE = {"yeast": "profiles/r05_yeast_pmc_fetch_write.json (round 5, recorded on the final build)", "ecoli": "profiles/r05_ecoli_pmc_fetch_write.json (round 5)"}
+# profiles/r06_yeast_pmc_fetch_write.json (average over the four launches of a step), profiles/r06_ecoli_pmc_fetch_write.json
+# (the dense kernel is round 5's: 2 * 26360.4 + 34008.2 and 2 * 38842.8 + 31692.6 KB then; round 4's: 2 * 37805.7 + 38330.9 and 2 * 52134.0 + 38965.5 KB; round 2's: 2 * 31766.7 + 38123.8 and 2 * 48516.1 + 39687.9)
+PMC_SOURCE = {"yeast": "profiles/r06_yeast_pmc_fetch_write.json (round 6)", "ecoli": "profiles/r06_ecoli_pmc_fetch_write.json (round 6)"}
 # k-mer table probes per polished bp the reference algorithm makes on these workloads (the oracle's kmer_probes stat over
 # the whole assembly: kappa of SURVEY.md §8(d)); measured again whenever the cpu_baseline leg runs
 KAPPA = {"yeast": 0.66996, "ecoli": 0.38471}
@@ -40,11 +40,11 @@ PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure 
 # dominant kernel of the path's algorithmic traffic — not the one the step spends most time in.  Its share of a step's kernel
 # time and the kernel that leads by time, from the tracked one-group kernel tables (rocprofv3 --kernel-trace --stats of
 # `bench.py --groups 1`; us per step): not measured in the run that prints the line.
-KERNEL_TIME = {"yeast": {"roofline_kernel_us": 144.5, "kernel_sum_us": 3386.0, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 581.1,
-                         "source": "profiles/r06_yeast_one_group_kernels_per_step.txt"},
-               "ecoli": {"roofline_kernel_us": 52.0, "kernel_sum_us": 700.0, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 110.0,
-                         "source": "profiles/r06_ecoli_kernels_per_step.txt"}}
-PMC_TRAFFIC = {"yeast": int((2 * 26360.4 + 34008.2) * 1024), "ecoli": int((2 * 38842.8 + 31692.6) * 1024)}
+KERNEL_TIME = {"yeast": {"roofline_kernel_us": 143.8, "kernel_sum_us": 3370.3, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 582.7,
+                         "source": "profiles/r06_yeast_one_group_kernels_per_step.txt (the table's total less k_yak_insert, a context's set-up)"},
+               "ecoli": {"roofline_kernel_us": 49.0, "kernel_sum_us": 758.6, "dominant_by_time": "copies of the result to the host (rocclr copyBuffer)", "dominant_by_time_us": 93.2,
+                         "source": "profiles/r06_ecoli_kernels_per_step.txt (the table's total less k_yak_insert)"}}
+PMC_TRAFFIC = {"yeast": int((2 * 26323.4 + 34003.1) * 1024), "ecoli": int((2 * 38840.5 + 31541.6) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):

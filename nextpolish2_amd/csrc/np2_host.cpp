@@ -1435,6 +1435,9 @@ void polish_impl(np2_ctx *cx, np2_contig *c, const np2_opts_t *o, ResultOut &res
         launch_kill_flagged(cx->stream, vd->d_bad, c->R, cx->alive.p);
         ++r.pass; // (what run_apply_losers does; the pass cannot be a reuse of the last one: reads are going)
         r.reuse = false;
+        // (the tile kernel's phase clocks are read back inside pass_front_issue — through the very staging the pairs still sit
+        // in, which may move: tools/pf_prof.py died there)
+        if (cx->hooks.pf_prof) vd->own();
         pass_front_issue(cx, c, r.T, (int)r.pass);
         r.front_issued = true;
         op_submit(cx);
