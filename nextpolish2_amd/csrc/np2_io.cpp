@@ -1866,6 +1866,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
     const size_t file_len = bam->map_len;
     const size_t c_lo = (size_t)(start_off >> 16);
     size_t c_hi = bam->ref_end[tid] ? (size_t)(bam->ref_end[tid] >> 16) : file_len; // file offset of the last block wanted
+    if (getenv("NP2_TEST_FETCH_SHORT_HINT")) c_hi = c_lo; // test hook: an index that understates where the reference's records end
     struct GBlk {
         uint64_t file_off; // of the block
         uint32_t hdr_len;  // 12 + XLEN: the raw DEFLATE payload starts there

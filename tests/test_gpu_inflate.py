@@ -112,3 +112,63 @@ def test_contig_through_the_device_equals_the_host_path(tmp_path, L, depth, dipl
     assert same_pileup(Pileup(s.pileup.ref, dev["reads"], dev["nib"]), pu)
     ob, op = orc.Oracle([s.yak(21)]).polish(pu, Opts())
     assert np.array_equal(dev["b"], ob) and np.array_equal(dev["p"], op)
+
+
+def _bundle4(tmp_path):
+    """a BAM of four references — two with reads, one without any, one more with reads — plus FASTA and k-mer dumps"""
+    import gzip
+    from test_oracle import yak_from_seqs
+    sA = Synth(50000, depth=20, seed=161, read_len_mean=6000.0, read_len_sd=900.0, name="ctgA")
+    sB = Synth(30000, depth=20, seed=162, diploid=True, read_len_mean=5000.0, read_len_sd=700.0, name="ctgB")
+    sD = Synth(20000, depth=15, seed=164, read_len_mean=4000.0, read_len_sd=600.0, name="ctgD")
+    recs = []
+    for tid, s, sd in ((0, sA, 3), (1, sB, 4), (3, sD, 5)):
+        recs += pileup_to_records(s.pileup, tid=tid, rng=np.random.default_rng(sd), decorate=True)
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    refs = [("ctgA", sA.pileup.L), ("ctgB", sB.pileup.L), ("ctgC", 25000), ("ctgD", sD.pileup.L)]
+    write_bam(str(tmp_path / "m.bam"), refs, recs)
+    rngc = np.random.default_rng(7)
+    ctgC = "".join(rngc.choice(list("ACGT"), 25000))
+    with gzip.open(tmp_path / "g.fa.gz", "wt") as f:
+        for nm, seq in (("ctgA", sA.pileup.ref.tobytes().decode()), ("ctgB", sB.pileup.ref.tobytes().decode()), ("ctgC", ctgC),
+                        ("ctgD", sD.pileup.ref.tobytes().decode())):
+            f.write(f">{nm}\n{seq}\n")
+    y21 = yak_from_seqs([sA.hap1.decode(), sB.hap1.decode(), sB.hap2.decode(), sD.hap1.decode()], 21)
+    np2io.write_yak(str(tmp_path / "k21.yak"), y21)
+    return recs, (sA, sB, sD), ctgC, y21
+
+
+@pytest.mark.parametrize("short_hint", [False, True])
+def test_references_of_one_bam_through_the_device(tmp_path, short_hint):
+    """The device path on a BAM of several references: a reference's records end inside a block the next one's begin in, a
+    reference without records, the last reference running to the end-of-file marker — and (short_hint) an index that
+    understates where a reference's records end, so that the range is extended until the walk meets another reference."""
+    recs, (sA, sB, sD), ctgC, y21 = _bundle4(tmp_path)
+    o = orc.Oracle([y21])
+    exp = b""
+    for nm, s, tid in (("ctgA", sA, 0), ("ctgB", sB, 1), ("ctgC", None, 2), ("ctgD", sD, 3)):
+        if s is None:  # no read: polishing changes nothing (every position is the contig's own node)
+            from nextpolish2_amd.synth import pileup_from_alignments
+            b, p = o.polish(pileup_from_alignments(ctgC, []), Opts())
+        else:
+            rr = [r for r in recs if r["tid"] == tid]
+            arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
+            b, p = o.polish(orc.front_end(s.pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts()), Opts())
+        exp += b">%s start:%d end:%d\n%s\n" % (nm.encode(), p[0], p[-1], b.tobytes())
+    outs = {}
+    for mode in ("gpu", "libdeflate"):
+        env = dict(os.environ, PYTHONPATH=ROOT, NP2_INFLATE=mode, NP2_IO_PROFILE="1")
+        if short_hint and mode == "gpu":
+            env["NP2_TEST_FETCH_SHORT_HINT"] = "1"
+        out = tmp_path / ("out_%s.fa" % mode)
+        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-L", "10000", "-o", str(out), str(tmp_path / "m.bam"),
+                            str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        outs[mode] = out.read_bytes()
+        if mode == "gpu":
+            err = r.stderr.decode()
+            assert err.count("fetch_records_gpu:") >= 3, err[-2000:]
+            if short_hint:
+                assert "after extending the range" in err
+    assert outs["gpu"] == outs["libdeflate"]
+    assert outs["gpu"] == exp
