@@ -396,10 +396,13 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[
 // One thread per chain c: records from starts[c] to starts[c + 1] (the last chain: to the first record of another
 // reference, or to `end`).  Counts the contig's records (refID == tid, pos < L: what fetch(tid, 0, L) returns) and their
 // CIGAR words.  chain_info[c] = {records, cigar words}; flags: WALK_* bits.
+// zone [zone_lo, zone_hi): the whole contig (0, L), or a shard's reference interval — then a record that starts before
+// zone_lo is taken only if it reaches it (reference span from its CIGAR, like fetch_records), and the walk ends at the first
+// record that starts at or beyond zone_hi.
 template <bool WRITE>
 __device__ __forceinline__ void bam_chain(const uint8_t *__restrict__ st, const uint64_t *__restrict__ starts, uint32_t n_chains, uint64_t end,
-                                          int32_t tid, uint32_t L, uint32_t c, uint2 *__restrict__ chain_info, uint32_t *__restrict__ flags,
-                                          unsigned long long *__restrict__ tail_at, const uint2 *__restrict__ chain_off,
+                                          int32_t tid, uint32_t L, uint32_t zone_lo, uint32_t zone_hi, uint32_t c, uint2 *__restrict__ chain_info,
+                                          uint32_t *__restrict__ flags, unsigned long long *__restrict__ tail_at, const uint2 *__restrict__ chain_off,
                                           np2_bamrec_t *__restrict__ recs, uint64_t *__restrict__ cig_src) {
     uint64_t p = starts[c];
     const bool last = c + 1 == n_chains;
@@ -434,11 +437,11 @@ __device__ __forceinline__ void bam_chain(const uint8_t *__restrict__ st, const 
         }
         const int32_t pos = (int32_t)ld32(rec + 4);
         const uint32_t l_name = rec[8], nc = ld16(rec + 12), l_seq = ld32(rec + 16);
-        if (pos >= 0 && (uint32_t)pos >= L) { // coordinate-sorted: nothing further starts inside the contig
+        if (pos >= 0 && (uint32_t)pos >= zone_hi) { // coordinate-sorted: nothing further starts inside the zone
             other = true;
             break;
         }
-        if (pos < 0) { // (fetch(tid, 0, L) skips a record placed on the reference without a position)
+        if (pos < 0 || (uint32_t)pos >= L) { // (fetch(tid, 0, L) skips a record placed on the reference without a position)
             p += 4 + (uint64_t)bs;
             continue;
         }
@@ -446,12 +449,24 @@ __device__ __forceinline__ void bam_chain(const uint8_t *__restrict__ st, const 
             if (!WRITE) atomicOr(flags, WALK_BAD);
             break;
         }
+        if ((uint32_t)pos < zone_lo) { // the record must reach the zone
+            const uint8_t *pc = rec + 32 + l_name;
+            uint64_t span = 0;
+            for (uint32_t k = 0; k < nc; ++k) {
+                const uint32_t w = ld32(pc + 4ull * k), op = w & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
+            }
+            if ((uint64_t)pos + span <= zone_lo) {
+                p += 4 + (uint64_t)bs;
+                continue;
+            }
+        }
         if (WRITE) {
             np2_bamrec_t r;
             r.pos = pos;
             r.flag = (uint16_t)ld16(rec + 14);
             r.mapq = rec[9];
-            r.pad = 0;
+            r.pad = (uint8_t)l_name; // (l_read_name: the record starts 36 + pad bytes before its CIGAR words)
             r.n_cigar = nc;
             r.cigar_off = co;
             r.l_seq = l_seq;
@@ -472,14 +487,16 @@ __device__ __forceinline__ void bam_chain(const uint8_t *__restrict__ st, const 
     }
 }
 __global__ void k_bam_chain_count(const uint8_t *__restrict__ st, const uint64_t *__restrict__ starts, uint32_t n_chains, uint64_t end, int32_t tid,
-                                  uint32_t L, uint2 *__restrict__ chain_info, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tail_at) {
+                                  uint32_t L, uint32_t zone_lo, uint32_t zone_hi, uint2 *__restrict__ chain_info, uint32_t *__restrict__ flags,
+                                  unsigned long long *__restrict__ tail_at) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_chains) bam_chain<false>(st, starts, n_chains, end, tid, L, c, chain_info, flags, tail_at, nullptr, nullptr, nullptr);
+    if (c < n_chains) bam_chain<false>(st, starts, n_chains, end, tid, L, zone_lo, zone_hi, c, chain_info, flags, tail_at, nullptr, nullptr, nullptr);
 }
 __global__ void k_bam_chain_write(const uint8_t *__restrict__ st, const uint64_t *__restrict__ starts, uint32_t n_chains, uint64_t end, int32_t tid,
-                                  uint32_t L, const uint2 *__restrict__ chain_off, np2_bamrec_t *__restrict__ recs, uint64_t *__restrict__ cig_src) {
+                                  uint32_t L, uint32_t zone_lo, uint32_t zone_hi, const uint2 *__restrict__ chain_off, np2_bamrec_t *__restrict__ recs,
+                                  uint64_t *__restrict__ cig_src) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_chains) bam_chain<true>(st, starts, n_chains, end, tid, L, c, nullptr, nullptr, nullptr, chain_off, recs, cig_src);
+    if (c < n_chains) bam_chain<true>(st, starts, n_chains, end, tid, L, zone_lo, zone_hi, c, nullptr, nullptr, nullptr, chain_off, recs, cig_src);
 }
 // CIGAR words of the records into one array (cigar_off), a wavefront per record
 __global__ void k_bam_cigars(const uint8_t *__restrict__ st, const np2_bamrec_t *__restrict__ recs, const uint64_t *__restrict__ cig_src, uint32_t n_recs,
@@ -497,12 +514,12 @@ void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, con
     if (n_blk) hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blk), dim3(64), 0, s, blk, n_blk, comp, out, status, n_bad, prof, probe);
 }
 void launch_bam_chain_count(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
-                            uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at) {
-    if (n_chains) hipLaunchKernelGGL(k_bam_chain_count, dim3((n_chains + 63) / 64), dim3(64), 0, s, stream, starts, n_chains, end, tid, L, chain_info, flags, tail_at);
+                            uint32_t zone_lo, uint32_t zone_hi, uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at) {
+    if (n_chains) hipLaunchKernelGGL(k_bam_chain_count, dim3((n_chains + 63) / 64), dim3(64), 0, s, stream, starts, n_chains, end, tid, L, zone_lo, zone_hi, chain_info, flags, tail_at);
 }
 void launch_bam_chain_write(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
-                            const uint2 *chain_off, np2_bamrec_t *recs, uint64_t *cig_src) {
-    if (n_chains) hipLaunchKernelGGL(k_bam_chain_write, dim3((n_chains + 63) / 64), dim3(64), 0, s, stream, starts, n_chains, end, tid, L, chain_off, recs, cig_src);
+                            uint32_t zone_lo, uint32_t zone_hi, const uint2 *chain_off, np2_bamrec_t *recs, uint64_t *cig_src) {
+    if (n_chains) hipLaunchKernelGGL(k_bam_chain_write, dim3((n_chains + 63) / 64), dim3(64), 0, s, stream, starts, n_chains, end, tid, L, zone_lo, zone_hi, chain_off, recs, cig_src);
 }
 void launch_bam_cigars(hipStream_t s, const uint8_t *stream, const np2_bamrec_t *recs, const uint64_t *cig_src, uint32_t n_recs, uint32_t *cigar) {
     if (n_recs) hipLaunchKernelGGL(k_bam_cigars, dim3((uint32_t)(((uint64_t)n_recs * 64 + 255) / 256)), dim3(256), 0, s, stream, recs, cig_src, n_recs, cigar);

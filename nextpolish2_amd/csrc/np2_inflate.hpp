@@ -26,10 +26,12 @@ static constexpr uint32_t WALK_EARLY_END = 16u; // the contig's records ended be
 void launch_bgzf_inflate(hipStream_t s, const InfBlock *blk, uint32_t n_blk, const uint8_t *comp, uint8_t *out, uint32_t *status, uint32_t *n_bad,
                          unsigned long long *prof = nullptr, uint32_t probe = 0);
 // starts[0 .. n_chains): stream offsets of record starts, ascending; the last chain ends at a record of another reference or at `end`
+// zone [zone_lo, zone_hi): (0, L) for the whole contig, a shard's reference interval otherwise; cig_src[i] = stream offset of
+// record i's CIGAR words (the record starts 36 + l_read_name bytes before: its BGZF virtual offset follows from that)
 void launch_bam_chain_count(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
-                            uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at);
+                            uint32_t zone_lo, uint32_t zone_hi, uint2 *chain_info, uint32_t *flags, unsigned long long *tail_at);
 void launch_bam_chain_write(hipStream_t s, const uint8_t *stream, const uint64_t *starts, uint32_t n_chains, uint64_t end, int32_t tid, uint32_t L,
-                            const uint2 *chain_off, np2_bamrec_t *recs, uint64_t *cig_src);
+                            uint32_t zone_lo, uint32_t zone_hi, const uint2 *chain_off, np2_bamrec_t *recs, uint64_t *cig_src);
 void launch_bam_cigars(hipStream_t s, const uint8_t *stream, const np2_bamrec_t *recs, const uint64_t *cig_src, uint32_t n_recs, uint32_t *cigar);
 
 } // namespace np2

@@ -1854,18 +1854,38 @@ struct GpuRecs {
 };
 // The records of reference `tid` (all of them: fetch(tid, 0, L)).  false: this BAM / index cannot take the device path
 // (no linear index, an index entry that is not a record start) — the caller reads it the host way.
-bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs &out) {
+// zone [zone_lo, zone_hi): (0, L) for the whole contig, or a shard's interval (then `voffs` receives the records' BGZF
+// virtual offsets: what the ranks exchange to number their reads contig-wide)
+bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint32_t zone_hi, hipStream_t s, GpuRecs &out,
+                       std::vector<uint64_t> *voffs = nullptr) {
     const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
     const double t0 = np2h::now_ms();
-    const uint64_t start_off = bam->ref_start[tid];
+    uint64_t start_off = bam->ref_start[tid];
     if (start_off == ~0ull) return true; // no record of this reference
     if (bam->lin[tid].empty()) return false;
+    uint64_t end_hint = bam->ref_end[tid];
+    {
+        // where to start / stop: the smallest offset of a record overlapping the 16 kb window of zone_lo (an empty window
+        // takes the next one's, like htslib); records that start at or beyond zone_hi lie behind the first record
+        // overlapping the window AFTER zone_hi's
+        const std::vector<uint64_t> &lin = bam->lin[tid];
+        if (zone_lo > 0) {
+            size_t w = std::min<size_t>(zone_lo >> 14, lin.size() - 1);
+            while (w + 1 < lin.size() && lin[w] == 0) ++w;
+            if (lin[w] != 0) start_off = lin[w];
+        }
+        if (zone_hi < L) {
+            size_t w = (size_t)(zone_hi >> 14) + 1;
+            while (w < lin.size() && lin[w] == 0) ++w;
+            if (w < lin.size()) end_hint = lin[w];
+        }
+    }
     if (!bam->gpu) bam->gpu = new GpuFetch();
     GpuFetch &g = *bam->gpu;
     const int fd = fileno(bam->z.f);
     const size_t file_len = bam->map_len;
     const size_t c_lo = (size_t)(start_off >> 16);
-    size_t c_hi = bam->ref_end[tid] ? (size_t)(bam->ref_end[tid] >> 16) : file_len; // file offset of the last block wanted
+    size_t c_hi = end_hint ? (size_t)(end_hint >> 16) : file_len; // file offset of the last block wanted
     if (getenv("NP2_TEST_FETCH_SHORT_HINT")) c_hi = c_lo; // test hook: an index that understates where the reference's records end
     struct GBlk {
         uint64_t file_off; // of the block
@@ -2018,7 +2038,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
         uint64_t *h_st = (uint64_t *)g.host_block(g.h_recs, g.h_recs_cap, (size_t)n_chains * 8 + 64);
         memcpy(h_st, starts.data(), (size_t)n_chains * 8);
         HIPCHK(hipMemcpyAsync(g.d_starts.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
-        np2::launch_bam_chain_count(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, g.d_info.p, g.d_status.p + w_flags,
+        np2::launch_bam_chain_count(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_info.p, g.d_status.p + w_flags,
                                     (unsigned long long *)(g.d_status.p + w_tail));
         // one wait: block statuses' summary, the walk's flags, the chains' counts
         std::vector<uint2> info(n_chains);
@@ -2060,7 +2080,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
             g.d_cigar.ensure(n_cig + 1);
             memcpy(h_st, off.data(), (size_t)n_chains * 8);
             HIPCHK(hipMemcpyAsync(g.d_off.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
-            np2::launch_bam_chain_write(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, g.d_off.p, g.d_recs.p, g.d_cig_src.p);
+            np2::launch_bam_chain_write(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_off.p, g.d_recs.p, g.d_cig_src.p);
             np2::launch_bam_cigars(s, g.d_inf.p, g.d_recs.p, g.d_cig_src.p, (uint32_t)n_rec, g.d_cigar.p);
             HIPCHK(hipStreamSynchronize(s)); // (h_st is about to be given up for a larger block)
             if (prof) fprintf(stderr, "  fetch_records_gpu: offsets + write + cigars %.2f ms\n", np2h::now_ms() - t2);
@@ -2070,6 +2090,18 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, hipStream_t s, GpuRecs
             if (n_cig) HIPCHK(hipMemcpyAsync(hc, g.d_cigar.p, n_cig * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             out.recs = hr, out.cigar = hc;
+            if (voffs) { // stream offset of every record's start -> (file offset of its block << 16 | offset inside the block)
+                std::vector<uint64_t> src(n_rec);
+                HIPCHK(hipMemcpy(src.data(), g.d_cig_src.p, n_rec * 8, hipMemcpyDeviceToHost));
+                voffs->resize(n_rec);
+                IoPool::get().parallel_for((size_t)((n_rec + 4095) / 4096), 16, [&](size_t blk) {
+                    for (uint64_t i = blk * 4096; i < std::min<uint64_t>(n_rec, (blk + 1) * 4096); ++i) {
+                        const uint64_t at = src[i] - 36u - hr[i].pad; // (first byte of the record's block_size field)
+                        const size_t bi = (size_t)(std::upper_bound(out_off.begin(), out_off.end(), at) - out_off.begin()) - 1;
+                        (*voffs)[i] = (blks[bi].file_off << 16) | (at - out_off[bi]);
+                    }
+                });
+            }
         }
         if (prof)
             fprintf(stderr, "fetch_records_gpu: %zu blocks (%.1f MB -> %.1f MB), %u chains, %llu records, %llu CIGAR words: file -> pinned pieces (+ block headers) %.2f ms, "
@@ -2173,7 +2205,7 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         uint64_t seq_bytes = 0;
         if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
             GpuRecs gr;
-            if (fetch_records_gpu(bam, tid, L, cx->stream, gr)) {
+            if (fetch_records_gpu(bam, tid, L, 0, L, cx->stream, gr)) {
                 const double t_g1 = np2h::now_ms();
                 FrontWork fw;
                 front_begin(cx, ref, L, gr.recs, gr.n_recs, gr.cigar, nullptr, gr.n_recs ? gr.stream_bytes : 0, opts, nullptr, fw, gr.n_recs ? gr.d_stream : nullptr);
@@ -2247,13 +2279,25 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         std::vector<uint32_t> cigar;
         HIPCHK(hipSetDevice(cx->device));
         uint64_t seq_bytes = 0;
-        fetch_records(bam, tid, L, pl.zone_lo, pl.zone_hi, opts, recs, cigar, &io->rec_voff, cx->stream, &seq_bytes);
+        // the interval's records: extracted on the device (fetch_records_gpu: a rank of eight has two of the node's CPUs) or
+        // by the host pool
+        GpuRecs gr;
+        const bool on_device = gpu_fetch_wanted(bam, tid) && !opts->use_secondary &&
+                               fetch_records_gpu(bam, tid, L, pl.zone_lo, pl.zone_hi, cx->stream, gr, &io->rec_voff);
+        if (on_device) {
+            recs.assign(gr.recs, gr.recs + gr.n_recs);
+            seq_bytes = gr.n_recs ? gr.stream_bytes : 0;
+        } else {
+            io->rec_voff.clear();
+            fetch_records(bam, tid, L, pl.zone_lo, pl.zone_hi, opts, recs, cigar, &io->rec_voff, cx->stream, &seq_bytes);
+        }
+        const uint32_t *cigar_p = on_device ? gr.cigar : cigar.data();
         // the sub-contig: from the first start to the last reference end among the fetched records
         uint32_t slo = pl.zone_lo, shi = pl.zone_hi;
         for (const np2_bamrec_t &r : recs) {
             uint64_t span = 0;
             for (uint32_t k = 0; k < r.n_cigar; ++k) {
-                const uint32_t w = cigar[r.cigar_off + k], op = w & 15;
+                const uint32_t w = cigar_p[r.cigar_off + k], op = w & 15;
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
             }
             if (r.pos >= 0) slo = std::min<uint32_t>(slo, (uint32_t)r.pos);
@@ -2263,8 +2307,8 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         pl.sub_hi = own_hi == L ? L : shi;
         ShardSpec sp;
         sp.sub_lo = pl.sub_lo, sp.sub_hi = pl.sub_hi, sp.zone_lo = pl.zone_lo, sp.zone_hi = pl.zone_hi;
-        front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar.data(), bam->seq4.data(), seq_bytes, opts, &sp, io->fw,
-                    opts->use_secondary ? nullptr : bam->seqs.dev.p);
+        front_begin(cx, ref, L, recs.data(), (uint32_t)recs.size(), cigar_p, on_device ? nullptr : bam->seq4.data(), seq_bytes, opts, &sp, io->fw,
+                    on_device ? (gr.n_recs ? gr.d_stream : nullptr) : (opts->use_secondary ? nullptr : bam->seqs.dev.p));
         for (size_t i = 1; i < io->fw.reads.size(); ++i) {
             const np2_bamrec_t &r = recs[io->fw.rec_of[i]];
             if ((uint32_t)r.pos >= own_lo && (uint32_t)r.pos < own_hi) io->own_voff.push_back(io->rec_voff[io->fw.rec_of[i]]);

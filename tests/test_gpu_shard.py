@@ -260,9 +260,14 @@ def test_full_size_chr1_diploid_whole_two_and_four_intervals(capsys):
         del runs, ctxs
 
 
-def test_shards_read_straight_from_the_bam_number_their_reads_contig_wide(tmp_path):
+@pytest.mark.parametrize("inflate", ["libdeflate", "gpu"])
+def test_shards_read_straight_from_the_bam_number_their_reads_contig_wide(tmp_path, monkeypatch, capfd, inflate):
     """np2_shard_bam_*: every shard parses only the records overlapping its interval +- halo; the exchanged file offsets
-    give every pushed record its contig-wide number; stitched result == whole-contig BAM path == oracle front end + polish."""
+    give every pushed record its contig-wide number; stitched result == whole-contig BAM path == oracle front end + polish.
+    inflate = gpu: the interval's records extracted on the device (blocks from the linear index's entry for the zone's start
+    on, the walk ending at the first record behind the zone, virtual offsets from the records' stream offsets)."""
+    monkeypatch.setenv("NP2_INFLATE", inflate)
+    monkeypatch.setenv("NP2_IO_PROFILE", "1")
     import gzip  # noqa: F401
     from nextpolish2_amd import io as np2io
     from nextpolish2_amd.bamio import pileup_to_records, records_to_arrays, write_bam
@@ -313,3 +318,6 @@ def test_shards_read_straight_from_the_bam_number_their_reads_contig_wide(tmp_pa
     pu = orc.front_end(ref, arr, cig, asc, asc_off, np2io.FrontOpts())
     ob, op = orc.Oracle(yaks).polish(pu, Opts())
     assert np.array_equal(ob, b0) and np.array_equal(op, p0)
+    err = capfd.readouterr().err
+    # (the whole contig once; then 2 and 3 shards, each read once by ShardFromBam and once by polish_sharded_bam_local)
+    assert (err.count("fetch_records_gpu:") >= 11) == (inflate == "gpu"), err[-1500:]
