@@ -223,7 +223,11 @@ int np2_shard_vote(np2_shard_run_t *run, np2_vote_t *out);
  * n_reads_total */
 int np2_vote_decide(const np2_vote_t *votes, int n_votes, uint32_t n_reads_total, const np2_opts_t *opts, uint32_t *losers,
                     uint32_t *n_losers);
-int np2_shard_apply(np2_shard_run_t *run, const uint32_t *losers, uint32_t n_losers); /* contig-wide ids */
+/* the decision's removed reads (contig-wide ids; any list: np2_vote_decide's, a replayed or a custom one).  If the pass
+ * np2_shard_vote started early went by other reads — the list removes more than the vote kernel flagged, or KEEPS a flagged
+ * read (np2_vote_decide never does: main.rs:977) — the difference is applied (reads removed / brought back) and the pass is
+ * started again; the result is the one of the list either way */
+int np2_shard_apply(np2_shard_run_t *run, const uint32_t *losers, uint32_t n_losers);
 /* the final pass; bases / positions (contig coordinates) of [own_lo - verify, own_hi + verify); release with np2_free */
 int np2_shard_final(np2_shard_run_t *run, uint8_t **out_bases, uint32_t **out_pos, uint64_t *out_len);
 void np2_shard_end(np2_shard_run_t *run);

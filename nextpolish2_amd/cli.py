@@ -271,8 +271,9 @@ def main(argv=None):
     # reference's reader / workers / writer threads around two bounded channels).
     # (two of each: a front end already spreads its inflate over the host pool, and two polish contexts keep the GPU busy
     # through each other's host phases — measured on the 17-contig 12 Mb assembly: 84 ms with 2 + 2, 109 ms with 3 + 4)
-    n_workers = max(1, min(2, a.thread))
-    n_front = max(1, min(2, a.thread))
+    # (NP2_CLI_FRONT / NP2_CLI_WORKERS: experiments with other splits; -t beyond 2 keeps 2 + 2, see above)
+    n_workers = int(os.environ.get("NP2_CLI_WORKERS", max(1, min(2, a.thread))))
+    n_front = int(os.environ.get("NP2_CLI_FRONT", max(1, min(2, a.thread))))
     tls = threading.local()
     base, base_lock = [], threading.Lock()
     yak_pool = ThreadPoolExecutor(max_workers=1)
