@@ -2205,7 +2205,16 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         uint64_t seq_bytes = 0;
         if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
             GpuRecs gr;
-            if (fetch_records_gpu(bam, tid, L, 0, L, cx->stream, gr)) {
+            bool on_device = false;
+            try {
+                on_device = fetch_records_gpu(bam, tid, L, 0, L, cx->stream, gr);
+            } catch (const np2h::Np2Error &e) {
+                // (no room on the device for the file bytes + the inflated stream — 13 GB for a human chromosome next to what
+                // else lives there: the host pool streams the same records through 128 MiB)
+                if (e.code != NP2_E_NOMEM) throw;
+                (void)hipStreamSynchronize(cx->stream);
+            }
+            if (on_device) {
                 const double t_g1 = np2h::now_ms();
                 FrontWork fw;
                 front_begin(cx, ref, L, gr.recs, gr.n_recs, gr.cigar, nullptr, gr.n_recs ? gr.stream_bytes : 0, opts, nullptr, fw, gr.n_recs ? gr.d_stream : nullptr);
@@ -2282,8 +2291,15 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         // the interval's records: extracted on the device (fetch_records_gpu: a rank of eight has two of the node's CPUs) or
         // by the host pool
         GpuRecs gr;
-        const bool on_device = gpu_fetch_wanted(bam, tid) && !opts->use_secondary &&
-                               fetch_records_gpu(bam, tid, L, pl.zone_lo, pl.zone_hi, cx->stream, gr, &io->rec_voff);
+        bool on_device = false;
+        if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) {
+            try {
+                on_device = fetch_records_gpu(bam, tid, L, pl.zone_lo, pl.zone_hi, cx->stream, gr, &io->rec_voff);
+            } catch (const np2h::Np2Error &e) {
+                if (e.code != NP2_E_NOMEM) throw; // (no room on the device: the host pool's path)
+                (void)hipStreamSynchronize(cx->stream);
+            }
+        }
         if (on_device) {
             recs.assign(gr.recs, gr.recs + gr.n_recs);
             seq_bytes = gr.n_recs ? gr.stream_bytes : 0;

@@ -455,13 +455,22 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     //      main.rs:1664-1674), then the nodes whose second column lies at the same position take the earlier nodes of their
     //      own position in three more rounds (node k's predecessors are final by round k); 64 quads a round over all four
     //      wavefronts.  Lane 0 closes the run and walks it back.
-    __shared__ uint16_t s_ql[TILE / 2 + 2]; // runs for quads from the front, runs for single lanes from the back
+    // The two lists take the place of the run starts themselves (quads from the front of s_run, single lanes from its back):
+    // every thread has its — at most two — run starts in registers before the first list entry is written.  (A list array of
+    // its own was the kilobyte of LDS between eight tiles per CU and seven.)
     __shared__ uint32_t s_nl[2];
     if (tid < 2) s_nl[tid] = 0;
+    static_assert(TILE / 2 <= 2 * 256, "a thread keeps at most two run starts");
+    uint32_t my_qa[2];
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) my_qa[k] = tid + 256u * k < n_runs ? (uint32_t)s_run[tid + 256u * k] : 0xFFFFFFFFu;
+    uint16_t *const s_ql = s_run; // [TILE / 2 + 1]
     __syncthreads();
     constexpr uint32_t PF_QN = 3; // exception nodes a quad holds
-    for (uint32_t r = tid; r < n_runs; r += 256) {
-        const uint32_t qa = s_run[r];
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+        const uint32_t qa = my_qa[k];
+        if (qa == 0xFFFFFFFFu) continue;
         const uint32_t a = start + qa;
         uint32_t q = qa, mxn = 0;
         int32_t g = 0;
@@ -485,7 +494,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
         } else if (mxn <= PF_QN) {
             s_ql[atomicAdd(&s_nl[0], 1u)] = (uint16_t)qa;
         } else {
-            s_ql[TILE / 2 + 1 - atomicAdd(&s_nl[1], 1u)] = (uint16_t)qa;
+            s_ql[TILE / 2 - atomicAdd(&s_nl[1], 1u)] = (uint16_t)qa;
         }
     }
     __syncthreads();
@@ -647,7 +656,7 @@ __device__ __forceinline__ void pf_tile_body(const uint32_t t, const PfTile &A) 
     }
     // (3) the runs with a deeper position: one lane each, every (node, predecessor) pair out of LDS
     for (uint32_t r = tid; r < n_one; r += 256) {
-        const uint32_t qa = s_ql[TILE / 2 + 1 - r];
+        const uint32_t qa = s_ql[TILE / 2 - r];
         const uint32_t a = start + qa;
         int32_t base = 0;
         if (a == 1 || a == 2) base = 6 * (int32_t)s_cov[0] + (a == 2 ? 6 * (int32_t)s_cov[1] : 0);
