@@ -1903,7 +1903,18 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
         blks.clear();
         const size_t read_end = std::min(file_len, c_hi + 65536 + extra);
         const size_t c_bytes = read_end - c_lo;
-        g.d_comp.ensure(c_bytes + 64);
+        // (file bytes + inflated stream: 13 GB for a human chromosome.  No room on the device next to what else lives there ->
+        // false: the host pool streams the same records through 128 MiB of host memory)
+        auto room = [&](auto &buf, size_t n) {
+            try {
+                buf.ensure(n);
+            } catch (const np2h::Np2Error &) {
+                (void)hipGetLastError();
+                return false;
+            }
+            return true;
+        };
+        if (!room(g.d_comp, c_bytes + 64)) return false;
         for (int i = 0; i < 2; ++i) {
             if (!g.pin[i]) {
                 g.pin[i] = np2h::pinned_pool().get(GpuFetch::PIECE);
@@ -1990,7 +2001,10 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
         const uint64_t total = out_off[n_blk];
         const double t1 = np2h::now_ms();
         // ---- inflate ------------------------------------------------------------------------------------------------------------
-        g.d_inf.ensure(total + 128);
+        if (!room(g.d_inf, total + 128)) {
+            HIPCHK(hipStreamSynchronize(s)); // (the uploads into d_comp)
+            return false;
+        }
         g.d_blk.ensure(n_blk + 1);
         g.d_status.ensure(n_blk + 8);
         double t_up = 0, t_inf = 0;
@@ -2205,16 +2219,7 @@ int np2_contig_from_bam(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         uint64_t seq_bytes = 0;
         if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) { // read extraction on the device (fetch_records_gpu)
             GpuRecs gr;
-            bool on_device = false;
-            try {
-                on_device = fetch_records_gpu(bam, tid, L, 0, L, cx->stream, gr);
-            } catch (const np2h::Np2Error &e) {
-                // (no room on the device for the file bytes + the inflated stream — 13 GB for a human chromosome next to what
-                // else lives there: the host pool streams the same records through 128 MiB)
-                if (e.code != NP2_E_NOMEM) throw;
-                (void)hipStreamSynchronize(cx->stream);
-            }
-            if (on_device) {
+            if (fetch_records_gpu(bam, tid, L, 0, L, cx->stream, gr)) { // (false: not this BAM / index, or no room on the device)
                 const double t_g1 = np2h::now_ms();
                 FrontWork fw;
                 front_begin(cx, ref, L, gr.recs, gr.n_recs, gr.cigar, nullptr, gr.n_recs ? gr.stream_bytes : 0, opts, nullptr, fw, gr.n_recs ? gr.d_stream : nullptr);
@@ -2291,15 +2296,8 @@ int np2_shard_bam_begin(np2_ctx_t *cx, np2_bam_t *bam, const char *name, const u
         // the interval's records: extracted on the device (fetch_records_gpu: a rank of eight has two of the node's CPUs) or
         // by the host pool
         GpuRecs gr;
-        bool on_device = false;
-        if (gpu_fetch_wanted(bam, tid) && !opts->use_secondary) {
-            try {
-                on_device = fetch_records_gpu(bam, tid, L, pl.zone_lo, pl.zone_hi, cx->stream, gr, &io->rec_voff);
-            } catch (const np2h::Np2Error &e) {
-                if (e.code != NP2_E_NOMEM) throw; // (no room on the device: the host pool's path)
-                (void)hipStreamSynchronize(cx->stream);
-            }
-        }
+        const bool on_device = gpu_fetch_wanted(bam, tid) && !opts->use_secondary &&
+                               fetch_records_gpu(bam, tid, L, pl.zone_lo, pl.zone_hi, cx->stream, gr, &io->rec_voff);
         if (on_device) {
             recs.assign(gr.recs, gr.recs + gr.n_recs);
             seq_bytes = gr.n_recs ? gr.stream_bytes : 0;
