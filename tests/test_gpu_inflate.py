@@ -172,3 +172,22 @@ def test_references_of_one_bam_through_the_device(tmp_path, short_hint):
                 assert "after extending the range" in err
     assert outs["gpu"] == outs["libdeflate"]
     assert outs["gpu"] == exp
+
+
+def test_no_room_on_the_device_takes_the_host_pools_path(tmp_path):
+    """The inflated stream of a reference does not fit on the device next to what else lives there (the allocation is refused:
+    NP2_TEST_FETCH_NO_ROOM stands in for a full device): the contig goes through the host pool instead, with the same output."""
+    _bundle4(tmp_path)
+    outs = {}
+    for mode in ("no_room", "libdeflate"):
+        env = dict(os.environ, PYTHONPATH=ROOT, NP2_INFLATE="gpu" if mode == "no_room" else mode, NP2_IO_PROFILE="1")
+        if mode == "no_room":
+            env["NP2_TEST_FETCH_NO_ROOM"] = "1"
+        out = tmp_path / ("out_%s.fa" % mode)
+        r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-L", "10000", "-o", str(out), str(tmp_path / "m.bam"),
+                            str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        outs[mode] = out.read_bytes()
+        if mode == "no_room":
+            assert "fetch_records_gpu:" not in r.stderr.decode()
+    assert outs["no_room"] == outs["libdeflate"] and len(outs["no_room"]) > 100000
