@@ -38,6 +38,26 @@ struct Np2Error : std::runtime_error {
         if (c) throw Np2Error(NP2_E_REFPANIC, std::string("reference would panic: ") + (m));        \
     } while (0)
 
+// NP2_ALLOC_PROFILE: driver calls that allocate, release or drain — the ones that take the runtime's process-wide locks —
+// reported on stderr when they take a millisecond or more (a tool's switch: tools/cli_probe.py)
+struct SlowCall {
+    static bool on() {
+        static const bool v = getenv("NP2_ALLOC_PROFILE") != nullptr;
+        return v;
+    }
+    const char *what;
+    size_t bytes;
+    std::chrono::steady_clock::time_point t0;
+    SlowCall(const char *w, size_t b = 0) : what(w), bytes(b) {
+        if (on()) t0 = std::chrono::steady_clock::now();
+    }
+    ~SlowCall() {
+        if (!on()) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms >= 1.0) fprintf(stderr, "[np2 alloc] %s %.1f MB: %.1f ms\n", what, (double)bytes / 1e6, ms);
+    }
+};
+
 // Device blocks of short-lived objects — the resident pileup of a contig, the front end's staging buffers — are cached
 // per device by size class instead of going back to the driver: hipMalloc / hipFree cost 0.1 - 1 ms each, hipFree
 // synchronises the device, and a contig of a many-contig assembly brings a dozen of each.  Only for memory whose owner
@@ -78,6 +98,7 @@ struct DevCache {
             }
         }
         void *p = nullptr;
+        SlowCall sc("hipMalloc (block)", bytes);
         if (hipMalloc(&p, bytes) != hipSuccess) {
             trim(0); // (the idle blocks may be what is missing)
             HIPCHK(hipMalloc(&p, bytes));
@@ -112,6 +133,7 @@ struct DevCache {
         (void)hipGetDevice(&cur);
         for (auto &d : drop) {
             (void)hipSetDevice(d.first);
+            SlowCall sc("hipFree (cache trim)");
             (void)hipFree(d.second);
         }
         (void)hipSetDevice(cur);
@@ -156,6 +178,7 @@ struct DevSlabs {
                 return p;
             }
         void *b = nullptr;
+        SlowCall sc("hipMalloc (slab)", SLAB);
         if (hipMalloc(&b, SLAB) != hipSuccess) {
             (void)hipGetLastError();
             dev_cache().trim(0); // (the idle blocks of the size-class cache may be what is missing)
@@ -189,6 +212,7 @@ inline int &dev_sync_depth() {
 }
 struct DevSyncScope {
     DevSyncScope() {
+        SlowCall sc("hipDeviceSynchronize (release scope)");
         (void)hipDeviceSynchronize();
         ++dev_sync_depth();
     }
@@ -225,7 +249,10 @@ template <class T> struct DevBuf {
             } else {
                 // a buffer grows while kernels that use its old storage may still be queued: drain the device first (what
                 // hipFree, which this replaces, does implicitly) unless the owner already has
-                if (dev_sync_depth() == 0) (void)hipDeviceSynchronize();
+                if (dev_sync_depth() == 0) {
+                    SlowCall sc("hipDeviceSynchronize (buffer regrown)", cap * sizeof(T));
+                    (void)hipDeviceSynchronize();
+                }
                 dev_release_idle(p, slab_bytes, cache_bytes);
             }
         }
@@ -277,6 +304,7 @@ struct PinnedPool {
             free_.erase(free_.begin() + (long)best);
         } else {
             cap = bytes + bytes / 8 + 4096;
+            SlowCall sc("hipHostMalloc (pool)", cap);
             if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
         }
         live[p] = cap;
@@ -295,6 +323,7 @@ struct PinnedPool {
         for (auto &f : free_) held += f.first;
         while (free_.size() > 4096 || (held > (2ull << 30) && free_.size() > 8)) {
             held -= free_.front().first;
+            SlowCall sc("hipHostFree (pool)", free_.front().first);
             (void)hipHostFree(free_.front().second);
             free_.erase(free_.begin());
         }
@@ -678,6 +707,12 @@ inline void op_d2h(np2_ctx *cx, void *pinned_dst, const void *src, size_t bytes)
             r->push_fn([=](hipStream_t s) { HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, s)); });
     } else
         HIPCHK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, cx->stream));
+}
+// device -> host of min(*n_dev * elem, cap_bytes) bytes (true: done; false: not this way — the caller copies cap_bytes)
+inline bool op_d2h_len(np2_ctx *cx, void *pinned_dst, const void *src, const uint32_t *n_dev, uint32_t elem, size_t cap_bytes) {
+    if (!tl_recorder() || cap_bytes > KERNEL_D2H_MAX) return false;
+    launch_copy_len(cx->stream, (uint8_t *)pinned_dst, (const uint8_t *)src, n_dev, elem, cap_bytes);
+    return true;
 }
 inline void op_h2d(np2_ctx *cx, void *dst, const void *pinned_src, size_t bytes) {
     if (!bytes) return;

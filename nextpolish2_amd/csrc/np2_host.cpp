@@ -1174,9 +1174,13 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
         if ((r.want_bases && !r.bases) || (r.want_pos && !r.pos)) throw Np2Error(NP2_E_NOMEM, "pinned result allocation failed");
         // (M_likely: a tighter guess of the length — every splice round reserves the full growth allowance, a region
         // is spliced in one of them —; should the sequence be longer after all, its rest follows in a second copy)
-        const uint32_t first = std::min(M_cap, M_likely);
-        if (r.want_bases) op_d2h(cx, r.bases, dbase, first);
-        if (r.want_pos) op_d2h(cx, r.pos, dpos, (size_t)first * 4);
+        // (under the batch driver the copy kernel reads the length on the device and moves exactly that)
+        uint32_t first = std::min(M_cap, M_likely);
+        const bool exact_b = r.want_bases && op_d2h_len(cx, r.bases, dbase, M_p, 1, M_cap);
+        const bool exact_p = r.want_pos && op_d2h_len(cx, r.pos, dpos, M_p, 4, (size_t)M_cap * 4);
+        if (r.want_bases && !exact_b) op_d2h(cx, r.bases, dbase, first);
+        if (r.want_pos && !exact_p) op_d2h(cx, r.pos, dpos, (size_t)first * 4);
+        if ((exact_b || !r.want_bases) && (exact_p || !r.want_pos)) first = M_cap; // (nothing left for a second copy)
         op_sync(cx);
         if (__atomic_load_n(&cx->mbox_host[0], __ATOMIC_ACQUIRE) != seq)
             throw Np2Error(NP2_E_DEVICE, "mailbox not posted after a synchronisation");

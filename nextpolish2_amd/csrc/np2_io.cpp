@@ -557,19 +557,6 @@ uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p +
 
 // std::vector storage in pinned host memory: the SEQ bytes gathered from the BAM go to the GPU by DMA straight from
 // here (a pageable source is staged through bounce buffers at a fraction of the bus rate)
-template <class T> struct PinnedAlloc {
-    using value_type = T;
-    PinnedAlloc() = default;
-    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
-    T *allocate(size_t n) {
-        void *p = nullptr;
-        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
-        return (T *)p;
-    }
-    void deallocate(T *p, size_t) { (void)hipHostFree(p); }
-    template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
-    template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
-};
 // growable byte buffer in pinned host memory WITHOUT value-initialisation (std::vector::resize zero-fills what the
 // record copies overwrite a moment later: 69 MB of SEQ per E. coli-sized contig)
 struct PinnedBytes {

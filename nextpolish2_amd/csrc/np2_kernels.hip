@@ -93,6 +93,13 @@ __device__ __forceinline__ void k_copy(const uint32_t np2_bid, const uint32_t np
         for (uint64_t i = o; i < min(o + 16, n); ++i) dst[i] = src[i];
     }
 }
+// k_copy of min(*n_dev * elem, cap) bytes: the polished sequence leaves for the host at its real length, which only the
+// device knows when the copy is recorded (the host's bound is the length plus every splice round's growth allowance:
+// 11 % more bytes over the bus on the yeast-sized assembly)
+__device__ __forceinline__ void k_copy_len(const uint32_t np2_bid, const uint32_t np2_nb, uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                           const uint32_t *__restrict__ n_dev, uint32_t elem, uint64_t cap) {
+    k_copy(np2_bid, np2_nb, dst, src, min((uint64_t)*n_dev * elem, cap));
+}
 // copy of n 32-bit words where n = min(*n_dev, cap) lives on the device: the grid is sized by the host's bound, the
 // threads walk the real length (16 bytes per thread and step).  A read-back whose size is only known on the device
 // rides in the same wait as the counters that say how large it is.
@@ -1594,6 +1601,9 @@ void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte) {
 }
 void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes) {
     if (bytes) NP2_LAUNCH(k_copy, grid1((bytes + 15) / 16), 256, s, dst, src, bytes);
+}
+void launch_copy_len(hipStream_t s, uint8_t *dst, const uint8_t *src, const uint32_t *n_dev, uint32_t elem, uint64_t cap_bytes) {
+    if (cap_bytes) NP2_LAUNCH(k_copy_len, grid1((cap_bytes + 15) / 16), 256, s, dst, src, n_dev, elem, cap_bytes);
 }
 void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap) {
     if (cap) NP2_LAUNCH(k_copy_counted, dim3(std::max<uint32_t>(1, std::min<uint32_t>((cap + 1023) / 1024, 2048))), 256, s, dst, src, n_dev, cap);

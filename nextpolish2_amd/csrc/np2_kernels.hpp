@@ -103,6 +103,7 @@ void launch_post(hipStream_t s, uint32_t *scal, uint32_t n_scal, uint32_t *mbox,
                  const uint32_t *ends_of = nullptr, uint32_t *ends_dst = nullptr);
 void launch_fill(hipStream_t s, uint8_t *p, uint64_t bytes, uint8_t byte);
 void launch_copy(hipStream_t s, uint8_t *dst, const uint8_t *src, uint64_t bytes);
+void launch_copy_len(hipStream_t s, uint8_t *dst, const uint8_t *src, const uint32_t *n_dev, uint32_t elem, uint64_t cap_bytes);
 // min(*n_dev, cap) 32-bit words, the count read on the device
 void launch_copy_counted(hipStream_t s, uint32_t *dst, const uint32_t *src, const uint32_t *n_dev, uint32_t cap);
 void launch_init_alive(hipStream_t s, const np2_read_t *reads, uint32_t R, uint8_t *alive);

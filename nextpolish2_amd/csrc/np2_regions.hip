@@ -687,6 +687,7 @@ __device__ __forceinline__ void k_splice_plan(const uint32_t np2_bid, const uint
 // per block for its first and last index with 16 probes in flight per round, threads only search the (usually empty)
 // slot range in between.
 static constexpr uint32_t SPLICE_SPAN = 2048;
+static constexpr uint32_t SPLICE_LDS_SLOTS = 256; // slots of a block's span staged in LDS (a span of 2048 bases holds ~20 of them)
 __device__ __forceinline__ void k_splice_bases(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ in_pos,
                                                       const uint8_t *__restrict__ in_base,
                                                       const uint32_t *__restrict__ M_p,
@@ -695,30 +696,59 @@ __device__ __forceinline__ void k_splice_bases(const uint32_t np2_bid, const uin
                                                       const uint32_t *__restrict__ n_ap_p, uint32_t *__restrict__ out_pos,
                                                       uint8_t *__restrict__ out_base) {
     __shared__ uint32_t s_lo[2];
+    __shared__ uint32_t s_s[SPLICE_LDS_SLOTS], s_e[SPLICE_LDS_SLOTS];
+    __shared__ int32_t s_sh[SPLICE_LDS_SLOTS];
     const uint32_t i0 = np2_bid * SPLICE_SPAN;
     const uint32_t n_ap = *n_ap_p, M = *M_p;
     if (i0 >= M) return;
+    // (the block's elements first: their loads are in flight while the slot range is found and staged)
+    uint32_t pv[SPLICE_SPAN / 256];
+    uint8_t bv[SPLICE_SPAN / 256];
+#pragma unroll
+    for (uint32_t k = 0; k < SPLICE_SPAN / 256; ++k) {
+        const uint32_t i = min(i0 + k * 256 + threadIdx.x, M - 1);
+        pv[k] = in_pos[i], bv[k] = in_base[i];
+    }
     if (threadIdx.x < 2) // number of slots with ap_s <= first / last index of the block
         s_lo[threadIdx.x] = upper_bound_u32(ap_s, n_ap, threadIdx.x == 0 ? i0 : min(M - 1, i0 + SPLICE_SPAN - 1));
     __syncthreads();
-    const uint32_t blo = s_lo[0], bhi = s_lo[1];
+    // slots blo - 1 (the one the block's first index may lie in or behind) .. bhi - 1
+    const uint32_t blo = s_lo[0], bhi = s_lo[1], b0 = blo ? blo - 1 : 0u;
+    const bool staged = bhi - b0 <= SPLICE_LDS_SLOTS; // (uniform)
+    if (staged && b0 + threadIdx.x < bhi) {
+        s_s[threadIdx.x] = ap_s[b0 + threadIdx.x];
+        s_e[threadIdx.x] = ap_e[b0 + threadIdx.x];
+        s_sh[threadIdx.x] = ap_shift_incl[b0 + threadIdx.x];
+    }
+    __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < SPLICE_SPAN / 256; ++k) {
         const uint32_t i = i0 + k * 256 + threadIdx.x;
         if (i >= M) break;
         uint32_t lo = blo, hi = bhi;
-        while (lo < hi) { // last slot with ap_s <= i
-            const uint32_t mid = (lo + hi) >> 1;
-            if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
-        }
         int64_t o = i;
-        if (lo > 0) {
-            const uint32_t sl = lo - 1;
-            if (i < ap_e[sl]) continue; // replaced by the region's seed
-            o += ap_shift_incl[sl];
+        if (staged) {
+            while (lo < hi) { // last slot with ap_s <= i
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_s[mid - b0] <= i) lo = mid + 1; else hi = mid;
+            }
+            if (lo > 0) {
+                if (i < s_e[lo - 1 - b0]) continue; // replaced by the region's seed
+                o += s_sh[lo - 1 - b0];
+            }
+        } else {
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ap_s[mid] <= i) lo = mid + 1; else hi = mid;
+            }
+            if (lo > 0) {
+                const uint32_t sl = lo - 1;
+                if (i < ap_e[sl]) continue;
+                o += ap_shift_incl[sl];
+            }
         }
-        out_pos[o] = in_pos[i];
-        out_base[o] = in_base[i];
+        out_pos[o] = pv[k];
+        out_base[o] = bv[k];
     }
 }
 __device__ __forceinline__ void k_splice_seeds(const uint32_t np2_bid, const uint32_t np2_nb, const uint32_t *__restrict__ ap_g, const uint32_t *__restrict__ ap_s,
