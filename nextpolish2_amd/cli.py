@@ -263,17 +263,22 @@ def main(argv=None):
 
     # Three stages, each on its own threads, a contig moving through them in input order:
     #   front end  (a.thread capped at 2 threads, each with a table-less context and its own BAM handle): BGZF inflate +
-    #              record walk on the host pool, admission, H2D, GPU columnariser -> the contig's pileup resident in HBM;
-    #   polish     (up to 2 contexts sharing ONE copy of the k-mer tables): np2_polish_resident, record formatting;
+    #              record walk (host pool or device), admission, H2D, GPU columnariser -> the contig's pileup resident in HBM;
+    #   polish     (up to 2 workers, each with a batch driver over contexts sharing ONE copy of the k-mer tables): a worker
+    #              takes the next contig in input order AND every following one whose pileup is already resident (up to 16
+    #              contigs / 64 Mb) and polishes them as ONE batch — one launch per pipeline step for all of them
+    #              (np2_batch_polish): the contigs of a many-contig assembly cost a few ms together instead of 2 - 3 ms each;
+    #              a long contig goes alone;
     #   output     (this thread): records written in input order.
     # The k-mer dumps are loaded and their HBM tables built next to the first front ends — a resident pileup does not
     # depend on them —, so a run starts reading alignments at once instead of after the tables (main.rs:1698-1853: the
     # reference's reader / workers / writer threads around two bounded channels).
-    # (two of each: a front end already spreads its inflate over the host pool, and two polish contexts keep the GPU busy
-    # through each other's host phases — measured on the 17-contig 12 Mb assembly: 84 ms with 2 + 2, 109 ms with 3 + 4)
+    # (two of each: a front end already spreads its inflate over the host pool, and two polish workers keep the GPU busy
+    # through each other's host phases)
     # (NP2_CLI_FRONT / NP2_CLI_WORKERS: experiments with other splits; -t beyond 2 keeps 2 + 2, see above)
     n_workers = int(os.environ.get("NP2_CLI_WORKERS", max(1, min(2, a.thread))))
     n_front = int(os.environ.get("NP2_CLI_FRONT", max(1, min(2, a.thread))))
+    BATCH_SLOTS, BATCH_BP = int(os.environ.get("NP2_CLI_BATCH", "16")), 64_000_000
     tls = threading.local()
     base, base_lock = [], threading.Lock()
     yak_pool = ThreadPoolExecutor(max_workers=1)
@@ -306,24 +311,7 @@ def main(argv=None):
             print(f"[np2 profile] {name}: front end {1e3 * (time.time() - t_f):.1f} ms (done at +{time.time() - t0:.3f} s)", file=sys.stderr)
         return c
 
-    def polish(name, fut):
-        """One contig on this worker thread's own context (created on first use): FASTA / table record bytes."""
-        contig = fut.result()
-        try:
-            if getattr(tls, "pol", None) is None:
-                b0 = base_future[0].result()
-                with base_lock:  # one copy of the k-mer tables in HBM: the other workers' contexts share it
-                    tls.pol = b0 if not base else b0.clone()
-                    base.append(tls.pol)
-            t_p = time.time()
-            if prof:
-                tls.pol.set_timing(True)
-            bases, pos = tls.pol.polish_resident(contig, opts, want_pos=a.out_pos)
-            if prof:
-                tm = {k: round(v, 1) for k, v in tls.pol.timings().items() if k.startswith("wall_") and v >= 1.0}
-                print(f"[np2 profile] {name}: polish {1e3 * (time.time() - t_p):.1f} ms (done at +{time.time() - t0:.3f} s); host clock per stage (ms): {tm}", file=sys.stderr)
-        finally:
-            contig.free()
+    def record(name, bases, pos):
         b = bases.tobytes()
         if a.uppercase:
             b = b.upper()
@@ -331,8 +319,66 @@ def main(argv=None):
             return b"".join(b"%s\t%c\t%d\n" % (name.encode(), b[i:i + 1], int(pos[i])) for i in range(len(b)))
         return b">%s start:%d end:%d\n%s\n" % (name.encode(), pos[0], pos[1], b)
 
+    from collections import deque
+    from concurrent.futures import Future
+    from .api import BatchPolisher
+    todo, todo_cv = deque(), threading.Condition()  # (name, length, front-end future, result future) in input order
+    closing = []
+
+    def polish_worker():
+        """takes the head of `todo` and every following contig that is already resident; one batch per turn"""
+        while True:
+            with todo_cv:
+                while not todo and not closing:
+                    todo_cv.wait()
+                if not todo:
+                    return
+                items = [todo.popleft()]
+            contigs = []
+            try:
+                contigs.append(items[0][2].result())  # (waits for the head's front end)
+                with todo_cv:
+                    bp = items[0][1]
+                    while todo and len(items) < BATCH_SLOTS and todo[0][2].done() and bp + todo[0][1] <= BATCH_BP:
+                        items.append(todo.popleft())
+                        bp += items[-1][1]
+                for it in items[1:]:
+                    contigs.append(it[2].result())
+                if getattr(tls, "batch", None) is None:
+                    b0 = base_future[0].result()
+                    with base_lock:  # one copy of the k-mer tables in HBM: the other worker's contexts share it
+                        tls.pol = b0 if not base else b0.clone()
+                        base.append(tls.pol)
+                    t_b = time.time()
+                    tls.batch = BatchPolisher(tls.pol, BATCH_SLOTS)
+                    if prof:
+                        print(f"[np2 profile] polish worker: batch driver with {BATCH_SLOTS} slot contexts {1e3 * (time.time() - t_b):.1f} ms", file=sys.stderr)
+                t_p = time.time()
+                res = tls.batch.polish(contigs, opts, want_pos=a.out_pos)
+                if prof:
+                    print(f"[np2 profile] {', '.join(it[0] for it in items)}: polished as one batch in {1e3 * (time.time() - t_p):.1f} ms "
+                          f"(done at +{time.time() - t0:.3f} s)", file=sys.stderr)
+                for it, (bases, pos) in zip(items, res):
+                    it[3].set_result(record(it[0], bases, pos))
+            except BaseException as e:  # (the writer re-raises it in input order)
+                for it in items:
+                    if not it[3].done():
+                        it[3].set_exception(e)
+                for it in items[len(contigs):]:  # front ends nobody waited for yet
+                    try:
+                        contigs.append(it[2].result())
+                    except BaseException:
+                        pass
+            finally:
+                for c in contigs:
+                    c.free()
+
+    workers = []
     try:
-        with ThreadPoolExecutor(max_workers=n_front) as fpool, ThreadPoolExecutor(max_workers=n_workers) as pool:
+        with ThreadPoolExecutor(max_workers=n_front) as fpool:
+            workers = [threading.Thread(target=polish_worker, name=f"np2-polish-{w}", daemon=True) for w in range(n_workers)]
+            for w in workers:
+                w.start()
             pending, pending_len = [], []  # records in input order: bytes or futures; the contigs' lengths
 
             def drain(keep):
@@ -341,28 +387,40 @@ def main(argv=None):
                     pending_len.pop(0)
                     out.write(rec if isinstance(rec, bytes) else rec.result())
 
-            for name, seq in np2io.read_fasta(a.fa):
-                if len(seq) >= 0xFFFFFFFF:
-                    raise SystemExit(f"{name} is too long!")
-                if len(seq) < a.min_ctg_len:  # pass-through (main.rs:1727-1730)
-                    s = seq.upper() if a.uppercase else seq
-                    if a.out_pos:
-                        pending.append(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
+            try:
+                for name, seq in np2io.read_fasta(a.fa):
+                    if len(seq) >= 0xFFFFFFFF:
+                        raise SystemExit(f"{name} is too long!")
+                    if len(seq) < a.min_ctg_len:  # pass-through (main.rs:1727-1730)
+                        s = seq.upper() if a.uppercase else seq
+                        if a.out_pos:
+                            pending.append(b"".join(b"%s\t%c\t%d\n" % (name.encode(), s[i:i + 1], i) for i in range(len(s))))
+                        else:
+                            pending.append(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
+                        pending_len.append(len(seq))
                     else:
-                        pending.append(b">%s start:0 end:%d\n%s\n" % (name.encode(), len(seq) - 1, s))
-                    pending_len.append(len(seq))
-                else:
-                    if not base_future:  # the first contig to polish: tables into HBM next to its front end
-                        base_future.append(yak_pool.submit(build_base))
-                    pending.append(pool.submit(polish, name, fpool.submit(front, name, seq)))
-                    pending_len.append(len(seq))
-                # bounded look-ahead: that many contigs held in memory at most — and, for long contigs, at most ~2 Gb of
-                # contig in flight (a resident 30x pileup is ~16 bytes per base of HBM: three chromosomes, not six)
-                keep = 2 * n_workers + n_front
-                while keep > 1 and sum(pending_len[-keep:]) > 2_000_000_000:
-                    keep -= 1
-                drain(keep)
-            drain(0)
+                        if not base_future:  # the first contig to polish: tables into HBM next to its front end
+                            base_future.append(yak_pool.submit(build_base))
+                        res = Future()
+                        with todo_cv:
+                            todo.append((name, len(seq), fpool.submit(front, name, seq), res))
+                            todo_cv.notify()
+                        pending.append(res)
+                        pending_len.append(len(seq))
+                    # bounded look-ahead: that many contigs held in memory at most — and at most ~2 Gb of contig in flight
+                    # (a resident 30x pileup is ~16 bytes per base of HBM: three chromosomes, not six); short contigs may
+                    # queue up to fill the workers' batches
+                    keep = n_workers * BATCH_SLOTS + n_front
+                    while keep > 1 and sum(pending_len[-keep:]) > 2_000_000_000:
+                        keep -= 1
+                    drain(keep)
+                drain(0)
+            finally:
+                with todo_cv:
+                    closing.append(True)
+                    todo_cv.notify_all()
+                for w in workers:
+                    w.join()
             out.flush()
             if prof:
                 print(f"[np2 profile] last record written at +{time.time() - t0:.3f} s", file=sys.stderr)

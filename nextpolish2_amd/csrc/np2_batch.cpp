@@ -372,15 +372,16 @@ int np2_batch_create(np2_batch_t **out, np2_ctx_t *parent, int n_slots) {
     try {
         HIPCHK(hipSetDevice(b->device));
         HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-        HIPCHK(hipHostMalloc((void **)&b->done_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
-        *b->done_host = 0;
+        // one host-mapped block: the completion word of the flushes, then a 64-word mailbox per slot
+        HIPCHK(hipHostMalloc((void **)&b->done_host, 256 * (size_t)(n_slots + 1), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(b->done_host, 0, 256 * (size_t)(n_slots + 1));
         HIPCHK(hipHostGetDevicePointer((void **)&b->done_dev, b->done_host, 0));
         b->recs.resize(n_slots);
         b->jobs.resize(n_slots);
         for (int i = 0; i < n_slots; ++i) {
-            np2_ctx *cx = nullptr;
-            int rc = np2_ctx_create_shared(&cx, parent);
-            if (rc) throw Np2Error(rc, "np2_ctx_create_shared failed");
+            // (a slot only records commands: it takes the batch's stream and a piece of its mailbox block instead of three
+            // streams and a pinned block of its own)
+            np2_ctx *cx = ctx_create_slot(parent, b->stream, b->done_host + 64 * (size_t)(i + 1), b->done_dev + 64 * (size_t)(i + 1));
             b->slots.push_back(cx);
             b->recs[i].group = b;
             b->recs[i].slot = i;
@@ -407,7 +408,10 @@ void np2_batch_destroy(np2_batch_t *b) {
     for (auto &t : b->workers) t.join();
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (np2_ctx *cx : b->slots) np2_ctx_destroy(cx);
+    {
+        DevSyncScope idle; // (one wait for the device, not one per slot)
+        for (np2_ctx *cx : b->slots) np2_ctx_destroy(cx);
+    }
     for (auto &e : b->diff_events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -431,6 +435,7 @@ int np2_batch_set_priority(np2_batch_t *b, int high) {
         HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
         (void)hipStreamDestroy(b->stream);
         b->stream = s;
+        for (np2_ctx *cx : b->slots) ctx_slot_set_stream(cx, s);
     } catch (const Np2Error &e) {
         b->err = e.what();
         return e.code;

@@ -212,8 +212,10 @@ inline int &dev_sync_depth() {
 }
 struct DevSyncScope {
     DevSyncScope() {
-        SlowCall sc("hipDeviceSynchronize (release scope)");
-        (void)hipDeviceSynchronize();
+        if (dev_sync_depth() == 0) { // (an enclosing scope has drained the device already: a batch driver releasing its slots)
+            SlowCall sc("hipDeviceSynchronize (release scope)");
+            (void)hipDeviceSynchronize();
+        }
         ++dev_sync_depth();
     }
     ~DevSyncScope() { --dev_sync_depth(); }
@@ -474,6 +476,10 @@ struct np2_ctx {
     PinnedBuf pin_d2h, pin_h2d;
     uint32_t *mbox_host = nullptr, *mbox_dev = nullptr; // host-mapped scalar mailbox: [0] = sequence, [1..] = scal
     uint32_t mbox_seq = 0;
+    // a batch driver's slot context: its three stream handles are the batch's ONE stream and its mailbox a piece of the
+    // batch's host-mapped block (a slot only records commands; making three streams and a pinned block per slot cost
+    // 10 - 16 ms each in a fresh process: 250 ms for a 16-slot driver)
+    bool borrowed_state = false;
     uint32_t last_first_pos = 0, last_last_pos = 0;
     const uint8_t *last_dbase = nullptr; // device copy of the last polished sequence (valid until the next call)
     const uint32_t *last_dpos = nullptr; // ... and of its positions
@@ -673,6 +679,8 @@ inline void recorder_sync(Recorder *r) {
 // The commands recorded so far are to be issued (with the rest of the batch group's), but the caller goes on with host
 // work that does not need their results: no wait for the device, nothing released.  Without a recorder the launches
 // went straight to the stream: nothing to do.
+np2_ctx *ctx_create_slot(np2_ctx *parent, hipStream_t s, uint32_t *mbox_host, uint32_t *mbox_dev); // (np2_host.cpp)
+void ctx_slot_set_stream(np2_ctx *cx, hipStream_t s);
 inline void op_submit(np2_ctx *cx) {
     (void)cx;
     if (Recorder *r = tl_recorder()) r->sync_fn(r, false);

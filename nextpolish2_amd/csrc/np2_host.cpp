@@ -1664,6 +1664,15 @@ static void destroy_streams(np2_ctx *cx) {
         cx->out_host[i] = nullptr;
         cx->out_host_cap[i] = 0;
     }
+    if (cx->borrowed_state) { // (streams and mailbox are the batch driver's)
+        if (cx->ev_out) (void)hipEventDestroy(cx->ev_out);
+        if (cx->ev_fork) (void)hipEventDestroy(cx->ev_fork);
+        if (cx->ev_join) (void)hipEventDestroy(cx->ev_join);
+        cx->stream = cx->stream2 = cx->stream_out = nullptr;
+        cx->ev_out = cx->ev_fork = cx->ev_join = nullptr;
+        cx->mbox_host = cx->mbox_dev = nullptr;
+        return;
+    }
     CtxDeviceState st;
     st.stream = cx->stream, st.stream2 = cx->stream2, st.stream_out = cx->stream_out;
     st.ev_out = cx->ev_out, st.ev_fork = cx->ev_fork, st.ev_join = cx->ev_join;
@@ -1683,7 +1692,7 @@ static void destroy_streams(np2_ctx *cx) {
 }
 
 // streams, events, mailbox: everything of a context but its k-mer tables
-static void init_ctx_device(np2_ctx *cx, int device) {
+static void init_ctx_device(np2_ctx *cx, int device, hipStream_t borrow = nullptr, uint32_t *mbox_host = nullptr, uint32_t *mbox_dev = nullptr) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         throw Np2Error(NP2_E_DEVICE, "no HIP device available (the np2 hot path has no CPU fallback)");
@@ -1692,7 +1701,14 @@ static void init_ctx_device(np2_ctx *cx, int device) {
     cx->hooks.read();
     HIPCHK(hipSetDevice(device));
     CtxDeviceState st;
-    if (ctx_state_pool().get(device, st)) {
+    if (borrow) {
+        cx->borrowed_state = true;
+        cx->stream = cx->stream2 = cx->stream_out = borrow;
+        cx->mbox_host = mbox_host, cx->mbox_dev = mbox_dev;
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_out, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cx->ev_join, hipEventDisableTiming));
+    } else if (ctx_state_pool().get(device, st)) {
         cx->stream = st.stream, cx->stream2 = st.stream2, cx->stream_out = st.stream_out;
         cx->ev_out = st.ev_out, cx->ev_fork = st.ev_fork, cx->ev_join = st.ev_join;
         cx->mbox_host = st.mbox_host, cx->mbox_dev = st.mbox_dev;
@@ -1794,6 +1810,26 @@ int np2_ctx_create_shared(np2_ctx_t **out, np2_ctx_t *parent) {
     *out = cx;
     return NP2_OK;
 }
+
+} // extern "C"
+// a batch driver's slot: the tables shared with `parent`, the stream and the mailbox the driver's (np2_batch.cpp)
+np2_ctx *np2h::ctx_create_slot(np2_ctx *parent, hipStream_t s, uint32_t *mbox_host, uint32_t *mbox_dev) {
+    np2_ctx *cx = new np2_ctx();
+    try {
+        init_ctx_device(cx, parent->device, s, mbox_host, mbox_dev);
+        cx->yaks = parent->yaks;
+        cx->tile_cap = parent->tile_cap;
+    } catch (...) {
+        destroy_streams(cx);
+        delete cx;
+        throw;
+    }
+    return cx;
+}
+void np2h::ctx_slot_set_stream(np2_ctx *cx, hipStream_t s) {
+    if (cx->borrowed_state) cx->stream = cx->stream2 = cx->stream_out = s;
+}
+extern "C" {
 
 void np2_ctx_destroy(np2_ctx_t *cx) {
     if (!cx) return;

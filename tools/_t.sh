@@ -1,7 +1,6 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_parity.py tests/test_gpu_loose_ends.py -x -q 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats -d gpurun_out/kt1 -o kt --output-format csv -- python bench.py --no-cpu-baseline --no-end-to-end --no-exclusive --repeats 1 --steps 10 --warmup 2 --groups 1 > gpurun_out/kt1.log 2>&1
-python tools/kstats.py gpurun_out/kt1/kt_kernel_stats.csv 12 | grep -E "k_splice|k_copy|total"
-rm -rf gpurun_out/kt1
+timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_frontend.py tests/test_ref_bundle.py tests/test_gpu_inflate.py tests/test_gpu_dist.py -x -q 2>&1 | tail -3
+NP2_CLI_PROFILE=1 timeout 300 python tools/cli_probe.py > gpurun_out/cli_batch.log 2>&1
+grep -E "^-t|batch driver|last record|contexts released" gpurun_out/cli_batch.log | head -40
+for b in 8 16; do echo "NP2_CLI_BATCH=$b"; NP2_CLI_BATCH=$b timeout 300 python tools/cli_probe.py 2>&1 | grep "^-t"; done
 python bench.py --no-cpu-baseline --no-end-to-end --no-exclusive 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('ms_per_step_regions'))"
