@@ -334,16 +334,26 @@ def main(argv=None):
                 if not todo:
                     return
                 items = [todo.popleft()]
-            contigs = []
             try:
-                contigs.append(items[0][2].result())  # (waits for the head's front end)
-                with todo_cv:
-                    bp = items[0][1]
-                    while todo and len(items) < BATCH_SLOTS and todo[0][2].done() and bp + todo[0][1] <= BATCH_BP:
-                        items.append(todo.popleft())
-                        bp += items[-1][1]
-                for it in items[1:]:
+                items[0][2].exception()  # (waits for the head's front end)
+            except BaseException:
+                pass
+            with todo_cv:
+                bp = items[0][1]
+                while todo and len(items) < BATCH_SLOTS and todo[0][2].done() and bp + todo[0][1] <= BATCH_BP:
+                    items.append(todo.popleft())
+                    bp += items[-1][1]
+            live, contigs = [], []
+            for it in items:  # a contig whose front end failed reports that, in its place of the output order
+                e = it[2].exception()
+                if e is not None:
+                    it[3].set_exception(e)
+                else:
+                    live.append(it)
                     contigs.append(it[2].result())
+            try:
+                if not live:
+                    continue
                 if getattr(tls, "batch", None) is None:
                     b0 = base_future[0].result()
                     with base_lock:  # one copy of the k-mer tables in HBM: the other worker's contexts share it
@@ -354,21 +364,30 @@ def main(argv=None):
                     if prof:
                         print(f"[np2 profile] polish worker: batch driver with {BATCH_SLOTS} slot contexts {1e3 * (time.time() - t_b):.1f} ms", file=sys.stderr)
                 t_p = time.time()
-                res = tls.batch.polish(contigs, opts, want_pos=a.out_pos)
+                try:
+                    res = tls.batch.polish(contigs, opts, want_pos=a.out_pos)
+                except Exception:
+                    if len(contigs) == 1:
+                        raise
+                    # one contig of the batch failed: each on its own, so that the records before the failing one (in input
+                    # order) are still written, as when every contig was polished by itself
+                    res = []
+                    for it, c in zip(live, contigs):
+                        try:
+                            res.append(tls.batch.polish([c], opts, want_pos=a.out_pos)[0])
+                        except Exception as e1:
+                            it[3].set_exception(e1)
+                            res.append(None)
                 if prof:
-                    print(f"[np2 profile] {', '.join(it[0] for it in items)}: polished as one batch in {1e3 * (time.time() - t_p):.1f} ms "
+                    print(f"[np2 profile] {', '.join(it[0] for it in live)}: polished as one batch in {1e3 * (time.time() - t_p):.1f} ms "
                           f"(done at +{time.time() - t0:.3f} s)", file=sys.stderr)
-                for it, (bases, pos) in zip(items, res):
-                    it[3].set_result(record(it[0], bases, pos))
+                for it, r in zip(live, res):
+                    if r is not None:
+                        it[3].set_result(record(it[0], r[0], r[1]))
             except BaseException as e:  # (the writer re-raises it in input order)
-                for it in items:
+                for it in live:
                     if not it[3].done():
                         it[3].set_exception(e)
-                for it in items[len(contigs):]:  # front ends nobody waited for yet
-                    try:
-                        contigs.append(it[2].result())
-                    except BaseException:
-                        pass
             finally:
                 for c in contigs:
                     c.free()

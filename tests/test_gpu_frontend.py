@@ -228,6 +228,39 @@ def test_cli_many_contigs_concurrent_contexts(tmp_path):
         assert b">c%d start:%d end:%d\n%s\n" % (tid, p[0], p[-1], b.tobytes()) in outs[0]
 
 
+def test_cli_failing_contig_in_the_middle_of_an_assembly(tmp_path):
+    """-S with a secondary record whose read has no primary on the SECOND of three contigs (the reference panics on the map
+    lookup there): the run fails, and the first contig's record — polished in the same batch turn or not — is the one a
+    run over that contig alone writes."""
+    from test_oracle import yak_from_seqs
+    syn = [Synth(30000, depth=15, seed=700 + i, read_len_mean=5000.0, read_len_sd=700.0, name=f"c{i}") for i in range(3)]
+    recs = []
+    for i, s in enumerate(syn):
+        recs += pileup_to_records(s.pileup, tid=i, rng=np.random.default_rng(710 + i), decorate=False)
+    good = sorted(recs, key=lambda r: (r["tid"], r["pos"]))
+    prim1 = [r for r in recs if r["tid"] == 1][-1]
+    bad = sorted(recs + [dict(prim1, flag=0x100, seq="", name=b"nobody")], key=lambda r: (r["tid"], r["pos"]))
+    refs = [(f"c{i}", s.pileup.L) for i, s in enumerate(syn)]
+    write_bam(str(tmp_path / "good.bam"), refs, good)
+    write_bam(str(tmp_path / "bad.bam"), refs, bad)
+    with open(tmp_path / "g.fa", "w") as f:
+        for i, s in enumerate(syn):
+            f.write(f">c{i}\n{s.pileup.ref.tobytes().decode()}\n")
+    np2io.write_yak(str(tmp_path / "k21.yak"), yak_from_seqs([s.hap1.decode() for s in syn], 21))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda bam, out: subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-S", "-t", "2", "-L", "10000", "-o", str(out), str(bam),
+                                           str(tmp_path / "g.fa"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
+    r = run(tmp_path / "good.bam", tmp_path / "good.fa")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = (tmp_path / "good.fa").read_bytes()
+    assert want.count(b">") == 3
+    r = run(tmp_path / "bad.bam", tmp_path / "bad.fa")
+    assert r.returncode != 0
+    got = (tmp_path / "bad.fa").read_bytes() if (tmp_path / "bad.fa").exists() else b""
+    first = want[:want.index(b">c1")]
+    assert got == first, (len(got), len(first))
+
+
 def test_command_line_on_a_whole_assembly_bam_equals_the_batch_driver(tmp_path):
     # bench.py's end_to_end_assembly leg at a small scale: BAM written from the generator's records, the CLI's code
     # path in process, output compared with the resident pileups polished through the batch driver

@@ -1,13 +1,18 @@
-import os, sys, time
-sys.path.insert(0, os.getcwd())
-from nextpolish2_amd import Opts, Polisher
+"""Host side of the phasing vote on a yeast-chromosome-sized diploid contig (run on a GPU box): NP2_PHASE_PROFILE marks
++ the stage clocks.  python tools/vote_small_probe.py [L]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["NP2_PHASE_PROFILE"] = "1"
 from nextpolish2_amd.synth import Synth
-s = Synth(1531933, depth=30, seed=104, diploid=True, name="chr4")
-yaks = [s.yak(21), s.yak(31)]
-pol = Polisher(yaks)
+from nextpolish2_amd import Polisher
+from nextpolish2_amd._types import Opts
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 1531933
+s = Synth(L, depth=30, seed=4, diploid=True)
+pol = Polisher([s.yak(21), s.yak(31)])
 c = pol.upload(s.pileup)
 pol.set_timing(True)
-for i in range(3):
-    t = time.time(); b, span = pol.polish_resident(c, Opts(), want_pos=False); dt = time.time() - t
-    tm = pol.timings()
-    print(f"polish {dt*1e3:.2f} ms; wall_louvain {tm.get('wall_louvain', 0.0):.2f} ms", flush=True)
+for rep in range(4):
+    print(f"--- polish {rep}", file=sys.stderr, flush=True)
+    pol.polish_resident(c, Opts())
+    tm = {k: round(v, 2) for k, v in pol.timings().items() if k.startswith("wall_")}
+    print(tm, file=sys.stderr, flush=True)
