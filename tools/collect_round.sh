@@ -21,4 +21,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/inf_pw -o w --output-for
 python tools/pmc_summary.py gpurun_out/inf_pf/f_counter_collection.csv gpurun_out/inf_pw/w_counter_collection.csv > gpurun_out/${R}_inflate_pmc_fetch_write.json 2>&1; rm -rf gpurun_out/inf_pf gpurun_out/inf_pw
 NP2_CLI_PROFILE=1 timeout 300 python tools/cli_probe.py > gpurun_out/${R}_cli_assembly_probe.log 2>&1
 python tools/pf_prof.py > gpurun_out/${R}_pf_tile_phases.txt 2>&1
+timeout 600 python tools/cli_split_probe.py > gpurun_out/${R}_cli_split_probe.log 2>&1
+for c in 0-1 0-3 0-7 0-15; do LOCAL_WORLD_SIZE=8 taskset -c $c python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-exclusive 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('taskset -c $c, LOCAL_WORLD_SIZE=8 (waits nap):', d['value'], 'Mbp/s,', d['ms_per_step'], 'ms per step (median', d['ms_per_step_regions']['median'], '), host CPUs busy', d['host_cpu']['cpu_seconds_per_wall_second'])"; done > gpurun_out/${R}_rank_cpu_budget.txt 2>&1
+for g in 4 5 6 8; do python bench.py --no-cpu-baseline --no-end-to-end --no-exclusive --groups $g 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('--groups $g:', d['value'], 'Mbp/s,', d['ms_per_step'], 'ms per step; per-group call ms', d['flush_ms']['call_breakdown_ms_per_group']['caller_clock'])"; done > gpurun_out/${R}_group_counts.txt 2>&1
+timeout 300 python tools/vote_small_probe.py 2>&1 | tail -18 > gpurun_out/${R}_vote_host_yeast_chromosome.txt
 ls gpurun_out | grep "^${R}_" | head -80
