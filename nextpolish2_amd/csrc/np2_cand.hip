@@ -793,6 +793,41 @@ __device__ __forceinline__ void k_cand_offsets_lb(const uint32_t np2_bid, const 
     }
 }
 
+// Merge rule of the raw LQ regions (main.rs:1613-1615: region j merges into j - 1 iff end_j >= start_{j-1}): head flags and
+// their exclusive scan.  The number of raw regions lives on the device, so the grid is a FIXED handful of blocks that
+// split whatever it turns out to be into equal stretches: a block counts its stretch's heads, the blocks chain their
+// counts (a look-back over at most MERGE_LB_BLOCKS predecessors: one round), then it scans and writes its stretch.
+// (One block of 1024 threads walking the whole array — a contig's 10^4 - 10^5 regions, 1024 at a time with a block scan
+// each — was 25 - 29 us per pass, 4 % of a bacterial contig's step.)
+static constexpr uint32_t MERGE_LB_BLOCKS = 32;
+__device__ __forceinline__ void k_lq_merge_scan_lb(const uint32_t np2_bid, const uint32_t np2_nb, Lookback lb, const uint32_t *__restrict__ raw_start,
+                                                   const uint32_t *__restrict__ raw_end, const uint32_t *__restrict__ n_raw, uint32_t n_host,
+                                                   uint32_t *__restrict__ headflag, uint32_t *__restrict__ hidx, uint32_t *__restrict__ err) {
+    __shared__ uint32_t sh[16];
+    const uint32_t bid = lb_block_id(lb, sh);
+    const uint32_t n = min(*n_raw, n_host);
+    const uint32_t seg = ((n + MERGE_LB_BLOCKS - 1) / MERGE_LB_BLOCKS + 1023u) & ~1023u; // a multiple of the block's width
+    const uint32_t lo = min(bid * seg, n), hi = min(lo + seg, n);
+    auto flag = [&](uint32_t j) { return (j >= 1 && raw_end[j] >= raw_start[j - 1]) ? 0u : 1u; };
+    uint32_t cnt = 0;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) cnt += flag(j);
+    uint32_t total, pre, dummy;
+    (void)block_excl_scan<OpAdd, 16>(cnt, sh, total);
+    lb_exclusive2(lb, bid, total, 0u, sh, err, pre, dummy);
+    uint32_t carry = pre;
+    for (uint32_t j0 = lo; j0 < hi; j0 += 1024) { // (uniform)
+        const uint32_t j = j0 + threadIdx.x;
+        const uint32_t v = j < hi ? flag(j) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<OpAdd, 16>(v, sh, tot);
+        if (j < hi) {
+            hidx[j] = carry + ex;
+            headflag[j] = v;
+        }
+        carry += tot;
+    }
+}
+
 // Second pass, once the offsets are known: order, string offset, string and first k-mer of every kept candidate.  One
 // wavefront per region (four regions per wavefront, one after the other), one lane per kept candidate (at most 60).  The
 // candidates that are the contig's own string (kept_col == CAND_CLEAN) copy it from LDS, where the region's wavefront
@@ -966,6 +1001,11 @@ void launch_cand_offsets(hipStream_t s, const uint32_t *blk_sum, uint32_t n_reg,
     else
         NP2_LAUNCH(k_cand_offsets, dim3(1), 1024, s, blk_sum, (n_reg + 3) / 4, n_reg, blk_coff, blk_soff, cand_off, reg_soff, n_cand, n_bytes, grow);
 }
+void launch_lq_merge_scan_lb(hipStream_t s, const Lookback &lb, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                             uint32_t n_host, uint32_t *headflag, uint32_t *hidx, uint32_t *err) {
+    NP2_LAUNCH(k_lq_merge_scan_lb, dim3(MERGE_LB_BLOCKS), 1024, s, lb, raw_start, raw_end, n_raw, n_host, headflag, hidx, err);
+}
+uint32_t lq_merge_lb_blocks() { return MERGE_LB_BLOCKS; }
 void launch_region_write(hipStream_t s, const CandPtrs &c, uint32_t n_reg, const uint32_t *kept_read,
                          const uint32_t *kept_len, const uint32_t *kept_col, const uint32_t *reg_ncand,
                          const uint32_t *reg_bytes, const uint32_t *blk_coff, const uint32_t *blk_soff, uint32_t *cand_off,

@@ -867,7 +867,8 @@ void lq_regions_issue(np2_ctx *cx, const CnsBounds &b, const uint32_t *M_p, cons
                         cx->scal.p + S_ERR);
     launch_scatter_regions(s, cx->hbits.p, b.n_words, cx->ridx.p, cx->rstart.p, cx->rend.p, cx->raw_start.p,
                            cx->raw_end.p, cx->scal.p + S_NRAW);
-    launch_lq_merge_scan(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, b.M_cap, cx->headflag.p, cx->hidx.p);
+    launch_lq_merge_scan_lb(s, next_lookback(cx, lq_merge_lb_blocks()), cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, b.M_cap,
+                            cx->headflag.p, cx->hidx.p, cx->scal.p + S_ERR);
     // (the merged regions written by the single-block scan kernel itself measured slower: 52 + 15 -> 95 us per step)
     launch_lq_merge_write(s, cx->raw_start.p, cx->raw_end.p, cx->scal.p + S_NRAW, cx->headflag.p, cx->hidx.p,
                           cx->lq_start.p, cx->lq_end.p, cx->scal.p + S_NREG);

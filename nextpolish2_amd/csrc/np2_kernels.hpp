@@ -142,6 +142,9 @@ void launch_default_tail(hipStream_t s, const GraphPtrs &gp, const uint32_t *bes
 void launch_lq_scan(hipStream_t s, const uint32_t *cns_pos, const uint8_t *cns_base, const uint8_t *cns_cls,
                     const uint32_t *M_p, const uint32_t *lq_list, const uint32_t *n_lq, uint32_t lq_cap, uint8_t *lq_kind,
                     uint32_t *lq_next, uint8_t *lq_nothead, uint32_t *hbits, uint32_t n_hwords, uint32_t *rstart, uint32_t *rend);
+void launch_lq_merge_scan_lb(hipStream_t s, const Lookback &lb, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw,
+                             uint32_t n_host, uint32_t *headflag, uint32_t *hidx, uint32_t *err);
+uint32_t lq_merge_lb_blocks();
 void launch_lq_merge_scan(hipStream_t s, const uint32_t *raw_start, const uint32_t *raw_end, const uint32_t *n_raw, uint32_t n_host,
                           uint32_t *headflag, uint32_t *hidx);
 // exclusive sums of popcount(bits[w]), w < n_words, into out[0 .. n_words] (out[n_words] = the total)
