@@ -2,9 +2,11 @@
 
 Usage: nextPolish2 [OPTIONS] <HiFi.map.bam> <genome.fa[.gz]> <short.read.yak>...
 Same positionals, flags, defaults and output format as the reference; contigs are polished on the GPU and written in
-input order.  `-t N` (N >= 2) keeps two front ends (BGZF inflate on the host pool, GPU columnariser) and two polish
-contexts going side by side: the host-side phases of one contig (BAM parsing, the phasing vote's Louvain) overlap the
-GPU phases of another; the k-mer dumps are streamed into their HBM tables next to the first front ends."""
+input order.  `-t N` (N >= 2) keeps two front ends (BGZF inflate + record walk on the host pool or the device, GPU
+columnariser) and two polish workers going side by side; a worker polishes the contigs that are resident by its turn as
+ONE batch (np2_batch_polish: one launch per pipeline step for all of them), and the host-side phases of one batch (the
+phasing vote's Louvain) overlap the GPU phases of the other; the k-mer dumps are streamed into their HBM tables next to
+the first front ends."""
 import argparse
 import os
 import resource
