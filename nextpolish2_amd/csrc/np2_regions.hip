@@ -572,8 +572,8 @@ __device__ __forceinline__ void k_seed(const uint32_t np2_bid0, const uint32_t n
 // Searches in the (multi-megabyte) consensus position array are latency chains: a binary search is ~22 dependent
 // loads.  Probe 16 evenly spaced points per round instead (independent loads, one round trip): 6 rounds for 4.6 M.
 template <bool UPPER>
-__device__ __forceinline__ uint32_t bound16_u32(const uint32_t *__restrict__ a, uint32_t n, uint32_t v) {
-    uint32_t lo = 0, hi = n; // the answer lies in [lo, hi]
+__device__ __forceinline__ uint32_t bound16_u32(const uint32_t *__restrict__ a, uint32_t n, uint32_t v, uint32_t lo0 = 0) {
+    uint32_t lo = lo0, hi = n; // the answer lies in [lo, hi]
     while (lo < hi) {
         const uint32_t step = (hi - lo + 15) >> 4;
         uint32_t x[16]; // unconditional (clamped) loads: all 16 are in flight together
@@ -609,7 +609,16 @@ __device__ __forceinline__ void k_splice_find(const uint32_t np2_bid, const uint
     const uint32_t s = lower_bound_u32(cns_pos, M, lq_start[g]);
     const bool found = s < M && cns_pos[s] == lq_start[g];
     idx_s[g] = s;
-    idx_e[g] = found ? max(s, upper_bound_u32(cns_pos, M, lq_end[g])) : s;
+    // (the region's end lies a region's length behind its start: one or two rounds over that stretch instead of six over the
+    // whole consensus, whenever the element that closes the stretch is already past the end)
+    uint32_t e = s;
+    if (found) {
+        const uint32_t en = lq_end[g];
+        const uint32_t near = (uint32_t)min((uint64_t)M, (uint64_t)s + (en - lq_start[g]) + 65u);
+        e = (near == M || cns_pos[near - 1] > en) ? bound16_u32<true>(cns_pos, near, en, s) : upper_bound_u32(cns_pos, M, en);
+        e = max(s, e);
+    }
+    idx_e[g] = e;
     if (!found) atomicMax(stuck, g + 1);
 }
 static constexpr uint32_t LB_REG_ITEMS = 4; // regions per thread of the look-back compaction kernels
@@ -757,13 +766,14 @@ __device__ __forceinline__ void k_splice_seeds(const uint32_t np2_bid, const uin
                                const uint32_t *__restrict__ seed_cand, const uint32_t *__restrict__ seq_off,
                                const uint8_t *__restrict__ seq, uint32_t *__restrict__ out_pos,
                                uint8_t *__restrict__ out_base) {
-    uint32_t sl = np2_bid * blockDim.x + threadIdx.x;
+    // eight lanes per applied region (a seed string is a few dozen bases: one or two rounds of stores instead of a serial walk)
+    const uint32_t sl = (np2_bid * blockDim.x + threadIdx.x) >> 3, q = threadIdx.x & 7u;
     if (sl >= *n_ap_p) return;
     const uint32_t g = ap_g[sl], c = seed_cand[g];
     const uint32_t so = seq_off[c], len = seq_off[c + 1] - so;
     const int64_t o = (int64_t)ap_s[sl] + (ap_shift_incl[sl] - ap_delta[sl]);
     const uint32_t p = lq_start[g];
-    for (uint32_t t = 0; t < len; ++t) { // spliced bases all carry pos == start (main.rs:1039-1045)
+    for (uint32_t t = q; t < len; t += 8) { // spliced bases all carry pos == start (main.rs:1039-1045)
         out_pos[o + t] = p;
         out_base[o + t] = seq[so + t];
     }
@@ -1180,7 +1190,7 @@ void launch_splice_write(hipStream_t s, const uint32_t *in_pos, const uint8_t *i
                          uint8_t *out_base) {
     NP2_LAUNCH(k_splice_bases, dim3((M_cap + SPLICE_SPAN - 1) / SPLICE_SPAN), 256, s, in_pos, in_base, M_p, ap_s, ap_e, ap_shift_incl, n_ap, out_pos, out_base);
     if (max_ap)
-        NP2_LAUNCH(k_splice_seeds, g1(max_ap, 64), 64, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap, lq_start, seed_cand, seq_off, seq, out_pos, out_base);
+        NP2_LAUNCH(k_splice_seeds, g1((uint64_t)max_ap * 8, 256), 256, s, ap_g, ap_s, ap_delta, ap_shift_incl, n_ap, lq_start, seed_cand, seq_off, seq, out_pos, out_base);
 }
 void launch_shard_bounds(hipStream_t s, const uint32_t *cns_pos, const uint32_t *M_p, const uint32_t *t, uint32_t *out) {
     NP2_LAUNCH(k_shard_bounds, dim3(1), 64, s, cns_pos, M_p, t[0], t[1], t[2], t[3], t[4], t[5], out);
