@@ -84,59 +84,65 @@ def write_bam_straddling(path, refs, records, limit, level):
         f.write(out)
 
 
-rng = np.random.default_rng(int(sys.argv[1])); n_files = int(sys.argv[2]); bad = n_ctg = 0
-td = tempfile.mkdtemp()
-pol = Polisher([Synth(2000, seed=3).yak(21)])
-t0 = time.time()
-for case in range(n_files):
-    n_ref = int(rng.integers(1, 6))
-    syn, recs, refs = [], [], []
-    for tid in range(n_ref):
-        L = int(rng.choice([2500, 9000, 20000, 50000]))
-        seed = int(rng.integers(1, 1 << 30)); rl = float(rng.choice([1500, 4000, 9000]))
-        s = Synth(L, depth=int(rng.choice([3, 10, 30])), seed=seed, diploid=bool(rng.integers(0, 2)), read_err_rate=float(rng.choice([0.002, 0.02])),
-                  read_len_mean=min(rl, L / 2), read_len_sd=rl / 6, read_len_min=min(1000, L // 4), name=f"c{tid}")
-        syn.append(s)
-        refs.append((f"c{tid}", s.pileup.L))
-        if rng.random() < 0.9:  # (a reference without any record now and then)
-            recs += pileup_to_records(s.pileup, tid=tid, rng=np.random.default_rng(seed), decorate=True)
-    recs.sort(key=lambda r: (r["tid"], r["pos"]))
-    path = os.path.join(td, f"f{case}.bam")
-    write_bam_straddling(path, refs, recs, int(rng.choice([300, 4096, 20000, 0xff00])), int(rng.integers(0, 10)))
-    fo = np2io.FrontOpts(use_supplementary=bool(rng.integers(0, 2)), min_map_qual=int(rng.choice([0, 1, 30])), min_read_len=int(rng.choice([500, 1000, 2000])),
-                         min_map_len=int(rng.choice([200, 500, 1500])), min_map_fra=float(rng.choice([0.2, 0.5, 0.9])), max_clip_len=int(rng.choice([0, 10, 100, 100000])))
-    for tid, s in enumerate(syn):
-        n_ctg += 1
-        rr = [r for r in recs if r["tid"] == tid]
-        ref = s.pileup.ref.tobytes()
-        try:
-            arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
-            exp = orc.front_end(ref, arr, cig, asc, asc_off, fo); oerr = None
-        except Exception as e:
-            oerr = str(e)[:60]
-        got = {}
-        for mode in ("gpu", "libdeflate"):
-            os.environ["NP2_INFLATE"] = mode
+def main():
+    global rng
+    rng = np.random.default_rng(int(sys.argv[1])); n_files = int(sys.argv[2]); bad = n_ctg = 0
+    td = tempfile.mkdtemp()
+    pol = Polisher([Synth(2000, seed=3).yak(21)])
+    t0 = time.time()
+    for case in range(n_files):
+        n_ref = int(rng.integers(1, 6))
+        syn, recs, refs = [], [], []
+        for tid in range(n_ref):
+            L = int(rng.choice([2500, 9000, 20000, 50000]))
+            seed = int(rng.integers(1, 1 << 30)); rl = float(rng.choice([1500, 4000, 9000]))
+            s = Synth(L, depth=int(rng.choice([3, 10, 30])), seed=seed, diploid=bool(rng.integers(0, 2)), read_err_rate=float(rng.choice([0.002, 0.02])),
+                      read_len_mean=min(rl, L / 2), read_len_sd=rl / 6, read_len_min=min(1000, L // 4), name=f"c{tid}")
+            syn.append(s)
+            refs.append((f"c{tid}", s.pileup.L))
+            if rng.random() < 0.9:  # (a reference without any record now and then)
+                recs += pileup_to_records(s.pileup, tid=tid, rng=np.random.default_rng(seed), decorate=True)
+        recs.sort(key=lambda r: (r["tid"], r["pos"]))
+        path = os.path.join(td, f"f{case}.bam")
+        write_bam_straddling(path, refs, recs, int(rng.choice([300, 4096, 20000, 0xff00])), int(rng.integers(0, 10)))
+        fo = np2io.FrontOpts(use_supplementary=bool(rng.integers(0, 2)), min_map_qual=int(rng.choice([0, 1, 30])), min_read_len=int(rng.choice([500, 1000, 2000])),
+                             min_map_len=int(rng.choice([200, 500, 1500])), min_map_fra=float(rng.choice([0.2, 0.5, 0.9])), max_clip_len=int(rng.choice([0, 10, 100, 100000])))
+        for tid, s in enumerate(syn):
+            n_ctg += 1
+            rr = [r for r in recs if r["tid"] == tid]
+            ref = s.pileup.ref.tobytes()
             try:
-                c = np2io.contig_from_bam(pol, np2io.Bam(path), f"c{tid}", ref, fo)
-                got[mode] = np2io.export_contig(pol, c, s.pileup.ref)
-                c.free()
-            except Np2Error as e:
-                got[mode] = str(e)[:60]
-        a, b = got["gpu"], got["libdeflate"]
-        if isinstance(a, str) or isinstance(b, str) or oerr:
-            if not (isinstance(a, str) and isinstance(b, str) and oerr):
-                bad += 1; print("ERR-MISMATCH", sys.argv[1], case, tid, oerr, a if isinstance(a, str) else "ok", b if isinstance(b, str) else "ok", flush=True)
-            continue
-        # (byte-wise first; the up to 15 alignment bytes between two reads' streams are nobody's and may differ: then column by column)
-        if not (np.array_equal(a.reads, b.reads) and (np.array_equal(a.nibbles, b.nibbles) or same_pileup(a, b))):
-            bad += 1
-            print("MISMATCH device vs host pool", sys.argv[1], case, tid, "device == oracle:", same_pileup(a, exp), "host pool == oracle:", same_pileup(b, exp),
-                  "reads", a.n_reads, b.n_reads, exp.n_reads, "nib bytes", len(a.nibbles), len(b.nibbles), flush=True)
-            if os.environ.get("NP2_FUZZ_KEEP"):
-                import shutil; shutil.copy(path, os.environ["NP2_FUZZ_KEEP"] + f"/bad_{sys.argv[1]}_{case}_{tid}.bam")
-            continue
-        if not same_pileup(a, exp):
-            bad += 1; print("MISMATCH vs oracle", sys.argv[1], case, tid, flush=True)
-    os.remove(path); os.remove(path + ".bai")
-print(f"bam files {n_files} contigs {n_ctg} bad {bad} time {time.time() - t0:.1f}")
+                arr, cig, seq4, asc, asc_off = records_to_arrays(rr)
+                exp = orc.front_end(ref, arr, cig, asc, asc_off, fo); oerr = None
+            except Exception as e:
+                oerr = str(e)[:60]
+            got = {}
+            for mode in ("gpu", "libdeflate"):
+                os.environ["NP2_INFLATE"] = mode
+                try:
+                    c = np2io.contig_from_bam(pol, np2io.Bam(path), f"c{tid}", ref, fo)
+                    got[mode] = np2io.export_contig(pol, c, s.pileup.ref)
+                    c.free()
+                except Np2Error as e:
+                    got[mode] = str(e)[:60]
+            a, b = got["gpu"], got["libdeflate"]
+            if isinstance(a, str) or isinstance(b, str) or oerr:
+                if not (isinstance(a, str) and isinstance(b, str) and oerr):
+                    bad += 1; print("ERR-MISMATCH", sys.argv[1], case, tid, oerr, a if isinstance(a, str) else "ok", b if isinstance(b, str) else "ok", flush=True)
+                continue
+            # (byte-wise first; the up to 15 alignment bytes between two reads' streams are nobody's and may differ: then column by column)
+            if not (np.array_equal(a.reads, b.reads) and (np.array_equal(a.nibbles, b.nibbles) or same_pileup(a, b))):
+                bad += 1
+                print("MISMATCH device vs host pool", sys.argv[1], case, tid, "device == oracle:", same_pileup(a, exp), "host pool == oracle:", same_pileup(b, exp),
+                      "reads", a.n_reads, b.n_reads, exp.n_reads, "nib bytes", len(a.nibbles), len(b.nibbles), flush=True)
+                if os.environ.get("NP2_FUZZ_KEEP"):
+                    import shutil; shutil.copy(path, os.environ["NP2_FUZZ_KEEP"] + f"/bad_{sys.argv[1]}_{case}_{tid}.bam")
+                continue
+            if not same_pileup(a, exp):
+                bad += 1; print("MISMATCH vs oracle", sys.argv[1], case, tid, flush=True)
+        os.remove(path); os.remove(path + ".bai")
+    print(f"bam files {n_files} contigs {n_ctg} bad {bad} time {time.time() - t0:.1f}")
+
+
+if __name__ == "__main__":
+    main()
