@@ -40,11 +40,11 @@ PMC_LAUNCHES = {"yeast": 4, "ecoli": 1}  # launches per step the traffic figure 
 # dominant kernel of the path's algorithmic traffic — not the one the step spends most time in.  Its share of a step's kernel
 # time and the kernel that leads by time, from the tracked one-group kernel tables (rocprofv3 --kernel-trace --stats of
 # `bench.py --groups 1`; us per step): not measured in the run that prints the line.
-KERNEL_TIME = {"yeast": {"roofline_kernel_us": 143.8, "kernel_sum_us": 3370.3, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 582.7,
+KERNEL_TIME = {"yeast": {"roofline_kernel_us": 145.7, "kernel_sum_us": 3258.5, "dominant_by_time": "k_pf_tile (+ _mid)", "dominant_by_time_us": 583.0,
                          "source": "profiles/r06_yeast_one_group_kernels_per_step.txt (the table's total less k_yak_insert, a context's set-up)"},
-               "ecoli": {"roofline_kernel_us": 49.0, "kernel_sum_us": 758.6, "dominant_by_time": "copies of the result to the host (rocclr copyBuffer)", "dominant_by_time_us": 93.2,
+               "ecoli": {"roofline_kernel_us": 47.9, "kernel_sum_us": 720.1, "dominant_by_time": "copies of the result to the host (rocclr copyBuffer)", "dominant_by_time_us": 96.2,
                          "source": "profiles/r06_ecoli_kernels_per_step.txt (the table's total less k_yak_insert)"}}
-PMC_TRAFFIC = {"yeast": int((2 * 26323.4 + 34003.1) * 1024), "ecoli": int((2 * 38840.5 + 31541.6) * 1024)}
+PMC_TRAFFIC = {"yeast": int((2 * 26312.2 + 33996.6) * 1024), "ecoli": int((2 * 38836.5 + 31654.1) * 1024)}
 
 
 def make_assembly(lengths, depth, seed0, diploid):
