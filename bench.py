@@ -426,12 +426,19 @@ def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=2):
     for y in yaks:
         yk.append(os.path.join(tmpdir, f"k{y.k}.yak"))
         np2io.write_yak(yk[-1], y)
-    walls = []
-    for rep in range(4):
+    walls, b2b = [], []
+    for rep in range(7):
         out = os.path.join(tmpdir, f"out{rep}.fa")
+        # Runs 0-3 each start 0.25 s after the one before: a run burns ~1.1 CPU-seconds in ~45 ms (the host pool inflates the
+        # assembly's 600 MB on every hardware thread), and in a container with a CFS quota (16 CPUs here: 1.6 CPU-seconds per
+        # 100 ms period) a run that starts in the period the previous one exhausted has all its threads stopped for the rest
+        # of it, 30-45 ms at a stretch.  The pause is outside the timed region.  Runs 4-6 follow each
+        # other at once: what the quota sustains (`back_to_back`).
+        if 0 < rep <= 4:
+            time.sleep(0.25)
         t0 = time.perf_counter()
         rc = cli.main([bam, fa] + yk + ["-o", out, "-t", str(workers), "-L", "20000"])  # (default -L 1000000 passes short contigs through)
-        walls.append(time.perf_counter() - t0)
+        (walls if rep < 4 else b2b).append(time.perf_counter() - t0)
         if rc != 0:
             raise RuntimeError("cli.main failed")
     best = min(walls)
@@ -441,11 +448,13 @@ def end_to_end_assembly(syn, yaks, tmpdir, bases, spans, workers=2):
     return {"value": round(total / best / 1e6, 2), "unit": "Mbp/s", "wall_s": round(best, 3), "assembly_bp": total,
             "first_run": {"value": round(total / walls[0] / 1e6, 2), "wall_s": round(walls[0], 3)},
             "all_runs_wall_s": [round(w, 3) for w in walls],
+            "back_to_back": {"value": round(total * len(b2b) / sum(b2b) / 1e6, 2), "unit": "Mbp/s", "runs_wall_s": [round(w, 3) for w in b2b],
+                             "note": "three runs one right after the other: the rate the container's CPU quota sustains"},
             "bam_bytes": os.path.getsize(bam), "yak_bytes": sum(os.path.getsize(p) for p in yk), "workers": workers,
             "identical_to_resident_path": open(out, "rb").read() == want,
             "path": "k21/k31 .yak + FASTA + BAM (BGZF, .bai) files -> nextPolish2 command line (in process; reading the dumps "
                     "and building the HBM tables included: ~10-20 ms, streamed to the device while the first alignments "
-                    "are read) -> FASTA file; value = best of 4 runs, first_run = the first one: every run makes and "
+                    "are read) -> FASTA file; value = best of 4 runs started 0.25 s apart, first_run = the first one: every run makes and "
                     "releases its own contexts, tables and BAM handles, but from the second on their streams, pinned "
                     "staging and device blocks come from the process-wide pools the first run filled"}
 
