@@ -16,9 +16,11 @@
 #include <condition_variable>
 #include <exception>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -702,6 +704,8 @@ struct np2_bam {
     SeqStream seqs;   // ... streamed to the device batch by batch (the usual path)
     BgzfBatch batch;  // batch inflater (its buffer is reused from contig to contig)
     struct GpuFetch *gpu = nullptr; // read extraction on the device (NP2_INFLATE=gpu / auto: fetch_records_gpu); made on first use
+    std::shared_ptr<struct ResidentBam> resident; // ... from the WHOLE file inflated on the device once (a many-reference BAM of moderate size)
+    bool resident_tried = false;
     ~np2_bam();
     const uint8_t *map = nullptr; // the whole file, mapped read-only (BgzfBatch inflates out of it)
     size_t map_len = 0;
@@ -1752,6 +1756,25 @@ int np2_contig_from_records(np2_ctx_t *cx, const uint8_t *ref, uint32_t L, const
     return NP2_OK;
 }
 
+struct GBlk { // a BGZF block of the file
+    uint64_t file_off; // of the block
+    uint32_t hdr_len;  // 12 + XLEN: the raw DEFLATE payload starts there
+    uint32_t clen, isize;
+    uint32_t bsize;    // the whole block
+};
+// The whole file inflated on the device, once per process and device, for BAMs of many references and moderate size (an
+// assembly's: yeast 96 MB -> 600 MB): ONE inflate launch over every block — a block's decode latency, 2 - 3 ms, is paid once
+// instead of once per reference, and 10^4 blocks fill the device where a reference's few hundred leave it idle —, after which
+// a reference's front end is the record walk over its stretch of the resident stream.  Shared by the handles a process
+// opens on the file (the command line: one per front-end thread); released with the last of them.
+struct ResidentBam {
+    std::mutex mu;
+    bool built = false, failed = false;
+    std::vector<GBlk> blks;        // every block from the first record's on, the end-of-file marker included
+    std::vector<uint64_t> out_off; // blks.size() + 1
+    np2h::DevBuf<uint8_t> d_inf;
+    ResidentBam() { d_inf.cached = true; }
+};
 // ---- read extraction on the device ---------------------------------------------------------------------------------------
 // The contig's BGZF blocks go to the device as they lie in the file, are inflated there (k_bgzf_inflate: one wavefront per
 // block), and the records are found by walking the inflated stream along the .bai linear index (k_bam_chain_*).  The host
@@ -1839,6 +1862,170 @@ struct GpuRecs {
     const uint8_t *d_stream = nullptr;
     uint64_t stream_bytes = 0;
 };
+// File bytes [c_lo, read_end) -> pinned pieces (pread on the pool's threads: the page cache is copied from, no mapping of the
+// file is faulted in — through the mmap the same 2 GB of a chromosome's BAM took 0.08 to 2.7 s) -> g.d_comp; the 18-byte block
+// headers are parsed out of each piece while it is there.  blks: the blocks that lie wholly inside the range; eof: nothing
+// (but the end-of-file marker) follows them in the file.
+void read_blocks_to_device(GpuFetch &g, int fd, size_t file_len, size_t c_lo, size_t read_end, hipStream_t s, std::vector<GBlk> &blks, bool &eof) {
+    const size_t c_bytes = read_end - c_lo;
+    for (int i = 0; i < 2; ++i) {
+        if (!g.pin[i]) {
+            g.pin[i] = np2h::pinned_pool().get(GpuFetch::PIECE);
+            if (!g.pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
+        }
+        if (!g.ev[i]) HIPCHK(hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming));
+    }
+    auto small_read = [&](uint64_t off, uint8_t *dst, size_t n) { // a few bytes that straddle a piece
+        if (off + n > file_len || pread(fd, dst, n, (off_t)off) != (ssize_t)n) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+    };
+    uint64_t hdr_at = c_lo; // file offset of the next block header
+    bool range_done = false;
+    size_t piece = 0;
+    for (size_t o = 0; o < c_bytes; o += GpuFetch::PIECE, ++piece) {
+        const int sl = (int)(piece & 1);
+        if (piece >= 2) HIPCHK(hipEventSynchronize(g.ev[sl]));
+        const size_t want = std::min(GpuFetch::PIECE, c_bytes - o);
+        uint8_t *stage = (uint8_t *)g.pin[sl];
+        const size_t SUB = (size_t)1 << 20;
+        std::atomic<int> bad{0};
+        IoPool::get().parallel_for((want + SUB - 1) / SUB, 16, [&](size_t k) {
+            size_t got = 0;
+            const size_t n = std::min(SUB, want - k * SUB);
+            while (got < n) {
+                const ssize_t r = pread(fd, stage + k * SUB + got, n - got, (off_t)(c_lo + o + k * SUB + got));
+                if (r <= 0) {
+                    bad.store(1);
+                    return;
+                }
+                got += (size_t)r;
+            }
+        });
+        if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
+        HIPCHK(hipMemcpyAsync(g.d_comp.p + o, stage, want, hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(g.ev[sl], s));
+        // the headers that begin inside this piece
+        const uint64_t p0 = c_lo + o, p1 = p0 + want;
+        while (!range_done && hdr_at < p1) {
+            if (hdr_at + 18 > file_len) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+            uint8_t hb[18 + 256];
+            const uint8_t *hd = stage + (hdr_at - p0);
+            if (hdr_at + 18 > p1) small_read(hdr_at, hb, 18), hd = hb;
+            if (hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
+            const uint32_t xlen = hd[10] | (hd[11] << 8);
+            if (xlen > 256) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+            if (hd == hb || hdr_at + 12 + xlen > p1) small_read(hdr_at, hb, 12 + (size_t)xlen), hd = hb;
+            const uint8_t *ex = hd + 12;
+            uint32_t bsize = 0;
+            for (size_t q = 0; q + 4 <= xlen;) {
+                const uint32_t slen = ex[q + 2] | (ex[q + 3] << 8);
+                if (ex[q] == 'B' && ex[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = (ex[q + 4] | (ex[q + 5] << 8)) + 1;
+                q += 4 + slen;
+            }
+            if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
+            if (bsize < 12 + xlen + 8 || hdr_at + bsize > file_len) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
+            if (hdr_at + bsize > read_end) { // (the block continues beyond what this round reads: not part of it)
+                range_done = true;
+                break;
+            }
+            uint8_t tb8[8];
+            const uint64_t tail = hdr_at + bsize - 8;
+            const uint8_t *tp = stage + (tail - p0);
+            if (tail + 8 > p1) small_read(tail, tb8, 8), tp = tb8;
+            GBlk b;
+            b.file_off = hdr_at, b.hdr_len = 12 + xlen, b.clen = bsize - 12 - xlen - 8, b.bsize = bsize;
+            b.isize = tp[4] | (tp[5] << 8) | (tp[6] << 16) | ((uint32_t)tp[7] << 24);
+            blks.push_back(b);
+            hdr_at += bsize;
+        }
+    }
+    eof = false;
+    if (hdr_at >= file_len) eof = true;
+    else if (hdr_at + 28 == file_len) { // nothing but the end-of-file marker behind the range: the range IS the rest of the file
+        uint8_t mk[28];
+        small_read(hdr_at, mk, 28);
+        if (mk[0] == 31 && mk[1] == 139 && (mk[24] | mk[25] | mk[26] | mk[27]) == 0) eof = true;
+    }
+}
+
+// The resident stream of this handle's file (ResidentBam), built by the first caller; nullptr: not this file (one reference,
+// too large, switched off, no room on the device, a damaged block — the per-reference path then says what is wrong with it).
+//   NP2_BAM_RESIDENT_MB: largest file taken (default 1024; 0 = never)
+ResidentBam *resident_for(np2_bam *bam, GpuFetch &g, hipStream_t s) {
+    if (bam->resident) return bam->resident->built ? bam->resident.get() : nullptr;
+    if (bam->resident_tried) return nullptr;
+    bam->resident_tried = true;
+    static const size_t max_mb = getenv("NP2_BAM_RESIDENT_MB") ? (size_t)std::max(0L, atol(getenv("NP2_BAM_RESIDENT_MB"))) : (size_t)1024;
+    const size_t file_len = bam->map_len, c_lo = (size_t)(bam->first_rec >> 16);
+    if (bam->ref_names.size() < 2 || !max_mb || file_len <= c_lo || file_len - c_lo > (max_mb << 20)) return nullptr;
+    if (getenv("NP2_TEST_FETCH_NO_ROOM")) return nullptr; // (tests/test_gpu_inflate.py: a device without room)
+    struct stat st;
+    const int fd = fileno(bam->z.f);
+    if (fstat(fd, &st) != 0) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::mutex reg_mu;
+    static std::map<std::tuple<int, uint64_t, uint64_t, uint64_t, int64_t>, std::weak_ptr<ResidentBam>> reg;
+    std::shared_ptr<ResidentBam> rb;
+    {
+        std::lock_guard<std::mutex> l(reg_mu);
+        auto &w = reg[std::make_tuple(dev, (uint64_t)st.st_dev, (uint64_t)st.st_ino, (uint64_t)st.st_size, (int64_t)st.st_mtime)];
+        rb = w.lock();
+        if (!rb) {
+            rb = std::make_shared<ResidentBam>();
+            w = rb;
+        }
+    }
+    bam->resident = rb;
+    std::lock_guard<std::mutex> l(rb->mu);
+    if (rb->built) return rb.get();
+    if (rb->failed) return nullptr;
+    const bool prof = getenv("NP2_IO_PROFILE") != nullptr;
+    const double t0 = np2h::now_ms();
+    rb->failed = true; // (until the stream stands)
+    try {
+        g.d_comp.ensure(file_len - c_lo + 64);
+        bool eof = false;
+        read_blocks_to_device(g, fd, file_len, c_lo, file_len, s, rb->blks, eof);
+        const size_t n_blk = rb->blks.size();
+        if (!n_blk || !eof) throw np2h::Np2Error(NP2_E_ARG, "BGZF blocks do not reach the end of the file");
+        rb->out_off.assign(n_blk + 1, 0);
+        for (size_t i = 0; i < n_blk; ++i) rb->out_off[i + 1] = rb->out_off[i] + rb->blks[i].isize;
+        const uint64_t total = rb->out_off[n_blk];
+        const double t1 = np2h::now_ms();
+        rb->d_inf.ensure(total + 128);
+        g.d_blk.ensure(n_blk + 1);
+        g.d_status.ensure(n_blk + 8);
+        std::vector<np2::InfBlock> tb(n_blk);
+        for (size_t i = 0; i < n_blk; ++i) tb[i] = np2::InfBlock{rb->blks[i].file_off + rb->blks[i].hdr_len - c_lo, rb->out_off[i], rb->blks[i].clen, rb->blks[i].isize};
+        np2::InfBlock *h_tb = (np2::InfBlock *)g.host_block(g.h_cigar, g.h_cigar_cap, n_blk * sizeof(np2::InfBlock));
+        memcpy(h_tb, tb.data(), n_blk * sizeof(np2::InfBlock));
+        HIPCHK(hipMemcpyAsync(g.d_blk.p, h_tb, n_blk * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
+        const size_t w_bad = (n_blk + 1) & ~(size_t)1;
+        HIPCHK(hipMemsetAsync(g.d_status.p, 0, (w_bad + 4) * 4, s));
+        HIPCHK(hipMemsetAsync(rb->d_inf.p + total, 0, 128, s)); // (the columnariser loads whole words behind the last SEQ)
+        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)n_blk, g.d_comp.p, rb->d_inf.p, g.d_status.p, g.d_status.p + w_bad);
+        uint32_t n_bad = 0;
+        HIPCHK(hipMemcpyAsync(h_tb, g.d_status.p + w_bad, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(&n_bad, h_tb, 4);
+        if (n_bad) throw np2h::Np2Error(NP2_E_ARG, "BGZF inflate failed");
+        g.d_comp.release(); // (the file's bytes are not needed again)
+        rb->built = true;
+        rb->failed = false;
+        if (prof)
+            fprintf(stderr, "resident BAM: %zu blocks (%.1f MB -> %.1f MB) inflated on the device once: file -> device %.2f ms, inflate %.2f ms\n", n_blk,
+                    (file_len - c_lo) / 1e6, total / 1e6, t1 - t0, np2h::now_ms() - t1);
+    } catch (const np2h::Np2Error &) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        rb->blks.clear();
+        rb->out_off.clear();
+        rb->d_inf.release();
+        return nullptr;
+    }
+    return rb.get();
+}
+
 // The records of reference `tid` (all of them: fetch(tid, 0, L)).  false: this BAM / index cannot take the device path
 // (no linear index, an index entry that is not a record start) — the caller reads it the host way.
 // zone [zone_lo, zone_hi): (0, L) for the whole contig, or a shard's interval (then `voffs` receives the records' BGZF
@@ -1874,147 +2061,90 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
     const size_t c_lo = (size_t)(start_off >> 16);
     size_t c_hi = end_hint ? (size_t)(end_hint >> 16) : file_len; // file offset of the last block wanted
     if (getenv("NP2_TEST_FETCH_SHORT_HINT")) c_hi = c_lo; // test hook: an index that understates where the reference's records end
-    struct GBlk {
-        uint64_t file_off; // of the block
-        uint32_t hdr_len;  // 12 + XLEN: the raw DEFLATE payload starts there
-        uint32_t clen, isize;
-    };
     std::vector<GBlk> blks;
     std::vector<uint64_t> out_off;
     size_t extra = 0; // bytes read beyond the index's end of the reference (an index that understates it costs a second round)
+    ResidentBam *res = resident_for(bam, g, s); // the whole file on the device already (or now), or nullptr
     for (int round = 0;; ++round) {
         if (round > 40) throw np2h::Np2Error(NP2_E_ARG, "BAM/SAM parsing failed!");
-        // ---- file bytes -> pinned pieces (pread on the pool's threads: the page cache is copied from, no mapping of the file
-        // is faulted in — through the mmap the same 2 GB of a chromosome's BAM took 0.08 to 2.7 s) -> device; the 18-byte
-        // block headers are parsed out of each piece while it is there -----------------------------------------------------------
         blks.clear();
         const size_t read_end = std::min(file_len, c_hi + 65536 + extra);
         const size_t c_bytes = read_end - c_lo;
-        // (file bytes + inflated stream: 13 GB for a human chromosome.  No room on the device next to what else lives there ->
-        // false: the host pool streams the same records through 128 MiB of host memory)
-        static const bool test_no_room = getenv("NP2_TEST_FETCH_NO_ROOM") != nullptr; // (tests/test_gpu_inflate.py)
-        auto room = [&](auto &buf, size_t n) {
-            if (test_no_room && (void *)&buf == (void *)&g.d_inf) return false;
-            try {
-                buf.ensure(n);
-            } catch (const np2h::Np2Error &) {
-                (void)hipGetLastError();
+        bool eof = false;
+        const uint8_t *inf = nullptr; // the inflated stream of the blocks taken
+        uint64_t total = 0;
+        double t1 = t0, t_up = 0, t_inf = 0;
+        size_t n_blk = 0;
+        if (res) {
+            // ---- the reference's stretch of the resident stream --------------------------------------------------------------
+            const auto &all = res->blks;
+            size_t first = (size_t)(std::lower_bound(all.begin(), all.end(), (uint64_t)c_lo, [](const GBlk &x, uint64_t v) { return x.file_off < v; }) - all.begin());
+            if (first == all.size() || all[first].file_off != c_lo) return false; // the index does not point at a block of this file
+            size_t last = first;
+            while (last < all.size() && all[last].file_off + all[last].bsize <= read_end) ++last;
+            blks.assign(all.begin() + (long)first, all.begin() + (long)last);
+            eof = last == all.size() || (last + 1 == all.size() && all[last].isize == 0);
+            n_blk = blks.size();
+            if (!n_blk) return true;
+            out_off.assign(n_blk + 1, 0);
+            for (size_t i = 0; i <= n_blk; ++i) out_off[i] = res->out_off[first + i] - res->out_off[first];
+            total = out_off[n_blk];
+            inf = res->d_inf.p + res->out_off[first];
+            g.d_status.ensure(n_blk + 8);
+            t1 = t_up = t_inf = np2h::now_ms();
+        } else {
+            // ---- file bytes -> pinned pieces -> device; the block headers parsed on the way ---------------------------------------
+            // (file bytes + inflated stream: 13 GB for a human chromosome.  No room on the device next to what else lives there ->
+            // false: the host pool streams the same records through 128 MiB of host memory)
+            static const bool test_no_room = getenv("NP2_TEST_FETCH_NO_ROOM") != nullptr; // (tests/test_gpu_inflate.py)
+            auto room = [&](auto &buf, size_t n) {
+                if (test_no_room && (void *)&buf == (void *)&g.d_inf) return false;
+                try {
+                    buf.ensure(n);
+                } catch (const np2h::Np2Error &) {
+                    (void)hipGetLastError();
+                    return false;
+                }
+                return true;
+            };
+            if (!room(g.d_comp, c_bytes + 64)) return false;
+            read_blocks_to_device(g, fd, file_len, c_lo, read_end, s, blks, eof);
+            if (blks.empty()) {
+                HIPCHK(hipStreamSynchronize(s));
+                return true;
+            }
+            n_blk = blks.size();
+            out_off.assign(n_blk + 1, 0);
+            for (size_t i = 0; i < n_blk; ++i) out_off[i + 1] = out_off[i] + blks[i].isize;
+            total = out_off[n_blk];
+            t1 = np2h::now_ms();
+            // ---- inflate --------------------------------------------------------------------------------------------------------
+            if (!room(g.d_inf, total + 128)) {
+                HIPCHK(hipStreamSynchronize(s)); // (the uploads into d_comp)
                 return false;
             }
-            return true;
-        };
-        if (!room(g.d_comp, c_bytes + 64)) return false;
-        for (int i = 0; i < 2; ++i) {
-            if (!g.pin[i]) {
-                g.pin[i] = np2h::pinned_pool().get(GpuFetch::PIECE);
-                if (!g.pin[i]) throw np2h::Np2Error(NP2_E_NOMEM, "hipHostMalloc failed");
-            }
-            if (!g.ev[i]) HIPCHK(hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming));
-        }
-        auto small_read = [&](uint64_t off, uint8_t *dst, size_t n) { // a few bytes that straddle a piece
-            if (off + n > file_len || pread(fd, dst, n, (off_t)off) != (ssize_t)n) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
-        };
-        uint64_t hdr_at = c_lo; // file offset of the next block header
-        bool eof = false, range_done = false;
-        size_t piece = 0;
-        for (size_t o = 0; o < c_bytes; o += GpuFetch::PIECE, ++piece) {
-            const int sl = (int)(piece & 1);
-            if (piece >= 2) HIPCHK(hipEventSynchronize(g.ev[sl]));
-            const size_t want = std::min(GpuFetch::PIECE, c_bytes - o);
-            uint8_t *stage = (uint8_t *)g.pin[sl];
-            const size_t SUB = (size_t)1 << 20;
-            std::atomic<int> bad{0};
-            IoPool::get().parallel_for((want + SUB - 1) / SUB, 16, [&](size_t k) {
-                size_t got = 0;
-                const size_t n = std::min(SUB, want - k * SUB);
-                while (got < n) {
-                    const ssize_t r = pread(fd, stage + k * SUB + got, n - got, (off_t)(c_lo + o + k * SUB + got));
-                    if (r <= 0) {
-                        bad.store(1);
-                        return;
-                    }
-                    got += (size_t)r;
-                }
-            });
-            if (bad.load()) throw np2h::Np2Error(NP2_E_ARG, "truncated BAM");
-            HIPCHK(hipMemcpyAsync(g.d_comp.p + o, stage, want, hipMemcpyHostToDevice, s));
-            HIPCHK(hipEventRecord(g.ev[sl], s));
-            // the headers that begin inside this piece
-            const uint64_t p0 = c_lo + o, p1 = p0 + want;
-            while (!range_done && hdr_at < p1) {
-                if (hdr_at + 18 > file_len) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
-                uint8_t hb[18 + 256];
-                const uint8_t *hd = stage + (hdr_at - p0);
-                if (hdr_at + 18 > p1) small_read(hdr_at, hb, 18), hd = hb;
-                if (hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw np2h::Np2Error(NP2_E_ARG, "not a BGZF block");
-                const uint32_t xlen = hd[10] | (hd[11] << 8);
-                if (xlen > 256) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
-                if (hd == hb || hdr_at + 12 + xlen > p1) small_read(hdr_at, hb, 12 + (size_t)xlen), hd = hb;
-                const uint8_t *ex = hd + 12;
-                uint32_t bsize = 0;
-                for (size_t q = 0; q + 4 <= xlen;) {
-                    const uint32_t slen = ex[q + 2] | (ex[q + 3] << 8);
-                    if (ex[q] == 'B' && ex[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = (ex[q + 4] | (ex[q + 5] << 8)) + 1;
-                    q += 4 + slen;
-                }
-                if (!bsize) throw np2h::Np2Error(NP2_E_ARG, "BGZF block without BC field");
-                if (bsize < 12 + xlen + 8 || hdr_at + bsize > file_len) throw np2h::Np2Error(NP2_E_ARG, "truncated BGZF block");
-                if (hdr_at + bsize > read_end) { // (the block continues beyond what this round reads: not part of it)
-                    range_done = true;
-                    break;
-                }
-                uint8_t tb8[8];
-                const uint64_t tail = hdr_at + bsize - 8;
-                const uint8_t *tp = stage + (tail - p0);
-                if (tail + 8 > p1) small_read(tail, tb8, 8), tp = tb8;
-                GBlk b;
-                b.file_off = hdr_at, b.hdr_len = 12 + xlen, b.clen = bsize - 12 - xlen - 8;
-                b.isize = tp[4] | (tp[5] << 8) | (tp[6] << 16) | ((uint32_t)tp[7] << 24);
-                blks.push_back(b);
-                hdr_at += bsize;
+            inf = g.d_inf.p;
+            g.d_blk.ensure(n_blk + 1);
+            g.d_status.ensure(n_blk + 8);
+            if (prof) {
+                HIPCHK(hipStreamSynchronize(s));
+                t_up = np2h::now_ms();
             }
         }
-        if (hdr_at >= file_len) eof = true;
-        else if (hdr_at + 28 == file_len) { // nothing but the end-of-file marker behind the range: the range IS the rest of the file
-            uint8_t mk[28];
-            small_read(hdr_at, mk, 28);
-            if (mk[0] == 31 && mk[1] == 139 && (mk[24] | mk[25] | mk[26] | mk[27]) == 0) eof = true;
-        }
-        if (blks.empty()) {
-            HIPCHK(hipStreamSynchronize(s));
-            return true;
-        }
-        const size_t n_blk = blks.size();
-        out_off.assign(n_blk + 1, 0);
-        for (size_t i = 0; i < n_blk; ++i) out_off[i + 1] = out_off[i] + blks[i].isize;
-        const uint64_t total = out_off[n_blk];
-        const double t1 = np2h::now_ms();
-        // ---- inflate ------------------------------------------------------------------------------------------------------------
-        if (!room(g.d_inf, total + 128)) {
-            HIPCHK(hipStreamSynchronize(s)); // (the uploads into d_comp)
-            return false;
-        }
-        g.d_blk.ensure(n_blk + 1);
-        g.d_status.ensure(n_blk + 8);
-        double t_up = 0, t_inf = 0;
-        if (prof) {
-            HIPCHK(hipStreamSynchronize(s));
-            t_up = np2h::now_ms();
-        }
-        std::vector<np2::InfBlock> tb(n_blk);
-        for (size_t i = 0; i < n_blk; ++i) tb[i] = np2::InfBlock{blks[i].file_off + blks[i].hdr_len - c_lo, out_off[i], blks[i].clen, blks[i].isize};
-        np2::InfBlock *h_tb = (np2::InfBlock *)g.host_block(g.h_cigar, g.h_cigar_cap, n_blk * sizeof(np2::InfBlock)); // (free until the records come back)
-        memcpy(h_tb, tb.data(), n_blk * sizeof(np2::InfBlock));
-        HIPCHK(hipMemcpyAsync(g.d_blk.p, h_tb, n_blk * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
+        np2::InfBlock *h_tb = (np2::InfBlock *)g.host_block(g.h_cigar, g.h_cigar_cap, std::max<size_t>(n_blk * sizeof(np2::InfBlock), 64)); // (free until the records come back)
         // status words: [0, n_blk) per block, then n_bad, walk flags, (pad), tail_at (64-bit, 8-byte aligned)
         const size_t w_bad = (n_blk + 1) & ~(size_t)1, w_flags = w_bad + 1, w_tail = w_bad + 2;
         HIPCHK(hipMemsetAsync(g.d_status.p, 0, (w_tail + 2) * 4, s));
         HIPCHK(hipMemsetAsync(g.d_status.p + w_tail, 0xFF, 8, s));
-        HIPCHK(hipMemsetAsync(g.d_inf.p + total, 0, 64, s)); // (the columnariser loads whole words behind the last SEQ)
-        np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)n_blk, g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + w_bad);
-        if (prof) {
-            HIPCHK(hipStreamSynchronize(s));
-            t_inf = np2h::now_ms();
+        if (!res) {
+            for (size_t i = 0; i < n_blk; ++i) h_tb[i] = np2::InfBlock{blks[i].file_off + blks[i].hdr_len - c_lo, out_off[i], blks[i].clen, blks[i].isize};
+            HIPCHK(hipMemcpyAsync(g.d_blk.p, h_tb, n_blk * sizeof(np2::InfBlock), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemsetAsync(g.d_inf.p + total, 0, 64, s)); // (the columnariser loads whole words behind the last SEQ)
+            np2::launch_bgzf_inflate(s, g.d_blk.p, (uint32_t)n_blk, g.d_comp.p, g.d_inf.p, g.d_status.p, g.d_status.p + w_bad);
+            if (prof) {
+                HIPCHK(hipStreamSynchronize(s));
+                t_inf = np2h::now_ms();
+            }
         }
         // ---- chain starts: the linear index's record starts inside the range ----------------------------------------------------
         std::vector<uint64_t> starts;
@@ -2041,7 +2171,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
         uint64_t *h_st = (uint64_t *)g.host_block(g.h_recs, g.h_recs_cap, (size_t)n_chains * 8 + 64);
         memcpy(h_st, starts.data(), (size_t)n_chains * 8);
         HIPCHK(hipMemcpyAsync(g.d_starts.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
-        np2::launch_bam_chain_count(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_info.p, g.d_status.p + w_flags,
+        np2::launch_bam_chain_count(s, inf, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_info.p, g.d_status.p + w_flags,
                                     (unsigned long long *)(g.d_status.p + w_tail));
         // one wait: block statuses' summary, the walk's flags, the chains' counts
         std::vector<uint2> info(n_chains);
@@ -2075,7 +2205,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
         }
         if (n_rec > 0xFFFFFFF0ull || n_cig > 0xFFFFFFF0ull) throw np2h::Np2Error(NP2_E_NOMEM, "too many records for one contig");
         out.n_recs = (uint32_t)n_rec;
-        out.d_stream = g.d_inf.p;
+        out.d_stream = inf;
         out.stream_bytes = total + 16;
         if (n_rec) {
             g.d_recs.ensure(n_rec + 1);
@@ -2083,8 +2213,8 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
             g.d_cigar.ensure(n_cig + 1);
             memcpy(h_st, off.data(), (size_t)n_chains * 8);
             HIPCHK(hipMemcpyAsync(g.d_off.p, h_st, (size_t)n_chains * 8, hipMemcpyHostToDevice, s));
-            np2::launch_bam_chain_write(s, g.d_inf.p, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_off.p, g.d_recs.p, g.d_cig_src.p);
-            np2::launch_bam_cigars(s, g.d_inf.p, g.d_recs.p, g.d_cig_src.p, (uint32_t)n_rec, g.d_cigar.p);
+            np2::launch_bam_chain_write(s, inf, g.d_starts.p, n_chains, total, tid, L, zone_lo, zone_hi, g.d_off.p, g.d_recs.p, g.d_cig_src.p);
+            np2::launch_bam_cigars(s, inf, g.d_recs.p, g.d_cig_src.p, (uint32_t)n_rec, g.d_cigar.p);
             HIPCHK(hipStreamSynchronize(s)); // (h_st is about to be given up for a larger block)
             if (prof) fprintf(stderr, "  fetch_records_gpu: offsets + write + cigars %.2f ms\n", np2h::now_ms() - t2);
             np2_bamrec_t *hr = (np2_bamrec_t *)g.host_block(g.h_recs, g.h_recs_cap, n_rec * sizeof(np2_bamrec_t) + 64);
@@ -2109,7 +2239,7 @@ bool fetch_records_gpu(np2_bam *bam, int tid, uint32_t L, uint32_t zone_lo, uint
         if (prof)
             fprintf(stderr, "fetch_records_gpu: %zu blocks (%.1f MB -> %.1f MB), %u chains, %llu records, %llu CIGAR words: file -> pinned pieces (+ block headers) %.2f ms, "
                             "rest of the upload %.2f ms, inflate %.2f ms, index + count + wait %.2f ms, records back %.2f ms%s\n", n_blk, c_bytes / 1e6, total / 1e6, n_chains,
-                    (unsigned long long)n_rec, (unsigned long long)n_cig, t1 - t0, t_up - t1, t_inf - t_up, t2 - t_inf, np2h::now_ms() - t2, round ? " (after extending the range)" : "");
+                    (unsigned long long)n_rec, (unsigned long long)n_cig, t1 - t0, t_up - t1, t_inf - t_up, t2 - t_inf, np2h::now_ms() - t2, res ? (round ? " (stretch of the resident stream, after extending the range)" : " (stretch of the resident stream)") : (round ? " (after extending the range)" : ""));
         return true;
     }
 }

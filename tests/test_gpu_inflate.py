@@ -156,21 +156,26 @@ def test_references_of_one_bam_through_the_device(tmp_path, short_hint):
             b, p = o.polish(orc.front_end(s.pileup.ref.tobytes(), arr, cig, asc, asc_off, np2io.FrontOpts()), Opts())
         exp += b">%s start:%d end:%d\n%s\n" % (nm.encode(), p[0], p[-1], b.tobytes())
     outs = {}
-    for mode in ("gpu", "libdeflate"):
-        env = dict(os.environ, PYTHONPATH=ROOT, NP2_INFLATE=mode, NP2_IO_PROFILE="1")
-        if short_hint and mode == "gpu":
+    # (gpu: the whole file inflated on the device once, every reference a stretch of that stream; gpu_per_ref: a reference's
+    # blocks uploaded and inflated by themselves — what a file too large to keep resident gets)
+    for mode in ("gpu", "gpu_per_ref", "libdeflate"):
+        env = dict(os.environ, PYTHONPATH=ROOT, NP2_INFLATE=mode.split("_")[0], NP2_IO_PROFILE="1")
+        if mode == "gpu_per_ref":
+            env["NP2_BAM_RESIDENT_MB"] = "0"
+        if short_hint and mode.startswith("gpu"):
             env["NP2_TEST_FETCH_SHORT_HINT"] = "1"
         out = tmp_path / ("out_%s.fa" % mode)
         r = subprocess.run([sys.executable, "-m", "nextpolish2_amd.cli", "-L", "10000", "-o", str(out), str(tmp_path / "m.bam"),
                             str(tmp_path / "g.fa.gz"), str(tmp_path / "k21.yak")], capture_output=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         outs[mode] = out.read_bytes()
-        if mode == "gpu":
+        if mode.startswith("gpu"):
             err = r.stderr.decode()
             assert err.count("fetch_records_gpu:") >= 3, err[-2000:]
+            assert ("resident BAM:" in err and err.count("stretch of the resident stream") >= 3) == (mode == "gpu"), err[-2000:]
             if short_hint:
                 assert "after extending the range" in err
-    assert outs["gpu"] == outs["libdeflate"]
+    assert outs["gpu"] == outs["libdeflate"] == outs["gpu_per_ref"]
     assert outs["gpu"] == exp
 
 
