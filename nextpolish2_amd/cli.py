@@ -327,6 +327,18 @@ def main(argv=None):
     todo, todo_cv = deque(), threading.Condition()  # (name, length, front-end future, result future) in input order
     closing = []
 
+    def ensure_batch():
+        if getattr(tls, "batch", None) is None:
+            b0 = base_future[0].result()
+            with base_lock:  # one copy of the k-mer tables in HBM: the other worker's contexts share it
+                tls.pol = b0 if not base else b0.clone()
+                base.append(tls.pol)
+            t_b = time.time()
+            tls.batch = BatchPolisher(tls.pol, BATCH_SLOTS)
+            if prof:
+                print(f"[np2 profile] polish worker: batch driver with {BATCH_SLOTS} slot contexts {1e3 * (time.time() - t_b):.1f} ms "
+                      f"(at +{time.time() - t0:.3f} s)", file=sys.stderr)
+
     def polish_worker():
         """takes the head of `todo` and every following contig that is already resident; one batch per turn"""
         while True:
@@ -336,6 +348,12 @@ def main(argv=None):
                 if not todo:
                     return
                 items = [todo.popleft()]
+            try:
+                # this worker's batch driver first (it waits for the k-mer tables, not for a pileup: made while the first front
+                # ends are still reading — 7-9 ms that used to sit between the first resident contig and its polish)
+                ensure_batch()
+            except BaseException:
+                pass  # (reported below, by the polish that needs it)
             try:
                 items[0][2].exception()  # (waits for the head's front end)
             except BaseException:
@@ -356,15 +374,7 @@ def main(argv=None):
             try:
                 if not live:
                     continue
-                if getattr(tls, "batch", None) is None:
-                    b0 = base_future[0].result()
-                    with base_lock:  # one copy of the k-mer tables in HBM: the other worker's contexts share it
-                        tls.pol = b0 if not base else b0.clone()
-                        base.append(tls.pol)
-                    t_b = time.time()
-                    tls.batch = BatchPolisher(tls.pol, BATCH_SLOTS)
-                    if prof:
-                        print(f"[np2 profile] polish worker: batch driver with {BATCH_SLOTS} slot contexts {1e3 * (time.time() - t_b):.1f} ms", file=sys.stderr)
+                ensure_batch()
                 t_p = time.time()
                 try:
                     res = tls.batch.polish(contigs, opts, want_pos=a.out_pos)
