@@ -29,4 +29,5 @@ for g in 4 5 6 8; do python bench.py --no-cpu-baseline --no-end-to-end --no-excl
 import json,sys
 d=json.loads(sys.stdin.read()); print('--groups $g:', d['value'], 'Mbp/s,', d['ms_per_step'], 'ms per step; per-group call ms', d['flush_ms']['call_breakdown_ms_per_group']['caller_clock'])"; done > gpurun_out/${R}_group_counts.txt 2>&1
 timeout 300 python tools/vote_small_probe.py 2>&1 | tail -18 > gpurun_out/${R}_vote_host_yeast_chromosome.txt
+timeout 300 python tools/cli_rss_probe.py > gpurun_out/${R}_cli_fresh_process.txt 2>&1
 ls gpurun_out | grep "^${R}_" | head -80
