@@ -91,6 +91,8 @@ class Groups:
                 b.set_priority(g % 2 == 0)
         self.contigs = contigs
         self.n = len(contigs)
+        # how many steps the groups may run in front of the per-step collective of a multi-rank run (one staging buffer each)
+        self.ahead = max(1, int(os.environ.get("NP2_BENCH_GATHER_AHEAD", "1")))
 
     def set_timing(self, on):
         for b in self.bps:
@@ -109,15 +111,17 @@ class Groups:
             out.append((i, p.value, n.value))
         return out
 
-    def run(self, opts, steps, after_step=None, exclusive=False, stage=None):
+    def run(self, opts, steps, after_step=None, exclusive=False, stage=None, sink=None):
         """`steps` passes over the assembly.  after_step(out) runs on the calling thread once every group has delivered
         a step (the groups may be one step ahead of it by then).  stage(k, items): called on a group's thread when it has
         delivered step k, with slot_results of its contigs (the multi-rank run copies them, device to device, into the
-        buffer the step's all-gather sends).  exclusive: one group at a time (the roofline kernel
+        buffer the step's all-gather sends).  sink(k, i) -> (device address, capacity): instead of `stage`, the batch driver
+        itself copies contig i's polished bases of step k there (np2_batch_set_sink).  exclusive: one group at a time (the roofline kernel
         measured without other kernels next to it).  -> (outputs of the last step, per-step sum of the k_diff_reads
         launch durations in ms, launches per step, mean np2_batch_polish call time in ms)"""
         G = len(self.bps)
-        outs = [[None] * self.n, [None] * self.n]
+        NB = self.ahead + 1  # steps whose outputs may be pending at once (the groups run up to `ahead` steps in front of after_step)
+        outs = [[None] * self.n for _ in range(NB)]
         done, seen = [0] * G, [0]
         acc = [[0.0, 0, 0.0, 0.0, 0.0, 0.0] for _ in range(G)]
         cv = threading.Condition()
@@ -126,10 +130,13 @@ class Groups:
         def loop(g):
             for k in range(steps):
                 with cv:
-                    cv.wait_for(lambda: (after_step is None or seen[0] >= k - 1) and (not exclusive or turn[0] % G == g))
+                    cv.wait_for(lambda: (after_step is None or seen[0] >= k - self.ahead) and (not exclusive or turn[0] % G == g))
+                if sink is not None:  # where this step's polished bases go on the device (the buffer the step's all-gather sends)
+                    for slot, i in enumerate(self.members[g]):
+                        self.bps[g].set_sink(slot, *sink(k, i))
                 res = self.bps[g].polish([self.contigs[i] for i in self.members[g]], opts)
                 for i, r in zip(self.members[g], res):
-                    outs[k & 1][i] = r
+                    outs[k % NB][i] = r
                 if stage is not None:
                     stage(k, self.slot_results(g))
                 ms, launches = self.bps[g].last_diff_ms()
@@ -151,7 +158,7 @@ class Groups:
             for k in range(steps):
                 with cv:
                     cv.wait_for(lambda: min(done) >= k + 1)
-                after_step(outs[k & 1]) if stage is None else after_step(k, outs[k & 1])
+                after_step(outs[k % NB]) if (stage is None and sink is None) else after_step(k, outs[k % NB])
                 with cv:
                     seen[0] = k + 1
                     cv.notify_all()
@@ -161,7 +168,7 @@ class Groups:
             # clock, the flushes inside it (host phase + issue + wait) and what follows the last flush
             "caller_clock": [round(x[2] / max(1, steps), 3) for x in acc], "inside_call": [round(x[3] / max(1, steps), 3) for x in acc],
             "flushes": [round(x[5] / max(1, steps), 3) for x in acc], "after_last_flush": [round(x[4] / max(1, steps), 3) for x in acc]}
-        return (outs[(steps - 1) & 1], sum(x[0] for x in acc) / max(1, steps), sum(x[1] for x in acc),
+        return (outs[(steps - 1) % NB], sum(x[0] for x in acc) / max(1, steps), sum(x[1] for x in acc),
                 sum(x[2] for x in acc) / max(1, steps * G))
 
 
@@ -721,7 +728,7 @@ def main():
         # go from its slot context's result buffer into its slot of the staging buffer (device to device) as soon as its
         # batch group has delivered it; two staging buffers, because the groups may be one step ahead of the collective
         caps = [l + l // 16 + 1024 for l in lengths]
-        gatherer = SequenceGatherer(sum(caps) + 16 * len(caps) + 4096, dev, collective_device=cdev, n_local=2)
+        gatherer = SequenceGatherer(sum(caps) + 16 * len(caps) + 4096, dev, collective_device=cdev, n_local=groups.ahead + 1)
         if not single:
             gatherer.set_slots(caps)
 
@@ -744,8 +751,18 @@ def main():
             pending[0] = False
         return [(np.array(last[0]), span)]
 
-    after = (lambda k, o: gatherer.gather_staged(k & 1, [len(x[0]) for x in o])) if distributed else None
-    stage = (lambda k, items: gatherer.stage(k & 1, items)) if distributed else None
+    NB = groups.ahead + 1
+    after = (lambda k, o: gatherer.gather_staged(k % NB, [len(x[0]) for x in o])) if distributed else None
+    # a contig's polished bases reach the step's staging buffer by a copy the batch driver records itself (np2_batch_set_sink:
+    # device to device, at the device-side length, inside the polish call); NP2_BENCH_STAGE_TORCH=1: by torch copies from the
+    # slot contexts' result buffers after the call, as before (0.5 ms per step and rank more)
+    stage = sink = None
+    if distributed and os.environ.get("NP2_BENCH_STAGE_TORCH"):
+        stage = lambda k, items: gatherer.stage(k % NB, items)
+    elif distributed:
+        sink = lambda k, i: gatherer.slot_address(k % NB, i)
+    if os.environ.get("NP2_BENCH_NO_GATHER"):  # (experiment: the multi-rank launch without its per-step collective)
+        after = stage = sink = None
 
     def sync():
         if distributed:
@@ -757,7 +774,7 @@ def main():
             out = step_single()
         drain_single(out)
     elif a.warmup:
-        groups.run(opts, a.warmup, after, stage=stage)
+        groups.run(opts, a.warmup, after, stage=stage, sink=sink)
     groups.set_timing(True)  # HIP events around the batched k_diff_reads launches, on the batch streams
     diff_ms, diff_launches, call_ms = [], 0, 0.0
     import gc
@@ -780,7 +797,7 @@ def main():
                 print(f"diff_probe {tm['diff_probe']:.4f} ms (diff_reads {tm.get('diff_reads', 0.0):.4f})", file=sys.stderr)
             diff_launches = 1
     else:
-        out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after, stage=stage)
+        out, ms, diff_launches, call_ms = groups.run(opts, a.steps, after, stage=stage, sink=sink)
         call_breakdown = groups.call_breakdown
         diff_ms.append(ms)
     if single:
@@ -809,7 +826,7 @@ def main():
                 o2 = step_single()
             drain_single(o2)
         else:
-            groups.run(opts, a.steps, after, stage=stage)
+            groups.run(opts, a.steps, after, stage=stage, sink=sink)
         sync()
         region_dt.append(time.perf_counter() - t1)
     gc.enable()

@@ -163,6 +163,11 @@ int np2_batch_set_priority(np2_batch_t *b, int high);
 int np2_batch_slots(np2_batch_t *b);
 np2_ctx_t *np2_batch_slot_ctx(np2_batch_t *b, int slot);
 const char *np2_batch_last_error(np2_batch_t *b);
+/* A copy of the polished bases of whatever contig runs on `slot` (contig i of a wave: slot i % n_slots) goes, device to
+ * device and at its polished length (at most `cap` bytes: compare out_len), to `device_ptr` — a slot of the buffer a rank's
+ * all-gather sends (what replaces the reference's channel to the writer thread, main.rs:1838-1853, between GPUs) —, complete
+ * when np2_batch_polish returns.  device_ptr == NULL: no copy.  Call while no np2_batch_polish is in flight. */
+int np2_batch_set_sink(np2_batch_t *b, int slot, void *device_ptr, uint64_t cap);
 int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const np2_opts_t *opts, uint8_t **out_bases,
                      uint32_t **out_pos, uint64_t *out_len, uint32_t *out_span /* first / last position per contig, or NULL */,
                      int *rcs);

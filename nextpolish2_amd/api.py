@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "np2_ctx_create", "np2_ctx_destroy", "np2_last_error", "np2_ctx_stream", "np2_contig_upload",
     "np2_contig_free", "np2_polish_resident", "np2_polish_contig", "np2_free", "np2_score_strings",
     "np2_lookup_hashes", "np2_ctx_set_trace", "np2_ctx_set_timing", "np2_trace_get", "np2_last_timings", "np2_last_span", "np2_last_result_device", "np2_result_fetch_begin", "np2_result_fetch_end", "np2_phase_vote",
-    "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx",
+    "np2_ctx_create_shared", "np2_batch_create", "np2_batch_destroy", "np2_batch_slots", "np2_batch_slot_ctx", "np2_batch_set_sink",
     "np2_batch_last_error", "np2_batch_polish", "np2_batch_flush_log", "np2_shard_plan", "np2_shard_upload",
     "np2_shard_begin", "np2_shard_passes_left", "np2_shard_vote", "np2_vote_decide", "np2_shard_apply", "np2_shard_final",
     "np2_shard_final_device", "np2_shard_fetch", "np2_alloc_pinned", "np2_trim_device_cache",
@@ -95,6 +95,7 @@ def _lib_locked():
         L.np2_batch_destroy.argtypes = [vp]
         L.np2_batch_destroy.restype = None
         L.np2_batch_slots.argtypes = [vp]
+        L.np2_batch_set_sink.argtypes = [vp, C.c_int, vp, C.c_uint64]
         L.np2_batch_slot_ctx.argtypes = [vp, C.c_int]
         L.np2_batch_slot_ctx.restype = vp
         L.np2_batch_last_error.argtypes = [vp]
@@ -412,6 +413,12 @@ class BatchPolisher:
             else:
                 out.append((b, (span[2 * i], span[2 * i + 1])))
         return out
+
+    def set_sink(self, slot, device_ptr, cap):
+        """np2_batch_set_sink: the polished bases of the contig on `slot` are also copied to device address `device_ptr`."""
+        rc = lib().np2_batch_set_sink(self._h, slot, C.c_void_p(device_ptr) if device_ptr else None, int(cap))
+        if rc != 0:
+            raise Np2Error(rc, "np2_batch_set_sink")
 
     def slot_fetch_begin(self, slot):
         rc = lib().np2_result_fetch_begin(lib().np2_batch_slot_ctx(self._h, slot))

@@ -448,6 +448,12 @@ np2_ctx_t *np2_batch_slot_ctx(np2_batch_t *b, int slot) {
     return (b && slot >= 0 && slot < (int)b->slots.size()) ? b->slots[slot] : nullptr;
 }
 const char *np2_batch_last_error(np2_batch_t *b) { return b ? b->err.c_str() : "null batch"; }
+int np2_batch_set_sink(np2_batch_t *b, int slot, void *device_ptr, uint64_t cap) {
+    if (!b || slot < 0 || slot >= (int)b->slots.size()) return NP2_E_ARG;
+    b->slots[slot]->sink_dst = (uint8_t *)device_ptr;
+    b->slots[slot]->sink_cap = device_ptr ? cap : 0;
+    return NP2_OK;
+}
 
 int np2_batch_polish(np2_batch_t *b, np2_contig_t *const *contigs, int n, const np2_opts_t *opts, uint8_t **out_bases,
                      uint32_t **out_pos, uint64_t *out_len, uint32_t *out_span, int *rcs) {

@@ -480,6 +480,9 @@ struct np2_ctx {
     // batch's host-mapped block (a slot only records commands; making three streams and a pinned block per slot cost
     // 10 - 16 ms each in a fresh process: 250 ms for a 16-slot driver)
     bool borrowed_state = false;
+    // np2_batch_set_sink: where a copy of the polished bases goes on the device (a rank's gather buffer), 0 = nowhere
+    uint8_t *sink_dst = nullptr;
+    uint64_t sink_cap = 0;
     uint32_t last_first_pos = 0, last_last_pos = 0;
     const uint8_t *last_dbase = nullptr; // device copy of the last polished sequence (valid until the next call)
     const uint32_t *last_dpos = nullptr; // ... and of its positions

@@ -1166,6 +1166,9 @@ void fetch_result(np2_ctx *cx, const uint32_t *dpos, const uint8_t *dbase, const
     // final length + the error word of everything that ran without a read-back since the last one
     // (the same post carries the first and the last consensus position: the FASTA header span)
     std::vector<uint32_t> sc;
+    // (a second copy of the bases, device to device, at its device-side length: into the caller's sink — np2_batch_set_sink —,
+    // done when this call's last wait returns)
+    if (cx->sink_dst && cx->sink_cap) launch_copy_len(cx->stream, cx->sink_dst, dbase, M_p, 1, cx->sink_cap);
     if (r.want_bases || r.want_pos) {
         const uint32_t seq = ++cx->mbox_seq;
         launch_post(cx->stream, cx->scal.p, S_COUNT, cx->mbox_dev, seq, cx->scal.p + S_M0, M_p, nullptr, nullptr, nullptr, nullptr,

@@ -556,6 +556,11 @@ class SequenceGatherer:
         if self.device.type == "cuda":
             self._tab_host = self._tab_host.pin_memory()
 
+    def slot_address(self, which, i):
+        """(device address, capacity) of contig i's slot in staging buffer `which`: what np2_batch_set_sink takes — the batch
+        driver then copies a contig's polished bases there itself, inside the polish call (no `stage`)."""
+        return self.locals[which].data_ptr() + self._slot_off[i], self._slot_cap[i]
+
     def stage(self, which, items):
         """items: [(contig index, device address, length)] — copied device to device into staging buffer `which`; returns
         when the copies are done (the result buffers may be overwritten by the next polish call)."""

@@ -23,6 +23,38 @@ def _assembly():
     return syn, [Synth.yak_assembly(syn, 21), Synth.yak_assembly(syn, 31)]
 
 
+def test_sinks_receive_the_polished_bases_on_the_device():
+    """np2_batch_set_sink: a copy of every contig's polished bases lands, device to device and at its polished length, in the
+    caller's buffer (a rank's all-gather staging buffer) by the time np2_batch_polish returns — with the bases delivered to
+    the host as well, and with the sequences kept on the device; a sink taken away again receives nothing."""
+    import torch
+    syn, yaks = _assembly()
+    pol = Polisher(yaks)
+    contigs = [pol.upload(s.pileup) for s in syn]
+    want = [pol.polish_resident(c, Opts())[0].tobytes() for c in contigs]
+    bp = BatchPolisher(pol, len(contigs))
+    cap = max(len(w) for w in want) + 4096
+    buf = torch.full((len(contigs), cap), 7, dtype=torch.uint8, device="cuda")
+    for slot in range(len(contigs)):
+        bp.set_sink(slot, buf[slot].data_ptr(), cap)
+    for keep in (False, True):
+        buf.fill_(7)
+        torch.cuda.synchronize()
+        out = bp.polish(contigs, Opts(), keep_on_device=keep)
+        host = buf.cpu().numpy()
+        for i, w in enumerate(want):
+            assert host[i, :len(w)].tobytes() == w and (host[i, len(w):] == 7).all()  # exactly the polished length
+            if not keep:
+                assert out[i][0].tobytes() == w
+    bp.set_sink(1, 0, 0)
+    buf.fill_(7)
+    torch.cuda.synchronize()
+    bp.polish(contigs, Opts())
+    host = buf.cpu().numpy()
+    assert (host[1] == 7).all() and host[0, :len(want[0])].tobytes() == want[0]
+    bp.close()
+
+
 @pytest.mark.parametrize("n_slots", [5, 2])
 def test_batch_equals_per_contig_and_oracle(n_slots):
     syn, yaks = _assembly()
